@@ -1,0 +1,136 @@
+"""Pin the oracle (oracle/ratelearn_oracle.py) against vectors produced by the
+real reference (tests/golden/make_golden.py).  CPU only."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, relerr
+from oracle import ratelearn_oracle as orc
+
+EVAL_CASES = ["toy3_init", "toy3_mask", "s20_mask", "s400_mask"]
+
+
+@pytest.mark.parametrize("case", EVAL_CASES)
+def test_single_evaluation_f64(case):
+    g = load_golden(f"eval_{case}.npz")
+    if case == "s400_mask":
+        torch.set_num_threads(8)
+    r = orc.evaluate(g["upper_diag"], g["log_pi"], g["mask"], g["t"], g["C"], torch.float64)
+    assert relerr(r["Q"], g["Q_f64"]) < 1e-14
+    assert abs(r["loss"] - float(g["loss_f64"])) < 1e-13 * abs(float(g["loss_f64"]))
+    assert relerr(r["dQ"], g["dQ_f64"]) < 1e-12
+    assert relerr(r["d_upper"], g["d_upper_f64"]) < 1e-12
+    assert relerr(r["d_log_pi"], g["d_log_pi_f64"]) < 1e-11
+
+
+@pytest.mark.parametrize("case", EVAL_CASES[:3])
+def test_single_evaluation_as_is_f32(case):
+    g = load_golden(f"eval_{case}.npz")
+    r = orc.evaluate(g["upper_diag"], g["log_pi"], g["mask"], g["t"], g["C"], torch.float32)
+    assert relerr(r["Q"], g["Q_f32"]) < 1e-7
+    assert abs(r["loss"] - float(g["loss_f32"])) < 1e-7 * abs(float(g["loss_f32"]))
+    assert relerr(r["dQ"], g["dQ_f32"]) < 1e-5
+    assert relerr(r["d_upper"], g["d_upper_f32"]) < 1e-5
+
+
+def test_init_inversion_matches_reference_params():
+    for case in ["toy3_init", "toy3_mask"]:
+        g = load_golden(f"eval_{case}.npz")
+        u, p = orc.invert_pande_reversible(g["init"], g["mask"])
+        # the reference stores these in float32 parameters
+        assert np.allclose(np.float32(p), g["log_pi"], rtol=0, atol=1e-6)
+        fin = np.isfinite(g["upper_diag"])
+        assert np.array_equal(np.isfinite(u), fin)
+        assert np.allclose(np.float32(u[fin]), g["upper_diag"][fin], rtol=1e-6, atol=1e-6)
+
+
+def test_mask_incompatible_initialisation_raises():
+    g = load_golden("eval_toy3_init.npz")
+    m = load_golden("eval_toy3_mask.npz")["mask"]
+    with pytest.raises(ValueError):
+        orc.invert_pande_reversible(g["init"], m)
+
+
+@pytest.mark.parametrize("case", ["toy3_init", "toy3_mask", "s20_mask"])
+def test_trajectory_f64(case):
+    e = load_golden(f"eval_{case}.npz")
+    g = load_golden(f"traj_{case}.npz")
+    kw = dict(initialization=e["init"]) if "init" in e else dict(
+        upper_diag=g["upper_diag0_f64"], log_pi=g["log_pi0_f64"])
+    r = orc.train(e["t"], e["C"], e["mask"], num_epochs=int(g["num_epochs"]),
+                  dtype=torch.float64, **kw)
+    assert np.allclose(r["loss"], g["loss_f64"], rtol=1e-11, atol=0)
+    for k in ["Q_best", "Q_last", "Q_1", "Q_2"]:
+        assert relerr(r[k], g[k + "_f64"]) < 1e-9, k
+
+
+@pytest.mark.parametrize("case", ["toy3_init", "toy3_mask"])
+def test_trajectory_as_is_f32(case):
+    """float32 mode reproduces `quantized_transitions_mle` as a user runs it
+    (output files hold ~8 significant digits)."""
+    e = load_golden(f"eval_{case}.npz")
+    g = load_golden(f"traj_{case}.npz")
+    r = orc.train(e["t"], e["C"], e["mask"], initialization=e["init"],
+                  num_epochs=int(g["num_epochs"]), dtype=torch.float32)
+    assert np.allclose(r["loss"], g["loss_f32"], rtol=2e-6, atol=0)
+    assert relerr(r["Q_best"], g["Q_best_f32"]) < 1e-4
+    assert relerr(r["result"], g["result_f32"]) < 1e-4
+
+
+def test_trajectory_random_init_as_is_f32():
+    """No initialisation: parameters come from torch.manual_seed(0) randn."""
+    e = load_golden("eval_s20_mask.npz")
+    g = load_golden("traj_s20_mask.npz")
+    r = orc.train(e["t"], e["C"], e["mask"], num_epochs=int(g["num_epochs"]),
+                  dtype=torch.float32)
+    assert np.allclose(r["loss"], g["loss_f32"], rtol=5e-6, atol=0)
+    assert relerr(r["Q_best"], g["Q_best_f32"]) < 1e-3
+
+
+def test_trajectory_lg_bank_f64():
+    g = load_golden("traj_lgbank.npz")
+    r = orc.train(g["t"], g["C"], None, initialization=g["init"],
+                  num_epochs=int(g["num_epochs"]), dtype=torch.float64)
+    assert np.allclose(r["loss"], g["loss_f64"], rtol=1e-10, atol=0)
+    assert relerr(r["Q_best"], g["Q_best_f64"]) < 1e-8
+    # distance of the f64 recipe to the as-is float32 reference (reported, loose)
+    assert relerr(r["Q_best"], g["Q_best_f32"]) < 1e-3
+
+
+@pytest.mark.slow
+def test_trajectory_s400_f64():
+    torch.set_num_threads(8)
+    e = load_golden("eval_s400_mask.npz")
+    g = load_golden("traj_s400_mask.npz")
+    r = orc.train(e["t"], e["C"], e["mask"], upper_diag=g["upper_diag0_f64"],
+                  log_pi=g["log_pi0_f64"], num_epochs=3, dtype=torch.float64)
+    assert np.allclose(r["loss"], g["loss_f64"], rtol=1e-11, atol=0)
+    assert relerr(r["Q_best"], g["Q_best_f64"]) < 1e-9
+
+
+def test_siterm_with_initialisation():
+    for name in ["siterm_dna.npz", "siterm_aa.npz"]:
+        g = load_golden(name)
+        E = g["lpe_init"].shape[0]
+        r = orc.siterm_train(g["counts"], g["times"], E, initialization=g["init"])
+        assert np.allclose(r["loss_per_epoch_per_site"], g["lpeps_init"], rtol=1e-10, atol=0)
+        assert relerr(r["res"], g["res_init"]) < 1e-9
+
+
+def test_siterm_random_init():
+    g = load_golden("siterm_dna.npz")
+    r = orc.siterm_train(g["counts"], g["times"], g["lpe_rand"].shape[0])
+    assert np.allclose(r["loss_per_epoch_per_site"], g["lpeps_rand"], rtol=1e-5, atol=0)
+    assert relerr(r["res"], g["res_rand"]) < 1e-4
+
+
+def test_jtt_ipw_reference_goldens():
+    """The reference's own golden files (tests/estimation_tests/jtt_ipw_test.py:12-74)."""
+    g = load_golden("jtt_ipw_toy.npz")
+    ones = np.ones((3, 3))
+    for key, mask, ipw in [("Q1_JTT_IPW_on_toy_matrix", ones, True),
+                           ("Q1_JTT_IPW_on_toy_matrix_mask", g["mask"], True),
+                           ("Q1_JTT_on_toy_matrix", ones, False),
+                           ("Q1_JTT_on_toy_matrix_mask", g["mask"], False)]:
+        got = orc.jtt_ipw(g["t"], g["C"], mask.astype(float), use_ipw=ipw)
+        np.testing.assert_almost_equal(got, g[key], decimal=7)
