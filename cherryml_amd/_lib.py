@@ -1,0 +1,72 @@
+"""ctypes binding of include/cherrybank.h.  There is no fallback: if the HIP
+library is missing or a call fails, the caller gets an exception."""
+import ctypes as C
+import os
+
+from ._build import LIB
+
+CB_PTR_DEVICE = 1
+CB_NORMALIZE = 2
+CB_NO_SYNC = 4
+
+CB_EINVAL, CB_EHIP, CB_ENOMEM, CB_ENUMERIC, CB_EUNSUPPORTED = -1, -2, -3, -4, -5
+
+_dp = C.POINTER(C.c_double)
+_vp = C.c_void_p
+
+# name -> (restype, argtypes); must list every symbol of include/cherrybank.h
+SIGNATURES = {
+    "cb_version": (C.c_int, []),
+    "cb_last_error": (C.c_char_p, []),
+    "cb_device_count": (C.c_int, []),
+    "cb_create": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, C.c_int, C.POINTER(_vp)]),
+    "cb_destroy": (None, [_vp]),
+    "cb_set_stream": (C.c_int, [_vp, _vp]),
+    "cb_total_counts": (C.c_int, [_vp, _vp]),
+    "cb_loss_grad": (C.c_int, [_vp, _vp, _vp, C.c_int, _vp, _vp]),
+    "cb_loss_grad_general": (C.c_int, [_vp, _vp, C.c_int, _vp, _vp]),
+    "cb_expm_bank": (C.c_int, [_vp, _vp, _vp, C.c_int, _vp]),
+    "cb_eigh": (C.c_int, [_vp, _vp, C.c_int, _vp, _vp]),
+    "cb_train_pande_reversible": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, C.c_double, C.c_int,
+                                            C.c_int, _vp, _vp, _vp, _vp, C.c_int]),
+    "cb_train_siterm": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_double, C.c_int, _vp, _vp]),
+}
+
+_lib = None
+
+
+class CherryBankError(RuntimeError):
+    pass
+
+
+def load():
+    """Load libcherrybank.so (built by cherryml_amd._build.build / __graft_entry__.build)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB):
+        raise CherryBankError(
+            f"{LIB} is missing: the HIP extension has not been built. Run "
+            "`python -c 'import __graft_entry__ as g; g.build()'` (needs hipcc). "
+            "cherryml_amd has no CPU fallback.")
+    lib = C.CDLL(LIB)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str):
+    if rc == 0:
+        return
+    msg = load().cb_last_error().decode("utf-8", "replace")
+    text = f"{what} failed ({rc}): {msg}"
+    if rc in (CB_EINVAL, CB_ENUMERIC):
+        raise ValueError(text)
+    if rc == CB_EUNSUPPORTED:
+        raise NotImplementedError(text)
+    if rc == CB_ENOMEM:
+        raise MemoryError(text)
+    raise CherryBankError(text)

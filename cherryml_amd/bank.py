@@ -1,0 +1,143 @@
+"""CherryBank: a count-matrix bank resident on one MI355X, evaluated by
+libcherrybank (HIP).  Thin, typed wrapper over the C ABI."""
+from typing import Optional, Tuple
+
+import numpy as np
+
+from . import _lib
+from ._lib import CB_NO_SYNC, CB_NORMALIZE, CB_PTR_DEVICE
+
+
+def _as_f64(a, shape=None) -> np.ndarray:
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    if shape is not None and tuple(a.shape) != tuple(shape):
+        raise ValueError(f"expected shape {tuple(shape)}, got {a.shape}")
+    return a
+
+
+class CherryBank:
+    """Count matrices C[L,B,S,S] (or [B,S,S]) at branch lengths t[L,B] (or [B]),
+    uploaded once to `device` and kept there (the reference re-uploads them
+    every epoch: cherryml/estimation/_ratelearn/trainer.py:164-167)."""
+
+    def __init__(self, t, C, device: int = 0):
+        self._h = None
+        lib = _lib.load()
+        if lib.cb_device_count() <= 0:
+            raise _lib.CherryBankError("no HIP device visible; cherryml_amd has no CPU fallback")
+        is_torch = hasattr(C, "data_ptr")
+        if is_torch:
+            import torch
+            if not C.is_cuda:
+                C = C.detach().cpu().numpy()
+                t = t.detach().cpu().numpy() if hasattr(t, "detach") else t
+                is_torch = False
+        shape = tuple(C.shape)
+        if len(shape) == 3:
+            shape = (1,) + shape
+        if len(shape) != 4 or shape[2] != shape[3]:
+            raise ValueError(f"C must be [L,B,S,S] or [B,S,S], got {tuple(C.shape)}")
+        self.L, self.B, self.S = shape[0], shape[1], shape[2]
+        self.device = int(device)
+        import ctypes as Ct
+        h = Ct.c_void_p()
+        if is_torch:
+            import torch
+            Cd = C.to(dtype=torch.float64).contiguous()
+            td = torch.as_tensor(t, dtype=torch.float64, device=Cd.device).reshape(-1)
+            td = td.expand(self.L, self.B).reshape(-1).contiguous() if td.numel() == self.B and self.L > 1 \
+                else td.contiguous()
+            if td.numel() != self.L * self.B:
+                raise ValueError("t must have L*B (or B) entries")
+            torch.cuda.synchronize(Cd.device)
+            rc = lib.cb_create(Cd.device.index or 0, self.S, self.L, self.B, td.data_ptr(),
+                               Cd.data_ptr(), CB_PTR_DEVICE, Ct.byref(h))
+            self.device = Cd.device.index or 0
+        else:
+            Cn = _as_f64(C).reshape(self.L, self.B, self.S, self.S)
+            tn = _as_f64(t).reshape(-1)
+            if tn.size == self.B and self.L > 1:
+                tn = np.tile(tn, self.L)
+            if tn.size != self.L * self.B:
+                raise ValueError("t must have L*B (or B) entries")
+            if not (np.all(np.isfinite(Cn)) and np.all(np.isfinite(tn))):
+                raise ValueError("non-finite counts or branch lengths")
+            rc = lib.cb_create(self.device, self.S, self.L, self.B, tn.ctypes.data, Cn.ctypes.data,
+                               0, Ct.byref(h))
+        _lib.check(rc, "cb_create")
+        self._h = h
+        n = np.zeros(self.L)
+        _lib.check(lib.cb_total_counts(self._h, n.ctypes.data), "cb_total_counts")
+        self.total_counts = n
+
+    # -- lifetime ---------------------------------------------------------
+    def close(self):
+        if getattr(self, "_h", None) is not None:
+            _lib.load().cb_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def set_stream(self, hip_stream: Optional[int]):
+        _lib.check(_lib.load().cb_set_stream(self._h, hip_stream or None), "cb_set_stream")
+
+    # -- host-pointer API (numpy) -----------------------------------------
+    def _shape_Q(self, Q, pi):
+        Q = _as_f64(Q).reshape(self.L, self.S, self.S)
+        pi = _as_f64(pi).reshape(self.L, self.S)
+        return Q, pi
+
+    def loss_grad(self, Q, pi, normalize: bool = True, want_grad: bool = True
+                  ) -> Tuple[np.ndarray, Optional[np.ndarray]]:
+        """loss[L], dL/dQ[L,S,S] for reversible Q (w.r.t. pi).  numpy in/out."""
+        Q, pi = self._shape_Q(Q, pi)
+        loss = np.zeros(self.L)
+        dQ = np.zeros_like(Q) if want_grad else None
+        rc = _lib.load().cb_loss_grad(self._h, Q.ctypes.data, pi.ctypes.data,
+                                      CB_NORMALIZE if normalize else 0, loss.ctypes.data,
+                                      dQ.ctypes.data if want_grad else None)
+        _lib.check(rc, "cb_loss_grad")
+        return loss, dQ
+
+    def expm_bank(self, Q, pi) -> np.ndarray:
+        Q, pi = self._shape_Q(Q, pi)
+        P = np.zeros((self.L, self.B, self.S, self.S))
+        _lib.check(_lib.load().cb_expm_bank(self._h, Q.ctypes.data, pi.ctypes.data, 0, P.ctypes.data),
+                   "cb_expm_bank")
+        return P
+
+    def eigh(self, A) -> Tuple[np.ndarray, np.ndarray]:
+        A = _as_f64(A).reshape(self.L, self.S, self.S)
+        lam = np.zeros((self.L, self.S))
+        U = np.zeros_like(A)
+        _lib.check(_lib.load().cb_eigh(self._h, A.ctypes.data, 0, lam.ctypes.data, U.ctypes.data),
+                   "cb_eigh")
+        return lam, U
+
+    # -- device-pointer API (torch ROCm tensors, zero copy) -----------------
+    def loss_grad_torch(self, Q, pi, normalize: bool = True, want_grad: bool = True):
+        """Q[L,S,S] / pi[L,S] float64 tensors on this bank's device; returns
+        (loss[L], dQ[L,S,S]) tensors.  Runs on torch's current stream."""
+        import torch
+        if not (Q.is_cuda and pi.is_cuda):
+            raise ValueError("loss_grad_torch needs tensors on the GPU")
+        Qc = Q.detach().to(torch.float64).reshape(self.L, self.S, self.S).contiguous()
+        pic = pi.detach().to(torch.float64).reshape(self.L, self.S).contiguous()
+        loss = torch.empty(self.L, dtype=torch.float64, device=Q.device)
+        dQ = torch.empty_like(Qc) if want_grad else None
+        self.set_stream(torch.cuda.current_stream(Q.device).cuda_stream)
+        flags = CB_PTR_DEVICE | CB_NO_SYNC | (CB_NORMALIZE if normalize else 0)
+        rc = _lib.load().cb_loss_grad(self._h, Qc.data_ptr(), pic.data_ptr(), flags, loss.data_ptr(),
+                                      dQ.data_ptr() if want_grad else None)
+        _lib.check(rc, "cb_loss_grad")
+        return loss, dQ

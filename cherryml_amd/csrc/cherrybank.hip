@@ -1,0 +1,602 @@
+// libcherrybank: C ABI (include/cherrybank.h) over the gfx950 kernels.
+#include "../../include/cherrybank.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "common.hip.h"
+#include "jacobi_block.hip.h"
+#include "jacobi_wave.hip.h"
+#include "large_bank.hip.h"
+#include "small_bank.hip.h"
+
+#define CB_ABI_VERSION 1
+
+// ------------------------------------------------------------------ errors
+static thread_local std::string g_err;
+
+static int fail(int code, const char *fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  g_err = buf;
+  return code;
+}
+
+#define HIP_TRY(expr)                                                                   \
+  do {                                                                                  \
+    hipError_t e_ = (expr);                                                             \
+    if (e_ != hipSuccess)                                                               \
+      return fail(e_ == hipErrorOutOfMemory ? CB_ENOMEM : CB_EHIP, "%s failed: %s (%s:%d)", \
+                  #expr, hipGetErrorString(e_), __FILE__, __LINE__);                    \
+  } while (0)
+
+// ------------------------------------------------------------------ handle
+struct cb_bank {
+  int dev = 0, S = 0, L = 0, B = 0;
+  int LD = 0;           // large path: padded leading dimension
+  bool large = false;
+  hipStream_t own_stream = nullptr, stream = nullptr;
+  std::vector<void *> allocs;
+  std::vector<double> n_host;  // [L]
+  // resident bank
+  double *t = nullptr;       // [L,B]
+  double *Ct = nullptr;      // small: [L,B,S,S]; large: [B,LD,LD]
+  double *n_dev = nullptr;   // [L]
+  double *inv_n = nullptr;   // [L]  1/n
+  double *ones = nullptr;    // [L]  1.0
+  double *dirsum = nullptr;  // [L,S] colsum - rowsum of sum_b C
+  // staging for host-pointer calls
+  double *Q = nullptr, *pi = nullptr, *loss = nullptr, *dQ = nullptr;
+  int *status = nullptr;
+  // large-path workspaces
+  double *A = nullptr, *dsq = nullptr, *Gc = nullptr, *Vc = nullptr, *U = nullptr, *lam = nullptr,
+         *sigma = nullptr, *F = nullptr, *E = nullptr, *H = nullptr, *Gt = nullptr, *T = nullptr,
+         *Mt_part = nullptr, *Mt = nullptr, *X = nullptr, *loss_part = nullptr;
+  unsigned long long *off_bits = nullptr;
+  int k3_chunk = 0, k3_nchunks = 0;
+  int last_sweeps = 0;
+};
+
+template <typename T>
+static int dev_alloc(cb_bank *h, T **p, size_t count) {
+  void *q = nullptr;
+  hipError_t e = hipMalloc(&q, count * sizeof(T) + 64);
+  if (e != hipSuccess)
+    return fail(CB_ENOMEM, "hipMalloc of %zu bytes failed: %s", count * sizeof(T),
+                hipGetErrorString(e));
+  h->allocs.push_back(q);
+  *p = static_cast<T *>(q);
+  return CB_OK;
+}
+#define ALLOC(ptr, count)                         \
+  do {                                            \
+    int rc_ = dev_alloc(h, &(ptr), (count));      \
+    if (rc_ != CB_OK) return rc_;                 \
+  } while (0)
+
+extern "C" int cb_version(void) { return CB_ABI_VERSION; }
+extern "C" const char *cb_last_error(void) { return g_err.c_str(); }
+extern "C" int cb_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) {
+    (void)hipGetLastError();
+    return 0;
+  }
+  return n;
+}
+
+// ---------------------------------------------------------------- create
+// per-site totals and (colsum - rowsum) of sum_b C; one block per site
+__global__ void prep_counts(int S, int B, const double *C, double *n, double *inv_n, double *ones,
+                            double *dirsum) {
+  extern __shared__ double sm[];  // tot[S*S]
+  const int l = blockIdx.x;
+  const double *Cl = C + (size_t)l * B * S * S;
+  for (int e = threadIdx.x; e < S * S; e += blockDim.x) {
+    double acc = 0.0;
+    for (int b = 0; b < B; ++b) acc += Cl[(size_t)b * S * S + e];
+    sm[e] = acc;
+  }
+  __syncthreads();
+  for (int k = threadIdx.x; k < S; k += blockDim.x) {
+    double cs = 0.0, rs = 0.0;
+    for (int i = 0; i < S; ++i) {
+      cs += sm[i * S + k];
+      rs += sm[k * S + i];
+    }
+    dirsum[(size_t)l * S + k] = cs - rs;
+  }
+  if (threadIdx.x == 0) {
+    double tot = 0.0;
+    for (int e = 0; e < S * S; ++e) tot += sm[e];
+    n[l] = tot;
+    inv_n[l] = 1.0 / tot;
+    ones[l] = 1.0;
+  }
+}
+
+// large S: the S*S totals do not fit LDS comfortably; two simple kernels
+__global__ void prep_counts_large_tot(int S, int B, const double *C, double *tot) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= S * S) return;
+  double acc = 0.0;
+  for (int b = 0; b < B; ++b) acc += C[(size_t)b * S * S + e];
+  tot[e] = acc;
+}
+__global__ void prep_counts_large_fin(int S, const double *tot, double *n, double *inv_n,
+                                      double *ones, double *dirsum) {
+  __shared__ double s[256];
+  double acc = 0.0;
+  for (int e = threadIdx.x; e < S * S; e += 256) acc += tot[e];
+  s[threadIdx.x] = acc;
+  __syncthreads();
+  for (int st = 128; st >= 1; st >>= 1) {
+    if ((int)threadIdx.x < st) s[threadIdx.x] += s[threadIdx.x + st];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    n[0] = s[0];
+    inv_n[0] = 1.0 / s[0];
+    ones[0] = 1.0;
+  }
+  for (int k = threadIdx.x; k < S; k += 256) {
+    double cs = 0.0, rs = 0.0;
+    for (int i = 0; i < S; ++i) {
+      cs += tot[(size_t)i * S + k];
+      rs += tot[(size_t)k * S + i];
+    }
+    dirsum[k] = cs - rs;
+  }
+}
+
+// small path: Ct[l,b][j][i] = C[l,b][i][j]
+__global__ void transpose_small(int S, size_t nmat, const double *C, double *Ct) {
+  const size_t m = blockIdx.x;
+  if (m >= nmat) return;
+  for (int e = threadIdx.x; e < S * S; e += blockDim.x) {
+    const int j = e / S, i = e - j * S;
+    Ct[m * S * S + e] = C[m * S * S + (size_t)i * S + j];
+  }
+}
+
+extern "C" int cb_create(int device, int S, int L, int B, const double *t, const double *C,
+                         int flags, cb_handle *out) {
+  if (!out) return fail(CB_EINVAL, "cb_create: out is NULL");
+  *out = nullptr;
+  if (S < 2 || L < 1 || B < 1) return fail(CB_EINVAL, "cb_create: need S>=2, L>=1, B>=1 (got %d,%d,%d)", S, L, B);
+  if (!t || !C) return fail(CB_EINVAL, "cb_create: t and C must not be NULL");
+  if (S > 32 && L != 1)
+    return fail(CB_EUNSUPPORTED, "cb_create: S > 32 is supported for L == 1 only (got L=%d)", L);
+  if (S > 1024) return fail(CB_EUNSUPPORTED, "cb_create: S > 1024 not supported");
+  int ndev = cb_device_count();
+  if (ndev <= 0) return fail(CB_EHIP, "cb_create: no HIP device visible");
+  if (device < 0 || device >= ndev) return fail(CB_EINVAL, "cb_create: device %d out of range (%d devices)", device, ndev);
+  HIP_TRY(hipSetDevice(device));
+  cb_bank *h = new cb_bank();
+  h->dev = device;
+  h->S = S;
+  h->L = L;
+  h->B = B;
+  h->large = S > 32;
+  h->LD = (S + 15) / 16 * 16;
+  auto cleanup = [&](int rc) {
+    cb_destroy(h);
+    return rc;
+  };
+  if (hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking) != hipSuccess)
+    return cleanup(fail(CB_EHIP, "hipStreamCreate failed"));
+  h->stream = h->own_stream;
+  const size_t nmat = (size_t)L * B, SS = (size_t)S * S;
+  int rc;
+#define TRY_ALLOC(ptr, count) \
+  if ((rc = dev_alloc(h, &(ptr), (count))) != CB_OK) return cleanup(rc)
+#define TRY_HIP(expr)                                                                          \
+  do {                                                                                         \
+    hipError_t e_ = (expr);                                                                    \
+    if (e_ != hipSuccess)                                                                      \
+      return cleanup(fail(CB_EHIP, "%s failed: %s", #expr, hipGetErrorString(e_)));            \
+  } while (0)
+  TRY_ALLOC(h->t, nmat);
+  TRY_ALLOC(h->n_dev, L);
+  TRY_ALLOC(h->inv_n, L);
+  TRY_ALLOC(h->ones, L);
+  TRY_ALLOC(h->dirsum, (size_t)L * S);
+  TRY_ALLOC(h->Q, (size_t)L * SS);
+  TRY_ALLOC(h->pi, (size_t)L * S);
+  TRY_ALLOC(h->loss, L);
+  TRY_ALLOC(h->dQ, (size_t)L * SS);
+  TRY_ALLOC(h->status, L);
+  // raw counts: device copy (temporary when they come from the host)
+  const double *Cdev = C;
+  double *Ctmp = nullptr;
+  const hipMemcpyKind kind = (flags & CB_PTR_DEVICE) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+  TRY_HIP(hipMemcpyAsync(h->t, t, nmat * sizeof(double), kind, h->stream));
+  if (!(flags & CB_PTR_DEVICE)) {
+    hipError_t e = hipMalloc((void **)&Ctmp, nmat * SS * sizeof(double));
+    if (e != hipSuccess) return cleanup(fail(CB_ENOMEM, "hipMalloc(C staging) failed"));
+    e = hipMemcpyAsync(Ctmp, C, nmat * SS * sizeof(double), hipMemcpyHostToDevice, h->stream);
+    if (e != hipSuccess) {
+      (void)hipFree(Ctmp);
+      return cleanup(fail(CB_EHIP, "copy of C failed"));
+    }
+    Cdev = Ctmp;
+  }
+  auto free_tmp = [&]() {
+    if (Ctmp) {
+      (void)hipStreamSynchronize(h->stream);
+      (void)hipFree(Ctmp);
+      Ctmp = nullptr;
+    }
+  };
+  if (!h->large) {
+    if ((rc = dev_alloc(h, &h->Ct, nmat * SS)) != CB_OK) {
+      free_tmp();
+      return cleanup(rc);
+    }
+    hipLaunchKernelGGL(prep_counts, dim3(L), dim3(256), SS * sizeof(double), h->stream, S, B, Cdev,
+                       h->n_dev, h->inv_n, h->ones, h->dirsum);
+    hipLaunchKernelGGL(transpose_small, dim3((unsigned)nmat), dim3(256), 0, h->stream, S, nmat, Cdev,
+                       h->Ct);
+  } else {
+    const size_t LL = (size_t)h->LD * h->LD;
+    const int tiles = ((h->LD + LG_TM - 1) / LG_TM) * ((h->LD + LG_TN - 1) / LG_TN);
+    h->k3_chunk = 4;
+    h->k3_nchunks = (B + h->k3_chunk - 1) / h->k3_chunk;
+    double *tot = nullptr;
+    bool ok = dev_alloc(h, &h->Ct, (size_t)B * LL) == CB_OK && dev_alloc(h, &tot, SS) == CB_OK &&
+              dev_alloc(h, &h->A, LL) == CB_OK && dev_alloc(h, &h->dsq, h->LD) == CB_OK &&
+              dev_alloc(h, &h->Gc, LL) == CB_OK && dev_alloc(h, &h->Vc, LL) == CB_OK &&
+              dev_alloc(h, &h->U, LL) == CB_OK && dev_alloc(h, &h->lam, h->LD) == CB_OK &&
+              dev_alloc(h, &h->sigma, 8) == CB_OK && dev_alloc(h, &h->off_bits, 8) == CB_OK &&
+              dev_alloc(h, &h->F, (size_t)B * h->LD) == CB_OK &&
+              dev_alloc(h, &h->E, (size_t)B * h->LD) == CB_OK &&
+              dev_alloc(h, &h->H, (size_t)B * h->LD) == CB_OK &&
+              dev_alloc(h, &h->Gt, (size_t)B * LL) == CB_OK &&
+              dev_alloc(h, &h->T, (size_t)B * LL) == CB_OK &&
+              dev_alloc(h, &h->Mt_part, (size_t)h->k3_nchunks * LL) == CB_OK &&
+              dev_alloc(h, &h->Mt, LL) == CB_OK && dev_alloc(h, &h->X, LL) == CB_OK &&
+              dev_alloc(h, &h->loss_part, (size_t)B * tiles) == CB_OK;
+    if (!ok) {
+      free_tmp();
+      return cleanup(CB_ENOMEM);
+    }
+    hipLaunchKernelGGL(prep_counts_large_tot, dim3((unsigned)((SS + 255) / 256)), dim3(256), 0,
+                       h->stream, S, B, Cdev, tot);
+    hipLaunchKernelGGL(prep_counts_large_fin, dim3(1), dim3(256), 0, h->stream, S, tot, h->n_dev,
+                       h->inv_n, h->ones, h->dirsum);
+    const int nt32 = (h->LD + 31) / 32;
+    hipLaunchKernelGGL(lg_transpose_pad, dim3(nt32, nt32, B), dim3(32, 8), 0, h->stream, S, h->LD,
+                       Cdev, h->Ct);
+  }
+  h->n_host.resize(L);
+  hipError_t e = hipMemcpyAsync(h->n_host.data(), h->n_dev, L * sizeof(double), hipMemcpyDeviceToHost,
+                                h->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+  if (Ctmp) (void)hipFree(Ctmp);
+  if (e != hipSuccess) return cleanup(fail(CB_EHIP, "cb_create: upload failed: %s", hipGetErrorString(e)));
+  e = hipGetLastError();
+  if (e != hipSuccess) return cleanup(fail(CB_EHIP, "cb_create: kernel failed: %s", hipGetErrorString(e)));
+  for (int l = 0; l < L; ++l)
+    if (!(h->n_host[l] > 0.0) || !std::isfinite(h->n_host[l]))
+      return cleanup(fail(CB_ENUMERIC, "cb_create: site %d has total count %g", l, h->n_host[l]));
+  *out = h;
+  return CB_OK;
+#undef TRY_ALLOC
+#undef TRY_HIP
+}
+
+extern "C" void cb_destroy(cb_handle h) {
+  if (!h) return;
+  (void)hipSetDevice(h->dev);
+  if (h->own_stream) (void)hipStreamSynchronize(h->own_stream);
+  for (void *p : h->allocs) (void)hipFree(p);
+  if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
+  delete h;
+}
+
+extern "C" int cb_set_stream(cb_handle h, void *hip_stream) {
+  if (!h) return fail(CB_EINVAL, "cb_set_stream: NULL handle");
+  h->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : h->own_stream;
+  return CB_OK;
+}
+
+extern "C" int cb_total_counts(cb_handle h, double *n) {
+  if (!h || !n) return fail(CB_EINVAL, "cb_total_counts: NULL argument");
+  memcpy(n, h->n_host.data(), h->L * sizeof(double));
+  return CB_OK;
+}
+
+// ------------------------------------------------------------- small dispatch
+template <int MODE, int NW>
+static int launch_small_nw(cb_bank *h, const SmallArgs &a) {
+  const size_t lds = SmallLds<NW>::TOTAL * sizeof(double);
+  const int S = h->S;
+#define LAUNCH(NT, KS)                                                                          \
+  do {                                                                                          \
+    auto kern = small_bank_kernel<NT, KS, NW, MODE>;                                            \
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),                           \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));         \
+    hipLaunchKernelGGL(kern, dim3(h->L), dim3(NW * 64), lds, h->stream, a);                     \
+  } while (0)
+  if (S <= 4) LAUNCH(1, 1);
+  else if (S <= 8) LAUNCH(1, 2);
+  else if (S <= 16) LAUNCH(1, 4);
+  else if (S <= 20) LAUNCH(2, 5);
+  else if (S <= 24) LAUNCH(2, 6);
+  else LAUNCH(2, 8);
+#undef LAUNCH
+  HIP_TRY(hipGetLastError());
+  return CB_OK;
+}
+
+template <int MODE>
+static int launch_small(cb_bank *h, const SmallArgs &a) {
+  // few sites: more waves per site; many sites: 4 waves (2 workgroups per CU)
+  if (h->L < 512) return launch_small_nw<MODE, 8>(h, a);
+  return launch_small_nw<MODE, 4>(h, a);
+}
+
+// --------------------------------------------------------------- large path
+static int large_eigh(cb_bank *h) {
+  const int LD = h->LD;
+  const size_t LL = (size_t)LD * LD;
+  hipLaunchKernelGGL(lgj_sigma, dim3(1), dim3(256), 0, h->stream, LD, h->A, h->sigma);
+  hipLaunchKernelGGL(lgj_init, dim3((unsigned)((LL + 255) / 256)), dim3(256), 0, h->stream, LD, h->A,
+                     h->sigma, h->Gc, h->Vc);
+  const int nb = LD / JB_W;
+  const int RS = LD + ((2 - LD % 32 + 32) % 32);
+  const size_t lds = (size_t)(16 * RS + 3 * 16 * 17 + 16 + 1024) * sizeof(double);
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(lgj_round),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  const int max_sweeps = 30;
+  int sweep = 0;
+  for (; sweep < max_sweeps; ++sweep) {
+    HIP_TRY(hipMemsetAsync(h->off_bits, 0, sizeof(unsigned long long), h->stream));
+    for (int r = 0; r < nb - 1; ++r)
+      hipLaunchKernelGGL(lgj_round, dim3(nb / 2), dim3(JB_THREADS), lds, h->stream, LD, r, h->Gc,
+                         h->Vc, h->off_bits);
+    unsigned long long bits = 0;
+    HIP_TRY(hipMemcpyAsync(&bits, h->off_bits, sizeof bits, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    double off;
+    memcpy(&off, &bits, sizeof off);
+    if (!(off == off)) return fail(CB_ENUMERIC, "eigensolver: non-finite input");
+    if (off <= CB_JAC_STOP) {
+      ++sweep;
+      break;
+    }
+  }
+  h->last_sweeps = sweep;
+  if (sweep >= max_sweeps) return fail(CB_ENUMERIC, "block Jacobi did not converge in %d sweeps", max_sweeps);
+  hipLaunchKernelGGL(lgj_finish, dim3((LD + 3) / 4), dim3(256), 0, h->stream, LD, h->Gc, h->Vc,
+                     h->sigma, h->lam, h->U);
+  HIP_TRY(hipGetLastError());
+  return CB_OK;
+}
+
+static int large_loss_grad(cb_bank *h, const double *Qd, const double *pid, bool normalize,
+                           double *lossd, double *dQd, double *Pd) {
+  const int S = h->S, LD = h->LD, B = h->B;
+  const size_t LL = (size_t)LD * LD;
+  hipLaunchKernelGGL(lg_build_A, dim3((unsigned)((LL + 255) / 256)), dim3(256), 0, h->stream, S, LD,
+                     Qd, pid, h->A, h->dsq);
+  int rc = large_eigh(h);
+  if (rc != CB_OK) return rc;
+  hipLaunchKernelGGL(lg_tables, dim3((unsigned)(((size_t)B * LD + 255) / 256)), dim3(256), 0,
+                     h->stream, LD, B, h->t, h->lam, h->sigma, h->F, h->E, h->H);
+  const int tm = (LD + LG_TM - 1) / LG_TM, tn = (LD + LG_TN - 1) / LG_TN, tiles = tm * tn;
+  const double inv_n = normalize ? 1.0 / h->n_host[0] : 1.0;
+  K1Args k1{S, LD, B, h->Vc, h->A, h->t, h->F, h->sigma, h->Ct, h->Gt, h->loss_part, inv_n, h->dsq, Pd};
+  hipLaunchKernelGGL(k1_pt_loss_gt, dim3(tiles, B), dim3(LG_THREADS), 0, h->stream, k1);
+  if (Pd) {
+    HIP_TRY(hipGetLastError());
+    return CB_OK;
+  }
+  hipLaunchKernelGGL(lg_finish_loss, dim3(1), dim3(256), 0, h->stream, h->loss_part, B * tiles, S,
+                     h->dsq, h->dirsum, inv_n, lossd);
+  if (dQd) {
+    K2Args k2{LD, h->Gt, h->U, h->T};
+    hipLaunchKernelGGL(k2_t_eq_g_u, dim3(tiles, B), dim3(LG_THREADS), 0, h->stream, k2);
+    K3Args k3{LD, B, h->k3_chunk, h->T, h->U, h->t, h->lam, h->E, h->H, h->Mt_part};
+    hipLaunchKernelGGL(k3_mt_accum, dim3(tiles, h->k3_nchunks), dim3(LG_THREADS), 0, h->stream, k3);
+    hipLaunchKernelGGL(k3_reduce, dim3((unsigned)((LL + 255) / 256)), dim3(256), 0, h->stream,
+                       h->Mt_part, h->k3_nchunks, LL, h->Mt);
+    K4Args k4a{S, LD, h->Mt, h->Vc, h->X, nullptr};
+    hipLaunchKernelGGL(k4_gemm, dim3(tiles), dim3(LG_THREADS), 0, h->stream, k4a);
+    K4Args k4b{S, LD, h->Vc, h->X, dQd, h->dsq};
+    hipLaunchKernelGGL(k4_gemm, dim3(tiles), dim3(LG_THREADS), 0, h->stream, k4b);
+  }
+  HIP_TRY(hipGetLastError());
+  return CB_OK;
+}
+
+// ---------------------------------------------------------------- entry points
+static int finish_call(cb_bank *h, int flags) {
+  if ((flags & CB_PTR_DEVICE) && (flags & CB_NO_SYNC)) return CB_OK;
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  return CB_OK;
+}
+
+extern "C" int cb_loss_grad(cb_handle h, const double *Q, const double *pi, int flags, double *loss,
+                            double *dQ) {
+  if (!h || !Q || !pi || !loss) return fail(CB_EINVAL, "cb_loss_grad: NULL argument");
+  HIP_TRY(hipSetDevice(h->dev));
+  const size_t SS = (size_t)h->S * h->S;
+  const bool devp = flags & CB_PTR_DEVICE;
+  const double *Qd = Q, *pid = pi;
+  double *lossd = loss, *dQd = dQ;
+  if (!devp) {
+    HIP_TRY(hipMemcpyAsync(h->Q, Q, h->L * SS * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipMemcpyAsync(h->pi, pi, (size_t)h->L * h->S * sizeof(double), hipMemcpyHostToDevice,
+                           h->stream));
+    Qd = h->Q;
+    pid = h->pi;
+    lossd = h->loss;
+    dQd = dQ ? h->dQ : nullptr;
+  }
+  int rc;
+  if (h->large) {
+    rc = large_loss_grad(h, Qd, pid, flags & CB_NORMALIZE, lossd, dQd, nullptr);
+  } else {
+    SmallArgs a{};
+    a.S = h->S;
+    a.L = h->L;
+    a.B = h->B;
+    a.t = h->t;
+    a.Ct = h->Ct;
+    a.inv_n = (flags & CB_NORMALIZE) ? h->inv_n : h->ones;
+    a.dirsum = h->dirsum;
+    a.Q = Qd;
+    a.pi = pid;
+    a.loss = lossd;
+    a.dQ = dQd;
+    a.status = h->status;
+    rc = launch_small<SMALL_LOSSGRAD>(h, a);
+  }
+  if (rc != CB_OK) return rc;
+  if (!devp) {
+    HIP_TRY(hipMemcpyAsync(loss, h->loss, h->L * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    if (dQ)
+      HIP_TRY(hipMemcpyAsync(dQ, h->dQ, h->L * SS * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  }
+  return finish_call(h, flags);
+}
+
+extern "C" int cb_expm_bank(cb_handle h, const double *Q, const double *pi, int flags, double *P) {
+  if (!h || !Q || !P) return fail(CB_EINVAL, "cb_expm_bank: NULL argument");
+  if (!pi) return fail(CB_EUNSUPPORTED, "cb_expm_bank: general (pi == NULL) path not built yet");
+  HIP_TRY(hipSetDevice(h->dev));
+  const size_t SS = (size_t)h->S * h->S, nP = (size_t)h->L * h->B * SS;
+  const bool devp = flags & CB_PTR_DEVICE;
+  const double *Qd = Q, *pid = pi;
+  double *Pd = P;
+  double *Ptmp = nullptr;
+  if (!devp) {
+    HIP_TRY(hipMemcpyAsync(h->Q, Q, h->L * SS * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipMemcpyAsync(h->pi, pi, (size_t)h->L * h->S * sizeof(double), hipMemcpyHostToDevice,
+                           h->stream));
+    HIP_TRY(hipMalloc((void **)&Ptmp, nP * sizeof(double)));
+    Qd = h->Q;
+    pid = h->pi;
+    Pd = Ptmp;
+  }
+  int rc;
+  if (h->large) {
+    rc = large_loss_grad(h, Qd, pid, false, h->loss, nullptr, Pd);
+  } else {
+    SmallArgs a{};
+    a.S = h->S;
+    a.L = h->L;
+    a.B = h->B;
+    a.t = h->t;
+    a.Ct = h->Ct;
+    a.inv_n = h->ones;
+    a.dirsum = h->dirsum;
+    a.Q = Qd;
+    a.pi = pid;
+    a.loss = h->loss;
+    a.P = Pd;
+    a.status = h->status;
+    rc = launch_small<SMALL_EXPM>(h, a);
+  }
+  if (rc == CB_OK && !devp) {
+    hipError_t e = hipMemcpyAsync(P, Ptmp, nP * sizeof(double), hipMemcpyDeviceToHost, h->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    if (e != hipSuccess) rc = fail(CB_EHIP, "cb_expm_bank: copy back failed: %s", hipGetErrorString(e));
+  }
+  if (Ptmp) {
+    (void)hipStreamSynchronize(h->stream);
+    (void)hipFree(Ptmp);
+  }
+  if (rc != CB_OK) return rc;
+  return finish_call(h, flags);
+}
+
+extern "C" int cb_eigh(cb_handle h, const double *A, int flags, double *lam, double *U) {
+  if (!h || !A || !lam || !U) return fail(CB_EINVAL, "cb_eigh: NULL argument");
+  if (flags & CB_PTR_DEVICE) return fail(CB_EUNSUPPORTED, "cb_eigh: host pointers only (debug entry)");
+  HIP_TRY(hipSetDevice(h->dev));
+  const int S = h->S;
+  const size_t SS = (size_t)S * S;
+  if (!h->large) {
+    double *lamd = nullptr, *Ud = nullptr;
+    HIP_TRY(hipMalloc((void **)&lamd, (size_t)h->L * S * sizeof(double)));
+    HIP_TRY(hipMalloc((void **)&Ud, h->L * SS * sizeof(double)));
+    HIP_TRY(hipMemcpyAsync(h->Q, A, h->L * SS * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    SmallArgs a{};
+    a.S = S;
+    a.L = h->L;
+    a.B = h->B;
+    a.Q = h->Q;
+    a.lam_out = lamd;
+    a.U_out = Ud;
+    a.status = h->status;
+    int rc = launch_small<SMALL_EIGH>(h, a);
+    if (rc == CB_OK) {
+      hipError_t e = hipMemcpyAsync(lam, lamd, (size_t)h->L * S * sizeof(double), hipMemcpyDeviceToHost, h->stream);
+      if (e == hipSuccess) e = hipMemcpyAsync(U, Ud, h->L * SS * sizeof(double), hipMemcpyDeviceToHost, h->stream);
+      if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+      if (e != hipSuccess) rc = fail(CB_EHIP, "cb_eigh: %s", hipGetErrorString(e));
+    }
+    (void)hipStreamSynchronize(h->stream);
+    (void)hipFree(lamd);
+    (void)hipFree(Ud);
+    return rc;
+  }
+  // large: pad A into h->A
+  const int LD = h->LD;
+  std::vector<double> Ap((size_t)LD * LD, 0.0);
+  for (int i = 0; i < S; ++i) memcpy(&Ap[(size_t)i * LD], A + (size_t)i * S, S * sizeof(double));
+  HIP_TRY(hipMemcpyAsync(h->A, Ap.data(), Ap.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  int rc = large_eigh(h);
+  if (rc != CB_OK) return rc;
+  std::vector<double> Up((size_t)LD * LD), lp(LD);
+  HIP_TRY(hipMemcpyAsync(Up.data(), h->U, Up.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipMemcpyAsync(lp.data(), h->lam, LD * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  // padded eigenpairs are unit vectors on pad indices: drop them (columns whose
+  // support is a pad index), keep the S columns living on real indices
+  int kk = 0;
+  for (int k = 0; k < LD && kk < S; ++k) {
+    double nr = 0.0;
+    for (int i = 0; i < S; ++i) nr += Up[(size_t)i * LD + k] * Up[(size_t)i * LD + k];
+    if (nr > 0.5) {
+      lam[kk] = lp[k];
+      for (int i = 0; i < S; ++i) U[(size_t)i * S + kk] = Up[(size_t)i * LD + k];
+      ++kk;
+    }
+  }
+  if (kk != S) return fail(CB_ENUMERIC, "cb_eigh: found %d real eigenvectors, expected %d", kk, S);
+  return CB_OK;
+}
+
+extern "C" int cb_loss_grad_general(cb_handle h, const double *Q, int flags, double *loss,
+                                    double *dQ) {
+  (void)h; (void)Q; (void)flags; (void)loss; (void)dQ;
+  return fail(CB_EUNSUPPORTED, "cb_loss_grad_general: not built yet (non-reversible path)");
+}
+
+extern "C" int cb_train_pande_reversible(cb_handle h, double *upper_diag, double *log_pi,
+                                         const double *mask, int num_epochs, double lr, int do_adam,
+                                         int flags, double *loss_curve, double *Q_best,
+                                         double *Q_last, double *Q_pow2, int n_pow2) {
+  (void)h; (void)upper_diag; (void)log_pi; (void)mask; (void)num_epochs; (void)lr; (void)do_adam;
+  (void)flags; (void)loss_curve; (void)Q_best; (void)Q_last; (void)Q_pow2; (void)n_pow2;
+  return fail(CB_EUNSUPPORTED, "cb_train_pande_reversible: not built yet");
+}
+
+extern "C" int cb_train_siterm(cb_handle h, double *theta, double *Theta, int num_epochs, double lr,
+                               int flags, double *res, double *loss_per_epoch_per_site) {
+  (void)h; (void)theta; (void)Theta; (void)num_epochs; (void)lr; (void)flags; (void)res;
+  (void)loss_per_epoch_per_site;
+  return fail(CB_EUNSUPPORTED, "cb_train_siterm: not built yet");
+}

@@ -1,0 +1,68 @@
+// Shared device helpers for libcherrybank (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef double d4 __attribute__((ext_vector_type(4)));
+
+// v_mfma_f64_16x16x4_f64:  D(16x16) = A(16x4) * B(4x16) + C
+//   lane l holds A[i = l & 15][k = l >> 4] and B[k = l >> 4][j = l & 15];
+//   C/D register r of lane l is element [row = (l >> 4) + 4 r][col = l & 15].
+// Consequence used throughout: register r of an accumulator tile is exactly
+// the A-operand (rows on l&15 after a transpose of roles) / B-operand fragment
+// of k-step r of the next product, so chains of products never leave registers.
+__device__ __forceinline__ d4 mfma_f64(double a, double b, d4 c) {
+  return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
+}
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+__device__ __forceinline__ double wave_max(double v) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) v = fmax(v, __shfl_xor(v, off, 64));
+  return v;
+}
+
+// e^x - 1 - x without cancellation (x <= 0 in practice: x = t * lambda).
+__device__ __forceinline__ double phi2(double x) {
+  if (fabs(x) < 0.5) {
+    // x^2/2 (1 + x/3 (1 + x/4 ( ... (1 + x/19))))
+    double p = 1.0;
+#pragma unroll
+    for (int k = 19; k >= 3; --k) p = fma(p, x * (1.0 / k), 1.0);
+    return 0.5 * x * x * p;
+  }
+  return expm1(x) - x;
+}
+
+// sinh(z)/z for |z| < 0.5 (Taylor to z^14).
+__device__ __forceinline__ double sinhc_small(double z) {
+  const double w = z * z;
+  double p = 1.0 / 1307674368000.0;          // 1/15!
+  p = fma(p, w, 1.0 / 6227020800.0);         // 1/13!
+  p = fma(p, w, 1.0 / 39916800.0);           // 1/11!
+  p = fma(p, w, 1.0 / 362880.0);             // 1/9!
+  p = fma(p, w, 1.0 / 5040.0);               // 1/7!
+  p = fma(p, w, 1.0 / 120.0);                // 1/5!
+  p = fma(p, w, 1.0 / 6.0);                  // 1/3!
+  return fma(p, w, 1.0);
+}
+
+// Divided difference of exp(t*lambda):  (e^{t la} - e^{t lc}) / (la - lc),
+// given E = e^{t l}, H = e^{t l / 2}.  Symmetric, = t e^{t l} on the diagonal.
+__device__ __forceinline__ double divdiff(double t, double la, double lc, double Ea,
+                                          double Ec, double Ha, double Hc) {
+  const double dl = la - lc;
+  const double z = 0.5 * t * dl;
+  if (fabs(z) < 0.5) return t * Ha * Hc * sinhc_small(z);
+  return (Ea - Ec) / dl;
+}
+
+// order-preserving map of a non-negative double for atomicMax on u64
+__device__ __forceinline__ unsigned long long dbl_bits(double v) {
+  return (unsigned long long)__double_as_longlong(v);
+}

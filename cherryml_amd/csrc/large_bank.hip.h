@@ -1,0 +1,373 @@
+// Large-state path (S > 32; co-evolution 400x400).  MFMA-bound.
+//
+// All internal matrices are LD x LD with LD = roundup(S, 16), zero padded, so
+// every 16x16 MFMA tile is either fully inside or fully outside the matrix.
+// Every product of the algorithm is brought to the single form
+//
+//     C[m][n] = sum_k Aop[k][m] * Bop[k][n]          ("TN", both operands k-major)
+//
+// by choosing which of U / U^T, G^T, T, M^T is stored, so one
+// kernel template serves them all:
+//   K1  Pt_b   = I + t_b A + (U^T diag(F_b))^T U^T      Aop = Ut (row-scaled), Bop = Ut
+//       epilogue: loss partial, Gt_b^T = -C_b^T / Pt_b / n
+//   K2  T_b    = Gt_b U                                  Aop = Gt_b^T, Bop = U
+//   K3  Mt    += (T_b^T U) o Phi_b  over a chunk of b    Aop = T_b,   Bop = U
+//   K4a X      = M U^T                                   Aop = Mt,    Bop = Ut
+//   K4b dA     = U X  -> dQ = D^1/2 dA D^-1/2            Aop = Ut,    Bop = X
+//
+// Tile: 80 x 80 per workgroup of 5 wavefronts (400 = 5 * 80); wave w owns the
+// 16-row strip w and five 16x16 f64 accumulators.  K is staged through LDS in
+// steps of 16 with register prefetch of the next step.
+#pragma once
+#include "common.hip.h"
+
+#define LG_TM 80
+#define LG_TN 80
+#define LG_KT 16
+#define LG_THREADS 320
+
+struct GemmOperands {
+  const double *A;   // [K][lda] k-major
+  const double *B;   // [K][ldb]
+  int lda, ldb;
+  int M, N, K;       // all multiples of 16
+  const double *kscale;  // optional [K] multiplier applied to rows of Aop
+};
+
+// Loads one K-step (16 rows) of an 80-wide panel into registers:
+// 16 rows x 40 16-byte chunks = 640 chunks, 2 per thread.
+__device__ __forceinline__ void lg_load_panel(const double *__restrict__ P, int ld, int rows_total,
+                                              int cols_total, int k0, int c0, double2 (&reg)[2]) {
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int chunk = threadIdx.x + u * LG_THREADS;  // 0..639
+    const int kr = chunk / 40, cc = (chunk - kr * 40) * 2;
+    const int k = k0 + kr, c = c0 + cc;
+    if (k < rows_total && c < cols_total)
+      reg[u] = *reinterpret_cast<const double2 *>(P + (size_t)k * ld + c);
+    else
+      reg[u] = double2{0.0, 0.0};
+  }
+}
+
+__device__ __forceinline__ void lg_store_panel(double *s, const double2 (&reg)[2],
+                                               const double *__restrict__ kscale, int k0,
+                                               int rows_total) {
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int chunk = threadIdx.x + u * LG_THREADS;
+    const int kr = chunk / 40, cc = (chunk - kr * 40) * 2;
+    double2 v = reg[u];
+    if (kscale) {
+      const double sc = (k0 + kr < rows_total) ? kscale[k0 + kr] : 0.0;
+      v.x *= sc;
+      v.y *= sc;
+    }
+    *reinterpret_cast<double2 *>(s + kr * LG_TM + cc) = v;
+  }
+}
+
+// acc[j] (j = 0..4): tile rows m0 + 16*wave + (l>>4) + 4r, cols n0 + 16*j + (l&15)
+__device__ __forceinline__ void lg_gemm_tile(const GemmOperands &g, int m0, int n0, double *sA,
+                                             double *sB, d4 (&acc)[5]) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int lo = lane & 15, hi = lane >> 4;
+#pragma unroll
+  for (int j = 0; j < 5; ++j) acc[j] = d4{0.0, 0.0, 0.0, 0.0};
+  double2 ra[2], rb[2];
+  lg_load_panel(g.A, g.lda, g.K, g.M, 0, m0, ra);
+  lg_load_panel(g.B, g.ldb, g.K, g.N, 0, n0, rb);
+  const int nk = g.K / LG_KT;
+  for (int kt = 0; kt < nk; ++kt) {
+    __syncthreads();  // previous step's LDS reads are done
+    lg_store_panel(sA, ra, g.kscale, kt * LG_KT, g.K);
+    lg_store_panel(sB, rb, nullptr, kt * LG_KT, g.K);
+    __syncthreads();
+    if (kt + 1 < nk) {
+      lg_load_panel(g.A, g.lda, g.K, g.M, (kt + 1) * LG_KT, m0, ra);
+      lg_load_panel(g.B, g.ldb, g.K, g.N, (kt + 1) * LG_KT, n0, rb);
+    }
+#pragma unroll
+    for (int s = 0; s < LG_KT / 4; ++s) {
+      const double av = sA[(4 * s + hi) * LG_TM + 16 * wave + lo];
+#pragma unroll
+      for (int j = 0; j < 5; ++j) {
+        const double bv = sB[(4 * s + hi) * LG_TN + 16 * j + lo];
+        acc[j] = mfma_f64(av, bv, acc[j]);
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------ K1
+struct K1Args {
+  int S, LD, B;
+  const double *Ut;      // [LD][LD]  Ut[k][i] = U[i][k]
+  const double *A;       // [LD][LD]  symmetric
+  const double *t;       // [B]
+  const double *F;       // [B][LD]   phi2(t_b lam_k) (split) or exp(t_b lam_k)
+  const double *sigma;   // max |A_ii|: bucket uses the split form iff 2 sigma t_b <= 1
+  const double *Ct;      // [B][LD][LD] transposed counts (padded)
+  double *Gt;            // [B][LD][LD] out: Gt^T
+  double *loss_part;     // [B * tiles] out
+  double inv_n;
+  const double *dsq;     // [LD] sqrt(pi) (expm mode)
+  double *P;             // [B][S][S] (expm mode) or null
+};
+
+__global__ __launch_bounds__(LG_THREADS) void k1_pt_loss_gt(K1Args a) {
+  __shared__ double sA[LG_KT * LG_TM];
+  __shared__ double sB[LG_KT * LG_TN];
+  __shared__ double sRed[5];
+  const int tilesN = (a.LD + LG_TN - 1) / LG_TN;
+  const int b = blockIdx.y;
+  const int tm = blockIdx.x / tilesN, tn = blockIdx.x - tm * tilesN;
+  const int m0 = tm * LG_TM, n0 = tn * LG_TN;
+  GemmOperands g{a.Ut, a.Ut, a.LD, a.LD, a.LD, a.LD, a.LD, a.F + (size_t)b * a.LD};
+  d4 acc[5];
+  lg_gemm_tile(g, m0, n0, sA, sB, acc);
+
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int lo = lane & 15, hi = lane >> 4;
+  const double tb = a.t[b];
+  const bool split = tb * 2.0 * (*a.sigma) <= 1.0;  // see small_bank.hip.h
+  const size_t boff = (size_t)b * a.LD * a.LD;
+  double lossacc = 0.0;
+#pragma unroll
+  for (int j = 0; j < 5; ++j)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = m0 + 16 * wave + hi + 4 * r, col = n0 + 16 * j + lo;
+      if (row < a.LD && col < a.LD) {
+        const size_t idx = (size_t)row * a.LD + col;
+        double pt = acc[j][r];
+        if (split) pt += tb * a.A[idx] + (row == col ? 1.0 : 0.0);
+        else if (row >= a.S || col >= a.S) pt = 1.0;  // pad (never used: C = 0 there)
+        if (a.P) {
+          if (row < a.S && col < a.S)
+            a.P[(size_t)b * a.S * a.S + (size_t)row * a.S + col] = pt * a.dsq[col] / a.dsq[row];
+        } else {
+          const double c = a.Ct[boff + idx];
+          double gv = 0.0;
+          if (c != 0.0) {
+            lossacc = fma(-c, log(pt), lossacc);
+            gv = -c * a.inv_n / pt;
+          }
+          a.Gt[boff + idx] = gv;
+        }
+      }
+    }
+  if (a.P) return;
+  lossacc = wave_sum(lossacc);
+  if (lane == 0) sRed[wave] = lossacc;
+  __syncthreads();
+  if (threadIdx.x == 0)
+    a.loss_part[(size_t)b * gridDim.x + blockIdx.x] =
+        sRed[0] + sRed[1] + sRed[2] + sRed[3] + sRed[4];
+}
+
+// ------------------------------------------------------------------ K2
+struct K2Args {
+  int LD;
+  const double *Gt;  // [B][LD][LD]
+  const double *U;   // [LD][LD]
+  double *T;         // [B][LD][LD]
+};
+
+__global__ __launch_bounds__(LG_THREADS) void k2_t_eq_g_u(K2Args a) {
+  __shared__ double sA[LG_KT * LG_TM];
+  __shared__ double sB[LG_KT * LG_TN];
+  const int tilesN = (a.LD + LG_TN - 1) / LG_TN;
+  const int b = blockIdx.y;
+  const int tm = blockIdx.x / tilesN, tn = blockIdx.x - tm * tilesN;
+  const int m0 = tm * LG_TM, n0 = tn * LG_TN;
+  const size_t boff = (size_t)b * a.LD * a.LD;
+  GemmOperands g{a.Gt + boff, a.U, a.LD, a.LD, a.LD, a.LD, a.LD, nullptr};
+  d4 acc[5];
+  lg_gemm_tile(g, m0, n0, sA, sB, acc);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int lo = lane & 15, hi = lane >> 4;
+#pragma unroll
+  for (int j = 0; j < 5; ++j)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = m0 + 16 * wave + hi + 4 * r, col = n0 + 16 * j + lo;
+      if (row < a.LD && col < a.LD) a.T[boff + (size_t)row * a.LD + col] = acc[j][r];
+    }
+}
+
+// ------------------------------------------------------------------ K3
+struct K3Args {
+  int LD, B, chunk;      // buckets per chunk
+  const double *T;       // [B][LD][LD]
+  const double *U;       // [LD][LD]
+  const double *t;       // [B]
+  const double *lam;     // [LD]
+  const double *E;       // [B][LD] exp(t lam)
+  const double *H;       // [B][LD] exp(t lam / 2)
+  double *Mt_part;       // [nchunks][LD][LD]
+};
+
+__global__ __launch_bounds__(LG_THREADS) void k3_mt_accum(K3Args a) {
+  __shared__ double sA[LG_KT * LG_TM];
+  __shared__ double sB[LG_KT * LG_TN];
+  const int tilesN = (a.LD + LG_TN - 1) / LG_TN;
+  const int ch = blockIdx.y;
+  const int tm = blockIdx.x / tilesN, tn = blockIdx.x - tm * tilesN;
+  const int m0 = tm * LG_TM, n0 = tn * LG_TN;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int lo = lane & 15, hi = lane >> 4;
+  // Mt[c][a] = sum_b Phi_b[c][a] * sum_i T_b[i][c] U[i][a] : rows = c, cols = a
+  double lamR[4], lamC[5];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int row = m0 + 16 * wave + hi + 4 * r;
+    lamR[r] = row < a.LD ? a.lam[row] : 0.0;
+  }
+#pragma unroll
+  for (int j = 0; j < 5; ++j) {
+    const int col = n0 + 16 * j + lo;
+    lamC[j] = col < a.LD ? a.lam[col] : 0.0;
+  }
+  d4 macc[5];
+#pragma unroll
+  for (int j = 0; j < 5; ++j) macc[j] = d4{0.0, 0.0, 0.0, 0.0};
+  const int b0 = ch * a.chunk, b1 = min(a.B, b0 + a.chunk);
+  for (int b = b0; b < b1; ++b) {
+    const size_t boff = (size_t)b * a.LD * a.LD;
+    GemmOperands g{a.T + boff, a.U, a.LD, a.LD, a.LD, a.LD, a.LD, nullptr};
+    d4 acc[5];
+    lg_gemm_tile(g, m0, n0, sA, sB, acc);
+    const double tb = a.t[b];
+    const double *Eb = a.E + (size_t)b * a.LD, *Hb = a.H + (size_t)b * a.LD;
+    double ER[4], HR[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = min(m0 + 16 * wave + hi + 4 * r, a.LD - 1);
+      ER[r] = Eb[row];
+      HR[r] = Hb[row];
+    }
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+      const int col = min(n0 + 16 * j + lo, a.LD - 1);
+      const double EC = Eb[col], HC = Hb[col];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const double ph = divdiff(tb, lamR[r], lamC[j], ER[r], EC, HR[r], HC);
+        macc[j][r] = fma(acc[j][r], ph, macc[j][r]);
+      }
+    }
+  }
+  double *out = a.Mt_part + (size_t)ch * a.LD * a.LD;
+#pragma unroll
+  for (int j = 0; j < 5; ++j)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = m0 + 16 * wave + hi + 4 * r, col = n0 + 16 * j + lo;
+      if (row < a.LD && col < a.LD) out[(size_t)row * a.LD + col] = macc[j][r];
+    }
+}
+
+// Mt = sum over chunks (fixed order => bitwise reproducible)
+__global__ void k3_reduce(const double *part, int nchunks, size_t n, double *out) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  double s = 0.0;
+  for (int c = 0; c < nchunks; ++c) s += part[(size_t)c * n + i];
+  out[i] = s;
+}
+
+// ------------------------------------------------------------------ K4 (plain / dQ epilogue)
+struct K4Args {
+  int S, LD;
+  const double *Aop, *Bop;  // [LD][LD] each
+  double *out;              // [LD][LD] or dQ [S][S]
+  const double *dsq;        // non-null => out = dQ[i][j] = d_i * acc / d_j, unpadded S x S
+};
+
+__global__ __launch_bounds__(LG_THREADS) void k4_gemm(K4Args a) {
+  __shared__ double sA[LG_KT * LG_TM];
+  __shared__ double sB[LG_KT * LG_TN];
+  const int tilesN = (a.LD + LG_TN - 1) / LG_TN;
+  const int tm = blockIdx.x / tilesN, tn = blockIdx.x - tm * tilesN;
+  const int m0 = tm * LG_TM, n0 = tn * LG_TN;
+  GemmOperands g{a.Aop, a.Bop, a.LD, a.LD, a.LD, a.LD, a.LD, nullptr};
+  d4 acc[5];
+  lg_gemm_tile(g, m0, n0, sA, sB, acc);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int lo = lane & 15, hi = lane >> 4;
+#pragma unroll
+  for (int j = 0; j < 5; ++j)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = m0 + 16 * wave + hi + 4 * r, col = n0 + 16 * j + lo;
+      if (a.dsq) {
+        if (row < a.S && col < a.S)
+          a.out[(size_t)row * a.S + col] = a.dsq[row] * acc[j][r] / a.dsq[col];
+      } else if (row < a.LD && col < a.LD) {
+        a.out[(size_t)row * a.LD + col] = acc[j][r];
+      }
+    }
+}
+
+// ------------------------------------------------------------------ small helpers
+// A = sym(D^1/2 Q D^-1/2) into padded LD x LD, dsq = sqrt(pi) (1 on the pad)
+__global__ void lg_build_A(int S, int LD, const double *Q, const double *pi, double *A,
+                           double *dsq) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx < LD) dsq[idx] = idx < S ? sqrt(pi[idx]) : 1.0;
+  if (idx >= LD * LD) return;
+  const int i = idx / LD, j = idx - i * LD;
+  double v = 0.0;
+  if (i < S && j < S) {
+    const double di = sqrt(pi[i]), dj = sqrt(pi[j]);
+    v = 0.5 * (di * Q[(size_t)i * S + j] / dj + dj * Q[(size_t)j * S + i] / di);
+  }
+  A[idx] = v;
+}
+
+// spectral tables F = phi2(t lam), E = exp(t lam), H = exp(t lam / 2): [B][LD]
+__global__ void lg_tables(int LD, int B, const double *t, const double *lam,
+                          const double *sigma, double *F, double *E, double *H) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= B * LD) return;
+  const int b = idx / LD, k = idx - b * LD;
+  const double x = t[b] * lam[k];
+  const bool split = t[b] * 2.0 * (*sigma) <= 1.0;
+  F[idx] = split ? phi2(x) : exp(x);
+  E[idx] = exp(x);
+  H[idx] = exp(0.5 * x);
+}
+
+// loss = (sum of partials - direct term) * inv_n, single thread-block, fixed order
+__global__ void lg_finish_loss(const double *part, int nparts, int S, const double *dsq,
+                               const double *dirsum, double inv_n, double *loss) {
+  __shared__ double s[256];
+  double acc = 0.0;
+  for (int i = threadIdx.x; i < nparts; i += 256) acc += part[i];
+  double dir = 0.0;
+  for (int k = threadIdx.x; k < S; k += 256) dir = fma(log(dsq[k]), dirsum[k], dir);
+  s[threadIdx.x] = acc - dir;
+  __syncthreads();
+  for (int st = 128; st >= 1; st >>= 1) {
+    if ((int)threadIdx.x < st) s[threadIdx.x] += s[threadIdx.x + st];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *loss = s[0] * inv_n;
+}
+
+// pad + transpose counts at create time: Ct[b][j][i] = C[b][i][j]
+__global__ void lg_transpose_pad(int S, int LD, const double *C, double *Ct) {
+  __shared__ double tile[32][33];
+  const int b = blockIdx.z;
+  const int i0 = blockIdx.y * 32, j0 = blockIdx.x * 32;
+  for (int r = threadIdx.y; r < 32; r += blockDim.y) {
+    const int i = i0 + r, j = j0 + threadIdx.x;
+    tile[r][threadIdx.x] = (i < S && j < S) ? C[(size_t)b * S * S + (size_t)i * S + j] : 0.0;
+  }
+  __syncthreads();
+  for (int r = threadIdx.y; r < 32; r += blockDim.y) {
+    const int j = j0 + r, i = i0 + threadIdx.x;
+    if (j < LD && i < LD) Ct[(size_t)b * LD * LD + (size_t)j * LD + i] = tile[threadIdx.x][r];
+  }
+}

@@ -1,0 +1,356 @@
+// Small-state path (S <= 32: LG 20x20, SiteRM 20x20 / 21x21 / 4x4, toys).
+//
+// One workgroup per site l, NW wavefronts.  Wave 0 diagonalises the
+// symmetrised rate matrix (jacobi_wave.hip.h); then the B buckets of the site
+// are dealt round-robin to the waves.  A bucket never touches LDS for matrix
+// data: U lives in registers in both MFMA operand forms and the three
+// products of a bucket are chained through the accumulator registers
+//
+//   Pt  = I + t A + (U phi2(t lam)) U^T          (= expm(t A), symmetric)
+//   Gt^T = -C^T / Pt / n                          (C^T streamed from HBM once)
+//   T   = Gt U ;  W = U^T T ;  M += W o Phi(t)    (Daleckii-Krein)
+//
+// using  v_mfma_f64_16x16x4_f64 on a 32x32 (NT = 2) or 16x16 (NT = 1) padded
+// frame.  The per-site epilogue forms dA = U M U^T and dQ = D^1/2 dA D^-1/2.
+//
+// HBM traffic: C^T once (B*S*S*8 bytes per site) + O(S^2) -- the algorithmic
+// minimum of SURVEY.md 8(d).
+#pragma once
+#include "common.hip.h"
+#include "jacobi_wave.hip.h"
+
+#define CB_LS 33  // LDS row stride (doubles) of the 32x32 frames
+
+struct SmallArgs {
+  int S, L, B;
+  const double *t;    // [L,B]
+  const double *Ct;   // [L,B,S,S]  (transposed counts)
+  const double *inv_n;  // [L]  1/n_l or 1
+  const double *dirsum; // [L,S]  colsum_k - rowsum_k of sum_b C (direct pi term)
+  const double *Q;    // [L,S,S]
+  const double *pi;   // [L,S]
+  double *loss;       // [L]
+  double *dQ;         // [L,S,S] or null
+  double *P;          // [L,B,S,S] (expm mode) or null
+  double *lam_out;    // [L,S] (eigh mode) or null
+  double *U_out;      // [L,S,S] (eigh mode) or null
+  int *status;        // [L] sweeps used by the eigensolver
+};
+
+// LDS carve-up (doubles)
+template <int NW>
+struct SmallLds {
+  static constexpr int FRAME = 32 * CB_LS;
+  static constexpr int A = 0;                 // A, later X
+  static constexpr int G = A + FRAME;         // Jacobi G, later M
+  static constexpr int V = G + FRAME;         // eigenvectors (column k at V + k*LS)
+  static constexpr int LAM = V + FRAME;       // 32
+  static constexpr int D = LAM + 32;          // sqrt(pi)
+  static constexpr int TAB = D + 32;          // per wave: F[32], E[32], H[32]
+  static constexpr int RED = TAB + NW * 96;   // (NW/2) * 1024 reduction slots (min 1)
+  static constexpr int LOSS = RED + ((NW / 2) > 0 ? (NW / 2) : 1) * 1024;
+  static constexpr int TOTAL = LOSS + NW;
+};
+
+enum { SMALL_LOSSGRAD = 0, SMALL_EXPM = 1, SMALL_EIGH = 2 };
+
+// ---- the bank of one site, given A (LDS), V/lam (LDS), d (LDS) -------------
+// Each wave returns its partial M (registers) and loss.
+template <int NT, int KS>
+struct SmallFrags {
+  double UA[NT][KS];  // U[16 mt + (l&15)][4 s + (l>>4)]
+  double UB[NT][KS];  // U[4 s + (l>>4)][16 nt + (l&15)]
+  double lamR[NT][4]; // lam[16 at + (l>>4) + 4 r]
+  double lamC[NT];    // lam[16 ct + (l&15)]
+};
+
+template <int NT, int KS>
+__device__ __forceinline__ void load_frags(SmallFrags<NT, KS> &f, const double *sV,
+                                           const double *sLam, int S) {
+  const int lane = threadIdx.x & 63;
+  const int lo = lane & 15, hi = lane >> 4;
+#pragma unroll
+  for (int x = 0; x < NT; ++x) {
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      const int i = 16 * x + lo, k = 4 * s + hi;
+      // U[i][k] = component i of eigenvector k = V[k*LS + i]
+      f.UA[x][s] = (i < S && k < S) ? sV[k * CB_LS + i] : 0.0;
+      // U[j = k][m = i] = V[i*LS + k]
+      f.UB[x][s] = (i < S && k < S) ? sV[i * CB_LS + k] : 0.0;
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int a = 16 * x + hi + 4 * r;
+      f.lamR[x][r] = (a < S) ? sLam[a] : 0.0;
+    }
+    const int c = 16 * x + lo;
+    f.lamC[x] = (c < S) ? sLam[c] : 0.0;
+  }
+}
+
+template <int NT, int KS, int MODE>
+__device__ __forceinline__ void small_bucket(const SmallFrags<NT, KS> &f, int S, double tb,
+                                             const double *__restrict__ Ctb, double inv_n,
+                                             const double *sA, const double *sD,
+                                             double *tab /* wave-private F,E,H */,
+                                             const double *sLam, double rho, d4 (&M)[NT][NT],
+                                             double &lossacc, double *__restrict__ Pout) {
+  const int lane = threadIdx.x & 63;
+  const int lo = lane & 15, hi = lane >> 4;
+
+  // issue the count loads first: they are consumed after the first product
+  double cval[NT][NT][4];
+  if (MODE == SMALL_LOSSGRAD) {
+#pragma unroll
+    for (int mt = 0; mt < NT; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = 16 * mt + hi + 4 * r, col = 16 * nt + lo;
+          cval[mt][nt][r] = (row < S && col < S) ? Ctb[row * S + col] : 0.0;
+        }
+  }
+
+  // Pt = U e^{t lam} U^T is evaluated as I + t A + U phi2(t lam) U^T while
+  // t * rho <= 1 (rho >= spectral radius): entries that are O(t^2) keep full
+  // RELATIVE accuracy.  Beyond that the split would cancel (I and t A against
+  // U (-1 - x) U^T) and the plain form is used; no entry is tiny there.
+  const bool split = tb * rho <= 1.0;
+  // per-bucket spectral tables (lanes k < S), wave-private LDS
+  if (lane < 32) {
+    const double x = (lane < S) ? tb * sLam[lane] : 0.0;
+    tab[lane] = split ? phi2(x) : (lane < S ? exp(x) : 0.0);
+    tab[32 + lane] = exp(x);
+    tab[64 + lane] = exp(0.5 * x);
+  }
+  wave_lds_fence();
+
+  // ---- Pt = I + t A + (U F) U^T ------------------------------------------
+  double Fk[KS];
+#pragma unroll
+  for (int s = 0; s < KS; ++s) Fk[s] = tab[4 * s + hi];
+  d4 g[NT][NT];
+#pragma unroll
+  for (int mt = 0; mt < NT; ++mt) {
+    double uf[KS];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) uf[s] = f.UA[mt][s] * Fk[s];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      d4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int s = 0; s < KS; ++s) acc = mfma_f64(uf[s], f.UA[nt][s], acc);
+      g[mt][nt] = acc;
+    }
+  }
+  // ---- epilogue: loss, Gt^T = -C^T / Pt / n  (in place) --------------------
+#pragma unroll
+  for (int mt = 0; mt < NT; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = 16 * mt + hi + 4 * r, col = 16 * nt + lo;
+        const bool valid = (row < S) && (col < S);
+        double pt = 1.0;
+        if (valid) {
+          pt = g[mt][nt][r];
+          if (split) pt += tb * sA[row * CB_LS + col] + (row == col ? 1.0 : 0.0);
+        }
+        if (MODE == SMALL_EXPM) {
+          // P[row][col] = Pt[row][col] d_col / d_row
+          if (valid) Pout[row * S + col] = pt * sD[col] / sD[row];
+        } else {
+          const double c = cval[mt][nt][r];
+          double gv = 0.0;
+          if (c != 0.0) {
+            lossacc = fma(-c, log(pt), lossacc);
+            gv = -c * inv_n / pt;
+          }
+          g[mt][nt][r] = gv;
+        }
+      }
+  if (MODE == SMALL_EXPM) return;
+
+  // ---- T = Gt U :  T[i][m] = sum_j Gt[i][j] U[j][m] -------------------------
+  // A operand of k-step (jt, s) is register s of tile g[jt][it] (Gt^T[j][i]).
+  d4 T[NT][NT];
+#pragma unroll
+  for (int it = 0; it < NT; ++it)
+#pragma unroll
+    for (int mt = 0; mt < NT; ++mt) {
+      d4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int jt = 0; jt < NT; ++jt)
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+          if (4 * jt + s < KS) acc = mfma_f64(g[jt][it][s], f.UB[mt][4 * jt + s], acc);
+      T[it][mt] = acc;
+    }
+  // ---- W = U^T T, M += W o Phi ---------------------------------------------
+  double ER[NT][4], HR[NT][4], EC[NT], HC[NT];
+#pragma unroll
+  for (int x = 0; x < NT; ++x) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      ER[x][r] = tab[32 + ((16 * x + hi + 4 * r) & 31)];
+      HR[x][r] = tab[64 + ((16 * x + hi + 4 * r) & 31)];
+    }
+    EC[x] = tab[32 + ((16 * x + lo) & 31)];
+    HC[x] = tab[64 + ((16 * x + lo) & 31)];
+  }
+#pragma unroll
+  for (int at = 0; at < NT; ++at)
+#pragma unroll
+    for (int ct = 0; ct < NT; ++ct) {
+      d4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int it = 0; it < NT; ++it)
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+          if (4 * it + s < KS) acc = mfma_f64(f.UB[at][4 * it + s], T[it][ct][s], acc);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const double ph = divdiff(tb, f.lamR[at][r], f.lamC[ct], ER[at][r], EC[ct], HR[at][r],
+                                  HC[ct]);
+        M[at][ct][r] = fma(acc[r], ph, M[at][ct][r]);
+      }
+    }
+  wave_lds_fence();  // tab is rewritten by the next bucket
+}
+
+// ---- A = sym(D^1/2 Q D^-1/2) into LDS -----------------------------------------
+__device__ __forceinline__ void small_build_A(int S, const double *__restrict__ Q,
+                                              const double *__restrict__ pi, double *sA,
+                                              double *sD) {
+  for (int i = threadIdx.x; i < 32; i += blockDim.x) sD[i] = (i < S) ? sqrt(pi[i]) : 1.0;
+  __syncthreads();
+  for (int e = threadIdx.x; e < S * S; e += blockDim.x) {
+    const int i = e / S, j = e - i * S;
+    const double di = sD[i], dj = sD[j];
+    sA[i * CB_LS + j] = 0.5 * (di * Q[i * S + j] / dj + dj * Q[j * S + i] / di);
+  }
+  __syncthreads();
+}
+
+template <int NT, int KS, int NW, int MODE>
+__global__ __launch_bounds__(NW * 64) void small_bank_kernel(SmallArgs a) {
+  extern __shared__ double lds[];
+  using LD = SmallLds<NW>;
+  double *sA = lds + LD::A, *sG = lds + LD::G, *sV = lds + LD::V, *sLam = lds + LD::LAM,
+         *sD = lds + LD::D;
+  const int l = blockIdx.x, S = a.S, B = a.B;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int lo = lane & 15, hi = lane >> 4;
+
+  if (MODE == SMALL_EIGH) {
+    // a.Q holds the symmetric matrices themselves
+    for (int e = threadIdx.x; e < S * S; e += blockDim.x)
+      sA[(e / S) * CB_LS + (e % S)] = a.Q[(size_t)l * S * S + e];
+    __syncthreads();
+  } else {
+    small_build_A(S, a.Q + (size_t)l * S * S, a.pi + (size_t)l * S, sA, sD);
+  }
+  if (wave == 0) {
+    const int sweeps = wave_jacobi(S, sA, sG, sV, sLam, CB_LS, -1.0);
+    if (lane == 0 && a.status) a.status[l] = sweeps;
+  }
+  __syncthreads();
+  if (MODE == SMALL_EIGH) {
+    for (int e = threadIdx.x; e < S * S; e += blockDim.x) {
+      const int i = e / S, k = e - i * S;
+      a.U_out[(size_t)l * S * S + e] = sV[k * CB_LS + i];
+    }
+    for (int k = threadIdx.x; k < S; k += blockDim.x) a.lam_out[(size_t)l * S + k] = sLam[k];
+    return;
+  }
+
+  SmallFrags<NT, KS> f;
+  load_frags<NT, KS>(f, sV, sLam, S);
+  d4 M[NT][NT];
+#pragma unroll
+  for (int x = 0; x < NT; ++x)
+#pragma unroll
+    for (int y = 0; y < NT; ++y) M[x][y] = d4{0.0, 0.0, 0.0, 0.0};
+  double lossacc = 0.0;
+  const double inv_n = a.inv_n[l];
+  double *tab = lds + LD::TAB + wave * 96;
+  // Gershgorin: |lam| <= 2 max |A_ii| for a symmetrised rate matrix
+  double rho = 0.0;
+  for (int i = lane; i < S; i += 64) rho = fmax(rho, fabs(sA[i * CB_LS + i]));
+  rho = 2.0 * wave_max(rho);
+  for (int b = wave; b < B; b += NW) {
+    const size_t lb = (size_t)l * B + b;
+    small_bucket<NT, KS, MODE>(f, S, a.t[lb], a.Ct + lb * S * S, inv_n, sA, sD, tab, sLam, rho, M,
+                               lossacc, MODE == SMALL_EXPM ? a.P + lb * S * S : nullptr);
+  }
+  if (MODE == SMALL_EXPM) return;
+
+  // ---- loss ------------------------------------------------------------------
+  lossacc = wave_sum(lossacc);
+  if (lane == 0) lds[LD::LOSS + wave] = lossacc;
+  // ---- deterministic tree reduction of M over the waves -----------------------
+  double *red = lds + LD::RED;
+  for (int stride = NW / 2; stride >= 1; stride >>= 1) {
+    if (wave >= stride && wave < 2 * stride) {
+      double *dst = red + (wave - stride) * 1024;
+#pragma unroll
+      for (int x = 0; x < NT; ++x)
+#pragma unroll
+        for (int y = 0; y < NT; ++y)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) dst[((x * NT + y) * 4 + r) * 64 + lane] = M[x][y][r];
+    }
+    __syncthreads();
+    if (wave < stride) {
+      const double *src = red + wave * 1024;
+#pragma unroll
+      for (int x = 0; x < NT; ++x)
+#pragma unroll
+        for (int y = 0; y < NT; ++y)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) M[x][y][r] += src[((x * NT + y) * 4 + r) * 64 + lane];
+    }
+    __syncthreads();
+  }
+  // M (wave 0) -> LDS frame sG[a][c]
+  if (wave == 0) {
+#pragma unroll
+    for (int x = 0; x < NT; ++x)
+#pragma unroll
+      for (int y = 0; y < NT; ++y)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int ra = 16 * x + hi + 4 * r, c = 16 * y + lo;
+          if (ra < 32 && c < 32) sG[ra * CB_LS + c] = M[x][y][r];
+        }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double tot = 0.0;
+    for (int w = 0; w < NW; ++w) tot += lds[LD::LOSS + w];
+    // direct pi term: -(1/n) sum_k log d_k (colsum_k - rowsum_k)
+    double dir = 0.0;
+    for (int k = 0; k < S; ++k) dir = fma(log(sD[k]), a.dirsum[(size_t)l * S + k], dir);
+    a.loss[l] = (tot - dir) * inv_n;
+  }
+  if (a.dQ == nullptr) return;
+  // ---- X = M U^T  (X[a][j] = sum_c M[a][c] U[j][c]) into sA -------------------
+  // all bucket work is done: sA is free
+  for (int e = threadIdx.x; e < S * S; e += blockDim.x) {
+    const int ra = e / S, j = e - ra * S;
+    double acc = 0.0;
+    for (int c = 0; c < S; ++c) acc = fma(sG[ra * CB_LS + c], sV[c * CB_LS + j], acc);
+    sA[ra * CB_LS + j] = acc;
+  }
+  __syncthreads();
+  // ---- dA = U X ; dQ = D^1/2 dA D^-1/2 ------------------------------------------
+  for (int e = threadIdx.x; e < S * S; e += blockDim.x) {
+    const int i = e / S, j = e - i * S;
+    double acc = 0.0;
+    for (int k = 0; k < S; ++k) acc = fma(sV[k * CB_LS + i], sA[k * CB_LS + j], acc);
+    a.dQ[(size_t)l * S * S + e] = sD[i] * acc / sD[j];
+  }
+}

@@ -1,0 +1,150 @@
+/*
+ * cherrybank.h -- C ABI of libcherrybank.so (HIP, gfx950 / MI355X).
+ *
+ * The drop-in boundary for CherryML's composite-likelihood hot path: the
+ * quantised-branch-length matrix-exponential bank expm(t_b Q) and the
+ * count-weighted log-likelihood / gradient reduction that the reference
+ * evaluates once per optimiser epoch.  The reference has no FFI seam on this
+ * path (it is Python calling torch); every entry point below names the
+ * reference code it replaces (paths relative to the reference repository).
+ *
+ * Conventions
+ *   - all matrices are row-major float64; S = number of states, L = number of
+ *     independent problems ("sites"; L = 1 for the LG / co-evolution models),
+ *     B = number of quantised branch lengths ("buckets").
+ *   - every function returns 0 on success or a negative CB_E* code and leaves
+ *     a message retrievable with cb_last_error() (thread-local).
+ *   - the caller owns every buffer it passes; the library owns what is behind
+ *     the opaque handle.  `flags & CB_PTR_DEVICE` says that the data pointers
+ *     of that call are device pointers (e.g. torch `tensor.data_ptr()` of a
+ *     ROCm tensor) and must then be valid on the handle's device; without it
+ *     they are host pointers and the call copies synchronously.
+ *   - one handle = one GPU = one HIP stream; a handle is not thread-safe, the
+ *     library is re-entrant across handles and keeps no global state.
+ */
+#ifndef CHERRYBANK_H
+#define CHERRYBANK_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct cb_bank *cb_handle;
+
+enum {
+  CB_OK = 0,
+  CB_EINVAL = -1,   /* bad argument                                  */
+  CB_EHIP = -2,     /* a HIP runtime call failed                     */
+  CB_ENOMEM = -3,   /* device allocation failed                      */
+  CB_ENUMERIC = -4, /* non-finite input / eigensolver did not converge */
+  CB_EUNSUPPORTED = -5
+};
+
+enum {
+  CB_PTR_DEVICE = 1, /* data pointers of this call are device pointers */
+  CB_NORMALIZE = 2,  /* divide each site's loss (and gradient) by its total count
+                        (trainer.py:176-177 `loss_normalization`)     */
+  CB_NO_SYNC = 4     /* with CB_PTR_DEVICE: enqueue only, do not wait  */
+};
+
+/* ABI version of the loaded library (bumped on incompatible change). */
+int cb_version(void);
+
+/* Message of the last failing call on this thread ("" if none). */
+const char *cb_last_error(void);
+
+/* Number of visible HIP devices (0 when there is none; never fails). */
+int cb_device_count(void);
+
+/*
+ * Upload a bank once: t[L*B] branch lengths and C[L*B*S*S] count matrices.
+ * Replaces the per-epoch host->device copy of (t, C) in
+ * cherryml/estimation/_ratelearn/trainer.py:164-167 and the tensorisation in
+ * ratelearner.py:147-152 / _siterm/_cherryml_vectorized.py:297-299: the
+ * counts stay resident in HBM (stored transposed per bucket, the layout the
+ * kernels stream) for the life of the handle.
+ */
+int cb_create(int device, int S, int L, int B, const double *t, const double *C,
+              int flags, cb_handle *out);
+
+void cb_destroy(cb_handle h);
+
+/* Run all work of this handle on `hip_stream` (a hipStream_t, e.g. torch's
+ * current stream) instead of the handle's own stream.  NULL restores it. */
+int cb_set_stream(cb_handle h, void *hip_stream);
+
+/* Total count n_l = sum(C[l]) per site, n[L] (host pointer). */
+int cb_total_counts(cb_handle h, double *n);
+
+/*
+ * One evaluation of the epoch body for reversible Q:
+ *   loss[l] = - sum_b <C[l,b], log expm(t[l,b] Q[l])>      (/ n_l with CB_NORMALIZE)
+ *   dQ[l]   = d loss[l] / d Q[l]   as a free S x S matrix
+ * Replaces trainer.py:170-177 (forward) and the `loss.backward()` of
+ * trainer.py:186 down to the Q node, and _cherryml_vectorized.py:264-293,378.
+ * pi[L*S] is the stationary distribution Q[l] is reversible with respect to
+ * (softmax of the reference's `_pi` / `theta`, rate.py:184); it is used only
+ * to symmetrise, A = D^1/2 Q D^-1/2, so that the bank is evaluated through one
+ * symmetric eigendecomposition A = U diag(lam) U^T per matrix.
+ * dQ may be NULL (loss only).
+ */
+int cb_loss_grad(cb_handle h, const double *Q, const double *pi, int flags,
+                 double *loss, double *dQ);
+
+/*
+ * Same contract for a general (non-reversible) Q, e.g. the reference's
+ * parameterisation under a non-symmetric mask (rate.py:182): scaling and
+ * squaring with a Taylor polynomial forward, its exact adjoint backward
+ * (the algorithm class of torch.matrix_exp, trainer.py:170-172,186).
+ */
+int cb_loss_grad_general(cb_handle h, const double *Q, int flags, double *loss,
+                         double *dQ);
+
+/* Debug / oracle cross-check: P[L*B*S*S] = expm(t[l,b] Q[l]) by the same device
+ * code path as cb_loss_grad (pi != NULL) or cb_loss_grad_general (pi == NULL). */
+int cb_expm_bank(cb_handle h, const double *Q, const double *pi, int flags,
+                 double *P);
+
+/* Debug: symmetric eigendecomposition used by the bank, A[L*S*S] ->
+ * lam[L*S], U[L*S*S] (columns are eigenvectors), by the device Jacobi solver. */
+int cb_eigh(cb_handle h, const double *A, int flags, double *lam, double *U);
+
+/*
+ * Fused optimiser for the reference's `pande_reversible` parameterisation
+ * (rate.py:167-188) -- `num_epochs` iterations of
+ *   Q = Q(upper_diag, log_pi, mask); loss, grad; best-iterate bookkeeping;
+ *   Adam / SGD step
+ * entirely on the device (trainer.py:156-218 + torch.optim.Adam as configured
+ * in ratelearner.py:123-130: betas (0.9, 0.999), eps 1e-8, no weight decay).
+ * Only for S <= 32 and L == 1 banks (LG-sized problems are launch-latency
+ * bound, so the whole epoch is one kernel).
+ *   upper_diag[S(S-1)/2], log_pi[S]  in: initial parameters, out: final ones
+ *   mask[S*S]                        0/1 (symmetric), NULL = all ones
+ *   loss_curve[num_epochs]           loss of every epoch (pre-step)
+ *   Q_best[S*S], Q_last[S*S]         as trainer.py:179-181,237-242
+ *   Q_pow2[n_pow2*S*S]               Q at epochs 1,2,4,... (trainer.py:183-184); may be NULL
+ * All pointers are host pointers.
+ */
+int cb_train_pande_reversible(cb_handle h, double *upper_diag, double *log_pi,
+                              const double *mask, int num_epochs, double lr,
+                              int do_adam, int flags, double *loss_curve,
+                              double *Q_best, double *Q_last, double *Q_pow2,
+                              int n_pow2);
+
+/*
+ * Fused optimiser for the SiteRM parameterisation (theta[L*N], Theta[L*N*N];
+ * _cherryml_vectorized.py:173-262) with per-site best-iterate tracking
+ * (:366-372) and Adam lr (:327).  Host pointers.
+ *   res[L*N*N]                       best Q per site
+ *   loss_per_epoch_per_site[E*L]     may be NULL
+ */
+int cb_train_siterm(cb_handle h, double *theta, double *Theta, int num_epochs,
+                    double lr, int flags, double *res,
+                    double *loss_per_epoch_per_site);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CHERRYBANK_H */

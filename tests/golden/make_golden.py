@@ -264,6 +264,12 @@ def main():
         "s400_mask": (f"{tid}/co_matrices_small/matrices_by_quantized_branch_length.txt",
                       None, f"{tid}/synthetic_rate_matrices/mask_Q2.txt"),
     }
+    # the reference's 20x20 random mask is NOT symmetric (=> non-reversible Q);
+    # add a symmetrised copy so the reversible path has a 20-state masked case.
+    symdir = tempfile.mkdtemp()
+    m20 = read_mask_matrix(f"{tid}/20x20_random_mask.txt")
+    (m20 * m20.T).to_csv(os.path.join(symdir, "mask_sym.txt"), sep=" ")
+    cases["s20_symmask"] = (cases["s20_mask"][0], None, os.path.join(symdir, "mask_sym.txt"))
     for name, (cpath, ipath, mpath) in cases.items():
         t, C = _count_arrays(read_count_matrices(cpath))
         S = C.shape[-1]
@@ -313,7 +319,7 @@ def main():
 
     # ------------------------------------------------------------ trajectories
     for name, epochs in [("toy3_init", 30), ("toy3_mask", 30), ("s20_mask", 50),
-                         ("s400_mask", 3)]:
+                         ("s20_symmask", 50), ("s400_mask", 3)]:
         cpath, ipath, mpath = cases[name]
         t, C = _count_arrays(read_count_matrices(cpath))
         S = C.shape[-1]

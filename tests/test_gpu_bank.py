@@ -1,0 +1,155 @@
+"""Parity of the HIP path (through the C ABI) against the oracle and the
+reference-generated golden vectors.  Needs an MI355X: `pytest -m gpu`."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, relerr
+from oracle import ratelearn_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+def _bank(t, C):
+    from cherryml_amd import CherryBank
+    return CherryBank(t, C, device=0)
+
+
+def _pi_of(log_pi):
+    p = np.exp(log_pi - np.max(log_pi))
+    return p / p.sum()
+
+
+def _sym_rate(rng, S, scale=1.0):
+    """random reversible rate matrix and its stationary distribution"""
+    pi = rng.dirichlet(np.full(S, 5.0))
+    R = rng.gamma(2.0, 0.5, size=(S, S)) * scale
+    R = np.triu(R, 1)
+    R = R + R.T
+    d = np.sqrt(pi)
+    Q = R * d[None, :] / d[:, None]
+    Q -= np.diag(Q.sum(1))
+    return Q, pi
+
+
+@pytest.mark.parametrize("S,L", [(3, 1), (4, 5), (16, 3), (20, 7), (21, 2), (32, 2)])
+def test_eigh_small(S, L):
+    rng = np.random.default_rng(S * 100 + L)
+    A = np.zeros((L, S, S))
+    for l in range(L):
+        Q, pi = _sym_rate(rng, S)
+        d = np.sqrt(pi)
+        A[l] = d[:, None] * Q / d[None, :]
+        A[l] = 0.5 * (A[l] + A[l].T)
+    with _bank(np.ones((L, 1)), np.ones((L, 1, S, S))) as bank:
+        lam, U = bank.eigh(A)
+    for l in range(L):
+        assert np.abs(U[l].T @ U[l] - np.eye(S)).max() < 1e-13
+        assert np.abs(A[l] @ U[l] - U[l] * lam[l][None, :]).max() < 1e-13 * max(1.0, np.abs(A[l]).max())
+        assert np.allclose(np.sort(lam[l]), np.linalg.eigvalsh(A[l]), atol=1e-13 * np.abs(A[l]).max())
+
+
+@pytest.mark.parametrize("case", ["toy3_init", "toy3_mask", "s20_symmask"])
+def test_expm_bank_small(case):
+    g = load_golden(f"eval_{case}.npz")
+    Q, pi = g["Q_f64"], _pi_of(g["log_pi"])
+    with _bank(g["t"], g["C"]) as bank:
+        P = bank.expm_bank(Q, pi)[0]
+    ref = orc.expm_bank(Q, g["t"])
+    # absolute error: eps-level, plus the unavoidable t * |dlambda| ~ t * eps * |Q|
+    # of any spectral (or squaring) method -- one fixture bucket has t = 9999
+    tol = 1e-13 + 8 * 2.2e-16 * g["t"][:, None, None] * np.abs(Q).max()
+    assert np.all(np.abs(P - ref) < tol)
+    small_t = g["t"] < 10
+    # elementwise RELATIVE accuracy (tiny masked entries too) at ordinary t
+    assert np.abs(P[small_t] / ref[small_t] - 1.0).max() < 1e-11
+
+
+@pytest.mark.parametrize("case", ["toy3_init", "toy3_mask", "s20_symmask"])
+def test_loss_grad_small_vs_reference_golden(case):
+    g = load_golden(f"eval_{case}.npz")
+    Q, pi = g["Q_f64"], _pi_of(g["log_pi"])
+    with _bank(g["t"], g["C"]) as bank:
+        loss, dQ = bank.loss_grad(Q, pi, normalize=True)
+        loss_u, dQ_u = bank.loss_grad(Q, pi, normalize=False)
+        n = bank.total_counts[0]
+    assert abs(loss[0] - float(g["loss_f64"])) < 1e-12 * abs(float(g["loss_f64"]))
+    assert relerr(dQ[0], g["dQ_f64"]) < 1e-11
+    assert abs(n - g["C"].sum()) < 1e-9 * n
+    assert abs(loss_u[0] / n - loss[0]) < 1e-12 * abs(loss[0])
+    assert relerr(dQ_u[0] / n, dQ[0]) < 1e-13
+
+
+def test_loss_grad_lg_bank_129_buckets():
+    g = load_golden("traj_lgbank.npz")
+    Q = g["Q_best_f64"]
+    pi = orc.stationary_distribution(Q)
+    Qt = torch.tensor(Q, requires_grad=True)
+    ref = orc.bank_loss(Qt, torch.tensor(g["t"]), torch.tensor(g["C"]))
+    ref.backward()
+    with _bank(g["t"], g["C"]) as bank:
+        loss, dQ = bank.loss_grad(Q, pi)
+    assert abs(loss[0] - ref.item()) < 1e-12 * abs(ref.item())
+    assert relerr(dQ[0], Qt.grad.numpy()) < 1e-10
+
+
+def test_loss_grad_siterm_batch():
+    """L independent sites with their own branch-length grids."""
+    g = load_golden("siterm_aa.npz")
+    counts, times = g["counts"], g["times"]
+    L, B, N, _ = counts.shape
+    rng = np.random.default_rng(1)
+    Qs = np.zeros((L, N, N))
+    pis = np.zeros((L, N))
+    for l in range(L):
+        Qs[l], pis[l] = _sym_rate(rng, N, scale=0.3)
+    Qt = torch.tensor(Qs, requires_grad=True)
+    per_site, total = orc.siterm_loss(Qt, torch.tensor(counts), torch.tensor(times))
+    total.backward()
+    with _bank(times, counts) as bank:
+        loss, dQ = bank.loss_grad(Qs, pis)
+    assert np.allclose(loss, per_site.detach().numpy(), rtol=1e-12, atol=0)
+    for l in range(L):
+        assert relerr(dQ[l], Qt.grad[l].numpy()) < 1e-10
+
+
+def test_eigh_large():
+    g = load_golden("eval_s400_mask.npz")
+    Q, pi = g["Q_f64"], _pi_of(g["log_pi"])
+    d = np.sqrt(pi)
+    A = d[:, None] * Q / d[None, :]
+    A = 0.5 * (A + A.T)
+    with _bank(g["t"], g["C"]) as bank:
+        lam, U = bank.eigh(A)
+    lam, U = lam[0], U[0]
+    assert np.abs(U.T @ U - np.eye(400)).max() < 1e-12
+    assert np.abs(A @ U - U * lam[None, :]).max() < 1e-12 * np.abs(A).max()
+
+
+def test_expm_bank_large():
+    g = load_golden("eval_s400_mask.npz")
+    Q, pi = g["Q_f64"], _pi_of(g["log_pi"])
+    with _bank(g["t"], g["C"]) as bank:
+        P = bank.expm_bank(Q, pi)[0]
+    ref = orc.expm_bank(Q, g["t"])
+    tol = 1e-13 + 8 * 2.2e-16 * g["t"][:, None, None] * np.abs(Q).max()
+    assert np.all(np.abs(P - ref) < tol)
+    small_t = g["t"] < 10
+    assert np.abs(P[small_t] / ref[small_t] - 1.0).max() < 1e-10
+
+
+def test_loss_grad_large_vs_reference_golden():
+    g = load_golden("eval_s400_mask.npz")
+    Q, pi = g["Q_f64"], _pi_of(g["log_pi"])
+    with _bank(g["t"], g["C"]) as bank:
+        loss, dQ = bank.loss_grad(Q, pi)
+    assert abs(loss[0] - float(g["loss_f64"])) < 1e-12 * abs(float(g["loss_f64"]))
+    assert relerr(dQ[0], g["dQ_f64"]) < 1e-10
+
+
+def test_bad_arguments_raise():
+    from cherryml_amd import CherryBank
+    with pytest.raises(ValueError):
+        CherryBank(np.ones(3), np.ones((3, 4, 5)))
+    with pytest.raises(ValueError):
+        CherryBank(np.ones(2), np.zeros((2, 3, 3)))  # zero total count

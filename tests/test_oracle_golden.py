@@ -7,7 +7,7 @@ import torch
 from conftest import load_golden, relerr
 from oracle import ratelearn_oracle as orc
 
-EVAL_CASES = ["toy3_init", "toy3_mask", "s20_mask", "s400_mask"]
+EVAL_CASES = ["toy3_init", "toy3_mask", "s20_mask", "s20_symmask", "s400_mask"]
 
 
 @pytest.mark.parametrize("case", EVAL_CASES)
@@ -23,7 +23,7 @@ def test_single_evaluation_f64(case):
     assert relerr(r["d_log_pi"], g["d_log_pi_f64"]) < 1e-11
 
 
-@pytest.mark.parametrize("case", EVAL_CASES[:3])
+@pytest.mark.parametrize("case", EVAL_CASES[:4])
 def test_single_evaluation_as_is_f32(case):
     g = load_golden(f"eval_{case}.npz")
     r = orc.evaluate(g["upper_diag"], g["log_pi"], g["mask"], g["t"], g["C"], torch.float32)
@@ -51,7 +51,7 @@ def test_mask_incompatible_initialisation_raises():
         orc.invert_pande_reversible(g["init"], m)
 
 
-@pytest.mark.parametrize("case", ["toy3_init", "toy3_mask", "s20_mask"])
+@pytest.mark.parametrize("case", ["toy3_init", "toy3_mask", "s20_mask", "s20_symmask"])
 def test_trajectory_f64(case):
     e = load_golden(f"eval_{case}.npz")
     g = load_golden(f"traj_{case}.npz")
