@@ -1,0 +1,317 @@
+#!/usr/bin/env python3
+"""Benchmark of the composite-likelihood hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload NAME]
+
+A "step" is one optimiser epoch of the reference's `train_quantization`
+(cherryml/estimation/_ratelearn/trainer.py:156-218) over one synthetic bank:
+    Q(theta) -> loss = -sum_b <C_b, log expm(t_b Q)>/n -> dL/dtheta -> Adam step
+with the bank resident in HBM.  metric = cherry-pairs/s = sum(C) / t_epoch
+(every counted cherry x site pair adds exactly 1 to C).
+
+Workloads (BASELINE.json configs):
+  coevo400  co-evolution 400x400, B = 129 dense bank, sum C = 1,057,194 (the size of
+            the reference's demo_data co-evolution bank)   [default]
+  lg20      LG 20x20, 1000 families x 200 sites x 64 cherries: sum C = 1.28e7
+  siterm    SiteRM per-site 20x20, L sites (--sites, default 5000), B = 129
+
+N > 1 (one process per GPU, torch.distributed/RCCL): coevo400 / lg20 shard the
+129 buckets over the ranks and all-reduce (loss, dL/dQ) each epoch -- strong
+scaling of one bank; siterm shards the sites (no collective) -- weak scaling.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8.0 TB/s spec
+F64_PEAK_TFLOPS = 78.6     # 256 CU x 4 SIMD x 32 flop/clk x 2.4 GHz (f64 MFMA = f64 vector rate)
+
+
+# --------------------------------------------------------------------- inputs
+def quantization_grid():
+    """reference estimation_end_to_end/_cherry.py:267-272"""
+    return np.array([float("%.8f" % (0.03 * 1.1 ** i)) for i in range(-64, 65)])
+
+
+def bucket_weights(n_pairs: float, rng) -> np.ndarray:
+    """cherry lengths ~ Exp(mean 0.4), snapped to the nearest grid point in log space"""
+    grid = quantization_grid()
+    lengths = rng.exponential(0.4, size=400000)
+    lengths = lengths[(lengths >= grid[0]) & (lengths <= grid[-1])]
+    idx = np.abs(np.log(lengths[:, None] / grid[None, :])).argmin(1)
+    w = np.bincount(idx, minlength=grid.size).astype(np.float64)
+    w = np.maximum(w, 1.0)  # dense bank: every bucket populated
+    return w * (n_pairs / w.sum())
+
+
+def lg_matrix():
+    z = np.load(os.path.join(ROOT, "tests", "golden", "data_lg.npz"))
+    return z["lg"]
+
+
+def stationary(Q):
+    w, v = np.linalg.eig(Q.T)
+    p = v[:, int(np.argmin(np.abs(w.real)))].real
+    return p / p.sum()
+
+
+def reversible_bank(Q, pi, n_pairs, rng):
+    """C_b = w_b diag(pi) expm(t_b Q), symmetrised (cherries are unordered)."""
+    grid = quantization_grid()
+    d = np.sqrt(pi)
+    A = d[:, None] * Q / d[None, :]
+    lam, U = np.linalg.eigh(0.5 * (A + A.T))
+    w = bucket_weights(n_pairs, rng)
+    C = np.empty((grid.size,) + Q.shape)
+    for b, t in enumerate(grid):
+        P = (U * np.exp(t * lam)) @ U.T
+        P = np.maximum(P * d[None, :] / d[:, None], 0.0)
+        J = pi[:, None] * P
+        C[b] = w[b] * 0.5 * (J + J.T)
+    return grid, C * (n_pairs / C.sum())
+
+
+def coevolution_truth(rng):
+    """400-state pair chain: two LG sites plus a symmetric log-normal coupling on
+    the allowed (single-substitution) rates; mask as data/mask_matrices/aa_coevolution_mask."""
+    lg = lg_matrix()
+    pi1 = stationary(lg)
+    I = np.eye(20)
+    Q = np.kron(lg, I) + np.kron(I, lg)
+    a = np.arange(400) // 20
+    b = np.arange(400) % 20
+    mask = ((a[:, None] == a[None, :]) | (b[:, None] == b[None, :])).astype(np.float64)
+    pi = np.kron(pi1, pi1)
+    d = np.sqrt(pi)
+    R = d[:, None] * Q / d[None, :]
+    noise = rng.normal(0.0, 0.3, size=(400, 400))
+    noise = np.triu(noise, 1)
+    R = R * np.exp(noise + noise.T)
+    np.fill_diagonal(R, 0.0)
+    R = R * mask
+    Qc = R * d[None, :] / d[:, None]
+    Qc -= np.diag(Qc.sum(1))
+    return Qc, pi, mask
+
+
+def make_workload(name, sites, rng):
+    if name == "coevo400":
+        Q, pi, mask = coevolution_truth(rng)
+        n_pairs = 1057194.0
+        t, C = reversible_bank(Q, pi, n_pairs, rng)
+        return dict(kind="single", t=t, C=C, mask=mask, S=400, n_pairs=n_pairs,
+                    desc="co-evolution 400x400, B=129 dense synthetic bank, sum C = 1,057,194 "
+                         "(= reference demo_data co-evolution bank)")
+    if name == "lg20":
+        Q = lg_matrix()
+        n_pairs = 1000 * 200 * 64.0
+        t, C = reversible_bank(Q, stationary(Q), n_pairs, rng)
+        return dict(kind="single", t=t, C=C, mask=np.ones((20, 20)), S=20, n_pairs=n_pairs,
+                    desc="LG 20x20, 1000 families x 200 sites x 64 cherries, B=129")
+    if name == "siterm":
+        lg = lg_matrix()
+        pi = stationary(lg)
+        grid = quantization_grid()
+        equ = (np.ones((20, 20)) - np.eye(20)) / 19.0
+        equ -= np.diag(equ.sum(1))
+        banks = []
+        for Qb, pb in ((lg, pi), (equ, np.full(20, 0.05))):
+            banks.append(reversible_bank(Qb, pb, 2000.0, rng)[1])
+        rates = rng.gamma(3.0, 1.0 / 3.0, size=sites)
+        C = np.empty((sites, grid.size, 20, 20))
+        T = np.empty((sites, grid.size))
+        Q0 = np.empty((sites, 20, 20))
+        for l in range(sites):
+            C[l] = banks[l % 2]
+            T[l] = grid / max(rates[l], 0.05)  # per-site grid (the reference's rate-scaled buckets)
+            Q0[l] = (lg if l % 2 == 0 else equ) * 0.9
+        return dict(kind="sites", t=T, C=C, S=20, n_pairs=float(C.sum()), init=Q0,
+                    desc=f"SiteRM per-site 20x20, L={sites} sites, B=129")
+    raise SystemExit(f"unknown workload {name}")
+
+
+# ----------------------------------------------------------------- cpu baseline
+def cpu_baseline(wl, name):
+    """The oracle (reference algorithm: float32 torch.matrix_exp + autograd on the
+    host cores) on a bounded sample of the same bank; scaled to one whole epoch."""
+    import torch
+    from oracle import ratelearn_oracle as orc
+    from cherryml_amd.estimation import jtt_ipw_from_arrays
+
+    cores = torch.get_num_threads()
+    if wl["kind"] == "single":
+        B = wl["C"].shape[0]
+        nb = {400: 6, 20: 129}[wl["S"]]
+        sel = np.linspace(0, B - 1, nb).round().astype(int)
+        t, C = wl["t"][sel], wl["C"][sel]
+        init = jtt_ipw_from_arrays(wl["t"], wl["C"], wl["mask"])
+        u, p = orc.invert_pande_reversible(init, wl["mask"])
+        reps = 1 if wl["S"] == 400 else 20
+        orc.evaluate(u, p, wl["mask"], t[:1], C[:1], torch.float32)  # warm up
+        t0 = time.time()
+        for _ in range(reps):
+            orc.evaluate(u, p, wl["mask"], t, C, torch.float32)
+        dt = (time.time() - t0) / reps * (B / nb)
+        sample = f"{nb} of {B} buckets x {reps} evaluation(s), float32 expm as the reference, scaled to {B}"
+    else:
+        L = min(16, wl["C"].shape[0])
+        Q = torch.tensor(wl["init"][:L], requires_grad=True)
+        t0 = time.time()
+        _, tot = orc.siterm_loss(Q, torch.tensor(wl["C"][:L]), torch.tensor(wl["t"][:L]))
+        tot.backward()
+        dt = (time.time() - t0) * (wl["C"].shape[0] / L)
+        sample = f"{L} of {wl['C'].shape[0]} sites, float64 as the reference's SiteRM path, scaled"
+    return dict(value=wl["n_pairs"] / dt, unit="cherry-pairs/s", cores=int(cores), kind="port",
+                sample=sample, seconds_per_epoch=dt)
+
+
+# ------------------------------------------------------------------------ main
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=None)
+    ap.add_argument("--warmup", type=int, default=None)
+    ap.add_argument("--workload", default="coevo400", choices=["coevo400", "lg20", "siterm"])
+    ap.add_argument("--sites", type=int, default=5000)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+    if args.gpus != world and rank == 0 and world > 1:
+        print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    import cherryml_amd
+    from cherryml_amd.distributed import ShardedBank
+    from cherryml_amd.estimation import jtt_ipw_from_arrays
+
+    defaults = {"coevo400": (10, 2), "lg20": (200, 20), "siterm": (5, 1)}
+    steps = args.steps if args.steps is not None else defaults[args.workload][0]
+    warmup = args.warmup if args.warmup is not None else defaults[args.workload][1]
+
+    rng = np.random.default_rng(0)
+    wl = make_workload(args.workload, args.sites, rng)
+    S = wl["S"]
+
+    # ---- model + resident bank
+    if wl["kind"] == "single":
+        init = jtt_ipw_from_arrays(wl["t"], wl["C"], wl["mask"])  # pipelines' default init
+        module = cherryml_amd.RateMatrix(
+            num_states=S, mode="pande_reversible", mask=torch.tensor(wl["mask"]),
+            pi=torch.ones(S, dtype=torch.float64) / S, pi_requires_grad=True,
+            initialization=init).to(dev)
+        sharded = ShardedBank(wl["t"], wl["C"])
+        bank = sharded.bank
+        opt = torch.optim.Adam(module.parameters(), lr=0.1)
+        n_pairs_total = wl["n_pairs"]
+        scaling = "strong"
+
+        def step():
+            opt.zero_grad()
+            Q = module()
+            loss = sharded.loss(Q, module.stationary(), normalize=True)[0]
+            loss.backward()
+            opt.step()
+            return loss
+    else:
+        from cherryml_amd._siterm._vectorized import _invert, _site_Q
+        L = wl["C"].shape[0]
+        th, Th = _invert(wl["init"])
+        theta = torch.tensor(th, device=dev).requires_grad_(True)
+        Theta = torch.tensor(Th, device=dev).requires_grad_(True)
+        upper = torch.triu(torch.ones(S, S, dtype=torch.float64, device=dev), diagonal=1)
+        bank = cherryml_amd.CherryBank(wl["t"], wl["C"], device=local_rank)
+        opt = torch.optim.Adam([theta, Theta], lr=0.1)
+        from cherryml_amd._autograd import bank_loss
+        n_pairs_total = wl["n_pairs"] * world  # every rank owns its own L sites
+        scaling = "weak"
+
+        def step():
+            opt.zero_grad()
+            Q, pi = _site_Q(theta, Theta, upper)
+            loss = bank_loss(Q, pi, bank, normalize=True).sum()
+            loss.backward()
+            opt.step()
+            return loss
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(warmup):
+        step()
+    bank.profile(True)
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        last = step()
+    fence()
+    dt = time.perf_counter() - t0
+    tm = bank.timing_means()
+    bank.profile(False)
+    if world > 1:
+        tdt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tdt, op=dist.ReduceOp.MAX)
+        dt = float(tdt.item())
+    final_loss = float(last.item())
+
+    if rank == 0:
+        ms_per_step = dt / steps * 1e3
+        value = n_pairs_total / (dt / steps)
+        B_local = len(sharded.local_buckets) if wl["kind"] == "single" else wl["C"].shape[1]
+        if S > 32:
+            # dominant MFMA kernels: K1/K2/K3 are one batched 2 S^3 B GEMM each
+            flops = 2.0 * S ** 3 * B_local
+            names = {"k1": "k1_pt_loss_gt", "k2": "k2_t_eq_g_u", "k3": "k3_mt_accum"}
+            dom = max(names, key=lambda k: tm[k])
+            achieved = flops / (tm[dom] * 1e-3) / 1e12 if tm[dom] > 0 else 0.0
+            roofline = dict(bound="mfma", kernel=names[dom], achieved=achieved,
+                            peak=F64_PEAK_TFLOPS, unit="TFLOP/s", frac=achieved / F64_PEAK_TFLOPS,
+                            traffic=None, ms_per_launch=tm[dom],
+                            flops_per_launch=flops)
+        else:
+            Lb = wl["C"].shape[0] if wl["kind"] == "sites" else 1
+            nbytes = float(Lb) * B_local * S * S * 8
+            achieved = nbytes / (tm["small"] * 1e-3) / 1e9 if tm["small"] > 0 else 0.0
+            roofline = dict(bound="hbm", kernel="small_bank_kernel", achieved=achieved,
+                            peak=HBM_PEAK_GBS, unit="GB/s", frac=achieved / HBM_PEAK_GBS,
+                            traffic=None, ms_per_launch=tm["small"], bytes_per_launch=nbytes)
+        out = {
+            "metric": "cherry-pairs/sec (whole node) per EM iter",
+            "value": value, "unit": "cherry-pairs/s", "n_gpus": world, "steps": steps,
+            "warmup": warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
+            "scaling": scaling, "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": wl["desc"], "states": S, "buckets": 129,
+                       "sharding": ("buckets" if wl["kind"] == "single" else "sites") + f" x{world}",
+                       "optimizer": "Adam lr 0.1 (torch glue)"},
+            "roofline": roofline,
+            "phase_ms": {k: round(v, 4) for k, v in tm.items()},
+            "final_loss": final_loss,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(wl, args.workload)
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -21,12 +21,16 @@ SIGNATURES = {
     "cb_device_count": (C.c_int, []),
     "cb_create": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, C.c_int, C.POINTER(_vp)]),
     "cb_destroy": (None, [_vp]),
-    "cb_set_stream": (C.c_int, [_vp, _vp]),
+    "cb_set_stream": (C.c_int, [_vp, _vp, C.c_int]),
     "cb_total_counts": (C.c_int, [_vp, _vp]),
     "cb_loss_grad": (C.c_int, [_vp, _vp, _vp, C.c_int, _vp, _vp]),
     "cb_loss_grad_general": (C.c_int, [_vp, _vp, C.c_int, _vp, _vp]),
     "cb_expm_bank": (C.c_int, [_vp, _vp, _vp, C.c_int, _vp]),
     "cb_eigh": (C.c_int, [_vp, _vp, C.c_int, _vp, _vp]),
+    "cb_profile": (C.c_int, [_vp, C.c_int]),
+    "cb_last_timings": (C.c_int, [_vp, _vp, C.c_int]),
+    "cb_timing_sums": (C.c_int, [_vp, _vp, C.c_int, C.POINTER(C.c_int)]),
+    "cb_last_sweeps": (C.c_int, [_vp]),
     "cb_train_pande_reversible": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, C.c_double, C.c_int,
                                             C.c_int, _vp, _vp, _vp, _vp, C.c_int]),
     "cb_train_siterm": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_double, C.c_int, _vp, _vp]),

@@ -88,8 +88,37 @@ class CherryBank:
     def __exit__(self, *exc):
         self.close()
 
-    def set_stream(self, hip_stream: Optional[int]):
-        _lib.check(_lib.load().cb_set_stream(self._h, hip_stream or None), "cb_set_stream")
+    def set_stream(self, hip_stream: Optional[int], own: bool = False):
+        """Run on `hip_stream` (0 / None = HIP's default stream, torch's default) or, with
+        own=True, on the handle's private stream."""
+        _lib.check(_lib.load().cb_set_stream(self._h, hip_stream or None, int(own)), "cb_set_stream")
+
+    # -- profiling ----------------------------------------------------------
+    TIMING_NAMES = ("total", "eigh", "k1", "k2", "k3", "k4", "small")
+
+    def profile(self, enable: bool = True):
+        _lib.check(_lib.load().cb_profile(self._h, int(enable)), "cb_profile")
+
+    def last_timings(self) -> dict:
+        """milliseconds per phase of the last profiled cb_loss_grad (HIP events)."""
+        ms = np.zeros(len(self.TIMING_NAMES))
+        _lib.check(_lib.load().cb_last_timings(self._h, ms.ctypes.data, ms.size), "cb_last_timings")
+        return dict(zip(self.TIMING_NAMES, ms.tolist()))
+
+    def timing_means(self) -> dict:
+        """mean milliseconds per phase over the profiled calls since profile(True)."""
+        import ctypes as Ct
+        ms = np.zeros(len(self.TIMING_NAMES))
+        calls = Ct.c_int(0)
+        _lib.check(_lib.load().cb_timing_sums(self._h, ms.ctypes.data, ms.size, Ct.byref(calls)),
+                   "cb_timing_sums")
+        k = max(calls.value, 1)
+        out = dict(zip(self.TIMING_NAMES, (ms / k).tolist()))
+        out["calls"] = calls.value
+        return out
+
+    def last_sweeps(self) -> int:
+        return int(_lib.load().cb_last_sweeps(self._h))
 
     # -- host-pointer API (numpy) -----------------------------------------
     def _shape_Q(self, Q, pi):

@@ -64,7 +64,24 @@ struct cb_bank {
   unsigned long long *off_bits = nullptr;
   int k3_chunk = 0, k3_nchunks = 0;
   int last_sweeps = 0;
+  // profiling
+  bool profile = false;
+  hipEvent_t ev[CB_T_COUNT + 1] = {};
+  bool ev_rec[CB_T_COUNT + 1] = {};
+  double t_sum[CB_T_COUNT] = {};
+  int t_calls = 0;
+  bool t_pending = false;  // last profiled call not yet folded into t_sum
 };
+
+static void fold_pending(cb_bank *h);
+// event i marks the END of phase i-1 .. see mark()
+enum { EV_START = 0, EV_EIGH, EV_K1, EV_K2, EV_K3, EV_K4, EV_SMALL, EV_END };
+static void mark(cb_bank *h, int which) {
+  if (!h->profile) return;
+  if (!h->ev[which]) (void)hipEventCreate(&h->ev[which]);
+  (void)hipEventRecord(h->ev[which], h->stream);
+  h->ev_rec[which] = true;
+}
 
 template <typename T>
 static int dev_alloc(cb_bank *h, T **p, size_t count) {
@@ -298,14 +315,16 @@ extern "C" void cb_destroy(cb_handle h) {
   if (!h) return;
   (void)hipSetDevice(h->dev);
   if (h->own_stream) (void)hipStreamSynchronize(h->own_stream);
+  for (hipEvent_t e : h->ev)
+    if (e) (void)hipEventDestroy(e);
   for (void *p : h->allocs) (void)hipFree(p);
   if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
   delete h;
 }
 
-extern "C" int cb_set_stream(cb_handle h, void *hip_stream) {
+extern "C" int cb_set_stream(cb_handle h, void *hip_stream, int own) {
   if (!h) return fail(CB_EINVAL, "cb_set_stream: NULL handle");
-  h->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : h->own_stream;
+  h->stream = own ? h->own_stream : static_cast<hipStream_t>(hip_stream);
   return CB_OK;
 }
 
@@ -351,10 +370,10 @@ static int large_eigh(cb_bank *h) {
   const size_t LL = (size_t)LD * LD;
   hipLaunchKernelGGL(lgj_sigma, dim3(1), dim3(256), 0, h->stream, LD, h->A, h->sigma);
   hipLaunchKernelGGL(lgj_init, dim3((unsigned)((LL + 255) / 256)), dim3(256), 0, h->stream, LD, h->A,
-                     h->sigma, h->Gc, h->Vc);
+                     h->sigma, h->Gc);
   const int nb = LD / JB_W;
   const int RS = LD + ((2 - LD % 32 + 32) % 32);
-  const size_t lds = (size_t)(16 * RS + 3 * 16 * 17 + 16 + 1024) * sizeof(double);
+  const size_t lds = (size_t)(16 * RS + 3 * 16 * 17 + 1024) * sizeof(double);
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(lgj_round),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   const int max_sweeps = 30;
@@ -363,7 +382,7 @@ static int large_eigh(cb_bank *h) {
     HIP_TRY(hipMemsetAsync(h->off_bits, 0, sizeof(unsigned long long), h->stream));
     for (int r = 0; r < nb - 1; ++r)
       hipLaunchKernelGGL(lgj_round, dim3(nb / 2), dim3(JB_THREADS), lds, h->stream, LD, r, h->Gc,
-                         h->Vc, h->off_bits);
+                         h->off_bits);
     unsigned long long bits = 0;
     HIP_TRY(hipMemcpyAsync(&bits, h->off_bits, sizeof bits, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
@@ -377,8 +396,8 @@ static int large_eigh(cb_bank *h) {
   }
   h->last_sweeps = sweep;
   if (sweep >= max_sweeps) return fail(CB_ENUMERIC, "block Jacobi did not converge in %d sweeps", max_sweeps);
-  hipLaunchKernelGGL(lgj_finish, dim3((LD + 3) / 4), dim3(256), 0, h->stream, LD, h->Gc, h->Vc,
-                     h->sigma, h->lam, h->U);
+  hipLaunchKernelGGL(lgj_finish, dim3((LD + 3) / 4), dim3(256), 0, h->stream, LD, h->Gc, h->sigma,
+                     h->lam, h->U, h->Vc);
   HIP_TRY(hipGetLastError());
   return CB_OK;
 }
@@ -391,12 +410,15 @@ static int large_loss_grad(cb_bank *h, const double *Qd, const double *pid, bool
                      Qd, pid, h->A, h->dsq);
   int rc = large_eigh(h);
   if (rc != CB_OK) return rc;
+  mark(h, EV_EIGH);
   hipLaunchKernelGGL(lg_tables, dim3((unsigned)(((size_t)B * LD + 255) / 256)), dim3(256), 0,
                      h->stream, LD, B, h->t, h->lam, h->sigma, h->F, h->E, h->H);
   const int tm = (LD + LG_TM - 1) / LG_TM, tn = (LD + LG_TN - 1) / LG_TN, tiles = tm * tn;
   const double inv_n = normalize ? 1.0 / h->n_host[0] : 1.0;
   K1Args k1{S, LD, B, h->Vc, h->A, h->t, h->F, h->sigma, h->Ct, h->Gt, h->loss_part, inv_n, h->dsq, Pd};
+  mark(h, EV_END);  // (re-used as "before K1" marker)
   hipLaunchKernelGGL(k1_pt_loss_gt, dim3(tiles, B), dim3(LG_THREADS), 0, h->stream, k1);
+  mark(h, EV_K1);
   if (Pd) {
     HIP_TRY(hipGetLastError());
     return CB_OK;
@@ -406,14 +428,17 @@ static int large_loss_grad(cb_bank *h, const double *Qd, const double *pid, bool
   if (dQd) {
     K2Args k2{LD, h->Gt, h->U, h->T};
     hipLaunchKernelGGL(k2_t_eq_g_u, dim3(tiles, B), dim3(LG_THREADS), 0, h->stream, k2);
+    mark(h, EV_K2);
     K3Args k3{LD, B, h->k3_chunk, h->T, h->U, h->t, h->lam, h->E, h->H, h->Mt_part};
     hipLaunchKernelGGL(k3_mt_accum, dim3(tiles, h->k3_nchunks), dim3(LG_THREADS), 0, h->stream, k3);
+    mark(h, EV_K3);
     hipLaunchKernelGGL(k3_reduce, dim3((unsigned)((LL + 255) / 256)), dim3(256), 0, h->stream,
                        h->Mt_part, h->k3_nchunks, LL, h->Mt);
     K4Args k4a{S, LD, h->Mt, h->Vc, h->X, nullptr};
     hipLaunchKernelGGL(k4_gemm, dim3(tiles), dim3(LG_THREADS), 0, h->stream, k4a);
     K4Args k4b{S, LD, h->Vc, h->X, dQd, h->dsq};
     hipLaunchKernelGGL(k4_gemm, dim3(tiles), dim3(LG_THREADS), 0, h->stream, k4b);
+    mark(h, EV_K4);
   }
   HIP_TRY(hipGetLastError());
   return CB_OK;
@@ -444,6 +469,9 @@ extern "C" int cb_loss_grad(cb_handle h, const double *Q, const double *pi, int 
     dQd = dQ ? h->dQ : nullptr;
   }
   int rc;
+  if (h->profile) fold_pending(h);
+  for (bool &b : h->ev_rec) b = false;
+  mark(h, EV_START);
   if (h->large) {
     rc = large_loss_grad(h, Qd, pid, flags & CB_NORMALIZE, lossd, dQd, nullptr);
   } else {
@@ -461,8 +489,10 @@ extern "C" int cb_loss_grad(cb_handle h, const double *Q, const double *pi, int 
     a.dQ = dQd;
     a.status = h->status;
     rc = launch_small<SMALL_LOSSGRAD>(h, a);
+    mark(h, EV_SMALL);
   }
   if (rc != CB_OK) return rc;
+  if (h->profile) h->t_pending = true;
   if (!devp) {
     HIP_TRY(hipMemcpyAsync(loss, h->loss, h->L * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     if (dQ)
@@ -599,4 +629,76 @@ extern "C" int cb_train_siterm(cb_handle h, double *theta, double *Theta, int nu
   (void)h; (void)theta; (void)Theta; (void)num_epochs; (void)lr; (void)flags; (void)res;
   (void)loss_per_epoch_per_site;
   return fail(CB_EUNSUPPORTED, "cb_train_siterm: not built yet");
+}
+
+static int read_phase_times(cb_bank *h, double (&v)[CB_T_COUNT]);
+
+// fold the previous profiled call (its events have normally completed long
+// ago) into the running sums
+static void fold_pending(cb_bank *h) {
+  if (!h->t_pending) return;
+  double v[CB_T_COUNT];
+  if (read_phase_times(h, v) == CB_OK) {
+    for (int i = 0; i < CB_T_COUNT; ++i) h->t_sum[i] += v[i];
+    h->t_calls += 1;
+  }
+  h->t_pending = false;
+}
+
+extern "C" int cb_profile(cb_handle h, int enable) {
+  if (!h) return fail(CB_EINVAL, "cb_profile: NULL handle");
+  h->profile = enable != 0;
+  for (double &x : h->t_sum) x = 0.0;
+  h->t_calls = 0;
+  h->t_pending = false;
+  return CB_OK;
+}
+
+extern "C" int cb_timing_sums(cb_handle h, double *ms_sum, int n, int *calls) {
+  if (!h || !ms_sum || !calls) return fail(CB_EINVAL, "cb_timing_sums: NULL argument");
+  fold_pending(h);
+  for (int i = 0; i < n; ++i) ms_sum[i] = i < CB_T_COUNT ? h->t_sum[i] : 0.0;
+  *calls = h->t_calls;
+  return CB_OK;
+}
+
+extern "C" int cb_last_sweeps(cb_handle h) { return h ? h->last_sweeps : 0; }
+
+extern "C" int cb_last_timings(cb_handle h, double *ms, int n) {
+  if (!h || !ms) return fail(CB_EINVAL, "cb_last_timings: NULL argument");
+  for (int i = 0; i < n; ++i) ms[i] = 0.0;
+  double v[CB_T_COUNT];
+  int rc = read_phase_times(h, v);
+  if (rc != CB_OK) return rc;
+  for (int i = 0; i < n && i < CB_T_COUNT; ++i) ms[i] = v[i];
+  return CB_OK;
+}
+
+static int read_phase_times(cb_bank *h, double (&v)[CB_T_COUNT]) {
+  for (double &x : v) x = 0.0;
+  if (!h->ev_rec[EV_START]) return fail(CB_EINVAL, "cb_last_timings: no profiled call recorded");
+  {
+    int last = EV_START;
+    for (int i = 0; i <= CB_T_COUNT; ++i)
+      if (h->ev_rec[i] && i != EV_END) last = i;
+    HIP_TRY(hipEventSynchronize(h->ev[last]));
+  }
+  auto span = [&](int a, int b) -> double {
+    if (!h->ev_rec[a] || !h->ev_rec[b]) return 0.0;
+    float t = 0.f;
+    if (hipEventElapsedTime(&t, h->ev[a], h->ev[b]) != hipSuccess) return 0.0;
+    return (double)t;
+  };
+  if (h->large) {
+    v[CB_T_EIGH] = span(EV_START, EV_EIGH);
+    v[CB_T_K1] = span(EV_END, EV_K1);
+    v[CB_T_K2] = span(EV_K1, EV_K2);
+    v[CB_T_K3] = span(EV_K2, EV_K3);
+    v[CB_T_K4] = span(EV_K3, EV_K4);
+    v[CB_T_TOTAL] = span(EV_START, h->ev_rec[EV_K4] ? EV_K4 : EV_K1);
+  } else {
+    v[CB_T_SMALL] = span(EV_START, EV_SMALL);
+    v[CB_T_TOTAL] = v[CB_T_SMALL];
+  }
+  return CB_OK;
 }

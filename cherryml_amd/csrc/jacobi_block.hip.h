@@ -1,15 +1,16 @@
 // Block one-sided Jacobi eigensolver for the large path (S > 32, LD <= 1024).
 //
 // Same mathematics as jacobi_wave.hip.h -- Hestenes Jacobi on A' = A - sigma I,
-// G = A' V -- but columns are grouped in blocks of 8.  One workgroup owns a
-// PAIR of blocks (16 columns) per round:
+// columns of G = A' V made mutually orthogonal, V never formed,
+// U = -normalised(G) -- but columns are grouped in blocks of 8.  One workgroup
+// owns a PAIR of blocks (16 columns) per round:
 //   1. stage its 16 columns of G in LDS,
 //   2. Gram matrix  Gamma = G_IJ^T G_IJ  (16x16) with f64 MFMA (the A and B
 //      operand of that product are the same register),
-//   3. wave 0 diagonalises Gamma (Gamma = R diag R^T) with the wave solver;
-//      because A' is well conditioned (kappa <= ~3) forming the Gram matrix
-//      loses nothing,
-//   4. G_IJ <- G_IJ R and V_IJ <- V_IJ R with MFMA (16 = exactly one tile).
+//   3. wave 0 finds the orthogonal R diagonalising Gamma with the wave solver
+//      (because A' is well conditioned, kappa <= ~3, forming the Gram matrix
+//      loses nothing) and polishes R with one Newton-Schulz step,
+//   4. G_IJ <- G_IJ R with MFMA (16 columns = exactly one tile).
 // Block pairs of a round are disjoint (round-robin tournament over the LD/8
 // blocks), so a sweep is LD/8 - 1 launches of LD/16 workgroups.
 #pragma once
@@ -32,27 +33,25 @@ __global__ void lgj_sigma(int LD, const double *A, double *sigma) {
   if (threadIdx.x == 0) *sigma = s[0] > 0.0 ? s[0] : 1.0;
 }
 
-// Gc[k][r] = A[r][k] - sigma (r == k);  Vc = I   (column-major == row-major: A symmetric)
-__global__ void lgj_init(int LD, const double *A, const double *sigma, double *Gc, double *Vc) {
+// Gc[k][r] = A[r][k] - sigma (r == k)   (column-major == row-major: A symmetric)
+__global__ void lgj_init(int LD, const double *A, const double *sigma, double *Gc) {
   const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= (size_t)LD * LD) return;
   const int k = idx / LD, r = idx - (size_t)k * LD;
   Gc[idx] = A[idx] - (r == k ? *sigma : 0.0);
-  Vc[idx] = (r == k) ? 1.0 : 0.0;
 }
 
 __device__ __forceinline__ int jb_rowstride(int LD) { return LD + ((2 - LD % 32 + 32) % 32); }
 
-__global__ __launch_bounds__(JB_THREADS) void lgj_round(int LD, int round, double *Gc, double *Vc,
+__global__ __launch_bounds__(JB_THREADS) void lgj_round(int LD, int round, double *Gc,
                                                         unsigned long long *off_bits) {
   extern __shared__ double lds[];
   const int RS = jb_rowstride(LD);
   double *sG = lds;                 // [16][RS]
-  double *sGam = sG + 16 * RS;      // [16][17]  Gram, also "A" of the wave solver
-  double *sJG = sGam + 16 * 17;     // [16][17]
-  double *sJV = sJG + 16 * 17;      // [16][17]  R: column c' at sJV + c'*17
-  double *sJl = sJV + 16 * 17;      // [16]
-  double *sPart = sJl + 16;         // [4][256] partial Gram per wave
+  double *sGam = sG + 16 * RS;      // [16][17]  Gram -> orthogonalised columns
+  double *sR = sGam + 16 * 17;      // [16][17]  R: column c' at sR + c'*17
+  double *sN = sR + 16 * 17;        // [16][17]  R^T R, then polished R
+  double *sPart = sN + 16 * 17;     // [4][256] partial Gram per wave
 
   const int nb = LD / JB_W;
   int bi, bj;
@@ -95,22 +94,20 @@ __global__ __launch_bounds__(JB_THREADS) void lgj_round(int LD, int round, doubl
     }
     off = wave_max(off);
     if (lane == 0) atomicMax(off_bits, dbl_bits(off));
-    wave_jacobi(16, sGam, sJG, sJV, sJl, 17, 0.0);
-    // One Newton-Schulz step R <- R (3 I - R^T R) / 2: the product of a few
-    // hundred plane rotations is orthogonal only to ~3e-15 and that defect
-    // would add up over the ~400 block rounds of a solve.
+    wave_diagonaliser_spd(16, sGam, sR, 17, CB_JAC_MAX_SWEEPS);
+    // One Newton-Schulz step R <- R (3 I - R^T R) / 2 makes R orthogonal to rounding.
     for (int e = lane; e < 256; e += 64) {
       const int p = e >> 4, q = e & 15;
       double d = 0.0;
-      for (int c = 0; c < 16; ++c) d = fma(sJV[p * 17 + c], sJV[q * 17 + c], d);
-      sJG[p * 17 + q] = d;  // N = R^T R
+      for (int c = 0; c < 16; ++c) d = fma(sR[p * 17 + c], sR[q * 17 + c], d);
+      sGam[p * 17 + q] = d;  // N = R^T R
     }
     wave_lds_fence();
     for (int e = lane; e < 256; e += 64) {
       const int q = e >> 4, c = e & 15;
       double d = 0.0;
-      for (int p = 0; p < 16; ++p) d = fma(sJV[p * 17 + c], sJG[p * 17 + q], d);
-      sGam[q * 17 + c] = 1.5 * sJV[q * 17 + c] - 0.5 * d;  // column q of R'
+      for (int p = 0; p < 16; ++p) d = fma(sR[p * 17 + c], sGam[p * 17 + q], d);
+      sN[q * 17 + c] = 1.5 * sR[q * 17 + c] - 0.5 * d;  // column q of R'
     }
     wave_lds_fence();
   }
@@ -118,39 +115,36 @@ __global__ __launch_bounds__(JB_THREADS) void lgj_round(int LD, int round, doubl
   // 4. apply R:  new^T[c'][r] = sum_c R[c][c'] old^T[c][r]
   double Rf[4];
 #pragma unroll
-  for (int s = 0; s < 4; ++s) Rf[s] = sGam[lo * 17 + 4 * s + hi];  // R[c = 4s+hi][c' = lo]
+  for (int s = 0; s < 4; ++s) Rf[s] = sN[lo * 17 + 4 * s + hi];  // R[c = 4s+hi][c' = lo]
   const int ntiles = LD / 16;
-  for (int job = wave; job < 2 * ntiles; job += 4) {
-    const bool isV = job >= ntiles;
-    const int r0 = (isV ? job - ntiles : job) * 16;
+  for (int job = wave; job < ntiles; job += 4) {
+    const int r0 = job * 16;
     d4 o = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      const int c = 4 * s + hi;
-      const double bv = isV ? Vc[(size_t)gcol(c) * LD + r0 + lo] : sG[c * RS + r0 + lo];
-      o = mfma_f64(Rf[s], bv, o);
-    }
-    double *dst = isV ? Vc : Gc;
+    for (int s = 0; s < 4; ++s) o = mfma_f64(Rf[s], sG[(4 * s + hi) * RS + r0 + lo], o);
 #pragma unroll
-    for (int r = 0; r < 4; ++r) dst[(size_t)gcol(hi + 4 * r) * LD + r0 + lo] = o[r];
+    for (int r = 0; r < 4; ++r) Gc[(size_t)gcol(hi + 4 * r) * LD + r0 + lo] = o[r];
   }
 }
 
-// lam_k = v_k . g_k + sigma ; Ut = Vc (as stored) ; U = Vc^T
-__global__ void lgj_finish(int LD, const double *Gc, const double *Vc, const double *sigma,
-                           double *lam, double *U) {
+// lam_k = sigma - |g_k| ; Ut[k][r] = U[r][k] = -g_k[r] / |g_k|   (A' negative definite)
+__global__ void lgj_finish(int LD, const double *Gc, const double *sigma, double *lam, double *U,
+                           double *Ut) {
   // one wave per column k
   const int k = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   if (k >= LD) return;
-  double d = 0.0, nn = 0.0;
+  double nn = 0.0;
   for (int r = lane; r < LD; r += 64) {
-    const double v = Vc[(size_t)k * LD + r];
-    d = fma(v, Gc[(size_t)k * LD + r], d);
+    const double v = Gc[(size_t)k * LD + r];
     nn = fma(v, v, nn);
+  }
+  nn = wave_sum(nn);
+  const double nrm = sqrt(nn), inv = -1.0 / nrm;
+  for (int r = lane; r < LD; r += 64) {
+    const double v = Gc[(size_t)k * LD + r] * inv;
+    Ut[(size_t)k * LD + r] = v;
     U[(size_t)r * LD + k] = v;
   }
-  d = wave_sum(d);
-  nn = wave_sum(nn);
-  if (lane == 0) lam[k] = d / nn + *sigma;
+  if (lane == 0) lam[k] = *sigma - nrm;
 }

@@ -3,14 +3,18 @@
 // One-sided (Hestenes) Jacobi on the SHIFTED matrix A' = A - sigma I with
 // sigma >= max |A_ii| (> 0): a symmetrised rate matrix is negative
 // semidefinite with a zero eigenvalue, so A' is negative definite with
-// condition number <= ~3, every column of G = A' V keeps a healthy norm and
-// the sweep count is small and predictable.  V accumulates the rotations
-// (orthogonal by construction), on exit
-//     A = V diag(lam) V^T,   lam_k = v_k . g_k + sigma.
+// condition number <= ~3 and every column of G = A' V keeps a healthy norm.
 //
-// Layout: Gc[k*LS + r] / Vc[k*LS + r] hold COLUMN k (component r).
-// Work split: the n/2 disjoint pairs of a round (round-robin tournament) are
-// handled by 4 lanes each (lanes 4p .. 4p+3 take rows sub, sub+4, ...).
+// V is never formed: when the columns of G are mutually orthogonal, V
+// diagonalises A'^2, hence (A' definite) A' itself, so g_k = lambda'_k v_k and
+//     U[:,k] = sign * g_k / |g_k|,   lambda_k = sign * |g_k| + sigma
+// (sign = -1 for a negative definite A', +1 for a positive definite one).
+// The orthogonality of U is then the orthogonality the sweeps converged to,
+// not an accumulated product of rotations.
+//
+// Layout: Gc[k*LS + r] holds COLUMN k (component r).  The n/2 disjoint pairs
+// of a round (round-robin tournament) are handled by 4 lanes each (lanes
+// 4p .. 4p+3 take rows sub, sub+4, ...; at most 8 rows per lane).
 #pragma once
 #include "common.hip.h"
 
@@ -38,44 +42,35 @@ __device__ __forceinline__ void rr_pair(int m, int r, int i, int &p, int &q) {
   }
 }
 
-// Returns the number of sweeps used (CB_JAC_MAX_SWEEPS + 1 if not converged).
-// A (row-major, stride LS) is read only; sigma_shift < 0 means "choose".
-__device__ int wave_jacobi(int n, const double *A, double *Gc, double *Vc, double *lam,
-                           int LS, double sigma_shift) {
+// Orthogonalises the columns of Gc in place.  RPL = rows per lane (ceil(n/4)),
+// a compile-time bound so that the column pieces stay in registers.
+// Returns the number of sweeps used.
+template <int RPL>
+__device__ int wave_jacobi_columns(int n, double *Gc, int LS, int max_sweeps) {
   const int lane = threadIdx.x & 63;
-  // shift
-  double sigma = sigma_shift;
-  if (sigma_shift < 0.0) {
-    double m = 0.0;
-    for (int i = lane; i < n; i += 64) m = fmax(m, fabs(A[i * LS + i]));
-    sigma = wave_max(m);
-    if (!(sigma > 0.0)) sigma = 1.0;
-  }
-  for (int e = lane; e < n * n; e += 64) {
-    const int k = e / n, r = e - k * n;
-    Gc[k * LS + r] = A[r * LS + k] - (r == k ? sigma : 0.0);
-    Vc[k * LS + r] = (r == k) ? 1.0 : 0.0;
-  }
-  wave_lds_fence();
-
   const int m = (n + 1) & ~1;  // even number of players (one dummy when n is odd)
+  const int mm = m - 1;
   const int slot = lane >> 2, sub = lane & 3;
+  const bool active = slot < (m >> 1);
   int sweeps = 0;
-  for (; sweeps < CB_JAC_MAX_SWEEPS; ++sweeps) {
+  for (; sweeps < max_sweeps; ++sweeps) {
     double off = 0.0;
-    for (int r = 0; r < m - 1; ++r) {
-      int p = 0, q = 0;
-      const bool active = slot < (m >> 1);
-      if (active) rr_pair(m, r, slot, p, q);
-      const bool real = active && p < n && q < n;
+    // positions advance by one per round: p = (r + slot) % mm, q = (r - slot) % mm
+    int p = slot % mm, q = (mm - slot) % mm;
+    for (int r = 0; r < mm; ++r) {
+      const int pp = slot == 0 ? mm : p, qq = slot == 0 ? r : q;
+      const bool real = active && pp < n && qq < n;
+      double x[RPL], y[RPL];
       double a = 0.0, b = 0.0, g = 0.0;
-      if (real) {
-        for (int row = sub; row < n; row += 4) {
-          const double x = Gc[p * LS + row], y = Gc[q * LS + row];
-          a = fma(x, x, a);
-          b = fma(y, y, b);
-          g = fma(x, y, g);
-        }
+#pragma unroll
+      for (int i = 0; i < RPL; ++i) {
+        const int row = sub + 4 * i;
+        const bool ok = real && row < n;
+        x[i] = ok ? Gc[pp * LS + row] : 0.0;
+        y[i] = ok ? Gc[qq * LS + row] : 0.0;
+        a = fma(x[i], x[i], a);
+        b = fma(y[i], y[i], b);
+        g = fma(x[i], y[i], g);
       }
       a += __shfl_xor(a, 1, 64);
       b += __shfl_xor(b, 1, 64);
@@ -84,36 +79,104 @@ __device__ int wave_jacobi(int n, const double *A, double *Gc, double *Vc, doubl
       b += __shfl_xor(b, 2, 64);
       g += __shfl_xor(g, 2, 64);
       if (real) {
-        const double denom = sqrt(a * b);
-        const double rel = (denom > 0.0) ? fabs(g) / denom : 0.0;
-        off = fmax(off, rel);
-        if (rel > CB_JAC_SKIP) {
-          const double zeta = (b - a) / (2.0 * g);
-          const double tt = copysign(1.0, zeta) / (fabs(zeta) + sqrt(fma(zeta, zeta, 1.0)));
-          const double c = 1.0 / sqrt(fma(tt, tt, 1.0));
-          const double s = c * tt;
-          for (int row = sub; row < n; row += 4) {
-            const double x = Gc[p * LS + row], y = Gc[q * LS + row];
-            Gc[p * LS + row] = c * x - s * y;
-            Gc[q * LS + row] = s * x + c * y;
-            const double u = Vc[p * LS + row], v = Vc[q * LS + row];
-            Vc[p * LS + row] = c * u - s * v;
-            Vc[q * LS + row] = s * u + c * v;
+        const double ab = a * b;
+        // cosine^2 = g^2 / (a b); compare squares, no sqrt / div on this path
+        const double g2 = g * g;
+        if (g2 > ab * (CB_JAC_STOP * CB_JAC_STOP)) off = 1.0;  // "not converged" flag
+        if (g2 > ab * (CB_JAC_SKIP * CB_JAC_SKIP)) {
+          // tan(theta) = sign(d) 2|g| ... : t = 2 g / (d + sign(d) sqrt(d^2 + 4 g^2)), d = b - a
+          const double d = b - a;
+          const double h = sqrt(fma(d, d, 4.0 * g2));
+          const double den = d + copysign(h, d);
+          const double t = (den != 0.0) ? 2.0 * g / den : 1.0;
+          const double c = rsqrt(fma(t, t, 1.0));
+          const double s = c * t;
+#pragma unroll
+          for (int i = 0; i < RPL; ++i) {
+            const int row = sub + 4 * i;
+            if (row < n) {
+              Gc[pp * LS + row] = c * x[i] - s * y[i];
+              Gc[qq * LS + row] = s * x[i] + c * y[i];
+            }
           }
         }
       }
       wave_lds_fence();
+      p = (p + 1 == mm) ? 0 : p + 1;
+      q = (q + 1 == mm) ? 0 : q + 1;
     }
     off = wave_max(off);
-    if (off <= CB_JAC_STOP) {
+    if (off == 0.0) {
       ++sweeps;
       break;
     }
   }
-  for (int k = lane; k < n; k += 64) {
-    double d = 0.0;
-    for (int r = 0; r < n; ++r) d = fma(Vc[k * LS + r], Gc[k * LS + r], d);
-    lam[k] = d + sigma;
+  return sweeps;
+}
+
+__device__ __forceinline__ int wave_jacobi_columns_n(int n, double *Gc, int LS, int max_sweeps) {
+  if (n <= 4) return wave_jacobi_columns<1>(n, Gc, LS, max_sweeps);
+  if (n <= 8) return wave_jacobi_columns<2>(n, Gc, LS, max_sweeps);
+  if (n <= 16) return wave_jacobi_columns<4>(n, Gc, LS, max_sweeps);
+  if (n <= 20) return wave_jacobi_columns<5>(n, Gc, LS, max_sweeps);
+  if (n <= 24) return wave_jacobi_columns<6>(n, Gc, LS, max_sweeps);
+  return wave_jacobi_columns<8>(n, Gc, LS, max_sweeps);
+}
+
+// Eigendecomposition of a symmetric matrix A (row-major, stride LS, read only)
+// that is negative semidefinite up to rounding (symmetrised rate matrix):
+//   Uc[k*LS + i] = component i of eigenvector k,  lam[k].
+// Gc is scratch (n x LS).  Returns the sweeps used.
+__device__ int wave_eigh_rate(int n, const double *A, double *Gc, double *Uc, double *lam,
+                              int LS) {
+  const int lane = threadIdx.x & 63;
+  double mx = 0.0;
+  for (int i = lane; i < n; i += 64) mx = fmax(mx, fabs(A[i * LS + i]));
+  double sigma = wave_max(mx);
+  if (!(sigma > 0.0)) sigma = 1.0;
+  for (int e = lane; e < n * n; e += 64) {
+    const int k = e / n, r = e - k * n;
+    Gc[k * LS + r] = A[r * LS + k] - (r == k ? sigma : 0.0);
+  }
+  wave_lds_fence();
+  const int sweeps = wave_jacobi_columns_n(n, Gc, LS, CB_JAC_MAX_SWEEPS);
+  // normalise: 4 lanes per column
+  for (int k0 = 0; k0 < n; k0 += 16) {
+    const int k = k0 + (lane >> 2), sub = lane & 3;
+    double nn = 0.0;
+    if (k < n)
+      for (int r = sub; r < n; r += 4) nn = fma(Gc[k * LS + r], Gc[k * LS + r], nn);
+    nn += __shfl_xor(nn, 1, 64);
+    nn += __shfl_xor(nn, 2, 64);
+    if (k < n) {
+      const double nrm = sqrt(nn);
+      const double inv = -1.0 / nrm;  // A' negative definite: g_k = lambda'_k v_k, lambda'_k < 0
+      for (int r = sub; r < n; r += 4) Uc[k * LS + r] = Gc[k * LS + r] * inv;
+      if (sub == 0) lam[k] = sigma - nrm;
+    }
+  }
+  wave_lds_fence();
+  return sweeps;
+}
+
+// Orthogonal R with R^T Gamma R diagonal for a symmetric POSITIVE definite
+// Gamma (n <= 16 used): columns of R at Rc[k*LS + i].  Gamma is destroyed
+// (used as the column array).  At most `max_sweeps` sweeps: the caller iterates.
+__device__ int wave_diagonaliser_spd(int n, double *Gam, double *Rc, int LS, int max_sweeps) {
+  const int lane = threadIdx.x & 63;
+  // columns of Gamma = rows of Gamma (symmetric): Gam[k*LS + r] is already column k
+  const int sweeps = wave_jacobi_columns_n(n, Gam, LS, max_sweeps);
+  for (int k0 = 0; k0 < n; k0 += 16) {
+    const int k = k0 + (lane >> 2), sub = lane & 3;
+    double nn = 0.0;
+    if (k < n)
+      for (int r = sub; r < n; r += 4) nn = fma(Gam[k * LS + r], Gam[k * LS + r], nn);
+    nn += __shfl_xor(nn, 1, 64);
+    nn += __shfl_xor(nn, 2, 64);
+    if (k < n) {
+      const double inv = rsqrt(nn);
+      for (int r = sub; r < n; r += 4) Rc[k * LS + r] = Gam[k * LS + r] * inv;
+    }
   }
   wave_lds_fence();
   return sweeps;

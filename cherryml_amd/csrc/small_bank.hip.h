@@ -254,7 +254,7 @@ __global__ __launch_bounds__(NW * 64) void small_bank_kernel(SmallArgs a) {
     small_build_A(S, a.Q + (size_t)l * S * S, a.pi + (size_t)l * S, sA, sD);
   }
   if (wave == 0) {
-    const int sweeps = wave_jacobi(S, sA, sG, sV, sLam, CB_LS, -1.0);
+    const int sweeps = wave_eigh_rate(S, sA, sG, sV, sLam, CB_LS);
     if (lane == 0 && a.status) a.status[l] = sweeps;
   }
   __syncthreads();

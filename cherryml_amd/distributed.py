@@ -1,0 +1,73 @@
+"""One process per GPU: the bank's buckets are dealt round-robin to the ranks
+(bucket b -> rank b mod world), every rank evaluates the partial loss and
+partial dL/dQ of its own buckets, and ONE all-reduce (RCCL over xGMI with the
+"nccl" backend; gloo in the CPU tests) of S*S + 1 float64 values per epoch sums
+them (option 1).  The parameters and the optimiser are
+replicated: identical inputs -> identical Adam steps, no broadcast needed.
+Counts (C) never cross GPUs during the epochs."""
+from typing import Callable, Optional
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+
+def bucket_shard(num_buckets: int, rank: int, world: int) -> np.ndarray:
+    """Indices of the buckets owned by `rank`."""
+    return np.arange(rank, num_buckets, world)
+
+
+class _ShardedLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, Q, pi, evaluate, inv_n, group):
+        loss, dQ = evaluate(Q.detach(), pi.detach())  # unnormalised partial sums
+        packed = torch.cat([loss.reshape(-1), dQ.reshape(-1)]).to(torch.float64)
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+            dist.all_reduce(packed, op=dist.ReduceOp.SUM, group=group)
+        packed = packed * inv_n
+        nl = loss.numel()
+        ctx.save_for_backward(packed[nl:].reshape(Q.shape))
+        return packed[:nl].reshape(loss.shape).to(Q.dtype)
+
+    @staticmethod
+    def backward(ctx, grad_loss):
+        (dQ,) = ctx.saved_tensors
+        return (dQ * grad_loss.reshape(-1, 1, 1)).reshape(dQ.shape), None, None, None, None
+
+
+class ShardedBank:
+    """A bank whose buckets are spread over the ranks of a process group.
+
+    `make_bank(t_local, C_local)` builds the local evaluator (a CherryBank on
+    this rank's GPU; the CPU tests inject an oracle-backed stand-in with the
+    same `loss_grad_torch` method)."""
+
+    def __init__(self, t, C, make_bank: Optional[Callable] = None, group=None):
+        t = np.asarray(t, dtype=np.float64).reshape(-1)
+        C = np.asarray(C, dtype=np.float64)
+        if C.ndim != 3:
+            raise ValueError("ShardedBank shards the buckets of a single (L = 1) bank: C must be [B,S,S]")
+        self.group = group
+        on = dist.is_available() and dist.is_initialized()
+        self.rank = dist.get_rank(group) if on else 0
+        self.world = dist.get_world_size(group) if on else 1
+        mine = bucket_shard(C.shape[0], self.rank, self.world)
+        if mine.size == 0:
+            raise ValueError(f"rank {self.rank} owns no bucket (B={C.shape[0]} < world={self.world})")
+        self.total_count = float(C.sum())  # every rank sees the full host array here
+        self.local_buckets = mine
+        if make_bank is None:
+            from .bank import CherryBank
+            dev = torch.cuda.current_device()
+            make_bank = lambda tt, CC: CherryBank(tt, CC, device=dev)  # noqa: E731
+        self.bank = make_bank(t[mine], C[mine])
+
+    def loss(self, Q: torch.Tensor, pi: torch.Tensor, normalize: bool = True) -> torch.Tensor:
+        """Differentiable (in Q) loss of the WHOLE bank; every rank gets the same value."""
+        ev = lambda q, p: self.bank.loss_grad_torch(q, p, normalize=False, want_grad=True)  # noqa: E731
+        inv_n = 1.0 / self.total_count if normalize else 1.0
+        return _ShardedLoss.apply(Q, pi, ev, inv_n, self.group)
+
+    def close(self):
+        if hasattr(self.bank, "close"):
+            self.bank.close()

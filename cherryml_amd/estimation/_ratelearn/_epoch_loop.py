@@ -1,0 +1,93 @@
+"""The optimiser's epoch loop (reference: cherryml/estimation/_ratelearn/
+trainer.py:118-243, `train_quantization`) with the expm bank, log-likelihood
+contraction and gradient evaluated by libcherrybank on the MI355X.
+
+What changes with respect to the reference, and nothing else:
+  * (t, C) are uploaded ONCE into a CherryBank (the reference re-sends them
+    every epoch, trainer.py:164-167);
+  * trainer.py:170-177 + the matrix_exp part of `loss.backward()` become one
+    call `bank_loss(Q, pi, bank)` (HIP); the parameterisation and the optimiser
+    step stay torch;
+  * arithmetic is float64.
+"""
+import logging
+import time
+from typing import Dict, Optional, Tuple
+
+import numpy as np
+import pandas as pd
+import torch
+
+from ..._autograd import bank_loss
+from ...bank import CherryBank
+
+
+def _snapshot(Q: torch.Tensor) -> np.ndarray:
+    return Q.detach().cpu().numpy().copy()
+
+
+def train_quantization(rate_module, quantized_dataset, m=1.0, lr=1e-1, num_epochs=2000,
+                       Q_true=None, optimizer=None, loss_normalization: bool = True,
+                       return_best_iter: bool = True,
+                       bank: Optional[CherryBank] = None) -> Tuple[pd.DataFrame, Dict]:
+    """Full-batch optimisation of `rate_module` on a TensorDataset(qtimes, cmats).
+
+    Returns (df_res, Q_dict) exactly like the reference: per-epoch rows
+    (nuc_norm, frob_norm, loss, time, epoch, frob_norm_diag, frob_norm_offdiag)
+    and Q at epochs 1,2,4,..., "Q_best", "Q_last", "result".
+    """
+    logger = logging.getLogger(__name__)
+    params = [p for p in rate_module.parameters()]
+    device = params[0].device
+    if device.type != "cuda":
+        raise RuntimeError("cherryml_amd.train_quantization runs on the MI355X only: move the "
+                           "rate module to device='cuda' (there is no CPU fallback)")
+    if not rate_module.is_reversible():
+        raise NotImplementedError(
+            f"mode={rate_module.mode!r} with this mask gives a non-reversible Q; the general "
+            "(scaling-and-squaring) HIP path is not built yet")
+    if optimizer is None:
+        optimizer = torch.optim.SGD(rate_module.parameters(), lr=lr, momentum=0.0, weight_decay=0)
+    own_bank = bank is None
+    if own_bank:
+        qtimes, cmats = quantized_dataset.tensors
+        bank = CherryBank(qtimes.detach().cpu().numpy().astype(np.float64),
+                          cmats.detach().cpu().numpy().astype(np.float64),
+                          device=device.index or 0)
+    logger.info(f"Training for {num_epochs} epochs")
+    Q_dict: Dict[str, np.ndarray] = {}
+    rows = []
+    best_loss, Q_best, Q = None, None, None
+    start = time.time()
+    try:
+        for epoch in range(num_epochs):
+            optimizer.zero_grad()
+            Q = rate_module()
+            loss = bank_loss(Q, rate_module.stationary(), bank, normalize=loss_normalization)[0]
+            if m != 1.0:
+                loss = loss / m
+            loss_value = float(loss.item())
+            if best_loss is None or loss_value < best_loss:  # strict <, Q before the step
+                best_loss, Q_best = loss_value, _snapshot(Q)
+            if (epoch & (epoch + 1)) == 0:
+                Q_dict[f"Q_{epoch + 1}"] = _snapshot(Q)
+            loss.backward()
+            optimizer.step()
+            frob = frob_d = frob_o = nuc = 0.0
+            if Q_true is not None:
+                dif = (Q.detach() - torch.as_tensor(Q_true, device=Q.device, dtype=Q.dtype)) ** 2
+                frob = float(torch.sqrt(dif.sum()))
+                frob_d = float(torch.sqrt(dif.diag().sum()))
+                frob_o = float(torch.sqrt((dif - torch.diag(dif.diag())).sum()))
+            rows.append((nuc, frob, loss_value, time.time() - start, epoch, frob_d, frob_o))
+    finally:
+        if own_bank:
+            bank.close()
+    df_res = pd.DataFrame(rows, columns=["nuc_norm", "frob_norm", "loss", "time", "epoch",
+                                         "frob_norm_diag", "frob_norm_offdiag"])
+    logger.info(f"Total time = {time.time() - start}")
+    if num_epochs > 0:
+        Q_dict["Q_best"] = Q_best.copy()
+        Q_dict["Q_last"] = _snapshot(Q)
+        Q_dict["result"] = Q_best.copy() if return_best_iter else _snapshot(Q)
+    return df_res, Q_dict

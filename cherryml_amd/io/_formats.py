@@ -1,0 +1,113 @@
+"""Readers / writers of the count-matrix and rate-matrix text files.
+
+File grammar (reference: cherryml/io/_count_matrices.py:8-81):
+    "<B> matrices\\n<S> states\\n" then, B times:
+    "<q>\\n" "<state names, whitespace separated (leading blank)>\\n"
+    S rows "<state> v_1 ... v_S" (tab or space separated).
+Rate / mask / probability files are whitespace tables with a header row of
+state names and the state name as first column (cherryml/io/_rate_matrix.py).
+
+The parsers tokenise with numpy instead of per-line Python loops: the
+co-evolution count file is ~80 MB of text.
+"""
+import os
+from typing import List, Tuple
+
+import numpy as np
+import pandas as pd
+
+
+def read_count_matrices_arrays(path: str) -> Tuple[np.ndarray, np.ndarray, List[str]]:
+    """-> (q[B], C[B,S,S], states) as float64 arrays."""
+    with open(path, "r") as f:
+        head1 = f.readline().strip().split(" ")
+        head2 = f.readline().strip().split(" ")
+        body = f.read()
+    if len(head1) != 2 or head1[1] != "matrices":
+        raise Exception(f"In file {path}, expected line '[num_matrices] matrices', "
+                        f"but found: '{' '.join(head1)}'")
+    if len(head2) != 2 or head2[1] != "states":
+        raise Exception(f"In file {path}, expected line '[num_states] states', "
+                        f"but found: '{' '.join(head2)}'")
+    B, S = int(head1[0]), int(head2[0])
+    tok = body.split()
+    per = 1 + S + S * (S + 1)
+    if len(tok) != B * per:
+        raise Exception(f"Error reading count matrices file: {path}\nExpected {B} blocks of "
+                        f"{S} states ({B * per} tokens), found {len(tok)} tokens")
+    tok = np.asarray(tok, dtype=object).reshape(B, per)
+    states = [str(s) for s in tok[0, 1:1 + S]]
+    q = tok[:, 0].astype(np.float64)
+    grid = tok[:, 1 + S:].reshape(B, S, S + 1)
+    for b in range(B):
+        if list(tok[b, 1:1 + S]) != states or list(grid[b, :, 0]) != states:
+            raise Exception(f"Error reading count matrices file: {path}: state labels of "
+                            f"matrix {b} differ from the first matrix")
+    C = grid[:, :, 1:].astype(np.float64)
+    return q, C, states
+
+
+def read_count_matrices(path: str) -> List[Tuple[float, pd.DataFrame]]:
+    """Same return type as the reference: list of (q, DataFrame S x S)."""
+    q, C, states = read_count_matrices_arrays(path)
+    return [(float(q[b]), pd.DataFrame(C[b], index=states, columns=states))
+            for b in range(len(q))]
+
+
+def write_count_matrices(count_matrices: List[Tuple[float, pd.DataFrame]], path: str) -> None:
+    d = os.path.dirname(path)
+    if d != "" and not os.path.exists(d):
+        os.makedirs(d)
+    B = len(count_matrices)
+    S = len(count_matrices[0][1])
+    with open(path, "w") as out:
+        out.write(f"{B} matrices\n{S} states\n")
+        for q, m in count_matrices:
+            out.write(f"{q}\n")
+            cols = [str(c) for c in m.columns]
+            out.write("\t" + "\t".join(cols) + "\n")
+            vals = m.to_numpy()
+            for name, row in zip(m.index, vals):
+                out.write(str(name) + "\t" + "\t".join(repr(float(v)) for v in row) + "\n")
+
+
+def _read_table(path: str) -> pd.DataFrame:
+    return pd.read_csv(path, sep=r"\s+", index_col=0, keep_default_na=False, na_values=["_"],
+                       float_precision="round_trip")
+
+
+def read_rate_matrix(path: str) -> pd.DataFrame:
+    return _read_table(path).astype(float)
+
+
+def read_mask_matrix(path: str) -> pd.DataFrame:
+    return _read_table(path).astype(int)
+
+
+def read_probability_distribution(path: str) -> pd.DataFrame:
+    res = _read_table(path).astype(float)
+    if res.shape[1] != 1:
+        raise Exception(f"Probability distribution at {path} should be one-dimensional.")
+    if abs(res.sum().sum() - 1.0) > 1e-6:
+        raise Exception(f"Probability distribution at {path} should add to 1.0, "
+                        "with a tolerance of 1e-6.")
+    return res
+
+
+def write_rate_matrix(rate_matrix: np.ndarray, states: List[str], path: str) -> None:
+    d = os.path.dirname(path)
+    if d != "" and not os.path.exists(d):
+        os.makedirs(d)
+    pd.DataFrame(rate_matrix, index=states, columns=states).to_csv(path, sep="\t", index=True)
+
+
+def write_probability_distribution(p: np.ndarray, states: List[str], path: str) -> None:
+    d = os.path.dirname(path)
+    if d != "" and not os.path.exists(d):
+        os.makedirs(d)
+    if len(states) != p.shape[0]:
+        raise Exception(f"probability_distribution has shape {p.shape}, "
+                        f"inconsistent with states: {states}")
+    df = pd.DataFrame(np.asarray(p).reshape(-1), index=states, columns=["prob"])
+    df.index.name = "state"
+    df.to_csv(path, sep="\t", index=True)

@@ -71,9 +71,10 @@ int cb_create(int device, int S, int L, int B, const double *t, const double *C,
 
 void cb_destroy(cb_handle h);
 
-/* Run all work of this handle on `hip_stream` (a hipStream_t, e.g. torch's
- * current stream) instead of the handle's own stream.  NULL restores it. */
-int cb_set_stream(cb_handle h, void *hip_stream);
+/* own == 0: run all work of this handle on `hip_stream` (a hipStream_t, e.g.
+ * torch's current stream; NULL is HIP's default stream, which is what torch
+ * uses unless told otherwise).  own != 0: back to the handle's own stream. */
+int cb_set_stream(cb_handle h, void *hip_stream, int own);
 
 /* Total count n_l = sum(C[l]) per site, n[L] (host pointer). */
 int cb_total_counts(cb_handle h, double *n);
@@ -110,6 +111,30 @@ int cb_expm_bank(cb_handle h, const double *Q, const double *pi, int flags,
 /* Debug: symmetric eigendecomposition used by the bank, A[L*S*S] ->
  * lam[L*S], U[L*S*S] (columns are eigenvectors), by the device Jacobi solver. */
 int cb_eigh(cb_handle h, const double *A, int flags, double *lam, double *U);
+
+/*
+ * Live per-phase timing with HIP events on the handle's stream (for bench.py's
+ * roofline figure).  cb_profile(h, 1) makes every following cb_loss_grad record
+ * events around its phases; cb_last_timings() waits for them and returns the
+ * milliseconds of the last call: ms[CB_T_*], n = number of slots provided.
+ */
+enum {
+  CB_T_TOTAL = 0,   /* whole call                                   */
+  CB_T_EIGH = 1,    /* symmetrise + eigendecomposition              */
+  CB_T_K1 = 2,      /* large path: Pt / loss / Gt kernel (one launch) */
+  CB_T_K2 = 3,      /* large path: T = Gt U (one launch)            */
+  CB_T_K3 = 4,      /* large path: Mt accumulation (one launch)     */
+  CB_T_K4 = 5,      /* large path: reduce + back-rotation           */
+  CB_T_SMALL = 6,   /* small path: the fused per-site kernel (one launch) */
+  CB_T_COUNT = 7
+};
+int cb_profile(cb_handle h, int enable);
+int cb_last_timings(cb_handle h, double *ms, int n);
+/* Sums over all profiled cb_loss_grad calls since cb_profile(h, 1) was last
+ * called: ms_sum[CB_T_*] and the number of calls (averages = sum / calls). */
+int cb_timing_sums(cb_handle h, double *ms_sum, int n, int *calls);
+/* sweeps used by the last large-path eigendecomposition */
+int cb_last_sweeps(cb_handle h);
 
 /*
  * Fused optimiser for the reference's `pande_reversible` parameterisation

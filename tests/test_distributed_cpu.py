@@ -1,0 +1,90 @@
+"""world_size-2 gloo test of the bucket-sharded bank (cherryml_amd/distributed.py).
+The local evaluator is an oracle-backed stand-in with the CherryBank interface
+(tests may use the oracle as the checker); what is under test is the sharding,
+the all-reduce and the autograd plumbing."""
+import os
+import socket
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import load_golden, relerr
+
+
+class OracleBank:
+    """CherryBank look-alike on the CPU: unnormalised loss and dL/dQ of its buckets."""
+
+    def __init__(self, t, C):
+        self.t = torch.tensor(np.asarray(t))
+        self.C = torch.tensor(np.asarray(C))
+
+    def loss_grad_torch(self, Q, pi, normalize=False, want_grad=True):
+        from oracle import ratelearn_oracle as orc
+        with torch.enable_grad():  # called from inside an autograd.Function.forward
+            q = Q.detach().reshape(Q.shape[-2:]).clone().requires_grad_(True)
+            loss = orc.bank_loss(q, self.t, self.C, normalize=normalize)
+            loss.backward()
+        return loss.detach().reshape(1), q.grad.reshape(1, *q.shape)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _worker(rank, world, port, out):
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, here)
+    sys.path.insert(0, os.path.dirname(here))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from cherryml_amd.distributed import ShardedBank, bucket_shard
+    from cherryml_amd.estimation._ratelearn._rate_matrix import RateMatrix
+    g = load_golden("traj_lgbank.npz")
+    t, C = g["t"][::8], g["C"][::8]  # 17 buckets
+    sb = ShardedBank(t, C, make_bank=lambda tt, CC: OracleBank(tt, CC))
+    assert list(sb.local_buckets) == list(bucket_shard(len(t), rank, world))
+    torch.manual_seed(0)
+    mod = RateMatrix(num_states=20, mode="pande_reversible", mask=torch.ones(20, 20),
+                     pi=torch.ones(20, dtype=torch.float64) / 20, pi_requires_grad=True,
+                     initialization=g["init"])
+    opt = torch.optim.Adam(mod.parameters(), lr=0.1)
+    losses = []
+    for _ in range(3):
+        opt.zero_grad()
+        loss = sb.loss(mod(), mod.stationary(), normalize=True)[0]
+        loss.backward()
+        opt.step()
+        losses.append(loss.item())
+    torch.save(dict(losses=losses, Q=mod().detach()), os.path.join(out, f"r{rank}.pt"))
+    dist.destroy_process_group()
+
+
+def test_sharded_bank_two_ranks_matches_single(tmp_path):
+    from oracle import ratelearn_oracle as orc
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0 = torch.load(os.path.join(tmp_path, "r0.pt"))
+    r1 = torch.load(os.path.join(tmp_path, "r1.pt"))
+    g = load_golden("traj_lgbank.npz")
+    ref = orc.train(g["t"][::8], g["C"][::8], None, initialization=g["init"], num_epochs=4)
+    # both ranks hold the same replica and it equals the unsharded optimisation
+    assert r0["losses"] == r1["losses"]
+    assert torch.equal(r0["Q"], r1["Q"])
+    assert np.allclose(r0["losses"], ref["loss"][:3], rtol=1e-12, atol=0)
+    assert relerr(r0["Q"].numpy(), ref["Q_4"]) < 1e-11
+
+
+def test_bucket_shard_partition():
+    from cherryml_amd.distributed import bucket_shard
+    for world in (1, 2, 3, 8):
+        parts = [bucket_shard(129, r, world) for r in range(world)]
+        assert sorted(np.concatenate(parts)) == list(range(129))
+        assert max(len(p) for p in parts) - min(len(p) for p in parts) <= 1

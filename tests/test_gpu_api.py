@@ -1,0 +1,150 @@
+"""End-to-end parity of the mirrored Python API on the MI355X against the
+reference's outputs (golden trajectories, f64 recipe) and the oracle."""
+import os
+
+import numpy as np
+import pandas as pd
+import pytest
+import torch
+
+from conftest import load_golden, relerr
+
+pytestmark = pytest.mark.gpu
+
+
+def _write_inputs(tmp_path, g, states, with_init=True):
+    from cherryml_amd.io import write_count_matrices, write_rate_matrix
+    cpath = str(tmp_path / "counts.txt")
+    write_count_matrices([(float(t), pd.DataFrame(C, index=states, columns=states))
+                          for t, C in zip(g["t"], g["C"])], cpath)
+    ipath = None
+    if with_init and "init" in g:
+        ipath = str(tmp_path / "init.txt")
+        write_rate_matrix(g["init"], states, ipath)
+    mpath = None
+    if "mask" in g and not np.all(g["mask"] == 1):
+        mpath = str(tmp_path / "mask.txt")
+        pd.DataFrame(g["mask"].astype(int), index=states, columns=states).to_csv(mpath, sep=" ")
+    return cpath, ipath, mpath
+
+
+@pytest.mark.parametrize("case,states", [("toy3_init", list("ABC")), ("toy3_mask", list("ABC"))])
+def test_stage_function_matches_reference_trajectory(case, states, tmp_path):
+    """quantized_transitions_mle (files in, files out) vs the reference's f64 recipe."""
+    import cherryml_amd
+    from cherryml_amd.io import read_rate_matrix
+    e = load_golden(f"eval_{case}.npz")
+    g = load_golden(f"traj_{case}.npz")
+    cpath, ipath, mpath = _write_inputs(tmp_path, e, states)
+    out = str(tmp_path / "out")
+    ret = cherryml_amd.quantized_transitions_mle(
+        count_matrices_path=cpath, initialization_path=ipath, mask_path=mpath,
+        output_rate_matrix_dir=out, stationary_distribution_path=None,
+        rate_matrix_parameterization="pande_reversible", device="cuda", learning_rate=1e-1,
+        num_epochs=int(g["num_epochs"]), do_adam=True)
+    assert ret is None  # no cache dir set: straight call, like the reference
+    have = set(os.listdir(out))
+    assert {str(f) for f in g["files"]} - {"training_plot.png"} <= have
+    df = pd.read_csv(os.path.join(out, "df_res.txt"))
+    assert np.allclose(df.loss.to_numpy(), g["loss_f64"], rtol=1e-9, atol=0)
+    for key in ["Q_best", "Q_last", "Q_1", "Q_2"]:
+        got = read_rate_matrix(os.path.join(out, key + ".txt")).to_numpy()
+        assert relerr(got, g[key + "_f64"]) < 1e-6, key
+    res = read_rate_matrix(os.path.join(out, "result.txt")).to_numpy()
+    assert relerr(res, g["Q_best_f64"]) < 1e-6
+    # distance to the reference exactly as a user runs it (float32 expm): reported bound
+    assert relerr(res, g["result_f32"]) < 1e-3
+    # mask pattern is respected (reference test_smoke_toy_matrix_mask)
+    assert np.all((res != 0) == (e["mask"] != 0))
+    prof = open(os.path.join(out, "profiling.txt")).read().split()
+    assert prof[:2] == ["Total", "time:"] and float(prof[2]) > 0
+
+
+def test_mask_incompatible_init_raises(tmp_path):
+    import cherryml_amd
+    e = dict(load_golden("eval_toy3_init.npz"))
+    e["mask"] = load_golden("eval_toy3_mask.npz")["mask"]
+    cpath, ipath, mpath = _write_inputs(tmp_path, e, list("ABC"))
+    with pytest.raises(ValueError):
+        cherryml_amd.quantized_transitions_mle(
+            count_matrices_path=cpath, initialization_path=ipath, mask_path=mpath,
+            output_rate_matrix_dir=str(tmp_path / "o"), device="cuda", num_epochs=3)
+
+
+def test_learner_class_lg_bank_100_epochs():
+    """RateMatrixLearner in memory (the SiteRM entry, _site_specific_rate_matrix.py:64-83)
+    on a 129-bucket LG-shaped bank: 1e-6 bar on Q vs the reference's f64 recipe."""
+    from cherryml_amd import RateMatrixLearner
+    g = load_golden("traj_lgbank.npz")
+    states = [str(s) for s in load_golden("data_lg.npz")["states"]]
+    learner = RateMatrixLearner(
+        branches=list(g["t"]), mats=list(g["C"]), states=states, output_dir=None,
+        stationnary_distribution=None, device="cuda", mask=None,
+        rate_matrix_parameterization="pande_reversible", initialization=g["init"],
+        skip_writing_to_output_dir=True)
+    with pytest.raises(ValueError):
+        learner.get_learnt_rate_matrix()
+    learner.train(lr=0.1, num_epochs=int(g["num_epochs"]), do_adam=True, loss_normalization=True,
+                  return_best_iter=True)
+    assert np.allclose(learner.df_res.loss.to_numpy(), g["loss_f64"], rtol=1e-9, atol=0)
+    Q = learner.get_learnt_rate_matrix()
+    assert list(Q.index) == states
+    assert relerr(Q.to_numpy(), g["Q_best_f64"]) < 1e-6
+    assert relerr(learner.Q_dict["Q_last"], g["Q_last_f64"]) < 1e-6
+    # reported: distance to the as-is float32 reference
+    print("dist to f32 reference Q_best:", relerr(Q.to_numpy(), g["Q_best_f32"]))
+
+
+def test_random_init_symmetric_mask_20_states():
+    """No initialisation: seed-0 randn parameters, 20x20 symmetric mask, 50 epochs."""
+    from cherryml_amd import RateMatrixLearner
+    e = load_golden("eval_s20_symmask.npz")
+    g = load_golden("traj_s20_symmask.npz")
+    states = [str(s) for s in load_golden("data_lg.npz")["states"]]
+    import tempfile
+    with tempfile.TemporaryDirectory() as d:
+        mpath = os.path.join(d, "m.txt")
+        np.savetxt(mpath, e["mask"], fmt="%d")
+        learner = RateMatrixLearner(
+            branches=list(e["t"]), mats=list(e["C"]), states=states, output_dir=None,
+            stationnary_distribution=None, device="cuda", mask=mpath,
+            initialization=None, skip_writing_to_output_dir=True)
+        learner.train(lr=0.1, num_epochs=int(g["num_epochs"]), do_adam=True,
+                      loss_normalization=True)
+    assert np.allclose(learner.df_res.loss.to_numpy(), g["loss_f64"], rtol=1e-8, atol=0)
+    assert relerr(learner.Q_dict["Q_best"], g["Q_best_f64"]) < 1e-6
+
+
+def test_coevolution_400_states_three_epochs():
+    from cherryml_amd import RateMatrix, train_quantization
+    from torch.utils.data import TensorDataset
+    e = load_golden("eval_s400_mask.npz")
+    g = load_golden("traj_s400_mask.npz")
+    mod = RateMatrix(num_states=400, mode="pande_reversible", mask=torch.tensor(e["mask"]),
+                     pi=torch.ones(400, dtype=torch.float64) / 400, pi_requires_grad=True)
+    with torch.no_grad():
+        mod.upper_diag.copy_(torch.tensor(g["upper_diag0_f64"]))
+        mod._pi.copy_(torch.tensor(g["log_pi0_f64"]))
+    mod = mod.to("cuda")
+    opt = torch.optim.Adam(mod.parameters(), lr=0.1)
+    ds = TensorDataset(torch.tensor(e["t"]), torch.tensor(e["C"]))
+    df, Qd = train_quantization(mod, ds, num_epochs=3, optimizer=opt, loss_normalization=True)
+    assert np.allclose(df.loss.to_numpy(), g["loss_f64"], rtol=1e-10, atol=0)
+    assert relerr(Qd["Q_best"], g["Q_best_f64"]) < 1e-8
+    assert relerr(Qd["Q_last"], g["Q_last_f64"]) < 1e-8
+
+
+def test_siterm_vectorized_matches_reference():
+    from cherryml_amd import quantized_transitions_mle_vectorized_over_sites as qvec
+    for name in ["siterm_dna.npz", "siterm_aa.npz"]:
+        g = load_golden(name)
+        E = g["lpe_init"].shape[0]
+        r = qvec(g["counts"], g["times"], num_epochs=E, initialization=g["init"], device="cuda")
+        assert np.allclose(r["loss_per_epoch_per_site"], g["lpeps_init"], rtol=1e-8, atol=0)
+        assert np.allclose(r["loss_per_epoch"], g["lpe_init"], rtol=1e-8, atol=0)
+        assert relerr(r["res"], g["res_init"]) < 1e-6
+    # no initialisation: the reference's parameters are float32 there, ours float64
+    g = load_golden("siterm_dna.npz")
+    r = qvec(g["counts"], g["times"], num_epochs=g["lpe_rand"].shape[0], device="cuda")
+    assert np.allclose(r["loss_per_epoch_per_site"], g["lpeps_rand"], rtol=1e-4, atol=0)
+    assert relerr(r["res"], g["res_rand"]) < 1e-3

@@ -1,0 +1,187 @@
+"""CPU-side tests: wire formats, caching convention, parameterisation mirror
+vs the oracle, C-ABI symbol table, loud failure without a GPU."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pandas as pd
+import pytest
+import torch
+
+from conftest import ROOT, load_golden, relerr
+from oracle import ratelearn_oracle as orc
+
+import cherryml_amd
+from cherryml_amd import _lib, caching
+from cherryml_amd.estimation._ratelearn._rate_matrix import RateMatrix
+from cherryml_amd.io import (read_count_matrices, read_count_matrices_arrays, read_mask_matrix,
+                             read_rate_matrix, write_count_matrices, write_rate_matrix)
+
+
+def test_library_exports_every_declared_symbol():
+    header = open(os.path.join(ROOT, "include", "cherrybank.h")).read()
+    declared = set(re.findall(r"\b(cb_[a-z_0-9]+)\s*\(", header))
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    lib = ctypes.CDLL(os.path.join(ROOT, "cherryml_amd", "libcherrybank.so"))
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert _lib.load().cb_version() >= 1
+
+
+def test_no_gpu_means_loud_failure_not_fallback():
+    if _lib.load().cb_device_count() > 0:
+        pytest.skip("a GPU is present")
+    with pytest.raises(_lib.CherryBankError):
+        cherryml_amd.CherryBank(np.ones(2), np.ones((2, 3, 3)))
+
+
+def test_device_cpu_is_refused(tmp_path):
+    g = load_golden("eval_toy3_init.npz")
+    states = list("ABC")
+    cpath = str(tmp_path / "c.txt")
+    write_count_matrices([(float(t), pd.DataFrame(C, index=states, columns=states))
+                          for t, C in zip(g["t"], g["C"])], cpath)
+    with pytest.raises(NotImplementedError):
+        cherryml_amd.quantized_transitions_mle(
+            count_matrices_path=cpath, initialization_path=None, mask_path=None,
+            output_rate_matrix_dir=str(tmp_path / "out"), device="cpu", num_epochs=1)
+    with pytest.raises(NotImplementedError):
+        cherryml_amd.quantized_transitions_mle_vectorized_over_sites(
+            np.ones((1, 1, 4, 4)), np.ones((1, 1)), 1, device="cpu")
+
+
+def test_positional_arguments_refused():
+    with pytest.raises(caching.CacheUsageError):
+        cherryml_amd.quantized_transitions_mle("a", None, None, "out")
+
+
+def test_cached_computation_convention(tmp_path):
+    calls = []
+
+    @caching.cached_computation(output_dirs=["out_dir"], exclude_args=["device"])
+    def stage(x: int, out_dir=None, device="cpu"):
+        calls.append(x)
+        open(os.path.join(out_dir, "result.txt"), "w").write(str(x))
+
+    caching.set_cache_dir(str(tmp_path))
+    try:
+        r1 = stage(x=1)
+        r2 = stage(x=1, device="cuda")  # excluded from the key -> cache hit
+        r3 = stage(x=2)
+    finally:
+        caching.set_cache_dir(None)
+    assert calls == [1, 2]
+    assert r1 == r2 and r1 != r3
+    assert os.path.exists(os.path.join(r1["out_dir"], "result.success"))
+    assert open(os.path.join(r3["out_dir"], "result.txt")).read() == "2"
+
+
+def test_count_matrix_roundtrip_and_reference_format(tmp_path):
+    g = load_golden("eval_s20_mask.npz")
+    states = [str(s) for s in load_golden("data_lg.npz")["states"]]
+    path = str(tmp_path / "counts.txt")
+    mats = [(float(t), pd.DataFrame(C, index=states, columns=states))
+            for t, C in zip(g["t"], g["C"])]
+    write_count_matrices(mats, path)
+    q, C, st = read_count_matrices_arrays(path)
+    assert st == states and np.array_equal(q, g["t"]) and np.array_equal(C, g["C"])
+    back = read_count_matrices(path)
+    assert back[1][0] == g["t"][1] and np.array_equal(back[1][1].to_numpy(), g["C"][1])
+    # space separated variant with a leading blank header, as the reference's test files
+    lines = open(path).read().replace("\t", " ")
+    open(path, "w").write(lines)
+    assert np.array_equal(read_count_matrices_arrays(path)[1], g["C"])
+    # malformed header
+    open(path, "w").write("2 matrixes\n20 states\n")
+    with pytest.raises(Exception):
+        read_count_matrices_arrays(path)
+
+
+def test_rate_and_mask_matrix_roundtrip(tmp_path):
+    lg = load_golden("data_lg.npz")
+    states = [str(s) for s in lg["states"]]
+    path = str(tmp_path / "d" / "lg.txt")
+    write_rate_matrix(lg["lg"], states, path)
+    back = read_rate_matrix(path)
+    assert list(back.index) == states and np.array_equal(back.to_numpy(), lg["lg"])
+    mpath = str(tmp_path / "mask.txt")
+    m = (np.arange(400).reshape(20, 20) % 3 > 0).astype(int)
+    pd.DataFrame(m, index=states, columns=states).to_csv(mpath, sep=" ")
+    assert np.array_equal(read_mask_matrix(mpath).to_numpy(), m)
+
+
+@pytest.mark.parametrize("case", ["toy3_init", "toy3_mask", "s20_symmask", "s20_mask"])
+def test_rate_matrix_module_matches_reference_Q(case):
+    """theta -> Q of the mirror == the reference's Q (golden) for the same params."""
+    g = load_golden(f"eval_{case}.npz")
+    S = g["mask"].shape[0]
+    torch.manual_seed(0)
+    mod = RateMatrix(num_states=S, mode="pande_reversible", mask=torch.tensor(g["mask"]),
+                     pi=torch.ones(S, dtype=torch.float64) / S, pi_requires_grad=True,
+                     initialization=g["init"] if "init" in g else None)
+    if "init" in g:  # parameters recovered from the initialisation (reference stores them f32)
+        fin = np.isfinite(g["upper_diag"])
+        assert np.allclose(mod.upper_diag.detach().numpy()[fin], g["upper_diag"][fin],
+                           rtol=1e-6, atol=1e-6)
+        assert np.array_equal(np.isfinite(mod.upper_diag.detach().numpy()), fin)
+    else:  # the seed-0 float32 draw of the reference
+        assert np.array_equal(mod.upper_diag.detach().numpy(), g["upper_diag"])
+    with torch.no_grad():
+        mod.upper_diag.copy_(torch.tensor(g["upper_diag"]))
+        mod._pi.copy_(torch.tensor(g["log_pi"]))
+    Q = mod()
+    assert relerr(Q.detach().numpy(), g["Q_f64"]) < 1e-14
+    assert mod.is_reversible() == (case != "s20_mask")
+    # and the parameter gradients through the mirror equal the reference's, given dL/dQ
+    Q.backward(torch.tensor(g["dQ_f64"]))
+    fin = np.isfinite(g["upper_diag"])
+    assert relerr(mod.upper_diag.grad.numpy()[fin], g["d_upper_f64"][fin]) < 1e-11
+    assert relerr(mod._pi.grad.numpy(), g["d_log_pi_f64"]) < 1e-10
+
+
+def test_rate_matrix_init_errors():
+    g = load_golden("eval_toy3_init.npz")
+    bad_mask = load_golden("eval_toy3_mask.npz")["mask"]
+    with pytest.raises(ValueError):
+        RateMatrix(num_states=3, mode="pande_reversible", mask=torch.tensor(bad_mask),
+                   pi=torch.ones(3, dtype=torch.float64) / 3, initialization=g["init"])
+    with pytest.raises(ValueError):
+        RateMatrix(num_states=3, mode="default", mask=torch.ones(3, 3),
+                   pi=torch.ones(3, dtype=torch.float64) / 3, initialization=g["init"])
+
+
+def test_other_modes_have_zero_row_sums():
+    torch.manual_seed(1)
+    for mode in ["default", "pande", "stationary", "stationary_reversible"]:
+        mod = RateMatrix(num_states=5, mode=mode, mask=torch.ones(5, 5),
+                         pi=torch.tensor([0.1, 0.2, 0.3, 0.25, 0.15], dtype=torch.float64))
+        Q = mod().detach().numpy()
+        if mode in ("default", "pande"):
+            assert np.abs(Q.sum(1)).max() < 1e-14
+        else:  # "stationary*" modes return R diag(pi) with pi-weighted zero row sums
+            pi = mod.stationary().detach().numpy()
+            assert np.abs((Q / pi[None, :]) @ pi).max() < 1e-14
+
+
+def test_jtt_ipw_reference_goldens(tmp_path):
+    """reference tests/estimation_tests/jtt_ipw_test.py:12-74 (exact goldens)."""
+    g = load_golden("jtt_ipw_toy.npz")
+    states = list("ABC")
+    cpath = str(tmp_path / "c.txt")
+    write_count_matrices([(float(t), pd.DataFrame(C, index=states, columns=states))
+                          for t, C in zip(g["t"], g["C"])], cpath)
+    mpath = str(tmp_path / "m.txt")
+    pd.DataFrame(g["mask"], index=states, columns=states).to_csv(mpath, sep=" ")
+    for key, mp, ipw in [("Q1_JTT_IPW_on_toy_matrix", None, True),
+                         ("Q1_JTT_IPW_on_toy_matrix_mask", mpath, True),
+                         ("Q1_JTT_on_toy_matrix", None, False),
+                         ("Q1_JTT_on_toy_matrix_mask", mpath, False)]:
+        out = str(tmp_path / key)
+        os.makedirs(out)
+        cherryml_amd.jtt_ipw(count_matrices_path=cpath, mask_path=mp, use_ipw=ipw,
+                             output_rate_matrix_dir=out)
+        got = read_rate_matrix(os.path.join(out, "result.txt")).to_numpy()
+        np.testing.assert_almost_equal(got, g[key], decimal=7)
+        np.testing.assert_almost_equal(got, orc.jtt_ipw(
+            g["t"], g["C"], g["mask"].astype(float) if mp else None, use_ipw=ipw), decimal=12)
