@@ -6,6 +6,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -64,6 +65,7 @@ struct cb_bank {
   unsigned long long *off_bits = nullptr;
   int k3_chunk = 0, k3_nchunks = 0;
   int last_sweeps = 0;
+  bool have_prev = false;  // h->U / h->Vc hold the eigenvectors of the previous solve
   // profiling
   bool profile = false;
   hipEvent_t ev[CB_T_COUNT + 1] = {};
@@ -365,40 +367,67 @@ static int launch_small(cb_bank *h, const SmallArgs &a) {
 }
 
 // --------------------------------------------------------------- large path
-static int large_eigh(cb_bank *h) {
+static int large_eigh(cb_bank *h, bool warm) {
   const int LD = h->LD;
   const size_t LL = (size_t)LD * LD;
   hipLaunchKernelGGL(lgj_sigma, dim3(1), dim3(256), 0, h->stream, LD, h->A, h->sigma);
-  hipLaunchKernelGGL(lgj_init, dim3((unsigned)((LL + 255) / 256)), dim3(256), 0, h->stream, LD, h->A,
-                     h->sigma, h->Gc);
+  if (warm && h->have_prev && !getenv("CB_NO_WARM")) {
+    // Warm start: Jacobi from the previous epoch's orthonormal basis V0 = U_prev,
+    //   G0 = A' V0 :  Gc[k][r] = sum_j U_prev[j][k] A[j][r] - sigma Ut_prev[k][r]
+    // (A changes by one optimiser step, so G0's columns are nearly orthogonal already).
+    const int tm = (LD + LG_TM - 1) / LG_TM, tn = (LD + LG_TN - 1) / LG_TN;
+    K4Args g0{h->S, LD, h->U, h->A, h->Gc, nullptr, h->Vc, h->sigma};
+    hipLaunchKernelGGL(k4_gemm, dim3(tm * tn), dim3(LG_THREADS), 0, h->stream, g0);
+  } else {
+    hipLaunchKernelGGL(lgj_init, dim3((unsigned)((LL + 255) / 256)), dim3(256), 0, h->stream, LD,
+                       h->A, h->sigma, h->Gc);
+  }
+  h->have_prev = false;
   const int nb = LD / JB_W;
   const int RS = LD + ((2 - LD % 32 + 32) % 32);
   const size_t lds = (size_t)(16 * RS + 3 * 16 * 17 + 1024) * sizeof(double);
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(lgj_round),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  const int max_sweeps = 30;
+  const int max_sweeps = 40;
+  const char *env_inner = getenv("CB_INNER_SWEEPS");
+  const int inner_sweeps = env_inner ? atoi(env_inner) : 1;
   int sweep = 0;
+  unsigned long long *dbg_stamps = nullptr;
+  if (getenv("CB_DEBUG_STAMPS")) HIP_TRY(hipMalloc((void **)&dbg_stamps, 8 * sizeof(unsigned long long)));
   for (; sweep < max_sweeps; ++sweep) {
     HIP_TRY(hipMemsetAsync(h->off_bits, 0, sizeof(unsigned long long), h->stream));
     for (int r = 0; r < nb - 1; ++r)
-      hipLaunchKernelGGL(lgj_round, dim3(nb / 2), dim3(JB_THREADS), lds, h->stream, LD, r, h->Gc,
-                         h->off_bits);
+      hipLaunchKernelGGL(lgj_round, dim3(nb / 2), dim3(JB_THREADS), lds, h->stream, LD, r,
+                         inner_sweeps, h->Gc, h->off_bits,
+                         (dbg_stamps && sweep == 2 && r == 5) ? dbg_stamps : nullptr);
     unsigned long long bits = 0;
     HIP_TRY(hipMemcpyAsync(&bits, h->off_bits, sizeof bits, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
     double off;
     memcpy(&off, &bits, sizeof off);
     if (!(off == off)) return fail(CB_ENUMERIC, "eigensolver: non-finite input");
-    if (off <= CB_JAC_STOP) {
+    if (getenv("CB_DEBUG")) fprintf(stderr, "[cherrybank] eigh sweep %d: max cosine %.3e\n", sweep, off);
+    // quadratic convergence: a sweep that STARTS below 1e-8 ends at rounding level
+    if (off <= 1e-8) {
       ++sweep;
       break;
     }
   }
   h->last_sweeps = sweep;
+  if (dbg_stamps) {
+    unsigned long long st[8];
+    HIP_TRY(hipMemcpy(st, dbg_stamps, sizeof st, hipMemcpyDeviceToHost));
+    (void)hipFree(dbg_stamps);
+    const char *names[] = {"stage", "gram", "reduce+sync", "offmeasure", "inner", "NS+sync", "apply"};
+    for (int i = 0; i < 6; ++i)
+      fprintf(stderr, "[cherrybank] lgj_round %-12s %6llu ticks (100 MHz)\n", names[i == 2 ? 3 : (i > 2 ? i + 1 : i)],
+              st[i + 1] - st[i]);
+  }
   if (sweep >= max_sweeps) return fail(CB_ENUMERIC, "block Jacobi did not converge in %d sweeps", max_sweeps);
   hipLaunchKernelGGL(lgj_finish, dim3((LD + 3) / 4), dim3(256), 0, h->stream, LD, h->Gc, h->sigma,
                      h->lam, h->U, h->Vc);
   HIP_TRY(hipGetLastError());
+  h->have_prev = true;
   return CB_OK;
 }
 
@@ -408,7 +437,7 @@ static int large_loss_grad(cb_bank *h, const double *Qd, const double *pid, bool
   const size_t LL = (size_t)LD * LD;
   hipLaunchKernelGGL(lg_build_A, dim3((unsigned)((LL + 255) / 256)), dim3(256), 0, h->stream, S, LD,
                      Qd, pid, h->A, h->dsq);
-  int rc = large_eigh(h);
+  int rc = large_eigh(h, true);
   if (rc != CB_OK) return rc;
   mark(h, EV_EIGH);
   hipLaunchKernelGGL(lg_tables, dim3((unsigned)(((size_t)B * LD + 255) / 256)), dim3(256), 0,
@@ -434,9 +463,9 @@ static int large_loss_grad(cb_bank *h, const double *Qd, const double *pid, bool
     mark(h, EV_K3);
     hipLaunchKernelGGL(k3_reduce, dim3((unsigned)((LL + 255) / 256)), dim3(256), 0, h->stream,
                        h->Mt_part, h->k3_nchunks, LL, h->Mt);
-    K4Args k4a{S, LD, h->Mt, h->Vc, h->X, nullptr};
+    K4Args k4a{S, LD, h->Mt, h->Vc, h->X, nullptr, nullptr, nullptr};
     hipLaunchKernelGGL(k4_gemm, dim3(tiles), dim3(LG_THREADS), 0, h->stream, k4a);
-    K4Args k4b{S, LD, h->Vc, h->X, dQd, h->dsq};
+    K4Args k4b{S, LD, h->Vc, h->X, dQd, h->dsq, nullptr, nullptr};
     hipLaunchKernelGGL(k4_gemm, dim3(tiles), dim3(LG_THREADS), 0, h->stream, k4b);
     mark(h, EV_K4);
   }
@@ -587,7 +616,7 @@ extern "C" int cb_eigh(cb_handle h, const double *A, int flags, double *lam, dou
   std::vector<double> Ap((size_t)LD * LD, 0.0);
   for (int i = 0; i < S; ++i) memcpy(&Ap[(size_t)i * LD], A + (size_t)i * S, S * sizeof(double));
   HIP_TRY(hipMemcpyAsync(h->A, Ap.data(), Ap.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
-  int rc = large_eigh(h);
+  int rc = large_eigh(h, false);
   if (rc != CB_OK) return rc;
   std::vector<double> Up((size_t)LD * LD), lp(LD);
   HIP_TRY(hipMemcpyAsync(Up.data(), h->U, Up.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));

@@ -66,3 +66,40 @@ __device__ __forceinline__ double divdiff(double t, double la, double lc, double
 __device__ __forceinline__ unsigned long long dbl_bits(double v) {
   return (unsigned long long)__double_as_longlong(v);
 }
+
+// xor-1 / xor-2 exchange inside a quad with DPP (VALU speed; __shfl_xor goes
+// through ds_bpermute, ~100 cycles of LDS-crossbar latency per dword).
+__device__ __forceinline__ double quad_xor1(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(lo, lo, 0xB1, 0xF, 0xF, false);  // quad_perm [1,0,3,2]
+  hi = __builtin_amdgcn_update_dpp(hi, hi, 0xB1, 0xF, 0xF, false);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double quad_xor2(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(lo, lo, 0x4E, 0xF, 0xF, false);  // quad_perm [2,3,0,1]
+  hi = __builtin_amdgcn_update_dpp(hi, hi, 0x4E, 0xF, 0xF, false);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double quad_sum(double v) {
+  v += quad_xor1(v);
+  v += quad_xor2(v);
+  return v;
+}
+
+// 1/sqrt(x) and 1/x from the hardware seeds (v_rsq_f64 / v_rcp_f64) + Newton
+// steps to full double precision (x > 0, normal range): shorter dependency
+// chains than the IEEE-exact library sequences, used only for rotation angles.
+__device__ __forceinline__ double fast_rsqrt(double x) {
+  double y = __builtin_amdgcn_rsq(x);
+  const double hx = 0.5 * x;
+  y = y * fma(-hx * y, y, 1.5);
+  y = y * fma(-hx * y, y, 1.5);
+  return y;
+}
+__device__ __forceinline__ double fast_rcp(double x) {
+  double y = __builtin_amdgcn_rcp(x);
+  y = fma(fma(-x, y, 1.0), y, y);
+  y = fma(fma(-x, y, 1.0), y, y);
+  return y;
+}

@@ -43,9 +43,13 @@ __global__ void lgj_init(int LD, const double *A, const double *sigma, double *G
 
 __device__ __forceinline__ int jb_rowstride(int LD) { return LD + ((2 - LD % 32 + 32) % 32); }
 
-__global__ __launch_bounds__(JB_THREADS) void lgj_round(int LD, int round, double *Gc,
-                                                        unsigned long long *off_bits) {
+__global__ __launch_bounds__(JB_THREADS) void lgj_round(int LD, int round, int inner_sweeps,
+                                                        double *Gc, unsigned long long *off_bits,
+                                                        unsigned long long *stamps) {
   extern __shared__ double lds[];
+#define JB_STAMP(i)                                                              \
+  if (stamps && blockIdx.x == 0 && threadIdx.x == 0) stamps[i] = __builtin_amdgcn_s_memtime();
+  JB_STAMP(0)
   const int RS = jb_rowstride(LD);
   double *sG = lds;                 // [16][RS]
   double *sGam = sG + 16 * RS;      // [16][17]  Gram -> orthogonalised columns
@@ -60,18 +64,42 @@ __global__ __launch_bounds__(JB_THREADS) void lgj_round(int LD, int round, doubl
   const int lo = lane & 15, hi = lane >> 4;
   auto gcol = [&](int c) { return c < JB_W ? bi * JB_W + c : bj * JB_W + (c - JB_W); };
 
-  // 1. stage G columns
-  for (int c = 0; c < 16; ++c) {
-    const double *src = Gc + (size_t)gcol(c) * LD;
-    for (int r = threadIdx.x; r < LD; r += JB_THREADS) sG[c * RS + r] = src[r];
+  // 1. stage G columns: all 16 loads of a row slab in flight before the first LDS store
+  {
+    const double *src_i = Gc + (size_t)bi * JB_W * LD, *src_j = Gc + (size_t)bj * JB_W * LD;
+    for (int r = threadIdx.x; r < LD; r += JB_THREADS) {
+      double v[16];
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        v[c] = src_i[(size_t)c * LD + r];
+        v[8 + c] = src_j[(size_t)c * LD + r];
+      }
+#pragma unroll
+      for (int c = 0; c < 16; ++c) sG[c * RS + r] = v[c];
+    }
   }
   __syncthreads();
-  // 2. Gram via MFMA: lane (lo, hi) feeds G[r = 4 s + hi][c = lo] as A and as B
+  JB_STAMP(1)
+  // 2. Gram via MFMA: lane (lo, hi) feeds G[r = 4 s + hi][c = lo] as A and as B.
+  //    Four independent accumulators: a dependent f64 MFMA chain costs ~300 cycles a link.
   d4 acc = {0.0, 0.0, 0.0, 0.0};
-  const int nsteps = LD / 4;
-  for (int s = wave; s < nsteps; s += 4) {
-    const double v = sG[lo * RS + 4 * s + hi];
-    acc = mfma_f64(v, v, acc);
+  {
+    d4 a0 = acc, a1 = acc, a2 = acc, a3 = acc;
+    const int nsteps = LD / 4;
+    int s0 = wave;
+    for (; s0 + 12 < nsteps; s0 += 16) {
+      const double v0 = sG[lo * RS + 4 * s0 + hi], v1 = sG[lo * RS + 4 * (s0 + 4) + hi];
+      const double v2 = sG[lo * RS + 4 * (s0 + 8) + hi], v3 = sG[lo * RS + 4 * (s0 + 12) + hi];
+      a0 = mfma_f64(v0, v0, a0);
+      a1 = mfma_f64(v1, v1, a1);
+      a2 = mfma_f64(v2, v2, a2);
+      a3 = mfma_f64(v3, v3, a3);
+    }
+    for (; s0 < nsteps; s0 += 4) {
+      const double v0 = sG[lo * RS + 4 * s0 + hi];
+      a0 = mfma_f64(v0, v0, a0);
+    }
+    acc = (a0 + a1) + (a2 + a3);
   }
 #pragma unroll
   for (int r = 0; r < 4; ++r) sPart[wave * 256 + (hi + 4 * r) * 16 + lo] = acc[r];
@@ -82,19 +110,22 @@ __global__ __launch_bounds__(JB_THREADS) void lgj_round(int LD, int round, doubl
     sGam[(e >> 4) * 17 + (e & 15)] = v;
   }
   __syncthreads();
+  JB_STAMP(2)
   // 3. off-diagonal measure + 16x16 eigenproblem (wave 0)
   if (wave == 0) {
     double off = 0.0;
     for (int e = lane; e < 256; e += 64) {
       const int p = e >> 4, q = e & 15;
       if (p < q) {
-        const double den = sqrt(sGam[p * 17 + p] * sGam[q * 17 + q]);
-        if (den > 0.0) off = fmax(off, fabs(sGam[p * 17 + q]) / den);
+        const double den2 = sGam[p * 17 + p] * sGam[q * 17 + q];
+        if (den2 > 0.0) off = fmax(off, fabs(sGam[p * 17 + q]) * fast_rsqrt(den2));
       }
     }
     off = wave_max(off);
     if (lane == 0) atomicMax(off_bits, dbl_bits(off));
-    wave_diagonaliser_spd(16, sGam, sR, 17, CB_JAC_MAX_SWEEPS);
+    JB_STAMP(3)
+    wave_rotation_spd16(sGam, sR, 17, inner_sweeps);
+    JB_STAMP(4)
     // One Newton-Schulz step R <- R (3 I - R^T R) / 2 makes R orthogonal to rounding.
     for (int e = lane; e < 256; e += 64) {
       const int p = e >> 4, q = e & 15;
@@ -112,12 +143,29 @@ __global__ __launch_bounds__(JB_THREADS) void lgj_round(int LD, int round, doubl
     wave_lds_fence();
   }
   __syncthreads();
+  JB_STAMP(5)
   // 4. apply R:  new^T[c'][r] = sum_c R[c][c'] old^T[c][r]
   double Rf[4];
 #pragma unroll
   for (int s = 0; s < 4; ++s) Rf[s] = sN[lo * 17 + 4 * s + hi];  // R[c = 4s+hi][c' = lo]
   const int ntiles = LD / 16;
-  for (int job = wave; job < ntiles; job += 4) {
+  int job = wave;
+  for (; job + 4 < ntiles; job += 8) {  // two row tiles per trip: independent MFMA chains
+    const int r0 = job * 16, r1 = (job + 4) * 16;
+    d4 o0 = {0.0, 0.0, 0.0, 0.0}, o1 = o0;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      o0 = mfma_f64(Rf[s], sG[(4 * s + hi) * RS + r0 + lo], o0);
+      o1 = mfma_f64(Rf[s], sG[(4 * s + hi) * RS + r1 + lo], o1);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      double *dst = Gc + (size_t)gcol(hi + 4 * r) * LD + lo;
+      dst[r0] = o0[r];
+      dst[r1] = o1[r];
+    }
+  }
+  for (; job < ntiles; job += 4) {
     const int r0 = job * 16;
     d4 o = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
@@ -125,6 +173,8 @@ __global__ __launch_bounds__(JB_THREADS) void lgj_round(int LD, int round, doubl
 #pragma unroll
     for (int r = 0; r < 4; ++r) Gc[(size_t)gcol(hi + 4 * r) * LD + r0 + lo] = o[r];
   }
+  JB_STAMP(6)
+#undef JB_STAMP
 }
 
 // lam_k = sigma - |g_k| ; Ut[k][r] = U[r][k] = -g_k[r] / |g_k|   (A' negative definite)

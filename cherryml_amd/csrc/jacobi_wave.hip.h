@@ -45,8 +45,11 @@ __device__ __forceinline__ void rr_pair(int m, int r, int i, int &p, int &q) {
 // Orthogonalises the columns of Gc in place.  RPL = rows per lane (ceil(n/4)),
 // a compile-time bound so that the column pieces stay in registers.
 // Returns the number of sweeps used.
-template <int RPL>
-__device__ int wave_jacobi_columns(int n, double *Gc, int LS, int max_sweeps) {
+// If Vc != nullptr the same rotations are applied to the columns of Vc (the
+// caller initialises it, e.g. to I), so a truncated run still yields an exactly
+// orthogonal accumulated transform.
+template <int RPL, bool ACC>
+__device__ int wave_jacobi_columns(int n, double *Gc, double *Vc, int LS, int max_sweeps) {
   const int lane = threadIdx.x & 63;
   const int m = (n + 1) & ~1;  // even number of players (one dummy when n is odd)
   const int mm = m - 1;
@@ -60,36 +63,46 @@ __device__ int wave_jacobi_columns(int n, double *Gc, int LS, int max_sweeps) {
     for (int r = 0; r < mm; ++r) {
       const int pp = slot == 0 ? mm : p, qq = slot == 0 ? r : q;
       const bool real = active && pp < n && qq < n;
-      double x[RPL], y[RPL];
+      // unconditional loads from clamped (always valid) addresses + selects:
+      // guarded loads make hipcc emit one exec-mask branch region per load
+      double x[RPL], y[RPL], u[RPL], v[RPL];
       double a = 0.0, b = 0.0, g = 0.0;
+      const int pbase = (real ? pp : 0) * LS, qbase = (real ? qq : 0) * LS;
 #pragma unroll
       for (int i = 0; i < RPL; ++i) {
-        const int row = sub + 4 * i;
-        const bool ok = real && row < n;
-        x[i] = ok ? Gc[pp * LS + row] : 0.0;
-        y[i] = ok ? Gc[qq * LS + row] : 0.0;
+        const int row = min(sub + 4 * i, n - 1);
+        x[i] = Gc[pbase + row];
+        y[i] = Gc[qbase + row];
+        if (ACC) {
+          u[i] = Vc[pbase + row];
+          v[i] = Vc[qbase + row];
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < RPL; ++i) {
+        const bool ok = real && (sub + 4 * i < n);
+        x[i] = ok ? x[i] : 0.0;
+        y[i] = ok ? y[i] : 0.0;
         a = fma(x[i], x[i], a);
         b = fma(y[i], y[i], b);
         g = fma(x[i], y[i], g);
       }
-      a += __shfl_xor(a, 1, 64);
-      b += __shfl_xor(b, 1, 64);
-      g += __shfl_xor(g, 1, 64);
-      a += __shfl_xor(a, 2, 64);
-      b += __shfl_xor(b, 2, 64);
-      g += __shfl_xor(g, 2, 64);
+      a = quad_sum(a);
+      b = quad_sum(b);
+      g = quad_sum(g);
       if (real) {
         const double ab = a * b;
         // cosine^2 = g^2 / (a b); compare squares, no sqrt / div on this path
         const double g2 = g * g;
         if (g2 > ab * (CB_JAC_STOP * CB_JAC_STOP)) off = 1.0;  // "not converged" flag
         if (g2 > ab * (CB_JAC_SKIP * CB_JAC_SKIP)) {
-          // tan(theta) = sign(d) 2|g| ... : t = 2 g / (d + sign(d) sqrt(d^2 + 4 g^2)), d = b - a
+          // t = tan(theta) = 2 g / (d + sign(d) sqrt(d^2 + 4 g^2)), d = b - a
           const double d = b - a;
-          const double h = sqrt(fma(d, d, 4.0 * g2));
+          const double hh = fma(d, d, 4.0 * g2);   // > 0 here
+          const double h = hh * fast_rsqrt(hh);     // sqrt
           const double den = d + copysign(h, d);
-          const double t = (den != 0.0) ? 2.0 * g / den : 1.0;
-          const double c = rsqrt(fma(t, t, 1.0));
+          const double t = 2.0 * g * copysign(fast_rcp(fabs(den)), den);
+          const double c = fast_rsqrt(fma(t, t, 1.0));
           const double s = c * t;
 #pragma unroll
           for (int i = 0; i < RPL; ++i) {
@@ -97,6 +110,10 @@ __device__ int wave_jacobi_columns(int n, double *Gc, int LS, int max_sweeps) {
             if (row < n) {
               Gc[pp * LS + row] = c * x[i] - s * y[i];
               Gc[qq * LS + row] = s * x[i] + c * y[i];
+              if (ACC) {
+                Vc[pp * LS + row] = c * u[i] - s * v[i];
+                Vc[qq * LS + row] = s * u[i] + c * v[i];
+              }
             }
           }
         }
@@ -115,12 +132,12 @@ __device__ int wave_jacobi_columns(int n, double *Gc, int LS, int max_sweeps) {
 }
 
 __device__ __forceinline__ int wave_jacobi_columns_n(int n, double *Gc, int LS, int max_sweeps) {
-  if (n <= 4) return wave_jacobi_columns<1>(n, Gc, LS, max_sweeps);
-  if (n <= 8) return wave_jacobi_columns<2>(n, Gc, LS, max_sweeps);
-  if (n <= 16) return wave_jacobi_columns<4>(n, Gc, LS, max_sweeps);
-  if (n <= 20) return wave_jacobi_columns<5>(n, Gc, LS, max_sweeps);
-  if (n <= 24) return wave_jacobi_columns<6>(n, Gc, LS, max_sweeps);
-  return wave_jacobi_columns<8>(n, Gc, LS, max_sweeps);
+  if (n <= 4) return wave_jacobi_columns<1, false>(n, Gc, nullptr, LS, max_sweeps);
+  if (n <= 8) return wave_jacobi_columns<2, false>(n, Gc, nullptr, LS, max_sweeps);
+  if (n <= 16) return wave_jacobi_columns<4, false>(n, Gc, nullptr, LS, max_sweeps);
+  if (n <= 20) return wave_jacobi_columns<5, false>(n, Gc, nullptr, LS, max_sweeps);
+  if (n <= 24) return wave_jacobi_columns<6, false>(n, Gc, nullptr, LS, max_sweeps);
+  return wave_jacobi_columns<8, false>(n, Gc, nullptr, LS, max_sweeps);
 }
 
 // Eigendecomposition of a symmetric matrix A (row-major, stride LS, read only)
@@ -159,25 +176,13 @@ __device__ int wave_eigh_rate(int n, const double *A, double *Gc, double *Uc, do
   return sweeps;
 }
 
-// Orthogonal R with R^T Gamma R diagonal for a symmetric POSITIVE definite
-// Gamma (n <= 16 used): columns of R at Rc[k*LS + i].  Gamma is destroyed
-// (used as the column array).  At most `max_sweeps` sweeps: the caller iterates.
-__device__ int wave_diagonaliser_spd(int n, double *Gam, double *Rc, int LS, int max_sweeps) {
+// Orthogonal R (16 x 16) that (approximately, after `max_sweeps` Jacobi sweeps)
+// diagonalises the symmetric positive definite Gamma: columns of R at
+// Rc[k*LS + i].  R is the accumulated product of the plane rotations, hence
+// orthogonal however few sweeps are run.  Gamma is destroyed.
+__device__ int wave_rotation_spd16(double *Gam, double *Rc, int LS, int max_sweeps) {
   const int lane = threadIdx.x & 63;
-  // columns of Gamma = rows of Gamma (symmetric): Gam[k*LS + r] is already column k
-  const int sweeps = wave_jacobi_columns_n(n, Gam, LS, max_sweeps);
-  for (int k0 = 0; k0 < n; k0 += 16) {
-    const int k = k0 + (lane >> 2), sub = lane & 3;
-    double nn = 0.0;
-    if (k < n)
-      for (int r = sub; r < n; r += 4) nn = fma(Gam[k * LS + r], Gam[k * LS + r], nn);
-    nn += __shfl_xor(nn, 1, 64);
-    nn += __shfl_xor(nn, 2, 64);
-    if (k < n) {
-      const double inv = rsqrt(nn);
-      for (int r = sub; r < n; r += 4) Rc[k * LS + r] = Gam[k * LS + r] * inv;
-    }
-  }
+  for (int e = lane; e < 256; e += 64) Rc[(e >> 4) * LS + (e & 15)] = ((e >> 4) == (e & 15)) ? 1.0 : 0.0;
   wave_lds_fence();
-  return sweeps;
+  return wave_jacobi_columns<4, true>(16, Gam, Rc, LS, max_sweeps);
 }

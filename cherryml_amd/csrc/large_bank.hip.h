@@ -283,6 +283,8 @@ struct K4Args {
   const double *Aop, *Bop;  // [LD][LD] each
   double *out;              // [LD][LD] or dQ [S][S]
   const double *dsq;        // non-null => out = dQ[i][j] = d_i * acc / d_j, unpadded S x S
+  const double *sub;        // non-null => out = acc - (*sub_scale) * sub[row][col]
+  const double *sub_scale;
 };
 
 __global__ __launch_bounds__(LG_THREADS) void k4_gemm(K4Args a) {
@@ -305,7 +307,8 @@ __global__ __launch_bounds__(LG_THREADS) void k4_gemm(K4Args a) {
         if (row < a.S && col < a.S)
           a.out[(size_t)row * a.S + col] = a.dsq[row] * acc[j][r] / a.dsq[col];
       } else if (row < a.LD && col < a.LD) {
-        a.out[(size_t)row * a.LD + col] = acc[j][r];
+        const size_t idx = (size_t)row * a.LD + col;
+        a.out[idx] = a.sub ? acc[j][r] - (*a.sub_scale) * a.sub[idx] : acc[j][r];
       }
     }
 }
