@@ -390,12 +390,15 @@ static int large_eigh(cb_bank *h, bool warm) {
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   const int max_sweeps = 40;
   const char *env_inner = getenv("CB_INNER_SWEEPS");
-  const int inner_sweeps = env_inner ? atoi(env_inner) : 1;
+  const int inner_sweeps = env_inner ? atoi(env_inner) : 0;  // 0 = each pair once per sweep
   int sweep = 0;
   unsigned long long *dbg_stamps = nullptr;
   if (getenv("CB_DEBUG_STAMPS")) HIP_TRY(hipMalloc((void **)&dbg_stamps, 8 * sizeof(unsigned long long)));
   for (; sweep < max_sweeps; ++sweep) {
     HIP_TRY(hipMemsetAsync(h->off_bits, 0, sizeof(unsigned long long), h->stream));
+    if (inner_sweeps == 0)  // pairs inside each block, once per sweep
+      hipLaunchKernelGGL(lgj_round, dim3(nb / 2), dim3(JB_THREADS), lds, h->stream, LD, -1, 0, h->Gc,
+                         h->off_bits, (unsigned long long *)nullptr);
     for (int r = 0; r < nb - 1; ++r)
       hipLaunchKernelGGL(lgj_round, dim3(nb / 2), dim3(JB_THREADS), lds, h->stream, LD, r,
                          inner_sweeps, h->Gc, h->off_bits,
@@ -517,8 +520,23 @@ extern "C" int cb_loss_grad(cb_handle h, const double *Q, const double *pi, int 
     a.loss = lossd;
     a.dQ = dQd;
     a.status = h->status;
+    unsigned long long *dbg = nullptr;
+    if (getenv("CB_DEBUG_STAMPS")) {
+      HIP_TRY(hipMalloc((void **)&dbg, 8 * sizeof(unsigned long long)));
+      a.stamps = dbg;
+    }
     rc = launch_small<SMALL_LOSSGRAD>(h, a);
     mark(h, EV_SMALL);
+    if (dbg) {
+      unsigned long long st[8];
+      HIP_TRY(hipStreamSynchronize(h->stream));
+      HIP_TRY(hipMemcpy(st, dbg, sizeof st, hipMemcpyDeviceToHost));
+      (void)hipFree(dbg);
+      const char *names[] = {"build A", "eigh", "frags", "buckets", "epilogue"};
+      for (int i = 0; i < 5; ++i)
+        fprintf(stderr, "[cherrybank] small kernel %-9s %8llu cycles\n", names[i], st[i + 1] - st[i]);
+      fprintf(stderr, "[cherrybank] eigh sweeps (site 0): see status; B=%d\n", h->B);
+    }
   }
   if (rc != CB_OK) return rc;
   if (h->profile) h->t_pending = true;

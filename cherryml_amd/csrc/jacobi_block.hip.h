@@ -43,6 +43,11 @@ __global__ void lgj_init(int LD, const double *A, const double *sigma, double *G
 
 __device__ __forceinline__ int jb_rowstride(int LD) { return LD + ((2 - LD % 32 + 32) % 32); }
 
+// round >= 0: tournament round `round`, cross-block pairs only (inner_sweeps == 0) or
+//             full sweeps of all 120 pairs (inner_sweeps > 0);
+// round <  0: the "within" pass: workgroup w takes blocks 2w, 2w+1 and rotates only
+//             the pairs inside each block.  One sweep = the LD/8 - 1 rounds + 1 within
+//             pass visits every column pair exactly once.
 __global__ __launch_bounds__(JB_THREADS) void lgj_round(int LD, int round, int inner_sweeps,
                                                         double *Gc, unsigned long long *off_bits,
                                                         unsigned long long *stamps) {
@@ -59,7 +64,12 @@ __global__ __launch_bounds__(JB_THREADS) void lgj_round(int LD, int round, int i
 
   const int nb = LD / JB_W;
   int bi, bj;
-  rr_pair(nb, round, blockIdx.x, bi, bj);
+  if (round >= 0) {
+    rr_pair(nb, round, blockIdx.x, bi, bj);
+  } else {
+    bi = 2 * blockIdx.x;
+    bj = bi + 1;
+  }
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int lo = lane & 15, hi = lane >> 4;
   auto gcol = [&](int c) { return c < JB_W ? bi * JB_W + c : bj * JB_W + (c - JB_W); };
@@ -116,7 +126,8 @@ __global__ __launch_bounds__(JB_THREADS) void lgj_round(int LD, int round, int i
     double off = 0.0;
     for (int e = lane; e < 256; e += 64) {
       const int p = e >> 4, q = e & 15;
-      if (p < q) {
+      const bool mine = inner_sweeps > 0 || ((round >= 0) ? (p < 8 && q >= 8) : ((p < 8) == (q < 8)));
+      if (p < q && mine) {
         const double den2 = sGam[p * 17 + p] * sGam[q * 17 + q];
         if (den2 > 0.0) off = fmax(off, fabs(sGam[p * 17 + q]) * fast_rsqrt(den2));
       }
@@ -124,7 +135,13 @@ __global__ __launch_bounds__(JB_THREADS) void lgj_round(int LD, int round, int i
     off = wave_max(off);
     if (lane == 0) atomicMax(off_bits, dbl_bits(off));
     JB_STAMP(3)
-    wave_rotation_spd16(sGam, sR, 17, inner_sweeps);
+    if (inner_sweeps > 0) {
+      wave_rotation_spd16(sGam, sR, 17, inner_sweeps);
+    } else {
+      for (int e = lane; e < 256; e += 64) sR[(e >> 4) * 17 + (e & 15)] = ((e >> 4) == (e & 15)) ? 1.0 : 0.0;
+      wave_lds_fence();
+      wave_rotation_spd16_blockpairs(sGam, sR, 17, round >= 0);
+    }
     JB_STAMP(4)
     // One Newton-Schulz step R <- R (3 I - R^T R) / 2 makes R orthogonal to rounding.
     for (int e = lane; e < 256; e += 64) {

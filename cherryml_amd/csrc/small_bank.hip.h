@@ -35,6 +35,7 @@ struct SmallArgs {
   double *lam_out;    // [L,S] (eigh mode) or null
   double *U_out;      // [L,S,S] (eigh mode) or null
   int *status;        // [L] sweeps used by the eigensolver
+  unsigned long long *stamps;  // diagnostic s_memtime stamps (block 0) or null
 };
 
 // LDS carve-up (doubles)
@@ -58,11 +59,16 @@ enum { SMALL_LOSSGRAD = 0, SMALL_EXPM = 1, SMALL_EIGH = 2 };
 // Each wave returns its partial M (registers) and loss.
 template <int NT, int KS>
 struct SmallFrags {
-  double UA[NT][KS];  // U[16 mt + (l&15)][4 s + (l>>4)]
-  double UB[NT][KS];  // U[4 s + (l>>4)][16 nt + (l&15)]
-  double lamR[NT][4]; // lam[16 at + (l>>4) + 4 r]
-  double lamC[NT];    // lam[16 ct + (l&15)]
+  double UA[NT][KS];  // U[16 mt + (l&15)][4 s + (l>>4)]   (A form; also the B form of U^T)
+  // The other operand form, UB[nt][s] = U[4 s + (l>>4)][16 nt + (l&15)], and the
+  // eigenvalues are re-read from LDS where used (ub()): 30 ds_read_b64 per bucket
+  // buy ~60 VGPRs, i.e. the second wave per SIMD.
 };
+
+// UB[x][s] = U[j = 4 s + hi][m = 16 x + lo] = V[m*LS + j]; LDS frames are zero padded to 32
+__device__ __forceinline__ double ub(const double *sV, int x, int s, int lo, int hi) {
+  return sV[(16 * x + lo) * CB_LS + 4 * s + hi];
+}
 
 template <int NT, int KS>
 __device__ __forceinline__ void load_frags(SmallFrags<NT, KS> &f, const double *sV,
@@ -76,42 +82,44 @@ __device__ __forceinline__ void load_frags(SmallFrags<NT, KS> &f, const double *
       const int i = 16 * x + lo, k = 4 * s + hi;
       // U[i][k] = component i of eigenvector k = V[k*LS + i]
       f.UA[x][s] = (i < S && k < S) ? sV[k * CB_LS + i] : 0.0;
-      // U[j = k][m = i] = V[i*LS + k]
-      f.UB[x][s] = (i < S && k < S) ? sV[i * CB_LS + k] : 0.0;
     }
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int a = 16 * x + hi + 4 * r;
-      f.lamR[x][r] = (a < S) ? sLam[a] : 0.0;
-    }
-    const int c = 16 * x + lo;
-    f.lamC[x] = (c < S) ? sLam[c] : 0.0;
   }
+}
+
+// Register slot (tile row-block x, register r) holds rows 16 x + (l>>4) + 4 r.
+// S <= 4 KS, so slots with 16 x + 4 r >= 4 KS are dead for every lane: pruned at
+// compile time (for S = 20: 10 of 16 slots survive).
+#define SLOT_LIVE(x, r) (16 * (x) + 4 * (r) < 4 * KS)
+
+template <int NT, int KS>
+__device__ __forceinline__ void load_counts(double (&cval)[NT][NT][4], int S,
+                                            const double *__restrict__ Ctb) {
+  const int lane = threadIdx.x & 63;
+  const int lo = lane & 15, hi = lane >> 4;
+#pragma unroll
+  for (int mt = 0; mt < NT; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (SLOT_LIVE(mt, r)) {
+          // clamped address + select: a guarded load costs a branch region each
+          const int row = 16 * mt + hi + 4 * r, col = 16 * nt + lo;
+          const double v = Ctb[min(row, S - 1) * S + min(col, S - 1)];
+          cval[mt][nt][r] = (row < S && col < S) ? v : 0.0;
+        }
 }
 
 template <int NT, int KS, int MODE>
 __device__ __forceinline__ void small_bucket(const SmallFrags<NT, KS> &f, int S, double tb,
-                                             const double *__restrict__ Ctb, double inv_n,
-                                             const double *sA, const double *sD,
+                                             double (&cval)[NT][NT][4],
+                                             const double *__restrict__ Ct_next, double inv_n,
+                                             const double *sA, const double *sD, const double *sV,
                                              double *tab /* wave-private F,E,H */,
                                              const double *sLam, double rho, d4 (&M)[NT][NT],
                                              double &lossacc, double *__restrict__ Pout) {
   const int lane = threadIdx.x & 63;
   const int lo = lane & 15, hi = lane >> 4;
-
-  // issue the count loads first: they are consumed after the first product
-  double cval[NT][NT][4];
-  if (MODE == SMALL_LOSSGRAD) {
-#pragma unroll
-    for (int mt = 0; mt < NT; ++mt)
-#pragma unroll
-      for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int row = 16 * mt + hi + 4 * r, col = 16 * nt + lo;
-          cval[mt][nt][r] = (row < S && col < S) ? Ctb[row * S + col] : 0.0;
-        }
-  }
 
   // Pt = U e^{t lam} U^T is evaluated as I + t A + U phi2(t lam) U^T while
   // t * rho <= 1 (rho >= spectral radius): entries that are O(t^2) keep full
@@ -121,9 +129,11 @@ __device__ __forceinline__ void small_bucket(const SmallFrags<NT, KS> &f, int S,
   // per-bucket spectral tables (lanes k < S), wave-private LDS
   if (lane < 32) {
     const double x = (lane < S) ? tb * sLam[lane] : 0.0;
-    tab[lane] = split ? phi2(x) : (lane < S ? exp(x) : 0.0);
-    tab[32 + lane] = exp(x);
-    tab[64 + lane] = exp(0.5 * x);
+    const double H = exp(0.5 * x);
+    const double E = H * H;
+    tab[lane] = split ? phi2(x) : (lane < S ? E : 0.0);
+    tab[32 + lane] = E;
+    tab[64 + lane] = H;
   }
   wave_lds_fence();
 
@@ -146,33 +156,36 @@ __device__ __forceinline__ void small_bucket(const SmallFrags<NT, KS> &f, int S,
     }
   }
   // ---- epilogue: loss, Gt^T = -C^T / Pt / n  (in place) --------------------
+  const double tsplit = split ? tb : 0.0, isplit = split ? 1.0 : 0.0;
 #pragma unroll
   for (int mt = 0; mt < NT; ++mt)
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
+        if (!SLOT_LIVE(mt, r)) {
+          g[mt][nt][r] = 0.0;
+          continue;
+        }
         const int row = 16 * mt + hi + 4 * r, col = 16 * nt + lo;
         const bool valid = (row < S) && (col < S);
-        double pt = 1.0;
-        if (valid) {
-          pt = g[mt][nt][r];
-          if (split) pt += tb * sA[row * CB_LS + col] + (row == col ? 1.0 : 0.0);
-        }
+        double pt = g[mt][nt][r] + tsplit * sA[min(row, 31) * CB_LS + col] +
+                    (row == col ? isplit : 0.0);
+        pt = valid ? pt : 1.0;
         if (MODE == SMALL_EXPM) {
           // P[row][col] = Pt[row][col] d_col / d_row
           if (valid) Pout[row * S + col] = pt * sD[col] / sD[row];
         } else {
-          const double c = cval[mt][nt][r];
-          double gv = 0.0;
-          if (c != 0.0) {
-            lossacc = fma(-c, log(pt), lossacc);
-            gv = -c * inv_n / pt;
-          }
-          g[mt][nt][r] = gv;
+          const double c = cval[mt][nt][r];  // 0 on invalid slots
+          const bool nz = c != 0.0;
+          const double lg = fast_log(nz ? pt : 1.0);
+          lossacc = fma(-c, lg, lossacc);
+          g[mt][nt][r] = nz ? -c * inv_n * fast_rcp(pt) : 0.0;
         }
       }
   if (MODE == SMALL_EXPM) return;
+  // the counts of this bucket are consumed: start fetching the next bucket's
+  if (Ct_next) load_counts<NT, KS>(cval, S, Ct_next);
 
   // ---- T = Gt U :  T[i][m] = sum_j Gt[i][j] U[j][m] -------------------------
   // A operand of k-step (jt, s) is register s of tile g[jt][it] (Gt^T[j][i]).
@@ -186,20 +199,16 @@ __device__ __forceinline__ void small_bucket(const SmallFrags<NT, KS> &f, int S,
       for (int jt = 0; jt < NT; ++jt)
 #pragma unroll
         for (int s = 0; s < 4; ++s)
-          if (4 * jt + s < KS) acc = mfma_f64(g[jt][it][s], f.UB[mt][4 * jt + s], acc);
+          if (4 * jt + s < KS) acc = mfma_f64(g[jt][it][s], ub(sV, mt, 4 * jt + s, lo, hi), acc);
       T[it][mt] = acc;
     }
   // ---- W = U^T T, M += W o Phi ---------------------------------------------
-  double ER[NT][4], HR[NT][4], EC[NT], HC[NT];
+  double EC[NT], HC[NT], LC[NT];
 #pragma unroll
   for (int x = 0; x < NT; ++x) {
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      ER[x][r] = tab[32 + ((16 * x + hi + 4 * r) & 31)];
-      HR[x][r] = tab[64 + ((16 * x + hi + 4 * r) & 31)];
-    }
     EC[x] = tab[32 + ((16 * x + lo) & 31)];
     HC[x] = tab[64 + ((16 * x + lo) & 31)];
+    LC[x] = sLam[(16 * x + lo) & 31];
   }
 #pragma unroll
   for (int at = 0; at < NT; ++at)
@@ -210,13 +219,20 @@ __device__ __forceinline__ void small_bucket(const SmallFrags<NT, KS> &f, int S,
       for (int it = 0; it < NT; ++it)
 #pragma unroll
         for (int s = 0; s < 4; ++s)
-          if (4 * it + s < KS) acc = mfma_f64(f.UB[at][4 * it + s], T[it][ct][s], acc);
+          if (4 * it + s < KS) acc = mfma_f64(ub(sV, at, 4 * it + s, lo, hi), T[it][ct][s], acc);
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const double ph = divdiff(tb, f.lamR[at][r], f.lamC[ct], ER[at][r], EC[ct], HR[at][r],
-                                  HC[ct]);
-        M[at][ct][r] = fma(acc[r], ph, M[at][ct][r]);
-      }
+      for (int r = 0; r < 4; ++r)
+        if (SLOT_LIVE(at, r)) {
+          const int ra = (16 * at + hi + 4 * r) & 31;
+          const double ER = tab[32 + ra], HR = tab[64 + ra];
+          // divided difference, branch-free: Taylor form for |z| < 1/2, quotient otherwise
+          const double dl = sLam[ra] - LC[ct];
+          const double z = 0.5 * tb * dl;
+          const bool near = fabs(z) < 0.5;
+          const double taylor = tb * HR * HC[ct] * sinhc_small(near ? z : 0.0);
+          const double quot = (ER - EC[ct]) * fast_rcp(near ? 1.0 : dl);
+          M[at][ct][r] = fma(acc[r], near ? taylor : quot, M[at][ct][r]);
+        }
     }
   wave_lds_fence();  // tab is rewritten by the next bucket
 }
@@ -236,7 +252,7 @@ __device__ __forceinline__ void small_build_A(int S, const double *__restrict__ 
 }
 
 template <int NT, int KS, int NW, int MODE>
-__global__ __launch_bounds__(NW * 64) void small_bank_kernel(SmallArgs a) {
+__global__ __launch_bounds__(NW * 64, 2) void small_bank_kernel(SmallArgs a) {
   extern __shared__ double lds[];
   using LD = SmallLds<NW>;
   double *sA = lds + LD::A, *sG = lds + LD::G, *sV = lds + LD::V, *sLam = lds + LD::LAM,
@@ -244,6 +260,9 @@ __global__ __launch_bounds__(NW * 64) void small_bank_kernel(SmallArgs a) {
   const int l = blockIdx.x, S = a.S, B = a.B;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int lo = lane & 15, hi = lane >> 4;
+#define SB_STAMP(i) \
+  if (a.stamps && blockIdx.x == 0 && threadIdx.x == 0) a.stamps[i] = __builtin_amdgcn_s_memtime();
+  SB_STAMP(0)
 
   if (MODE == SMALL_EIGH) {
     // a.Q holds the symmetric matrices themselves
@@ -253,11 +272,13 @@ __global__ __launch_bounds__(NW * 64) void small_bank_kernel(SmallArgs a) {
   } else {
     small_build_A(S, a.Q + (size_t)l * S * S, a.pi + (size_t)l * S, sA, sD);
   }
+  SB_STAMP(1)
   if (wave == 0) {
     const int sweeps = wave_eigh_rate(S, sA, sG, sV, sLam, CB_LS);
     if (lane == 0 && a.status) a.status[l] = sweeps;
   }
   __syncthreads();
+  SB_STAMP(2)
   if (MODE == SMALL_EIGH) {
     for (int e = threadIdx.x; e < S * S; e += blockDim.x) {
       const int i = e / S, k = e - i * S;
@@ -267,6 +288,13 @@ __global__ __launch_bounds__(NW * 64) void small_bank_kernel(SmallArgs a) {
     return;
   }
 
+  // zero padding of the 32 x 32 eigenvector frame and of lam (operands are read unguarded)
+  for (int e = threadIdx.x; e < 32 * 32; e += blockDim.x) {
+    const int k = e >> 5, i = e & 31;
+    if (k >= S || i >= S) sV[k * CB_LS + i] = 0.0;
+  }
+  for (int k = S + threadIdx.x; k < 32; k += blockDim.x) sLam[k] = 0.0;
+  __syncthreads();
   SmallFrags<NT, KS> f;
   load_frags<NT, KS>(f, sV, sLam, S);
   d4 M[NT][NT];
@@ -281,11 +309,16 @@ __global__ __launch_bounds__(NW * 64) void small_bank_kernel(SmallArgs a) {
   double rho = 0.0;
   for (int i = lane; i < S; i += 64) rho = fmax(rho, fabs(sA[i * CB_LS + i]));
   rho = 2.0 * wave_max(rho);
+  SB_STAMP(3)
+  double cval[NT][NT][4];
+  if (MODE == SMALL_LOSSGRAD && wave < B) load_counts<NT, KS>(cval, S, a.Ct + ((size_t)l * B + wave) * S * S);
   for (int b = wave; b < B; b += NW) {
     const size_t lb = (size_t)l * B + b;
-    small_bucket<NT, KS, MODE>(f, S, a.t[lb], a.Ct + lb * S * S, inv_n, sA, sD, tab, sLam, rho, M,
+    const double *next = (MODE == SMALL_LOSSGRAD && b + NW < B) ? a.Ct + (lb + NW) * S * S : nullptr;
+    small_bucket<NT, KS, MODE>(f, S, a.t[lb], cval, next, inv_n, sA, sD, sV, tab, sLam, rho, M,
                                lossacc, MODE == SMALL_EXPM ? a.P + lb * S * S : nullptr);
   }
+  SB_STAMP(4)
   if (MODE == SMALL_EXPM) return;
 
   // ---- loss ------------------------------------------------------------------
@@ -353,4 +386,6 @@ __global__ __launch_bounds__(NW * 64) void small_bank_kernel(SmallArgs a) {
     for (int k = 0; k < S; ++k) acc = fma(sV[k * CB_LS + i], sA[k * CB_LS + j], acc);
     a.dQ[(size_t)l * S * S + e] = sD[i] * acc / sD[j];
   }
+  SB_STAMP(5)
+#undef SB_STAMP
 }
