@@ -281,7 +281,6 @@ extern "C" int cb_create(int device, int S, int L, int B, const double *t, const
               dev_alloc(h, &h->H, (size_t)B * h->LD) == CB_OK &&
               dev_alloc(h, &h->Gt, (size_t)B * LL) == CB_OK &&
               dev_alloc(h, &h->T, (size_t)B * LL) == CB_OK &&
-              dev_alloc(h, &h->Mt_part, (size_t)h->k3_nchunks * LL) == CB_OK &&
               dev_alloc(h, &h->Mt, LL) == CB_OK && dev_alloc(h, &h->X, LL) == CB_OK &&
               dev_alloc(h, &h->loss_part, (size_t)B * tiles) == CB_OK;
     if (!ok) {
@@ -449,7 +448,7 @@ static int large_loss_grad(cb_bank *h, const double *Qd, const double *pid, bool
   const double inv_n = normalize ? 1.0 / h->n_host[0] : 1.0;
   K1Args k1{S, LD, B, h->Vc, h->A, h->t, h->F, h->sigma, h->Ct, h->Gt, h->loss_part, inv_n, h->dsq, Pd};
   mark(h, EV_END);  // (re-used as "before K1" marker)
-  hipLaunchKernelGGL(k1_pt_loss_gt, dim3(tiles, B), dim3(LG_THREADS), 0, h->stream, k1);
+  hipLaunchKernelGGL(k1_pt_loss_gt, dim3(tiles * B), dim3(LG_THREADS), 0, h->stream, k1);
   mark(h, EV_K1);
   if (Pd) {
     HIP_TRY(hipGetLastError());
@@ -459,13 +458,13 @@ static int large_loss_grad(cb_bank *h, const double *Qd, const double *pid, bool
                      h->dsq, h->dirsum, inv_n, lossd);
   if (dQd) {
     K2Args k2{LD, h->Gt, h->U, h->T};
-    hipLaunchKernelGGL(k2_t_eq_g_u, dim3(tiles, B), dim3(LG_THREADS), 0, h->stream, k2);
+    hipLaunchKernelGGL(k2_t_eq_g_u, dim3(tiles * B), dim3(LG_THREADS), 0, h->stream, k2);
     mark(h, EV_K2);
-    K3Args k3{LD, B, h->k3_chunk, h->T, h->U, h->t, h->lam, h->E, h->H, h->Mt_part};
-    hipLaunchKernelGGL(k3_mt_accum, dim3(tiles, h->k3_nchunks), dim3(LG_THREADS), 0, h->stream, k3);
+    K3Args k3{LD, B, h->T, h->U, h->t, h->lam, h->E, h->H, h->Gt};
+    hipLaunchKernelGGL(k3_w_phi, dim3(tiles * B), dim3(LG_THREADS), 0, h->stream, k3);
     mark(h, EV_K3);
     hipLaunchKernelGGL(k3_reduce, dim3((unsigned)((LL + 255) / 256)), dim3(256), 0, h->stream,
-                       h->Mt_part, h->k3_nchunks, LL, h->Mt);
+                       h->Gt, B, LL, h->Mt);
     K4Args k4a{S, LD, h->Mt, h->Vc, h->X, nullptr, nullptr, nullptr};
     hipLaunchKernelGGL(k4_gemm, dim3(tiles), dim3(LG_THREADS), 0, h->stream, k4a);
     K4Args k4b{S, LD, h->Vc, h->X, dQd, h->dsq, nullptr, nullptr};

@@ -62,6 +62,20 @@ __device__ __forceinline__ double divdiff(double t, double la, double lc, double
   return (Ea - Ec) / dl;
 }
 
+// same value, branch-free and without IEEE division (rotation-grade reciprocal)
+__device__ __forceinline__ double divdiff_fast(double t, double la, double lc, double Ea,
+                                               double Ec, double Ha, double Hc) {
+  const double dl = la - lc;
+  const double z = 0.5 * t * dl;
+  const bool near = fabs(z) < 0.5;
+  const double taylor = t * Ha * Hc * sinhc_small(near ? z : 0.0);
+  double y = __builtin_amdgcn_rcp(near ? 1.0 : dl);
+  const double x = near ? 1.0 : dl;
+  y = fma(fma(-x, y, 1.0), y, y);
+  y = fma(fma(-x, y, 1.0), y, y);
+  return near ? taylor : (Ea - Ec) * y;
+}
+
 // order-preserving map of a non-negative double for atomicMax on u64
 __device__ __forceinline__ unsigned long long dbl_bits(double v) {
   return (unsigned long long)__double_as_longlong(v);

@@ -37,7 +37,9 @@ struct GemmOperands {
 // Loads one K-step (16 rows) of an 80-wide panel into registers:
 // 16 rows x 40 16-byte chunks = 640 chunks, 2 per thread.
 __device__ __forceinline__ void lg_load_panel(const double *__restrict__ P, int ld, int rows_total,
-                                              int cols_total, int k0, int c0, double2 (&reg)[2]) {
+                                              int cols_total, int k0, int c0, double2 (&reg)[2],
+                                              const double *__restrict__ kscale = nullptr,
+                                              double *sc = nullptr) {
 #pragma unroll
   for (int u = 0; u < 2; ++u) {
     const int chunk = threadIdx.x + u * LG_THREADS;  // 0..639
@@ -47,27 +49,30 @@ __device__ __forceinline__ void lg_load_panel(const double *__restrict__ P, int 
       reg[u] = *reinterpret_cast<const double2 *>(P + (size_t)k * ld + c);
     else
       reg[u] = double2{0.0, 0.0};
+    // the row scale travels with the panel (fetching it at LDS-store time exposed a
+    // global-load latency in every K-step)
+    if (kscale) sc[u] = (k < rows_total) ? kscale[k] : 0.0;
   }
 }
 
 __device__ __forceinline__ void lg_store_panel(double *s, const double2 (&reg)[2],
-                                               const double *__restrict__ kscale, int k0,
-                                               int rows_total) {
+                                               const double *sc /* null: unscaled */) {
 #pragma unroll
   for (int u = 0; u < 2; ++u) {
     const int chunk = threadIdx.x + u * LG_THREADS;
     const int kr = chunk / 40, cc = (chunk - kr * 40) * 2;
     double2 v = reg[u];
-    if (kscale) {
-      const double sc = (k0 + kr < rows_total) ? kscale[k0 + kr] : 0.0;
-      v.x *= sc;
-      v.y *= sc;
+    if (sc) {
+      v.x *= sc[u];
+      v.y *= sc[u];
     }
     *reinterpret_cast<double2 *>(s + kr * LG_TM + cc) = v;
   }
 }
 
 // acc[j] (j = 0..4): tile rows m0 + 16*wave + (l>>4) + 4r, cols n0 + 16*j + (l&15)
+// sA / sB hold TWO K-steps each (double buffer): one barrier per K-step; the
+// global loads of step k+1 are in flight during the MFMAs of step k.
 __device__ __forceinline__ void lg_gemm_tile(const GemmOperands &g, int m0, int n0, double *sA,
                                              double *sB, d4 (&acc)[5]) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -75,28 +80,48 @@ __device__ __forceinline__ void lg_gemm_tile(const GemmOperands &g, int m0, int 
 #pragma unroll
   for (int j = 0; j < 5; ++j) acc[j] = d4{0.0, 0.0, 0.0, 0.0};
   double2 ra[2], rb[2];
-  lg_load_panel(g.A, g.lda, g.K, g.M, 0, m0, ra);
-  lg_load_panel(g.B, g.ldb, g.K, g.N, 0, n0, rb);
+  double sc[2];
+  double *scp = g.kscale ? sc : nullptr;
   const int nk = g.K / LG_KT;
+  lg_load_panel(g.A, g.lda, g.K, g.M, 0, m0, ra, g.kscale, sc);
+  lg_load_panel(g.B, g.ldb, g.K, g.N, 0, n0, rb);
+  __syncthreads();  // the previous tile's readers of buffer 0 are done
+  lg_store_panel(sA, ra, scp);
+  lg_store_panel(sB, rb, nullptr);
+  __syncthreads();
   for (int kt = 0; kt < nk; ++kt) {
-    __syncthreads();  // previous step's LDS reads are done
-    lg_store_panel(sA, ra, g.kscale, kt * LG_KT, g.K);
-    lg_store_panel(sB, rb, nullptr, kt * LG_KT, g.K);
-    __syncthreads();
+    const double *cA = sA + (kt & 1) * (LG_KT * LG_TM), *cB = sB + (kt & 1) * (LG_KT * LG_TN);
     if (kt + 1 < nk) {
-      lg_load_panel(g.A, g.lda, g.K, g.M, (kt + 1) * LG_KT, m0, ra);
+      lg_load_panel(g.A, g.lda, g.K, g.M, (kt + 1) * LG_KT, m0, ra, g.kscale, sc);
       lg_load_panel(g.B, g.ldb, g.K, g.N, (kt + 1) * LG_KT, n0, rb);
     }
 #pragma unroll
     for (int s = 0; s < LG_KT / 4; ++s) {
-      const double av = sA[(4 * s + hi) * LG_TM + 16 * wave + lo];
+      const double av = cA[(4 * s + hi) * LG_TM + 16 * wave + lo];
 #pragma unroll
       for (int j = 0; j < 5; ++j) {
-        const double bv = sB[(4 * s + hi) * LG_TN + 16 * j + lo];
+        const double bv = cB[(4 * s + hi) * LG_TN + 16 * j + lo];
         acc[j] = mfma_f64(av, bv, acc[j]);
       }
     }
+    if (kt + 1 < nk) {
+      // buffer (kt+1)&1 was last read in step kt-1; every wave passed the barrier since
+      lg_store_panel(sA + ((kt + 1) & 1) * (LG_KT * LG_TM), ra, scp);
+      lg_store_panel(sB + ((kt + 1) & 1) * (LG_KT * LG_TN), rb, nullptr);
+    }
+    __syncthreads();
   }
+}
+
+// XCD-aware block id: hardware deals consecutive workgroup ids round-robin over the 8
+// XCDs (ids i and i + 8 share an L2).  Remap so that each XCD walks a CONTIGUOUS range
+// of virtual ids: the 25 tiles of one bucket then run on one XCD and share its L2 for
+// the operand panels (measured before: 5.4x the algorithmic bytes left L2).  Bijective
+// for any grid size (guide 5.5 T1).  Speed only, never correctness.
+__device__ __forceinline__ int xcd_swizzle(int id, int n) {
+  const int q = n >> 3, r = n & 7, xcd = id & 7, k = id >> 3;
+  const int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return base + k;
 }
 
 // ------------------------------------------------------------------ K1
@@ -116,22 +141,22 @@ struct K1Args {
 };
 
 __global__ __launch_bounds__(LG_THREADS) void k1_pt_loss_gt(K1Args a) {
-  __shared__ double sA[LG_KT * LG_TM];
-  __shared__ double sB[LG_KT * LG_TN];
-  __shared__ double sRed[5];
-  const int tilesN = (a.LD + LG_TN - 1) / LG_TN;
-  const int b = blockIdx.y;
-  const int tm = blockIdx.x / tilesN, tn = blockIdx.x - tm * tilesN;
+  __shared__ double sA[2 * LG_KT * LG_TM];
+  __shared__ double sB[2 * LG_KT * LG_TN];
+  const int tilesN = (a.LD + LG_TN - 1) / LG_TN, tiles = tilesN * tilesN;
+  const int vid = xcd_swizzle(blockIdx.x, gridDim.x);
+  const int b = vid / tiles, tile = vid - b * tiles;
+  const int tm = tile / tilesN, tn = tile - tm * tilesN;
   const int m0 = tm * LG_TM, n0 = tn * LG_TN;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int lo = lane & 15, hi = lane >> 4;
+  const size_t boff = (size_t)b * a.LD * a.LD;
   GemmOperands g{a.Ut, a.Ut, a.LD, a.LD, a.LD, a.LD, a.LD, a.F + (size_t)b * a.LD};
   d4 acc[5];
   lg_gemm_tile(g, m0, n0, sA, sB, acc);
 
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int lo = lane & 15, hi = lane >> 4;
   const double tb = a.t[b];
   const bool split = tb * 2.0 * (*a.sigma) <= 1.0;  // see small_bank.hip.h
-  const size_t boff = (size_t)b * a.LD * a.LD;
   double lossacc = 0.0;
 #pragma unroll
   for (int j = 0; j < 5; ++j)
@@ -148,22 +173,18 @@ __global__ __launch_bounds__(LG_THREADS) void k1_pt_loss_gt(K1Args a) {
             a.P[(size_t)b * a.S * a.S + (size_t)row * a.S + col] = pt * a.dsq[col] / a.dsq[row];
         } else {
           const double c = a.Ct[boff + idx];
-          double gv = 0.0;
-          if (c != 0.0) {
-            lossacc = fma(-c, log(pt), lossacc);
-            gv = -c * a.inv_n / pt;
-          }
-          a.Gt[boff + idx] = gv;
+          const bool nz = c != 0.0;
+          lossacc = fma(-c, fast_log(nz ? pt : 1.0), lossacc);
+          a.Gt[boff + idx] = nz ? -c * a.inv_n * fast_rcp(pt) : 0.0;
         }
       }
     }
   if (a.P) return;
   lossacc = wave_sum(lossacc);
-  if (lane == 0) sRed[wave] = lossacc;
+  // sA is free after the K loop (lg_gemm_tile ends with a barrier)
+  if (lane == 0) sA[wave] = lossacc;
   __syncthreads();
-  if (threadIdx.x == 0)
-    a.loss_part[(size_t)b * gridDim.x + blockIdx.x] =
-        sRed[0] + sRed[1] + sRed[2] + sRed[3] + sRed[4];
+  if (threadIdx.x == 0) a.loss_part[vid] = sA[0] + sA[1] + sA[2] + sA[3] + sA[4];
 }
 
 // ------------------------------------------------------------------ K2
@@ -175,11 +196,12 @@ struct K2Args {
 };
 
 __global__ __launch_bounds__(LG_THREADS) void k2_t_eq_g_u(K2Args a) {
-  __shared__ double sA[LG_KT * LG_TM];
-  __shared__ double sB[LG_KT * LG_TN];
-  const int tilesN = (a.LD + LG_TN - 1) / LG_TN;
-  const int b = blockIdx.y;
-  const int tm = blockIdx.x / tilesN, tn = blockIdx.x - tm * tilesN;
+  __shared__ double sA[2 * LG_KT * LG_TM];
+  __shared__ double sB[2 * LG_KT * LG_TN];
+  const int tilesN = (a.LD + LG_TN - 1) / LG_TN, tiles = tilesN * tilesN;
+  const int vid = xcd_swizzle(blockIdx.x, gridDim.x);
+  const int b = vid / tiles, tile = vid - b * tiles;
+  const int tm = tile / tilesN, tn = tile - tm * tilesN;
   const int m0 = tm * LG_TM, n0 = tn * LG_TN;
   const size_t boff = (size_t)b * a.LD * a.LD;
   GemmOperands g{a.Gt + boff, a.U, a.LD, a.LD, a.LD, a.LD, a.LD, nullptr};
@@ -197,75 +219,51 @@ __global__ __launch_bounds__(LG_THREADS) void k2_t_eq_g_u(K2Args a) {
 }
 
 // ------------------------------------------------------------------ K3
+// Wt_b[c][a] = Phi_b[c][a] * sum_i T_b[i][c] U[i][a], one (bucket, tile) per workgroup,
+// written over Gt_b (dead once K2 has produced T_b); k3_reduce then sums the buckets
+// in a fixed order.  (A version that kept the running sum over a chunk of buckets in
+// registers needed 2 accumulator sets: 256 VGPRs, one workgroup per CU.)
 struct K3Args {
-  int LD, B, chunk;      // buckets per chunk
+  int LD, B;
   const double *T;       // [B][LD][LD]
   const double *U;       // [LD][LD]
   const double *t;       // [B]
   const double *lam;     // [LD]
   const double *E;       // [B][LD] exp(t lam)
   const double *H;       // [B][LD] exp(t lam / 2)
-  double *Mt_part;       // [nchunks][LD][LD]
+  double *W;             // [B][LD][LD] out (aliases the Gt buffer)
 };
 
-__global__ __launch_bounds__(LG_THREADS) void k3_mt_accum(K3Args a) {
-  __shared__ double sA[LG_KT * LG_TM];
-  __shared__ double sB[LG_KT * LG_TN];
-  const int tilesN = (a.LD + LG_TN - 1) / LG_TN;
-  const int ch = blockIdx.y;
-  const int tm = blockIdx.x / tilesN, tn = blockIdx.x - tm * tilesN;
+__global__ __launch_bounds__(LG_THREADS) void k3_w_phi(K3Args a) {
+  __shared__ double sA[2 * LG_KT * LG_TM];
+  __shared__ double sB[2 * LG_KT * LG_TN];
+  const int tilesN = (a.LD + LG_TN - 1) / LG_TN, tiles = tilesN * tilesN;
+  const int vid = xcd_swizzle(blockIdx.x, gridDim.x);
+  const int b = vid / tiles, tile = vid - b * tiles;
+  const int tm = tile / tilesN, tn = tile - tm * tilesN;
   const int m0 = tm * LG_TM, n0 = tn * LG_TN;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int lo = lane & 15, hi = lane >> 4;
-  // Mt[c][a] = sum_b Phi_b[c][a] * sum_i T_b[i][c] U[i][a] : rows = c, cols = a
-  double lamR[4], lamC[5];
+  const size_t boff = (size_t)b * a.LD * a.LD;
+  GemmOperands g{a.T + boff, a.U, a.LD, a.LD, a.LD, a.LD, a.LD, nullptr};
+  d4 acc[5];
+  lg_gemm_tile(g, m0, n0, sA, sB, acc);
+  const double tb = a.t[b];
+  const double *Eb = a.E + (size_t)b * a.LD, *Hb = a.H + (size_t)b * a.LD;
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int row = m0 + 16 * wave + hi + 4 * r;
-    lamR[r] = row < a.LD ? a.lam[row] : 0.0;
-  }
-#pragma unroll
-  for (int j = 0; j < 5; ++j) {
-    const int col = n0 + 16 * j + lo;
-    lamC[j] = col < a.LD ? a.lam[col] : 0.0;
-  }
-  d4 macc[5];
-#pragma unroll
-  for (int j = 0; j < 5; ++j) macc[j] = d4{0.0, 0.0, 0.0, 0.0};
-  const int b0 = ch * a.chunk, b1 = min(a.B, b0 + a.chunk);
-  for (int b = b0; b < b1; ++b) {
-    const size_t boff = (size_t)b * a.LD * a.LD;
-    GemmOperands g{a.T + boff, a.U, a.LD, a.LD, a.LD, a.LD, a.LD, nullptr};
-    d4 acc[5];
-    lg_gemm_tile(g, m0, n0, sA, sB, acc);
-    const double tb = a.t[b];
-    const double *Eb = a.E + (size_t)b * a.LD, *Hb = a.H + (size_t)b * a.LD;
-    double ER[4], HR[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int row = min(m0 + 16 * wave + hi + 4 * r, a.LD - 1);
-      ER[r] = Eb[row];
-      HR[r] = Hb[row];
-    }
+    if (row >= a.LD) continue;
+    const double lr = a.lam[row], er = Eb[row], hr = Hb[row];
 #pragma unroll
     for (int j = 0; j < 5; ++j) {
-      const int col = min(n0 + 16 * j + lo, a.LD - 1);
-      const double EC = Eb[col], HC = Hb[col];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const double ph = divdiff(tb, lamR[r], lamC[j], ER[r], EC, HR[r], HC);
-        macc[j][r] = fma(acc[j][r], ph, macc[j][r]);
+      const int col = n0 + 16 * j + lo;
+      if (col < a.LD) {
+        const double ph = divdiff_fast(tb, lr, a.lam[col], er, Eb[col], hr, Hb[col]);
+        a.W[boff + (size_t)row * a.LD + col] = acc[j][r] * ph;
       }
     }
   }
-  double *out = a.Mt_part + (size_t)ch * a.LD * a.LD;
-#pragma unroll
-  for (int j = 0; j < 5; ++j)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int row = m0 + 16 * wave + hi + 4 * r, col = n0 + 16 * j + lo;
-      if (row < a.LD && col < a.LD) out[(size_t)row * a.LD + col] = macc[j][r];
-    }
 }
 
 // Mt = sum over chunks (fixed order => bitwise reproducible)
@@ -288,8 +286,8 @@ struct K4Args {
 };
 
 __global__ __launch_bounds__(LG_THREADS) void k4_gemm(K4Args a) {
-  __shared__ double sA[LG_KT * LG_TM];
-  __shared__ double sB[LG_KT * LG_TN];
+  __shared__ double sA[2 * LG_KT * LG_TM];
+  __shared__ double sB[2 * LG_KT * LG_TN];
   const int tilesN = (a.LD + LG_TN - 1) / LG_TN;
   const int tm = blockIdx.x / tilesN, tn = blockIdx.x - tm * tilesN;
   const int m0 = tm * LG_TM, n0 = tn * LG_TN;
