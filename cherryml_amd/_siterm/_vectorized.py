@@ -63,7 +63,7 @@ def _site_Q(theta: torch.Tensor, Theta: torch.Tensor, upper: torch.Tensor):
 
 def quantized_transitions_mle_vectorized_over_sites(
     counts: np.ndarray, times, num_epochs: int, initialization: Optional[np.ndarray] = None,
-    num_cores: int = 1, device: str = "cpu",
+    num_cores: int = 1, device: str = "cpu", fused: bool = True,
 ) -> Dict:
     prof = {}
     st = time.time()
@@ -91,9 +91,28 @@ def quantized_transitions_mle_vectorized_over_sites(
     if initialization is not None:
         a, b = _invert(np.asarray(initialization, dtype=np.float64))
         theta0, Theta0 = torch.tensor(a), torch.tensor(b)
+    upper = torch.triu(torch.ones(N, N, dtype=torch.float64, device=dev), diagonal=1)
+    if fused and N <= 32:
+        # every site runs its whole optimisation in one workgroup of one kernel launch
+        with torch.no_grad():
+            Q0 = _site_Q(theta0.to(dev), Theta0.to(dev), upper)[0].cpu().numpy()
+        if initialization is not None:
+            np.testing.assert_almost_equal(Q0, initialization, decimal=3)
+        prof["time_initialize_model"] = time.time() - st
+        st = time.time()
+        try:
+            r = bank.train_siterm(theta0.numpy(), Theta0.numpy(), num_epochs, lr=0.1)
+        finally:
+            bank.close()
+        lp = r["loss_per_epoch_per_site"]
+        logger.info(f"Optimization complete. Time: {time.time() - st}")
+        out = {"res": r["res"] if num_epochs > 0 else Q0, "loss_per_epoch": lp.sum(axis=1),
+               "loss_per_epoch_per_site": lp, "time_zero_grad": 0.0, "time_get_Q": 0.0,
+               "time_compute_loss": time.time() - st, "time_cpu_loss_analysis": 0.0,
+               "time_backwards": 0.0, "time_optimizer_step": 0.0, "time_initialize_tensors": 0.0}
+        return {**out, **prof}
     theta = theta0.to(dev).requires_grad_(True)
     Theta = Theta0.to(dev).requires_grad_(True)
-    upper = torch.triu(torch.ones(N, N, dtype=torch.float64, device=dev), diagonal=1)
     if initialization is not None:
         with torch.no_grad():
             np.testing.assert_almost_equal(_site_Q(theta, Theta, upper)[0].cpu().numpy(),

@@ -153,6 +153,40 @@ class CherryBank:
                    "cb_eigh")
         return lam, U
 
+    # -- fused device-side optimisers (S <= 32) --------------------------------
+    def train_pande_reversible(self, upper_diag, log_pi, mask=None, num_epochs=2000, lr=0.1,
+                               do_adam=True, normalize=True):
+        """All epochs of the reference loop (trainer.py:156-218) in one kernel launch.
+        Returns dict(loss[E], Q_best, Q_last, Q_pow2 {epoch: Q}, upper_diag, log_pi)."""
+        S, E = self.S, int(num_epochs)
+        up = _as_f64(upper_diag, (S * (S - 1) // 2,)).copy()
+        lp = _as_f64(log_pi, (S,)).copy()
+        mk = None if mask is None else _as_f64(mask, (S, S))
+        n_pow2 = max(E, 1).bit_length() if E > 0 else 0
+        loss = np.zeros(E)
+        Qb, Ql = np.zeros((S, S)), np.zeros((S, S))
+        Qp = np.zeros((max(n_pow2, 1), S, S))
+        rc = _lib.load().cb_train_pande_reversible(
+            self._h, up.ctypes.data, lp.ctypes.data, None if mk is None else mk.ctypes.data, E,
+            float(lr), int(bool(do_adam)), CB_NORMALIZE if normalize else 0, loss.ctypes.data,
+            Qb.ctypes.data, Ql.ctypes.data, Qp.ctypes.data, n_pow2)
+        _lib.check(rc, "cb_train_pande_reversible")
+        snaps = {1 << i: Qp[i] for i in range(n_pow2) if (1 << i) <= E}
+        return dict(loss=loss, Q_best=Qb, Q_last=Ql, Q_pow2=snaps, upper_diag=up, log_pi=lp)
+
+    def train_siterm(self, theta, Theta, num_epochs, lr=0.1):
+        """SiteRM loop (_cherryml_vectorized.py:351-383) for all sites in one launch.
+        Returns dict(res[L,N,N] best Q per site, loss_per_epoch_per_site[E,L], theta, Theta)."""
+        L, N, E = self.L, self.S, int(num_epochs)
+        th = _as_f64(theta, (L, N)).copy()
+        Th = _as_f64(Theta, (L, N, N)).copy()
+        res = np.zeros((L, N, N))
+        lpeps = np.zeros((max(E, 1), L))
+        rc = _lib.load().cb_train_siterm(self._h, th.ctypes.data, Th.ctypes.data, E, float(lr), 0,
+                                         res.ctypes.data, lpeps.ctypes.data)
+        _lib.check(rc, "cb_train_siterm")
+        return dict(res=res, loss_per_epoch_per_site=lpeps[:E], theta=th, Theta=Th)
+
     # -- device-pointer API (torch ROCm tensors, zero copy) -----------------
     def loss_grad_torch(self, Q, pi, normalize: bool = True, want_grad: bool = True):
         """Q[L,S,S] / pi[L,S] float64 tensors on this bank's device; returns

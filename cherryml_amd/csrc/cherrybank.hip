@@ -16,6 +16,7 @@
 #include "jacobi_wave.hip.h"
 #include "large_bank.hip.h"
 #include "small_bank.hip.h"
+#include "train_small.hip.h"
 
 #define CB_ABI_VERSION 1
 
@@ -519,23 +520,8 @@ extern "C" int cb_loss_grad(cb_handle h, const double *Q, const double *pi, int 
     a.loss = lossd;
     a.dQ = dQd;
     a.status = h->status;
-    unsigned long long *dbg = nullptr;
-    if (getenv("CB_DEBUG_STAMPS")) {
-      HIP_TRY(hipMalloc((void **)&dbg, 8 * sizeof(unsigned long long)));
-      a.stamps = dbg;
-    }
     rc = launch_small<SMALL_LOSSGRAD>(h, a);
     mark(h, EV_SMALL);
-    if (dbg) {
-      unsigned long long st[8];
-      HIP_TRY(hipStreamSynchronize(h->stream));
-      HIP_TRY(hipMemcpy(st, dbg, sizeof st, hipMemcpyDeviceToHost));
-      (void)hipFree(dbg);
-      const char *names[] = {"build A", "eigh", "frags", "buckets", "epilogue"};
-      for (int i = 0; i < 5; ++i)
-        fprintf(stderr, "[cherrybank] small kernel %-9s %8llu cycles\n", names[i], st[i + 1] - st[i]);
-      fprintf(stderr, "[cherrybank] eigh sweeps (site 0): see status; B=%d\n", h->B);
-    }
   }
   if (rc != CB_OK) return rc;
   if (h->profile) h->t_pending = true;
@@ -661,20 +647,117 @@ extern "C" int cb_loss_grad_general(cb_handle h, const double *Q, int flags, dou
   return fail(CB_EUNSUPPORTED, "cb_loss_grad_general: not built yet (non-reversible path)");
 }
 
+// ------------------------------------------------------------- fused trainers
+template <int NW>
+static int launch_train_nw(cb_bank *h, const TrainArgs &a) {
+  const size_t lds = (SmallLds<NW>::TOTAL + 72) * sizeof(double);
+  const int S = h->S;
+#define LAUNCH(NT, KS)                                                                          \
+  do {                                                                                          \
+    auto kern = small_train_kernel<NT, KS, NW>;                                                 \
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),                           \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));         \
+    hipLaunchKernelGGL(kern, dim3(h->L), dim3(NW * 64), lds, h->stream, a);                     \
+  } while (0)
+  if (S <= 4) LAUNCH(1, 1);
+  else if (S <= 8) LAUNCH(1, 2);
+  else if (S <= 16) LAUNCH(1, 4);
+  else if (S <= 20) LAUNCH(2, 5);
+  else if (S <= 24) LAUNCH(2, 6);
+  else LAUNCH(2, 8);
+#undef LAUNCH
+  HIP_TRY(hipGetLastError());
+  return CB_OK;
+}
+
+// shared host driver: parameters in, E epochs on the device, results out
+static int run_fused_training(cb_bank *h, int kind, double *pi_param, double *up_param,
+                              const double *mask, int E, double lr, int do_adam, int flags,
+                              double *loss_curve, double *Q_best, double *Q_last, double *Q_pow2,
+                              int n_pow2) {
+  if (h->large) return fail(CB_EUNSUPPORTED, "fused training: S <= 32 only (S = %d)", h->S);
+  if (E < 0) return fail(CB_EINVAL, "fused training: num_epochs < 0");
+  HIP_TRY(hipSetDevice(h->dev));
+  const int S = h->S, L = h->L;
+  const size_t SS = (size_t)S * S, nup = kind == 0 ? (size_t)S * (S - 1) / 2 : SS;
+  double *d_pi = nullptr, *d_up = nullptr, *d_mom = nullptr, *d_mask = nullptr, *d_loss = nullptr,
+         *d_Qb = nullptr, *d_Ql = nullptr, *d_Qp = nullptr;
+  std::vector<void *> tmp;
+  auto alloc = [&](double **p, size_t n) -> bool {
+    if (hipMalloc((void **)p, (n ? n : 1) * sizeof(double)) != hipSuccess) return false;
+    tmp.push_back(*p);
+    return true;
+  };
+  auto release = [&]() {
+    (void)hipStreamSynchronize(h->stream);
+    for (void *p : tmp) (void)hipFree(p);
+  };
+  const size_t nmom = 2 * ((size_t)L * S + (size_t)L * nup);
+  bool ok = alloc(&d_pi, (size_t)L * S) && alloc(&d_up, L * nup) && alloc(&d_mom, nmom) &&
+            alloc(&d_loss, (size_t)E * L) && alloc(&d_Qb, L * SS) && alloc(&d_Ql, L * SS) &&
+            (!mask || alloc(&d_mask, SS)) && (!(Q_pow2 && n_pow2 > 0) || alloc(&d_Qp, n_pow2 * SS));
+  if (!ok) {
+    release();
+    return fail(CB_ENOMEM, "fused training: device allocation failed");
+  }
+  int rc = CB_OK;
+#define TRYH(expr)                                                                  \
+  if (rc == CB_OK && (expr) != hipSuccess) rc = fail(CB_EHIP, "%s failed", #expr)
+  TRYH(hipMemcpyAsync(d_pi, pi_param, (size_t)L * S * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  TRYH(hipMemcpyAsync(d_up, up_param, L * nup * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  TRYH(hipMemsetAsync(d_mom, 0, nmom * sizeof(double), h->stream));
+  TRYH(hipMemsetAsync(d_Qb, 0, L * SS * sizeof(double), h->stream));
+  TRYH(hipMemsetAsync(d_Ql, 0, L * SS * sizeof(double), h->stream));
+  if (mask) TRYH(hipMemcpyAsync(d_mask, mask, SS * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  if (rc == CB_OK) {
+    TrainArgs a{};
+    a.S = S; a.L = L; a.B = h->B; a.E = E; a.kind = kind; a.do_adam = do_adam; a.n_pow2 = d_Qp ? n_pow2 : 0;
+    a.t = h->t; a.Ct = h->Ct; a.inv_n = (flags & CB_NORMALIZE) ? h->inv_n : h->ones; a.dirsum = h->dirsum;
+    a.p_pi = d_pi; a.p_up = d_up;
+    a.m_pi = d_mom; a.v_pi = d_mom + (size_t)L * S;
+    a.m_up = d_mom + 2 * (size_t)L * S; a.v_up = a.m_up + L * nup;
+    a.mask = d_mask; a.lr = lr; a.beta1 = 0.9; a.beta2 = 0.999; a.eps = 1e-8;
+    a.loss_curve = d_loss; a.Q_best = d_Qb; a.Q_last = d_Ql; a.Q_pow2 = d_Qp;
+    if (E > 0) rc = (L < 512) ? launch_train_nw<8>(h, a) : launch_train_nw<4>(h, a);
+  }
+  TRYH(hipMemcpyAsync(pi_param, d_pi, (size_t)L * S * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  TRYH(hipMemcpyAsync(up_param, d_up, L * nup * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  if (loss_curve && E > 0)
+    TRYH(hipMemcpyAsync(loss_curve, d_loss, (size_t)E * L * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  if (Q_best) TRYH(hipMemcpyAsync(Q_best, d_Qb, L * SS * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  if (Q_last) TRYH(hipMemcpyAsync(Q_last, d_Ql, L * SS * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  if (d_Qp) TRYH(hipMemcpyAsync(Q_pow2, d_Qp, n_pow2 * SS * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  TRYH(hipStreamSynchronize(h->stream));
+  if (rc == CB_OK) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) rc = fail(CB_EHIP, "fused training kernel failed: %s", hipGetErrorString(e));
+  }
+#undef TRYH
+  release();
+  return rc;
+}
+
 extern "C" int cb_train_pande_reversible(cb_handle h, double *upper_diag, double *log_pi,
                                          const double *mask, int num_epochs, double lr, int do_adam,
                                          int flags, double *loss_curve, double *Q_best,
                                          double *Q_last, double *Q_pow2, int n_pow2) {
-  (void)h; (void)upper_diag; (void)log_pi; (void)mask; (void)num_epochs; (void)lr; (void)do_adam;
-  (void)flags; (void)loss_curve; (void)Q_best; (void)Q_last; (void)Q_pow2; (void)n_pow2;
-  return fail(CB_EUNSUPPORTED, "cb_train_pande_reversible: not built yet");
+  if (!h || !upper_diag || !log_pi) return fail(CB_EINVAL, "cb_train_pande_reversible: NULL argument");
+  if (h->L != 1) return fail(CB_EUNSUPPORTED, "cb_train_pande_reversible: L == 1 banks only");
+  if (mask)
+    for (int i = 0; i < h->S; ++i)
+      for (int j = 0; j < i; ++j)
+        if (mask[i * h->S + j] != mask[j * h->S + i])
+          return fail(CB_EUNSUPPORTED, "cb_train_pande_reversible: mask must be symmetric "
+                                       "(a non-symmetric mask makes Q non-reversible)");
+  return run_fused_training(h, 0, log_pi, upper_diag, mask, num_epochs, lr, do_adam, flags,
+                            loss_curve, Q_best, Q_last, Q_pow2, n_pow2);
 }
 
 extern "C" int cb_train_siterm(cb_handle h, double *theta, double *Theta, int num_epochs, double lr,
                                int flags, double *res, double *loss_per_epoch_per_site) {
-  (void)h; (void)theta; (void)Theta; (void)num_epochs; (void)lr; (void)flags; (void)res;
-  (void)loss_per_epoch_per_site;
-  return fail(CB_EUNSUPPORTED, "cb_train_siterm: not built yet");
+  if (!h || !theta || !Theta) return fail(CB_EINVAL, "cb_train_siterm: NULL argument");
+  return run_fused_training(h, 1, theta, Theta, nullptr, num_epochs, lr, 1, flags | CB_NORMALIZE,
+                            loss_per_epoch_per_site, res, nullptr, nullptr, 0);
 }
 
 static int read_phase_times(cb_bank *h, double (&v)[CB_T_COUNT]);

@@ -35,7 +35,6 @@ struct SmallArgs {
   double *lam_out;    // [L,S] (eigh mode) or null
   double *U_out;      // [L,S,S] (eigh mode) or null
   int *status;        // [L] sweeps used by the eigensolver
-  unsigned long long *stamps;  // diagnostic s_memtime stamps (block 0) or null
 };
 
 // LDS carve-up (doubles)
@@ -50,7 +49,8 @@ struct SmallLds {
   static constexpr int TAB = D + 32;          // per wave: F[32], E[32], H[32]
   static constexpr int RED = TAB + NW * 96;   // (NW/2) * 1024 reduction slots (min 1)
   static constexpr int LOSS = RED + ((NW / 2) > 0 ? (NW / 2) : 1) * 1024;
-  static constexpr int TOTAL = LOSS + NW;
+  static constexpr int LOSSTOT = LOSS + NW;
+  static constexpr int TOTAL = LOSSTOT + 1;
 };
 
 enum { SMALL_LOSSGRAD = 0, SMALL_EXPM = 1, SMALL_EIGH = 2 };
@@ -251,43 +251,29 @@ __device__ __forceinline__ void small_build_A(int S, const double *__restrict__ 
   __syncthreads();
 }
 
+// ---- one site: A (LDS) -> loss, dL/dA (LDS) -----------------------------------
+// Precondition : sA = A (symmetric, stride CB_LS), sD = sqrt(pi); all threads call.
+// Postcondition: lds[LD::LOSS + NW - 1 ... ] unchanged; returns nothing, but
+//   lds[LD::TOTAL - 1]  (slot "LOSSTOT") = loss of the site (thread 0 wrote it),
+//   sG = dL/dA (free S x S matrix) when want_grad, sV / sLam = eigenvectors / values.
+// Ends with a barrier.
 template <int NT, int KS, int NW, int MODE>
-__global__ __launch_bounds__(NW * 64, 2) void small_bank_kernel(SmallArgs a) {
-  extern __shared__ double lds[];
+__device__ __forceinline__ void small_site_eval(double *lds, int S, int B,
+                                                const double *__restrict__ t_l,
+                                                const double *__restrict__ Ct_l, double inv_n,
+                                                const double *__restrict__ dirsum_l,
+                                                double *__restrict__ P_l, bool want_grad,
+                                                int *sweeps_out) {
   using LD = SmallLds<NW>;
   double *sA = lds + LD::A, *sG = lds + LD::G, *sV = lds + LD::V, *sLam = lds + LD::LAM,
          *sD = lds + LD::D;
-  const int l = blockIdx.x, S = a.S, B = a.B;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int lo = lane & 15, hi = lane >> 4;
-#define SB_STAMP(i) \
-  if (a.stamps && blockIdx.x == 0 && threadIdx.x == 0) a.stamps[i] = __builtin_amdgcn_s_memtime();
-  SB_STAMP(0)
-
-  if (MODE == SMALL_EIGH) {
-    // a.Q holds the symmetric matrices themselves
-    for (int e = threadIdx.x; e < S * S; e += blockDim.x)
-      sA[(e / S) * CB_LS + (e % S)] = a.Q[(size_t)l * S * S + e];
-    __syncthreads();
-  } else {
-    small_build_A(S, a.Q + (size_t)l * S * S, a.pi + (size_t)l * S, sA, sD);
-  }
-  SB_STAMP(1)
   if (wave == 0) {
     const int sweeps = wave_eigh_rate(S, sA, sG, sV, sLam, CB_LS);
-    if (lane == 0 && a.status) a.status[l] = sweeps;
+    if (lane == 0 && sweeps_out) *sweeps_out = sweeps;
   }
   __syncthreads();
-  SB_STAMP(2)
-  if (MODE == SMALL_EIGH) {
-    for (int e = threadIdx.x; e < S * S; e += blockDim.x) {
-      const int i = e / S, k = e - i * S;
-      a.U_out[(size_t)l * S * S + e] = sV[k * CB_LS + i];
-    }
-    for (int k = threadIdx.x; k < S; k += blockDim.x) a.lam_out[(size_t)l * S + k] = sLam[k];
-    return;
-  }
-
   // zero padding of the 32 x 32 eigenvector frame and of lam (operands are read unguarded)
   for (int e = threadIdx.x; e < 32 * 32; e += blockDim.x) {
     const int k = e >> 5, i = e & 31;
@@ -303,22 +289,19 @@ __global__ __launch_bounds__(NW * 64, 2) void small_bank_kernel(SmallArgs a) {
 #pragma unroll
     for (int y = 0; y < NT; ++y) M[x][y] = d4{0.0, 0.0, 0.0, 0.0};
   double lossacc = 0.0;
-  const double inv_n = a.inv_n[l];
   double *tab = lds + LD::TAB + wave * 96;
   // Gershgorin: |lam| <= 2 max |A_ii| for a symmetrised rate matrix
   double rho = 0.0;
   for (int i = lane; i < S; i += 64) rho = fmax(rho, fabs(sA[i * CB_LS + i]));
   rho = 2.0 * wave_max(rho);
-  SB_STAMP(3)
   double cval[NT][NT][4];
-  if (MODE == SMALL_LOSSGRAD && wave < B) load_counts<NT, KS>(cval, S, a.Ct + ((size_t)l * B + wave) * S * S);
+  if (MODE == SMALL_LOSSGRAD && wave < B) load_counts<NT, KS>(cval, S, Ct_l + (size_t)wave * S * S);
   for (int b = wave; b < B; b += NW) {
-    const size_t lb = (size_t)l * B + b;
-    const double *next = (MODE == SMALL_LOSSGRAD && b + NW < B) ? a.Ct + (lb + NW) * S * S : nullptr;
-    small_bucket<NT, KS, MODE>(f, S, a.t[lb], cval, next, inv_n, sA, sD, sV, tab, sLam, rho, M,
-                               lossacc, MODE == SMALL_EXPM ? a.P + lb * S * S : nullptr);
+    const double *next =
+        (MODE == SMALL_LOSSGRAD && b + NW < B) ? Ct_l + (size_t)(b + NW) * S * S : nullptr;
+    small_bucket<NT, KS, MODE>(f, S, t_l[b], cval, next, inv_n, sA, sD, sV, tab, sLam, rho, M,
+                               lossacc, MODE == SMALL_EXPM ? P_l + (size_t)b * S * S : nullptr);
   }
-  SB_STAMP(4)
   if (MODE == SMALL_EXPM) return;
 
   // ---- loss ------------------------------------------------------------------
@@ -326,39 +309,41 @@ __global__ __launch_bounds__(NW * 64, 2) void small_bank_kernel(SmallArgs a) {
   if (lane == 0) lds[LD::LOSS + wave] = lossacc;
   // ---- deterministic tree reduction of M over the waves -----------------------
   double *red = lds + LD::RED;
-  for (int stride = NW / 2; stride >= 1; stride >>= 1) {
-    if (wave >= stride && wave < 2 * stride) {
-      double *dst = red + (wave - stride) * 1024;
+  if (want_grad) {
+    for (int stride = NW / 2; stride >= 1; stride >>= 1) {
+      if (wave >= stride && wave < 2 * stride) {
+        double *dst = red + (wave - stride) * 1024;
+#pragma unroll
+        for (int x = 0; x < NT; ++x)
+#pragma unroll
+          for (int y = 0; y < NT; ++y)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) dst[((x * NT + y) * 4 + r) * 64 + lane] = M[x][y][r];
+      }
+      __syncthreads();
+      if (wave < stride) {
+        const double *src = red + wave * 1024;
+#pragma unroll
+        for (int x = 0; x < NT; ++x)
+#pragma unroll
+          for (int y = 0; y < NT; ++y)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) M[x][y][r] += src[((x * NT + y) * 4 + r) * 64 + lane];
+      }
+      __syncthreads();
+    }
+    // M (wave 0) -> LDS frame sG[a][c]
+    if (wave == 0) {
 #pragma unroll
       for (int x = 0; x < NT; ++x)
 #pragma unroll
         for (int y = 0; y < NT; ++y)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) dst[((x * NT + y) * 4 + r) * 64 + lane] = M[x][y][r];
+          for (int r = 0; r < 4; ++r) {
+            const int ra = 16 * x + hi + 4 * r, c = 16 * y + lo;
+            if (ra < 32 && c < 32) sG[ra * CB_LS + c] = M[x][y][r];
+          }
     }
-    __syncthreads();
-    if (wave < stride) {
-      const double *src = red + wave * 1024;
-#pragma unroll
-      for (int x = 0; x < NT; ++x)
-#pragma unroll
-        for (int y = 0; y < NT; ++y)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) M[x][y][r] += src[((x * NT + y) * 4 + r) * 64 + lane];
-    }
-    __syncthreads();
-  }
-  // M (wave 0) -> LDS frame sG[a][c]
-  if (wave == 0) {
-#pragma unroll
-    for (int x = 0; x < NT; ++x)
-#pragma unroll
-      for (int y = 0; y < NT; ++y)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int ra = 16 * x + hi + 4 * r, c = 16 * y + lo;
-          if (ra < 32 && c < 32) sG[ra * CB_LS + c] = M[x][y][r];
-        }
   }
   __syncthreads();
   if (threadIdx.x == 0) {
@@ -366,26 +351,70 @@ __global__ __launch_bounds__(NW * 64, 2) void small_bank_kernel(SmallArgs a) {
     for (int w = 0; w < NW; ++w) tot += lds[LD::LOSS + w];
     // direct pi term: -(1/n) sum_k log d_k (colsum_k - rowsum_k)
     double dir = 0.0;
-    for (int k = 0; k < S; ++k) dir = fma(log(sD[k]), a.dirsum[(size_t)l * S + k], dir);
-    a.loss[l] = (tot - dir) * inv_n;
+    for (int k = 0; k < S; ++k) dir = fma(log(sD[k]), dirsum_l[k], dir);
+    lds[LD::LOSSTOT] = (tot - dir) * inv_n;
   }
-  if (a.dQ == nullptr) return;
-  // ---- X = M U^T  (X[a][j] = sum_c M[a][c] U[j][c]) into sA -------------------
-  // all bucket work is done: sA is free
+  if (!want_grad) {
+    __syncthreads();
+    return;
+  }
+  // ---- X = M U^T  (X[a][j] = sum_c M[a][c] U[j][c]) into the TAB/RED scratch ----
+  // (sA must survive for the caller: the trainers read A_ii afterwards)
+  double *sX = lds + LD::RED;  // >= 1024 doubles, free after the reduction
   for (int e = threadIdx.x; e < S * S; e += blockDim.x) {
     const int ra = e / S, j = e - ra * S;
     double acc = 0.0;
     for (int c = 0; c < S; ++c) acc = fma(sG[ra * CB_LS + c], sV[c * CB_LS + j], acc);
-    sA[ra * CB_LS + j] = acc;
+    sX[ra * 32 + j] = acc;
   }
   __syncthreads();
-  // ---- dA = U X ; dQ = D^1/2 dA D^-1/2 ------------------------------------------
+  // ---- dA = U X into sG ----------------------------------------------------------
   for (int e = threadIdx.x; e < S * S; e += blockDim.x) {
     const int i = e / S, j = e - i * S;
     double acc = 0.0;
-    for (int k = 0; k < S; ++k) acc = fma(sV[k * CB_LS + i], sA[k * CB_LS + j], acc);
-    a.dQ[(size_t)l * S * S + e] = sD[i] * acc / sD[j];
+    for (int k = 0; k < S; ++k) acc = fma(sV[k * CB_LS + i], sX[k * 32 + j], acc);
+    sG[i * CB_LS + j] = acc;
   }
-  SB_STAMP(5)
-#undef SB_STAMP
+  __syncthreads();
+}
+
+template <int NT, int KS, int NW, int MODE>
+__global__ __launch_bounds__(NW * 64, 2) void small_bank_kernel(SmallArgs a) {
+  extern __shared__ double lds[];
+  using LD = SmallLds<NW>;
+  double *sA = lds + LD::A, *sG = lds + LD::G, *sV = lds + LD::V, *sLam = lds + LD::LAM,
+         *sD = lds + LD::D;
+  const int l = blockIdx.x, S = a.S, B = a.B;
+
+  if (MODE == SMALL_EIGH) {
+    // a.Q holds the symmetric matrices themselves
+    for (int e = threadIdx.x; e < S * S; e += blockDim.x)
+      sA[(e / S) * CB_LS + (e % S)] = a.Q[(size_t)l * S * S + e];
+    __syncthreads();
+    if (threadIdx.x < 64) {
+      const int sweeps = wave_eigh_rate(S, sA, sG, sV, sLam, CB_LS);
+      if (threadIdx.x == 0 && a.status) a.status[l] = sweeps;
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < S * S; e += blockDim.x) {
+      const int i = e / S, k = e - i * S;
+      a.U_out[(size_t)l * S * S + e] = sV[k * CB_LS + i];
+    }
+    for (int k = threadIdx.x; k < S; k += blockDim.x) a.lam_out[(size_t)l * S + k] = sLam[k];
+    return;
+  }
+  small_build_A(S, a.Q + (size_t)l * S * S, a.pi + (size_t)l * S, sA, sD);
+  const size_t lb = (size_t)l * B;
+  small_site_eval<NT, KS, NW, MODE>(lds, S, B, a.t + lb, a.Ct + lb * S * S, a.inv_n[l],
+                                    a.dirsum + (size_t)l * S,
+                                    MODE == SMALL_EXPM ? a.P + lb * S * S : nullptr,
+                                    a.dQ != nullptr, a.status ? a.status + l : nullptr);
+  if (MODE == SMALL_EXPM) return;
+  if (threadIdx.x == 0) a.loss[l] = lds[LD::LOSSTOT];
+  if (a.dQ == nullptr) return;
+  // dQ = D^1/2 dA D^-1/2
+  for (int e = threadIdx.x; e < S * S; e += blockDim.x) {
+    const int i = e / S, j = e - i * S;
+    a.dQ[(size_t)l * S * S + e] = sD[i] * sG[i * CB_LS + j] / sD[j];
+  }
 }

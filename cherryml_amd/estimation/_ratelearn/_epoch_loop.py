@@ -26,10 +26,52 @@ def _snapshot(Q: torch.Tensor) -> np.ndarray:
     return Q.detach().cpu().numpy().copy()
 
 
+def _fusable(rate_module, optimizer, Q_true, m) -> bool:
+    """The whole loop can run in one kernel (cb_train_pande_reversible) when nothing but
+    the reference's standard configuration is asked for."""
+    if rate_module.mode != "pande_reversible" or rate_module.num_states > 32:
+        return False
+    if Q_true is not None or m != 1.0 or not rate_module._pi.requires_grad:
+        return False
+    if len(optimizer.param_groups) != 1 or optimizer.state:
+        return False
+    g = optimizer.param_groups[0]
+    if isinstance(optimizer, torch.optim.Adam):
+        return (tuple(g["betas"]) == (0.9, 0.999) and g["eps"] == 1e-8 and g["weight_decay"] == 0
+                and not g["amsgrad"] and not g.get("maximize", False))
+    if isinstance(optimizer, torch.optim.SGD):
+        return (g["momentum"] == 0 and g["weight_decay"] == 0 and not g["nesterov"]
+                and not g.get("maximize", False))
+    return False
+
+
+def _train_fused(rate_module, bank, optimizer, num_epochs, loss_normalization, return_best_iter):
+    g = optimizer.param_groups[0]
+    start = time.time()
+    r = bank.train_pande_reversible(
+        rate_module.upper_diag.detach().cpu().numpy(), rate_module._pi.detach().cpu().numpy(),
+        mask=rate_module.mask.detach().cpu().numpy(), num_epochs=num_epochs, lr=g["lr"],
+        do_adam=isinstance(optimizer, torch.optim.Adam), normalize=loss_normalization)
+    elapsed = time.time() - start
+    with torch.no_grad():  # leave the module at the final parameters, like the torch loop does
+        rate_module.upper_diag.copy_(torch.as_tensor(r["upper_diag"]))
+        rate_module._pi.copy_(torch.as_tensor(r["log_pi"]))
+    E = num_epochs
+    rows = [(0.0, 0.0, float(r["loss"][e]), elapsed * (e + 1) / max(E, 1), e, 0.0, 0.0)
+            for e in range(E)]
+    Q_dict = {f"Q_{k}": v.copy() for k, v in r["Q_pow2"].items()}
+    if E > 0:
+        Q_dict["Q_best"] = r["Q_best"].copy()
+        Q_dict["Q_last"] = r["Q_last"].copy()
+        Q_dict["result"] = (r["Q_best"] if return_best_iter else r["Q_last"]).copy()
+    return rows, Q_dict
+
+
 def train_quantization(rate_module, quantized_dataset, m=1.0, lr=1e-1, num_epochs=2000,
                        Q_true=None, optimizer=None, loss_normalization: bool = True,
                        return_best_iter: bool = True,
-                       bank: Optional[CherryBank] = None) -> Tuple[pd.DataFrame, Dict]:
+                       bank: Optional[CherryBank] = None,
+                       fused: Optional[bool] = None) -> Tuple[pd.DataFrame, Dict]:
     """Full-batch optimisation of `rate_module` on a TensorDataset(qtimes, cmats).
 
     Returns (df_res, Q_dict) exactly like the reference: per-epoch rows
@@ -59,8 +101,17 @@ def train_quantization(rate_module, quantized_dataset, m=1.0, lr=1e-1, num_epoch
     rows = []
     best_loss, Q_best, Q = None, None, None
     start = time.time()
+    use_fused = _fusable(rate_module, optimizer, Q_true, m) if fused is None else fused
     try:
-        for epoch in range(num_epochs):
+        if use_fused:
+            # S <= 32: the problem is launch-latency bound, so the WHOLE loop (theta -> Q,
+            # bank, gradient, best-iterate bookkeeping, Adam) runs in one kernel launch.
+            rows, Q_dict = _train_fused(rate_module, bank, optimizer, num_epochs,
+                                        loss_normalization, return_best_iter)
+            num_epochs_torch = 0
+        else:
+            num_epochs_torch = num_epochs
+        for epoch in range(num_epochs_torch):
             optimizer.zero_grad()
             Q = rate_module()
             loss = bank_loss(Q, rate_module.stationary(), bank, normalize=loss_normalization)[0]
@@ -86,7 +137,7 @@ def train_quantization(rate_module, quantized_dataset, m=1.0, lr=1e-1, num_epoch
     df_res = pd.DataFrame(rows, columns=["nuc_norm", "frob_norm", "loss", "time", "epoch",
                                          "frob_norm_diag", "frob_norm_offdiag"])
     logger.info(f"Total time = {time.time() - start}")
-    if num_epochs > 0:
+    if num_epochs > 0 and not use_fused:
         Q_dict["Q_best"] = Q_best.copy()
         Q_dict["Q_last"] = _snapshot(Q)
         Q_dict["result"] = Q_best.copy() if return_best_iter else _snapshot(Q)

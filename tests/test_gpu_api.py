@@ -148,3 +148,75 @@ def test_siterm_vectorized_matches_reference():
     r = qvec(g["counts"], g["times"], num_epochs=g["lpe_rand"].shape[0], device="cuda")
     assert np.allclose(r["loss_per_epoch_per_site"], g["lpeps_rand"], rtol=1e-4, atol=0)
     assert relerr(r["res"], g["res_rand"]) < 1e-3
+
+
+@pytest.mark.parametrize("case", ["toy3_init", "toy3_mask", "s20_symmask", "lgbank"])
+def test_fused_trainer_matches_oracle_and_torch_glue_path(case):
+    """cb_train_pande_reversible (whole loop in one kernel) vs the oracle's f64 trajectory,
+    and vs the torch-glue path of the same package."""
+    from cherryml_amd import CherryBank, RateMatrix, train_quantization
+    from oracle import ratelearn_oracle as orc
+    from torch.utils.data import TensorDataset
+    if case == "lgbank":
+        g = load_golden("traj_lgbank.npz")
+        t, C, mask, E = g["t"], g["C"], np.ones((20, 20)), 60
+        u0, p0 = orc.invert_pande_reversible(g["init"], mask)
+    else:
+        e = load_golden(f"eval_{case}.npz")
+        g = load_golden(f"traj_{case}.npz")
+        t, C, mask, E = e["t"], e["C"], e["mask"], int(g["num_epochs"])
+        u0, p0 = g["upper_diag0_f64"], g["log_pi0_f64"]
+    ref = orc.train(t, C, mask, upper_diag=u0, log_pi=p0, num_epochs=E, dtype=torch.float64)
+    with CherryBank(t, C) as bank:
+        r = bank.train_pande_reversible(u0, p0, mask=mask, num_epochs=E, lr=0.1)
+    assert np.allclose(r["loss"], ref["loss"], rtol=1e-9, atol=0)
+    assert relerr(r["Q_best"], ref["Q_best"]) < 1e-6
+    assert relerr(r["Q_last"], ref["Q_last"]) < 1e-6
+    for k, Qk in r["Q_pow2"].items():
+        assert relerr(Qk, ref[f"Q_{k}"]) < 1e-6, k
+    assert set(r["Q_pow2"]) == {1 << i for i in range(E.bit_length()) if (1 << i) <= E}
+    fin = np.isfinite(u0)
+    assert np.array_equal(np.isfinite(r["upper_diag"]), fin)  # masked logits stay -inf
+    assert np.allclose(r["upper_diag"][fin], ref["upper_diag"][fin], rtol=1e-6, atol=1e-8)
+    # the mirrored train_quantization picks the fused path by itself and agrees with fused=False
+    outs = []
+    for fused in (None, False):
+        S = mask.shape[0]
+        mod = RateMatrix(num_states=S, mode="pande_reversible", mask=torch.tensor(mask),
+                         pi=torch.ones(S, dtype=torch.float64) / S, pi_requires_grad=True)
+        with torch.no_grad():
+            mod.upper_diag.copy_(torch.tensor(u0))
+            mod._pi.copy_(torch.tensor(p0))
+        mod = mod.to("cuda")
+        opt = torch.optim.Adam(mod.parameters(), lr=0.1)
+        df, Qd = train_quantization(mod, TensorDataset(torch.tensor(t), torch.tensor(C)),
+                                    num_epochs=E, optimizer=opt, fused=fused)
+        outs.append((df.loss.to_numpy(), Qd))
+    assert np.allclose(outs[0][0], outs[1][0], rtol=1e-10, atol=0)
+    assert set(outs[0][1]) == set(outs[1][1])
+    for k in outs[0][1]:
+        assert relerr(outs[0][1][k], outs[1][1][k]) < 1e-7, k
+
+
+def test_fused_sgd_option():
+    from cherryml_amd import CherryBank
+    from oracle import ratelearn_oracle as orc
+    e = load_golden("eval_toy3_init.npz")
+    g = load_golden("traj_toy3_init.npz")
+    ref = orc.train(e["t"], e["C"], e["mask"], upper_diag=g["upper_diag0_f64"],
+                    log_pi=g["log_pi0_f64"], num_epochs=5, lr=0.01, do_adam=False)
+    with CherryBank(e["t"], e["C"]) as bank:
+        r = bank.train_pande_reversible(g["upper_diag0_f64"], g["log_pi0_f64"], mask=e["mask"],
+                                        num_epochs=5, lr=0.01, do_adam=False)
+    assert np.allclose(r["loss"], ref["loss"], rtol=1e-11, atol=0)
+
+
+def test_fused_siterm_matches_torch_glue_path():
+    from cherryml_amd import quantized_transitions_mle_vectorized_over_sites as qvec
+    g = load_golden("siterm_aa.npz")
+    E = g["lpe_init"].shape[0]
+    a = qvec(g["counts"], g["times"], num_epochs=E, initialization=g["init"], device="cuda", fused=True)
+    b = qvec(g["counts"], g["times"], num_epochs=E, initialization=g["init"], device="cuda", fused=False)
+    assert np.allclose(a["loss_per_epoch_per_site"], b["loss_per_epoch_per_site"], rtol=1e-10, atol=0)
+    assert relerr(a["res"], b["res"]) < 1e-8
+    assert np.allclose(a["loss_per_epoch_per_site"], g["lpeps_init"], rtol=1e-8, atol=0)
