@@ -181,6 +181,7 @@ def main():
     ap.add_argument("--workload", default="coevo400", choices=["coevo400", "lg20", "siterm"])
     ap.add_argument("--sites", type=int, default=5000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true")
     args = ap.parse_args()
 
     import torch
@@ -197,120 +198,160 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
-    import cherryml_amd
-    from cherryml_amd.distributed import ShardedBank
-    from cherryml_amd.estimation import jtt_ipw_from_arrays
-
-    defaults = {"coevo400": (10, 2), "lg20": (200, 20), "siterm": (5, 1)}
-    steps = args.steps if args.steps is not None else defaults[args.workload][0]
-    warmup = args.warmup if args.warmup is not None else defaults[args.workload][1]
-
-    rng = np.random.default_rng(0)
-    wl = make_workload(args.workload, args.sites, rng)
-    S = wl["S"]
-
-    # ---- model + resident bank
-    if wl["kind"] == "single":
-        init = jtt_ipw_from_arrays(wl["t"], wl["C"], wl["mask"])  # pipelines' default init
-        module = cherryml_amd.RateMatrix(
-            num_states=S, mode="pande_reversible", mask=torch.tensor(wl["mask"]),
-            pi=torch.ones(S, dtype=torch.float64) / S, pi_requires_grad=True,
-            initialization=init).to(dev)
-        sharded = ShardedBank(wl["t"], wl["C"])
-        bank = sharded.bank
-        opt = torch.optim.Adam(module.parameters(), lr=0.1)
-        n_pairs_total = wl["n_pairs"]
-        scaling = "strong"
-
-        def step():
-            opt.zero_grad()
-            Q = module()
-            loss = sharded.loss(Q, module.stationary(), normalize=True)[0]
-            loss.backward()
-            opt.step()
-            return loss
-    else:
-        from cherryml_amd._siterm._vectorized import _invert, _site_Q
-        L = wl["C"].shape[0]
-        th, Th = _invert(wl["init"])
-        theta = torch.tensor(th, device=dev).requires_grad_(True)
-        Theta = torch.tensor(Th, device=dev).requires_grad_(True)
-        upper = torch.triu(torch.ones(S, S, dtype=torch.float64, device=dev), diagonal=1)
-        bank = cherryml_amd.CherryBank(wl["t"], wl["C"], device=local_rank)
-        opt = torch.optim.Adam([theta, Theta], lr=0.1)
-        from cherryml_amd._autograd import bank_loss
-        n_pairs_total = wl["n_pairs"] * world  # every rank owns its own L sites
-        scaling = "weak"
-
-        def step():
-            opt.zero_grad()
-            Q, pi = _site_Q(theta, Theta, upper)
-            loss = bank_loss(Q, pi, bank, normalize=True).sum()
-            loss.backward()
-            opt.step()
-            return loss
-
     def fence():
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(warmup):
-        step()
-    bank.profile(True)
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        last = step()
-    fence()
-    dt = time.perf_counter() - t0
-    tm = bank.timing_means()
-    bank.profile(False)
-    if world > 1:
-        tdt = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(tdt, op=dist.ReduceOp.MAX)
-        dt = float(tdt.item())
-    final_loss = float(last.item())
+    def run(workload, steps, warmup, with_cpu):
+        import cherryml_amd
+        from cherryml_amd.distributed import ShardedBank
+        from cherryml_amd.estimation import jtt_ipw_from_arrays
 
-    if rank == 0:
-        ms_per_step = dt / steps * 1e3
-        value = n_pairs_total / (dt / steps)
-        B_local = len(sharded.local_buckets) if wl["kind"] == "single" else wl["C"].shape[1]
+        rng = np.random.default_rng(0)
+        wl = make_workload(workload, args.sites, rng)
+        S = wl["S"]
+        if wl["kind"] == "single" and S > 32:
+            # ---- co-evolution: torch keeps theta -> Q and Adam, HIP does loss + dL/dQ;
+            #      buckets sharded over the ranks, one all-reduce of S^2 + 1 doubles per epoch
+            init = jtt_ipw_from_arrays(wl["t"], wl["C"], wl["mask"])  # pipelines' default init
+            module = cherryml_amd.RateMatrix(
+                num_states=S, mode="pande_reversible", mask=torch.tensor(wl["mask"]),
+                pi=torch.ones(S, dtype=torch.float64) / S, pi_requires_grad=True,
+                initialization=init).to(dev)
+            sharded = ShardedBank(wl["t"], wl["C"])
+            bank = sharded.bank
+            opt = torch.optim.Adam(module.parameters(), lr=0.1)
+            n_pairs_total, scaling = wl["n_pairs"], "strong"
+            sharding = f"buckets x{world}, all-reduce(loss, dL/dQ) per epoch"
+            glue = "theta->Q and Adam in torch, loss + dL/dQ in HIP"
+            B_local = len(sharded.local_buckets)
+
+            def step():
+                opt.zero_grad()
+                loss = sharded.loss(module(), module.stationary(), normalize=True)[0]
+                loss.backward()
+                opt.step()
+                return loss
+
+            for _ in range(warmup):
+                step()
+            bank.profile(True)
+            fence()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                last = step()
+            fence()
+            dt = time.perf_counter() - t0
+            tm = bank.timing_means()
+            bank.profile(False)
+            final_loss = float(last.item())
+            kernel_ms = None
+        else:
+            # ---- S <= 32: launch-latency bound, so the WHOLE epoch loop is one kernel
+            #      (cb_train_pande_reversible / cb_train_siterm): K steps = K epochs of it.
+            #      LG: one 0.4 MB bank does not shard -> N independent replicas;
+            #      SiteRM: every rank owns its own `--sites` sites (no collective).
+            bank = cherryml_amd.CherryBank(wl["t"], wl["C"], device=local_rank)
+            n_pairs_total, scaling = wl["n_pairs"] * world, "weak"
+            B_local = wl["C"].shape[-3]
+            glue = "whole loop fused in one HIP kernel (theta->Q, eigh, bank, grads, Adam)"
+            if wl["kind"] == "single":
+                init = jtt_ipw_from_arrays(wl["t"], wl["C"], wl["mask"])
+                mod = cherryml_amd.RateMatrix(
+                    num_states=S, mode="pande_reversible", mask=torch.tensor(wl["mask"]),
+                    pi=torch.ones(S, dtype=torch.float64) / S, pi_requires_grad=True,
+                    initialization=init)
+                u0 = mod.upper_diag.detach().numpy().copy()
+                p0 = mod._pi.detach().numpy().copy()
+                sharding = f"replicas only x{world}"
+                call = lambda E: bank.train_pande_reversible(u0, p0, mask=wl["mask"], num_epochs=E, lr=0.1)  # noqa: E731
+            else:
+                from cherryml_amd._siterm._vectorized import _invert
+                th0, Th0 = _invert(wl["init"])
+                sharding = f"sites x{world} (no collective)"
+                call = lambda E: bank.train_siterm(th0, Th0, E, lr=0.1)  # noqa: E731
+            if warmup > 0:
+                call(warmup)
+            bank.profile(True)
+            fence()
+            t0 = time.perf_counter()
+            r = call(steps)
+            fence()
+            dt = time.perf_counter() - t0
+            kernel_ms = bank.last_timings()["small"]
+            bank.profile(False)
+            tm = {"small": kernel_ms / steps, "calls": 1}
+            final_loss = float(np.sum(r["loss"][-1]) if "loss" in r
+                               else np.sum(r["loss_per_epoch_per_site"][-1]))
+        if world > 1:
+            tdt = torch.tensor([dt], dtype=torch.float64, device=dev)
+            dist.all_reduce(tdt, op=dist.ReduceOp.MAX)
+            dt = float(tdt.item())
+        if rank != 0:
+            return None
+        traffic = _pmc_traffic()
         if S > 32:
             # dominant MFMA kernels: K1/K2/K3 are one batched 2 S^3 B GEMM each
             flops = 2.0 * S ** 3 * B_local
-            names = {"k1": "k1_pt_loss_gt", "k2": "k2_t_eq_g_u", "k3": "k3_mt_accum"}
+            names = {"k1": "k1_pt_loss_gt", "k2": "k2_t_eq_g_u", "k3": "k3_w_phi"}
             dom = max(names, key=lambda k: tm[k])
             achieved = flops / (tm[dom] * 1e-3) / 1e12 if tm[dom] > 0 else 0.0
             roofline = dict(bound="mfma", kernel=names[dom], achieved=achieved,
                             peak=F64_PEAK_TFLOPS, unit="TFLOP/s", frac=achieved / F64_PEAK_TFLOPS,
-                            traffic=None, ms_per_launch=tm[dom],
-                            flops_per_launch=flops)
+                            traffic=traffic.get(names[dom]) if world == 1 else None,
+                            ms_per_launch=tm[dom], flops_per_launch=flops)
         else:
             Lb = wl["C"].shape[0] if wl["kind"] == "sites" else 1
-            nbytes = float(Lb) * B_local * S * S * 8
+            nbytes = float(Lb) * B_local * S * S * 8  # C streamed once per epoch
             achieved = nbytes / (tm["small"] * 1e-3) / 1e9 if tm["small"] > 0 else 0.0
-            roofline = dict(bound="hbm", kernel="small_bank_kernel", achieved=achieved,
+            roofline = dict(bound="hbm", kernel="small_train_kernel", achieved=achieved,
                             peak=HBM_PEAK_GBS, unit="GB/s", frac=achieved / HBM_PEAK_GBS,
-                            traffic=None, ms_per_launch=tm["small"], bytes_per_launch=nbytes)
+                            traffic=traffic.get("small_train_kernel:" + workload) if world == 1 else None,
+                            ms_per_epoch_in_kernel=tm["small"], bytes_per_epoch=nbytes,
+                            note="one launch runs all K epochs; figures are per epoch")
         out = {
             "metric": "cherry-pairs/sec (whole node) per EM iter",
-            "value": value, "unit": "cherry-pairs/s", "n_gpus": world, "steps": steps,
-            "warmup": warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
-            "scaling": scaling, "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": wl["desc"], "states": S, "buckets": 129,
-                       "sharding": ("buckets" if wl["kind"] == "single" else "sites") + f" x{world}",
-                       "optimizer": "Adam lr 0.1 (torch glue)"},
+            "value": n_pairs_total / (dt / steps), "unit": "cherry-pairs/s", "n_gpus": world,
+            "steps": steps, "warmup": warmup, "ms_per_step": dt / steps * 1e3,
+            "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": wl["desc"], "states": S, "buckets": 129, "sharding": sharding,
+                       "epoch": glue},
             "roofline": roofline,
             "phase_ms": {k: round(v, 4) for k, v in tm.items()},
             "final_loss": final_loss,
         }
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(wl, args.workload)
+        if with_cpu:
+            out["cpu_baseline"] = cpu_baseline(wl, workload)
+        bank.close()
+        return out
+
+    defaults = {"coevo400": (10, 2), "lg20": (500, 50), "siterm": (5, 1)}
+    steps = args.steps if args.steps is not None else defaults[args.workload][0]
+    warmup = args.warmup if args.warmup is not None else defaults[args.workload][1]
+    out = run(args.workload, steps, warmup, world == 1 and not args.no_cpu_baseline)
+    if (rank == 0 and world == 1 and args.workload == "coevo400" and not args.no_secondary
+            and args.steps is None):
+        # BASELINE.json's metric names both sizes: also report the 20x20 LG configuration
+        sec = run("lg20", *defaults["lg20"], not args.no_cpu_baseline)
+        out["secondary"] = {k: sec[k] for k in ("value", "unit", "ms_per_step", "steps", "config",
+                                                "roofline", "cpu_baseline") if k in sec}
+    if rank == 0:
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
+
+
+def _pmc_traffic():
+    """HBM-side bytes per launch from the rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE,
+    corrected as MI355X_MICROARCH.md prescribes), committed under profiles/."""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if not os.path.exists(path):
+        return {}
+    with open(path) as f:
+        return json.load(f).get("bytes_per_launch", {})
 
 
 if __name__ == "__main__":

@@ -718,7 +718,10 @@ static int run_fused_training(cb_bank *h, int kind, double *pi_param, double *up
     a.m_up = d_mom + 2 * (size_t)L * S; a.v_up = a.m_up + L * nup;
     a.mask = d_mask; a.lr = lr; a.beta1 = 0.9; a.beta2 = 0.999; a.eps = 1e-8;
     a.loss_curve = d_loss; a.Q_best = d_Qb; a.Q_last = d_Ql; a.Q_pow2 = d_Qp;
+    for (bool &b : h->ev_rec) b = false;
+    mark(h, EV_START);
     if (E > 0) rc = (L < 512) ? launch_train_nw<8>(h, a) : launch_train_nw<4>(h, a);
+    mark(h, EV_SMALL);  // cb_last_timings(): CB_T_SMALL = the whole E-epoch launch
   }
   TRYH(hipMemcpyAsync(pi_param, d_pi, (size_t)L * S * sizeof(double), hipMemcpyDeviceToHost, h->stream));
   TRYH(hipMemcpyAsync(up_param, d_up, L * nup * sizeof(double), hipMemcpyDeviceToHost, h->stream));
