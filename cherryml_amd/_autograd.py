@@ -25,5 +25,6 @@ class _BankLoss(torch.autograd.Function):
 
 def bank_loss(Q: torch.Tensor, pi: torch.Tensor, bank, normalize: bool = True) -> torch.Tensor:
     """loss[L] = -sum_b <C[l,b], log expm(t[l,b] Q[l])> (/ n_l); differentiable in Q.
-    `pi` (the stationary distribution Q is reversible for) is used detached."""
-    return _BankLoss.apply(Q, pi.detach(), bank, normalize)
+    `pi` (the stationary distribution Q is reversible for) is used detached;
+    pi=None selects the general scaling-and-squaring path (any rate matrix)."""
+    return _BankLoss.apply(Q, None if pi is None else pi.detach(), bank, normalize)

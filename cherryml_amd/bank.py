@@ -138,12 +138,27 @@ class CherryBank:
         _lib.check(rc, "cb_loss_grad")
         return loss, dQ
 
-    def expm_bank(self, Q, pi) -> np.ndarray:
-        Q, pi = self._shape_Q(Q, pi)
+    def expm_bank(self, Q, pi=None) -> np.ndarray:
+        """P[l,b] = expm(t[l,b] Q[l]); pi=None uses the general (scaling-and-squaring) path."""
+        Q = _as_f64(Q).reshape(self.L, self.S, self.S)
+        pi_ptr = None
+        if pi is not None:
+            pi = _as_f64(pi).reshape(self.L, self.S)
+            pi_ptr = pi.ctypes.data
         P = np.zeros((self.L, self.B, self.S, self.S))
-        _lib.check(_lib.load().cb_expm_bank(self._h, Q.ctypes.data, pi.ctypes.data, 0, P.ctypes.data),
+        _lib.check(_lib.load().cb_expm_bank(self._h, Q.ctypes.data, pi_ptr, 0, P.ctypes.data),
                    "cb_expm_bank")
         return P
+
+    def loss_grad_general(self, Q, normalize: bool = True, want_grad: bool = True):
+        """loss[L], dL/dQ for ANY rate matrix (no reversibility assumed): scaling and squaring."""
+        Q = _as_f64(Q).reshape(self.L, self.S, self.S)
+        loss = np.zeros(self.L)
+        dQ = np.zeros_like(Q) if want_grad else None
+        rc = _lib.load().cb_loss_grad_general(self._h, Q.ctypes.data, CB_NORMALIZE if normalize else 0,
+                                              loss.ctypes.data, dQ.ctypes.data if want_grad else None)
+        _lib.check(rc, "cb_loss_grad_general")
+        return loss, dQ
 
     def eigh(self, A) -> Tuple[np.ndarray, np.ndarray]:
         A = _as_f64(A).reshape(self.L, self.S, self.S)
@@ -190,16 +205,22 @@ class CherryBank:
     # -- device-pointer API (torch ROCm tensors, zero copy) -----------------
     def loss_grad_torch(self, Q, pi, normalize: bool = True, want_grad: bool = True):
         """Q[L,S,S] / pi[L,S] float64 tensors on this bank's device; returns
-        (loss[L], dQ[L,S,S]) tensors.  Runs on torch's current stream."""
+        (loss[L], dQ[L,S,S]) tensors.  Runs on torch's current stream.
+        pi=None: general (non-reversible) path."""
         import torch
-        if not (Q.is_cuda and pi.is_cuda):
+        if not Q.is_cuda or (pi is not None and not pi.is_cuda):
             raise ValueError("loss_grad_torch needs tensors on the GPU")
         Qc = Q.detach().to(torch.float64).reshape(self.L, self.S, self.S).contiguous()
-        pic = pi.detach().to(torch.float64).reshape(self.L, self.S).contiguous()
         loss = torch.empty(self.L, dtype=torch.float64, device=Q.device)
         dQ = torch.empty_like(Qc) if want_grad else None
         self.set_stream(torch.cuda.current_stream(Q.device).cuda_stream)
         flags = CB_PTR_DEVICE | CB_NO_SYNC | (CB_NORMALIZE if normalize else 0)
+        if pi is None:
+            rc = _lib.load().cb_loss_grad_general(self._h, Qc.data_ptr(), flags, loss.data_ptr(),
+                                                  dQ.data_ptr() if want_grad else None)
+            _lib.check(rc, "cb_loss_grad_general")
+            return loss, dQ
+        pic = pi.detach().to(torch.float64).reshape(self.L, self.S).contiguous()
         rc = _lib.load().cb_loss_grad(self._h, Qc.data_ptr(), pic.data_ptr(), flags, loss.data_ptr(),
                                       dQ.data_ptr() if want_grad else None)
         _lib.check(rc, "cb_loss_grad")

@@ -17,6 +17,7 @@
 #include "large_bank.hip.h"
 #include "small_bank.hip.h"
 #include "train_small.hip.h"
+#include "general_small.hip.h"
 
 #define CB_ABI_VERSION 1
 
@@ -66,6 +67,8 @@ struct cb_bank {
   unsigned long long *off_bits = nullptr;
   int k3_chunk = 0, k3_nchunks = 0;
   int last_sweeps = 0;
+  double *gn_scratch = nullptr, *gn_partial = nullptr;  // general path, allocated on first use
+  int gn_nw = 0;
   bool have_prev = false;  // h->U / h->Vc hold the eigenvectors of the previous solve
   // profiling
   bool profile = false;
@@ -477,6 +480,8 @@ static int large_loss_grad(cb_bank *h, const double *Qd, const double *pid, bool
 }
 
 // ---------------------------------------------------------------- entry points
+static int general_run(cb_bank *h, const double *Qd, int flags, double *lossd, double *dQd,
+                       double *Pd);
 static int finish_call(cb_bank *h, int flags) {
   if ((flags & CB_PTR_DEVICE) && (flags & CB_NO_SYNC)) return CB_OK;
   HIP_TRY(hipStreamSynchronize(h->stream));
@@ -535,7 +540,6 @@ extern "C" int cb_loss_grad(cb_handle h, const double *Q, const double *pi, int 
 
 extern "C" int cb_expm_bank(cb_handle h, const double *Q, const double *pi, int flags, double *P) {
   if (!h || !Q || !P) return fail(CB_EINVAL, "cb_expm_bank: NULL argument");
-  if (!pi) return fail(CB_EUNSUPPORTED, "cb_expm_bank: general (pi == NULL) path not built yet");
   HIP_TRY(hipSetDevice(h->dev));
   const size_t SS = (size_t)h->S * h->S, nP = (size_t)h->L * h->B * SS;
   const bool devp = flags & CB_PTR_DEVICE;
@@ -544,15 +548,18 @@ extern "C" int cb_expm_bank(cb_handle h, const double *Q, const double *pi, int 
   double *Ptmp = nullptr;
   if (!devp) {
     HIP_TRY(hipMemcpyAsync(h->Q, Q, h->L * SS * sizeof(double), hipMemcpyHostToDevice, h->stream));
-    HIP_TRY(hipMemcpyAsync(h->pi, pi, (size_t)h->L * h->S * sizeof(double), hipMemcpyHostToDevice,
-                           h->stream));
+    if (pi)
+      HIP_TRY(hipMemcpyAsync(h->pi, pi, (size_t)h->L * h->S * sizeof(double), hipMemcpyHostToDevice,
+                             h->stream));
     HIP_TRY(hipMalloc((void **)&Ptmp, nP * sizeof(double)));
     Qd = h->Q;
     pid = h->pi;
     Pd = Ptmp;
   }
   int rc;
-  if (h->large) {
+  if (!pi) {
+    rc = general_run(h, Qd, 0, h->loss, nullptr, Pd);
+  } else if (h->large) {
     rc = large_loss_grad(h, Qd, pid, false, h->loss, nullptr, Pd);
   } else {
     SmallArgs a{};
@@ -641,10 +648,53 @@ extern "C" int cb_eigh(cb_handle h, const double *A, int flags, double *lam, dou
   return CB_OK;
 }
 
+// ------------------------------------------------------------- general (non-reversible) path
+static int general_run(cb_bank *h, const double *Qd, int flags, double *lossd, double *dQd,
+                       double *Pd) {
+  if (h->large)
+    return fail(CB_EUNSUPPORTED, "general (non-reversible) path: S <= 32 only in this build (S = %d)", h->S);
+  const int NW = h->L < 512 ? 8 : 4;
+  if (!h->gn_scratch) {
+    const size_t waves = (size_t)h->L * NW;
+    int rc = dev_alloc(h, &h->gn_scratch, waves * GN_SLOTS * GN_MAT);
+    if (rc != CB_OK) return rc;
+    rc = dev_alloc(h, &h->gn_partial, waves * (GN_MAT + 1));
+    if (rc != CB_OK) return rc;
+    h->gn_nw = NW;
+  }
+  GeneralArgs a{};
+  a.S = h->S; a.L = h->L; a.B = h->B;
+  a.t = h->t; a.Ct = h->Ct; a.inv_n = (flags & CB_NORMALIZE) ? h->inv_n : h->ones;
+  a.Q = Qd; a.loss = lossd; a.dQ = dQd; a.P = Pd;
+  a.scratch = h->gn_scratch; a.partial = h->gn_partial;
+  if (NW == 8) hipLaunchKernelGGL(general_bank_kernel<8>, dim3(h->L), dim3(512), 0, h->stream, a);
+  else hipLaunchKernelGGL(general_bank_kernel<4>, dim3(h->L), dim3(256), 0, h->stream, a);
+  HIP_TRY(hipGetLastError());
+  return CB_OK;
+}
+
 extern "C" int cb_loss_grad_general(cb_handle h, const double *Q, int flags, double *loss,
                                     double *dQ) {
-  (void)h; (void)Q; (void)flags; (void)loss; (void)dQ;
-  return fail(CB_EUNSUPPORTED, "cb_loss_grad_general: not built yet (non-reversible path)");
+  if (!h || !Q || !loss) return fail(CB_EINVAL, "cb_loss_grad_general: NULL argument");
+  HIP_TRY(hipSetDevice(h->dev));
+  const size_t SS = (size_t)h->S * h->S;
+  const bool devp = flags & CB_PTR_DEVICE;
+  const double *Qd = Q;
+  double *lossd = loss, *dQd = dQ;
+  if (!devp) {
+    HIP_TRY(hipMemcpyAsync(h->Q, Q, h->L * SS * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    Qd = h->Q;
+    lossd = h->loss;
+    dQd = dQ ? h->dQ : nullptr;
+  }
+  int rc = general_run(h, Qd, flags, lossd, dQd, nullptr);
+  if (rc != CB_OK) return rc;
+  if (!devp) {
+    HIP_TRY(hipMemcpyAsync(loss, h->loss, h->L * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    if (dQ)
+      HIP_TRY(hipMemcpyAsync(dQ, h->dQ, h->L * SS * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  }
+  return finish_call(h, flags);
 }
 
 // ------------------------------------------------------------- fused trainers

@@ -84,10 +84,11 @@ def train_quantization(rate_module, quantized_dataset, m=1.0, lr=1e-1, num_epoch
     if device.type != "cuda":
         raise RuntimeError("cherryml_amd.train_quantization runs on the MI355X only: move the "
                            "rate module to device='cuda' (there is no CPU fallback)")
-    if not rate_module.is_reversible():
+    reversible = rate_module.is_reversible()
+    if not reversible and rate_module.num_states > 32:
         raise NotImplementedError(
             f"mode={rate_module.mode!r} with this mask gives a non-reversible Q; the general "
-            "(scaling-and-squaring) HIP path is not built yet")
+            "(scaling-and-squaring) HIP path covers num_states <= 32 only in this build")
     if optimizer is None:
         optimizer = torch.optim.SGD(rate_module.parameters(), lr=lr, momentum=0.0, weight_decay=0)
     own_bank = bank is None
@@ -101,7 +102,7 @@ def train_quantization(rate_module, quantized_dataset, m=1.0, lr=1e-1, num_epoch
     rows = []
     best_loss, Q_best, Q = None, None, None
     start = time.time()
-    use_fused = _fusable(rate_module, optimizer, Q_true, m) if fused is None else fused
+    use_fused = (reversible and _fusable(rate_module, optimizer, Q_true, m)) if fused is None else fused
     try:
         if use_fused:
             # S <= 32: the problem is launch-latency bound, so the WHOLE loop (theta -> Q,
@@ -114,7 +115,9 @@ def train_quantization(rate_module, quantized_dataset, m=1.0, lr=1e-1, num_epoch
         for epoch in range(num_epochs_torch):
             optimizer.zero_grad()
             Q = rate_module()
-            loss = bank_loss(Q, rate_module.stationary(), bank, normalize=loss_normalization)[0]
+            # non-reversible Q (non-symmetric mask, modes default/pande/stationary): general path
+            loss = bank_loss(Q, rate_module.stationary() if reversible else None, bank,
+                             normalize=loss_normalization)[0]
             if m != 1.0:
                 loss = loss / m
             loss_value = float(loss.item())

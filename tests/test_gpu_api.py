@@ -220,3 +220,39 @@ def test_fused_siterm_matches_torch_glue_path():
     assert np.allclose(a["loss_per_epoch_per_site"], b["loss_per_epoch_per_site"], rtol=1e-10, atol=0)
     assert relerr(a["res"], b["res"]) < 1e-8
     assert np.allclose(a["loss_per_epoch_per_site"], g["lpeps_init"], rtol=1e-8, atol=0)
+
+
+def test_reference_20x20_non_symmetric_mask_case(tmp_path):
+    """The reference's test_smoke 20x20 random (non-symmetric) mask, no initialisation:
+    non-reversible Q -> general HIP path; trajectory vs the reference's f64 recipe."""
+    import cherryml_amd
+    from cherryml_amd.io import read_rate_matrix
+    e = load_golden("eval_s20_mask.npz")
+    g = load_golden("traj_s20_mask.npz")
+    states = [str(s) for s in load_golden("data_lg.npz")["states"]]
+    cpath, ipath, mpath = _write_inputs(tmp_path, e, states, with_init=False)
+    out = str(tmp_path / "out")
+    cherryml_amd.quantized_transitions_mle(
+        count_matrices_path=cpath, initialization_path=None, mask_path=mpath,
+        output_rate_matrix_dir=out, device="cuda", num_epochs=int(g["num_epochs"]))
+    df = pd.read_csv(os.path.join(out, "df_res.txt"))
+    assert np.allclose(df.loss.to_numpy(), g["loss_f64"], rtol=1e-8, atol=0)
+    res = read_rate_matrix(os.path.join(out, "result.txt")).to_numpy()
+    assert relerr(res, g["Q_best_f64"]) < 1e-6
+    assert np.all((res != 0) == (e["mask"] != 0))  # learned zero pattern == mask
+
+
+@pytest.mark.parametrize("mode", ["default", "pande", "stationary", "stationary_reversible"])
+def test_other_parameterisations_run_and_descend(mode):
+    from cherryml_amd import RateMatrix, train_quantization
+    from torch.utils.data import TensorDataset
+    e = load_golden("eval_toy3_init.npz")
+    torch.manual_seed(0)
+    mod = RateMatrix(num_states=3, mode=mode, mask=torch.ones(3, 3),
+                     pi=torch.tensor([0.2, 0.3, 0.5], dtype=torch.float64),
+                     pi_requires_grad=True).to("cuda")
+    opt = torch.optim.Adam(mod.parameters(), lr=0.05)
+    df, Qd = train_quantization(mod, TensorDataset(torch.tensor(e["t"]), torch.tensor(e["C"])),
+                                num_epochs=20, optimizer=opt)
+    loss = df.loss.to_numpy()
+    assert np.all(np.isfinite(loss)) and loss[-1] < loss[0]

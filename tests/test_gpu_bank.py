@@ -153,3 +153,42 @@ def test_bad_arguments_raise():
         CherryBank(np.ones(3), np.ones((3, 4, 5)))
     with pytest.raises(ValueError):
         CherryBank(np.ones(2), np.zeros((2, 3, 3)))  # zero total count
+
+
+def _random_rate_matrix(rng, S):
+    Q = rng.gamma(2.0, 0.3, size=(S, S)) + 0.01  # dense and NOT reversible
+    np.fill_diagonal(Q, 0.0)
+    Q -= np.diag(Q.sum(1))
+    return Q
+
+
+@pytest.mark.parametrize("S,B", [(3, 4), (20, 9), (21, 5), (32, 3)])
+def test_general_path_non_reversible(S, B):
+    """cb_loss_grad_general / cb_expm_bank(pi=NULL): arbitrary (non-reversible) Q."""
+    rng = np.random.default_rng(S)
+    Q = _random_rate_matrix(rng, S)
+    t = np.array([float("%.8f" % (0.03 * 1.1 ** i)) for i in np.linspace(-64, 64, B).astype(int)])
+    C = rng.poisson(3.0, size=(B, S, S)).astype(float)
+    Qt = torch.tensor(Q, requires_grad=True)
+    ref = orc.bank_loss(Qt, torch.tensor(t), torch.tensor(C))
+    ref.backward()
+    with _bank(t, C) as bank:
+        P = bank.expm_bank(Q, None)[0]
+        loss, dQ = bank.loss_grad_general(Q)
+    assert np.abs(P - orc.expm_bank(Q, t)).max() < 1e-13
+    assert abs(loss[0] - ref.item()) < 1e-12 * abs(ref.item()), (loss[0], ref.item())
+    assert relerr(dQ[0], Qt.grad.numpy()) < 1e-10, relerr(dQ[0], Qt.grad.numpy())
+
+
+def test_general_path_reference_non_symmetric_mask_golden():
+    """The reference's own 20x20 case (non-symmetric random mask): golden from the reference."""
+    g = load_golden("eval_s20_mask.npz")
+    with _bank(g["t"], g["C"]) as bank:
+        loss, dQ = bank.loss_grad_general(g["Q_f64"])
+        # and the reversible golden through the general path too: both paths must agree
+        gs = load_golden("eval_s20_symmask.npz")
+        loss_s, dQ_s = bank.loss_grad_general(gs["Q_f64"])
+    assert abs(loss[0] - float(g["loss_f64"])) < 1e-11 * abs(float(g["loss_f64"]))
+    assert relerr(dQ[0], g["dQ_f64"]) < 1e-9  # one bucket has t = 9999 (18 squarings)
+    assert abs(loss_s[0] - float(gs["loss_f64"])) < 1e-11 * abs(float(gs["loss_f64"]))
+    assert relerr(dQ_s[0], gs["dQ_f64"]) < 1e-9
