@@ -192,3 +192,91 @@ def test_general_path_reference_non_symmetric_mask_golden():
     assert relerr(dQ[0], g["dQ_f64"]) < 1e-9  # one bucket has t = 9999 (18 squarings)
     assert abs(loss_s[0] - float(gs["loss_f64"])) < 1e-11 * abs(float(gs["loss_f64"]))
     assert relerr(dQ_s[0], gs["dQ_f64"]) < 1e-9
+
+
+def _oracle_loss_grad(Q, t, C):
+    Qt = torch.tensor(Q, requires_grad=True)
+    loss = orc.bank_loss(Qt, torch.tensor(t), torch.tensor(C))
+    loss.backward()
+    return loss.item(), Qt.grad.numpy()
+
+
+@pytest.mark.parametrize("S,B", [(2, 3), (5, 1), (17, 4), (32, 5), (33, 3), (48, 2), (100, 3), (161, 2)])
+def test_odd_sizes_padding_and_partial_tiles(S, B):
+    """S = 33..161 take the large path with LD = ceil16(S) zero padding and partial 80-tiles;
+    S <= 32 the register-chained path with every (NT, KS) instantiation."""
+    rng = np.random.default_rng(S * 7 + B)
+    Q, pi = _sym_rate(rng, S, scale=2.0 / S)
+    t = np.array([3e-4, 0.02, 0.3, 1.7, 9.0])[:B] if B <= 5 else np.linspace(0.01, 5, B)
+    C = rng.poisson(2.0, size=(B, S, S)).astype(float)
+    C[:, np.arange(S), np.arange(S)] += 20
+    if B > 1:
+        C[1] = 0.0  # an empty bucket contributes nothing
+    ref_loss, ref_dQ = _oracle_loss_grad(Q, t, C)
+    with _bank(t, C) as bank:
+        loss, dQ = bank.loss_grad(Q, pi)
+        P = bank.expm_bank(Q, pi)[0]
+    assert abs(loss[0] - ref_loss) < 1e-12 * abs(ref_loss)
+    assert relerr(dQ[0], ref_dQ) < 1e-10
+    assert np.abs(P - orc.expm_bank(Q, t)).max() < 1e-13
+
+
+def test_many_small_sites():
+    """2000 independent 4-state sites with their own grids (SiteRM DNA shape)."""
+    rng = np.random.default_rng(5)
+    L, B, N = 2000, 7, 4
+    Qs = np.zeros((L, N, N)); pis = np.zeros((L, N))
+    for l in range(L):
+        Qs[l], pis[l] = _sym_rate(rng, N)
+    times = rng.uniform(0.01, 2.0, size=(L, B))
+    counts = rng.poisson(5.0, size=(L, B, N, N)).astype(float) + 1.0
+    Qt = torch.tensor(Qs, requires_grad=True)
+    per_site, total = orc.siterm_loss(Qt, torch.tensor(counts), torch.tensor(times))
+    total.backward()
+    with _bank(times, counts) as bank:
+        loss, dQ = bank.loss_grad(Qs, pis)
+    assert np.allclose(loss, per_site.detach().numpy(), rtol=1e-12, atol=0)
+    assert relerr(dQ, Qt.grad.numpy()) < 1e-11
+
+
+def test_masked_rates_and_zero_counts():
+    """Structural zeros in Q (co-evolution style mask) with zero counts on them."""
+    rng = np.random.default_rng(11)
+    S = 16
+    Q, pi = _sym_rate(rng, S)
+    mask = (rng.random((S, S)) < 0.4)
+    mask = np.triu(mask, 1); mask = (mask | mask.T | np.eye(S, dtype=bool)).astype(float)
+    d = np.sqrt(pi)
+    R = (d[:, None] * Q / d[None, :]) * mask
+    np.fill_diagonal(R, 0.0)
+    Q = R * d[None, :] / d[:, None]
+    Q -= np.diag(Q.sum(1))
+    t = np.array([6.73e-5, 1e-3, 0.05, 2.0])
+    P = orc.expm_bank(Q, t)
+    C = np.round(1e6 * pi[None, :, None] * P)  # exact zeros where P is tiny
+    ref_loss, ref_dQ = _oracle_loss_grad(Q, t, C)
+    with _bank(t, C) as bank:
+        loss, dQ = bank.loss_grad(Q, pi)
+        Pd = bank.expm_bank(Q, pi)[0]
+    assert abs(loss[0] - ref_loss) < 1e-12 * abs(ref_loss)
+    assert relerr(dQ[0], ref_dQ) < 1e-10
+    nz = P > 0
+    assert np.abs(Pd[nz] / P[nz] - 1.0).max() < 1e-9  # relative, including O(t^2) entries
+
+
+def test_non_finite_input_rejected():
+    from cherryml_amd import CherryBank
+    with pytest.raises(ValueError):
+        CherryBank(np.array([0.1, np.nan]), np.ones((2, 3, 3)))
+    with pytest.raises(ValueError):
+        CherryBank(np.array([0.1, 0.2]), np.full((2, 3, 3), np.inf))
+
+
+def test_results_are_bitwise_reproducible():
+    g = load_golden("eval_s400_mask.npz")
+    Q, pi = g["Q_f64"], _pi_of(g["log_pi"])
+    with _bank(g["t"], g["C"]) as bank:
+        a = bank.loss_grad(Q, pi)
+    with _bank(g["t"], g["C"]) as bank:
+        b = bank.loss_grad(Q, pi)
+    assert a[0][0] == b[0][0] and np.array_equal(a[1], b[1])
