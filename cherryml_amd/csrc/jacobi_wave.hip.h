@@ -144,8 +144,11 @@ __device__ __forceinline__ int wave_jacobi_columns_n(int n, double *Gc, int LS, 
 // that is negative semidefinite up to rounding (symmetrised rate matrix):
 //   Uc[k*LS + i] = component i of eigenvector k,  lam[k].
 // Gc is scratch (n x LS).  Returns the sweeps used.
+// warm = true: Uc holds an orthonormal basis (the eigenvectors of a nearby matrix,
+// e.g. the previous optimiser epoch): the sweeps start from G0 = A' Uc, whose columns
+// are already nearly orthogonal (2-3 sweeps instead of 6-8).
 __device__ int wave_eigh_rate(int n, const double *A, double *Gc, double *Uc, double *lam,
-                              int LS) {
+                              int LS, bool warm = false) {
   const int lane = threadIdx.x & 63;
   double mx = 0.0;
   for (int i = lane; i < n; i += 64) mx = fmax(mx, fabs(A[i * LS + i]));
@@ -153,7 +156,14 @@ __device__ int wave_eigh_rate(int n, const double *A, double *Gc, double *Uc, do
   if (!(sigma > 0.0)) sigma = 1.0;
   for (int e = lane; e < n * n; e += 64) {
     const int k = e / n, r = e - k * n;
-    Gc[k * LS + r] = A[r * LS + k] - (r == k ? sigma : 0.0);
+    double v;
+    if (warm) {  // (A' u_k)[r] = sum_j A[r][j] u_k[j] - sigma u_k[r]
+      v = -sigma * Uc[k * LS + r];
+      for (int j = 0; j < n; ++j) v = fma(A[r * LS + j], Uc[k * LS + j], v);
+    } else {
+      v = A[r * LS + k] - (r == k ? sigma : 0.0);
+    }
+    Gc[k * LS + r] = v;
   }
   wave_lds_fence();
   const int sweeps = wave_jacobi_columns_n(n, Gc, LS, CB_JAC_MAX_SWEEPS);

@@ -263,14 +263,14 @@ __device__ __forceinline__ void small_site_eval(double *lds, int S, int B,
                                                 const double *__restrict__ Ct_l, double inv_n,
                                                 const double *__restrict__ dirsum_l,
                                                 double *__restrict__ P_l, bool want_grad,
-                                                int *sweeps_out) {
+                                                int *sweeps_out, bool warm = false) {
   using LD = SmallLds<NW>;
   double *sA = lds + LD::A, *sG = lds + LD::G, *sV = lds + LD::V, *sLam = lds + LD::LAM,
          *sD = lds + LD::D;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int lo = lane & 15, hi = lane >> 4;
   if (wave == 0) {
-    const int sweeps = wave_eigh_rate(S, sA, sG, sV, sLam, CB_LS);
+    const int sweeps = wave_eigh_rate(S, sA, sG, sV, sLam, CB_LS, warm);
     if (lane == 0 && sweeps_out) *sweeps_out = sweeps;
   }
   __syncthreads();

@@ -127,8 +127,9 @@ __global__ __launch_bounds__(NW * 64, 2) void small_train_kernel(TrainArgs a) {
       if (pow2 && pidx < a.n_pow2) a.Q_pow2[(size_t)pidx * S * S + e] = q;
     }
     // ---- loss and dL/dA -------------------------------------------------------------------
+    // sV still holds the previous epoch's eigenvectors (zero padded): warm start
     small_site_eval<NT, KS, NW, SMALL_LOSSGRAD>(lds, S, B, a.t + lb, a.Ct + lb * S * S, inv_n,
-                                                dirsum, nullptr, true, nullptr);
+                                                dirsum, nullptr, true, nullptr, epoch > 0);
     // (ends with a barrier: sG = dA, sA = A, LOSSTOT = loss)
     const double loss = lds[LD::LOSSTOT];
     if (tid == 0) {
