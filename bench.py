@@ -308,7 +308,7 @@ def main():
             achieved = nbytes / (tm["small"] * 1e-3) / 1e9 if tm["small"] > 0 else 0.0
             roofline = dict(bound="hbm", kernel="small_train_kernel", achieved=achieved,
                             peak=HBM_PEAK_GBS, unit="GB/s", frac=achieved / HBM_PEAK_GBS,
-                            traffic=traffic.get("small_train_kernel:" + workload) if world == 1 else None,
+                            traffic=traffic.get("small_train_kernel:" + workload + ":per_epoch") if world == 1 else None,
                             ms_per_epoch_in_kernel=tm["small"], bytes_per_epoch=nbytes,
                             note="one launch runs all K epochs; figures are per epoch")
         out = {
