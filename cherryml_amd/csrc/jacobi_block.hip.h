@@ -94,20 +94,26 @@ __global__ __launch_bounds__(JB_THREADS) void lgj_round(int LD, int round, int i
   //    Four independent accumulators: a dependent f64 MFMA chain costs ~300 cycles a link.
   d4 acc = {0.0, 0.0, 0.0, 0.0};
   {
+    // this wave's k-steps are s = wave, wave + 4, ...; batches of 8: all 8 LDS reads in
+    // flight, then 8 MFMAs on 4 independent accumulators
     d4 a0 = acc, a1 = acc, a2 = acc, a3 = acc;
     const int nsteps = LD / 4;
-    int s0 = wave;
-    for (; s0 + 12 < nsteps; s0 += 16) {
-      const double v0 = sG[lo * RS + 4 * s0 + hi], v1 = sG[lo * RS + 4 * (s0 + 4) + hi];
-      const double v2 = sG[lo * RS + 4 * (s0 + 8) + hi], v3 = sG[lo * RS + 4 * (s0 + 12) + hi];
-      a0 = mfma_f64(v0, v0, a0);
-      a1 = mfma_f64(v1, v1, a1);
-      a2 = mfma_f64(v2, v2, a2);
-      a3 = mfma_f64(v3, v3, a3);
-    }
-    for (; s0 < nsteps; s0 += 4) {
-      const double v0 = sG[lo * RS + 4 * s0 + hi];
-      a0 = mfma_f64(v0, v0, a0);
+    for (int s0 = wave; s0 < nsteps; s0 += 32) {
+      double v[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int st = s0 + 4 * i;
+        const double x = sG[lo * RS + 4 * min(st, nsteps - 1) + hi];
+        v[i] = st < nsteps ? x : 0.0;
+      }
+      a0 = mfma_f64(v[0], v[0], a0);
+      a1 = mfma_f64(v[1], v[1], a1);
+      a2 = mfma_f64(v[2], v[2], a2);
+      a3 = mfma_f64(v[3], v[3], a3);
+      a0 = mfma_f64(v[4], v[4], a0);
+      a1 = mfma_f64(v[5], v[5], a1);
+      a2 = mfma_f64(v[6], v[6], a2);
+      a3 = mfma_f64(v[7], v[7], a3);
     }
     acc = (a0 + a1) + (a2 + a3);
   }
@@ -121,43 +127,49 @@ __global__ __launch_bounds__(JB_THREADS) void lgj_round(int LD, int round, int i
   }
   __syncthreads();
   JB_STAMP(2)
-  // 3. off-diagonal measure + 16x16 eigenproblem (wave 0)
+  // 3. 16x16 rotation (wave 0); the convergence measure comes out of the rotation loop
   if (wave == 0) {
-    double off = 0.0;
-    for (int e = lane; e < 256; e += 64) {
-      const int p = e >> 4, q = e & 15;
-      const bool mine = inner_sweeps > 0 || ((round >= 0) ? (p < 8 && q >= 8) : ((p < 8) == (q < 8)));
-      if (p < q && mine) {
-        const double den2 = sGam[p * 17 + p] * sGam[q * 17 + q];
-        if (den2 > 0.0) off = fmax(off, fabs(sGam[p * 17 + q]) * fast_rsqrt(den2));
-      }
-    }
-    off = wave_max(off);
-    if (lane == 0) atomicMax(off_bits, dbl_bits(off));
-    JB_STAMP(3)
+    double off;
     if (inner_sweeps > 0) {
+      off = 0.0;
+      for (int e = lane; e < 256; e += 64) {
+        const int p = e >> 4, q = e & 15;
+        if (p < q) {
+          const double den2 = sGam[p * 17 + p] * sGam[q * 17 + q];
+          if (den2 > 0.0) off = fmax(off, fabs(sGam[p * 17 + q]) * fast_rsqrt(den2));
+        }
+      }
+      off = wave_max(off);
+      JB_STAMP(3)
       wave_rotation_spd16(sGam, sR, 17, inner_sweeps);
     } else {
       for (int e = lane; e < 256; e += 64) sR[(e >> 4) * 17 + (e & 15)] = ((e >> 4) == (e & 15)) ? 1.0 : 0.0;
       wave_lds_fence();
-      wave_rotation_spd16_blockpairs(sGam, sR, 17, round >= 0);
+      JB_STAMP(3)
+      const double off2 = wave_rotation_spd16_blockpairs(sGam, sR, 17, round >= 0);
+      off = off2 > 0.0 ? off2 * fast_rsqrt(off2) : 0.0;
     }
     JB_STAMP(4)
-    // One Newton-Schulz step R <- R (3 I - R^T R) / 2 makes R orthogonal to rounding.
-    for (int e = lane; e < 256; e += 64) {
-      const int p = e >> 4, q = e & 15;
-      double d = 0.0;
-      for (int c = 0; c < 16; ++c) d = fma(sR[p * 17 + c], sR[q * 17 + c], d);
-      sGam[p * 17 + q] = d;  // N = R^T R
-    }
-    wave_lds_fence();
-    for (int e = lane; e < 256; e += 64) {
-      const int q = e >> 4, c = e & 15;
-      double d = 0.0;
-      for (int p = 0; p < 16; ++p) d = fma(sR[p * 17 + c], sGam[p * 17 + q], d);
-      sN[q * 17 + c] = 1.5 * sR[q * 17 + c] - 0.5 * d;  // column q of R'
-    }
-    wave_lds_fence();
+    if (lane == 0) atomicMax(off_bits, dbl_bits(off));
+  }
+  __syncthreads();
+  // One Newton-Schulz step R <- R (3 I - R^T R) / 2 (all four waves, one entry per thread):
+  // a product of plane rotations is orthogonal only to a few 1e-16 and that defect would
+  // add up over the ~300 block rounds of a solve.
+  {
+    const int e = threadIdx.x, p = e >> 4, q = e & 15;
+    double d = 0.0;
+#pragma unroll
+    for (int c = 0; c < 16; ++c) d = fma(sR[p * 17 + c], sR[q * 17 + c], d);
+    sGam[p * 17 + q] = d;  // N = R^T R  (symmetric)
+  }
+  __syncthreads();
+  {
+    const int e = threadIdx.x, q = e >> 4, c = e & 15;
+    double d = 0.0;
+#pragma unroll
+    for (int p = 0; p < 16; ++p) d = fma(sR[p * 17 + c], sGam[p * 17 + q], d);
+    sN[q * 17 + c] = 1.5 * sR[q * 17 + c] - 0.5 * d;  // column q of R'
   }
   __syncthreads();
   JB_STAMP(5)

@@ -203,11 +203,13 @@ __device__ int wave_rotation_spd16(double *Gam, double *Rc, int LS, int max_swee
 //                  perfect matchings  i <-> 8 + (i + r) % 8
 //   cross = false: the 2 x 28 pairs inside each block, 7 tournament rounds each
 // 4 lanes per pair (8 pairs -> 32 lanes), 4 rows per lane.
-__device__ void wave_rotation_spd16_blockpairs(double *Gc, double *Vc, int LS, bool cross) {
+// Returns (wave-uniform) the largest squared cosine g^2 / (a b) met BEFORE its rotation.
+__device__ double wave_rotation_spd16_blockpairs(double *Gc, double *Vc, int LS, bool cross) {
   const int lane = threadIdx.x & 63;
   const int slot = lane >> 2, sub = lane & 3;
   const bool active = slot < 8;
   const int nrounds = cross ? 8 : 7;
+  double off2 = 0.0;
   for (int r = 0; r < nrounds; ++r) {
     int pp, qq;
     if (cross) {
@@ -241,8 +243,9 @@ __device__ void wave_rotation_spd16_blockpairs(double *Gc, double *Vc, int LS, b
     a = quad_sum(a);
     b = quad_sum(b);
     g = quad_sum(g);
-    const double g2 = g * g;
-    if (active && g2 > a * b * (CB_JAC_SKIP * CB_JAC_SKIP)) {
+    const double g2 = g * g, ab = a * b;
+    if (active && g2 > ab * (CB_JAC_SKIP * CB_JAC_SKIP)) {
+      off2 = fmax(off2, g2 * fast_rcp(ab));
       const double d = b - a;
       const double hh = fma(d, d, 4.0 * g2);
       const double h = hh * fast_rsqrt(hh);
@@ -261,4 +264,5 @@ __device__ void wave_rotation_spd16_blockpairs(double *Gc, double *Vc, int LS, b
     }
     wave_lds_fence();
   }
+  return wave_max(off2);
 }
