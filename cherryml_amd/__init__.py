@@ -1,6 +1,7 @@
 """cherryml_amd: MI355X-native composite-likelihood core with CherryML's API
 surface for that path (see DESIGN.md / INTEGRATION.md)."""
-from . import caching, io  # noqa: F401
+from . import caching, counting, io  # noqa: F401
+from .counting import count_co_transitions, count_transitions  # noqa: F401
 from ._siterm import quantized_transitions_mle_vectorized_over_sites  # noqa: F401
 from .bank import CherryBank  # noqa: F401
 from .estimation import (RateMatrix, RateMatrixLearner, jtt_ipw, quantized_transitions_mle,  # noqa: F401
@@ -9,5 +10,5 @@ from .estimation import (RateMatrix, RateMatrixLearner, jtt_ipw, quantized_trans
 __all__ = [
     "CherryBank", "RateMatrix", "RateMatrixLearner", "train_quantization",
     "quantized_transitions_mle", "quantized_transitions_mle_vectorized_over_sites", "jtt_ipw",
-    "io", "caching",
+    "io", "caching", "counting", "count_transitions", "count_co_transitions",
 ]

@@ -18,6 +18,7 @@
 #include "small_bank.hip.h"
 #include "train_small.hip.h"
 #include "general_small.hip.h"
+#include "counting.hip.h"
 
 #define CB_ABI_VERSION 1
 
@@ -883,4 +884,100 @@ static int read_phase_times(cb_bank *h, double (&v)[CB_T_COUNT]) {
     v[CB_T_TOTAL] = v[CB_T_SMALL];
   }
   return CB_OK;
+}
+
+// ------------------------------------------------------------------------ counting
+static int count_common(int device, int S, int B, const double *grid, const int8_t *seqs,
+                        int64_t seqs_bytes, const void *aux, size_t aux_bytes,
+                        const cb_count_pair *pairs, int64_t n_pairs, int symmetric,
+                        unsigned long long *counts, bool co) {
+  if (S < 1 || B < 1 || !grid || !counts) return fail(CB_EINVAL, "counting: bad S/B/grid/counts");
+  if (n_pairs < 0 || (n_pairs > 0 && (!pairs || !seqs))) return fail(CB_EINVAL, "counting: bad pairs");
+  for (int b = 1; b < B; ++b)
+    if (!(grid[b] > grid[b - 1])) return fail(CB_EINVAL, "counting: quantization points must be sorted");
+  int ndev = cb_device_count();
+  if (ndev <= 0) return fail(CB_EHIP, "counting: no HIP device visible");
+  if (device < 0 || device >= ndev) return fail(CB_EINVAL, "counting: device %d out of range", device);
+  // validate offsets on the host: the kernels trust them
+  const size_t nbins = co ? (size_t)B * S * S * S * S : (size_t)B * S * S;
+  for (int64_t p = 0; p < n_pairs; ++p) {
+    const cb_count_pair &pr = pairs[p];
+    const int64_t span = co ? 1 : pr.n;  // co: sites are indexed through the contact list
+    if (pr.n < 0 || pr.seq_a < 0 || pr.seq_b < 0 || pr.aux < 0 || pr.seq_a + span > seqs_bytes ||
+        pr.seq_b + span > seqs_bytes)
+      return fail(CB_EINVAL, "counting: pair %lld has offsets outside the sequence buffer", (long long)p);
+    const size_t need = co ? ((size_t)pr.aux + pr.n) * 2 * sizeof(int32_t) : ((size_t)pr.aux + pr.n) * sizeof(double);
+    if (need > aux_bytes) return fail(CB_EINVAL, "counting: pair %lld reads past its rates/contacts", (long long)p);
+  }
+  HIP_TRY(hipSetDevice(device));
+  double *d_grid = nullptr;
+  int8_t *d_seqs = nullptr;
+  void *d_aux = nullptr;
+  cb_count_pair *d_pairs = nullptr;
+  unsigned long long *d_counts = nullptr;
+  int rc = CB_OK;
+  auto freeall = [&]() {
+    (void)hipFree(d_grid); (void)hipFree(d_seqs); (void)hipFree(d_aux); (void)hipFree(d_pairs); (void)hipFree(d_counts);
+  };
+#define TRYC(expr)                                                                       \
+  if (rc == CB_OK) {                                                                     \
+    hipError_t e_ = (expr);                                                              \
+    if (e_ != hipSuccess) rc = fail(e_ == hipErrorOutOfMemory ? CB_ENOMEM : CB_EHIP, "%s failed: %s", #expr, hipGetErrorString(e_)); \
+  }
+  TRYC(hipMalloc((void **)&d_grid, B * sizeof(double)));
+  TRYC(hipMalloc((void **)&d_seqs, seqs_bytes > 0 ? seqs_bytes : 1));
+  TRYC(hipMalloc(&d_aux, aux_bytes > 0 ? aux_bytes : 1));
+  TRYC(hipMalloc((void **)&d_pairs, (n_pairs > 0 ? n_pairs : 1) * sizeof(cb_count_pair)));
+  TRYC(hipMalloc((void **)&d_counts, nbins * sizeof(unsigned long long)));
+  TRYC(hipMemcpy(d_grid, grid, B * sizeof(double), hipMemcpyHostToDevice));
+  if (seqs_bytes > 0) TRYC(hipMemcpy(d_seqs, seqs, seqs_bytes, hipMemcpyHostToDevice));
+  if (aux_bytes > 0) TRYC(hipMemcpy(d_aux, aux, aux_bytes, hipMemcpyHostToDevice));
+  if (n_pairs > 0) TRYC(hipMemcpy(d_pairs, pairs, n_pairs * sizeof(cb_count_pair), hipMemcpyHostToDevice));
+  TRYC(hipMemset(d_counts, 0, nbins * sizeof(unsigned long long)));
+  if (rc == CB_OK && n_pairs > 0) {
+    const unsigned blocks = (unsigned)((n_pairs + 3) / 4);
+    if (co)
+      hipLaunchKernelGGL(count_co_transitions_kernel, dim3(blocks), dim3(256), 0, 0, S, B, d_grid, d_seqs,
+                         (const int32_t *)d_aux, d_pairs, (long long)n_pairs, symmetric, d_counts);
+    else
+      hipLaunchKernelGGL(count_transitions_kernel, dim3(blocks), dim3(256), 0, 0, S, B, d_grid, d_seqs,
+                         (const double *)d_aux, d_pairs, (long long)n_pairs, symmetric, d_counts);
+    TRYC(hipGetLastError());
+    TRYC(hipDeviceSynchronize());
+  }
+  TRYC(hipMemcpy(counts, d_counts, nbins * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+#undef TRYC
+  freeall();
+  return rc;
+}
+
+extern "C" int cb_count_transitions(int device, int S, int B, const double *grid, const int8_t *seqs,
+                                    int64_t seqs_bytes, const double *rates, int64_t n_rates,
+                                    const cb_count_pair *pairs, int64_t n_pairs, int symmetric,
+                                    unsigned long long *counts) {
+  if (S > 127) return fail(CB_EINVAL, "cb_count_transitions: at most 127 states (int8 codes)");
+  return count_common(device, S, B, grid, seqs, seqs_bytes, rates, (size_t)(n_rates > 0 ? n_rates : 0) * sizeof(double),
+                      pairs, n_pairs, symmetric, counts, false);
+}
+
+extern "C" int cb_count_co_transitions(int device, int S, int B, const double *grid, const int8_t *seqs,
+                                       int64_t seqs_bytes, const int32_t *contacts, int64_t n_contacts,
+                                       const cb_count_pair *pairs, int64_t n_pairs, int symmetric,
+                                       unsigned long long *counts) {
+  if (S > 127) return fail(CB_EINVAL, "cb_count_co_transitions: at most 127 states (int8 codes)");
+  // contact indices must address sites inside the sequences: checked per pair on the host
+  for (int64_t p = 0; p < n_pairs && pairs && contacts; ++p) {
+    const cb_count_pair &pr = pairs[p];
+    if (pr.aux < 0 || pr.n < 0 || pr.aux + pr.n > n_contacts)
+      return fail(CB_EINVAL, "cb_count_co_transitions: pair %lld contact range outside the list", (long long)p);
+    for (int c = 0; c < pr.n; ++c) {
+      const int32_t i = contacts[2 * (pr.aux + c)], j = contacts[2 * (pr.aux + c) + 1];
+      if (i < 0 || j < 0 || pr.seq_a + i >= seqs_bytes || pr.seq_a + j >= seqs_bytes ||
+          pr.seq_b + i >= seqs_bytes || pr.seq_b + j >= seqs_bytes)
+        return fail(CB_EINVAL, "cb_count_co_transitions: contact site outside the sequence buffer");
+    }
+  }
+  return count_common(device, S, B, grid, seqs, seqs_bytes, contacts,
+                      (size_t)(n_contacts > 0 ? n_contacts : 0) * 2 * sizeof(int32_t), pairs, n_pairs, symmetric,
+                      counts, true);
 }

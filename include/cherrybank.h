@@ -169,6 +169,43 @@ int cb_train_siterm(cb_handle h, double *theta, double *Theta, int num_epochs,
                     double lr, int flags, double *res,
                     double *loss_per_epoch_per_site);
 
+/* ------------------------------------------------------------------------------
+ * Counting stage: the producer of the bank.  Replaces the hot loops
+ * of cherryml/counting/_count_transitions.py:98-123,143-197 (C++: _count_transitions.cpp:
+ * 316-390) and cherryml/counting/_count_co_transitions.py:108-140,169-223 (C++:
+ * _count_co_transitions.cpp:359-381).  The host parses trees / MSAs and decides which
+ * sequence pairs are counted (edge, cherry, cherry++ pairing); the device does the
+ * per-site work: quantise (len_a + len_b) * rate onto the grid exactly as
+ * cherryml/utils.py:35-56 (nearest in relative error, ties right, outside -> dropped)
+ * and histogram the states.  Counts are INTEGERS (u64 atomics): bit-exact and
+ * order-independent; the caller multiplies by the unit (0.5 / 1 / 0.25).
+ * Sequences are int8 codes: state index, or negative for any symbol outside the alphabet.
+ * All pointers are host pointers; the call is stateless and synchronous.
+ */
+typedef struct {
+  int64_t seq_a, seq_b; /* byte offsets of the two encoded sequences in `seqs`        */
+  int64_t aux;          /* transitions: offset (doubles) of the family's site rates;
+                           co-transitions: offset (pairs) of its contact-pair list     */
+  int32_t n;            /* transitions: number of sites; co: number of contact pairs  */
+  int32_t reserved;
+  double len_a, len_b;  /* branch length of the pair = len_a + len_b                  */
+} cb_count_pair;
+
+/* counts[B*S*S] += 1 at [q][a_k][b_k] (and at [q][b_k][a_k] when symmetric) for every
+ * site k of every pair with q = quantization_idx((len_a + len_b) * rates[aux + k]). */
+int cb_count_transitions(int device, int S, int B, const double *grid, const int8_t *seqs,
+                         int64_t seqs_bytes, const double *rates, int64_t n_rates,
+                         const cb_count_pair *pairs, int64_t n_pairs, int symmetric,
+                         unsigned long long *counts);
+
+/* counts[B*S^2*S^2]: for every pair with q = quantization_idx(len_a + len_b) and every
+ * contact (i, j) of its list, states s = a_i*S + a_j, e = b_i*S + b_j and their site-swapped
+ * versions s', e':  += 1 at (s,e), (s',e')  [and (e,s), (e',s') when symmetric]. */
+int cb_count_co_transitions(int device, int S, int B, const double *grid, const int8_t *seqs,
+                            int64_t seqs_bytes, const int32_t *contacts, int64_t n_contacts,
+                            const cb_count_pair *pairs, int64_t n_pairs, int symmetric,
+                            unsigned long long *counts);
+
 #ifdef __cplusplus
 }
 #endif
