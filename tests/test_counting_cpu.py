@@ -126,3 +126,29 @@ def test_counting_bad_inputs(tmp_path):
         _host.read_tree_arrays(str(p))  # c has two parents
     with pytest.raises(ValueError):
         _host.build_pairs([[]], 0, "cherries")
+
+
+def test_maximal_matching_equals_networkx(tmp_path):
+    """create_maximal_matching_contact_map == networkx.maximal_matching on the same graph
+    construction as the reference (evaluation/_maximal_matching.py:70-93)."""
+    nx = pytest.importorskip("networkx")
+    from cherryml_amd.estimation_end_to_end import create_maximal_matching_contact_map
+    from cherryml_amd.counting import _host
+    src = f"{CNT}/synth/contact_map_dir"
+    fams = ["famA", "famB", "famD"]
+    out = str(tmp_path / "mm")
+    create_maximal_matching_contact_map(i_contact_map_dir=src, families=fams,
+                                        minimum_distance_for_nontrivial_contact=3, num_processes=1,
+                                        o_contact_map_dir=out)
+    for fam in fams:
+        cm = _host.read_contact_map(f"{src}/{fam}.txt")
+        n = cm.shape[0]
+        G = nx.Graph()
+        G.add_nodes_from(range(n))
+        G.add_edges_from([(i, j) for i, j in zip(*np.where(cm == 1)) if i < j and abs(i - j) >= 3])
+        want = np.zeros((n, n), dtype=int)
+        for u, v in nx.maximal_matching(G):
+            want[u, v] = want[v, u] = 1
+        got = _host.read_contact_map(f"{out}/{fam}.txt")
+        assert np.array_equal(got, want)
+        assert got.sum(axis=0).max() <= 1

@@ -256,3 +256,75 @@ def test_other_parameterisations_run_and_descend(mode):
                                 num_epochs=20, optimizer=opt)
     loss = df.loss.to_numpy()
     assert np.all(np.isfinite(loss)) and loss[-1] < loss[0]
+
+
+def test_lg_end_to_end_pipeline(tmp_path):
+    """trees + site rates given -> counting [GPU] -> JTT-IPW -> optimiser [GPU]; every stage
+    checked against the oracle chain on the same synthetic families."""
+    import cherryml_amd
+    from cherryml_amd import caching
+    from cherryml_amd.io import read_count_matrices_arrays, read_rate_matrix
+    from oracle import counting_oracle as co
+    from oracle import ratelearn_oracle as orc
+    d = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "counting", "synth")
+    fams = ["famA", "famB", "famC", "famD"]
+    with pytest.raises(caching.CacheUsageError):
+        cherryml_amd.lg_end_to_end_with_cherryml_optimizer(
+            msa_dir=f"{d}/msa_dir", families=fams, tree_estimator=None,
+            initial_tree_estimator_rate_matrix_path=None, tree_dir=f"{d}/tree_dir",
+            site_rates_dir=f"{d}/site_rates_dir")
+    caching.set_cache_dir(str(tmp_path / "cache"))
+    try:
+        res = cherryml_amd.lg_end_to_end_with_cherryml_optimizer(
+            msa_dir=f"{d}/msa_dir", families=fams, tree_estimator=None,
+            initial_tree_estimator_rate_matrix_path=None, num_epochs=40,
+            tree_dir=f"{d}/tree_dir", site_rates_dir=f"{d}/site_rates_dir", edge_or_cherry="edge")
+        res2 = cherryml_amd.lg_end_to_end_with_cherryml_optimizer(  # second call: all cached
+            msa_dir=f"{d}/msa_dir", families=fams, tree_estimator=None,
+            initial_tree_estimator_rate_matrix_path=None, num_epochs=40,
+            tree_dir=f"{d}/tree_dir", site_rates_dir=f"{d}/site_rates_dir", edge_or_cherry="edge")
+    finally:
+        caching.set_cache_dir(None)
+    assert res["learned_rate_matrix_path"] == res2["learned_rate_matrix_path"]
+    grid = [float(x) for x in res["quantization_points"]]
+    assert len(grid) == 129 and res["quantization_points"][0] == "0.00006730"
+    aa = list("ARNDCQEGHILKMFPSTWYV")
+    C = co.count_transitions(f"{d}/tree_dir", f"{d}/msa_dir", f"{d}/site_rates_dir", fams, aa, grid, "edge")
+    q, Cg, st = read_count_matrices_arrays(os.path.join(res["count_matrices_dir_0"], "result.txt"))
+    assert st == aa and np.array_equal(Cg, C)
+    init = orc.jtt_ipw(np.array(grid), C)
+    got_init = read_rate_matrix(os.path.join(res["jtt_ipw_dir_0"], "result.txt")).to_numpy()
+    assert np.allclose(got_init, init, rtol=1e-12, atol=1e-15)
+    ref = orc.train(np.array(grid), C, None, initialization=got_init, num_epochs=40)
+    learned = read_rate_matrix(res["learned_rate_matrix_path"]).to_numpy()
+    assert relerr(learned, ref["Q_best"]) < 1e-6
+    assert res["time_counting"] > 0 and "time_optimization" in res["profiling_str"]
+
+
+def test_coevolution_end_to_end_pipeline_small_alphabet(tmp_path):
+    """co-evolution pipeline on the reference's tiny_2 data (4-letter alphabet -> 16 pair
+    states): maximal matching -> co-counting [GPU] -> masked JTT-IPW -> optimiser [GPU]."""
+    import cherryml_amd
+    from cherryml_amd import caching
+    from cherryml_amd.io import read_rate_matrix
+    d = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "counting", "tiny_2")
+    aa = ["I", "L", "S", "T"]
+    pairs = [a + b for a in aa for b in aa]
+    mask = np.array([[1 if (p[0] == q[0] or p[1] == q[1]) else 0 for q in pairs] for p in pairs])
+    mpath = str(tmp_path / "mask.txt")
+    pd.DataFrame(mask, index=pairs, columns=pairs).to_csv(mpath, sep=" ")
+    caching.set_cache_dir(str(tmp_path / "cache"))
+    try:
+        res = cherryml_amd.coevolution_end_to_end_with_cherryml_optimizer(
+            msa_dir=f"{d}/msa_dir", contact_map_dir=f"{d}/contact_map_dir",
+            minimum_distance_for_nontrivial_contact=2, coevolution_mask_path=mpath,
+            families=["fam1", "fam2", "fam3"], tree_estimator=None,
+            initial_tree_estimator_rate_matrix_path=None, num_epochs=5, tree_dir=f"{d}/tree_dir",
+            quantization_grid_center=4.0, quantization_grid_step=1.5, quantization_grid_num_steps=3,
+            alphabet=aa, optimizer_initialization="random")
+    finally:
+        caching.set_cache_dir(None)
+    Q = read_rate_matrix(res["learned_rate_matrix_path"])
+    assert list(Q.index) == pairs
+    assert np.all((Q.to_numpy() != 0) == (mask != 0))
+    assert np.abs(Q.to_numpy().sum(1)).max() < 1e-12
