@@ -14,6 +14,8 @@ Workloads (BASELINE.json configs):
             the reference's demo_data co-evolution bank)   [default]
   lg20      LG 20x20, 1000 families x 200 sites x 64 cherries: sum C = 1.28e7
   siterm    SiteRM per-site 20x20, L sites (--sites, default 5000), B = 129
+  counting  the stage that PRODUCES the LG bank: 1000 families x 64 cherries
+            x 200 sites, step = one histogram pass over all cherries, inputs resident in HBM
 
 N > 1 (one process per GPU, torch.distributed/RCCL): coevo400 / lg20 shard the
 129 buckets over the ranks and all-reduce (loss, dL/dQ) each epoch -- strong
@@ -178,7 +180,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None)
     ap.add_argument("--warmup", type=int, default=None)
-    ap.add_argument("--workload", default="coevo400", choices=["coevo400", "lg20", "siterm"])
+    ap.add_argument("--workload", default="coevo400",
+                    choices=["coevo400", "lg20", "siterm", "counting"])
     ap.add_argument("--sites", type=int, default=5000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true")
@@ -328,9 +331,17 @@ def main():
         bank.close()
         return out
 
-    defaults = {"coevo400": (10, 2), "lg20": (500, 50), "siterm": (5, 1)}
+    defaults = {"coevo400": (10, 2), "lg20": (500, 50), "siterm": (5, 1), "counting": (20, 3)}
     steps = args.steps if args.steps is not None else defaults[args.workload][0]
     warmup = args.warmup if args.warmup is not None else defaults[args.workload][1]
+    if args.workload == "counting":
+        out = run_counting(steps, warmup, world, rank, local_rank, fence,
+                           world == 1 and not args.no_cpu_baseline)
+        if rank == 0:
+            print(json.dumps(out))
+        if world > 1:
+            dist.destroy_process_group()
+        return
     out = run(args.workload, steps, warmup, world == 1 and not args.no_cpu_baseline)
     if (rank == 0 and world == 1 and args.workload == "coevo400" and not args.no_secondary
             and args.steps is None):
@@ -342,6 +353,112 @@ def main():
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
+
+
+def run_counting(steps, warmup, world, rank, local_rank, fence, with_cpu):
+    """cb_count_transitions on a config-2-shaped synthetic input: 1000 families x 64 cherries
+    x 200 sites per rank (families shard over ranks like the reference's MPI ranks; the
+    integer counts are all-reduced once per pass)."""
+    import ctypes
+    import torch
+    import torch.distributed as dist
+    from cherryml_amd import _lib
+    from cherryml_amd.counting._stage import PAIR_DTYPE
+
+    rng = np.random.default_rng(1 + rank)
+    F, NCH, L, S = 1000, 64, 200, 20
+    grid = quantization_grid()
+    B = grid.size
+    seqs = rng.integers(0, S, size=(F, 2 * NCH, L), dtype=np.int8)
+    same = rng.random((F, NCH, L)) < 0.7          # leaves of a cherry mostly agree
+    seqs[:, 1::2][same] = seqs[:, 0::2][same]
+    seqs[rng.random(seqs.shape) < 0.05] = -1       # gaps
+    rates = np.round(rng.gamma(3.0, 1.0 / 3.0, size=(F, L)) + 0.01, 5)
+    pairs = np.zeros(F * NCH, dtype=PAIR_DTYPE)
+    fam = np.repeat(np.arange(F), NCH)
+    ch = np.tile(np.arange(NCH), F)
+    pairs["seq_a"] = (fam * 2 * NCH + 2 * ch) * L
+    pairs["seq_b"] = (fam * 2 * NCH + 2 * ch + 1) * L
+    pairs["aux"] = fam * L
+    pairs["n"] = L
+    pairs["len_a"] = rng.exponential(0.2, size=F * NCH)
+    pairs["len_b"] = rng.exponential(0.2, size=F * NCH)
+    dev = torch.device("cuda", local_rank)
+    d_seqs = torch.from_numpy(seqs.reshape(-1)).to(dev)
+    d_rates = torch.from_numpy(rates.reshape(-1)).to(dev)
+    d_grid = torch.from_numpy(grid).to(dev)
+    d_pairs = torch.from_numpy(pairs.view(np.uint8)).to(dev)
+    d_counts = torch.zeros(B * S * S, dtype=torch.int64, device=dev)
+    lib = _lib.load()
+
+    def step():
+        d_counts.zero_()
+        rc = lib.cb_count_transitions(local_rank, S, B, d_grid.data_ptr(), d_seqs.data_ptr(),
+                                      d_seqs.numel(), d_rates.data_ptr(), d_rates.numel(),
+                                      d_pairs.data_ptr(), len(pairs), 1, _lib.CB_PTR_DEVICE,
+                                      d_counts.data_ptr())
+        _lib.check(rc, "cb_count_transitions")
+        if world > 1:
+            dist.all_reduce(d_counts, op=dist.ReduceOp.SUM)
+
+    for _ in range(warmup):
+        step()
+    fence()
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+    t0 = time.perf_counter()
+    ev[0].record()
+    for _ in range(steps):
+        step()
+    ev[1].record()
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tdt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tdt, op=dist.ReduceOp.MAX)
+        dt = float(tdt.item())
+    if rank != 0:
+        return None
+    counted = float(d_counts.sum().item()) * 0.5   # all ranks' pairs after the all-reduce
+    kernel_ms = ev[0].elapsed_time(ev[1]) / steps  # default stream: zero + histogram (+ all-reduce)
+    # algorithmic bytes of one pass: both code bytes of every pair x site, the pair records,
+    # the site rates once per family and the count tensor once (atomics are not "bytes moved")
+    nbytes = 2.0 * len(pairs) * L + pairs.nbytes + rates.nbytes + B * S * S * 8
+    achieved = nbytes / (kernel_ms * 1e-3) / 1e9
+    out = {
+        "metric": "cherry-pairs/sec (whole node) counted per pass", "value": counted / (dt / steps),
+        "unit": "cherry-pairs/s", "n_gpus": world, "steps": steps, "warmup": warmup,
+        "ms_per_step": dt / steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "i8/u64", "data": "synthetic",
+        "config": {"workload": f"counting: {F} families x {NCH} cherries x {L} sites per GPU, "
+                               "B=129 grid, cherry (symmetric) mode", "states": S, "buckets": B,
+                   "sharding": f"families x{world}, all-reduce of integer counts"},
+        "roofline": {"bound": "hbm", "kernel": "count_transitions_kernel", "achieved": achieved,
+                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                     "traffic": None, "ms_per_launch": kernel_ms, "bytes_per_launch": nbytes,
+                     "note": "atomic-bound: 2 u64 atomics per counted pair x site into 51,600 bins"},
+        "counted_pairs": counted,
+    }
+    if with_cpu:
+        from oracle import counting_oracle as co
+        npairs = 150
+        t0 = time.time()
+        C = np.zeros((B, S, S))
+        for p in pairs[:npairs]:
+            sa = seqs.reshape(-1)[p["seq_a"]:p["seq_a"] + L]
+            sb = seqs.reshape(-1)[p["seq_b"]:p["seq_b"] + L]
+            rt = rates.reshape(-1)[p["aux"]:p["aux"] + L]
+            total = p["len_a"] + p["len_b"]
+            for k in range(L):
+                q = co.quantization_idx(total * rt[k], grid)
+                if q is None or sa[k] < 0 or sb[k] < 0:
+                    continue
+                C[q, sa[k], sb[k]] += 0.5
+                C[q, sb[k], sa[k]] += 0.5
+        cdt = time.time() - t0
+        out["cpu_baseline"] = {"value": float(C.sum()) / cdt, "unit": "cherry-pairs/s", "cores": 1,
+                               "kind": "port", "sample": f"{npairs} of {len(pairs)} cherries x {L} sites, "
+                               "the oracle's per-site loop (the reference's Python counter)"}
+    return out
 
 
 def _pmc_traffic():

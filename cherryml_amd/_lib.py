@@ -35,9 +35,9 @@ SIGNATURES = {
                                             C.c_int, _vp, _vp, _vp, _vp, C.c_int]),
     "cb_train_siterm": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_double, C.c_int, _vp, _vp]),
     "cb_count_transitions": (C.c_int, [C.c_int, C.c_int, C.c_int, _vp, _vp, C.c_int64, _vp, C.c_int64,
-                                       _vp, C.c_int64, C.c_int, _vp]),
+                                       _vp, C.c_int64, C.c_int, C.c_int, _vp]),
     "cb_count_co_transitions": (C.c_int, [C.c_int, C.c_int, C.c_int, _vp, _vp, C.c_int64, _vp, C.c_int64,
-                                          _vp, C.c_int64, C.c_int, _vp]),
+                                          _vp, C.c_int64, C.c_int, C.c_int, _vp]),
 }
 
 _lib = None

@@ -144,7 +144,7 @@ def count_transitions(
     counts = np.zeros((B, S, S), dtype=np.uint64)
     rc = _lib.load().cb_count_transitions(
         _device_index(), S, B, grid.ctypes.data, seqs.ctypes.data, seqs.size, rates.ctypes.data,
-        rates.size, pairs.ctypes.data, len(pairs), int(mode != "edge"), counts.ctypes.data)
+        rates.size, pairs.ctypes.data, len(pairs), int(mode != "edge"), 0, counts.ctypes.data)
     _lib.check(rc, "cb_count_transitions")
     counts = _all_reduce_counts(counts)
     _write(output_count_matrices_dir, grid, counts, 1.0 if mode == "edge" else 0.5,
@@ -194,7 +194,7 @@ def count_co_transitions(
     counts = np.zeros((B, S * S, S * S), dtype=np.uint64)
     rc = _lib.load().cb_count_co_transitions(
         _device_index(), S, B, grid.ctypes.data, seqs.ctypes.data, seqs.size, contacts.ctypes.data,
-        contacts.size // 2, pairs.ctypes.data, len(pairs), int(mode != "edge"), counts.ctypes.data)
+        contacts.size // 2, pairs.ctypes.data, len(pairs), int(mode != "edge"), 0, counts.ctypes.data)
     _lib.check(rc, "cb_count_co_transitions")
     counts = _all_reduce_counts(counts)
     states = [a + b for a in amino_acids for b in amino_acids]

@@ -887,11 +887,52 @@ static int read_phase_times(cb_bank *h, double (&v)[CB_T_COUNT]) {
 }
 
 // ------------------------------------------------------------------------ counting
+// Replica scratch of the resident (device-pointer) form, kept per device for the life of the
+// process (the only process-wide state of the library; never holds results between calls).
+static int count_scratch(int device, size_t elems, unsigned long long **out) {
+  static unsigned long long *buf[64] = {};
+  static size_t cap[64] = {};
+  if (device < 0 || device >= 64) return fail(CB_EINVAL, "counting: device %d out of range", device);
+  if (cap[device] < elems) {
+    if (buf[device]) (void)hipFree(buf[device]);
+    buf[device] = nullptr;
+    cap[device] = 0;
+    hipError_t e = hipMalloc((void **)&buf[device], elems * sizeof(unsigned long long));
+    if (e != hipSuccess) return fail(CB_ENOMEM, "counting: replica scratch allocation failed");
+    cap[device] = elems;
+  }
+  *out = buf[device];
+  return CB_OK;
+}
+
 static int count_common(int device, int S, int B, const double *grid, const int8_t *seqs,
                         int64_t seqs_bytes, const void *aux, size_t aux_bytes,
-                        const cb_count_pair *pairs, int64_t n_pairs, int symmetric,
+                        const cb_count_pair *pairs, int64_t n_pairs, int symmetric, int flags,
                         unsigned long long *counts, bool co) {
   if (S < 1 || B < 1 || !grid || !counts) return fail(CB_EINVAL, "counting: bad S/B/grid/counts");
+  if (flags & CB_PTR_DEVICE) {  // resident form: enqueue only, add into counts
+    if (n_pairs < 0 || (n_pairs > 0 && (!pairs || !seqs))) return fail(CB_EINVAL, "counting: bad pairs");
+    HIP_TRY(hipSetDevice(device));
+    if (n_pairs > 0) {
+      const unsigned blocks = (unsigned)((n_pairs + 3) / 4);
+      if (co)
+        hipLaunchKernelGGL(count_co_transitions_kernel, dim3(blocks), dim3(256), 0, 0, S, B, grid, seqs,
+                           (const int32_t *)aux, pairs, (long long)n_pairs, symmetric, counts);
+      else {
+        unsigned long long *rep = nullptr;
+        int rc = count_scratch(device, (size_t)B * S * S * CNT_REPLICAS, &rep);
+        if (rc != CB_OK) return rc;
+        const size_t nb = (size_t)B * S * S;
+        HIP_TRY(hipMemsetAsync(rep, 0, nb * CNT_REPLICAS * sizeof(unsigned long long), 0));
+        hipLaunchKernelGGL(count_transitions_kernel, dim3(blocks), dim3(256), 0, 0, S, B, grid, seqs,
+                           (const double *)aux, pairs, (long long)n_pairs, symmetric, rep, CNT_REPLICAS);
+        hipLaunchKernelGGL(count_reduce_replicas, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, 0, rep,
+                           CNT_REPLICAS, nb, counts);
+      }
+      HIP_TRY(hipGetLastError());
+    }
+    return CB_OK;
+  }
   if (n_pairs < 0 || (n_pairs > 0 && (!pairs || !seqs))) return fail(CB_EINVAL, "counting: bad pairs");
   for (int b = 1; b < B; ++b)
     if (!(grid[b] > grid[b - 1])) return fail(CB_EINVAL, "counting: quantization points must be sorted");
@@ -941,7 +982,7 @@ static int count_common(int device, int S, int B, const double *grid, const int8
                          (const int32_t *)d_aux, d_pairs, (long long)n_pairs, symmetric, d_counts);
     else
       hipLaunchKernelGGL(count_transitions_kernel, dim3(blocks), dim3(256), 0, 0, S, B, d_grid, d_seqs,
-                         (const double *)d_aux, d_pairs, (long long)n_pairs, symmetric, d_counts);
+                         (const double *)d_aux, d_pairs, (long long)n_pairs, symmetric, d_counts, 1);
     TRYC(hipGetLastError());
     TRYC(hipDeviceSynchronize());
   }
@@ -954,19 +995,19 @@ static int count_common(int device, int S, int B, const double *grid, const int8
 extern "C" int cb_count_transitions(int device, int S, int B, const double *grid, const int8_t *seqs,
                                     int64_t seqs_bytes, const double *rates, int64_t n_rates,
                                     const cb_count_pair *pairs, int64_t n_pairs, int symmetric,
-                                    unsigned long long *counts) {
+                                    int flags, unsigned long long *counts) {
   if (S > 127) return fail(CB_EINVAL, "cb_count_transitions: at most 127 states (int8 codes)");
   return count_common(device, S, B, grid, seqs, seqs_bytes, rates, (size_t)(n_rates > 0 ? n_rates : 0) * sizeof(double),
-                      pairs, n_pairs, symmetric, counts, false);
+                      pairs, n_pairs, symmetric, flags, counts, false);
 }
 
 extern "C" int cb_count_co_transitions(int device, int S, int B, const double *grid, const int8_t *seqs,
                                        int64_t seqs_bytes, const int32_t *contacts, int64_t n_contacts,
                                        const cb_count_pair *pairs, int64_t n_pairs, int symmetric,
-                                       unsigned long long *counts) {
+                                       int flags, unsigned long long *counts) {
   if (S > 127) return fail(CB_EINVAL, "cb_count_co_transitions: at most 127 states (int8 codes)");
   // contact indices must address sites inside the sequences: checked per pair on the host
-  for (int64_t p = 0; p < n_pairs && pairs && contacts; ++p) {
+  for (int64_t p = 0; !(flags & CB_PTR_DEVICE) && p < n_pairs && pairs && contacts; ++p) {
     const cb_count_pair &pr = pairs[p];
     if (pr.aux < 0 || pr.n < 0 || pr.aux + pr.n > n_contacts)
       return fail(CB_EINVAL, "cb_count_co_transitions: pair %lld contact range outside the list", (long long)p);
@@ -979,5 +1020,5 @@ extern "C" int cb_count_co_transitions(int device, int S, int B, const double *g
   }
   return count_common(device, S, B, grid, seqs, seqs_bytes, contacts,
                       (size_t)(n_contacts > 0 ? n_contacts : 0) * 2 * sizeof(int32_t), pairs, n_pairs, symmetric,
-                      counts, true);
+                      flags, counts, true);
 }

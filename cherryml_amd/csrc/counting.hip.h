@@ -22,12 +22,29 @@ __device__ __forceinline__ int cnt_quantize(double bl, const double *__restrict_
   return (rel_left < rel_right) ? lo - 1 : lo;
 }
 
+// `counts` may be CNT_REPLICAS copies of the [B][S][S] tensor: workgroup g adds into copy
+// g % replicas, so that the hot bins (identical residues on both leaves, i.e. the diagonal
+// of a few buckets) are hit by 1/replicas of the atomics each -- same-address float/int
+// atomics serialise at the memory side (MI355X_MICROARCH.md, Global float atomics:
+// contention row).  count_reduce_replicas then sums the copies (integers: exact).
+#define CNT_REPLICAS 32
+
+__global__ void count_reduce_replicas(const unsigned long long *__restrict__ rep, int replicas,
+                                      size_t nbins, unsigned long long *__restrict__ counts) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nbins) return;
+  unsigned long long s = 0;
+  for (int r = 0; r < replicas; ++r) s += rep[(size_t)r * nbins + i];
+  counts[i] += s;
+}
+
 __global__ __launch_bounds__(256) void count_transitions_kernel(
     int S, int B, const double *__restrict__ grid, const int8_t *__restrict__ seqs,
     const double *__restrict__ rates, const cb_count_pair *__restrict__ pairs, long long n_pairs,
-    int symmetric, unsigned long long *__restrict__ counts) {
+    int symmetric, unsigned long long *__restrict__ counts_base, int replicas) {
   const long long p = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (p >= n_pairs) return;
+  unsigned long long *counts = counts_base + (size_t)(blockIdx.x % replicas) * B * S * S;
   const cb_count_pair pr = pairs[p];
   const double total = pr.len_a + pr.len_b;
   const int8_t *sa = seqs + pr.seq_a, *sb = seqs + pr.seq_b;

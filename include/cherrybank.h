@@ -180,7 +180,11 @@ int cb_train_siterm(cb_handle h, double *theta, double *Theta, int num_epochs,
  * and histogram the states.  Counts are INTEGERS (u64 atomics): bit-exact and
  * order-independent; the caller multiplies by the unit (0.5 / 1 / 0.25).
  * Sequences are int8 codes: state index, or negative for any symbol outside the alphabet.
- * All pointers are host pointers; the call is stateless and synchronous.
+ * flags = 0: all pointers are host pointers, `counts` is overwritten; the call is stateless
+ * and synchronous.  flags & CB_PTR_DEVICE: every pointer (grid, seqs, rates / contacts,
+ * pairs, counts) is a device pointer on `device`, the kernel is enqueued on HIP's default
+ * stream and ADDS into `counts` (the caller zeroes it, validates its offsets, and
+ * synchronises): the form a resident pipeline and bench.py use.
  */
 typedef struct {
   int64_t seq_a, seq_b; /* byte offsets of the two encoded sequences in `seqs`        */
@@ -195,7 +199,7 @@ typedef struct {
  * site k of every pair with q = quantization_idx((len_a + len_b) * rates[aux + k]). */
 int cb_count_transitions(int device, int S, int B, const double *grid, const int8_t *seqs,
                          int64_t seqs_bytes, const double *rates, int64_t n_rates,
-                         const cb_count_pair *pairs, int64_t n_pairs, int symmetric,
+                         const cb_count_pair *pairs, int64_t n_pairs, int symmetric, int flags,
                          unsigned long long *counts);
 
 /* counts[B*S^2*S^2]: for every pair with q = quantization_idx(len_a + len_b) and every
@@ -203,7 +207,7 @@ int cb_count_transitions(int device, int S, int B, const double *grid, const int
  * versions s', e':  += 1 at (s,e), (s',e')  [and (e,s), (e',s') when symmetric]. */
 int cb_count_co_transitions(int device, int S, int B, const double *grid, const int8_t *seqs,
                             int64_t seqs_bytes, const int32_t *contacts, int64_t n_contacts,
-                            const cb_count_pair *pairs, int64_t n_pairs, int symmetric,
+                            const cb_count_pair *pairs, int64_t n_pairs, int symmetric, int flags,
                             unsigned long long *counts);
 
 #ifdef __cplusplus
