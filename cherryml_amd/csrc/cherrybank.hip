@@ -389,7 +389,7 @@ static int large_eigh(cb_bank *h, bool warm) {
   h->have_prev = false;
   const int nb = LD / JB_W;
   const int RS = LD + ((2 - LD % 32 + 32) % 32);
-  const size_t lds = (size_t)(16 * RS + 3 * 16 * 17 + 1024) * sizeof(double);
+  const size_t lds = (size_t)(16 * RS + 3 * 16 * 17 + JB_WAVES * 256) * sizeof(double);
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(lgj_round),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   const int max_sweeps = 40;

@@ -95,10 +95,23 @@ __device__ __forceinline__ double quad_xor2(double v) {
   hi = __builtin_amdgcn_update_dpp(hi, hi, 0x4E, 0xF, 0xF, false);
   return __hiloint2double(hi, lo);
 }
+// lane i <-> lane 7 - i inside every group of 8 lanes (DPP row_half_mirror): after a quad_sum
+// the four lanes of a quad agree, so this exchanges the two quads of an 8-lane group
+__device__ __forceinline__ double half_mirror(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(lo, lo, 0x141, 0xF, 0xF, false);  // row_half_mirror
+  hi = __builtin_amdgcn_update_dpp(hi, hi, 0x141, 0xF, 0xF, false);
+  return __hiloint2double(hi, lo);
+}
 __device__ __forceinline__ double quad_sum(double v) {
   v += quad_xor1(v);
   v += quad_xor2(v);
   return v;
+}
+
+__device__ __forceinline__ double oct_sum(double v) {  // sum over aligned groups of 8 lanes
+  v = quad_sum(v);
+  return v + half_mirror(v);
 }
 
 // 1/sqrt(x) and 1/x from the hardware seeds (v_rsq_f64 / v_rcp_f64) + Newton

@@ -18,7 +18,8 @@
 #include "jacobi_wave.hip.h"
 
 #define JB_W 8        // columns per block
-#define JB_THREADS 256
+#define JB_THREADS 512
+#define JB_WAVES (JB_THREADS / 64)
 
 __global__ void lgj_sigma(int LD, const double *A, double *sigma) {
   __shared__ double s[256];
@@ -60,7 +61,7 @@ __global__ __launch_bounds__(JB_THREADS) void lgj_round(int LD, int round, int i
   double *sGam = sG + 16 * RS;      // [16][17]  Gram -> orthogonalised columns
   double *sR = sGam + 16 * 17;      // [16][17]  R: column c' at sR + c'*17
   double *sN = sR + 16 * 17;        // [16][17]  R^T R, then polished R
-  double *sPart = sN + 16 * 17;     // [4][256] partial Gram per wave
+  double *sPart = sN + 16 * 17;     // [JB_WAVES][256] partial Gram per wave
 
   const int nb = LD / JB_W;
   int bi, bj;
@@ -94,15 +95,15 @@ __global__ __launch_bounds__(JB_THREADS) void lgj_round(int LD, int round, int i
   //    Four independent accumulators: a dependent f64 MFMA chain costs ~300 cycles a link.
   d4 acc = {0.0, 0.0, 0.0, 0.0};
   {
-    // this wave's k-steps are s = wave, wave + 4, ...; batches of 8: all 8 LDS reads in
-    // flight, then 8 MFMAs on 4 independent accumulators
+    // this wave's k-steps are s = wave, wave + JB_WAVES, ...; batches of 8: all 8 LDS reads
+    // in flight, then 8 MFMAs on 4 independent accumulators
     d4 a0 = acc, a1 = acc, a2 = acc, a3 = acc;
     const int nsteps = LD / 4;
-    for (int s0 = wave; s0 < nsteps; s0 += 32) {
+    for (int s0 = wave; s0 < nsteps; s0 += 8 * JB_WAVES) {
       double v[8];
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
-        const int st = s0 + 4 * i;
+        const int st = s0 + JB_WAVES * i;
         const double x = sG[lo * RS + 4 * min(st, nsteps - 1) + hi];
         v[i] = st < nsteps ? x : 0.0;
       }
@@ -120,9 +121,11 @@ __global__ __launch_bounds__(JB_THREADS) void lgj_round(int LD, int round, int i
 #pragma unroll
   for (int r = 0; r < 4; ++r) sPart[wave * 256 + (hi + 4 * r) * 16 + lo] = acc[r];
   __syncthreads();
-  {
+  if (threadIdx.x < 256) {
     const int e = threadIdx.x;  // 256 entries
-    const double v = sPart[e] + sPart[256 + e] + sPart[512 + e] + sPart[768 + e];
+    double v = 0.0;
+#pragma unroll
+    for (int w = 0; w < JB_WAVES; ++w) v += sPart[w * 256 + e];
     sGam[(e >> 4) * 17 + (e & 15)] = v;
   }
   __syncthreads();
@@ -156,7 +159,7 @@ __global__ __launch_bounds__(JB_THREADS) void lgj_round(int LD, int round, int i
   // One Newton-Schulz step R <- R (3 I - R^T R) / 2 (all four waves, one entry per thread):
   // a product of plane rotations is orthogonal only to a few 1e-16 and that defect would
   // add up over the ~300 block rounds of a solve.
-  {
+  if (threadIdx.x < 256) {
     const int e = threadIdx.x, p = e >> 4, q = e & 15;
     double d = 0.0;
 #pragma unroll
@@ -164,7 +167,7 @@ __global__ __launch_bounds__(JB_THREADS) void lgj_round(int LD, int round, int i
     sGam[p * 17 + q] = d;  // N = R^T R  (symmetric)
   }
   __syncthreads();
-  {
+  if (threadIdx.x < 256) {
     const int e = threadIdx.x, q = e >> 4, c = e & 15;
     double d = 0.0;
 #pragma unroll
@@ -179,8 +182,8 @@ __global__ __launch_bounds__(JB_THREADS) void lgj_round(int LD, int round, int i
   for (int s = 0; s < 4; ++s) Rf[s] = sN[lo * 17 + 4 * s + hi];  // R[c = 4s+hi][c' = lo]
   const int ntiles = LD / 16;
   int job = wave;
-  for (; job + 4 < ntiles; job += 8) {  // two row tiles per trip: independent MFMA chains
-    const int r0 = job * 16, r1 = (job + 4) * 16;
+  for (; job + JB_WAVES < ntiles; job += 2 * JB_WAVES) {  // two row tiles per trip
+    const int r0 = job * 16, r1 = (job + JB_WAVES) * 16;
     d4 o0 = {0.0, 0.0, 0.0, 0.0}, o1 = o0;
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
@@ -194,7 +197,7 @@ __global__ __launch_bounds__(JB_THREADS) void lgj_round(int LD, int round, int i
       dst[r1] = o1[r];
     }
   }
-  for (; job < ntiles; job += 4) {
+  for (; job < ntiles; job += JB_WAVES) {
     const int r0 = job * 16;
     d4 o = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll

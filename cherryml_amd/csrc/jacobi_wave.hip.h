@@ -197,24 +197,23 @@ __device__ int wave_rotation_spd16(double *Gam, double *Rc, int LS, int max_swee
   return wave_jacobi_columns<4, true>(16, Gam, Rc, LS, max_sweeps);
 }
 
-// One pass over a chosen family of pairs of the 16 columns (same rotation code
-// as wave_jacobi_columns<4, true>):
+// One pass over a chosen family of pairs of the 16 columns (same rotation arithmetic as
+// wave_jacobi_columns):
 //   cross = true : the 64 pairs (i, 8 + j) between the two 8-column blocks, as 8
 //                  perfect matchings  i <-> 8 + (i + r) % 8
 //   cross = false: the 2 x 28 pairs inside each block, 7 tournament rounds each
-// 4 lanes per pair (8 pairs -> 32 lanes), 4 rows per lane.
+// All 64 lanes work: 8 lanes per pair, 2 of the 16 rows per lane (rows sub, sub + 8).
 // Returns (wave-uniform) the largest squared cosine g^2 / (a b) met BEFORE its rotation.
 __device__ double wave_rotation_spd16_blockpairs(double *Gc, double *Vc, int LS, bool cross) {
   const int lane = threadIdx.x & 63;
-  const int slot = lane >> 2, sub = lane & 3;
-  const bool active = slot < 8;
+  const int slot = lane >> 3, sub = lane & 7;
   const int nrounds = cross ? 8 : 7;
   double off2 = 0.0;
   for (int r = 0; r < nrounds; ++r) {
     int pp, qq;
     if (cross) {
-      pp = slot & 7;
-      qq = 8 + ((pp + r) & 7);
+      pp = slot;
+      qq = 8 + ((slot + r) & 7);
     } else {
       // slots 0-3: block 0, slots 4-7: block 1; 8 players each, circle method
       const int i = slot & 3, base = (slot & 4) ? 8 : 0;
@@ -223,28 +222,14 @@ __device__ double wave_rotation_spd16_blockpairs(double *Gc, double *Vc, int LS,
       pp = base + a;
       qq = base + b;
     }
-    double x[4], y[4], u[4], v[4];
-    double a = 0.0, b = 0.0, g = 0.0;
-    const int pbase = (active ? pp : 0) * LS, qbase = (active ? qq : 1) * LS;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int row = sub + 4 * i;
-      x[i] = Gc[pbase + row];
-      y[i] = Gc[qbase + row];
-      u[i] = Vc[pbase + row];
-      v[i] = Vc[qbase + row];
-    }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      a = fma(x[i], x[i], a);
-      b = fma(y[i], y[i], b);
-      g = fma(x[i], y[i], g);
-    }
-    a = quad_sum(a);
-    b = quad_sum(b);
-    g = quad_sum(g);
+    const int pbase = pp * LS + sub, qbase = qq * LS + sub;
+    const double x0 = Gc[pbase], x1 = Gc[pbase + 8], y0 = Gc[qbase], y1 = Gc[qbase + 8];
+    const double u0 = Vc[pbase], u1 = Vc[pbase + 8], v0 = Vc[qbase], v1 = Vc[qbase + 8];
+    const double a = oct_sum(fma(x1, x1, x0 * x0));
+    const double b = oct_sum(fma(y1, y1, y0 * y0));
+    const double g = oct_sum(fma(x1, y1, x0 * y0));
     const double g2 = g * g, ab = a * b;
-    if (active && g2 > ab * (CB_JAC_SKIP * CB_JAC_SKIP)) {
+    if (g2 > ab * (CB_JAC_SKIP * CB_JAC_SKIP)) {
       off2 = fmax(off2, g2 * fast_rcp(ab));
       const double d = b - a;
       const double hh = fma(d, d, 4.0 * g2);
@@ -253,14 +238,14 @@ __device__ double wave_rotation_spd16_blockpairs(double *Gc, double *Vc, int LS,
       const double t = 2.0 * g * copysign(fast_rcp(fabs(den)), den);
       const double c = fast_rsqrt(fma(t, t, 1.0));
       const double s = c * t;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int row = sub + 4 * i;
-        Gc[pbase + row] = c * x[i] - s * y[i];
-        Gc[qbase + row] = s * x[i] + c * y[i];
-        Vc[pbase + row] = c * u[i] - s * v[i];
-        Vc[qbase + row] = s * u[i] + c * v[i];
-      }
+      Gc[pbase] = c * x0 - s * y0;
+      Gc[pbase + 8] = c * x1 - s * y1;
+      Gc[qbase] = s * x0 + c * y0;
+      Gc[qbase + 8] = s * x1 + c * y1;
+      Vc[pbase] = c * u0 - s * v0;
+      Vc[pbase + 8] = c * u1 - s * v1;
+      Vc[qbase] = s * u0 + c * v0;
+      Vc[qbase + 8] = s * u1 + c * v1;
     }
     wave_lds_fence();
   }
