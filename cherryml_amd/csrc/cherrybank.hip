@@ -771,8 +771,48 @@ static int run_fused_training(cb_bank *h, int kind, double *pi_param, double *up
     a.loss_curve = d_loss; a.Q_best = d_Qb; a.Q_last = d_Ql; a.Q_pow2 = d_Qp;
     for (bool &b : h->ev_rec) b = false;
     mark(h, EV_START);
-    if (E > 0) rc = (L < 512) ? launch_train_nw<8>(h, a) : launch_train_nw<4>(h, a);
-    mark(h, EV_SMALL);  // cb_last_timings(): CB_T_SMALL = the whole E-epoch launch
+    const char *env_split = getenv("CB_LG_SPLIT");
+    const bool split = kind == 0 && L == 1 && !(env_split && atoi(env_split) == 0);
+    if (E > 0 && split) {
+      // one LG-sized bank: the epoch spread over the chip, three small launches per epoch
+      LgSplit g{};
+      double *buf = nullptr;
+      const size_t nbuf = LGS_TOTAL + (size_t)h->B * 1025 + 8;
+      if (!alloc(&buf, nbuf)) rc = fail(CB_ENOMEM, "fused training: device allocation failed");
+      if (rc == CB_OK) {
+        g.frames = buf;
+        g.Mpart = buf + LGS_TOTAL;
+        g.lpart = g.Mpart + (size_t)h->B * 1024;
+        g.best = g.lpart + h->B;
+        const size_t lds_pf = (SmallLds<4>::TOTAL + 72) * sizeof(double);
+        const size_t lds_b = SmallLds<4>::TOTAL * sizeof(double);
+        const unsigned nblk = (unsigned)((h->B + 3) / 4);
+        double pow_b1 = 1.0, pow_b2 = 1.0;
+        for (int e = 0; e < E && rc == CB_OK; ++e) {
+          pow_b1 *= a.beta1;
+          pow_b2 *= a.beta2;
+          hipLaunchKernelGGL(lg_prepare, dim3(1), dim3(256), lds_pf, h->stream, a, g, e);
+#define LGB(NT, KS) hipLaunchKernelGGL((lg_bank<NT, KS>), dim3(nblk), dim3(256), lds_b, h->stream, a, g)
+          if (S <= 4) LGB(1, 1);
+          else if (S <= 8) LGB(1, 2);
+          else if (S <= 16) LGB(1, 4);
+          else if (S <= 20) LGB(2, 5);
+          else if (S <= 24) LGB(2, 6);
+          else LGB(2, 8);
+#undef LGB
+          if (S <= 16)
+            hipLaunchKernelGGL(lg_finish<1>, dim3(1), dim3(256), lds_pf, h->stream, a, g, e, 1.0 - pow_b1,
+                               std::sqrt(1.0 - pow_b2));
+          else
+            hipLaunchKernelGGL(lg_finish<2>, dim3(1), dim3(256), lds_pf, h->stream, a, g, e, 1.0 - pow_b1,
+                               std::sqrt(1.0 - pow_b2));
+          if ((e & 63) == 63 && hipGetLastError() != hipSuccess) rc = fail(CB_EHIP, "fused training launch failed");
+        }
+      }
+    } else if (E > 0) {
+      rc = (L < 512) ? launch_train_nw<8>(h, a) : launch_train_nw<4>(h, a);
+    }
+    mark(h, EV_SMALL);  // cb_last_timings(): CB_T_SMALL = all E epochs
   }
   TRYH(hipMemcpyAsync(pi_param, d_pi, (size_t)L * S * sizeof(double), hipMemcpyDeviceToHost, h->stream));
   TRYH(hipMemcpyAsync(up_param, d_up, L * nup * sizeof(double), hipMemcpyDeviceToHost, h->stream));

@@ -251,6 +251,27 @@ __device__ __forceinline__ void small_build_A(int S, const double *__restrict__ 
   __syncthreads();
 }
 
+// ---- dA = U M U^T in place: sG holds M on entry, dL/dA on exit ---------------------
+// sX: >= 1024 doubles of scratch.  All threads call; ends with a barrier.
+__device__ __forceinline__ void small_dA_from_M(int S, double *sG, const double *sV, double *sX) {
+  // X = M U^T  (X[a][j] = sum_c M[a][c] U[j][c])
+  for (int e = threadIdx.x; e < S * S; e += blockDim.x) {
+    const int ra = e / S, j = e - ra * S;
+    double acc = 0.0;
+    for (int c = 0; c < S; ++c) acc = fma(sG[ra * CB_LS + c], sV[c * CB_LS + j], acc);
+    sX[ra * 32 + j] = acc;
+  }
+  __syncthreads();
+  // dA = U X
+  for (int e = threadIdx.x; e < S * S; e += blockDim.x) {
+    const int i = e / S, j = e - i * S;
+    double acc = 0.0;
+    for (int k = 0; k < S; ++k) acc = fma(sV[k * CB_LS + i], sX[k * 32 + j], acc);
+    sG[i * CB_LS + j] = acc;
+  }
+  __syncthreads();
+}
+
 // ---- one site: A (LDS) -> loss, dL/dA (LDS) -----------------------------------
 // Precondition : sA = A (symmetric, stride CB_LS), sD = sqrt(pi); all threads call.
 // Postcondition: lds[LD::LOSS + NW - 1 ... ] unchanged; returns nothing, but
@@ -358,24 +379,7 @@ __device__ __forceinline__ void small_site_eval(double *lds, int S, int B,
     __syncthreads();
     return;
   }
-  // ---- X = M U^T  (X[a][j] = sum_c M[a][c] U[j][c]) into the TAB/RED scratch ----
-  // (sA must survive for the caller: the trainers read A_ii afterwards)
-  double *sX = lds + LD::RED;  // >= 1024 doubles, free after the reduction
-  for (int e = threadIdx.x; e < S * S; e += blockDim.x) {
-    const int ra = e / S, j = e - ra * S;
-    double acc = 0.0;
-    for (int c = 0; c < S; ++c) acc = fma(sG[ra * CB_LS + c], sV[c * CB_LS + j], acc);
-    sX[ra * 32 + j] = acc;
-  }
-  __syncthreads();
-  // ---- dA = U X into sG ----------------------------------------------------------
-  for (int e = threadIdx.x; e < S * S; e += blockDim.x) {
-    const int i = e / S, j = e - i * S;
-    double acc = 0.0;
-    for (int k = 0; k < S; ++k) acc = fma(sV[k * CB_LS + i], sX[k * 32 + j], acc);
-    sG[i * CB_LS + j] = acc;
-  }
-  __syncthreads();
+  small_dA_from_M(S, sG, sV, lds + LD::RED);
 }
 
 template <int NT, int KS, int NW, int MODE>

@@ -53,6 +53,139 @@ __device__ __forceinline__ void adam_update(double &p, double &m, double &v, dou
   }
 }
 
+// theta -> pi, d (sPi, sD), A (sA); Q of this epoch -> Q_last (+ snapshot at epochs 1, 2, 4 ...)
+__device__ __forceinline__ void tr_build(const TrainArgs &a, int l, int epoch, double *sA, double *sD,
+                                         double *sPi) {
+  const int S = a.S, tid = threadIdx.x;
+  const int NUP = a.kind == 0 ? S * (S - 1) / 2 : S * S;
+  const double *p_pi = a.p_pi + (size_t)l * S, *p_up = a.p_up + (size_t)l * NUP;
+  double *Qlast = a.Q_last + (size_t)l * S * S;
+  if (tid < 64) {
+    const double x = tid < S ? p_pi[tid] : -INFINITY;
+    const double mx = wave_max(x);
+    const double e = tid < S ? exp(x - mx) : 0.0;
+    const double sum = wave_sum(e);
+    if (tid < 32) {
+      const double pk = tid < S ? e / sum : 1.0;
+      sPi[tid] = pk;
+      sD[tid] = sqrt(pk);
+    }
+  }
+  __syncthreads();
+  for (int e = tid; e < S * S; e += blockDim.x) {
+    const int i = e / S, j = e - i * S;
+    double r = 0.0;
+    if (i != j) {
+      if (a.kind == 0) {
+        const int lo_ = min(i, j), hi_ = max(i, j);
+        const int k = lo_ * S - lo_ * (lo_ + 1) / 2 + (hi_ - lo_ - 1);
+        r = softplus_t(p_up[k]) * (a.mask ? a.mask[e] : 1.0);
+      } else {
+        r = softplus_t(p_up[i * S + j] + p_up[j * S + i]);
+      }
+    }
+    sA[i * CB_LS + j] = r;
+  }
+  __syncthreads();
+  if (tid < S) {
+    double acc = 0.0;
+    for (int j = 0; j < S; ++j)
+      if (j != tid) acc = fma(sA[tid * CB_LS + j], sD[j], acc);
+    sA[tid * CB_LS + tid] = -acc / sD[tid];
+  }
+  __syncthreads();
+  const bool pow2 = a.Q_pow2 && l == 0 && ((epoch & (epoch + 1)) == 0);
+  int pidx = 0;
+  if (pow2) {
+    int e1 = epoch + 1;
+    while (e1 > 1) {
+      e1 >>= 1;
+      ++pidx;
+    }
+  }
+  for (int e = tid; e < S * S; e += blockDim.x) {
+    const int i = e / S, j = e - i * S;
+    const double q = (i == j) ? sA[i * CB_LS + i] : sA[i * CB_LS + j] * sD[j] / sD[i];
+    Qlast[e] = q;
+    if (pow2 && pidx < a.n_pow2) a.Q_pow2[(size_t)pidx * S * S + e] = q;
+  }
+}
+
+// given loss, sG = dL/dA, sA = A, sD, sPi: bookkeeping (loss curve, best iterate), parameter
+// gradients, optimiser step.  best[0] = best loss so far (+inf initially), lives in `best`
+// (LDS or global).  sGd: 32 doubles, sRed: >= S*S doubles of scratch.  Ends with a barrier.
+__device__ __forceinline__ void tr_update(const TrainArgs &a, int l, int epoch, double loss,
+                                          double bc1, double bc2s, const double *sA,
+                                          const double *sG, const double *sD, const double *sPi,
+                                          double *sGd, double *sFlag, double *sRed, double *best) {
+  const int S = a.S, tid = threadIdx.x;
+  const int NUP = a.kind == 0 ? S * (S - 1) / 2 : S * S;
+  double *p_pi = a.p_pi + (size_t)l * S, *p_up = a.p_up + (size_t)l * NUP;
+  double *m_pi = a.m_pi + (size_t)l * S, *v_pi = a.v_pi + (size_t)l * S;
+  double *m_up = a.m_up + (size_t)l * NUP, *v_up = a.v_up + (size_t)l * NUP;
+  double *Qlast = a.Q_last + (size_t)l * S * S, *Qbest = a.Q_best + (size_t)l * S * S;
+  const double inv_n = a.inv_n[l];
+  const double *dirsum = a.dirsum + (size_t)l * S;
+  if (tid == 0) {
+    a.loss_curve[(size_t)epoch * a.L + l] = loss;
+    const bool better = loss < *best;  // strict <, as trainer.py:179
+    sFlag[0] = better ? 1.0 : 0.0;
+    if (better) *best = loss;
+  }
+  if (tid < S) {
+    const int k = tid;
+    double acc = 0.0;
+    for (int i = 0; i < S; ++i)
+      if (i != k) acc = fma(sG[i * CB_LS + i] * sA[i * CB_LS + k], 1.0 / sD[i], acc);
+    sGd[k] = -sD[k] * acc - sG[k * CB_LS + k] * sA[k * CB_LS + k] - dirsum[k] * inv_n;
+  }
+  __syncthreads();
+  if (sFlag[0] != 0.0)
+    for (int e = tid; e < S * S; e += blockDim.x) Qbest[e] = Qlast[e];
+  if (tid < S) {
+    double tot = 0.0;
+    for (int m = 0; m < S; ++m) tot += sGd[m];
+    const double g = 0.5 * (sGd[tid] - sPi[tid] * tot);
+    adam_update(p_pi[tid], m_pi[tid], v_pi[tid], g, a.lr, a.beta1, a.beta2, a.eps, bc1, bc2s, a.do_adam);
+  }
+  for (int k = tid; k < NUP; k += blockDim.x) {
+    int i, j;
+    if (a.kind == 0) {  // k-th entry of the row-major upper triangle
+      i = 0;
+      int rem = k;
+      while (rem >= S - 1 - i) {
+        rem -= S - 1 - i;
+        ++i;
+      }
+      j = i + 1 + rem;
+    } else {
+      i = k / S;
+      j = k - i * S;
+    }
+    double g = 0.0;
+    if (i != j) {
+      const int lo_ = min(i, j), hi_ = max(i, j);
+      const double mk = (a.kind == 0 && a.mask) ? a.mask[lo_ * S + hi_] : 1.0;
+      const double dR_ab = mk * (sG[lo_ * CB_LS + hi_] - sG[lo_ * CB_LS + lo_] * sD[hi_] / sD[lo_]);
+      const double dR_ba = mk * (sG[hi_ * CB_LS + lo_] - sG[hi_ * CB_LS + hi_] * sD[lo_] / sD[hi_]);
+      const double x = a.kind == 0 ? p_up[k] : p_up[i * S + j] + p_up[j * S + i];
+      g = sigmoid_t(x) * (dR_ab + dR_ba);
+    }
+    // SiteRM: Theta_ij and Theta_ji get the same gradient, computed from the pre-step sum
+    // Theta_ij + Theta_ji; the partner's update must not race with that read, so the
+    // SiteRM step is a second, barrier-separated phase.
+    if (a.kind == 0) adam_update(p_up[k], m_up[k], v_up[k], g, a.lr, a.beta1, a.beta2, a.eps, bc1, bc2s, a.do_adam);
+    else sRed[k] = g;
+  }
+  if (a.kind != 0) {
+    __syncthreads();
+    for (int k = tid; k < NUP; k += blockDim.x)
+      adam_update(p_up[k], m_up[k], v_up[k], sRed[k], a.lr, a.beta1, a.beta2, a.eps, bc1, bc2s, a.do_adam);
+  }
+  __threadfence_block();
+  __syncthreads();
+}
+
 template <int NT, int KS, int NW>
 __global__ __launch_bounds__(NW * 64, 2) void small_train_kernel(TrainArgs a) {
   extern __shared__ double lds[];
@@ -60,145 +193,169 @@ __global__ __launch_bounds__(NW * 64, 2) void small_train_kernel(TrainArgs a) {
   double *sA = lds + LD::A, *sG = lds + LD::G, *sD = lds + LD::D;
   double *sPi = lds + LD::TOTAL;       // [32]
   double *sGd = sPi + 32;              // [32] dL/d log d
-  double *sFlag = sGd + 32;            // [2]  best loss, improved flag
-  const int l = blockIdx.x, S = a.S, B = a.B, tid = threadIdx.x;
-  const int NUP = a.kind == 0 ? S * (S - 1) / 2 : S * S;
-  double *p_pi = a.p_pi + (size_t)l * S, *p_up = a.p_up + (size_t)l * NUP;
-  double *m_pi = a.m_pi + (size_t)l * S, *v_pi = a.v_pi + (size_t)l * S;
-  double *m_up = a.m_up + (size_t)l * NUP, *v_up = a.v_up + (size_t)l * NUP;
-  double *Qlast = a.Q_last + (size_t)l * S * S, *Qbest = a.Q_best + (size_t)l * S * S;
+  double *sFlag = sGd + 32;            // [2]  improved flag, best loss
+  const int l = blockIdx.x, S = a.S, B = a.B;
   const size_t lb = (size_t)l * B;
-  const double inv_n = a.inv_n[l];
-  const double *dirsum = a.dirsum + (size_t)l * S;
-  if (tid == 0) sFlag[0] = INFINITY;
+  if (threadIdx.x == 0) sFlag[1] = INFINITY;
   double pow_b1 = 1.0, pow_b2 = 1.0;
-
   for (int epoch = 0; epoch < a.E; ++epoch) {
-    // ---- pi = softmax(log_pi), d = sqrt(pi) ------------------------------------
-    if (tid < 64) {
-      const double x = tid < S ? p_pi[tid] : -INFINITY;
-      const double mx = wave_max(x);
-      const double e = tid < S ? exp(x - mx) : 0.0;
-      const double sum = wave_sum(e);
-      if (tid < 32) {
-        const double pk = tid < S ? e / sum : 1.0;
-        sPi[tid] = pk;
-        sD[tid] = sqrt(pk);
-      }
-    }
-    __syncthreads();
-    // ---- off-diagonal of A (= R) ---------------------------------------------------
-    for (int e = tid; e < S * S; e += blockDim.x) {
-      const int i = e / S, j = e - i * S;
-      double r = 0.0;
-      if (i != j) {
-        if (a.kind == 0) {
-          const int lo_ = min(i, j), hi_ = max(i, j);
-          const int k = lo_ * S - lo_ * (lo_ + 1) / 2 + (hi_ - lo_ - 1);
-          r = softplus_t(p_up[k]) * (a.mask ? a.mask[e] : 1.0);
-        } else {
-          r = softplus_t(p_up[i * S + j] + p_up[j * S + i]);
-        }
-      }
-      sA[i * CB_LS + j] = r;
-    }
-    __syncthreads();
-    if (tid < S) {
-      double acc = 0.0;
-      for (int j = 0; j < S; ++j)
-        if (j != tid) acc = fma(sA[tid * CB_LS + j], sD[j], acc);
-      sA[tid * CB_LS + tid] = -acc / sD[tid];
-    }
-    __syncthreads();
-    // ---- Q of this epoch (pre-step) -> Q_last; snapshots at epochs 1, 2, 4, ... -------
-    const bool pow2 = a.Q_pow2 && l == 0 && ((epoch & (epoch + 1)) == 0);
-    int pidx = 0;
-    if (pow2) {
-      int e1 = epoch + 1;
-      while (e1 > 1) {
-        e1 >>= 1;
-        ++pidx;
-      }
-    }
-    for (int e = tid; e < S * S; e += blockDim.x) {
-      const int i = e / S, j = e - i * S;
-      const double q = (i == j) ? sA[i * CB_LS + i] : sA[i * CB_LS + j] * sD[j] / sD[i];
-      Qlast[e] = q;
-      if (pow2 && pidx < a.n_pow2) a.Q_pow2[(size_t)pidx * S * S + e] = q;
-    }
-    // ---- loss and dL/dA -------------------------------------------------------------------
+    tr_build(a, l, epoch, sA, sD, sPi);
     // sV still holds the previous epoch's eigenvectors (zero padded): warm start
-    small_site_eval<NT, KS, NW, SMALL_LOSSGRAD>(lds, S, B, a.t + lb, a.Ct + lb * S * S, inv_n,
-                                                dirsum, nullptr, true, nullptr, epoch > 0);
+    small_site_eval<NT, KS, NW, SMALL_LOSSGRAD>(lds, S, B, a.t + lb, a.Ct + lb * S * S, a.inv_n[l],
+                                                a.dirsum + (size_t)l * S, nullptr, true, nullptr,
+                                                epoch > 0);
     // (ends with a barrier: sG = dA, sA = A, LOSSTOT = loss)
-    const double loss = lds[LD::LOSSTOT];
-    if (tid == 0) {
-      a.loss_curve[(size_t)epoch * a.L + l] = loss;
-      const bool better = loss < sFlag[0];  // strict <, as trainer.py:179
-      sFlag[1] = better ? 1.0 : 0.0;
-      if (better) sFlag[0] = loss;
-    }
-    // ---- dL/d log d -----------------------------------------------------------------------------
-    if (tid < S) {
-      const int k = tid;
-      double acc = 0.0;
-      for (int i = 0; i < S; ++i)
-        if (i != k) acc = fma(sG[i * CB_LS + i] * sA[i * CB_LS + k], 1.0 / sD[i], acc);
-      sGd[k] = -sD[k] * acc - sG[k * CB_LS + k] * sA[k * CB_LS + k] - dirsum[k] * inv_n;
-    }
-    __syncthreads();
-    if (sFlag[1] != 0.0)
-      for (int e = tid; e < S * S; e += blockDim.x) Qbest[e] = Qlast[e];  // own writes: visible
-    // ---- parameter gradients + optimiser step ---------------------------------------------------
     pow_b1 *= a.beta1;
     pow_b2 *= a.beta2;
-    const double bc1 = 1.0 - pow_b1, bc2s = sqrt(1.0 - pow_b2);
-    if (tid < S) {
-      double tot = 0.0;
-      for (int m = 0; m < S; ++m) tot += sGd[m];
-      const double g = 0.5 * (sGd[tid] - sPi[tid] * tot);
-      adam_update(p_pi[tid], m_pi[tid], v_pi[tid], g, a.lr, a.beta1, a.beta2, a.eps, bc1, bc2s,
-                  a.do_adam);
-    }
-    for (int k = tid; k < NUP; k += blockDim.x) {
-      int i, j;
-      if (a.kind == 0) {  // k-th entry of the row-major upper triangle
-        i = 0;
-        int rem = k;
-        while (rem >= S - 1 - i) {
-          rem -= S - 1 - i;
-          ++i;
-        }
-        j = i + 1 + rem;
-      } else {
-        i = k / S;
-        j = k - i * S;
-      }
-      double g = 0.0;
-      if (i != j) {
-        const int lo_ = min(i, j), hi_ = max(i, j);
-        const double mk = (a.kind == 0 && a.mask) ? a.mask[lo_ * S + hi_] : 1.0;
-        const double dR_ab = mk * (sG[lo_ * CB_LS + hi_] - sG[lo_ * CB_LS + lo_] * sD[hi_] / sD[lo_]);
-        const double dR_ba = mk * (sG[hi_ * CB_LS + lo_] - sG[hi_ * CB_LS + hi_] * sD[lo_] / sD[hi_]);
-        const double x = a.kind == 0 ? p_up[k] : p_up[i * S + j] + p_up[j * S + i];
-        g = sigmoid_t(x) * (dR_ab + dR_ba);
-      }
-      // SiteRM: Theta_ij and Theta_ji get the same gradient, computed from the pre-step sum
-      // Theta_ij + Theta_ji; the partner's update must not race with that read, so the
-      // SiteRM step is a second, barrier-separated phase.
-      if (a.kind == 0) {
-        adam_update(p_up[k], m_up[k], v_up[k], g, a.lr, a.beta1, a.beta2, a.eps, bc1, bc2s, a.do_adam);
-      } else {
-        (lds + LD::RED)[k] = g;  // reduction scratch (>= 1024 doubles) is free here
-      }
-    }
-    if (a.kind != 0) {
-      __syncthreads();
-      for (int k = tid; k < NUP; k += blockDim.x)
-        adam_update(p_up[k], m_up[k], v_up[k], (lds + LD::RED)[k], a.lr, a.beta1, a.beta2, a.eps, bc1,
-                    bc2s, a.do_adam);
-    }
-    __threadfence_block();
-    __syncthreads();
+    tr_update(a, l, epoch, lds[LD::LOSSTOT], 1.0 - pow_b1, sqrt(1.0 - pow_b2), sA, sG, sD, sPi, sGd,
+              sFlag, lds + LD::RED, sFlag + 1);
   }
+}
+
+// ---------------------------------------------------------------------------------------
+// L = 1 (LG-sized single bank): the epoch split over the chip.  A single workgroup holds at
+// most 8 waves of this register-heavy code, so 129 buckets cost 17 sequential buckets per
+// wave; instead three small kernels per epoch, enqueued back to back (no host sync):
+//   lg_prepare : theta -> A, eigh (warm), frames to global            1 workgroup
+//   lg_bank    : one bucket per wavefront, partial M / loss to global  ceil(B/4) workgroups
+//   lg_finish  : sum the partials (fixed order), dA, gradients, Adam   1 workgroup
+struct LgSplit {
+  double *frames;  // A[32*33] | V[32*33] | lam[32] | d[32] | pi[32]
+  double *Mpart;   // [B][1024]
+  double *lpart;   // [B]
+  double *best;    // [1] best loss so far
+};
+#define LGS_A 0
+#define LGS_V (32 * CB_LS)
+#define LGS_LAM (2 * 32 * CB_LS)
+#define LGS_D (LGS_LAM + 32)
+#define LGS_PI (LGS_D + 32)
+#define LGS_TOTAL (LGS_PI + 32)
+
+__global__ __launch_bounds__(256) void lg_prepare(TrainArgs a, LgSplit g, int epoch) {
+  extern __shared__ double lds[];
+  using LD = SmallLds<4>;
+  double *sA = lds + LD::A, *sG = lds + LD::G, *sV = lds + LD::V, *sLam = lds + LD::LAM,
+         *sD = lds + LD::D, *sPi = lds + LD::TOTAL;
+  const int S = a.S, tid = threadIdx.x;
+  if (epoch == 0 && tid == 0) *g.best = INFINITY;
+  tr_build(a, 0, epoch, sA, sD, sPi);
+  if (epoch > 0)  // previous eigenvectors: warm start
+    for (int e = tid; e < 32 * CB_LS; e += 256) sV[e] = g.frames[LGS_V + e];
+  __syncthreads();
+  if (tid < 64) wave_eigh_rate(S, sA, sG, sV, sLam, CB_LS, epoch > 0);
+  __syncthreads();
+  for (int e = tid; e < 32 * 32; e += 256) {
+    const int k = e >> 5, i = e & 31;
+    if (k >= S || i >= S) sV[k * CB_LS + i] = 0.0;
+  }
+  for (int k = S + tid; k < 32; k += 256) sLam[k] = 0.0;
+  __syncthreads();
+  for (int e = tid; e < 32 * CB_LS; e += 256) {
+    g.frames[LGS_A + e] = sA[e];
+    g.frames[LGS_V + e] = sV[e];
+  }
+  if (tid < 32) {
+    g.frames[LGS_LAM + tid] = sLam[tid];
+    g.frames[LGS_D + tid] = sD[tid];
+    g.frames[LGS_PI + tid] = sPi[tid];
+  }
+}
+
+template <int NT, int KS>
+__global__ __launch_bounds__(256, 2) void lg_bank(TrainArgs a, LgSplit g) {
+  extern __shared__ double lds[];
+  using LD = SmallLds<4>;
+  double *sA = lds + LD::A, *sV = lds + LD::V, *sLam = lds + LD::LAM, *sD = lds + LD::D;
+  const int S = a.S, B = a.B, tid = threadIdx.x;
+  const int wave = tid >> 6, lane = tid & 63;
+  for (int e = tid; e < 32 * CB_LS; e += 256) {
+    sA[e] = g.frames[LGS_A + e];
+    sV[e] = g.frames[LGS_V + e];
+  }
+  if (tid < 32) {
+    sLam[tid] = g.frames[LGS_LAM + tid];
+    sD[tid] = g.frames[LGS_D + tid];
+  }
+  __syncthreads();
+  const int b = blockIdx.x * 4 + wave;
+  if (b >= B) return;
+  SmallFrags<NT, KS> f;
+  load_frags<NT, KS>(f, sV, sLam, S);
+  d4 M[NT][NT];
+#pragma unroll
+  for (int x = 0; x < NT; ++x)
+#pragma unroll
+    for (int y = 0; y < NT; ++y) M[x][y] = d4{0.0, 0.0, 0.0, 0.0};
+  double rho = 0.0;
+  for (int i = lane; i < S; i += 64) rho = fmax(rho, fabs(sA[i * CB_LS + i]));
+  rho = 2.0 * wave_max(rho);
+  double cval[NT][NT][4];
+  load_counts<NT, KS>(cval, S, a.Ct + (size_t)b * S * S);
+  double lossacc = 0.0;
+  small_bucket<NT, KS, SMALL_LOSSGRAD>(f, S, a.t[b], cval, nullptr, a.inv_n[0], sA, sD, sV,
+                                        lds + LD::TAB + wave * 96, sLam, rho, M, lossacc, nullptr);
+  lossacc = wave_sum(lossacc);
+  double *dst = g.Mpart + (size_t)b * 1024;
+#pragma unroll
+  for (int x = 0; x < NT; ++x)
+#pragma unroll
+    for (int y = 0; y < NT; ++y)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) dst[((x * 2 + y) * 4 + r) * 64 + lane] = M[x][y][r];
+  if (lane == 0) g.lpart[b] = lossacc;
+}
+
+template <int NT>
+__global__ __launch_bounds__(256) void lg_finish(TrainArgs a, LgSplit g, int epoch, double bc1,
+                                                 double bc2s) {
+  extern __shared__ double lds[];
+  using LD = SmallLds<4>;
+  double *sA = lds + LD::A, *sG = lds + LD::G, *sV = lds + LD::V, *sD = lds + LD::D;
+  double *sPi = lds + LD::TOTAL, *sGd = sPi + 32, *sFlag = sGd + 32;
+  const int S = a.S, B = a.B, tid = threadIdx.x;
+  for (int e = tid; e < 32 * CB_LS; e += 256) {
+    sA[e] = g.frames[LGS_A + e];
+    sV[e] = g.frames[LGS_V + e];
+    sG[e] = 0.0;
+  }
+  if (tid < 32) {
+    sD[tid] = g.frames[LGS_D + tid];
+    sPi[tid] = g.frames[LGS_PI + tid];
+  }
+  __syncthreads();
+  // M = sum over buckets in a fixed order; slot (x, y, r, lane) -> M[16x + hi + 4r][16y + lo].
+  // Loads are issued 8 at a time (independent) -- one dependent load per iteration would
+  // cost B global round trips.
+  for (int e = tid; e < NT * NT * 256; e += 256) {
+    const int slot = e >> 6, lane = e & 63;
+    const int x = (slot >> 2) / NT, y = (slot >> 2) % NT, r = slot & 3;
+    const double *src = g.Mpart + ((x * 2 + y) * 4 + r) * 64 + lane;
+    double acc = 0.0;
+    int b = 0;
+    for (; b + 8 <= B; b += 8) {
+      double v[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) v[i] = src[(size_t)(b + i) * 1024];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) acc += v[i];
+    }
+    for (; b < B; ++b) acc += src[(size_t)b * 1024];
+    const int ra = 16 * x + (lane >> 4) + 4 * r, c = 16 * y + (lane & 15);
+    sG[ra * CB_LS + c] = acc;
+  }
+  // loss partials through LDS (scratch RED), then one thread adds them in order
+  double *sL = lds + LD::RED;
+  for (int b = tid; b < B; b += 256) sL[b] = g.lpart[b];
+  __syncthreads();
+  if (tid == 0) {
+    double tot = 0.0;
+    for (int b = 0; b < B; ++b) tot += sL[b];
+    double dir = 0.0;
+    for (int k = 0; k < S; ++k) dir = fma(log(sD[k]), a.dirsum[k], dir);
+    lds[LD::LOSSTOT] = (tot - dir) * a.inv_n[0];
+  }
+  __syncthreads();
+  small_dA_from_M(S, sG, sV, lds + LD::RED);
+  tr_update(a, 0, epoch, lds[LD::LOSSTOT], bc1, bc2s, sA, sG, sD, sPi, sGd, sFlag, lds + LD::RED, g.best);
 }

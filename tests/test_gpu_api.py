@@ -328,3 +328,24 @@ def test_coevolution_end_to_end_pipeline_small_alphabet(tmp_path):
     assert list(Q.index) == pairs
     assert np.all((Q.to_numpy() != 0) == (mask != 0))
     assert np.abs(Q.to_numpy().sum(1)).max() < 1e-12
+
+
+def test_split_and_single_kernel_lg_trainers_agree():
+    """L = 1 banks use three small launches per epoch (bank spread over the chip); the
+    single-workgroup kernel (CB_LG_SPLIT=0) must give the same trajectory."""
+    from cherryml_amd import CherryBank
+    from oracle import ratelearn_oracle as orc
+    g = load_golden("traj_lgbank.npz")
+    u0, p0 = orc.invert_pande_reversible(g["init"], np.ones((20, 20)))
+    outs = []
+    for env in ("1", "0"):
+        os.environ["CB_LG_SPLIT"] = env
+        try:
+            with CherryBank(g["t"], g["C"]) as bank:
+                outs.append(bank.train_pande_reversible(u0, p0, num_epochs=30, lr=0.1))
+        finally:
+            del os.environ["CB_LG_SPLIT"]
+    assert np.allclose(outs[0]["loss"], outs[1]["loss"], rtol=1e-12, atol=0)
+    assert relerr(outs[0]["Q_best"], outs[1]["Q_best"]) < 1e-9
+    assert relerr(outs[0]["Q_last"], outs[1]["Q_last"]) < 1e-9
+    assert np.allclose(outs[0]["loss"], g["loss_f64"][:30], rtol=1e-9, atol=0)
