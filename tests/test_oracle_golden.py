@@ -134,3 +134,25 @@ def test_jtt_ipw_reference_goldens():
                            ("Q1_JTT_on_toy_matrix_mask", g["mask"], False)]:
         got = orc.jtt_ipw(g["t"], g["C"], mask.astype(float), use_ipw=ipw)
         np.testing.assert_almost_equal(got, g[key], decimal=7)
+
+
+def test_oracle_expm_against_reference_native_pade():
+    """oracle/_ref/libref_expm.so = the reference's vendored r8mat_expm1 (Pade, FastCherries'
+    bank: io_helpers.cpp:150-174), built from the reference's own sources by oracle/Makefile.
+    Cross-checks the oracle's expm (torch.matrix_exp, f64) on the LG matrix over the grid."""
+    import ctypes
+    import os
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                        "oracle", "_ref", "libref_expm.so")
+    if not os.path.exists(path):
+        pytest.skip("oracle/_ref not built (needs /root/reference: `make -C oracle`)")
+    lib = ctypes.CDLL(path)
+    lib.ref_expm.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+    Q = load_golden("data_lg.npz")["lg"]
+    grid = np.array([float("%.8f" % (0.03 * 1.1 ** i)) for i in range(-64, 65)])[::8]
+    P = orc.expm_bank(Q, grid)
+    for b, t in enumerate(grid):
+        A = np.asfortranarray(t * Q)
+        out = np.empty((20, 20), order="F")
+        assert lib.ref_expm(20, A.ctypes.data, out.ctypes.data) == 0
+        assert np.abs(np.ascontiguousarray(out) - P[b]).max() < 5e-14
