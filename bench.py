@@ -395,7 +395,7 @@ def run_counting(steps, warmup, world, rank, local_rank, fence, with_cpu):
         d_counts.zero_()
         rc = lib.cb_count_transitions(local_rank, S, B, d_grid.data_ptr(), d_seqs.data_ptr(),
                                       d_seqs.numel(), d_rates.data_ptr(), d_rates.numel(),
-                                      d_pairs.data_ptr(), len(pairs), 1, _lib.CB_PTR_DEVICE,
+                                      d_pairs.data_ptr(), len(pairs), 1, _lib.CB_PTR_DEVICE | (L << 8),
                                       d_counts.data_ptr())
         _lib.check(rc, "cb_count_transitions")
         if world > 1:
@@ -432,10 +432,10 @@ def run_counting(steps, warmup, world, rank, local_rank, fence, with_cpu):
         "config": {"workload": f"counting: {F} families x {NCH} cherries x {L} sites per GPU, "
                                "B=129 grid, cherry (symmetric) mode", "states": S, "buckets": B,
                    "sharding": f"families x{world}, all-reduce of integer counts"},
-        "roofline": {"bound": "hbm", "kernel": "count_transitions_kernel", "achieved": achieved,
+        "roofline": {"bound": "hbm", "kernel": "count_transitions_lds_kernel", "achieved": achieved,
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      "traffic": None, "ms_per_launch": kernel_ms, "bytes_per_launch": nbytes,
-                     "note": "atomic-bound: 2 u64 atomics per counted pair x site into 51,600 bins"},
+                     "note": "per-workgroup LDS histogram (packed 16-bit bins) + slab reduction"},
         "counted_pairs": counted,
     }
     if with_cpu:

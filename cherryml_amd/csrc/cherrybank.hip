@@ -945,6 +945,45 @@ static int count_scratch(int device, size_t elems, unsigned long long **out) {
   return CB_OK;
 }
 
+// device-pointer launch of the single-site counter: adds into counts[B*S*S].
+// max_sites = largest pair.n (0 = unknown -> replica path).
+static int launch_count_transitions(int device, int S, int B, const double *grid, const int8_t *seqs,
+                                    const double *rates, const cb_count_pair *pairs, int64_t n_pairs,
+                                    int symmetric, int max_sites, unsigned long long *counts) {
+  const size_t nb = (size_t)B * S * S;
+  const int words = (int)((nb + 1) / 2);
+  const size_t lds = (size_t)((words + 1) & ~1) * sizeof(unsigned) + (size_t)B * sizeof(double);
+  int chunk = max_sites > 0 ? 65535 / (2 * max_sites) : 0;
+  if (chunk >= 8 && lds <= 150 * 1024) {
+    // keep at least ~2 workgroups per CU worth of slabs when there is enough work
+    const int64_t want = (n_pairs + 511) / 512;
+    if (want < chunk) chunk = (int)(want > 8 ? want : 8);
+    const int64_t nwg = (n_pairs + chunk - 1) / chunk;
+    unsigned long long *scratch = nullptr;
+    int rc = count_scratch(device, ((size_t)nwg * words + 1) / 2 + 1, &scratch);
+    if (rc != CB_OK) return rc;
+    unsigned *slabs = reinterpret_cast<unsigned *>(scratch);
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(count_transitions_lds_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(count_transitions_lds_kernel, dim3((unsigned)nwg), dim3(CNT_LDS_THREADS), lds, 0, S, B,
+                       grid, seqs, rates, pairs, (long long)n_pairs, symmetric, chunk, slabs, words);
+    hipLaunchKernelGGL(count_reduce_slabs, dim3((unsigned)((words + 63) / 64)), dim3(256), 0, 0, slabs, (int)nwg,
+                       words, nb, counts);
+  } else {
+    unsigned long long *rep = nullptr;
+    int rc = count_scratch(device, nb * CNT_REPLICAS, &rep);
+    if (rc != CB_OK) return rc;
+    HIP_TRY(hipMemsetAsync(rep, 0, nb * CNT_REPLICAS * sizeof(unsigned long long), 0));
+    const unsigned blocks = (unsigned)((n_pairs + 3) / 4);
+    hipLaunchKernelGGL(count_transitions_kernel, dim3(blocks), dim3(256), 0, 0, S, B, grid, seqs, rates, pairs,
+                       (long long)n_pairs, symmetric, rep, CNT_REPLICAS);
+    hipLaunchKernelGGL(count_reduce_replicas, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, 0, rep,
+                       CNT_REPLICAS, nb, counts);
+  }
+  HIP_TRY(hipGetLastError());
+  return CB_OK;
+}
+
 static int count_common(int device, int S, int B, const double *grid, const int8_t *seqs,
                         int64_t seqs_bytes, const void *aux, size_t aux_bytes,
                         const cb_count_pair *pairs, int64_t n_pairs, int symmetric, int flags,
@@ -959,15 +998,10 @@ static int count_common(int device, int S, int B, const double *grid, const int8
         hipLaunchKernelGGL(count_co_transitions_kernel, dim3(blocks), dim3(256), 0, 0, S, B, grid, seqs,
                            (const int32_t *)aux, pairs, (long long)n_pairs, symmetric, counts);
       else {
-        unsigned long long *rep = nullptr;
-        int rc = count_scratch(device, (size_t)B * S * S * CNT_REPLICAS, &rep);
+        // resident form: the caller states the largest pair.n in flags bits 8..23 (0 = unknown)
+        int rc = launch_count_transitions(device, S, B, grid, seqs, (const double *)aux, pairs, n_pairs,
+                                          symmetric, (flags >> 8) & 0xFFFF, counts);
         if (rc != CB_OK) return rc;
-        const size_t nb = (size_t)B * S * S;
-        HIP_TRY(hipMemsetAsync(rep, 0, nb * CNT_REPLICAS * sizeof(unsigned long long), 0));
-        hipLaunchKernelGGL(count_transitions_kernel, dim3(blocks), dim3(256), 0, 0, S, B, grid, seqs,
-                           (const double *)aux, pairs, (long long)n_pairs, symmetric, rep, CNT_REPLICAS);
-        hipLaunchKernelGGL(count_reduce_replicas, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, 0, rep,
-                           CNT_REPLICAS, nb, counts);
       }
       HIP_TRY(hipGetLastError());
     }
@@ -1020,9 +1054,13 @@ static int count_common(int device, int S, int B, const double *grid, const int8
     if (co)
       hipLaunchKernelGGL(count_co_transitions_kernel, dim3(blocks), dim3(256), 0, 0, S, B, d_grid, d_seqs,
                          (const int32_t *)d_aux, d_pairs, (long long)n_pairs, symmetric, d_counts);
-    else
-      hipLaunchKernelGGL(count_transitions_kernel, dim3(blocks), dim3(256), 0, 0, S, B, d_grid, d_seqs,
-                         (const double *)d_aux, d_pairs, (long long)n_pairs, symmetric, d_counts, 1);
+    else {
+      int max_sites = 0;
+      for (int64_t p = 0; p < n_pairs; ++p) max_sites = pairs[p].n > max_sites ? pairs[p].n : max_sites;
+      if (rc == CB_OK)
+        rc = launch_count_transitions(device, S, B, d_grid, d_seqs, (const double *)d_aux, d_pairs, n_pairs,
+                                      symmetric, max_sites < 32768 ? max_sites : 0, d_counts);
+    }
     TRYC(hipGetLastError());
     TRYC(hipDeviceSynchronize());
   }

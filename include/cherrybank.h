@@ -184,7 +184,9 @@ int cb_train_siterm(cb_handle h, double *theta, double *Theta, int num_epochs,
  * and synchronous.  flags & CB_PTR_DEVICE: every pointer (grid, seqs, rates / contacts,
  * pairs, counts) is a device pointer on `device`, the kernel is enqueued on HIP's default
  * stream and ADDS into `counts` (the caller zeroes it, validates its offsets, and
- * synchronises): the form a resident pipeline and bench.py use.
+ * synchronises): the form a resident pipeline and bench.py use.  In that form bits 8..23
+ * of `flags` may carry the largest pair.n (sites per pair); when given and the [B][S][S]
+ * histogram fits LDS, cb_count_transitions uses the LDS-privatised kernel.
  */
 typedef struct {
   int64_t seq_a, seq_b; /* byte offsets of the two encoded sequences in `seqs`        */
