@@ -69,6 +69,9 @@ class CherryBank:
         n = np.zeros(self.L)
         _lib.check(lib.cb_total_counts(self._h, n.ctypes.data), "cb_total_counts")
         self.total_counts = n
+        nl = np.zeros(self.L, dtype=np.int32)
+        _lib.check(lib.cb_live_buckets(self._h, nl.ctypes.data), "cb_live_buckets")
+        self.live_buckets = nl      # non-empty buckets per site: the ones the loss visits
 
     # -- lifetime ---------------------------------------------------------
     def close(self):

@@ -3,6 +3,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -58,6 +59,11 @@ struct cb_bank {
   double *inv_n = nullptr;   // [L]  1/n
   double *ones = nullptr;    // [L]  1.0
   double *dirsum = nullptr;  // [L,S] colsum - rowsum of sum_b C
+  // live buckets (C_b != 0), stored first per site; Bl = max over sites = stride of Ct / t_live
+  int Bl = 0;
+  double *t_live = nullptr;  // [L,Bl]
+  int *nlive = nullptr;      // [L] device
+  std::vector<int> nlive_host;
   // staging for host-pointer calls
   double *Q = nullptr, *pi = nullptr, *loss = nullptr, *dQ = nullptr;
   int *status = nullptr;
@@ -182,13 +188,31 @@ __global__ void prep_counts_large_fin(int S, const double *tot, double *n, doubl
   }
 }
 
-// small path: Ct[l,b][j][i] = C[l,b][i][j]
-__global__ void transpose_small(int S, size_t nmat, const double *C, double *Ct) {
+// sum |C_b| per (site, bucket): buckets with C_b == 0 add nothing to the loss or its gradient
+__global__ void bucket_mass(size_t SS, const double *C, double *mass) {
+  __shared__ double s[256];
+  const double *Cm = C + (size_t)blockIdx.x * SS;
+  double acc = 0.0;
+  for (size_t e = threadIdx.x; e < SS; e += 256) acc += fabs(Cm[e]);
+  s[threadIdx.x] = acc;
+  __syncthreads();
+  for (int st = 128; st >= 1; st >>= 1) {
+    if ((int)threadIdx.x < st) s[threadIdx.x] += s[threadIdx.x + st];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) mass[blockIdx.x] = s[0];
+}
+
+// small path: Ct[l,k][j][i] = C[l,src[l,k]][i][j]  for the live slots k < nlive[l]
+__global__ void transpose_small(int S, int B, int Bl, const int *nlive, const int *src, const double *C,
+                                double *Ct) {
   const size_t m = blockIdx.x;
-  if (m >= nmat) return;
+  const int l = (int)(m / Bl), k = (int)(m - (size_t)l * Bl);
+  if (k >= nlive[l]) return;
+  const double *Cs = C + ((size_t)l * B + src[m]) * S * S;
   for (int e = threadIdx.x; e < S * S; e += blockDim.x) {
     const int j = e / S, i = e - j * S;
-    Ct[m * S * S + e] = C[m * S * S + (size_t)i * S + j];
+    Ct[m * S * S + e] = Cs[(size_t)i * S + j];
   }
 }
 
@@ -261,22 +285,71 @@ extern "C" int cb_create(int device, int S, int L, int B, const double *t, const
       Ctmp = nullptr;
     }
   };
+  // ---- live buckets: an exact work reduction: C_b == 0 contributes nothing -------
+  int *src_idx = nullptr;
+  {
+    double *mass_d = nullptr;
+    if ((rc = dev_alloc(h, &mass_d, nmat)) != CB_OK || (rc = dev_alloc(h, &h->nlive, L)) != CB_OK) {
+      free_tmp();
+      return cleanup(rc);
+    }
+    hipLaunchKernelGGL(bucket_mass, dim3((unsigned)nmat), dim3(256), 0, h->stream, SS, Cdev, mass_d);
+    std::vector<double> mass(nmat), th(nmat);
+    hipError_t e = hipMemcpyAsync(mass.data(), mass_d, nmat * sizeof(double), hipMemcpyDeviceToHost, h->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(th.data(), h->t, nmat * sizeof(double), hipMemcpyDeviceToHost, h->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    if (e != hipSuccess) {
+      free_tmp();
+      return cleanup(fail(CB_EHIP, "cb_create: bucket scan failed: %s", hipGetErrorString(e)));
+    }
+    h->nlive_host.assign(L, 0);
+    for (int l = 0; l < L; ++l)
+      for (int b = 0; b < B; ++b)
+        if (mass[(size_t)l * B + b] != 0.0) h->nlive_host[l]++;   // NaN counts stay live (and fail later)
+    h->Bl = 1;
+    for (int l = 0; l < L; ++l) h->Bl = std::max(h->Bl, h->nlive_host[l]);
+    const size_t nl = (size_t)L * h->Bl;
+    std::vector<int> src(nl, 0);
+    std::vector<double> tl(nl, 1.0);
+    for (int l = 0; l < L; ++l) {
+      int k = 0;
+      for (int b = 0; b < B; ++b)
+        if (mass[(size_t)l * B + b] != 0.0) {
+          src[(size_t)l * h->Bl + k] = b;
+          tl[(size_t)l * h->Bl + k] = th[(size_t)l * B + b];
+          ++k;
+        }
+    }
+    if ((rc = dev_alloc(h, &src_idx, nl)) != CB_OK || (rc = dev_alloc(h, &h->t_live, nl)) != CB_OK) {
+      free_tmp();
+      return cleanup(rc);
+    }
+    e = hipMemcpyAsync(src_idx, src.data(), nl * sizeof(int), hipMemcpyHostToDevice, h->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(h->t_live, tl.data(), nl * sizeof(double), hipMemcpyHostToDevice, h->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(h->nlive, h->nlive_host.data(), L * sizeof(int), hipMemcpyHostToDevice, h->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);  // src / tl are stack-owned
+    if (e != hipSuccess) {
+      free_tmp();
+      return cleanup(fail(CB_EHIP, "cb_create: upload failed: %s", hipGetErrorString(e)));
+    }
+  }
+  const int Bl = h->Bl;
   if (!h->large) {
-    if ((rc = dev_alloc(h, &h->Ct, nmat * SS)) != CB_OK) {
+    if ((rc = dev_alloc(h, &h->Ct, (size_t)L * Bl * SS)) != CB_OK) {
       free_tmp();
       return cleanup(rc);
     }
     hipLaunchKernelGGL(prep_counts, dim3(L), dim3(256), SS * sizeof(double), h->stream, S, B, Cdev,
                        h->n_dev, h->inv_n, h->ones, h->dirsum);
-    hipLaunchKernelGGL(transpose_small, dim3((unsigned)nmat), dim3(256), 0, h->stream, S, nmat, Cdev,
-                       h->Ct);
+    hipLaunchKernelGGL(transpose_small, dim3((unsigned)((size_t)L * Bl)), dim3(256), 0, h->stream, S, B, Bl,
+                       h->nlive, src_idx, Cdev, h->Ct);
   } else {
     const size_t LL = (size_t)h->LD * h->LD;
     const int tiles = ((h->LD + LG_TM - 1) / LG_TM) * ((h->LD + LG_TN - 1) / LG_TN);
     h->k3_chunk = 4;
     h->k3_nchunks = (B + h->k3_chunk - 1) / h->k3_chunk;
     double *tot = nullptr;
-    bool ok = dev_alloc(h, &h->Ct, (size_t)B * LL) == CB_OK && dev_alloc(h, &tot, SS) == CB_OK &&
+    bool ok = dev_alloc(h, &h->Ct, (size_t)Bl * LL) == CB_OK && dev_alloc(h, &tot, SS) == CB_OK &&
               dev_alloc(h, &h->A, LL) == CB_OK && dev_alloc(h, &h->dsq, h->LD) == CB_OK &&
               dev_alloc(h, &h->Gc, LL) == CB_OK && dev_alloc(h, &h->Vc, LL) == CB_OK &&
               dev_alloc(h, &h->U, LL) == CB_OK && dev_alloc(h, &h->lam, h->LD) == CB_OK &&
@@ -284,8 +357,8 @@ extern "C" int cb_create(int device, int S, int L, int B, const double *t, const
               dev_alloc(h, &h->F, (size_t)B * h->LD) == CB_OK &&
               dev_alloc(h, &h->E, (size_t)B * h->LD) == CB_OK &&
               dev_alloc(h, &h->H, (size_t)B * h->LD) == CB_OK &&
-              dev_alloc(h, &h->Gt, (size_t)B * LL) == CB_OK &&
-              dev_alloc(h, &h->T, (size_t)B * LL) == CB_OK &&
+              dev_alloc(h, &h->Gt, (size_t)Bl * LL) == CB_OK &&
+              dev_alloc(h, &h->T, (size_t)Bl * LL) == CB_OK &&
               dev_alloc(h, &h->Mt, LL) == CB_OK && dev_alloc(h, &h->X, LL) == CB_OK &&
               dev_alloc(h, &h->loss_part, (size_t)B * tiles) == CB_OK;
     if (!ok) {
@@ -297,8 +370,8 @@ extern "C" int cb_create(int device, int S, int L, int B, const double *t, const
     hipLaunchKernelGGL(prep_counts_large_fin, dim3(1), dim3(256), 0, h->stream, S, tot, h->n_dev,
                        h->inv_n, h->ones, h->dirsum);
     const int nt32 = (h->LD + 31) / 32;
-    hipLaunchKernelGGL(lg_transpose_pad, dim3(nt32, nt32, B), dim3(32, 8), 0, h->stream, S, h->LD,
-                       Cdev, h->Ct);
+    hipLaunchKernelGGL(lg_transpose_pad, dim3(nt32, nt32, Bl), dim3(32, 8), 0, h->stream, S, h->LD,
+                       Cdev, h->Ct, src_idx);
   }
   h->n_host.resize(L);
   hipError_t e = hipMemcpyAsync(h->n_host.data(), h->n_dev, L * sizeof(double), hipMemcpyDeviceToHost,
@@ -331,6 +404,12 @@ extern "C" void cb_destroy(cb_handle h) {
 extern "C" int cb_set_stream(cb_handle h, void *hip_stream, int own) {
   if (!h) return fail(CB_EINVAL, "cb_set_stream: NULL handle");
   h->stream = own ? h->own_stream : static_cast<hipStream_t>(hip_stream);
+  return CB_OK;
+}
+
+extern "C" int cb_live_buckets(cb_handle h, int *nlive) {
+  if (!h || !nlive) return fail(CB_EINVAL, "cb_live_buckets: NULL argument");
+  memcpy(nlive, h->nlive_host.data(), h->L * sizeof(int));
   return CB_OK;
 }
 
@@ -440,7 +519,9 @@ static int large_eigh(cb_bank *h, bool warm) {
 
 static int large_loss_grad(cb_bank *h, const double *Qd, const double *pid, bool normalize,
                            double *lossd, double *dQd, double *Pd) {
-  const int S = h->S, LD = h->LD, B = h->B;
+  const int S = h->S, LD = h->LD;
+  const int B = Pd ? h->B : h->Bl;                 // the loss visits live buckets only
+  const double *tb = Pd ? h->t : h->t_live;
   const size_t LL = (size_t)LD * LD;
   hipLaunchKernelGGL(lg_build_A, dim3((unsigned)((LL + 255) / 256)), dim3(256), 0, h->stream, S, LD,
                      Qd, pid, h->A, h->dsq);
@@ -448,10 +529,10 @@ static int large_loss_grad(cb_bank *h, const double *Qd, const double *pid, bool
   if (rc != CB_OK) return rc;
   mark(h, EV_EIGH);
   hipLaunchKernelGGL(lg_tables, dim3((unsigned)(((size_t)B * LD + 255) / 256)), dim3(256), 0,
-                     h->stream, LD, B, h->t, h->lam, h->sigma, h->F, h->E, h->H);
+                     h->stream, LD, B, tb, h->lam, h->sigma, h->F, h->E, h->H);
   const int tm = (LD + LG_TM - 1) / LG_TM, tn = (LD + LG_TN - 1) / LG_TN, tiles = tm * tn;
   const double inv_n = normalize ? 1.0 / h->n_host[0] : 1.0;
-  K1Args k1{S, LD, B, h->Vc, h->A, h->t, h->F, h->sigma, h->Ct, h->Gt, h->loss_part, inv_n, h->dsq, Pd};
+  K1Args k1{S, LD, B, h->Vc, h->A, tb, h->F, h->sigma, h->Ct, h->Gt, h->loss_part, inv_n, h->dsq, Pd};
   mark(h, EV_END);  // (re-used as "before K1" marker)
   hipLaunchKernelGGL(k1_pt_loss_gt, dim3(tiles * B), dim3(LG_THREADS), 0, h->stream, k1);
   mark(h, EV_K1);
@@ -465,7 +546,7 @@ static int large_loss_grad(cb_bank *h, const double *Qd, const double *pid, bool
     K2Args k2{LD, h->Gt, h->U, h->T};
     hipLaunchKernelGGL(k2_t_eq_g_u, dim3(tiles * B), dim3(LG_THREADS), 0, h->stream, k2);
     mark(h, EV_K2);
-    K3Args k3{LD, B, h->T, h->U, h->t, h->lam, h->E, h->H, h->Gt};
+    K3Args k3{LD, B, h->T, h->U, tb, h->lam, h->E, h->H, h->Gt};
     hipLaunchKernelGGL(k3_w_phi, dim3(tiles * B), dim3(LG_THREADS), 0, h->stream, k3);
     mark(h, EV_K3);
     hipLaunchKernelGGL(k3_reduce, dim3((unsigned)((LL + 255) / 256)), dim3(256), 0, h->stream,
@@ -516,8 +597,9 @@ extern "C" int cb_loss_grad(cb_handle h, const double *Q, const double *pi, int 
     SmallArgs a{};
     a.S = h->S;
     a.L = h->L;
-    a.B = h->B;
-    a.t = h->t;
+    a.B = h->Bl;
+    a.nlive = h->nlive;
+    a.t = h->t_live;
     a.Ct = h->Ct;
     a.inv_n = (flags & CB_NORMALIZE) ? h->inv_n : h->ones;
     a.dirsum = h->dirsum;
@@ -664,8 +746,10 @@ static int general_run(cb_bank *h, const double *Qd, int flags, double *lossd, d
     h->gn_nw = NW;
   }
   GeneralArgs a{};
-  a.S = h->S; a.L = h->L; a.B = h->B;
-  a.t = h->t; a.Ct = h->Ct; a.inv_n = (flags & CB_NORMALIZE) ? h->inv_n : h->ones;
+  a.S = h->S; a.L = h->L;
+  if (Pd) { a.B = h->B; a.t = h->t; a.nlive = nullptr; }            // expm: every bucket, original order
+  else { a.B = h->Bl; a.t = h->t_live; a.nlive = h->nlive; }        // loss: live buckets only
+  a.Ct = h->Ct; a.inv_n = (flags & CB_NORMALIZE) ? h->inv_n : h->ones;
   a.Q = Qd; a.loss = lossd; a.dQ = dQd; a.P = Pd;
   a.scratch = h->gn_scratch; a.partial = h->gn_partial;
   if (NW == 8) hipLaunchKernelGGL(general_bank_kernel<8>, dim3(h->L), dim3(512), 0, h->stream, a);
@@ -762,8 +846,8 @@ static int run_fused_training(cb_bank *h, int kind, double *pi_param, double *up
   if (mask) TRYH(hipMemcpyAsync(d_mask, mask, SS * sizeof(double), hipMemcpyHostToDevice, h->stream));
   if (rc == CB_OK) {
     TrainArgs a{};
-    a.S = S; a.L = L; a.B = h->B; a.E = E; a.kind = kind; a.do_adam = do_adam; a.n_pow2 = d_Qp ? n_pow2 : 0;
-    a.t = h->t; a.Ct = h->Ct; a.inv_n = (flags & CB_NORMALIZE) ? h->inv_n : h->ones; a.dirsum = h->dirsum;
+    a.S = S; a.L = L; a.B = h->Bl; a.E = E; a.kind = kind; a.do_adam = do_adam; a.n_pow2 = d_Qp ? n_pow2 : 0;
+    a.nlive = h->nlive; a.t = h->t_live; a.Ct = h->Ct; a.inv_n = (flags & CB_NORMALIZE) ? h->inv_n : h->ones; a.dirsum = h->dirsum;
     a.p_pi = d_pi; a.p_up = d_up;
     a.m_pi = d_mom; a.v_pi = d_mom + (size_t)L * S;
     a.m_up = d_mom + 2 * (size_t)L * S; a.v_up = a.m_up + L * nup;
@@ -777,16 +861,16 @@ static int run_fused_training(cb_bank *h, int kind, double *pi_param, double *up
       // one LG-sized bank: the epoch spread over the chip, three small launches per epoch
       LgSplit g{};
       double *buf = nullptr;
-      const size_t nbuf = LGS_TOTAL + (size_t)h->B * 1025 + 8;
+      const size_t nbuf = LGS_TOTAL + (size_t)h->Bl * 1025 + 8;  // L == 1: nlive[0] == Bl
       if (!alloc(&buf, nbuf)) rc = fail(CB_ENOMEM, "fused training: device allocation failed");
       if (rc == CB_OK) {
         g.frames = buf;
         g.Mpart = buf + LGS_TOTAL;
-        g.lpart = g.Mpart + (size_t)h->B * 1024;
-        g.best = g.lpart + h->B;
+        g.lpart = g.Mpart + (size_t)h->Bl * 1024;
+        g.best = g.lpart + h->Bl;
         const size_t lds_pf = (SmallLds<4>::TOTAL + 72) * sizeof(double);
         const size_t lds_b = SmallLds<4>::TOTAL * sizeof(double);
-        const unsigned nblk = (unsigned)((h->B + 3) / 4);
+        const unsigned nblk = (unsigned)((h->Bl + 3) / 4);
         double pow_b1 = 1.0, pow_b2 = 1.0;
         for (int e = 0; e < E && rc == CB_OK; ++e) {
           pow_b1 *= a.beta1;

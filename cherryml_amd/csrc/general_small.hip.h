@@ -26,7 +26,8 @@
 #define GN_MAT 1024                // doubles per 32x32 matrix
 
 struct GeneralArgs {
-  int S, L, B;
+  int S, L, B;             // B = bucket stride
+  const int *nlive;        // [L] buckets to visit (live first) or null = B
   const double *t, *Ct, *inv_n, *Q;
   double *loss, *dQ, *P;   // P: expm mode (or null)
   double *scratch;         // [L][NW][GN_SLOTS][1024]
@@ -112,7 +113,8 @@ __global__ __launch_bounds__(NW * 64) void general_bank_kernel(GeneralArgs a) {
   const double inv_n = a.inv_n[l];
   double lossacc = 0.0;
 
-  for (int b = wave; b < B; b += NW) {
+  const int Bn = a.nlive ? a.nlive[l] : B;
+  for (int b = wave; b < Bn; b += NW) {
     const size_t lb = (size_t)l * B + b;
     const double tb = a.t[lb];
     int s = 0;

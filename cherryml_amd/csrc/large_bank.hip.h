@@ -358,9 +358,10 @@ __global__ void lg_finish_loss(const double *part, int nparts, int S, const doub
 }
 
 // pad + transpose counts at create time: Ct[b][j][i] = C[b][i][j]
-__global__ void lg_transpose_pad(int S, int LD, const double *C, double *Ct) {
+// destination bucket z holds source bucket src[z] (live buckets only, see cb_create)
+__global__ void lg_transpose_pad(int S, int LD, const double *C, double *Ct, const int *src) {
   __shared__ double tile[32][33];
-  const int b = blockIdx.z;
+  const int b = src[blockIdx.z];
   const int i0 = blockIdx.y * 32, j0 = blockIdx.x * 32;
   for (int r = threadIdx.y; r < 32; r += blockDim.y) {
     const int i = i0 + r, j = j0 + threadIdx.x;
@@ -369,6 +370,6 @@ __global__ void lg_transpose_pad(int S, int LD, const double *C, double *Ct) {
   __syncthreads();
   for (int r = threadIdx.y; r < 32; r += blockDim.y) {
     const int j = j0 + r, i = i0 + threadIdx.x;
-    if (j < LD && i < LD) Ct[(size_t)b * LD * LD + (size_t)j * LD + i] = tile[threadIdx.x][r];
+    if (j < LD && i < LD) Ct[(size_t)blockIdx.z * LD * LD + (size_t)j * LD + i] = tile[threadIdx.x][r];
   }
 }

@@ -22,7 +22,8 @@
 #define CB_LS 33  // LDS row stride (doubles) of the 32x32 frames
 
 struct SmallArgs {
-  int S, L, B;
+  int S, L, B;        // B = bucket stride of t / Ct / P
+  const int *nlive;   // [L] buckets to visit per site (live ones are stored first), or null = B
   const double *t;    // [L,B]
   const double *Ct;   // [L,B,S,S]  (transposed counts)
   const double *inv_n;  // [L]  1/n_l or 1
@@ -409,7 +410,7 @@ __global__ __launch_bounds__(NW * 64, 2) void small_bank_kernel(SmallArgs a) {
   }
   small_build_A(S, a.Q + (size_t)l * S * S, a.pi + (size_t)l * S, sA, sD);
   const size_t lb = (size_t)l * B;
-  small_site_eval<NT, KS, NW, MODE>(lds, S, B, a.t + lb, a.Ct + lb * S * S, a.inv_n[l],
+  small_site_eval<NT, KS, NW, MODE>(lds, S, a.nlive ? a.nlive[l] : B, a.t + lb, a.Ct + lb * S * S, a.inv_n[l],
                                     a.dirsum + (size_t)l * S,
                                     MODE == SMALL_EXPM ? a.P + lb * S * S : nullptr,
                                     a.dQ != nullptr, a.status ? a.status + l : nullptr);

@@ -25,6 +25,7 @@
 
 struct TrainArgs {
   int S, L, B, E, kind, do_adam, n_pow2;
+  const int *nlive;                 // [L] live buckets per site (stored first); B = stride
   const double *t, *Ct, *inv_n, *dirsum;
   double *p_pi, *p_up;              // parameters  [L][S], [L][NUP]
   double *m_pi, *v_pi, *m_up, *v_up;  // Adam moments (zero initialised)
@@ -201,7 +202,7 @@ __global__ __launch_bounds__(NW * 64, 2) void small_train_kernel(TrainArgs a) {
   for (int epoch = 0; epoch < a.E; ++epoch) {
     tr_build(a, l, epoch, sA, sD, sPi);
     // sV still holds the previous epoch's eigenvectors (zero padded): warm start
-    small_site_eval<NT, KS, NW, SMALL_LOSSGRAD>(lds, S, B, a.t + lb, a.Ct + lb * S * S, a.inv_n[l],
+    small_site_eval<NT, KS, NW, SMALL_LOSSGRAD>(lds, S, a.nlive[l], a.t + lb, a.Ct + lb * S * S, a.inv_n[l],
                                                 a.dirsum + (size_t)l * S, nullptr, true, nullptr,
                                                 epoch > 0);
     // (ends with a barrier: sG = dA, sA = A, LOSSTOT = loss)

@@ -51,9 +51,15 @@ class ShardedBank:
         on = dist.is_available() and dist.is_initialized()
         self.rank = dist.get_rank(group) if on else 0
         self.world = dist.get_world_size(group) if on else 1
-        mine = bucket_shard(C.shape[0], self.rank, self.world)
+        # only non-empty buckets cost anything (cb_create drops the others), so deal those:
+        # on real co-evolution banks 2/3 of the buckets are empty and dealing all of them
+        # round-robin would leave the ranks unbalanced
+        live = np.flatnonzero(np.any(C.reshape(C.shape[0], -1) != 0.0, axis=1))
+        if live.size == 0:
+            raise ValueError("the bank has no counts")
+        mine = live[bucket_shard(live.size, self.rank, self.world)]
         if mine.size == 0:
-            raise ValueError(f"rank {self.rank} owns no bucket (B={C.shape[0]} < world={self.world})")
+            raise ValueError(f"rank {self.rank} owns no bucket ({live.size} non-empty buckets < world={self.world})")
         self.total_count = float(C.sum())  # every rank sees the full host array here
         self.local_buckets = mine
         if make_bank is None:

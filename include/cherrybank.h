@@ -79,6 +79,13 @@ int cb_set_stream(cb_handle h, void *hip_stream, int own);
 /* Total count n_l = sum(C[l]) per site, n[L] (host pointer). */
 int cb_total_counts(cb_handle h, double *n);
 
+/* Number of non-empty buckets (C[l,b] != 0) per site, nlive[L] (host pointer).  Empty
+ * buckets add nothing to the loss or its gradient (the reference still exponentiates them,
+ * trainer.py:170; only SiteRM compacts, _site_specific_rate_matrix.py:590-615): cb_create
+ * stores the live buckets only and every loss / training entry point visits only those.
+ * cb_expm_bank still returns all B buckets in the caller's order. */
+int cb_live_buckets(cb_handle h, int *nlive);
+
 /*
  * One evaluation of the epoch body for reversible Q:
  *   loss[l] = - sum_b <C[l,b], log expm(t[l,b] Q[l])>      (/ n_l with CB_NORMALIZE)

@@ -349,3 +349,31 @@ def test_split_and_single_kernel_lg_trainers_agree():
     assert relerr(outs[0]["Q_best"], outs[1]["Q_best"]) < 1e-9
     assert relerr(outs[0]["Q_last"], outs[1]["Q_last"]) < 1e-9
     assert np.allclose(outs[0]["loss"], g["loss_f64"][:30], rtol=1e-9, atol=0)
+
+
+def test_fused_trainers_with_empty_buckets():
+    """Empty buckets are dropped at cb_create; trajectories still equal the oracle's on the
+    full (zero-padded) bank -- single bank (split LG trainer) and SiteRM (ragged per site)."""
+    from cherryml_amd import CherryBank
+    from oracle import ratelearn_oracle as orc
+    g = load_golden("traj_lgbank.npz")
+    t, C, mask, E = g["t"], g["C"].copy(), np.ones((20, 20)), 30
+    C[::3] = 0.0
+    C[100:] = 0.0
+    u0, p0 = orc.invert_pande_reversible(g["init"], mask)
+    ref = orc.train(t, C, mask, upper_diag=u0, log_pi=p0, num_epochs=E, dtype=torch.float64)
+    with CherryBank(t, C) as bank:
+        assert bank.live_buckets[0] == int(np.any(C.reshape(len(t), -1) != 0, axis=1).sum())
+        r = bank.train_pande_reversible(u0, p0, mask=mask, num_epochs=E, lr=0.1)
+    assert np.allclose(r["loss"], ref["loss"], rtol=1e-9, atol=0)
+    assert relerr(r["Q_best"], ref["Q_best"]) < 1e-6
+    s = load_golden("siterm_aa.npz")
+    counts, times = s["counts"].copy(), s["times"]
+    for l in range(counts.shape[0]):
+        counts[l, l % counts.shape[1]::2] = 0.0
+    E = 12
+    ref = orc.siterm_train(counts, times, E, initialization=s["init"])
+    from cherryml_amd import quantized_transitions_mle_vectorized_over_sites as qvec
+    a = qvec(counts, times, num_epochs=E, initialization=s["init"], device="cuda", fused=True)
+    assert np.allclose(a["loss_per_epoch_per_site"], ref["loss_per_epoch_per_site"], rtol=1e-8, atol=0)
+    assert relerr(a["res"], ref["res"]) < 1e-6

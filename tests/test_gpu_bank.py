@@ -280,3 +280,61 @@ def test_results_are_bitwise_reproducible():
     with _bank(g["t"], g["C"]) as bank:
         b = bank.loss_grad(Q, pi)
     assert a[0][0] == b[0][0] and np.array_equal(a[1], b[1])
+
+
+# ---- empty buckets: stored and visited live-only; results identical to the dense oracle ----
+def _with_empty_buckets(rng, C, frac=0.6):
+    """zero out a random subset of buckets (never all)"""
+    C = C.copy()
+    B = C.shape[-3]
+    kill = rng.random(B) < frac
+    kill[rng.integers(B)] = False
+    C[..., kill, :, :] = 0.0
+    return C, kill
+
+
+@pytest.mark.parametrize("S,B", [(20, 12), (48, 7), (100, 5)])
+def test_empty_buckets_single_bank(S, B):
+    rng = np.random.default_rng(S + B)
+    Q, pi = _sym_rate(rng, S, scale=0.2)
+    t = np.sort(rng.uniform(0.01, 2.0, size=B))
+    C = rng.poisson(3.0, size=(B, S, S)).astype(np.float64)
+    C, kill = _with_empty_buckets(rng, C)
+    ref_loss, ref_grad = _oracle_loss_grad(Q, t, C)
+    with _bank(t, C) as bank:
+        assert bank.live_buckets[0] == int((~kill).sum())
+        loss, dQ = bank.loss_grad(Q, pi)
+        P = bank.expm_bank(Q, pi)[0]          # all B buckets, caller's order
+    assert abs(loss[0] - ref_loss) < 1e-12 * abs(ref_loss)
+    assert relerr(dQ[0], ref_grad) < 1e-10
+    assert P.shape == (B, S, S)
+    assert relerr(P, orc.expm_bank(Q, t)) < 1e-12
+
+
+def test_empty_buckets_differ_per_site_and_general_path():
+    rng = np.random.default_rng(11)
+    L, B, N = 9, 10, 20
+    counts = rng.poisson(2.0, size=(L, B, N, N)).astype(np.float64)
+    times = np.sort(rng.uniform(0.02, 3.0, size=(L, B)), axis=1)
+    live = []
+    for l in range(L):
+        counts[l], kill = _with_empty_buckets(rng, counts[l], frac=0.1 * l)
+        live.append(int((~kill).sum()))
+    Qs = np.zeros((L, N, N))
+    pis = np.zeros((L, N))
+    for l in range(L):
+        Qs[l], pis[l] = _sym_rate(rng, N, scale=0.3)
+    Qt = torch.tensor(Qs, requires_grad=True)
+    per_site, total = orc.siterm_loss(Qt, torch.tensor(counts), torch.tensor(times))
+    total.backward()
+    with _bank(times, counts) as bank:
+        assert list(bank.live_buckets) == live
+        loss, dQ = bank.loss_grad(Qs, pis)
+        loss_g, dQ_g = bank.loss_grad_general(Qs)
+        P = bank.expm_bank(Qs, pis)
+    assert np.allclose(loss, per_site.detach().numpy(), rtol=1e-12, atol=0)
+    assert np.allclose(loss_g, per_site.detach().numpy(), rtol=1e-11, atol=0)
+    for l in range(L):
+        assert relerr(dQ[l], Qt.grad[l].numpy()) < 1e-10
+        assert relerr(dQ_g[l], Qt.grad[l].numpy()) < 1e-9
+        assert relerr(P[l], orc.expm_bank(Qs[l], times[l])) < 1e-12
