@@ -474,14 +474,23 @@ static int large_eigh(cb_bank *h, bool warm) {
   const int max_sweeps = 40;
   const char *env_inner = getenv("CB_INNER_SWEEPS");
   const int inner_sweeps = env_inner ? atoi(env_inner) : 0;  // 0 = each pair once per sweep
+  const char *env_within = getenv("CB_WITHIN_SWEEPS");
+  const char *env_passes = getenv("CB_WITHIN_PASSES");
   int sweep = 0;
   unsigned long long *dbg_stamps = nullptr;
   if (getenv("CB_DEBUG_STAMPS")) HIP_TRY(hipMalloc((void **)&dbg_stamps, 8 * sizeof(unsigned long long)));
   for (; sweep < max_sweeps; ++sweep) {
     HIP_TRY(hipMemsetAsync(h->off_bits, 0, sizeof(unsigned long long), h->stream));
-    if (inner_sweeps == 0)  // pairs inside each block, once per sweep
-      hipLaunchKernelGGL(lgj_round, dim3(nb / 2), dim3(JB_THREADS), lds, h->stream, LD, -1, 0, h->Gc,
-                         h->off_bits, (unsigned long long *)nullptr);
+    if (inner_sweeps == 0) {
+      // within passes: each 16-column group fully diagonalised (all 120 pairs, to convergence);
+      // the group alignment alternates so that the groups overlap by one block
+      const int within = env_within ? atoi(env_within) : 6;
+      const int passes = env_passes ? atoi(env_passes) : 2;
+      for (int w = 0; w < passes; ++w)
+        hipLaunchKernelGGL(lgj_round, dim3(nb / 2), dim3(JB_THREADS), lds, h->stream, LD,
+                           ((sweep + w) & 1) && nb > 2 ? -2 : -1, within, h->Gc, h->off_bits,
+                           (unsigned long long *)nullptr);
+    }
     for (int r = 0; r < nb - 1; ++r)
       hipLaunchKernelGGL(lgj_round, dim3(nb / 2), dim3(JB_THREADS), lds, h->stream, LD, r,
                          inner_sweeps, h->Gc, h->off_bits,
@@ -510,7 +519,8 @@ static int large_eigh(cb_bank *h, bool warm) {
               st[i + 1] - st[i]);
   }
   if (sweep >= max_sweeps) return fail(CB_ENUMERIC, "block Jacobi did not converge in %d sweeps", max_sweeps);
-  hipLaunchKernelGGL(lgj_finish, dim3((LD + 3) / 4), dim3(256), 0, h->stream, LD, h->Gc, h->sigma,
+  hipLaunchKernelGGL(lgj_norms, dim3((LD + 3) / 4), dim3(256), 0, h->stream, LD, h->Gc, h->X);
+  hipLaunchKernelGGL(lgj_finish, dim3((LD + 3) / 4), dim3(256), 0, h->stream, LD, h->Gc, h->X, h->sigma,
                      h->lam, h->U, h->Vc);
   HIP_TRY(hipGetLastError());
   h->have_prev = true;

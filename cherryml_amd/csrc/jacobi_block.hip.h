@@ -67,9 +67,12 @@ __global__ __launch_bounds__(JB_THREADS) void lgj_round(int LD, int round, int i
   int bi, bj;
   if (round >= 0) {
     rr_pair(nb, round, blockIdx.x, bi, bj);
-  } else {
+  } else if (round == -1) {
     bi = 2 * blockIdx.x;
     bj = bi + 1;
+  } else {  // -2: groups shifted by one block, so clusters straddling a group edge get their turn
+    bi = 2 * blockIdx.x + 1;
+    bj = (bi + 1) % nb;
   }
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int lo = lane & 15, hi = lane >> 4;
@@ -209,10 +212,8 @@ __global__ __launch_bounds__(JB_THREADS) void lgj_round(int LD, int round, int i
 #undef JB_STAMP
 }
 
-// lam_k = sigma - |g_k| ; Ut[k][r] = U[r][k] = -g_k[r] / |g_k|   (A' negative definite)
-__global__ void lgj_finish(int LD, const double *Gc, const double *sigma, double *lam, double *U,
-                           double *Ut) {
-  // one wave per column k
+// |g_k| per column (one wave per column)
+__global__ void lgj_norms(int LD, const double *Gc, double *nrm) {
   const int k = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   if (k >= LD) return;
@@ -222,11 +223,31 @@ __global__ void lgj_finish(int LD, const double *Gc, const double *sigma, double
     nn = fma(v, v, nn);
   }
   nn = wave_sum(nn);
-  const double nrm = sqrt(nn), inv = -1.0 / nrm;
+  if (lane == 0) nrm[k] = sqrt(nn);
+}
+
+// lam = sigma - |g_k| ; Ut[pos][r] = U[r][pos] = -g_k[r] / |g_k|   (A' negative definite), with
+// pos = rank of |g_k| in descending order (eigenvalues ascending).  Sorted output keeps
+// near-degenerate eigenvectors in neighbouring columns, i.e. inside one 16-column group of the
+// next (warm-started) solve, where the within pass resolves the whole cluster at once.
+__global__ void lgj_finish(int LD, const double *Gc, const double *nrm, const double *sigma, double *lam,
+                           double *U, double *Ut) {
+  const int k = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (k >= LD) return;
+  const double mine = nrm[k];
+  int before = 0;
+  for (int j = lane; j < LD; j += 64) {
+    const double o = nrm[j];
+    before += (o > mine || (o == mine && j < k)) ? 1 : 0;
+  }
+  before = (int)wave_sum((double)before);
+  const int pos = before;
+  const double inv = -1.0 / mine;
   for (int r = lane; r < LD; r += 64) {
     const double v = Gc[(size_t)k * LD + r] * inv;
-    Ut[(size_t)k * LD + r] = v;
-    U[(size_t)r * LD + k] = v;
+    Ut[(size_t)pos * LD + r] = v;
+    U[(size_t)r * LD + pos] = v;
   }
-  if (lane == 0) lam[k] = *sigma - nrm;
+  if (lane == 0) lam[pos] = *sigma - mine;
 }
