@@ -353,7 +353,7 @@ extern "C" int cb_create(int device, int S, int L, int B, const double *t, const
               dev_alloc(h, &h->A, LL) == CB_OK && dev_alloc(h, &h->dsq, h->LD) == CB_OK &&
               dev_alloc(h, &h->Gc, LL) == CB_OK && dev_alloc(h, &h->Vc, LL) == CB_OK &&
               dev_alloc(h, &h->U, LL) == CB_OK && dev_alloc(h, &h->lam, h->LD) == CB_OK &&
-              dev_alloc(h, &h->sigma, 8) == CB_OK && dev_alloc(h, &h->off_bits, 8) == CB_OK &&
+              dev_alloc(h, &h->sigma, 8) == CB_OK && dev_alloc(h, &h->off_bits, 64) == CB_OK &&
               dev_alloc(h, &h->F, (size_t)B * h->LD) == CB_OK &&
               dev_alloc(h, &h->E, (size_t)B * h->LD) == CB_OK &&
               dev_alloc(h, &h->H, (size_t)B * h->LD) == CB_OK &&
@@ -476,16 +476,15 @@ static int large_eigh(cb_bank *h, bool warm) {
   const int inner_sweeps = env_inner ? atoi(env_inner) : 0;  // 0 = each pair once per sweep
   const char *env_within = getenv("CB_WITHIN_SWEEPS");
   const char *env_passes = getenv("CB_WITHIN_PASSES");
-  int sweep = 0;
+  const int within = env_within ? atoi(env_within) : 6;
+  const int passes = env_passes ? atoi(env_passes) : 2;
   unsigned long long *dbg_stamps = nullptr;
   if (getenv("CB_DEBUG_STAMPS")) HIP_TRY(hipMalloc((void **)&dbg_stamps, 8 * sizeof(unsigned long long)));
-  for (; sweep < max_sweeps; ++sweep) {
-    HIP_TRY(hipMemsetAsync(h->off_bits, 0, sizeof(unsigned long long), h->stream));
+  HIP_TRY(hipMemsetAsync(h->off_bits, 0, 64 * sizeof(unsigned long long), h->stream));
+  auto enqueue_sweep = [&](int sweep) {
     if (inner_sweeps == 0) {
       // within passes: each 16-column group fully diagonalised (all 120 pairs, to convergence);
       // the group alignment alternates so that the groups overlap by one block
-      const int within = env_within ? atoi(env_within) : 6;
-      const int passes = env_passes ? atoi(env_passes) : 2;
       for (int w = 0; w < passes; ++w)
         hipLaunchKernelGGL(lgj_round, dim3(nb / 2), dim3(JB_THREADS), lds, h->stream, LD,
                            ((sweep + w) & 1) && nb > 2 ? -2 : -1, within, h->Gc, h->off_bits,
@@ -495,19 +494,31 @@ static int large_eigh(cb_bank *h, bool warm) {
       hipLaunchKernelGGL(lgj_round, dim3(nb / 2), dim3(JB_THREADS), lds, h->stream, LD, r,
                          inner_sweeps, h->Gc, h->off_bits,
                          (dbg_stamps && sweep == 2 && r == 5) ? dbg_stamps : nullptr);
-    unsigned long long bits = 0;
-    HIP_TRY(hipMemcpyAsync(&bits, h->off_bits, sizeof bits, hipMemcpyDeviceToHost, h->stream));
+    // a sweep that STARTS below 1e-8 ends at rounding level (quadratic convergence)
+    hipLaunchKernelGGL(lgj_check, dim3(1), dim3(64), 0, h->stream, h->off_bits, 1e-8);
+  };
+  // Sweeps are enqueued without waiting for the host: as many as the previous (warm) solve needed
+  // minus one, then one at a time.  Launches after convergence return immediately.
+  int sweep = 0, enq = 0;
+  unsigned long long st[64] = {};
+  const bool speculate = warm && h->last_sweeps > 1 && !getenv("CB_NO_SPECULATE");
+  int batch = speculate ? h->last_sweeps - 1 : 1;
+  for (;;) {
+    for (int i = 0; i < batch && enq < max_sweeps; ++i) enqueue_sweep(enq++);
+    HIP_TRY(hipMemcpyAsync(st, h->off_bits, sizeof st, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
-    double off;
-    memcpy(&off, &bits, sizeof off);
-    if (!(off == off)) return fail(CB_ENUMERIC, "eigensolver: non-finite input");
-    if (getenv("CB_DEBUG")) fprintf(stderr, "[cherrybank] eigh sweep %d: max cosine %.3e\n", sweep, off);
-    // quadratic convergence: a sweep that STARTS below 1e-8 ends at rounding level
-    if (off <= 1e-8) {
-      ++sweep;
-      break;
-    }
+    sweep = (int)st[2];
+    if (getenv("CB_DEBUG"))
+      for (int k = 0; k < sweep && k < 48; ++k) {
+        double off;
+        memcpy(&off, &st[8 + k], sizeof off);
+        if (k >= sweep - batch) fprintf(stderr, "[cherrybank] eigh sweep %d: max cosine %.3e\n", k, off);
+      }
+    if (st[1] == 2ull) return fail(CB_ENUMERIC, "eigensolver: non-finite input");
+    if (st[1] == 1ull || enq >= max_sweeps) break;
+    batch = 1;
   }
+  const bool converged = st[1] == 1ull;
   h->last_sweeps = sweep;
   if (dbg_stamps) {
     unsigned long long st[8];
@@ -518,7 +529,7 @@ static int large_eigh(cb_bank *h, bool warm) {
       fprintf(stderr, "[cherrybank] lgj_round %-12s %6llu ticks (100 MHz)\n", names[i == 2 ? 3 : (i > 2 ? i + 1 : i)],
               st[i + 1] - st[i]);
   }
-  if (sweep >= max_sweeps) return fail(CB_ENUMERIC, "block Jacobi did not converge in %d sweeps", max_sweeps);
+  if (!converged) return fail(CB_ENUMERIC, "block Jacobi did not converge in %d sweeps", max_sweeps);
   hipLaunchKernelGGL(lgj_norms, dim3((LD + 3) / 4), dim3(256), 0, h->stream, LD, h->Gc, h->X);
   hipLaunchKernelGGL(lgj_finish, dim3((LD + 3) / 4), dim3(256), 0, h->stream, LD, h->Gc, h->X, h->sigma,
                      h->lam, h->U, h->Vc);

@@ -51,7 +51,11 @@ __device__ __forceinline__ int jb_rowstride(int LD) { return LD + ((2 - LD % 32 
 //             pass visits every column pair exactly once.
 __global__ __launch_bounds__(JB_THREADS) void lgj_round(int LD, int round, int inner_sweeps,
                                                         double *Gc, unsigned long long *off_bits,
-                                                        unsigned long long *stamps) {
+                                                        unsigned long long *stamps,
+                                                        unsigned long long *dist_bits = nullptr) {
+  // off_bits[0]: running max cosine of this sweep; off_bits[1]: solve finished (set by lgj_check):
+  // sweeps are enqueued speculatively, the surplus launches return at once
+  if (off_bits[1] != 0ull) return;
   extern __shared__ double lds[];
 #define JB_STAMP(i)                                                              \
   if (stamps && blockIdx.x == 0 && threadIdx.x == 0) stamps[i] = __builtin_amdgcn_s_memtime();
@@ -149,14 +153,23 @@ __global__ __launch_bounds__(JB_THREADS) void lgj_round(int LD, int round, int i
       JB_STAMP(3)
       wave_rotation_spd16(sGam, sR, 17, inner_sweeps);
     } else {
-      for (int e = lane; e < 256; e += 64) sR[(e >> 4) * 17 + (e & 15)] = ((e >> 4) == (e & 15)) ? 1.0 : 0.0;
-      wave_lds_fence();
-      JB_STAMP(3)
-      const double off2 = wave_rotation_spd16_blockpairs(sGam, sR, 17, round >= 0);
+      double off2;
+      if (round >= 0) {
+        JB_STAMP(3)
+        off2 = wave_rotation_cross16_regs(sGam, sR, 17);
+      } else {
+        for (int e = lane; e < 256; e += 64) sR[(e >> 4) * 17 + (e & 15)] = ((e >> 4) == (e & 15)) ? 1.0 : 0.0;
+        wave_lds_fence();
+        JB_STAMP(3)
+        off2 = wave_rotation_spd16_blockpairs(sGam, sR, 17, false);
+      }
       off = off2 > 0.0 ? off2 * fast_rsqrt(off2) : 0.0;
     }
     JB_STAMP(4)
-    if (lane == 0) atomicMax(off_bits, dbl_bits(off));
+    if (lane == 0) {
+      atomicMax(off_bits, dbl_bits(off));
+      if (dist_bits && round >= 0) atomicMax(dist_bits + (bi > bj ? bi - bj : bj - bi), dbl_bits(off));
+    }
   }
   __syncthreads();
   // One Newton-Schulz step R <- R (3 I - R^T R) / 2 (all four waves, one entry per thread):
@@ -210,6 +223,22 @@ __global__ __launch_bounds__(JB_THREADS) void lgj_round(int LD, int round, int i
   }
   JB_STAMP(6)
 #undef JB_STAMP
+}
+
+// End of a sweep: state[0] = largest cosine met before its rotation during the sweep.  Quadratic
+// convergence: a sweep that STARTS below `tol` ends at rounding level, so it was the last one.
+// state[1] = done (1) / non-finite input (2); state[2] = sweeps run; state[8 + k] = cosine of sweep k.
+__global__ void lgj_check(unsigned long long *state, double tol) {
+  if (threadIdx.x != 0 || state[1] != 0ull) return;
+  const unsigned long long bits = state[0];
+  double off;
+  memcpy(&off, &bits, sizeof off);
+  const unsigned long long k = state[2];
+  if (k < 48) state[8 + k] = bits;
+  state[2] = k + 1;
+  state[0] = 0ull;
+  if (!(off == off) || off > 1e300) state[1] = 2ull;   // NaN / inf
+  else if (off <= tol) state[1] = 1ull;
 }
 
 // |g_k| per column (one wave per column)

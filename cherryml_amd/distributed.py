@@ -1,4 +1,13 @@
-"""One process per GPU: the bank's buckets are dealt round-robin to the ranks
+"""One process per GPU.
+
+Two ways to build the sharded bank:
+* `ShardedBank(t, C)`: every rank sees the whole host array and keeps its own buckets.
+* `ShardedBank.from_rank_counts(t, C_rank)`: every rank holds the sufficient statistics of ITS OWN
+  families (the counting stage is family-sharded, SURVEY 8e option 2); one reduce-scatter over the
+  buckets sums them and leaves each rank with exactly the buckets it owns -- no rank ever holds
+  the summed [B,S,S] tensor.
+
+Then, per epoch: the bank's buckets are dealt round-robin to the ranks
 (bucket b -> rank b mod world), every rank evaluates the partial loss and
 partial dL/dQ of its own buckets, and ONE all-reduce (RCCL over xGMI with the
 "nccl" backend; gloo in the CPU tests) of S*S + 1 float64 values per epoch sums
@@ -62,11 +71,58 @@ class ShardedBank:
             raise ValueError(f"rank {self.rank} owns no bucket ({live.size} non-empty buckets < world={self.world})")
         self.total_count = float(C.sum())  # every rank sees the full host array here
         self.local_buckets = mine
-        if make_bank is None:
-            from .bank import CherryBank
-            dev = torch.cuda.current_device()
-            make_bank = lambda tt, CC: CherryBank(tt, CC, device=dev)  # noqa: E731
-        self.bank = make_bank(t[mine], C[mine])
+        self.bank = self._make(make_bank)(t[mine], C[mine])
+
+    @staticmethod
+    def _make(make_bank):
+        if make_bank is not None:
+            return make_bank
+        from .bank import CherryBank
+        dev = torch.cuda.current_device()
+        return lambda tt, CC: CherryBank(tt, CC, device=dev)
+
+    @classmethod
+    def from_rank_counts(cls, t, C_rank, make_bank: Optional[Callable] = None, group=None):
+        """`C_rank` [B,S,S] (numpy, or a torch tensor already on this rank's GPU): the counts of
+        the families THIS rank counted.  Bucket b belongs to rank b mod world; the tensor is laid
+        out owner-major (zero padded to equal chunks) and reduce-scattered, so rank r receives
+        sum_over_ranks C[b] for its own buckets only.  The grand total (the loss normaliser) is
+        one scalar all-reduce."""
+        self = cls.__new__(cls)
+        t = np.asarray(t, dtype=np.float64).reshape(-1)
+        on = dist.is_available() and dist.is_initialized()
+        self.group = group
+        self.rank = dist.get_rank(group) if on else 0
+        self.world = dist.get_world_size(group) if on else 1
+        Ct = torch.as_tensor(C_rank, dtype=torch.float64)
+        if Ct.ndim != 3 or Ct.shape[0] != t.size:
+            raise ValueError("from_rank_counts: C_rank must be [B,S,S] with B = len(t)")
+        B, S = Ct.shape[0], Ct.shape[1]
+        chunk = -(-B // self.world)
+        owner_major = [bucket_shard(B, r, self.world) for r in range(self.world)]
+        mine = owner_major[self.rank]
+        total = Ct.sum().reshape(1)
+        if self.world > 1:
+            packed = torch.zeros((self.world * chunk, S, S), dtype=torch.float64, device=Ct.device)
+            for r, idx in enumerate(owner_major):
+                packed[r * chunk:r * chunk + idx.size] = Ct[torch.as_tensor(idx, device=Ct.device)]
+            if dist.get_backend(group) == "gloo":   # CPU tests: gloo has no reduce-scatter
+                dist.all_reduce(packed, op=dist.ReduceOp.SUM, group=group)
+                got = packed[self.rank * chunk:(self.rank + 1) * chunk].clone()
+            else:
+                got = torch.empty((chunk, S, S), dtype=torch.float64, device=Ct.device)
+                dist.reduce_scatter_tensor(got, packed, op=dist.ReduceOp.SUM, group=group)
+            del packed
+            dist.all_reduce(total, op=dist.ReduceOp.SUM, group=group)
+            C_mine = got[:mine.size]
+        else:
+            C_mine = Ct
+        if mine.size == 0:
+            raise ValueError(f"rank {self.rank} owns no bucket (B={B} < world={self.world})")
+        self.total_count = float(total.item())
+        self.local_buckets = mine
+        self.bank = cls._make(make_bank)(t[mine], C_mine if C_mine.is_cuda else C_mine.numpy())
+        return self
 
     def loss(self, Q: torch.Tensor, pi: torch.Tensor, normalize: bool = True) -> torch.Tensor:
         """Differentiable (in Q) loss of the WHOLE bank; every rank gets the same value."""

@@ -83,6 +83,46 @@ def test_sharded_bank_two_ranks_matches_single(tmp_path):
     assert relerr(r0["Q"].numpy(), ref["Q_4"]) < 1e-11
 
 
+def _worker_family(rank, world, port, out):
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, here)
+    sys.path.insert(0, os.path.dirname(here))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from cherryml_amd.distributed import ShardedBank
+    g = load_golden("traj_lgbank.npz")
+    t, C = g["t"][::8], g["C"][::8]
+    # family sharding: each rank counted a different part of the data (integer counts, so the
+    # split is exact): rank 0 holds floor(C/3), rank 1 the rest
+    part = np.floor(C / 3.0) if rank == 0 else C - np.floor(C / 3.0)
+    sb = ShardedBank.from_rank_counts(t, part, make_bank=lambda tt, CC: OracleBank(tt, CC))
+    assert abs(sb.total_count - float(C.sum())) <= 1e-12 * float(C.sum())
+    assert np.array_equal(sb.bank.C.numpy(), C[rank::world])   # summed counts of MY buckets only
+    Q = torch.tensor(g["init"], dtype=torch.float64, requires_grad=True)
+    pi = torch.full((20,), 0.05, dtype=torch.float64)
+    loss = sb.loss(Q, pi, normalize=True)[0]
+    loss.backward()
+    torch.save(dict(loss=loss.item(), grad=Q.grad), os.path.join(out, f"f{rank}.pt"))
+    dist.destroy_process_group()
+
+
+def test_family_sharded_counts_reduce_scatter_two_ranks(tmp_path):
+    from oracle import ratelearn_oracle as orc
+    port = _free_port()
+    mp.spawn(_worker_family, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0 = torch.load(os.path.join(tmp_path, "f0.pt"))
+    r1 = torch.load(os.path.join(tmp_path, "f1.pt"))
+    g = load_golden("traj_lgbank.npz")
+    Q = torch.tensor(g["init"], dtype=torch.float64, requires_grad=True)
+    ref = orc.bank_loss(Q, torch.tensor(g["t"][::8]), torch.tensor(g["C"][::8]))
+    ref.backward()
+    assert r0["loss"] == r1["loss"] and torch.equal(r0["grad"], r1["grad"])
+    assert abs(r0["loss"] - ref.item()) < 1e-12 * abs(ref.item())
+    assert relerr(r0["grad"].numpy(), Q.grad.numpy()) < 1e-11
+
+
 def test_bucket_shard_partition():
     from cherryml_amd.distributed import bucket_shard
     for world in (1, 2, 3, 8):
