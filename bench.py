@@ -319,11 +319,13 @@ def main():
             Lb = wl["C"].shape[0] if wl["kind"] == "sites" else 1
             nbytes = float(Lb) * B_local * S * S * 8  # C streamed once per epoch
             achieved = nbytes / (tm["small"] * 1e-3) / 1e9 if tm["small"] > 0 else 0.0
-            roofline = dict(bound="hbm", kernel="small_train_kernel", achieved=achieved,
+            kname = ("lg_prepare + lg_bank + lg_finish (3 launches per epoch)" if wl["kind"] == "single"
+                     else "small_train_kernel")
+            roofline = dict(bound="hbm", kernel=kname, achieved=achieved,
                             peak=HBM_PEAK_GBS, unit="GB/s", frac=achieved / HBM_PEAK_GBS,
-                            traffic=traffic.get("small_train_kernel:" + workload + ":per_epoch") if world == 1 else None,
+                            traffic=traffic.get("epoch:" + workload) if world == 1 else None,
                             ms_per_epoch_in_kernel=tm["small"], bytes_per_epoch=nbytes,
-                            note="one launch runs all K epochs; figures are per epoch")
+                            note="figures are per epoch (SiteRM: one launch runs all K epochs)")
         out = {
             "metric": "cherry-pairs/sec (whole node) per EM iter",
             "value": n_pairs_total / (dt / steps), "unit": "cherry-pairs/s", "n_gpus": world,
@@ -445,7 +447,7 @@ def run_counting(steps, warmup, world, rank, local_rank, fence, with_cpu):
                    "sharding": f"families x{world}, all-reduce of integer counts"},
         "roofline": {"bound": "hbm", "kernel": "count_transitions_lds_kernel", "achieved": achieved,
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                     "traffic": None, "ms_per_launch": kernel_ms, "bytes_per_launch": nbytes,
+                     "traffic": _pmc_traffic().get("pass:counting"), "ms_per_launch": kernel_ms, "bytes_per_launch": nbytes,
                      "note": "per-workgroup LDS histogram (packed 16-bit bins) + slab reduction"},
         "counted_pairs": counted,
     }

@@ -22,8 +22,11 @@ out = {"bytes_per_launch": {}, "detail": {}, "calibration": {},
        "source": f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), gpurun_out/{tag}_pmc_*"}
 names = {"k1_pt_loss_gt": "k1_pt_loss_gt", "k2_t_eq_g_u": "k2_t_eq_g_u", "k3_w_phi": "k3_w_phi",
          "lgj_round": "lgj_round", "lg_transpose_pad": "lg_transpose_pad",
-         "small_train_kernel": "small_train_kernel", "small_bank_kernel": "small_bank_kernel"}
-for w in ["coevo400", "lg20", "siterm"]:
+         "small_train_kernel": "small_train_kernel", "small_bank_kernel": "small_bank_kernel",
+         "lg_prepare": "lg_prepare", "lg_bank": "lg_bank", "lg_finish": "lg_finish",
+         "count_transitions_lds_kernel": "count_transitions_lds_kernel",
+         "count_reduce_slabs": "count_reduce_slabs", "k3_reduce": "k3_reduce", "k4_gemm": "k4_gemm"}
+for w in ["coevo400", "lg20", "siterm", "counting"]:
     st = glob.glob(f"{root}/gpurun_out/{tag}_trace_{w}/*/*_kernel_stats.csv")
     if st:
         shutil.copy(st[0], f"{here}/r01_{tag}_{w}_kernel_stats.csv")
@@ -57,10 +60,14 @@ if "lg_transpose_pad" in out["detail"]:
     out["calibration"] = {"kernel": "lg_transpose_pad", "true_read_bytes": 129 * 400 * 400 * 8,
                           "FETCH_SIZE_x1024": d["fetch_KB_raw"] * 1024,
                           "ratio": 129 * 400 * 400 * 8 / (d["fetch_KB_raw"] * 1024)}
-# the fused trainers run `steps` epochs per launch: divide by the epoch count of the PMC runs (3)
-for k in list(out["bytes_per_launch"]):
-    if k.startswith("small_train_kernel"):
-        out["bytes_per_launch"][k + ":per_epoch"] = out["bytes_per_launch"][k] / 3.0
+# per-epoch / per-pass totals of the workloads whose step is more than one launch
+bpl = out["bytes_per_launch"]
+if "small_train_kernel:siterm" in bpl:   # one launch runs all epochs of the PMC run (3)
+    bpl["epoch:siterm"] = bpl["small_train_kernel:siterm"] / 3.0
+if all(f"{k}:lg20" in bpl for k in ("lg_prepare", "lg_bank", "lg_finish")):   # 3 launches per epoch
+    bpl["epoch:lg20"] = sum(bpl[f"{k}:lg20"] for k in ("lg_prepare", "lg_bank", "lg_finish"))
+if all(f"{k}:counting" in bpl for k in ("count_transitions_lds_kernel", "count_reduce_slabs")):
+    bpl["pass:counting"] = bpl["count_transitions_lds_kernel:counting"] + bpl["count_reduce_slabs:counting"]
 json.dump(out, open(f"{here}/pmc_traffic.json", "w"), indent=1)
 d = f"{root}/gpurun_out/{tag}_bench_default.log"
 if os.path.exists(d):
