@@ -215,24 +215,22 @@ def main():
         rng = np.random.default_rng(0)
         wl = make_workload(workload, args.sites, rng)
         S = wl["S"]
-        if wl["kind"] == "single" and S > 32:
-            # ---- co-evolution: torch keeps theta -> Q and Adam, HIP does loss + dL/dQ;
-            #      buckets sharded over the ranks, one all-reduce of S^2 + 1 doubles per epoch
+        if wl["kind"] == "single" and S > 32 and world > 1:
+            # ---- co-evolution on N > 1 GPUs: torch keeps theta -> Q and Adam (the collective is
+            #      torch.distributed's), HIP does loss + dL/dQ; buckets sharded over the ranks,
+            #      one all-reduce of S^2 + 1 doubles per epoch
             init = jtt_ipw_from_arrays(wl["t"], wl["C"], wl["mask"])  # pipelines' default init
             module = cherryml_amd.RateMatrix(
                 num_states=S, mode="pande_reversible", mask=torch.tensor(wl["mask"]),
                 pi=torch.ones(S, dtype=torch.float64) / S, pi_requires_grad=True,
                 initialization=init).to(dev)
-            if world == 1:
-                sharded = ShardedBank(wl["t"], wl["C"])
-            else:
-                # families are sharded (weak scaling: every GPU brings the sufficient statistics of
-                # its own 1,057,194 cherry x contact pairs -- its own draw of the synthetic bank);
-                # ONE reduce-scatter over the buckets sums them and leaves each rank with the
-                # buckets it owns; then per epoch one all-reduce of S^2 + 1 doubles
-                own = make_workload(workload, args.sites, np.random.default_rng(1000 + rank))
-                sharded = ShardedBank.from_rank_counts(wl["t"], torch.tensor(own["C"], device=dev))
-                del own
+            # families are sharded (weak scaling: every GPU brings the sufficient statistics of
+            # its own 1,057,194 cherry x contact pairs -- its own draw of the synthetic bank);
+            # ONE reduce-scatter over the buckets sums them and leaves each rank with the
+            # buckets it owns; then per epoch one all-reduce of S^2 + 1 doubles
+            own = make_workload(workload, args.sites, np.random.default_rng(1000 + rank))
+            sharded = ShardedBank.from_rank_counts(wl["t"], torch.tensor(own["C"], device=dev))
+            del own
             bank = sharded.bank
             opt = torch.optim.Adam(module.parameters(), lr=0.1)
             n_pairs_total, scaling = sharded.total_count, "weak"
@@ -262,14 +260,16 @@ def main():
             final_loss = float(last.item())
             kernel_ms = None
         else:
-            # ---- S <= 32: launch-latency bound, so the WHOLE epoch loop is one kernel
-            #      (cb_train_pande_reversible / cb_train_siterm): K steps = K epochs of it.
+            # ---- the WHOLE epoch loop on the device (cb_train_pande_reversible /
+            #      cb_train_siterm): K steps = K epochs of it, no torch in the loop.
+            #      co-evolution on one GPU: C-driven kernel sequence (train_large.hip.h);
             #      LG: one 0.4 MB bank does not shard -> N independent replicas;
             #      SiteRM: every rank owns its own `--sites` sites (no collective).
             bank = cherryml_amd.CherryBank(wl["t"], wl["C"], device=local_rank)
             n_pairs_total, scaling = wl["n_pairs"] * world, "weak"
             B_local = wl["C"].shape[-3]
-            glue = "whole loop fused in one HIP kernel (theta->Q, eigh, bank, grads, Adam)"
+            glue = ("whole loop on the device, driven from C (theta->A, eigh, bank, grads, Adam in HIP)" if S > 32
+                    else "whole loop fused in one HIP kernel (theta->Q, eigh, bank, grads, Adam)")
             if wl["kind"] == "single":
                 init = jtt_ipw_from_arrays(wl["t"], wl["C"], wl["mask"])
                 mod = cherryml_amd.RateMatrix(
@@ -293,9 +293,13 @@ def main():
             r = call(steps)
             fence()
             dt = time.perf_counter() - t0
-            kernel_ms = bank.last_timings()["small"]
+            if S > 32:
+                tm = bank.timing_means()
+                kernel_ms = None
+            else:
+                kernel_ms = bank.last_timings()["small"]
+                tm = {"small": kernel_ms / steps, "calls": 1}
             bank.profile(False)
-            tm = {"small": kernel_ms / steps, "calls": 1}
             final_loss = float(np.sum(r["loss"][-1]) if "loss" in r
                                else np.sum(r["loss_per_epoch_per_site"][-1]))
         if world > 1:
@@ -344,7 +348,7 @@ def main():
         bank.close()
         return out
 
-    defaults = {"coevo400": (10, 2), "lg20": (500, 50), "siterm": (5, 1), "counting": (20, 3)}
+    defaults = {"coevo400": (50, 5), "lg20": (500, 50), "siterm": (5, 1), "counting": (20, 3)}
     steps = args.steps if args.steps is not None else defaults[args.workload][0]
     warmup = args.warmup if args.warmup is not None else defaults[args.workload][1]
     if args.workload == "counting":

@@ -171,7 +171,7 @@ class CherryBank:
                    "cb_eigh")
         return lam, U
 
-    # -- fused device-side optimisers (S <= 32) --------------------------------
+    # -- fused device-side optimisers (pande_reversible: any S; SiteRM: S <= 32) -----
     def train_pande_reversible(self, upper_diag, log_pi, mask=None, num_epochs=2000, lr=0.1,
                                do_adam=True, normalize=True):
         """All epochs of the reference loop (trainer.py:156-218) in one kernel launch.

@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -18,6 +19,7 @@
 #include "large_bank.hip.h"
 #include "small_bank.hip.h"
 #include "train_small.hip.h"
+#include "train_large.hip.h"
 #include "general_small.hip.h"
 #include "counting.hip.h"
 
@@ -77,6 +79,13 @@ struct cb_bank {
   double *gn_scratch = nullptr, *gn_partial = nullptr;  // general path, allocated on first use
   int gn_nw = 0;
   bool have_prev = false;  // h->U / h->Vc hold the eigenvectors of the previous solve
+  // trainer workspaces, kept between calls (hipMalloc / hipFree cost milliseconds each)
+  double *ws_ptr[16] = {};
+  size_t ws_cap[16] = {};
+  // pinned staging for the trainers' parameter / result transfers: hipMemcpyAsync straight from
+  // fresh pageable user arrays re-pins pages and was measured at ~20 ms per call
+  char *pin = nullptr;
+  size_t pin_cap = 0, pin_off = 0;
   // profiling
   bool profile = false;
   hipEvent_t ev[CB_T_COUNT + 1] = {};
@@ -112,6 +121,62 @@ static int dev_alloc(cb_bank *h, T **p, size_t count) {
     int rc_ = dev_alloc(h, &(ptr), (count));      \
     if (rc_ != CB_OK) return rc_;                 \
   } while (0)
+
+// workspace slot `slot` with room for `n` doubles (grown on demand -- generously, because a
+// hipFree + hipMalloc pair stalls the next call by ~13 ms -- and freed with the handle)
+static bool ws_get(cb_bank *h, int slot, size_t n, double **out) {
+  if (n == 0) n = 1;
+  if (h->ws_cap[slot] < n) {
+    size_t want = 4096;
+    while (want < n) want *= 2;
+    if (want * sizeof(double) <= (size_t)256 << 20) n = want;
+    if (h->ws_ptr[slot]) {
+      (void)hipStreamSynchronize(h->stream);
+      (void)hipFree(h->ws_ptr[slot]);
+      h->ws_ptr[slot] = nullptr;
+      h->ws_cap[slot] = 0;
+    }
+    void *q = nullptr;
+    if (hipMalloc(&q, n * sizeof(double) + 64) != hipSuccess) return false;
+    h->ws_ptr[slot] = static_cast<double *>(q);
+    h->ws_cap[slot] = n;
+  }
+  *out = h->ws_ptr[slot];
+  return true;
+}
+
+static bool pin_reserve(cb_bank *h, size_t bytes) {
+  h->pin_off = 0;
+  if (h->pin_cap >= bytes) return true;
+  if (h->pin) {
+    (void)hipStreamSynchronize(h->stream);
+    (void)hipHostFree(h->pin);
+    h->pin = nullptr;
+    h->pin_cap = 0;
+  }
+  size_t want = (size_t)1 << 20;
+  while (want < bytes) want *= 2;
+  void *q = nullptr;
+  if (hipHostMalloc(&q, want, hipHostMallocDefault) != hipSuccess) return false;
+  h->pin = static_cast<char *>(q);
+  h->pin_cap = want;
+  return true;
+}
+// host -> device through the staging buffer (asynchronous; the slice stays reserved until the
+// next pin_reserve)
+static hipError_t h2d_staged(cb_bank *h, void *dst, const void *src, size_t bytes) {
+  char *slice = h->pin + h->pin_off;
+  h->pin_off += (bytes + 63) & ~(size_t)63;
+  memcpy(slice, src, bytes);
+  return hipMemcpyAsync(dst, slice, bytes, hipMemcpyHostToDevice, h->stream);
+}
+// device -> staging slice (asynchronous); *slice_out is valid after the stream is synchronised
+static hipError_t d2h_staged(cb_bank *h, const void *src, size_t bytes, char **slice_out) {
+  char *slice = h->pin + h->pin_off;
+  h->pin_off += (bytes + 63) & ~(size_t)63;
+  *slice_out = slice;
+  return hipMemcpyAsync(slice, src, bytes, hipMemcpyDeviceToHost, h->stream);
+}
 
 extern "C" int cb_version(void) { return CB_ABI_VERSION; }
 extern "C" const char *cb_last_error(void) { return g_err.c_str(); }
@@ -397,6 +462,9 @@ extern "C" void cb_destroy(cb_handle h) {
   for (hipEvent_t e : h->ev)
     if (e) (void)hipEventDestroy(e);
   for (void *p : h->allocs) (void)hipFree(p);
+  for (double *p : h->ws_ptr)
+    if (p) (void)hipFree(p);
+  if (h->pin) (void)hipHostFree(h->pin);
   if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
   delete h;
 }
@@ -538,14 +606,14 @@ static int large_eigh(cb_bank *h, bool warm) {
   return CB_OK;
 }
 
-static int large_loss_grad(cb_bank *h, const double *Qd, const double *pid, bool normalize,
-                           double *lossd, double *dQd, double *Pd) {
+// h->A (padded, symmetric) and h->dsq are filled.  Output: dQ (S x S, dQ = D^1/2 dA D^-1/2) when
+// `dA_padded` is false, else dL/dA itself as a padded LD x LD matrix.
+static int large_eval(cb_bank *h, bool normalize, double *lossd, double *out, bool dA_padded, double *Pd) {
   const int S = h->S, LD = h->LD;
   const int B = Pd ? h->B : h->Bl;                 // the loss visits live buckets only
   const double *tb = Pd ? h->t : h->t_live;
   const size_t LL = (size_t)LD * LD;
-  hipLaunchKernelGGL(lg_build_A, dim3((unsigned)((LL + 255) / 256)), dim3(256), 0, h->stream, S, LD,
-                     Qd, pid, h->A, h->dsq);
+  double *dQd = out;
   int rc = large_eigh(h, true);
   if (rc != CB_OK) return rc;
   mark(h, EV_EIGH);
@@ -574,12 +642,20 @@ static int large_loss_grad(cb_bank *h, const double *Qd, const double *pid, bool
                        h->Gt, B, LL, h->Mt);
     K4Args k4a{S, LD, h->Mt, h->Vc, h->X, nullptr, nullptr, nullptr};
     hipLaunchKernelGGL(k4_gemm, dim3(tiles), dim3(LG_THREADS), 0, h->stream, k4a);
-    K4Args k4b{S, LD, h->Vc, h->X, dQd, h->dsq, nullptr, nullptr};
+    K4Args k4b{S, LD, h->Vc, h->X, dQd, dA_padded ? nullptr : h->dsq, nullptr, nullptr};
     hipLaunchKernelGGL(k4_gemm, dim3(tiles), dim3(LG_THREADS), 0, h->stream, k4b);
     mark(h, EV_K4);
   }
   HIP_TRY(hipGetLastError());
   return CB_OK;
+}
+
+static int large_loss_grad(cb_bank *h, const double *Qd, const double *pid, bool normalize,
+                           double *lossd, double *dQd, double *Pd) {
+  const size_t LL = (size_t)h->LD * h->LD;
+  hipLaunchKernelGGL(lg_build_A, dim3((unsigned)((LL + 255) / 256)), dim3(256), 0, h->stream, h->S, h->LD,
+                     Qd, pid, h->A, h->dsq);
+  return large_eval(h, normalize, lossd, dQd, false, Pd);
 }
 
 // ---------------------------------------------------------------- entry points
@@ -826,32 +902,127 @@ static int launch_train_nw(cb_bank *h, const TrainArgs &a) {
   return CB_OK;
 }
 
+// S > 32 (one bank, pande_reversible): the epoch loop driven from here, kernels of train_large.hip.h
+static int run_fused_training_large(cb_bank *h, double *pi_param, double *up_param, const double *mask, int E,
+                                    double lr, int do_adam, int flags, double *loss_curve, double *Q_best,
+                                    double *Q_last, double *Q_pow2, int n_pow2) {
+  HIP_TRY(hipSetDevice(h->dev));
+  const bool dbg = getenv("CB_DEBUG") != nullptr;
+  auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  const double t_enter = now();
+  const int S = h->S, LD = h->LD;
+  const size_t SS = (size_t)S * S, nup = (size_t)S * (S - 1) / 2;
+  int slot = 0;
+  auto alloc = [&](double **p, size_t n) -> bool { return ws_get(h, slot++, n, p); };
+  auto release = [&]() { (void)hipStreamSynchronize(h->stream); };
+  double *d_pi = nullptr, *d_up = nullptr, *d_mom = nullptr, *d_mask = nullptr, *d_loss = nullptr, *d_Qb = nullptr,
+         *d_Ql = nullptr, *d_Qp = nullptr, *d_vec = nullptr;
+  const size_t nmom = 2 * (S + nup);
+  bool ok = alloc(&d_pi, S) && alloc(&d_up, nup) && alloc(&d_mom, nmom) && alloc(&d_loss, E) && alloc(&d_Qb, SS) &&
+            alloc(&d_Ql, SS) && (!mask || alloc(&d_mask, SS)) && (!(Q_pow2 && n_pow2 > 0) || alloc(&d_Qp, std::max<size_t>(n_pow2, 16) * SS)) &&
+            alloc(&d_vec, (size_t)LD + S + 8);
+  if (!ok) {
+    release();
+    return fail(CB_ENOMEM, "fused training: device allocation failed");
+  }
+  if (dbg) fprintf(stderr, "[cherrybank] large trainer: workspaces ready after %.2f ms\n", now() - t_enter);
+  int rc = CB_OK;
+#define TRYH(expr) \
+  if (rc == CB_OK && (expr) != hipSuccess) rc = fail(CB_EHIP, "%s failed", #expr)
+  {
+    const size_t up_bytes = (S + nup + SS + 64) * sizeof(double);
+    const size_t down_bytes = (S + nup + (size_t)E + (2 + (size_t)(d_Qp ? n_pow2 : 0)) * SS + 64) * sizeof(double);
+    if (!pin_reserve(h, std::max(up_bytes, down_bytes) + 1024)) {
+      release();
+      return fail(CB_ENOMEM, "fused training: pinned staging allocation failed");
+    }
+  }
+  TRYH(h2d_staged(h, d_pi, pi_param, S * sizeof(double)));
+  TRYH(h2d_staged(h, d_up, up_param, nup * sizeof(double)));
+  TRYH(hipMemsetAsync(d_mom, 0, nmom * sizeof(double), h->stream));
+  TRYH(hipMemsetAsync(d_Qb, 0, SS * sizeof(double), h->stream));
+  TRYH(hipMemsetAsync(d_Ql, 0, SS * sizeof(double), h->stream));
+  if (mask) TRYH(h2d_staged(h, d_mask, mask, SS * sizeof(double)));
+  const double init_state[2] = {INFINITY, 0.0};
+  LargeTrain a{};
+  a.S = S; a.LD = LD; a.do_adam = do_adam; a.n_pow2 = d_Qp ? n_pow2 : 0;
+  a.p_pi = d_pi; a.p_up = d_up;
+  a.m_pi = d_mom; a.v_pi = d_mom + S; a.m_up = d_mom + 2 * (size_t)S; a.v_up = a.m_up + nup;
+  a.mask = d_mask; a.lr = lr; a.beta1 = 0.9; a.beta2 = 0.999; a.eps = 1e-8;
+  a.pi = d_vec; a.gd = d_vec + LD; a.state = d_vec + LD + S;
+  a.dsq = h->dsq; a.A = h->A; a.G = h->Mt; a.loss = h->loss; a.dirsum = h->dirsum;
+  a.inv_n = (flags & CB_NORMALIZE) ? 1.0 / h->n_host[0] : 1.0;
+  a.loss_curve = d_loss; a.Q_last = d_Ql; a.Q_best = d_Qb; a.Q_pow2 = d_Qp;
+  if (dbg) fprintf(stderr, "[cherrybank] large trainer: copies enqueued after %.2f ms\n", now() - t_enter);
+  TRYH(h2d_staged(h, a.state, init_state, sizeof init_state));
+  TRYH(hipStreamSynchronize(h->stream));  // init_state is on this stack frame
+  if (dbg) fprintf(stderr, "[cherrybank] large trainer: synced after %.2f ms\n", now() - t_enter);
+  if (h->profile) fold_pending(h);
+  if (dbg) fprintf(stderr, "[cherrybank] large trainer: parameters uploaded after %.2f ms\n", now() - t_enter);
+  double pow_b1 = 1.0, pow_b2 = 1.0;
+  for (int e = 0; e < E && rc == CB_OK; ++e) {
+    if (h->profile) fold_pending(h);  // the previous epoch's phase events, before they are re-recorded
+    for (bool &b : h->ev_rec) b = false;
+    hipLaunchKernelGGL(lt_pi, dim3(1), dim3(256), 0, h->stream, a);
+    hipLaunchKernelGGL(lt_build, dim3(LD), dim3(256), 0, h->stream, a, e);
+    mark(h, EV_START);
+    rc = large_eval(h, flags & CB_NORMALIZE, h->loss, h->Mt, true, nullptr);
+    if (rc != CB_OK) break;
+    if (h->profile) h->t_pending = true;
+    pow_b1 *= a.beta1;
+    pow_b2 *= a.beta2;
+    hipLaunchKernelGGL(lt_gd, dim3((S + 3) / 4), dim3(256), 0, h->stream, a);
+    hipLaunchKernelGGL(lt_step_pi, dim3(1), dim3(256), 0, h->stream, a, e, 1.0 - pow_b1, std::sqrt(1.0 - pow_b2));
+    hipLaunchKernelGGL(lt_step_up, dim3(S), dim3(256), 0, h->stream, a, 1.0 - pow_b1, std::sqrt(1.0 - pow_b2));
+    if (hipGetLastError() != hipSuccess) rc = fail(CB_EHIP, "fused training launch failed");
+  }
+  TRYH(hipStreamSynchronize(h->stream));
+  h->pin_off = 0;  // uploads are consumed
+  char *s_pi = nullptr, *s_up = nullptr, *s_loss = nullptr, *s_Qb = nullptr, *s_Ql = nullptr, *s_Qp = nullptr;
+  TRYH(d2h_staged(h, d_pi, S * sizeof(double), &s_pi));
+  TRYH(d2h_staged(h, d_up, nup * sizeof(double), &s_up));
+  if (loss_curve && E > 0) TRYH(d2h_staged(h, d_loss, (size_t)E * sizeof(double), &s_loss));
+  if (Q_best) TRYH(d2h_staged(h, d_Qb, SS * sizeof(double), &s_Qb));
+  if (Q_last) TRYH(d2h_staged(h, d_Ql, SS * sizeof(double), &s_Ql));
+  if (d_Qp) TRYH(d2h_staged(h, d_Qp, n_pow2 * SS * sizeof(double), &s_Qp));
+  TRYH(hipStreamSynchronize(h->stream));
+  if (rc == CB_OK) {
+    memcpy(pi_param, s_pi, S * sizeof(double));
+    memcpy(up_param, s_up, nup * sizeof(double));
+    if (s_loss) memcpy(loss_curve, s_loss, (size_t)E * sizeof(double));
+    if (s_Qb) memcpy(Q_best, s_Qb, SS * sizeof(double));
+    if (s_Ql) memcpy(Q_last, s_Ql, SS * sizeof(double));
+    if (s_Qp) memcpy(Q_pow2, s_Qp, n_pow2 * SS * sizeof(double));
+  }
+#undef TRYH
+  release();
+  if (dbg) fprintf(stderr, "[cherrybank] large trainer: %d epochs done after %.2f ms\n", E, now() - t_enter);
+  return rc;
+}
+
 // shared host driver: parameters in, E epochs on the device, results out
 static int run_fused_training(cb_bank *h, int kind, double *pi_param, double *up_param,
                               const double *mask, int E, double lr, int do_adam, int flags,
                               double *loss_curve, double *Q_best, double *Q_last, double *Q_pow2,
                               int n_pow2) {
-  if (h->large) return fail(CB_EUNSUPPORTED, "fused training: S <= 32 only (S = %d)", h->S);
   if (E < 0) return fail(CB_EINVAL, "fused training: num_epochs < 0");
+  if (h->large) {
+    if (kind != 0) return fail(CB_EUNSUPPORTED, "fused SiteRM training: S <= 32 only (S = %d)", h->S);
+    return run_fused_training_large(h, pi_param, up_param, mask, E, lr, do_adam, flags, loss_curve, Q_best, Q_last,
+                                    Q_pow2, n_pow2);
+  }
   HIP_TRY(hipSetDevice(h->dev));
   const int S = h->S, L = h->L;
   const size_t SS = (size_t)S * S, nup = kind == 0 ? (size_t)S * (S - 1) / 2 : SS;
   double *d_pi = nullptr, *d_up = nullptr, *d_mom = nullptr, *d_mask = nullptr, *d_loss = nullptr,
          *d_Qb = nullptr, *d_Ql = nullptr, *d_Qp = nullptr;
-  std::vector<void *> tmp;
-  auto alloc = [&](double **p, size_t n) -> bool {
-    if (hipMalloc((void **)p, (n ? n : 1) * sizeof(double)) != hipSuccess) return false;
-    tmp.push_back(*p);
-    return true;
-  };
-  auto release = [&]() {
-    (void)hipStreamSynchronize(h->stream);
-    for (void *p : tmp) (void)hipFree(p);
-  };
+  int slot = 0;
+  auto alloc = [&](double **p, size_t n) -> bool { return ws_get(h, slot++, n, p); };
+  auto release = [&]() { (void)hipStreamSynchronize(h->stream); };
   const size_t nmom = 2 * ((size_t)L * S + (size_t)L * nup);
   bool ok = alloc(&d_pi, (size_t)L * S) && alloc(&d_up, L * nup) && alloc(&d_mom, nmom) &&
             alloc(&d_loss, (size_t)E * L) && alloc(&d_Qb, L * SS) && alloc(&d_Ql, L * SS) &&
-            (!mask || alloc(&d_mask, SS)) && (!(Q_pow2 && n_pow2 > 0) || alloc(&d_Qp, n_pow2 * SS));
+            (!mask || alloc(&d_mask, SS)) && (!(Q_pow2 && n_pow2 > 0) || alloc(&d_Qp, std::max<size_t>(n_pow2, 16) * SS));
   if (!ok) {
     release();
     return fail(CB_ENOMEM, "fused training: device allocation failed");
@@ -859,12 +1030,20 @@ static int run_fused_training(cb_bank *h, int kind, double *pi_param, double *up
   int rc = CB_OK;
 #define TRYH(expr)                                                                  \
   if (rc == CB_OK && (expr) != hipSuccess) rc = fail(CB_EHIP, "%s failed", #expr)
-  TRYH(hipMemcpyAsync(d_pi, pi_param, (size_t)L * S * sizeof(double), hipMemcpyHostToDevice, h->stream));
-  TRYH(hipMemcpyAsync(d_up, up_param, L * nup * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  {
+    const size_t up_bytes = ((size_t)L * S + L * nup + SS + 64) * sizeof(double);
+    const size_t down_bytes = ((size_t)L * S + L * nup + (size_t)E * L + 2 * L * SS + (size_t)(d_Qp ? n_pow2 : 0) * SS + 64) * sizeof(double);
+    if (!pin_reserve(h, std::max(up_bytes, down_bytes) + 1024)) {
+      release();
+      return fail(CB_ENOMEM, "fused training: pinned staging allocation failed");
+    }
+  }
+  TRYH(h2d_staged(h, d_pi, pi_param, (size_t)L * S * sizeof(double)));
+  TRYH(h2d_staged(h, d_up, up_param, L * nup * sizeof(double)));
   TRYH(hipMemsetAsync(d_mom, 0, nmom * sizeof(double), h->stream));
   TRYH(hipMemsetAsync(d_Qb, 0, L * SS * sizeof(double), h->stream));
   TRYH(hipMemsetAsync(d_Ql, 0, L * SS * sizeof(double), h->stream));
-  if (mask) TRYH(hipMemcpyAsync(d_mask, mask, SS * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  if (mask) TRYH(h2d_staged(h, d_mask, mask, SS * sizeof(double)));
   if (rc == CB_OK) {
     TrainArgs a{};
     a.S = S; a.L = L; a.B = h->Bl; a.E = E; a.kind = kind; a.do_adam = do_adam; a.n_pow2 = d_Qp ? n_pow2 : 0;
@@ -919,14 +1098,24 @@ static int run_fused_training(cb_bank *h, int kind, double *pi_param, double *up
     }
     mark(h, EV_SMALL);  // cb_last_timings(): CB_T_SMALL = all E epochs
   }
-  TRYH(hipMemcpyAsync(pi_param, d_pi, (size_t)L * S * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-  TRYH(hipMemcpyAsync(up_param, d_up, L * nup * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-  if (loss_curve && E > 0)
-    TRYH(hipMemcpyAsync(loss_curve, d_loss, (size_t)E * L * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-  if (Q_best) TRYH(hipMemcpyAsync(Q_best, d_Qb, L * SS * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-  if (Q_last) TRYH(hipMemcpyAsync(Q_last, d_Ql, L * SS * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-  if (d_Qp) TRYH(hipMemcpyAsync(Q_pow2, d_Qp, n_pow2 * SS * sizeof(double), hipMemcpyDeviceToHost, h->stream));
   TRYH(hipStreamSynchronize(h->stream));
+  h->pin_off = 0;  // uploads are consumed
+  char *s_pi = nullptr, *s_up = nullptr, *s_loss = nullptr, *s_Qb = nullptr, *s_Ql = nullptr, *s_Qp = nullptr;
+  TRYH(d2h_staged(h, d_pi, (size_t)L * S * sizeof(double), &s_pi));
+  TRYH(d2h_staged(h, d_up, L * nup * sizeof(double), &s_up));
+  if (loss_curve && E > 0) TRYH(d2h_staged(h, d_loss, (size_t)E * L * sizeof(double), &s_loss));
+  if (Q_best) TRYH(d2h_staged(h, d_Qb, L * SS * sizeof(double), &s_Qb));
+  if (Q_last) TRYH(d2h_staged(h, d_Ql, L * SS * sizeof(double), &s_Ql));
+  if (d_Qp) TRYH(d2h_staged(h, d_Qp, n_pow2 * SS * sizeof(double), &s_Qp));
+  TRYH(hipStreamSynchronize(h->stream));
+  if (rc == CB_OK) {
+    memcpy(pi_param, s_pi, (size_t)L * S * sizeof(double));
+    memcpy(up_param, s_up, L * nup * sizeof(double));
+    if (s_loss) memcpy(loss_curve, s_loss, (size_t)E * L * sizeof(double));
+    if (s_Qb) memcpy(Q_best, s_Qb, L * SS * sizeof(double));
+    if (s_Ql) memcpy(Q_last, s_Ql, L * SS * sizeof(double));
+    if (s_Qp) memcpy(Q_pow2, s_Qp, n_pow2 * SS * sizeof(double));
+  }
   if (rc == CB_OK) {
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) rc = fail(CB_EHIP, "fused training kernel failed: %s", hipGetErrorString(e));

@@ -1,0 +1,159 @@
+// Fused optimiser for large state spaces (S > 32, one bank): the reference's whole epoch loop
+// (trainer.py:156-218 with rate.py:167-188, "pande_reversible") driven from C, no torch in the
+// loop.  Same closed-form chain rule as train_small.hip.h, spread over the chip:
+//
+//   lt_pi        pi = softmax(log_pi), d = sqrt(pi)                          1 workgroup
+//   lt_build     A (padded, symmetric) straight from the parameters,
+//                Q of this epoch -> Q_last (+ power-of-two snapshot)        1 workgroup per row
+//   eigh, K1..K4 loss and G = dL/dA                                          (large_bank.hip.h)
+//   lt_gd        dL/d log d_k (one wave per k)
+//   lt_step_pi   loss curve, best-iterate flag, Adam / SGD on log_pi         1 workgroup
+//   lt_step_up   Adam / SGD on the S(S-1)/2 upper-diagonal logits,
+//                Q_best <- Q_last when this epoch improved                   1 workgroup per row
+//
+//   A_ij = R_ij = softplus(up_k) mask_ij,  A_ii = -sum_j R_ij d_j / d_i,  Q_ij = R_ij d_j / d_i
+//   dR_ij = mask_ij (G_ij - G_ii d_j / d_i);  dup_k = sigmoid(up_k) (dR_ij + dR_ji)
+//   dld_k = -d_k sum_{i != k} G_ii A_ik / d_i - G_kk A_kk - (colsum_k - rowsum_k) / n
+//   dlogpi_k = (dld_k - pi_k sum_m dld_m) / 2
+#pragma once
+#include "train_small.hip.h"
+
+struct LargeTrain {
+  int S, LD, do_adam, n_pow2;
+  double *p_pi, *p_up;                  // [S], [S(S-1)/2]
+  double *m_pi, *v_pi, *m_up, *v_up;    // Adam moments
+  const double *mask;                   // [S][S] or null
+  double lr, beta1, beta2, eps;
+  double *pi, *dsq;                     // [LD]: softmax, its square root (pad: 0 / 1)
+  double *A;                            // [LD][LD]
+  const double *G;                      // [LD][LD] dL/dA of this epoch
+  const double *loss;                   // device scalar: loss of this epoch
+  const double *dirsum;                 // [S]
+  double inv_n;
+  double *gd;                           // [S] scratch: dL/d log d
+  double *state;                        // [0] best loss so far, [1] improved flag of this epoch
+  double *loss_curve;                   // [E]
+  double *Q_last, *Q_best, *Q_pow2;     // [S][S], [S][S], [n_pow2][S][S]
+};
+
+__device__ __forceinline__ double lt_block_sum(double v, double *s) {  // 256 threads, fixed order
+  s[threadIdx.x] = v;
+  __syncthreads();
+  for (int st = 128; st >= 1; st >>= 1) {
+    if ((int)threadIdx.x < st) s[threadIdx.x] += s[threadIdx.x + st];
+    __syncthreads();
+  }
+  const double r = s[0];
+  __syncthreads();
+  return r;
+}
+
+__global__ __launch_bounds__(256) void lt_pi(LargeTrain a) {
+  __shared__ double s[256];
+  const int S = a.S;
+  double mx = -INFINITY;
+  for (int k = threadIdx.x; k < S; k += 256) mx = fmax(mx, a.p_pi[k]);
+  s[threadIdx.x] = mx;
+  __syncthreads();
+  for (int st = 128; st >= 1; st >>= 1) {
+    if ((int)threadIdx.x < st) s[threadIdx.x] = fmax(s[threadIdx.x], s[threadIdx.x + st]);
+    __syncthreads();
+  }
+  mx = s[0];
+  __syncthreads();
+  double acc = 0.0;
+  for (int k = threadIdx.x; k < S; k += 256) acc += exp(a.p_pi[k] - mx);
+  const double sum = lt_block_sum(acc, s);
+  for (int k = threadIdx.x; k < a.LD; k += 256) {
+    const double p = k < S ? exp(a.p_pi[k] - mx) / sum : 0.0;
+    a.pi[k] = p;
+    a.dsq[k] = k < S ? sqrt(p) : 1.0;
+  }
+}
+
+__global__ __launch_bounds__(256) void lt_build(LargeTrain a, int epoch) {
+  __shared__ double s[256];
+  const int S = a.S, LD = a.LD, i = blockIdx.x;
+  double *Arow = a.A + (size_t)i * LD;
+  if (i >= S) {
+    for (int j = threadIdx.x; j < LD; j += 256) Arow[j] = 0.0;
+    return;
+  }
+  const bool pow2 = a.Q_pow2 && ((epoch & (epoch + 1)) == 0);  // epochs 1, 2, 4, ... (1-based)
+  int pidx = 0;
+  for (int e1 = epoch + 1; e1 > 1; e1 >>= 1) ++pidx;
+  double *Qp = (pow2 && pidx < a.n_pow2) ? a.Q_pow2 + (size_t)pidx * S * S + (size_t)i * S : nullptr;
+  double *Ql = a.Q_last + (size_t)i * S;
+  const double di = a.dsq[i], inv_di = 1.0 / di;
+  double acc = 0.0;
+  for (int j = threadIdx.x; j < LD; j += 256) {
+    double r = 0.0;
+    if (j < S && j != i) {
+      const int lo_ = min(i, j), hi_ = max(i, j);
+      const size_t k = (size_t)lo_ * S - (size_t)lo_ * (lo_ + 1) / 2 + (hi_ - lo_ - 1);
+      r = softplus_t(a.p_up[k]) * (a.mask ? a.mask[(size_t)i * S + j] : 1.0);
+      const double rd = r * a.dsq[j];
+      acc += rd;
+      const double q = rd * inv_di;
+      Ql[j] = q;
+      if (Qp) Qp[j] = q;
+    }
+    if (j != i) Arow[j] = r;
+  }
+  const double tot = lt_block_sum(acc, s);
+  if (threadIdx.x == 0) {
+    const double aii = -tot * inv_di;
+    Arow[i] = aii;
+    Ql[i] = aii;
+    if (Qp) Qp[i] = aii;
+  }
+}
+
+// one wave per k
+__global__ __launch_bounds__(256) void lt_gd(LargeTrain a) {
+  const int S = a.S, LD = a.LD;
+  const int k = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (k >= S) return;
+  double acc = 0.0;
+  for (int i = lane; i < S; i += 64)
+    if (i != k) acc = fma(a.G[(size_t)i * LD + i] / a.dsq[i], a.A[(size_t)k * LD + i], acc);
+  acc = wave_sum(acc);
+  if (lane == 0)
+    a.gd[k] = -a.dsq[k] * acc - a.G[(size_t)k * LD + k] * a.A[(size_t)k * LD + k] - a.dirsum[k] * a.inv_n;
+}
+
+__global__ __launch_bounds__(256) void lt_step_pi(LargeTrain a, int epoch, double bc1, double bc2s) {
+  __shared__ double s[256];
+  const int S = a.S;
+  if (threadIdx.x == 0) {
+    const double loss = *a.loss;
+    a.loss_curve[epoch] = loss;
+    const bool better = loss < a.state[0];  // strict <, trainer.py:179
+    a.state[1] = better ? 1.0 : 0.0;
+    if (better) a.state[0] = loss;
+  }
+  double acc = 0.0;
+  for (int k = threadIdx.x; k < S; k += 256) acc += a.gd[k];
+  const double tot = lt_block_sum(acc, s);
+  for (int k = threadIdx.x; k < S; k += 256) {
+    const double g = 0.5 * (a.gd[k] - a.pi[k] * tot);
+    adam_update(a.p_pi[k], a.m_pi[k], a.v_pi[k], g, a.lr, a.beta1, a.beta2, a.eps, bc1, bc2s, a.do_adam);
+  }
+}
+
+__global__ __launch_bounds__(256) void lt_step_up(LargeTrain a, double bc1, double bc2s) {
+  const int S = a.S, LD = a.LD, i = blockIdx.x;
+  if (a.state[1] != 0.0)  // this epoch's (pre-step) Q is the best so far
+    for (int j = threadIdx.x; j < S; j += 256) a.Q_best[(size_t)i * S + j] = a.Q_last[(size_t)i * S + j];
+  const double di = a.dsq[i], gii = a.G[(size_t)i * LD + i];
+  const size_t kbase = (size_t)i * S - (size_t)i * (i + 1) / 2;
+  for (int j = i + 1 + threadIdx.x; j < S; j += 256) {
+    const size_t k = kbase + (j - i - 1);
+    const double mk = a.mask ? a.mask[(size_t)i * S + j] : 1.0;
+    const double dj = a.dsq[j];
+    const double dR_ab = mk * (a.G[(size_t)i * LD + j] - gii * dj / di);
+    const double dR_ba = mk * (a.G[(size_t)j * LD + i] - a.G[(size_t)j * LD + j] * di / dj);
+    const double g = sigmoid_t(a.p_up[k]) * (dR_ab + dR_ba);
+    adam_update(a.p_up[k], a.m_up[k], a.v_up[k], g, a.lr, a.beta1, a.beta2, a.eps, bc1, bc2s, a.do_adam);
+  }
+}

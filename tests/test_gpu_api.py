@@ -115,7 +115,10 @@ def test_random_init_symmetric_mask_20_states():
     assert relerr(learner.Q_dict["Q_best"], g["Q_best_f64"]) < 1e-6
 
 
-def test_coevolution_400_states_three_epochs():
+@pytest.mark.parametrize("fused", [True, False])
+def test_coevolution_400_states_three_epochs(fused):
+    """fused=True: the C-driven device loop (train_large.hip.h); False: torch glue + cb_loss_grad.
+    Both against the reference's own f64 trajectory."""
     from cherryml_amd import RateMatrix, train_quantization
     from torch.utils.data import TensorDataset
     e = load_golden("eval_s400_mask.npz")
@@ -128,10 +131,38 @@ def test_coevolution_400_states_three_epochs():
     mod = mod.to("cuda")
     opt = torch.optim.Adam(mod.parameters(), lr=0.1)
     ds = TensorDataset(torch.tensor(e["t"]), torch.tensor(e["C"]))
-    df, Qd = train_quantization(mod, ds, num_epochs=3, optimizer=opt, loss_normalization=True)
+    df, Qd = train_quantization(mod, ds, num_epochs=3, optimizer=opt, loss_normalization=True, fused=fused)
     assert np.allclose(df.loss.to_numpy(), g["loss_f64"], rtol=1e-10, atol=0)
     assert relerr(Qd["Q_best"], g["Q_best_f64"]) < 1e-8
     assert relerr(Qd["Q_last"], g["Q_last_f64"]) < 1e-8
+    assert set(Qd) >= {"Q_1", "Q_2", "Q_best", "Q_last"}
+
+
+def test_fused_large_trainer_matches_torch_glue_over_40_epochs():
+    """Odd size (S = 50: padding, partial tiles), empty buckets, a symmetric mask with zeros,
+    40 epochs: C-driven loop vs torch glue of the same package, and vs the oracle."""
+    from cherryml_amd import CherryBank
+    from oracle import ratelearn_oracle as orc
+    rng = np.random.default_rng(5)
+    S, B, E = 50, 9, 40
+    t = np.sort(rng.uniform(0.02, 2.0, size=B))
+    C = rng.poisson(4.0, size=(B, S, S)).astype(np.float64)
+    C[2] = 0.0
+    mask = (rng.random((S, S)) < 0.7).astype(np.float64)
+    mask = np.triu(mask, 1)
+    mask = mask + mask.T
+    C *= (mask + np.eye(S))
+    u0 = rng.normal(0.0, 0.3, size=S * (S - 1) // 2)
+    p0 = rng.normal(0.0, 0.2, size=S)
+    ref = orc.train(t, C, mask, upper_diag=u0, log_pi=p0, num_epochs=E, dtype=torch.float64)
+    with CherryBank(t, C) as bank:
+        r = bank.train_pande_reversible(u0, p0, mask=mask, num_epochs=E, lr=0.1)
+    assert np.allclose(r["loss"], ref["loss"], rtol=1e-9, atol=0)
+    assert relerr(r["Q_best"], ref["Q_best"]) < 1e-6
+    assert relerr(r["Q_last"], ref["Q_last"]) < 1e-6
+    for k, Qk in r["Q_pow2"].items():
+        assert relerr(Qk, ref[f"Q_{k}"]) < 1e-6, k
+    assert np.allclose(r["upper_diag"], ref["upper_diag"], rtol=1e-6, atol=1e-8)
 
 
 def test_siterm_vectorized_matches_reference():
