@@ -70,6 +70,9 @@ struct cb_bank {
   double *Q = nullptr, *pi = nullptr, *loss = nullptr, *dQ = nullptr;
   int *status = nullptr;
   // large-path workspaces
+  double *Gc2 = nullptr, *gx = nullptr;  // second column buffer and 4 LD^2 scratch of the first-order sweep
+  int last_light = 0;
+  int spec_sweeps = 0;  // Jacobi sweeps to enqueue before the first host check (learned from the previous solve)
   double *A = nullptr, *dsq = nullptr, *Gc = nullptr, *Vc = nullptr, *U = nullptr, *lam = nullptr,
          *sigma = nullptr, *F = nullptr, *E = nullptr, *H = nullptr, *Gt = nullptr, *T = nullptr,
          *Mt_part = nullptr, *Mt = nullptr, *X = nullptr, *loss_part = nullptr;
@@ -417,6 +420,7 @@ extern "C" int cb_create(int device, int S, int L, int B, const double *t, const
     bool ok = dev_alloc(h, &h->Ct, (size_t)Bl * LL) == CB_OK && dev_alloc(h, &tot, SS) == CB_OK &&
               dev_alloc(h, &h->A, LL) == CB_OK && dev_alloc(h, &h->dsq, h->LD) == CB_OK &&
               dev_alloc(h, &h->Gc, LL) == CB_OK && dev_alloc(h, &h->Vc, LL) == CB_OK &&
+              dev_alloc(h, &h->Gc2, LL) == CB_OK && dev_alloc(h, &h->gx, 4 * LL) == CB_OK &&
               dev_alloc(h, &h->U, LL) == CB_OK && dev_alloc(h, &h->lam, h->LD) == CB_OK &&
               dev_alloc(h, &h->sigma, 8) == CB_OK && dev_alloc(h, &h->off_bits, 64) == CB_OK &&
               dev_alloc(h, &h->F, (size_t)B * h->LD) == CB_OK &&
@@ -518,6 +522,16 @@ static int launch_small(cb_bank *h, const SmallArgs &a) {
 }
 
 // --------------------------------------------------------------- large path
+static void launch_sg(cb_bank *h, const K4Args &g, int ns) {
+  if (getenv("CB_OLD_K4") && !ns) {
+    const int t = (h->LD + LG_TM - 1) / LG_TM;
+    hipLaunchKernelGGL(k4_gemm, dim3(t * t), dim3(LG_THREADS), 0, h->stream, g);
+    return;
+  }
+  const unsigned nwg = (unsigned)((h->LD / 16) * ((h->LD + 79) / 80));
+  hipLaunchKernelGGL(sg_gemm, dim3(nwg), dim3(256), 0, h->stream, g, ns);
+}
+
 static int large_eigh(cb_bank *h, bool warm) {
   const int LD = h->LD;
   const size_t LL = (size_t)LD * LD;
@@ -528,7 +542,8 @@ static int large_eigh(cb_bank *h, bool warm) {
     // (A changes by one optimiser step, so G0's columns are nearly orthogonal already).
     const int tm = (LD + LG_TM - 1) / LG_TM, tn = (LD + LG_TN - 1) / LG_TN;
     K4Args g0{h->S, LD, h->U, h->A, h->Gc, nullptr, h->Vc, h->sigma};
-    hipLaunchKernelGGL(k4_gemm, dim3(tm * tn), dim3(LG_THREADS), 0, h->stream, g0);
+    (void)tm; (void)tn;
+    launch_sg(h, g0, 0);
   } else {
     hipLaunchKernelGGL(lgj_init, dim3((unsigned)((LL + 255) / 256)), dim3(256), 0, h->stream, LD,
                        h->A, h->sigma, h->Gc);
@@ -565,28 +580,96 @@ static int large_eigh(cb_bank *h, bool warm) {
     // a sweep that STARTS below 1e-8 ends at rounding level (quadratic convergence)
     hipLaunchKernelGGL(lgj_check, dim3(1), dim3(64), 0, h->stream, h->off_bits, 1e-8);
   };
-  // Sweeps are enqueued without waiting for the host: as many as the previous (warm) solve needed
-  // minus one, then one at a time.  Launches after convergence return immediately.
+  // First-order sweep (jacobi_block.hip.h, lgx_*): returns 1 when applied and final (solve
+  // finished), 2 when applied but another one is needed, 0 when its preconditions do not hold
+  // (nothing changed), < 0 on error.
+  auto light_sweep = [&]() -> int {
+    double *Gr = h->gx, *Gam = h->gx + LL, *X = h->gx + 2 * LL, *R = h->gx + 3 * LL;
+    const int nt32 = (LD + 31) / 32;
+    HIP_TRY(hipMemsetAsync(h->off_bits + 4, 0, 2 * sizeof(unsigned long long), h->stream));
+    hipLaunchKernelGGL(lgx_transpose, dim3(nt32, nt32), dim3(32, 8), 0, h->stream, LD, h->Gc, Gr);
+    launch_sg(h, K4Args{h->S, LD, Gr, Gr, Gam, nullptr, nullptr, nullptr}, 0);
+    hipLaunchKernelGGL(lgx_build, dim3(LD), dim3(256), 0, h->stream, LD, Gam, X, h->off_bits);
+    unsigned long long m[2] = {};
+    HIP_TRY(hipMemcpyAsync(m, h->off_bits + 4, sizeof m, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    double cosmax, rowsum;
+    memcpy(&cosmax, &m[0], sizeof cosmax);
+    memcpy(&rowsum, &m[1], sizeof rowsum);
+    if (getenv("CB_DEBUG"))
+      fprintf(stderr, "[cherrybank] eigh first-order sweep: max cosine %.3e, |X| <= %.3e\n", cosmax, rowsum);
+    if (!(cosmax == cosmax) || !(rowsum == rowsum)) return fail(CB_ENUMERIC, "eigensolver: non-finite input");
+    if (rowsum > 2e-3) return 0;
+    if (rowsum <= 1e-5) {
+      launch_sg(h, K4Args{h->S, LD, X, X, R, nullptr, X, nullptr}, 1);      // R = I + X - X^T X / 2
+    } else {
+      double *P2 = Gr, *P3 = Gam;                                            // both free by now
+      launch_sg(h, K4Args{h->S, LD, X, X, P2, nullptr, nullptr, nullptr}, 0);    // X^T X   = -X^2
+      launch_sg(h, K4Args{h->S, LD, X, P2, P3, nullptr, nullptr, nullptr}, 0);   // X^T P2  =  X^3
+      launch_sg(h, K4Args{h->S, LD, P2, P2, R, nullptr, nullptr, nullptr}, 0);   // P2^T P2 =  X^4
+      hipLaunchKernelGGL(lgx_combine, dim3((unsigned)((LL + 255) / 256)), dim3(256), 0, h->stream, LD, X, P2, P3, R);
+    }
+    launch_sg(h, K4Args{h->S, LD, R, h->Gc, h->Gc2, nullptr, nullptr, nullptr}, 0);  // Gc2[c'][r] = sum_c R[c][c'] Gc[c][r]
+    std::swap(h->Gc, h->Gc2);
+    return cosmax <= 1e-8 ? 1 : 2;
+  };
+  // Sweeps are enqueued without waiting for the host: as many as the previous (warm) solve needed,
+  // then one at a time.  Launches after convergence return immediately.  Once a sweep started
+  // below 2e-5 the state is expected below 1e-8 and the first-order sweep is tried.
   int sweep = 0, enq = 0;
   unsigned long long st[64] = {};
+  const bool use_light = !getenv("CB_NO_LIGHT");
+  const double light_trigger = getenv("CB_LIGHT_TRIGGER") ? atof(getenv("CB_LIGHT_TRIGGER")) : 3e-4;
   const bool speculate = warm && h->last_sweeps > 1 && !getenv("CB_NO_SPECULATE");
-  int batch = speculate ? h->last_sweeps - 1 : 1;
+  int batch = speculate ? std::max(1, h->spec_sweeps) : 1;
+  bool converged = false;
+  int light_done = 0;
   for (;;) {
     for (int i = 0; i < batch && enq < max_sweeps; ++i) enqueue_sweep(enq++);
     HIP_TRY(hipMemcpyAsync(st, h->off_bits, sizeof st, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
     sweep = (int)st[2];
-    if (getenv("CB_DEBUG"))
+    double c_last = 1.0;
+    for (int k = 0; k < sweep && k < 48; ++k) {
+      double off;
+      memcpy(&off, &st[8 + k], sizeof off);
+      if (k == sweep - 1) c_last = off;
+      if (getenv("CB_DEBUG") && k >= sweep - batch) fprintf(stderr, "[cherrybank] eigh sweep %d: max cosine %.3e\n", k, off);
+    }
+    if (st[1] == 2ull) return fail(CB_ENUMERIC, "eigensolver: non-finite input");
+    if (st[1] == 1ull) {
+      converged = true;
+      break;
+    }
+    if (use_light && c_last <= light_trigger) {
+      int lr = 2, guard = 0;
+      while (lr == 2 && guard++ < 4) lr = light_sweep();
+      if (lr < 0) return lr;
+      if (lr == 1) {
+        converged = true;
+        light_done = 1;
+        break;
+      }
+    }
+    if (enq >= max_sweeps) break;
+    batch = 1;
+  }
+  h->last_light = light_done;
+  {
+    // how many Jacobi sweeps would have been enough: up to the first one that started below the
+    // first-order trigger (then first-order sweeps finish), else all but the verification sweep
+    int need = std::max(1, sweep - 1);
+    if (use_light)
       for (int k = 0; k < sweep && k < 48; ++k) {
         double off;
         memcpy(&off, &st[8 + k], sizeof off);
-        if (k >= sweep - batch) fprintf(stderr, "[cherrybank] eigh sweep %d: max cosine %.3e\n", k, off);
+        if (off <= light_trigger) {
+          need = k + 1;
+          break;
+        }
       }
-    if (st[1] == 2ull) return fail(CB_ENUMERIC, "eigensolver: non-finite input");
-    if (st[1] == 1ull || enq >= max_sweeps) break;
-    batch = 1;
+    h->spec_sweeps = need;
   }
-  const bool converged = st[1] == 1ull;
   h->last_sweeps = sweep;
   if (dbg_stamps) {
     unsigned long long st[8];
@@ -641,9 +724,9 @@ static int large_eval(cb_bank *h, bool normalize, double *lossd, double *out, bo
     hipLaunchKernelGGL(k3_reduce, dim3((unsigned)((LL + 255) / 256)), dim3(256), 0, h->stream,
                        h->Gt, B, LL, h->Mt);
     K4Args k4a{S, LD, h->Mt, h->Vc, h->X, nullptr, nullptr, nullptr};
-    hipLaunchKernelGGL(k4_gemm, dim3(tiles), dim3(LG_THREADS), 0, h->stream, k4a);
+    launch_sg(h, k4a, 0);
     K4Args k4b{S, LD, h->Vc, h->X, dQd, dA_padded ? nullptr : h->dsq, nullptr, nullptr};
-    hipLaunchKernelGGL(k4_gemm, dim3(tiles), dim3(LG_THREADS), 0, h->stream, k4b);
+    launch_sg(h, k4b, 0);
     mark(h, EV_K4);
   }
   HIP_TRY(hipGetLastError());

@@ -241,6 +241,77 @@ __global__ void lgj_check(unsigned long long *state, double tol) {
   else if (off <= tol) state[1] = 1ull;
 }
 
+// ---- first-order final sweep ------------------------------------------------------------
+// Once every cosine is <= 1e-8 the remaining rotations are tiny and commute to first order, so
+// the last ("verification") sweep -- LD/8 + 1 launches -- is replaced by
+//   Gamma = G^T G (GEMM);  X_ij = Gamma_ij / (Gamma_jj - Gamma_ii)  (the small-angle limit of the
+//   Jacobi rotation of pair (i, j); X is antisymmetric);  R = I + X + X^2 / 2 = I + X - X^T X / 2
+//   (GEMM; orthogonal to O(|X|^3));  G <- G R (GEMM).
+// lgx_build also measures what decides whether this is legitimate: the largest cosine c and
+// max_i sum_j |X_ij| >= |X|_2 (near-degenerate neighbours amplify angles by ~ sigma / gap):
+//   |X| <= 1e-5: R as above;  |X| <= 2e-3: R = exp(X) to 4th order (two more GEMMs, orthogonal to
+//   |X|^5 / 120 < 1e-15);  larger: the caller runs an ordinary Jacobi sweep instead.
+// The sweep is the last one when it started with c <= 1e-8 (it ends at rounding level, like a
+// Jacobi sweep); otherwise the residual is ~ |X| c and another first-order sweep follows.
+__global__ void lgx_transpose(int LD, const double *Gc, double *Gr) {
+  __shared__ double tile[32][33];
+  const int i0 = blockIdx.y * 32, j0 = blockIdx.x * 32;
+  for (int r = threadIdx.y; r < 32; r += blockDim.y) {
+    const int i = i0 + r, j = j0 + threadIdx.x;
+    tile[r][threadIdx.x] = (i < LD && j < LD) ? Gc[(size_t)i * LD + j] : 0.0;
+  }
+  __syncthreads();
+  for (int r = threadIdx.y; r < 32; r += blockDim.y) {
+    const int j = j0 + r, i = i0 + threadIdx.x;
+    if (j < LD && i < LD) Gr[(size_t)j * LD + i] = tile[threadIdx.x][r];
+  }
+}
+
+// one workgroup (256 threads) per row i; state[4] = max cosine (bits), state[5] = max row sum (bits)
+__global__ __launch_bounds__(256) void lgx_build(int LD, const double *Gam, double *X, unsigned long long *state) {
+  __shared__ double s0[256], s1[256];
+  const int i = blockIdx.x;
+  const double gii = Gam[(size_t)i * LD + i];
+  double mc2 = 0.0, rs = 0.0;
+  for (int j = threadIdx.x; j < LD; j += 256) {
+    double x = 0.0;
+    if (j != i) {
+      const double g = Gam[(size_t)i * LD + j], gjj = Gam[(size_t)j * LD + j];
+      const double g2 = g * g, ab = gii * gjj;
+      if (g2 > ab * (CB_JAC_SKIP * CB_JAC_SKIP)) {
+        mc2 = fmax(mc2, g2 / ab);
+        const double d = gjj - gii;
+        x = d != 0.0 ? g / d : (g > 0.0 ? 1.0 : -1.0);  // exactly degenerate and coupled: refuse (huge row sum)
+        rs += fabs(x);
+      }
+    }
+    X[(size_t)i * LD + j] = x;
+  }
+  s0[threadIdx.x] = mc2;
+  s1[threadIdx.x] = rs;
+  __syncthreads();
+  for (int st = 128; st >= 1; st >>= 1) {
+    if ((int)threadIdx.x < st) {
+      s0[threadIdx.x] = fmax(s0[threadIdx.x], s0[threadIdx.x + st]);
+      s1[threadIdx.x] += s1[threadIdx.x + st];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    atomicMax(state + 4, dbl_bits(sqrt(s0[0])));
+    atomicMax(state + 5, dbl_bits(s1[0]));
+  }
+}
+
+// R = I + X - P2/2 + P3/6 + P4/24  (= exp(X) to 4th order: P2 = X^T X = -X^2, P3 = X^T P2 = X^3,
+// P4 = P2^T P2 = X^4); P4 arrives in R and is overwritten.
+__global__ void lgx_combine(int LD, const double *X, const double *P2, const double *P3, double *R) {
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (size_t)LD * LD) return;
+  const int i = idx / LD, j = idx - (size_t)i * LD;
+  R[idx] = (i == j ? 1.0 : 0.0) + X[idx] - 0.5 * P2[idx] + P3[idx] * (1.0 / 6.0) + R[idx] * (1.0 / 24.0);
+}
+
 // |g_k| per column (one wave per column)
 __global__ void lgj_norms(int LD, const double *Gc, double *nrm) {
   const int k = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);

@@ -311,6 +311,68 @@ __global__ __launch_bounds__(LG_THREADS) void k4_gemm(K4Args a) {
     }
 }
 
+// Single-matrix products (K4a, K4b, the warm-start G0 = A' U_prev, the first-order eigen
+// correction): one LD^3 GEMM is only (LD/80)^2 = 25 of the 80x80 tiles, i.e. 25 of 256 CUs and
+// a 25-step serial K loop per tile (43 us at LD = 400).  Here a workgroup owns a 16 x 80 strip
+// and its four waves split K (k-step s goes to wave s mod 4); operand fragments are read
+// straight from L2 in MFMA layout (no LDS staging: the matrices are 1.3 MB), the four partial
+// strips are summed through LDS in a fixed order.  (LD/16) x ceil(LD/80) = 125 workgroups.
+// Same argument block and epilogues as k4_gemm, plus:
+//   ns != 0 :  out = (row == col) + sub[row][col] - acc / 2      (R = I + X + X^2/2, X^2 = -X^T X)
+__global__ __launch_bounds__(256) void sg_gemm(K4Args a, int ns) {
+  __shared__ double sRed[4][5][256];
+  const int LD = a.LD, tilesN = (LD + 79) / 80;
+  const int tm = blockIdx.x / tilesN, tn = blockIdx.x - tm * tilesN;
+  const int m0 = tm * 16, n0 = tn * 80;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, lo = lane & 15, hi = lane >> 4;
+  d4 acc[5];
+#pragma unroll
+  for (int j = 0; j < 5; ++j) acc[j] = d4{0.0, 0.0, 0.0, 0.0};
+  int ncol[5];
+#pragma unroll
+  for (int j = 0; j < 5; ++j) ncol[j] = min(n0 + 16 * j + lo, LD - 1);  // clamped: tiles past LD are discarded
+  const int nsteps = LD / 4;
+  const double *Ap = a.Aop + m0 + lo, *Bp = a.Bop;
+  for (int s0 = wave; s0 < nsteps; s0 += 16) {   // 4 k-steps of this wave in flight
+    double av[4], bv[4][5];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int s = min(s0 + 4 * u, nsteps - 1);
+      const size_t krow = (size_t)(4 * s + hi) * LD;
+      av[u] = Ap[krow];
+#pragma unroll
+      for (int j = 0; j < 5; ++j) bv[u][j] = Bp[krow + ncol[j]];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      if (s0 + 4 * u < nsteps) {
+#pragma unroll
+        for (int j = 0; j < 5; ++j) acc[j] = mfma_f64(av[u], bv[u][j], acc[j]);
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 5; ++j)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) sRed[wave][j][r * 64 + lane] = acc[j][r];
+  __syncthreads();
+  const int t = threadIdx.x, r = t >> 6, l = t & 63;
+  const int row = m0 + (l >> 4) + 4 * r;
+#pragma unroll
+  for (int j = 0; j < 5; ++j) {
+    const int col = n0 + 16 * j + (l & 15);
+    if (col >= LD) continue;
+    const double v = (sRed[0][j][t] + sRed[1][j][t]) + (sRed[2][j][t] + sRed[3][j][t]);
+    if (a.dsq) {
+      if (row < a.S && col < a.S) a.out[(size_t)row * a.S + col] = a.dsq[row] * v / a.dsq[col];
+    } else {
+      const size_t idx = (size_t)row * LD + col;
+      if (ns) a.out[idx] = (row == col ? 1.0 : 0.0) + a.sub[idx] - 0.5 * v;
+      else a.out[idx] = a.sub ? v - (*a.sub_scale) * a.sub[idx] : v;
+    }
+  }
+}
+
 // ------------------------------------------------------------------ small helpers
 // A = sym(D^1/2 Q D^-1/2) into padded LD x LD, dsq = sqrt(pi) (1 on the pad)
 __global__ void lg_build_A(int S, int LD, const double *Q, const double *pi, double *A,
