@@ -315,10 +315,16 @@ def main():
             names = {"k1": "k1_pt_loss_gt", "k2": "k2_t_eq_g_u", "k3": "k3_w_phi"}
             dom = max(names, key=lambda k: tm[k])
             achieved = flops / (tm[dom] * 1e-3) / 1e12 if tm[dom] > 0 else 0.0
+            tn_ = -(-S // 80)
+            tri = (tn_ * (tn_ + 1) / 2) / float(tn_ * tn_)   # share of 80x80 tiles actually multiplied
             roofline = dict(bound="mfma", kernel=names[dom], achieved=achieved,
                             peak=F64_PEAK_TFLOPS, unit="TFLOP/s", frac=achieved / F64_PEAK_TFLOPS,
                             traffic=traffic.get(names[dom]) if world == 1 else None,
-                            ms_per_launch=tm[dom], flops_per_launch=flops)
+                            ms_per_launch=tm[dom], flops_per_launch=flops,
+                            note="achieved = algorithmic 2 S^3 B flops (SURVEY 8d) / launch time; k1 (Pt symmetric) "
+                                 f"and k3 (symmetric counts) multiply only the upper-triangular tiles, {tri:.2f} of "
+                                 "those flops; k2 multiplies all of them",
+                            per_kernel_tflops={k: round(flops / (tm[k] * 1e-3) / 1e12, 2) for k in names if tm[k] > 0})
         else:
             Lb = wl["C"].shape[0] if wl["kind"] == "sites" else 1
             nbytes = float(Lb) * B_local * S * S * 8  # C streamed once per epoch

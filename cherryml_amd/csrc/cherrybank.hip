@@ -72,6 +72,7 @@ struct cb_bank {
   // large-path workspaces
   double *Gc2 = nullptr, *gx = nullptr;  // second column buffer and 4 LD^2 scratch of the first-order sweep
   int last_light = 0;
+  bool sym_counts = false;  // every live bucket has C_b == C_b^T (cherry counts are, by construction)
   int spec_sweeps = 0;  // Jacobi sweeps to enqueue before the first host check (learned from the previous solve)
   double *A = nullptr, *dsq = nullptr, *Gc = nullptr, *Vc = nullptr, *U = nullptr, *lam = nullptr,
          *sigma = nullptr, *F = nullptr, *E = nullptr, *H = nullptr, *Gt = nullptr, *T = nullptr,
@@ -441,6 +442,15 @@ extern "C" int cb_create(int device, int S, int L, int B, const double *t, const
     const int nt32 = (h->LD + 31) / 32;
     hipLaunchKernelGGL(lg_transpose_pad, dim3(nt32, nt32, Bl), dim3(32, 8), 0, h->stream, S, h->LD,
                        Cdev, h->Ct, src_idx);
+    {
+      int *flag = reinterpret_cast<int *>(h->status);  // [L] ints, unused by the large path
+      (void)hipMemsetAsync(flag, 0, sizeof(int), h->stream);
+      hipLaunchKernelGGL(lg_sym_check, dim3(nt32, nt32, Bl), dim3(32, 32), 0, h->stream, h->LD, h->Ct, flag);
+      int hf = 1;
+      if (hipMemcpyAsync(&hf, flag, sizeof hf, hipMemcpyDeviceToHost, h->stream) == hipSuccess &&
+          hipStreamSynchronize(h->stream) == hipSuccess)
+        h->sym_counts = hf == 0 && !getenv("CB_NO_SYM");
+    }
   }
   h->n_host.resize(L);
   hipError_t e = hipMemcpyAsync(h->n_host.data(), h->n_dev, L * sizeof(double), hipMemcpyDeviceToHost,
@@ -706,20 +716,21 @@ static int large_eval(cb_bank *h, bool normalize, double *lossd, double *out, bo
   const double inv_n = normalize ? 1.0 / h->n_host[0] : 1.0;
   K1Args k1{S, LD, B, h->Vc, h->A, tb, h->F, h->sigma, h->Ct, h->Gt, h->loss_part, inv_n, h->dsq, Pd};
   mark(h, EV_END);  // (re-used as "before K1" marker)
-  hipLaunchKernelGGL(k1_pt_loss_gt, dim3(tiles * B), dim3(LG_THREADS), 0, h->stream, k1);
+  const int tiles_k1 = tn * (tn + 1) / 2;  // Pt is symmetric: upper-triangular tiles only
+  hipLaunchKernelGGL(k1_pt_loss_gt, dim3(tiles_k1 * B), dim3(LG_THREADS), 0, h->stream, k1);
   mark(h, EV_K1);
   if (Pd) {
     HIP_TRY(hipGetLastError());
     return CB_OK;
   }
-  hipLaunchKernelGGL(lg_finish_loss, dim3(1), dim3(256), 0, h->stream, h->loss_part, B * tiles, S,
+  hipLaunchKernelGGL(lg_finish_loss, dim3(1), dim3(256), 0, h->stream, h->loss_part, B * tiles_k1, S,
                      h->dsq, h->dirsum, inv_n, lossd);
   if (dQd) {
     K2Args k2{LD, h->Gt, h->U, h->T};
     hipLaunchKernelGGL(k2_t_eq_g_u, dim3(tiles * B), dim3(LG_THREADS), 0, h->stream, k2);
     mark(h, EV_K2);
-    K3Args k3{LD, B, h->T, h->U, tb, h->lam, h->E, h->H, h->Gt};
-    hipLaunchKernelGGL(k3_w_phi, dim3(tiles * B), dim3(LG_THREADS), 0, h->stream, k3);
+    K3Args k3{LD, B, h->T, h->U, tb, h->lam, h->E, h->H, h->Gt, h->sym_counts ? 1 : 0};
+    hipLaunchKernelGGL(k3_w_phi, dim3((h->sym_counts ? tiles_k1 : tiles) * B), dim3(LG_THREADS), 0, h->stream, k3);
     mark(h, EV_K3);
     hipLaunchKernelGGL(k3_reduce, dim3((unsigned)((LL + 255) / 256)), dim3(256), 0, h->stream,
                        h->Gt, B, LL, h->Mt);

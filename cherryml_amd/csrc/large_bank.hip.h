@@ -140,13 +140,21 @@ struct K1Args {
   double *P;             // [B][S][S] (expm mode) or null
 };
 
+// Pt_b is symmetric: only the tilesN (tilesN + 1) / 2 tiles with tm <= tn run the main loop; an
+// off-diagonal tile serves both (row, col) and (col, row) in its epilogue (same Pt value, its own
+// count and its own Gt^T entry).  40 % fewer MFMAs than the full grid at LD = 400.
 __global__ __launch_bounds__(LG_THREADS) void k1_pt_loss_gt(K1Args a) {
   __shared__ double sA[2 * LG_KT * LG_TM];
   __shared__ double sB[2 * LG_KT * LG_TN];
-  const int tilesN = (a.LD + LG_TN - 1) / LG_TN, tiles = tilesN * tilesN;
+  const int tilesN = (a.LD + LG_TN - 1) / LG_TN, tiles = tilesN * (tilesN + 1) / 2;
   const int vid = xcd_swizzle(blockIdx.x, gridDim.x);
-  const int b = vid / tiles, tile = vid - b * tiles;
-  const int tm = tile / tilesN, tn = tile - tm * tilesN;
+  const int b = vid / tiles;
+  int tile = vid - b * tiles, tm = 0;
+  while (tile >= tilesN - tm) {  // row tm of the upper triangle holds tilesN - tm tiles
+    tile -= tilesN - tm;
+    ++tm;
+  }
+  const int tn = tm + tile;
   const int m0 = tm * LG_TM, n0 = tn * LG_TN;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int lo = lane & 15, hi = lane >> 4;
@@ -157,26 +165,31 @@ __global__ __launch_bounds__(LG_THREADS) void k1_pt_loss_gt(K1Args a) {
 
   const double tb = a.t[b];
   const bool split = tb * 2.0 * (*a.sigma) <= 1.0;  // see small_bank.hip.h
+  const bool mirror = tm != tn;
   double lossacc = 0.0;
+  auto emit = [&](int row, int col, double pt) {
+    const size_t idx = (size_t)row * a.LD + col;
+    if (a.P) {
+      if (row < a.S && col < a.S)
+        a.P[(size_t)b * a.S * a.S + (size_t)row * a.S + col] = pt * a.dsq[col] / a.dsq[row];
+    } else {
+      const double c = a.Ct[boff + idx];
+      const bool nz = c != 0.0;
+      lossacc = fma(-c, fast_log(nz ? pt : 1.0), lossacc);
+      a.Gt[boff + idx] = nz ? -c * a.inv_n * fast_rcp(pt) : 0.0;
+    }
+  };
 #pragma unroll
   for (int j = 0; j < 5; ++j)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int row = m0 + 16 * wave + hi + 4 * r, col = n0 + 16 * j + lo;
       if (row < a.LD && col < a.LD) {
-        const size_t idx = (size_t)row * a.LD + col;
         double pt = acc[j][r];
-        if (split) pt += tb * a.A[idx] + (row == col ? 1.0 : 0.0);
+        if (split) pt += tb * a.A[(size_t)row * a.LD + col] + (row == col ? 1.0 : 0.0);
         else if (row >= a.S || col >= a.S) pt = 1.0;  // pad (never used: C = 0 there)
-        if (a.P) {
-          if (row < a.S && col < a.S)
-            a.P[(size_t)b * a.S * a.S + (size_t)row * a.S + col] = pt * a.dsq[col] / a.dsq[row];
-        } else {
-          const double c = a.Ct[boff + idx];
-          const bool nz = c != 0.0;
-          lossacc = fma(-c, fast_log(nz ? pt : 1.0), lossacc);
-          a.Gt[boff + idx] = nz ? -c * a.inv_n * fast_rcp(pt) : 0.0;
-        }
+        emit(row, col, pt);
+        if (mirror) emit(col, row, pt);
       }
     }
   if (a.P) return;
@@ -232,15 +245,29 @@ struct K3Args {
   const double *E;       // [B][LD] exp(t lam)
   const double *H;       // [B][LD] exp(t lam / 2)
   double *W;             // [B][LD][LD] out (aliases the Gt buffer)
+  int sym;               // counts symmetric => Gt_b, hence W_b, symmetric: upper-triangular tiles only
 };
 
 __global__ __launch_bounds__(LG_THREADS) void k3_w_phi(K3Args a) {
   __shared__ double sA[2 * LG_KT * LG_TM];
   __shared__ double sB[2 * LG_KT * LG_TN];
-  const int tilesN = (a.LD + LG_TN - 1) / LG_TN, tiles = tilesN * tilesN;
+  const int tilesN = (a.LD + LG_TN - 1) / LG_TN;
+  const int tiles = a.sym ? tilesN * (tilesN + 1) / 2 : tilesN * tilesN;
   const int vid = xcd_swizzle(blockIdx.x, gridDim.x);
-  const int b = vid / tiles, tile = vid - b * tiles;
-  const int tm = tile / tilesN, tn = tile - tm * tilesN;
+  const int b = vid / tiles;
+  int tile = vid - b * tiles, tm, tn;
+  if (a.sym) {
+    tm = 0;
+    while (tile >= tilesN - tm) {
+      tile -= tilesN - tm;
+      ++tm;
+    }
+    tn = tm + tile;
+  } else {
+    tm = tile / tilesN;
+    tn = tile - tm * tilesN;
+  }
+  const bool mirror = a.sym && tm != tn;
   const int m0 = tm * LG_TM, n0 = tn * LG_TN;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int lo = lane & 15, hi = lane >> 4;
@@ -260,7 +287,9 @@ __global__ __launch_bounds__(LG_THREADS) void k3_w_phi(K3Args a) {
       const int col = n0 + 16 * j + lo;
       if (col < a.LD) {
         const double ph = divdiff_fast(tb, lr, a.lam[col], er, Eb[col], hr, Hb[col]);
-        a.W[boff + (size_t)row * a.LD + col] = acc[j][r] * ph;
+        const double w = acc[j][r] * ph;
+        a.W[boff + (size_t)row * a.LD + col] = w;
+        if (mirror) a.W[boff + (size_t)col * a.LD + row] = w;
       }
     }
   }
@@ -417,6 +446,13 @@ __global__ void lg_finish_loss(const double *part, int nparts, int S, const doub
     __syncthreads();
   }
   if (threadIdx.x == 0) *loss = s[0] * inv_n;
+}
+
+// flag[0] |= 1 when some live bucket has C_b != C_b^T
+__global__ void lg_sym_check(int LD, const double *Ct, int *flag) {
+  const size_t boff = (size_t)blockIdx.z * LD * LD;
+  const int i = blockIdx.y * blockDim.y + threadIdx.y, j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < LD && j < i && Ct[boff + (size_t)i * LD + j] != Ct[boff + (size_t)j * LD + i]) atomicOr(flag, 1);
 }
 
 // pad + transpose counts at create time: Ct[b][j][i] = C[b][i][j]

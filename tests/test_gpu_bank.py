@@ -201,6 +201,22 @@ def _oracle_loss_grad(Q, t, C):
     return loss.item(), Qt.grad.numpy()
 
 
+@pytest.mark.parametrize("S,B", [(48, 3), (100, 2), (161, 2), (400, 2)])
+def test_symmetric_counts_take_the_triangular_tile_path(S, B):
+    """C_b == C_b^T (what cherry counting produces): K3 multiplies upper-triangular tiles only
+    and mirrors; same answers as the oracle on the full matrices."""
+    rng = np.random.default_rng(S + 7 * B)
+    Q, pi = _sym_rate(rng, S, scale=4.0 / S)
+    t = np.sort(rng.uniform(0.02, 1.5, size=B))
+    C = rng.poisson(2.0, size=(B, S, S)).astype(np.float64)
+    C = C + C.transpose(0, 2, 1)
+    ref_loss, ref_grad = _oracle_loss_grad(Q, t, C)
+    with _bank(t, C) as bank:
+        loss, dQ = bank.loss_grad(Q, pi)
+    assert abs(loss[0] - ref_loss) < 1e-12 * abs(ref_loss)
+    assert relerr(dQ[0], ref_grad) < 1e-10
+
+
 @pytest.mark.parametrize("S,B", [(2, 3), (5, 1), (17, 4), (32, 5), (33, 3), (48, 2), (100, 3), (161, 2)])
 def test_odd_sizes_padding_and_partial_tiles(S, B):
     """S = 33..161 take the large path with LD = ceil16(S) zero padding and partial 80-tiles;
