@@ -39,6 +39,8 @@ SIGNATURES = {
                                        _vp, C.c_int64, C.c_int, C.c_int, _vp]),
     "cb_count_co_transitions": (C.c_int, [C.c_int, C.c_int, C.c_int, _vp, _vp, C.c_int64, _vp, C.c_int64,
                                           _vp, C.c_int64, C.c_int, C.c_int, _vp]),
+    "cb_siterm_assemble": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, C.c_int64, _vp, C.c_int64,
+                                     _vp, _vp, C.c_double, C.c_int, C.c_int, _vp]),
 }
 
 _lib = None

@@ -1,0 +1,189 @@
+"""SiteRM count / pseudocount assembly and the per-family estimator driver: the interface of the
+reference's cherryml/_siterm/_site_specific_rate_matrix.py (file:line cited per function) with the
+per-transition / per-site loops on the GPU (`cb_siterm_assemble`, csrc/counting.hip.h) and the
+optimiser on the GPU (`cb_train_siterm`).  The count tensor [L,B,S,S] is produced on the device
+and handed to the bank without a host round trip; `cb_create` drops the empty (site, bucket)
+matrices, which is the reference's "compactification" (:577-602).
+
+Host side (like the reference: tiny, closed form): the cherry++ pairing walk and the prior
+matrices diag(pi0) expm(t_b Q0)."""
+import time
+from typing import Dict, List, Optional, Tuple
+
+import numpy as np
+
+from .. import _lib
+from .._lib import CB_PTR_DEVICE
+from ..counting._host import encode_msa
+from ..counting._stage import PAIR_DTYPE
+
+
+def get_cherry_transitions(tree, msa: Dict[str, str]) -> List[Tuple[str, str, float]]:
+    """:87-139 (`_get_cherry_transitions`): (seq_1, seq_2, total length) per generalised cherry."""
+    return [(msa[a], msa[b], la + lb) for a, b, la, lb in _cherry_pairs(tree)]
+
+
+def get_edge_transitions(tree, msa: Dict[str, str]) -> List[Tuple[str, str, float]]:
+    """:393-405 (`_get_edge_transitions`)."""
+    assert sorted(tree.nodes()) == sorted(msa.keys())
+    return [(msa[u], msa[v], t) for (u, v, t) in tree.edges()]
+
+
+def _cherry_pairs(tree) -> List[Tuple[str, str, float, float]]:
+    """Post-order greedy pairing of the unmatched leaves under every node, children in
+    insertion order, an odd leaf is passed up with its accumulated distance (:96-136)."""
+    pairs: List[Tuple[str, str, float, float]] = []
+    up: Dict[str, Optional[Tuple[str, float]]] = {}
+    stack = [(tree.root(), False)]
+    while stack:
+        node, done = stack.pop()
+        if tree.is_leaf(node):
+            up[node] = (node, 0.0)
+            continue
+        if not done:
+            stack.append((node, True))
+            for child, _ in reversed(tree.children(node)):
+                stack.append((child, False))
+            continue
+        leaves, dists = [], []
+        for child, bl in tree.children(node):
+            if up[child] is not None:
+                leaves.append(up[child][0])
+                dists.append(up[child][1] + bl)
+        for i in range(0, len(leaves) - 1, 2):
+            pairs.append((leaves[i], leaves[i + 1], dists[i], dists[i + 1]))
+        up[node] = (leaves[-1], dists[-1]) if len(leaves) % 2 == 1 else None
+    assert len(pairs) == len(tree.leaves()) // 2
+    return pairs
+
+
+def _pairs_and_codes(tree, msa, alphabet, transitions_strategy):
+    if transitions_strategy == "cherry++":
+        assert sorted(tree.leaves()) == sorted(msa.keys())
+        named = _cherry_pairs(tree)
+    elif transitions_strategy == "edges":
+        assert sorted(tree.nodes()) == sorted(msa.keys())
+        named = [(u, v, t, 0.0) for (u, v, t) in tree.edges()]
+    else:
+        raise ValueError(f"Unknown transitions_strategy: {transitions_strategy}")
+    names = list(msa.keys())
+    row = {nm: i for i, nm in enumerate(names)}
+    codes = encode_msa(msa, names, list(alphabet))
+    L = codes.shape[1]
+    pairs = np.zeros(len(named), dtype=PAIR_DTYPE)
+    for k, (a, b, la, lb) in enumerate(named):
+        pairs[k] = (row[a] * L, row[b] * L, 0, L, 0, la, lb)
+    return pairs, codes
+
+
+def get_count_prior_probability_matrices(rate_matrix: np.ndarray, quantization_points_sorted) -> np.ndarray:
+    """:325-355: prior[b] = diag(pi0) expm(t_b Q0) through the reversible factorisation
+    (markov_chain/_markov_chain.py:56-155); ValueError when a matrix does not sum to 1."""
+    Q0 = np.asarray(rate_matrix, dtype=np.float64)
+    w, v = np.linalg.eig(Q0.transpose())
+    pi = v[:, int(np.argmin(np.abs(w.real)))].real
+    pi = pi / pi.sum()
+    P1, P2 = np.diag(np.sqrt(pi)), np.diag(np.sqrt(1.0 / pi))
+    D, U = np.linalg.eigh(P1 @ Q0 @ P2)
+    left, right = P2 @ U, U.T @ P1
+    out = np.zeros((len(quantization_points_sorted),) + Q0.shape)
+    for b, t in enumerate(quantization_points_sorted):
+        out[b] = pi[:, None] * (left @ (np.diag(np.exp(t * D)) @ right))
+        if abs(float(out[b].sum()) - 1.0) > 1e-6:
+            raise ValueError("count_prior_probability_matrices[b, :, :] does not add up to 1!")
+    return out
+
+
+def _assemble(pairs, codes, grid, site_rates, prior, lam, reverse, S, device: int, to_torch: bool):
+    L, B = codes.shape[1], len(grid)
+    codes = np.ascontiguousarray(codes)
+    grid = np.ascontiguousarray(grid, dtype=np.float64)
+    rates = np.ascontiguousarray(site_rates, dtype=np.float64)
+    prior = np.ascontiguousarray(prior, dtype=np.float64)
+    if rates.size != L:
+        raise ValueError(f"site_rates has {rates.size} entries, the MSA has {L} sites")
+    lib = _lib.load()
+    if to_torch:
+        import torch
+        out = torch.empty((L, B, S, S), dtype=torch.float64, device=torch.device("cuda", device))
+        torch.cuda.synchronize(out.device)
+        ptr, flags = out.data_ptr(), CB_PTR_DEVICE
+    else:
+        out = np.empty((L, B, S, S))
+        ptr, flags = out.ctypes.data, 0
+    rc = lib.cb_siterm_assemble(device, S, B, L, grid.ctypes.data, codes.ctypes.data, codes.size,
+                                pairs.ctypes.data, len(pairs), rates.ctypes.data, prior.ctypes.data,
+                                float(lam), int(bool(reverse)), flags, ptr)
+    _lib.check(rc, "cb_siterm_assemble")
+    return out
+
+
+def get_raw_count_matrices(transitions: List[Tuple[str, str, float]], quantization_points_sorted,
+                           alphabet: List[str], include_reverse_transitions: bool = True,
+                           device: int = 0) -> np.ndarray:
+    """:189-261 (`_get_raw_count_matrices`): [L,B,S,S] numpy; counted on the GPU (lambda = 0)."""
+    msa = {}
+    pairs = np.zeros(len(transitions), dtype=PAIR_DTYPE)
+    L = len(transitions[0][0])
+    for k, (x, y, t) in enumerate(transitions):
+        msa[f"a{k}"], msa[f"b{k}"] = x, y
+        pairs[k] = (2 * k * L, (2 * k + 1) * L, 0, L, 0, t, 0.0)
+    codes = encode_msa(msa, list(msa.keys()), list(alphabet))
+    S, B = len(alphabet), len(quantization_points_sorted)
+    return _assemble(pairs, codes, quantization_points_sorted, np.ones(L), np.zeros((B, S, S)), 0.0,
+                     include_reverse_transitions, S, device, False)
+
+
+def estimate_site_specific_rate_matrices_given_tree_and_site_rates(
+    tree, site_rates: List[float], msa: Dict[str, str], alphabet: List[str],
+    regularization_strength: float, regularization_rate_matrix: np.ndarray,
+    quantization_points: List[float], optimization_num_epochs: int,
+    transitions_strategy: str = "cherry++", include_reverse_transitions: bool = True,
+    rate_matrix_parameterization: str = "pande_reversible", log_dir: Optional[str] = None,
+    plot_site_specific_rate_matrices: int = 0, use_vectorized_cherryml_implementation: bool = True,
+    vectorized_cherryml_implementation_device: str = "cuda",
+    vectorized_cherryml_implementation_num_cores: int = 1,
+) -> Dict:
+    """:442-731 (`_estimate_site_specific_rate_matrices_given_tree_and_site_rates`), vectorised path:
+    {"res": [L,S,S] site-specific rate matrices, "time_*": seconds per sub-step}.  Sites without
+    any count (e.g. all gaps) get the prior `Q0 * rate_l`, like the reference's per-site path
+    (:655-658)."""
+    if vectorized_cherryml_implementation_device != "cuda":
+        raise NotImplementedError("this build computes on the GPU only: device must be 'cuda'")
+    if rate_matrix_parameterization != "pande_reversible":
+        raise NotImplementedError("only the reference's default parameterisation 'pande_reversible'")
+    import torch
+    from ..bank import CherryBank
+    from ._vectorized import _invert
+    prof = {}
+    st = time.time()
+    grid = sorted(quantization_points)
+    Q0 = np.asarray(regularization_rate_matrix, dtype=np.float64)
+    S = len(alphabet)
+    pairs, codes = _pairs_and_codes(tree, msa, alphabet, transitions_strategy)
+    L = codes.shape[1]
+    prof["time_get_transitions"] = time.time() - st
+    st = time.time()
+    prior = get_count_prior_probability_matrices(Q0, grid)
+    prof["time_get_count_prior_probability_matrices"] = time.time() - st
+    st = time.time()
+    dev = torch.cuda.current_device()
+    counts = _assemble(pairs, codes, grid, site_rates, prior, regularization_strength,
+                       include_reverse_transitions, S, dev, True)
+    totals = counts.sum(dim=(1, 2, 3)).cpu().numpy()
+    prof["time_get_count_matrices"] = time.time() - st
+    st = time.time()
+    rates = np.asarray(site_rates, dtype=np.float64)
+    init = Q0[None, :, :] * rates[:, None, None]
+    res = init.copy()
+    has = totals > 0
+    if has.any():
+        idx = np.flatnonzero(has)
+        sub = counts if has.all() else counts[torch.as_tensor(idx, device=counts.device)]
+        times = np.tile(np.asarray(grid, dtype=np.float64), (len(idx), 1))
+        th0, Th0 = _invert(init[idx])
+        with CherryBank(times, sub) as bank:
+            r = bank.train_siterm(th0, Th0, int(optimization_num_epochs), lr=0.1)
+        res[idx] = r["res"]
+    prof["time_optimization"] = time.time() - st
+    return {"res": res, **prof}

@@ -1488,3 +1488,65 @@ extern "C" int cb_count_co_transitions(int device, int S, int B, const double *g
                       (size_t)(n_contacts > 0 ? n_contacts : 0) * 2 * sizeof(int32_t), pairs, n_pairs, symmetric,
                       flags, counts, true);
 }
+
+extern "C" int cb_siterm_assemble(int device, int S, int B, int n_sites, const double *grid, const int8_t *seqs,
+                                  int64_t seqs_bytes, const cb_count_pair *pairs, int64_t n_pairs,
+                                  const double *site_rates, const double *prior, double lambda,
+                                  int include_reverse, int flags, double *counts) {
+  if (!grid || !seqs || !pairs || !site_rates || !prior || !counts)
+    return fail(CB_EINVAL, "cb_siterm_assemble: NULL argument");
+  if (S < 2 || S > 64 || B < 1 || n_sites < 1 || n_pairs < 0 || seqs_bytes < 0)
+    return fail(CB_EINVAL, "cb_siterm_assemble: bad sizes (S=%d, B=%d, n_sites=%d)", S, B, n_sites);
+  if (!(lambda >= 0.0 && lambda <= 1.0)) return fail(CB_EINVAL, "cb_siterm_assemble: lambda must be in [0, 1]");
+  for (int b = 1; b < B; ++b)
+    if (!(grid[b] > grid[b - 1])) return fail(CB_EINVAL, "cb_siterm_assemble: grid must be strictly increasing");
+  for (int64_t p = 0; p < n_pairs; ++p)
+    if (pairs[p].seq_a < 0 || pairs[p].seq_b < 0 || pairs[p].seq_a + n_sites > seqs_bytes ||
+        pairs[p].seq_b + n_sites > seqs_bytes)
+      return fail(CB_EINVAL, "cb_siterm_assemble: pair %lld points outside seqs", (long long)p);
+  const int ndev = cb_device_count();
+  if (ndev <= 0) return fail(CB_EHIP, "cb_siterm_assemble: no HIP device visible");
+  if (device < 0 || device >= ndev) return fail(CB_EINVAL, "cb_siterm_assemble: device %d out of range", device);
+  HIP_TRY(hipSetDevice(device));
+  const size_t SS = (size_t)S * S, nmat = (size_t)n_sites * B, ncounts = nmat * SS;
+  void *d_grid = nullptr, *d_seqs = nullptr, *d_pairs = nullptr, *d_rates = nullptr, *d_prior = nullptr,
+       *d_live = nullptr, *d_counts_own = nullptr;
+  int rc = CB_OK;
+#define TRYA(expr) \
+  if (rc == CB_OK && (expr) != hipSuccess) rc = fail(CB_EHIP, "cb_siterm_assemble: %s failed", #expr)
+  TRYA(hipMalloc(&d_grid, B * sizeof(double)));
+  TRYA(hipMalloc(&d_seqs, seqs_bytes > 0 ? seqs_bytes : 1));
+  TRYA(hipMalloc(&d_pairs, (n_pairs > 0 ? n_pairs : 1) * sizeof(cb_count_pair)));
+  TRYA(hipMalloc(&d_rates, n_sites * sizeof(double)));
+  TRYA(hipMalloc(&d_prior, (size_t)B * SS * sizeof(double)));
+  TRYA(hipMalloc(&d_live, nmat * sizeof(int)));
+  double *d_counts = counts;
+  if (!(flags & CB_PTR_DEVICE)) {
+    TRYA(hipMalloc(&d_counts_own, ncounts * sizeof(double)));
+    d_counts = static_cast<double *>(d_counts_own);
+  }
+  TRYA(hipMemcpyAsync(d_grid, grid, B * sizeof(double), hipMemcpyHostToDevice, 0));
+  TRYA(hipMemcpyAsync(d_seqs, seqs, seqs_bytes, hipMemcpyHostToDevice, 0));
+  TRYA(hipMemcpyAsync(d_pairs, pairs, n_pairs * sizeof(cb_count_pair), hipMemcpyHostToDevice, 0));
+  TRYA(hipMemcpyAsync(d_rates, site_rates, n_sites * sizeof(double), hipMemcpyHostToDevice, 0));
+  TRYA(hipMemcpyAsync(d_prior, prior, (size_t)B * SS * sizeof(double), hipMemcpyHostToDevice, 0));
+  TRYA(hipMemsetAsync(d_live, 0, nmat * sizeof(int), 0));
+  TRYA(hipMemsetAsync(d_counts, 0, ncounts * sizeof(double), 0));
+  if (rc == CB_OK) {
+    if (n_pairs > 0)
+      hipLaunchKernelGGL(siterm_raw_counts_kernel, dim3((unsigned)((n_pairs + 3) / 4)), dim3(256), 0, 0, S, B, n_sites,
+                         (const double *)d_grid, (const int8_t *)d_seqs, (const cb_count_pair *)d_pairs,
+                         (long long)n_pairs, d_counts, (int *)d_live);
+    hipLaunchKernelGGL(siterm_mix_kernel, dim3((unsigned)nmat), dim3(64), 0, 0, S, B, (const double *)d_grid,
+                       (const double *)d_rates, (const double *)d_prior, lambda, include_reverse,
+                       (const int *)d_live, d_counts);
+    TRYA(hipGetLastError());
+  }
+  if (!(flags & CB_PTR_DEVICE)) TRYA(hipMemcpyAsync(counts, d_counts, ncounts * sizeof(double), hipMemcpyDeviceToHost, 0));
+  TRYA(hipStreamSynchronize(0));
+#undef TRYA
+  for (void *q : {d_grid, d_seqs, d_pairs, d_rates, d_prior, d_live, d_counts_own})
+    if (q) (void)hipFree(q);
+  return rc;
+}
+

@@ -257,3 +257,64 @@ __global__ __launch_bounds__(256) void count_co_transitions_kernel(
     }
   }
 }
+
+// ---- SiteRM count / pseudocount assembly (reference _siterm/_site_specific_rate_matrix.py) ------
+// raw[l][b][x][y] += 1 for every transition whose total length quantises to bucket b and whose
+// two sequences carry states (x, y) at site l (:226-256).  One wavefront per transition, lanes
+// over the sites; the increments are small integers, so double atomics are exact and order
+// independent.  live[l * B + b] marks the (site, bucket) matrices that received anything.
+__global__ __launch_bounds__(256) void siterm_raw_counts_kernel(
+    int S, int B, int n_sites, const double *__restrict__ grid, const int8_t *__restrict__ seqs,
+    const cb_count_pair *__restrict__ pairs, long long n_pairs, double *__restrict__ raw,
+    int *__restrict__ live) {
+  const long long p = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (p >= n_pairs) return;
+  const cb_count_pair pr = pairs[p];
+  const int b = cnt_quantize(pr.len_a + pr.len_b, grid, B);
+  if (b < 0) return;  // outside the grid: dropped (:240-247)
+  const int8_t *sa = seqs + pr.seq_a, *sb = seqs + pr.seq_b;
+  for (int l = threadIdx.x & 63; l < n_sites; l += 64) {
+    const int x = sa[l], y = sb[l];
+    if (x < 0 || y < 0) continue;
+    atomicAdd(&raw[(((size_t)l * B + b) * S + x) * S + y], 1.0);
+    live[(size_t)l * B + b] = 1;
+  }
+}
+
+// counts[l][b] = (1 - lambda) sym(raw[l][b]) + lambda * (l1 * prior[b_adj])     (:503-567), in place;
+// sym = (R + R^T) / 2 when reverse transitions are included (:257-258);  l1 = sum(raw[l][b]);
+// b_adj = quantization_idx(grid[b] * rate_l), clamped to the last / first bucket outside the grid.
+// Products and sums are kept un-fused (__dmul_rn / __dadd_rn) so the result is the reference's
+// float64 arithmetic bit for bit.  One workgroup of 64 threads per live (site, bucket).
+__global__ __launch_bounds__(64) void siterm_mix_kernel(int S, int B, const double *__restrict__ grid,
+                                                        const double *__restrict__ site_rates,
+                                                        const double *__restrict__ prior, double lambda,
+                                                        int include_reverse, const int *__restrict__ live,
+                                                        double *__restrict__ counts) {
+  const int l = blockIdx.x / B, b = blockIdx.x - l * B;
+  if (!live[blockIdx.x]) return;
+  double *M = counts + (size_t)blockIdx.x * S * S;
+  const int lane = threadIdx.x;
+  // all entries are multiples of 1/2 and small: the sum is exact in any order
+  double part = 0.0;
+  for (int e = lane; e < S * S; e += 64) part += M[e];
+  const double l1 = wave_sum(part);
+  if (!(l1 > 0.0)) return;
+  const double tt = grid[b] * site_rates[l];
+  int ba = cnt_quantize(tt, grid, B);
+  if (ba < 0) ba = tt > grid[B - 1] ? B - 1 : 0;
+  const double *P = prior + (size_t)ba * S * S;
+  const double one_m = 1.0 - lambda;
+  for (int e = lane; e < S * S; e += 64) {
+    const int x = e / S, y = e - x * S;
+    if (x > y) continue;  // the thread of (x, y), x <= y, also writes (y, x)
+    double rxy = M[x * S + y], ryx = M[y * S + x];
+    if (include_reverse) {
+      const double s = __dmul_rn(__dadd_rn(rxy, ryx), 0.5);  // (R + R^T) / 2, symmetric sum is commutative
+      rxy = s;
+      ryx = s;
+    }
+    M[x * S + y] = __dadd_rn(__dmul_rn(rxy, one_m), __dmul_rn(__dmul_rn(l1, P[x * S + y]), lambda));
+    if (x != y) M[y * S + x] = __dadd_rn(__dmul_rn(ryx, one_m), __dmul_rn(__dmul_rn(l1, P[y * S + x]), lambda));
+  }
+}

@@ -219,6 +219,25 @@ int cb_count_co_transitions(int device, int S, int B, const double *grid, const 
                             const cb_count_pair *pairs, int64_t n_pairs, int symmetric, int flags,
                             unsigned long long *counts);
 
+/* ---- SiteRM count / pseudocount assembly of ONE family ----------------------------
+ * Replaces the per-transition / per-site Python loops of
+ * cherryml/_siterm/_site_specific_rate_matrix.py:189-261 (_get_raw_count_matrices) and :503-567
+ * (pseudocounts + lambda mix inside _estimate_site_specific_rate_matrices_given_tree_and_site_rates):
+ *   raw[l,b,x,y]  = number of transitions whose total length len_a + len_b quantises to bucket b
+ *                   (utils.py:35-56; outside the grid: dropped) with states (x, y) at site l;
+ *                   include_reverse != 0: raw <- (raw + raw^T) / 2
+ *   counts[l,b]   = (1 - lambda) raw[l,b] + lambda * sum(raw[l,b]) * prior[b_adj(l,b)],
+ *   b_adj(l,b)    = quantization_idx(grid[b] * site_rates[l]), clamped into the grid
+ * seqs / pairs: as cb_count_transitions (int8 state codes, -1 = not a state; byte offsets; every
+ * pair spans n_sites codes; pair.aux / pair.n are ignored).  prior [B][S][S] = diag(pi0) expm(t_b Q0).
+ * All inputs are HOST pointers.  counts [n_sites][B][S][S] doubles: host pointer, or with
+ * CB_PTR_DEVICE a device pointer (the tensor then never leaves the GPU and feeds cb_create).
+ * The arithmetic is the reference's float64 arithmetic bit for bit. */
+int cb_siterm_assemble(int device, int S, int B, int n_sites, const double *grid, const int8_t *seqs,
+                       int64_t seqs_bytes, const cb_count_pair *pairs, int64_t n_pairs,
+                       const double *site_rates, const double *prior, double lambda,
+                       int include_reverse, int flags, double *counts);
+
 #ifdef __cplusplus
 }
 #endif

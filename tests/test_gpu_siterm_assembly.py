@@ -1,0 +1,88 @@
+"""SiteRM count / pseudocount assembly on the GPU (cb_siterm_assemble) and the per-family estimator
+driver, against vectors produced by running the reference (tests/golden/siterm_assembly.npz) and
+against the oracle.  Needs an MI355X: `pytest -m gpu`."""
+import numpy as np
+import pytest
+
+from conftest import load_golden, relerr
+from test_oracle_golden import ASSEMBLY_CASES, _assembly_case
+
+pytestmark = pytest.mark.gpu
+
+
+def _inputs(z, c):
+    tree, msa, raw = _assembly_case(z, c)
+    return dict(tree=tree, msa=msa, raw=raw, grid=sorted(z[c + "_grid"].tolist()),
+                alphabet=[str(a) for a in z[c + "_alphabet"]], strategy=str(z[c + "_strategy"]),
+                reverse=bool(z[c + "_reverse"]), rates=z[c + "_site_rates"], Q0=z[c + "_Q0"],
+                lam=float(z[c + "_lambda"]), epochs=int(z[c + "_epochs"]))
+
+
+@pytest.mark.parametrize("case", ASSEMBLY_CASES)
+def test_raw_counts_bit_exact(case):
+    from cherryml_amd._siterm import get_cherry_transitions, get_edge_transitions, get_raw_count_matrices
+    z = load_golden("siterm_assembly.npz")
+    a = _inputs(z, case)
+    tr = (get_cherry_transitions(a["tree"], a["msa"]) if a["strategy"] == "cherry++"
+          else get_edge_transitions(a["tree"], a["msa"]))
+    assert [(x, y) for x, y, _ in tr] == [(str(x), str(y)) for x, y in zip(z[case + "_tr_a"], z[case + "_tr_b"])]
+    assert np.array_equal(np.array([t for _, _, t in tr]), z[case + "_tr_t"])
+    raw = get_raw_count_matrices(tr, a["grid"], a["alphabet"], a["reverse"])
+    assert np.array_equal(raw, a["raw"])
+
+
+@pytest.mark.parametrize("case", ASSEMBLY_CASES)
+def test_mixed_counts_bit_exact_and_prior(case):
+    """The full assembly (raw -> pseudocounts -> lambda mix) equals what the reference hands to its
+    optimiser, bit for bit, once compactified the reference's way."""
+    from cherryml_amd._siterm import get_count_prior_probability_matrices
+    from cherryml_amd._siterm._assembly import _assemble, _pairs_and_codes
+    from oracle import siterm_assembly_oracle as sa
+    z = load_golden("siterm_assembly.npz")
+    a = _inputs(z, case)
+    prior = get_count_prior_probability_matrices(a["Q0"], a["grid"])
+    assert np.allclose(prior, z[case + "_prior"], rtol=1e-12, atol=1e-15)
+    pairs, codes = _pairs_and_codes(a["tree"], a["msa"], a["alphabet"], a["strategy"])
+    mixed = _assemble(pairs, codes, a["grid"], a["rates"], z[case + "_prior"], a["lam"], a["reverse"],
+                      len(a["alphabet"]), 0, False)
+    cc, tt, _ = sa.compactify(mixed, a["grid"], a["Q0"], a["rates"])
+    assert np.array_equal(tt, z[case + "_times"])
+    assert np.array_equal(cc, z[case + "_counts"])
+
+
+@pytest.mark.parametrize("case", ASSEMBLY_CASES)
+def test_estimator_matches_reference(case):
+    from cherryml_amd._siterm import estimate_site_specific_rate_matrices_given_tree_and_site_rates as est
+    z = load_golden("siterm_assembly.npz")
+    a = _inputs(z, case)
+    r = est(tree=a["tree"], site_rates=list(a["rates"]), msa=a["msa"], alphabet=a["alphabet"],
+            regularization_strength=a["lam"], regularization_rate_matrix=a["Q0"], quantization_points=a["grid"],
+            optimization_num_epochs=a["epochs"], transitions_strategy=a["strategy"],
+            include_reverse_transitions=a["reverse"])
+    assert r["res"].shape == z[case + "_res"].shape
+    for l in range(r["res"].shape[0]):
+        assert relerr(r["res"][l], z[case + "_res"][l]) < 1e-6, l
+
+
+def test_all_gap_site_gets_the_prior_and_bad_arguments_raise():
+    from cherryml_amd._siterm import estimate_site_specific_rate_matrices_given_tree_and_site_rates as est
+    from cherryml_amd._siterm import get_raw_count_matrices
+    z = load_golden("siterm_assembly.npz")
+    a = _inputs(z, "t2_some_missing")
+    alphabet = a["alphabet"][:-1]   # without the gap state: site 0 has no counts at all
+    Q0 = np.full((6, 6), 0.2)
+    np.fill_diagonal(Q0, -1.0)
+    r = est(tree=a["tree"], site_rates=[2.0, 0.5], msa=a["msa"], alphabet=alphabet, regularization_strength=0.5,
+            regularization_rate_matrix=Q0, quantization_points=a["grid"], optimization_num_epochs=5)
+    assert np.array_equal(r["res"][0], Q0 * 2.0)
+    assert not np.array_equal(r["res"][1], Q0 * 0.5)
+    with pytest.raises(ValueError):
+        est(tree=a["tree"], site_rates=[2.0, 0.5], msa=a["msa"], alphabet=alphabet, regularization_strength=0.5,
+            regularization_rate_matrix=Q0, quantization_points=a["grid"], optimization_num_epochs=5,
+            transitions_strategy="nope")
+    with pytest.raises(NotImplementedError):
+        est(tree=a["tree"], site_rates=[2.0, 0.5], msa=a["msa"], alphabet=alphabet, regularization_strength=0.5,
+            regularization_rate_matrix=Q0, quantization_points=a["grid"], optimization_num_epochs=5,
+            vectorized_cherryml_implementation_device="cpu")
+    with pytest.raises(ValueError):   # unsorted grid is refused by the C ABI
+        get_raw_count_matrices([("AD", "DA", 0.1)], [0.2, 0.1], ["A", "D"])

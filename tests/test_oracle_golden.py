@@ -156,3 +156,43 @@ def test_oracle_expm_against_reference_native_pade():
         out = np.empty((20, 20), order="F")
         assert lib.ref_expm(20, A.ctypes.data, out.ctypes.data) == 0
         assert np.abs(np.ascontiguousarray(out) - P[b]).max() < 5e-14
+
+
+# ---- SiteRM count / pseudocount assembly -------------------------------------
+def _assembly_case(z, c):
+    from cherryml_amd.io._tree import Tree
+    tree = Tree()
+    tree.add_nodes([str(v) for v in z[c + "_nodes"]])
+    for u, v, t in zip(z[c + "_edges_u"], z[c + "_edges_v"], z[c + "_edges_t"]):
+        tree.add_edge(str(u), str(v), float(t))
+    msa = {str(k): str(s) for k, s in zip(z[c + "_msa_names"], z[c + "_msa_seqs"])}
+    raw = np.zeros(tuple(z[c + "_raw_shape"]))
+    raw[tuple(z[c + "_raw_nz"].T)] = z[c + "_raw_val"]
+    return tree, msa, raw
+
+
+ASSEMBLY_CASES = ["t2_eq_cherry", "t2_eq_edges", "t2_eq_edges_rev", "t2_uneq_cherry", "t2_uneq_edges",
+                  "t2_uneq_edges_rev", "t2_some_missing", "rand_cherry"]
+
+
+@pytest.mark.parametrize("case", ASSEMBLY_CASES)
+def test_siterm_assembly_oracle_against_reference(case):
+    from oracle import siterm_assembly_oracle as sa
+    z = load_golden("siterm_assembly.npz")
+    tree, msa, raw_ref = _assembly_case(z, case)
+    grid = sorted(z[case + "_grid"].tolist())
+    alphabet = [str(a) for a in z[case + "_alphabet"]]
+    tr = sa.cherry_transitions(tree, msa) if str(z[case + "_strategy"]) == "cherry++" else sa.edge_transitions(tree, msa)
+    assert [a for a, _, _ in tr] == [str(a) for a in z[case + "_tr_a"]]
+    assert [b for _, b, _ in tr] == [str(b) for b in z[case + "_tr_b"]]
+    assert np.array_equal(np.array([t for _, _, t in tr]), z[case + "_tr_t"])
+    raw = sa.raw_count_matrices(tr, grid, alphabet, bool(z[case + "_reverse"]))
+    assert np.array_equal(raw, raw_ref)
+    prior = sa.count_prior_matrices(z[case + "_Q0"], grid)
+    assert np.allclose(prior, z[case + "_prior"], rtol=1e-12, atol=1e-15)
+    mixed = sa.mixed_count_matrices(raw, z[case + "_prior"], z[case + "_site_rates"], grid, float(z[case + "_lambda"]))
+    cc, tt, init = sa.compactify(mixed, grid, z[case + "_Q0"], z[case + "_site_rates"])
+    assert cc.shape == z[case + "_counts"].shape
+    assert np.array_equal(tt, z[case + "_times"])
+    assert np.array_equal(init, z[case + "_init"])
+    assert np.allclose(cc, z[case + "_counts"], rtol=1e-14, atol=0)
