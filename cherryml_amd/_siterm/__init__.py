@@ -6,3 +6,4 @@ from ._assembly import (  # noqa: F401
     get_edge_transitions,
     get_raw_count_matrices,
 )
+from ._site_rates import compute_optimal_site_rates  # noqa: F401

@@ -22,6 +22,7 @@
 #include "train_large.hip.h"
 #include "general_small.hip.h"
 #include "counting.hip.h"
+#include "ble.hip.h"
 
 #define CB_ABI_VERSION 1
 
@@ -1548,5 +1549,183 @@ extern "C" int cb_siterm_assemble(int device, int S, int B, int n_sites, const d
   for (void *q : {d_grid, d_seqs, d_pairs, d_rates, d_prior, d_live, d_counts_own})
     if (q) (void)hipFree(q);
   return rc;
+}
+
+// ----------------------------------------------------------------- FastCherries BLE (8f #3)
+extern "C" int cb_ble_log_bank(int device, int S, int T, int R, const double *Q, const double *pi,
+                               const double *grid, const double *rates, double *logP) {
+  if (!Q || !grid || !rates || !logP) return fail(CB_EINVAL, "cb_ble_log_bank: NULL argument");
+  if (S < 2 || T < 1 || R < 1) return fail(CB_EINVAL, "cb_ble_log_bank: bad sizes");
+  const size_t nb = (size_t)T * R, SS = (size_t)S * S;
+  std::vector<double> tt(nb), ones(nb * SS, 1.0);
+  for (int t = 0; t < T; ++t)
+    for (int r = 0; r < R; ++r) tt[(size_t)t * R + r] = grid[t] * rates[r];   // as io_helpers.cpp:161
+  cb_handle h = nullptr;
+  int rc = cb_create(device, S, 1, (int)nb, tt.data(), ones.data(), 0, &h);
+  if (rc != CB_OK) return rc;
+  rc = cb_expm_bank(h, Q, pi, 0, logP);
+  cb_destroy(h);
+  if (rc != CB_OK) return rc;
+  for (size_t i = 0; i < nb * SS; ++i) logP[i] = std::log(logP[i]);
+  return CB_OK;
+}
+
+namespace {
+struct BleDev {
+  std::vector<void *> ptrs;
+  ~BleDev() {
+    for (void *p : ptrs)
+      if (p) (void)hipFree(p);
+  }
+  template <typename T>
+  T *up(const T *host, size_t count, int &rc) {
+    void *q = nullptr;
+    if (rc != CB_OK) return nullptr;
+    if (hipMalloc(&q, (count ? count : 1) * sizeof(T)) != hipSuccess) {
+      rc = fail(CB_ENOMEM, "ble: device allocation failed");
+      return nullptr;
+    }
+    ptrs.push_back(q);
+    if (host && count && hipMemcpyAsync(q, host, count * sizeof(T), hipMemcpyHostToDevice, 0) != hipSuccess)
+      rc = fail(CB_EHIP, "ble: upload failed");
+    return static_cast<T *>(q);
+  }
+};
+int ble_check(int device, int S, int T, int R, int n, int L, const int8_t *cx, const int8_t *cy) {
+  if (S < 2 || S > 127 || T < 1 || R < 1 || n < 1 || L < 1) return fail(CB_EINVAL, "ble: bad sizes");
+  const int ndev = cb_device_count();
+  if (ndev <= 0) return fail(CB_EHIP, "ble: no HIP device visible");
+  if (device < 0 || device >= ndev) return fail(CB_EINVAL, "ble: device %d out of range", device);
+  for (size_t i = 0; i < (size_t)n * L; ++i)
+    if (cx[i] >= S || cy[i] >= S) return fail(CB_EINVAL, "ble: state code out of range");
+  return CB_OK;
+}
+}  // namespace
+
+extern "C" int cb_ble_branch_lengths(int device, int S, int T, int R, const double *logP, const int8_t *cx,
+                                     const int8_t *cy, int n, int L, const int *site_to_rate, int *lengths_index) {
+  if (!logP || !cx || !cy || !site_to_rate || !lengths_index) return fail(CB_EINVAL, "cb_ble_branch_lengths: NULL argument");
+  int rc = ble_check(device, S, T, R, n, L, cx, cy);
+  if (rc != CB_OK) return rc;
+  for (int i = 0; i < L; ++i)
+    if (site_to_rate[i] < 0 || site_to_rate[i] >= R) return fail(CB_EINVAL, "cb_ble_branch_lengths: rate index out of range");
+  HIP_TRY(hipSetDevice(device));
+  BleDev d;
+  const double *dP = d.up(logP, (size_t)T * R * S * S, rc);
+  const int8_t *dx = d.up(cx, (size_t)n * L, rc), *dy = d.up(cy, (size_t)n * L, rc);
+  const int *ds = d.up(site_to_rate, L, rc);
+  int *dout = d.up<int>(nullptr, n, rc);
+  if (rc != CB_OK) return rc;
+  hipLaunchKernelGGL(ble_branch_lengths_kernel, dim3((n + 3) / 4), dim3(256), 0, 0, S, T, R, n, L, dP, dx, dy, ds,
+                     (const int *)nullptr, dout, (int *)nullptr);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpy(lengths_index, dout, n * sizeof(int), hipMemcpyDeviceToHost));
+  return CB_OK;
+}
+
+extern "C" int cb_ble_site_rates(int device, int S, int T, int R, const double *logP, const int8_t *cx,
+                                 const int8_t *cy, int n, int L, const int *lengths_index, const double *priors,
+                                 int *rate_index) {
+  if (!logP || !cx || !cy || !lengths_index || !priors || !rate_index) return fail(CB_EINVAL, "cb_ble_site_rates: NULL argument");
+  int rc = ble_check(device, S, T, R, n, L, cx, cy);
+  if (rc != CB_OK) return rc;
+  for (int i = 0; i < n; ++i)
+    if (lengths_index[i] < 0 || lengths_index[i] >= T) return fail(CB_EINVAL, "cb_ble_site_rates: length index out of range");
+  HIP_TRY(hipSetDevice(device));
+  BleDev d;
+  const double *dP = d.up(logP, (size_t)T * R * S * S, rc), *dpr = d.up(priors, R, rc);
+  const int8_t *dx = d.up(cx, (size_t)n * L, rc), *dy = d.up(cy, (size_t)n * L, rc);
+  const int *dl = d.up(lengths_index, n, rc);
+  int *dout = d.up<int>(nullptr, L, rc);
+  if (rc != CB_OK) return rc;
+  hipLaunchKernelGGL(ble_site_rates_kernel, dim3((L + 3) / 4), dim3(256), 0, 0, S, T, R, n, L, dP, dx, dy, dl, dpr, dout);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpy(rate_index, dout, L * sizeof(int), hipMemcpyDeviceToHost));
+  return CB_OK;
+}
+
+extern "C" int cb_ble(int device, int S, int T, int R, const double *logP, const int8_t *cx, const int8_t *cy, int n,
+                      int L, const int8_t *all_seqs, int n_seqs, const double *rates, const double *weights,
+                      int max_iters, int *lengths_index, int *rate_index) {
+  if (!logP || !cx || !cy || !all_seqs || !rates || !weights || !lengths_index || !rate_index)
+    return fail(CB_EINVAL, "cb_ble: NULL argument");
+  int rc = ble_check(device, S, T, R, n, L, cx, cy);
+  if (rc != CB_OK) return rc;
+  if (n_seqs < 1 || max_iters < 0) return fail(CB_EINVAL, "cb_ble: bad sizes");
+  // ---- initial site-rate bins (branch_length_estimation.cpp:10-58): sites ordered by the number of
+  //      differing sequence pairs (ties: site index); the i-th site of that order gets category rc,
+  //      rc advancing while i >= round(weights[rc] * L)
+  std::vector<int> s2r(L, 0);
+  {
+    std::vector<long long> cnt((size_t)L * S, 0);
+    for (int i = 0; i < n_seqs; ++i)
+      for (int j = 0; j < L; ++j) {
+        const int v = all_seqs[(size_t)i * L + j];
+        if (v >= S) return fail(CB_EINVAL, "cb_ble: state code out of range");
+        if (v >= 0) cnt[(size_t)j * S + v] += 1;
+      }
+    std::vector<std::pair<long long, int>> order(L);
+    for (int j = 0; j < L; ++j) {
+      long long non_missing = 0, total = 0;
+      for (int k = 0; k < S; ++k) non_missing += cnt[(size_t)j * S + k];
+      for (int k = 0; k < S; ++k) total += (non_missing - cnt[(size_t)j * S + k]) * cnt[(size_t)j * S + k];
+      order[j] = {total, j};
+    }
+    std::sort(order.begin(), order.end());
+    std::vector<long long> w(R);
+    for (int r = 0; r < R; ++r) w[r] = (long long)std::llround(weights[r] * L);
+    int cat = 0;
+    for (int i = 0; i < L; ++i) {
+      if (cat < R && i >= w[cat]) ++cat;
+      s2r[order[i].second] = cat < R ? cat : R - 1;
+    }
+  }
+  std::vector<double> priors(R);
+  for (int r = 0; r < R; ++r) priors[r] = 2 * std::log(rates[r]) - 3 * rates[r];   // :199-203
+  HIP_TRY(hipSetDevice(device));
+  BleDev d;
+  const double *dP = d.up(logP, (size_t)T * R * S * S, rc), *dpr = d.up(priors.data(), R, rc);
+  const int8_t *dx = d.up(cx, (size_t)n * L, rc), *dy = d.up(cy, (size_t)n * L, rc);
+  int *ds = d.up(s2r.data(), L, rc);
+  int *dl0 = d.up<int>(nullptr, n, rc), *dl1 = d.up<int>(nullptr, n, rc), *dflag = d.up<int>(nullptr, 1, rc);
+  if (rc != CB_OK) return rc;
+  const dim3 gb((n + 3) / 4), gs((L + 3) / 4), blk(256);
+  hipLaunchKernelGGL(ble_branch_lengths_kernel, gb, blk, 0, 0, S, T, R, n, L, dP, dx, dy, (const int *)ds,
+                     (const int *)nullptr, dl0, (int *)nullptr);
+  bool match = false;
+  while (!match && max_iters) {
+    HIP_TRY(hipMemsetAsync(dflag, 0, sizeof(int), 0));
+    hipLaunchKernelGGL(ble_site_rates_kernel, gs, blk, 0, 0, S, T, R, n, L, dP, dx, dy, (const int *)dl0, dpr, ds);
+    hipLaunchKernelGGL(ble_branch_lengths_kernel, gb, blk, 0, 0, S, T, R, n, L, dP, dx, dy, (const int *)ds,
+                       (const int *)dl0, dl1, dflag);
+    int flag = 0;
+    HIP_TRY(hipMemcpy(&flag, dflag, sizeof flag, hipMemcpyDeviceToHost));
+    match = flag == 0;
+    std::swap(dl0, dl1);
+    --max_iters;
+  }
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpy(lengths_index, dl0, n * sizeof(int), hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(rate_index, ds, L * sizeof(int), hipMemcpyDeviceToHost));
+  return CB_OK;
+}
+
+extern "C" int cb_site_rate_gather(int device, int S, int R, int n, int L, const double *tens, const int8_t *cx,
+                                   const int8_t *cy, const double *log_prior, int *best) {
+  if (!tens || !cx || !cy || !log_prior || !best) return fail(CB_EINVAL, "cb_site_rate_gather: NULL argument");
+  int rc = ble_check(device, S, 1, R, n, L, cx, cy);
+  if (rc != CB_OK) return rc;
+  for (size_t i = 0; i < (size_t)n * L; ++i)
+    if (cx[i] < 0 || cy[i] < 0) return fail(CB_EINVAL, "cb_site_rate_gather: negative state code (map gaps to a state)");
+  HIP_TRY(hipSetDevice(device));
+  BleDev d;
+  const double *dt = d.up(tens, (size_t)R * n * S * S, rc), *dpr = d.up(log_prior, R, rc);
+  const int8_t *dx = d.up(cx, (size_t)n * L, rc), *dy = d.up(cy, (size_t)n * L, rc);
+  int *dout = d.up<int>(nullptr, L, rc);
+  if (rc != CB_OK) return rc;
+  hipLaunchKernelGGL(site_rate_gather_kernel, dim3((L + 3) / 4), dim3(256), 0, 0, S, R, n, L, dt, dx, dy, dpr, dout);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpy(best, dout, L * sizeof(int), hipMemcpyDeviceToHost));
+  return CB_OK;
 }
 

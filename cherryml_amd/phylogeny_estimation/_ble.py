@@ -1,0 +1,103 @@
+"""Python face of cb_ble_* (csrc/ble.hip.h).  Reference:
+cherryml/phylogeny_estimation/FastCherries/branch_length_estimation.cpp (get_branch_lengths :60-103,
+get_site_rates :105-144, ble :146-241) and io_helpers.cpp:150-174 (the log-transition bank).
+Sequences are integer arrays [n, L] with -1 for gaps / unknown states."""
+from typing import Optional, Sequence, Tuple
+
+import numpy as np
+
+from .. import _lib
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def _i8(a):
+    a = np.asarray(a)
+    if a.size and (a.min() < -1 or a.max() > 126):
+        raise ValueError("state codes must be in [-1, 126]")
+    return np.ascontiguousarray(a, dtype=np.int8)
+
+
+def rate_priors(rate_categories) -> np.ndarray:
+    """log density of Gamma(shape 3, rate 3) up to a constant (:199-203)."""
+    r = _f64(rate_categories)
+    return 2.0 * np.log(r) - 3.0 * r
+
+
+def compute_log_transition_matrices(Q, quantization_points, rate_categories, device: int = 0,
+                                    stationary_distribution: Optional[np.ndarray] = None) -> np.ndarray:
+    """log expm(t_i * rate_r * Q) for every grid point and rate category: [T, R, S, S]
+    (`read_rate_compute_log_transition_matrices`, io_helpers.cpp:150-174), computed by the expm bank
+    of this library: spectral kernels when Q is reversible w.r.t. `stationary_distribution` (pass it
+    to assert that), else the general scaling-and-squaring kernels."""
+    Q, grid, rates = _f64(Q), _f64(quantization_points), _f64(rate_categories)
+    S = Q.shape[0]
+    out = np.empty((grid.size, rates.size, S, S))
+    pi = None
+    if stationary_distribution is not None:
+        pi = _f64(stationary_distribution)
+        flux = pi[:, None] * Q
+        if not np.allclose(flux, flux.T, rtol=1e-9, atol=1e-12 * np.abs(flux).max()):
+            raise ValueError("Q is not reversible with respect to the given stationary distribution")
+    rc = _lib.load().cb_ble_log_bank(device, S, grid.size, rates.size, Q.ctypes.data,
+                                     None if pi is None else pi.ctypes.data, grid.ctypes.data,
+                                     rates.ctypes.data, out.ctypes.data)
+    _lib.check(rc, "cb_ble_log_bank")
+    return out
+
+
+def _shapes(cx, cy, logP):
+    cx, cy, logP = _i8(cx), _i8(cy), _f64(logP)
+    if cx.shape != cy.shape or cx.ndim != 2 or logP.ndim != 4 or logP.shape[2] != logP.shape[3]:
+        raise ValueError("cherries must be two [n, L] arrays and the bank [T, R, S, S]")
+    return cx, cy, logP
+
+
+def branch_lengths(cx, cy, log_transition_matrices, site_to_rate_index, device: int = 0) -> np.ndarray:
+    """`get_branch_lengths` (:60-103): grid index of the ML total length of every cherry."""
+    cx, cy, logP = _shapes(cx, cy, log_transition_matrices)
+    T, R, S, _ = logP.shape
+    n, L = cx.shape
+    s2r = np.ascontiguousarray(site_to_rate_index, dtype=np.int32)
+    out = np.zeros(n, dtype=np.int32)
+    rc = _lib.load().cb_ble_branch_lengths(device, S, T, R, logP.ctypes.data, cx.ctypes.data, cy.ctypes.data, n, L,
+                                           s2r.ctypes.data, out.ctypes.data)
+    _lib.check(rc, "cb_ble_branch_lengths")
+    return out
+
+
+def site_rates(cx, cy, log_transition_matrices, lengths_index, priors, device: int = 0) -> np.ndarray:
+    """`get_site_rates` (:105-144): rate-category index of every site."""
+    cx, cy, logP = _shapes(cx, cy, log_transition_matrices)
+    T, R, S, _ = logP.shape
+    n, L = cx.shape
+    li = np.ascontiguousarray(lengths_index, dtype=np.int32)
+    pr = _f64(priors)
+    out = np.zeros(L, dtype=np.int32)
+    rc = _lib.load().cb_ble_site_rates(device, S, T, R, logP.ctypes.data, cx.ctypes.data, cy.ctypes.data, n, L,
+                                       li.ctypes.data, pr.ctypes.data, out.ctypes.data)
+    _lib.check(rc, "cb_ble_site_rates")
+    return out
+
+
+def estimate_branch_lengths_and_site_rates(cx, cy, all_sequences, log_transition_matrices,
+                                           quantization_points: Sequence[float],
+                                           rate_categories: Sequence[float],
+                                           weights_for_initial_site_rates: Sequence[float],
+                                           max_iters: int, device: int = 0) -> Tuple[np.ndarray, np.ndarray]:
+    """`ble` (:146-241): (cherry lengths [n], site rates [L]) as values of the grid / categories."""
+    cx, cy, logP = _shapes(cx, cy, log_transition_matrices)
+    T, R, S, _ = logP.shape
+    n, L = cx.shape
+    seqs = _i8(all_sequences)
+    grid, rates, w = _f64(quantization_points), _f64(rate_categories), _f64(weights_for_initial_site_rates)
+    if seqs.ndim != 2 or seqs.shape[1] != L or grid.size != T or rates.size != R or w.size != R:
+        raise ValueError("inconsistent shapes")
+    li, ri = np.zeros(n, dtype=np.int32), np.zeros(L, dtype=np.int32)
+    rc = _lib.load().cb_ble(device, S, T, R, logP.ctypes.data, cx.ctypes.data, cy.ctypes.data, n, L, seqs.ctypes.data,
+                            seqs.shape[0], rates.ctypes.data, w.ctypes.data, int(max_iters), li.ctypes.data,
+                            ri.ctypes.data)
+    _lib.check(rc, "cb_ble")
+    return grid[li], rates[ri]

@@ -238,6 +238,33 @@ int cb_siterm_assemble(int device, int S, int B, int n_sites, const double *grid
                        const double *site_rates, const double *prior, double lambda,
                        int include_reverse, int flags, double *counts);
 
+/* ---- FastCherries branch lengths / site rates of ONE family -----------------------
+ * Replaces cherryml/phylogeny_estimation/FastCherries/branch_length_estimation.cpp
+ * (get_branch_lengths :60-103, get_site_rates :105-144, ble :146-241, initial bins :10-58) and the
+ * bank of io_helpers.cpp:150-174.  All pointers are HOST pointers.
+ *   logP  [T][R][S][S]  log expm(grid[t] * rates[r] * Q)
+ *   cx,cy [n][L] int8   the two sequences of every cherry (state index, -1 = gap / unknown)
+ * cb_ble_log_bank fills logP through the expm bank of this library (pi != NULL: Q is reversible
+ * w.r.t. pi -> spectral kernels; NULL -> general scaling-and-squaring kernels).
+ * cb_ble_branch_lengths / cb_ble_site_rates are the two bisection passes; cb_ble is the whole
+ * coordinate ascent: initial site-rate bins from all_seqs [n_seqs][L] and the cumulative bin
+ * weights[R], then site rates <-> branch lengths until the lengths stop changing or max_iters;
+ * out: lengths_index[n] (into grid), rate_index[L] (into rates).
+ * cb_site_rate_gather: cherryml/_siterm/fast_site_rates.pyx:8-47, tens [R][n][S][S],
+ * best[L] = first r maximising log_prior[r] + sum_c tens[r][c][x][y] (states must be >= 0). */
+int cb_ble_log_bank(int device, int S, int T, int R, const double *Q, const double *pi, const double *grid,
+                    const double *rates, double *logP);
+int cb_ble_branch_lengths(int device, int S, int T, int R, const double *logP, const int8_t *cx,
+                          const int8_t *cy, int n, int L, const int *site_to_rate, int *lengths_index);
+int cb_ble_site_rates(int device, int S, int T, int R, const double *logP, const int8_t *cx,
+                      const int8_t *cy, int n, int L, const int *lengths_index, const double *priors,
+                      int *rate_index);
+int cb_ble(int device, int S, int T, int R, const double *logP, const int8_t *cx, const int8_t *cy, int n,
+           int L, const int8_t *all_seqs, int n_seqs, const double *rates, const double *weights,
+           int max_iters, int *lengths_index, int *rate_index);
+int cb_site_rate_gather(int device, int S, int R, int n, int L, const double *tens, const int8_t *cx,
+                        const int8_t *cy, const double *log_prior, int *best);
+
 #ifdef __cplusplus
 }
 #endif

@@ -196,3 +196,44 @@ def test_siterm_assembly_oracle_against_reference(case):
     assert np.array_equal(tt, z[case + "_times"])
     assert np.array_equal(init, z[case + "_init"])
     assert np.allclose(cc, z[case + "_counts"], rtol=1e-14, atol=0)
+
+
+# ---- FastCherries branch-length / site-rate estimation ------------------------
+def test_ble_oracle_known_answers_of_the_reference_tests():
+    """tests/test_branch_length_estimation.cpp: expected indices typed into the reference's tests."""
+    from oracle import ble_oracle as bo
+    z = load_golden("ble.npz")
+    bank = bo.log_bank(z["Q"], z["grid_bl"], z["rates_bl"])
+    for k in range(3):
+        got = bo.get_branch_lengths(z[f"bl{k}_x"], z[f"bl{k}_y"], bank, z["s2r_bl"])
+        assert list(got) == list(z[f"bl{k}_expected"]), k
+    bank = bo.log_bank(z["Q"], z["grid_sr"], z["rates_sr"])
+    pri = bo.rate_priors(z["rates_sr"])
+    for k in range(6):
+        x = z[f"sr{k}_x"]
+        got = bo.get_site_rates(x, z[f"sr{k}_y"], bank, z["lengths_sr"][:len(x)], pri)
+        assert list(got) == list(z[f"sr{k}_expected"]), k
+
+
+@pytest.mark.parametrize("k", [0, 1, 2])
+def test_ble_oracle_against_compiled_reference_outputs(k):
+    from oracle import ble_oracle as bo
+    z = load_golden("ble.npz")
+    rates, grid = z[f"rnd{k}_rates"], z["grid_sr"]
+    bank = bo.log_bank(z["Q"], grid, rates)
+    cx, cy = z[f"rnd{k}_x"], z[f"rnd{k}_y"]
+    assert list(bo.get_branch_lengths(cx, cy, bank, z[f"rnd{k}_s2r"])) == list(z[f"rnd{k}_bl"])
+    assert list(bo.get_site_rates(cx, cy, bank, z[f"rnd{k}_li"], bo.rate_priors(rates))) == list(z[f"rnd{k}_sr"])
+    lengths, site_rates, _, _ = bo.ble(cx, cy, np.concatenate([cx, cy]), bank, grid, rates, z[f"rnd{k}_weights"], 50)
+    assert np.array_equal(lengths, z[f"rnd{k}_ble_lengths"])
+    assert np.array_equal(site_rates, z[f"rnd{k}_ble_rates"])
+    if bo.ref_available():   # the bank itself against the reference's native Pade expm
+        assert np.allclose(bank, bo.ref_log_bank(z["Q"], grid, rates), rtol=1e-9, atol=1e-12)
+
+
+def test_siterm_site_rate_gather_oracle():
+    from oracle import ble_oracle as bo
+    z = load_golden("ble.npz")
+    got = bo.compute_optimal_site_rates(z["gather_x"], z["gather_y"], z["gather_tensor"], z["gather_grid"],
+                                        z["gather_prior"])
+    assert np.array_equal(got, z["gather_expected"])
