@@ -185,6 +185,8 @@ def main():
     ap.add_argument("--sites", type=int, default=5000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true")
+    ap.add_argument("--force-sharded", action="store_true",
+                    help="run the multi-GPU code path (torch glue + ShardedBank + collectives) even at N = 1")
     args = ap.parse_args()
 
     import torch
@@ -193,8 +195,9 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    if world > 1 or args.force_sharded:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world)
     if args.gpus != world and rank == 0 and world > 1:
         print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
@@ -215,7 +218,7 @@ def main():
         rng = np.random.default_rng(0)
         wl = make_workload(workload, args.sites, rng)
         S = wl["S"]
-        if wl["kind"] == "single" and S > 32 and world > 1:
+        if wl["kind"] == "single" and S > 32 and (world > 1 or args.force_sharded):
             # ---- co-evolution on N > 1 GPUs: torch keeps theta -> Q and Adam (the collective is
             #      torch.distributed's), HIP does loss + dL/dQ; buckets sharded over the ranks,
             #      one all-reduce of S^2 + 1 doubles per epoch
@@ -354,16 +357,27 @@ def main():
         bank.close()
         return out
 
+    def finish(out):
+        """The JSON line is the LAST thing on stdout: RCCL prints a version banner through C stdio,
+        which (on a pipe) would otherwise be flushed after Python's line at exit."""
+        if dist.is_initialized():
+            dist.destroy_process_group()
+        import ctypes
+        try:
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        if rank == 0:
+            sys.stdout.write(json.dumps(out) + "\n")
+            sys.stdout.flush()
+
     defaults = {"coevo400": (50, 5), "lg20": (500, 50), "siterm": (5, 1), "counting": (20, 3)}
     steps = args.steps if args.steps is not None else defaults[args.workload][0]
     warmup = args.warmup if args.warmup is not None else defaults[args.workload][1]
     if args.workload == "counting":
         out = run_counting(steps, warmup, world, rank, local_rank, fence,
                            world == 1 and not args.no_cpu_baseline)
-        if rank == 0:
-            print(json.dumps(out))
-        if world > 1:
-            dist.destroy_process_group()
+        finish(out)
         return
     out = run(args.workload, steps, warmup, world == 1 and not args.no_cpu_baseline)
     if (rank == 0 and world == 1 and args.workload == "coevo400" and not args.no_secondary
@@ -372,10 +386,7 @@ def main():
         sec = run("lg20", *defaults["lg20"], not args.no_cpu_baseline)
         out["secondary"] = {k: sec[k] for k in ("value", "unit", "ms_per_step", "steps", "config",
                                                 "roofline", "cpu_baseline") if k in sec}
-    if rank == 0:
-        print(json.dumps(out))
-    if world > 1:
-        dist.destroy_process_group()
+    finish(out)
 
 
 def run_counting(steps, warmup, world, rank, local_rank, fence, with_cpu):

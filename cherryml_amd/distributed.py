@@ -31,7 +31,7 @@ class _ShardedLoss(torch.autograd.Function):
     def forward(ctx, Q, pi, evaluate, inv_n, group):
         loss, dQ = evaluate(Q.detach(), pi.detach())  # unnormalised partial sums
         packed = torch.cat([loss.reshape(-1), dQ.reshape(-1)]).to(torch.float64)
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        if dist.is_available() and dist.is_initialized():
             dist.all_reduce(packed, op=dist.ReduceOp.SUM, group=group)
         packed = packed * inv_n
         nl = loss.numel()
@@ -102,7 +102,7 @@ class ShardedBank:
         owner_major = [bucket_shard(B, r, self.world) for r in range(self.world)]
         mine = owner_major[self.rank]
         total = Ct.sum().reshape(1)
-        if self.world > 1:
+        if on:
             packed = torch.zeros((self.world * chunk, S, S), dtype=torch.float64, device=Ct.device)
             for r, idx in enumerate(owner_major):
                 packed[r * chunk:r * chunk + idx.size] = Ct[torch.as_tensor(idx, device=Ct.device)]

@@ -408,3 +408,23 @@ def test_fused_trainers_with_empty_buckets():
     a = qvec(counts, times, num_epochs=E, initialization=s["init"], device="cuda", fused=True)
     assert np.allclose(a["loss_per_epoch_per_site"], ref["loss_per_epoch_per_site"], rtol=1e-8, atol=0)
     assert relerr(a["res"], ref["res"]) < 1e-6
+
+
+def test_sharded_bank_from_rank_counts_on_device_tensor():
+    """The multi-GPU constructor with this rank's counts already on the GPU (world = 1: no process
+    group; the N > 1 collectives are covered by the gloo tests and by `bench.py --force-sharded`)."""
+    from cherryml_amd.distributed import ShardedBank
+    from oracle import ratelearn_oracle as orc
+    g = load_golden("traj_lgbank.npz")
+    t, C = g["t"][::4], g["C"][::4]
+    sb = ShardedBank.from_rank_counts(t, torch.tensor(C, device="cuda"))
+    Q = torch.tensor(g["init"], dtype=torch.float64, device="cuda", requires_grad=True)
+    pi = torch.tensor(orc.stationary_distribution(g["init"]), device="cuda")
+    loss = sb.loss(Q, pi, normalize=True)[0]
+    loss.backward()
+    Qr = torch.tensor(g["init"], dtype=torch.float64, requires_grad=True)
+    ref = orc.bank_loss(Qr, torch.tensor(t), torch.tensor(C))
+    ref.backward()
+    assert abs(loss.item() - ref.item()) < 1e-12 * abs(ref.item())
+    assert relerr(Q.grad.cpu().numpy(), Qr.grad.numpy()) < 1e-10
+    sb.close()
