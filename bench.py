@@ -181,7 +181,7 @@ def main():
     ap.add_argument("--steps", type=int, default=None)
     ap.add_argument("--warmup", type=int, default=None)
     ap.add_argument("--workload", default="coevo400",
-                    choices=["coevo400", "lg20", "siterm", "counting"])
+                    choices=["coevo400", "lg20", "siterm", "counting", "ble"])
     ap.add_argument("--sites", type=int, default=5000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true")
@@ -371,9 +371,12 @@ def main():
             sys.stdout.write(json.dumps(out) + "\n")
             sys.stdout.flush()
 
-    defaults = {"coevo400": (50, 5), "lg20": (500, 50), "siterm": (5, 1), "counting": (20, 3)}
+    defaults = {"coevo400": (50, 5), "lg20": (500, 50), "siterm": (5, 1), "counting": (20, 3), "ble": (5, 1)}
     steps = args.steps if args.steps is not None else defaults[args.workload][0]
     warmup = args.warmup if args.warmup is not None else defaults[args.workload][1]
+    if args.workload == "ble":
+        finish(run_ble(steps, warmup, world, rank, local_rank, fence, world == 1 and not args.no_cpu_baseline))
+        return
     if args.workload == "counting":
         out = run_counting(steps, warmup, world, rank, local_rank, fence,
                            world == 1 and not args.no_cpu_baseline)
@@ -492,6 +495,88 @@ def run_counting(steps, warmup, world, rank, local_rank, fence, with_cpu):
         out["cpu_baseline"] = {"value": float(C.sum()) / cdt, "unit": "cherry-pairs/s", "cores": 1,
                                "kind": "port", "sample": f"{npairs} of {len(pairs)} cherries x {L} sites, "
                                "the oracle's per-site loop (the reference's Python counter)"}
+    return out
+
+
+def run_ble(steps, warmup, world, rank, local_rank, fence, with_cpu):
+    """FastCherries branch lengths / site rates (cb_ble) on one large synthetic family per rank
+    (2048 cherries x 512 sites, 129 grid points x 20 rate categories, LG): a step is one whole
+    coordinate ascent.  CPU baseline: the reference's own C++ compiled into oracle/_ref."""
+    import torch
+    import torch.distributed as dist
+    from cherryml_amd.phylogeny_estimation import compute_log_transition_matrices, estimate_branch_lengths_and_site_rates
+    rng = np.random.default_rng(100 + rank)
+    n, L, R = 2048, 512, 20
+    Q = lg_matrix()
+    grid = quantization_grid()
+    rates = np.geomspace(1.0 / R, float(R), R)
+    weights = np.arange(1, R + 1) / R
+    bank = compute_log_transition_matrices(Q, grid, rates, device=local_rank, stationary_distribution=stationary(Q))
+    true_rate = rng.choice(R, size=L, p=np.diff(np.concatenate([[0.0], weights])))
+    t_idx = rng.integers(40, 100, size=n)
+    anc = rng.integers(0, 20, size=(n, L))
+    cy = anc.copy()
+    cum = np.cumsum(np.exp(bank), axis=3)               # [T,R,S,S] row-wise cdf
+    u = rng.random((n, L))
+    rows = cum[t_idx[:, None], true_rate[None, :], anc]  # [n,L,S]
+    cy = (u[:, :, None] > rows).sum(axis=2).clip(0, 19)
+    cx = anc.copy()
+    gaps = rng.random((2, n, L)) < 0.05
+    cx[gaps[0]] = -1
+    cy[gaps[1]] = -1
+    seqs = np.concatenate([cx, cy])
+    prof = {}
+    call = lambda: estimate_branch_lengths_and_site_rates(cx, cy, seqs, bank, grid, rates, weights, 50,  # noqa: E731
+                                                          device=local_rank, profile=prof)
+    for _ in range(warmup):
+        call()
+    fence()
+    kms, iters = [], []
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        lengths, srates = call()
+        kms.append(prof["kernel_ms"])
+        iters.append(prof["iterations"])
+    fence()
+    dt = time.perf_counter() - t0
+    kernel_ms = float(np.mean(kms))
+    if world > 1:
+        tdt = torch.tensor([kernel_ms], dtype=torch.float64, device=torch.device("cuda", local_rank))
+        dist.all_reduce(tdt, op=dist.ReduceOp.MAX)
+        kernel_ms = float(tdt.item())
+    if rank != 0:
+        return None
+    valid = int(((cx >= 0) & (cy >= 0)).sum())
+    passes = 1 + 2 * int(np.mean(iters))                # first branch-length pass + 2 per iteration
+    # bytes a pass must at least touch: both code bytes of every cherry x site, per bisection step
+    steps_bl, steps_sr = int(np.ceil(np.log2(len(grid)))), int(np.ceil(np.log2(R)))
+    nbytes = 2.0 * n * L * (steps_bl * (1 + int(np.mean(iters))) + steps_sr * int(np.mean(iters)))
+    out = {
+        "metric": "cherry-pairs/sec (whole node): cherry x site pairs fitted per coordinate ascent",
+        "value": valid * world / (kernel_ms * 1e-3), "unit": "cherry-pairs/s", "n_gpus": world, "steps": steps,
+        "warmup": warmup, "ms_per_step": kernel_ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f64", "data": "synthetic",
+        "config": {"workload": f"FastCherries branch lengths + site rates: {n} cherries x {L} sites per GPU, "
+                               f"129 grid points x {R} rate categories, LG", "iterations": int(np.mean(iters)),
+                   "sharding": f"families x{world} (no collective)",
+                   "host_ms_per_call_including_uploads": dt / steps * 1e3},
+        "roofline": {"bound": "hbm", "kernel": "ble_branch_lengths_kernel + ble_site_rates_kernel", "achieved":
+                     nbytes / (kernel_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": nbytes / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                     "bytes_per_step": nbytes, "passes": passes,
+                     "note": "gathers from the L2-resident 8 MB log-transition bank; algorithmic bytes = the "
+                             "sequence codes re-read at every bisection step"},
+    }
+    if with_cpu:
+        from oracle import ble_oracle as bo
+        if bo.ref_available():
+            sub = 256                                    # bounded sample: the first 256 cherries
+            t0 = time.perf_counter()
+            bo.ref_ble(cx[:sub], cy[:sub], np.concatenate([cx[:sub], cy[:sub]]), bank, grid, rates, weights, 50)
+            dtc = (time.perf_counter() - t0) * (n / sub)
+            out["cpu_baseline"] = dict(value=valid / dtc, unit="cherry-pairs/s", cores=1, kind="reference",
+                                       sample=f"the reference's ble() (oracle/_ref/libref_ble.so) on {sub} of {n} "
+                                              "cherries, scaled", seconds_per_step=dtc)
     return out
 
 

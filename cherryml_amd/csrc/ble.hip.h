@@ -42,10 +42,12 @@ __global__ __launch_bounds__(256) void ble_branch_lengths_kernel(
   }
 }
 
-// out[s] = rate category maximising prior[r] + sum_cherries (logP[len(c)][r][x][y] + logP[..][y][x])
+// out[s] = rate category maximising prior[r] + sum_cherries (logP[len(c)][r][x][y] + logP[..][y][x]).
+// cxT / cyT are the SITE-major copies [L][n] of the cherries, so that the lanes (consecutive
+// cherries of one site) read consecutive bytes.
 __global__ __launch_bounds__(256) void ble_site_rates_kernel(
-    int S, int T, int R, int n, int L, const double *__restrict__ logP, const int8_t *__restrict__ cx,
-    const int8_t *__restrict__ cy, const int *__restrict__ lengths_index, const double *__restrict__ priors,
+    int S, int T, int R, int n, int L, const double *__restrict__ logP, const int8_t *__restrict__ cxT,
+    const int8_t *__restrict__ cyT, const int *__restrict__ lengths_index, const double *__restrict__ priors,
     int *__restrict__ out) {
   const int s = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (s >= L) return;
@@ -55,7 +57,7 @@ __global__ __launch_bounds__(256) void ble_site_rates_kernel(
     const int mid = low + (high - low) / 2;
     double a = 0.0, b = 0.0;
     for (int i = lane; i < n; i += 64) {
-      const int xi = cx[(size_t)i * L + s], yi = cy[(size_t)i * L + s];
+      const int xi = cxT[(size_t)s * n + i], yi = cyT[(size_t)s * n + i];
       if (xi < 0 || yi < 0) continue;
       const double *M = logP + (size_t)lengths_index[i] * RSS + (size_t)mid * SS;
       a += M[xi * S + yi] + M[yi * S + xi];

@@ -1591,6 +1591,12 @@ struct BleDev {
     return static_cast<T *>(q);
   }
 };
+std::vector<int8_t> ble_transposed(const int8_t *c, int n, int L) {
+  std::vector<int8_t> t((size_t)n * L);
+  for (int i = 0; i < n; ++i)
+    for (int s = 0; s < L; ++s) t[(size_t)s * n + i] = c[(size_t)i * L + s];
+  return t;
+}
 int ble_check(int device, int S, int T, int R, int n, int L, const int8_t *cx, const int8_t *cy) {
   if (S < 2 || S > 127 || T < 1 || R < 1 || n < 1 || L < 1) return fail(CB_EINVAL, "ble: bad sizes");
   const int ndev = cb_device_count();
@@ -1633,12 +1639,14 @@ extern "C" int cb_ble_site_rates(int device, int S, int T, int R, const double *
     if (lengths_index[i] < 0 || lengths_index[i] >= T) return fail(CB_EINVAL, "cb_ble_site_rates: length index out of range");
   HIP_TRY(hipSetDevice(device));
   BleDev d;
+  const std::vector<int8_t> xT = ble_transposed(cx, n, L), yT = ble_transposed(cy, n, L);
   const double *dP = d.up(logP, (size_t)T * R * S * S, rc), *dpr = d.up(priors, R, rc);
-  const int8_t *dx = d.up(cx, (size_t)n * L, rc), *dy = d.up(cy, (size_t)n * L, rc);
+  const int8_t *dxT = d.up(xT.data(), (size_t)n * L, rc), *dyT = d.up(yT.data(), (size_t)n * L, rc);
   const int *dl = d.up(lengths_index, n, rc);
   int *dout = d.up<int>(nullptr, L, rc);
   if (rc != CB_OK) return rc;
-  hipLaunchKernelGGL(ble_site_rates_kernel, dim3((L + 3) / 4), dim3(256), 0, 0, S, T, R, n, L, dP, dx, dy, dl, dpr, dout);
+  HIP_TRY(hipStreamSynchronize(0));  // xT / yT are locals
+  hipLaunchKernelGGL(ble_site_rates_kernel, dim3((L + 3) / 4), dim3(256), 0, 0, S, T, R, n, L, dP, dxT, dyT, dl, dpr, dout);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipMemcpy(rate_index, dout, L * sizeof(int), hipMemcpyDeviceToHost));
   return CB_OK;
@@ -1646,7 +1654,7 @@ extern "C" int cb_ble_site_rates(int device, int S, int T, int R, const double *
 
 extern "C" int cb_ble(int device, int S, int T, int R, const double *logP, const int8_t *cx, const int8_t *cy, int n,
                       int L, const int8_t *all_seqs, int n_seqs, const double *rates, const double *weights,
-                      int max_iters, int *lengths_index, int *rate_index) {
+                      int max_iters, int *lengths_index, int *rate_index, int *iterations, double *kernel_ms) {
   if (!logP || !cx || !cy || !all_seqs || !rates || !weights || !lengths_index || !rate_index)
     return fail(CB_EINVAL, "cb_ble: NULL argument");
   int rc = ble_check(device, S, T, R, n, L, cx, cy);
@@ -1685,17 +1693,28 @@ extern "C" int cb_ble(int device, int S, int T, int R, const double *logP, const
   HIP_TRY(hipSetDevice(device));
   BleDev d;
   const double *dP = d.up(logP, (size_t)T * R * S * S, rc), *dpr = d.up(priors.data(), R, rc);
+  const std::vector<int8_t> xT = ble_transposed(cx, n, L), yT = ble_transposed(cy, n, L);
   const int8_t *dx = d.up(cx, (size_t)n * L, rc), *dy = d.up(cy, (size_t)n * L, rc);
+  const int8_t *dxT = d.up(xT.data(), (size_t)n * L, rc), *dyT = d.up(yT.data(), (size_t)n * L, rc);
   int *ds = d.up(s2r.data(), L, rc);
   int *dl0 = d.up<int>(nullptr, n, rc), *dl1 = d.up<int>(nullptr, n, rc), *dflag = d.up<int>(nullptr, 1, rc);
   if (rc != CB_OK) return rc;
   const dim3 gb((n + 3) / 4), gs((L + 3) / 4), blk(256);
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  if (kernel_ms) {
+    HIP_TRY(hipEventCreate(&ev0));
+    HIP_TRY(hipEventCreate(&ev1));
+    HIP_TRY(hipStreamSynchronize(0));  // uploads done: the timed region starts with resident inputs
+    HIP_TRY(hipEventRecord(ev0, 0));
+  }
   hipLaunchKernelGGL(ble_branch_lengths_kernel, gb, blk, 0, 0, S, T, R, n, L, dP, dx, dy, (const int *)ds,
                      (const int *)nullptr, dl0, (int *)nullptr);
   bool match = false;
+  int iters = 0;
   while (!match && max_iters) {
+    ++iters;
     HIP_TRY(hipMemsetAsync(dflag, 0, sizeof(int), 0));
-    hipLaunchKernelGGL(ble_site_rates_kernel, gs, blk, 0, 0, S, T, R, n, L, dP, dx, dy, (const int *)dl0, dpr, ds);
+    hipLaunchKernelGGL(ble_site_rates_kernel, gs, blk, 0, 0, S, T, R, n, L, dP, dxT, dyT, (const int *)dl0, dpr, ds);
     hipLaunchKernelGGL(ble_branch_lengths_kernel, gb, blk, 0, 0, S, T, R, n, L, dP, dx, dy, (const int *)ds,
                        (const int *)dl0, dl1, dflag);
     int flag = 0;
@@ -1704,6 +1723,16 @@ extern "C" int cb_ble(int device, int S, int T, int R, const double *logP, const
     std::swap(dl0, dl1);
     --max_iters;
   }
+  if (kernel_ms) {
+    float ms = 0.f;
+    HIP_TRY(hipEventRecord(ev1, 0));
+    HIP_TRY(hipEventSynchronize(ev1));
+    HIP_TRY(hipEventElapsedTime(&ms, ev0, ev1));
+    *kernel_ms = ms;
+    (void)hipEventDestroy(ev0);
+    (void)hipEventDestroy(ev1);
+  }
+  if (iterations) *iterations = iters;
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipMemcpy(lengths_index, dl0, n * sizeof(int), hipMemcpyDeviceToHost));
   HIP_TRY(hipMemcpy(rate_index, ds, L * sizeof(int), hipMemcpyDeviceToHost));

@@ -86,8 +86,10 @@ def estimate_branch_lengths_and_site_rates(cx, cy, all_sequences, log_transition
                                            quantization_points: Sequence[float],
                                            rate_categories: Sequence[float],
                                            weights_for_initial_site_rates: Sequence[float],
-                                           max_iters: int, device: int = 0) -> Tuple[np.ndarray, np.ndarray]:
-    """`ble` (:146-241): (cherry lengths [n], site rates [L]) as values of the grid / categories."""
+                                           max_iters: int, device: int = 0, profile: Optional[dict] = None
+                                           ) -> Tuple[np.ndarray, np.ndarray]:
+    """`ble` (:146-241): (cherry lengths [n], site rates [L]) as values of the grid / categories.
+    `profile` (a dict) receives `iterations` and `kernel_ms` (GPU time of the ascent, HIP events)."""
     cx, cy, logP = _shapes(cx, cy, log_transition_matrices)
     T, R, S, _ = logP.shape
     n, L = cx.shape
@@ -96,8 +98,12 @@ def estimate_branch_lengths_and_site_rates(cx, cy, all_sequences, log_transition
     if seqs.ndim != 2 or seqs.shape[1] != L or grid.size != T or rates.size != R or w.size != R:
         raise ValueError("inconsistent shapes")
     li, ri = np.zeros(n, dtype=np.int32), np.zeros(L, dtype=np.int32)
+    import ctypes
+    iters, ms = ctypes.c_int(0), ctypes.c_double(0.0)
     rc = _lib.load().cb_ble(device, S, T, R, logP.ctypes.data, cx.ctypes.data, cy.ctypes.data, n, L, seqs.ctypes.data,
                             seqs.shape[0], rates.ctypes.data, w.ctypes.data, int(max_iters), li.ctypes.data,
-                            ri.ctypes.data)
+                            ri.ctypes.data, ctypes.addressof(iters), ctypes.addressof(ms) if profile is not None else None)
     _lib.check(rc, "cb_ble")
+    if profile is not None:
+        profile["iterations"], profile["kernel_ms"] = iters.value, ms.value
     return grid[li], rates[ri]

@@ -261,7 +261,9 @@ int cb_ble_site_rates(int device, int S, int T, int R, const double *logP, const
                       int *rate_index);
 int cb_ble(int device, int S, int T, int R, const double *logP, const int8_t *cx, const int8_t *cy, int n,
            int L, const int8_t *all_seqs, int n_seqs, const double *rates, const double *weights,
-           int max_iters, int *lengths_index, int *rate_index);
+           int max_iters, int *lengths_index, int *rate_index, int *iterations, double *kernel_ms);
+/* iterations (may be NULL): coordinate-ascent iterations run; kernel_ms (may be NULL): GPU time of
+ * the ascent (first branch-length pass + all iterations), inputs already resident, by HIP events. */
 int cb_site_rate_gather(int device, int S, int R, int n, int L, const double *tens, const int8_t *cx,
                         const int8_t *cy, const double *log_prior, int *best);
 

@@ -8,7 +8,7 @@ set -u
 R=${GRAFT_REPO_ROOT:-$PWD}
 cd /tmp && export TMPDIR=/tmp
 TAG=${1:-final}
-for w in coevo400 lg20 siterm counting; do
+for w in coevo400 lg20 siterm counting ble; do
   rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${TAG}_trace_$w -- \
     python3 $R/bench.py --workload $w --no-cpu-baseline --no-secondary > $R/gpurun_out/${TAG}_bench_$w.log 2>&1
   for c in FETCH_SIZE WRITE_SIZE; do

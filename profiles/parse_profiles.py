@@ -25,8 +25,10 @@ names = {"k1_pt_loss_gt": "k1_pt_loss_gt", "k2_t_eq_g_u": "k2_t_eq_g_u", "k3_w_p
          "small_train_kernel": "small_train_kernel", "small_bank_kernel": "small_bank_kernel",
          "lg_prepare": "lg_prepare", "lg_bank": "lg_bank", "lg_finish": "lg_finish",
          "count_transitions_lds_kernel": "count_transitions_lds_kernel",
-         "count_reduce_slabs": "count_reduce_slabs", "k3_reduce": "k3_reduce", "k4_gemm": "k4_gemm"}
-for w in ["coevo400", "lg20", "siterm", "counting"]:
+         "count_reduce_slabs": "count_reduce_slabs", "k3_reduce": "k3_reduce", "k4_gemm": "k4_gemm",
+         "sg_gemm": "sg_gemm", "lgx_build": "lgx_build", "ble_branch_lengths_kernel": "ble_branch_lengths_kernel",
+         "ble_site_rates_kernel": "ble_site_rates_kernel"}
+for w in ["coevo400", "lg20", "siterm", "counting", "ble"]:
     st = glob.glob(f"{root}/gpurun_out/{tag}_trace_{w}/*/*_kernel_stats.csv")
     if st:
         shutil.copy(st[0], f"{here}/r01_{tag}_{w}_kernel_stats.csv")
