@@ -187,6 +187,17 @@ __device__ __forceinline__ void tr_update(const TrainArgs &a, int l, int epoch, 
   __syncthreads();
 }
 
+// The per-epoch evaluation behind a real call: inlined into the epoch loop, the optimiser state
+// that lives across it pushed the bucket loop of the 20-state instance to 256 VGPRs + 81 spilled
+// registers (~35 scratch accesses per bucket); as a callee it is allocated on its own (the plain
+// bank kernel's allocation), and the call costs one jump per epoch.
+template <int NT, int KS, int NW>
+__device__ __attribute__((noinline)) void small_site_eval_call(double *lds, int S, int B, const double *t_l,
+                                                               const double *Ct_l, double inv_n,
+                                                               const double *dirsum_l, bool warm) {
+  small_site_eval<NT, KS, NW, SMALL_LOSSGRAD>(lds, S, B, t_l, Ct_l, inv_n, dirsum_l, nullptr, true, nullptr, warm);
+}
+
 template <int NT, int KS, int NW>
 __global__ __launch_bounds__(NW * 64, 2) void small_train_kernel(TrainArgs a) {
   extern __shared__ double lds[];
@@ -202,9 +213,8 @@ __global__ __launch_bounds__(NW * 64, 2) void small_train_kernel(TrainArgs a) {
   for (int epoch = 0; epoch < a.E; ++epoch) {
     tr_build(a, l, epoch, sA, sD, sPi);
     // sV still holds the previous epoch's eigenvectors (zero padded): warm start
-    small_site_eval<NT, KS, NW, SMALL_LOSSGRAD>(lds, S, a.nlive[l], a.t + lb, a.Ct + lb * S * S, a.inv_n[l],
-                                                a.dirsum + (size_t)l * S, nullptr, true, nullptr,
-                                                epoch > 0);
+    small_site_eval_call<NT, KS, NW>(lds, S, a.nlive[l], a.t + lb, a.Ct + lb * S * S, a.inv_n[l],
+                                     a.dirsum + (size_t)l * S, epoch > 0);
     // (ends with a barrier: sG = dA, sA = A, LOSSTOT = loss)
     pow_b1 *= a.beta1;
     pow_b2 *= a.beta2;
