@@ -66,9 +66,8 @@ def write_count_matrices(count_matrices: List[Tuple[float, pd.DataFrame]], path:
             out.write(f"{q}\n")
             cols = [str(c) for c in m.columns]
             out.write("\t" + "\t".join(cols) + "\n")
-            vals = m.to_numpy()
-            for name, row in zip(m.index, vals):
-                out.write(str(name) + "\t" + "\t".join(repr(float(v)) for v in row) + "\n")
+            vals = np.asarray(m.to_numpy(), dtype=np.float64).tolist()   # Python floats: repr = shortest round trip
+            out.write("".join(str(name) + "\t" + "\t".join(map(repr, row)) + "\n" for name, row in zip(m.index, vals)))
 
 
 def _read_table(path: str) -> pd.DataFrame:
