@@ -8,6 +8,8 @@ set -u
 R=${GRAFT_REPO_ROOT:-$PWD}
 cd /tmp && export TMPDIR=/tmp
 TAG=${1:-final}
+# plain (unprofiled) default bench line first, on the fresh box, as the driver runs it
+python3 $R/bench.py > $R/gpurun_out/${TAG}_bench_default.log 2>&1
 for w in coevo400 lg20 siterm counting ble; do
   rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${TAG}_trace_$w -- \
     python3 $R/bench.py --workload $w --no-cpu-baseline --no-secondary > $R/gpurun_out/${TAG}_bench_$w.log 2>&1
@@ -16,5 +18,3 @@ for w in coevo400 lg20 siterm counting ble; do
       python3 $R/bench.py --workload $w --steps 3 --warmup 1 --no-cpu-baseline --no-secondary > /dev/null 2>&1
   done
 done
-# plain (unprofiled) default bench line
-python3 $R/bench.py > $R/gpurun_out/${TAG}_bench_default.log 2>&1
