@@ -61,6 +61,8 @@ struct cb_bank {
   double *n_dev = nullptr;   // [L]
   double *inv_n = nullptr;   // [L]  1/n
   double *ones = nullptr;    // [L]  1.0
+  double *Cq = nullptr;      // S <= 20: counts in quad order [L][nq][TS*TS][64]
+  int nq = 0;
   double *dirsum = nullptr;  // [L,S] colsum - rowsum of sum_b C
   // live buckets (C_b != 0), stored first per site; Bl = max over sites = stride of Ct / t_live
   int Bl = 0;
@@ -273,6 +275,23 @@ __global__ void bucket_mass(size_t SS, const double *C, double *mass) {
   if (threadIdx.x == 0) mass[blockIdx.x] = s[0];
 }
 
+// S <= 20: quad order.  Block (l, quad): Cq[(I*TS + J)*64 + lane] = C[l, src[l, 4 quad + blk]][4J + r][4I + q]
+// (lane = 16 q + 4 blk + r; transposed like Ct), zero where the slot / row / column does not exist.
+__global__ void pack_counts_quad(int S, int B, int Bl, int nq, int TS, const int *nlive, const int *src,
+                                 const double *C, double *Cq) {
+  const int l = blockIdx.x / nq, quad = blockIdx.x - l * nq;
+  double *dst = Cq + (size_t)blockIdx.x * TS * TS * 64;
+  for (int e = threadIdx.x; e < TS * TS * 64; e += blockDim.x) {
+    const int tile = e >> 6, lane = e & 63, I = tile / TS, J = tile - I * TS;
+    const int q = lane >> 4, blk = (lane >> 2) & 3, r = lane & 3;
+    const int k = 4 * quad + blk, row = 4 * I + q, col = 4 * J + r;
+    double v = 0.0;
+    if (k < nlive[l] && row < S && col < S)
+      v = C[((size_t)l * B + src[(size_t)l * Bl + k]) * S * S + (size_t)col * S + row];
+    dst[e] = v;
+  }
+}
+
 // small path: Ct[l,k][j][i] = C[l,src[l,k]][i][j]  for the live slots k < nlive[l]
 __global__ void transpose_small(int S, int B, int Bl, const int *nlive, const int *src, const double *C,
                                 double *Ct) {
@@ -413,6 +432,16 @@ extern "C" int cb_create(int device, int S, int L, int B, const double *t, const
                        h->n_dev, h->inv_n, h->ones, h->dirsum);
     hipLaunchKernelGGL(transpose_small, dim3((unsigned)((size_t)L * Bl)), dim3(256), 0, h->stream, S, B, Bl,
                        h->nlive, src_idx, Cdev, h->Ct);
+    if (S <= 20) {
+      const int TS = S <= 4 ? 1 : S <= 8 ? 2 : S <= 16 ? 4 : 5;   // = quad_ts(S), the kernels' instantiation
+      h->nq = (Bl + 3) / 4;
+      if ((rc = dev_alloc(h, &h->Cq, (size_t)L * h->nq * TS * TS * 64)) != CB_OK) {
+        free_tmp();
+        return cleanup(rc);
+      }
+      hipLaunchKernelGGL(pack_counts_quad, dim3((unsigned)((size_t)L * h->nq)), dim3(256), 0, h->stream, S, B, Bl,
+                         h->nq, TS, h->nlive, src_idx, Cdev, h->Cq);
+    }
   } else {
     const size_t LL = (size_t)h->LD * h->LD;
     const int tiles = ((h->LD + LG_TM - 1) / LG_TM) * ((h->LD + LG_TN - 1) / LG_TN);
@@ -501,6 +530,9 @@ extern "C" int cb_total_counts(cb_handle h, double *n) {
   memcpy(n, h->n_host.data(), h->L * sizeof(double));
   return CB_OK;
 }
+
+// tiles per side of the 4x4-tile path, as the kernel dispatch instantiates it (S <= 20)
+static int quad_ts(int S) { return S <= 4 ? 1 : S <= 8 ? 2 : S <= 16 ? 4 : 5; }
 
 // ------------------------------------------------------------- small dispatch
 template <int MODE, int NW>
@@ -793,6 +825,8 @@ extern "C" int cb_loss_grad(cb_handle h, const double *Q, const double *pi, int 
     a.nlive = h->nlive;
     a.t = h->t_live;
     a.Ct = h->Ct;
+    a.Cq = h->Cq;
+    a.nq = h->nq;
     a.inv_n = (flags & CB_NORMALIZE) ? h->inv_n : h->ones;
     a.dirsum = h->dirsum;
     a.Q = Qd;
@@ -1142,7 +1176,7 @@ static int run_fused_training(cb_bank *h, int kind, double *pi_param, double *up
   if (rc == CB_OK) {
     TrainArgs a{};
     a.S = S; a.L = L; a.B = h->Bl; a.E = E; a.kind = kind; a.do_adam = do_adam; a.n_pow2 = d_Qp ? n_pow2 : 0;
-    a.nlive = h->nlive; a.t = h->t_live; a.Ct = h->Ct; a.inv_n = (flags & CB_NORMALIZE) ? h->inv_n : h->ones; a.dirsum = h->dirsum;
+    a.nlive = h->nlive; a.t = h->t_live; a.Ct = h->Ct; a.Cq = h->Cq; a.nq = h->nq; a.inv_n = (flags & CB_NORMALIZE) ? h->inv_n : h->ones; a.dirsum = h->dirsum;
     a.p_pi = d_pi; a.p_up = d_up;
     a.m_pi = d_mom; a.v_pi = d_mom + (size_t)L * S;
     a.m_up = d_mom + 2 * (size_t)L * S; a.v_up = a.m_up + L * nup;
@@ -1151,8 +1185,53 @@ static int run_fused_training(cb_bank *h, int kind, double *pi_param, double *up
     for (bool &b : h->ev_rec) b = false;
     mark(h, EV_START);
     const char *env_split = getenv("CB_LG_SPLIT");
-    const bool split = kind == 0 && L == 1 && !(env_split && atoi(env_split) == 0);
-    if (E > 0 && split) {
+    const char *env_sp = getenv("CB_SITE_SPLIT");
+    const bool site_split = S <= 20 && !(env_sp && atoi(env_sp) == 0) && !(L == 1 && env_split && atoi(env_split) == 0);
+    const bool split = !site_split && kind == 0 && L == 1 && !(env_split && atoi(env_split) == 0);
+    if (E > 0 && site_split) {
+      // three launches per epoch over all sites (train_small.hip.h: sp_prepare / sp_bank / sp_finish)
+      SpSplit g{};
+      int max_live = 1;
+      for (int l = 0; l < L; ++l) max_live = std::max(max_live, h->nlive_host[l]);
+      const int nquads = (max_live + 3) / 4;
+      // few sites: one quad per wave spreads a single bank over the chip; many sites: longer chunks
+      const int qpw = L < 64 ? 1 : 3;
+      g.quads_per_chunk = std::min(nquads, 4 * qpw);
+      g.nchunk = (nquads + g.quads_per_chunk - 1) / g.quads_per_chunk;
+      g.quads_per_chunk = (nquads + g.nchunk - 1) / g.nchunk;  // even split
+      double *buf = nullptr;
+      const size_t nbuf = (size_t)L * LGS_TOTAL + (size_t)L * g.nchunk * 401 + L + 8;
+      if (!alloc(&buf, nbuf)) rc = fail(CB_ENOMEM, "fused training: device allocation failed");
+      if (rc == CB_OK) {
+        g.frames = buf;
+        g.Mpart = buf + (size_t)L * LGS_TOTAL;
+        g.lpart = g.Mpart + (size_t)L * g.nchunk * 400;
+        g.best = g.lpart + (size_t)L * g.nchunk;
+        const size_t lds_p = SPP_TOTAL * sizeof(double), lds_b = SPB_TOTAL * sizeof(double), lds_f = SPF_TOTAL * sizeof(double);
+        const int TS = quad_ts(S);
+        double pow_b1 = 1.0, pow_b2 = 1.0;
+        for (int e = 0; e < E && rc == CB_OK; ++e) {
+          pow_b1 *= a.beta1;
+          pow_b2 *= a.beta2;
+          hipLaunchKernelGGL(sp_prepare, dim3(L), dim3(256), lds_p, h->stream, a, g, e);
+          const dim3 gb((unsigned)((size_t)L * g.nchunk));
+          const double bc1 = 1.0 - pow_b1, bc2s = std::sqrt(1.0 - pow_b2);
+#define SPK(T)                                                                                         \
+  do {                                                                                                 \
+    hipLaunchKernelGGL((sp_bank<T>), gb, dim3(256), lds_b, h->stream, a, g);                            \
+    hipLaunchKernelGGL((sp_finish<T>), dim3(L), dim3(256), lds_f, h->stream, a, g, e, bc1, bc2s);       \
+  } while (0)
+          switch (TS) {
+            case 1: SPK(1); break;
+            case 2: SPK(2); break;
+            case 4: SPK(4); break;
+            default: SPK(5); break;
+          }
+#undef SPK
+          if ((e & 63) == 63 && hipGetLastError() != hipSuccess) rc = fail(CB_EHIP, "fused training launch failed");
+        }
+      }
+    } else if (E > 0 && split) {
       // one LG-sized bank: the epoch spread over the chip, three small launches per epoch
       LgSplit g{};
       double *buf = nullptr;
@@ -1189,7 +1268,27 @@ static int run_fused_training(cb_bank *h, int kind, double *pi_param, double *up
         }
       }
     } else if (E > 0) {
+      unsigned long long *stamps = nullptr;
+      if (getenv("CB_DEBUG_STAMPS")) {
+        (void)hipMalloc((void **)&stamps, 16 * sizeof(unsigned long long));
+        (void)hipMemset(stamps, 0, 16 * sizeof(unsigned long long));
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_small_stamps), &stamps, sizeof stamps);
+      }
       rc = (L < 512) ? launch_train_nw<8>(h, a) : launch_train_nw<4>(h, a);
+      if (stamps) {
+        unsigned long long st[16];
+        (void)hipStreamSynchronize(h->stream);
+        (void)hipMemcpy(st, stamps, sizeof st, hipMemcpyDeviceToHost);
+        const char *names[] = {"theta->A (tr_build)", "eigh (wave 0)", "bucket loop", "loss + M reduction", "dA = U M U^T", "gradients + Adam"};
+        for (int i = 0; i < 6; ++i)
+          fprintf(stderr, "[cherrybank] small trainer, workgroup 0, epoch 1: %-22s %8llu ticks\n", names[i], st[i + 1] - st[i]);
+        const char *qn[] = {"quad: tables (exp, phi2)", "quad: Pt + epilogue", "quad: counts + T", "quad: W + Phi + M"};
+        for (int i = 0; i < 4; ++i)
+          fprintf(stderr, "[cherrybank] small trainer, first 4x4-tile quad of wave 0:  %-26s %8llu ticks\n", qn[i], st[9 + i] - st[8 + i]);
+        unsigned long long *null_p = nullptr;
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_small_stamps), &null_p, sizeof null_p);
+        (void)hipFree(stamps);
+      }
     }
     mark(h, EV_SMALL);  // cb_last_timings(): CB_T_SMALL = all E epochs
   }

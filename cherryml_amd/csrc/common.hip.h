@@ -11,6 +11,15 @@ typedef double d4 __attribute__((ext_vector_type(4)));
 // Consequence used throughout: register r of an accumulator tile is exactly
 // the A-operand (rows on l&15 after a transpose of roles) / B-operand fragment
 // of k-step r of the next product, so chains of products never leave registers.
+// v_mfma_f64_4x4x4f64: FOUR independent 4x4x4 products per instruction (one per "block").
+// Lane layouts (measured, profiles/tools/mfma4_probe.hip), with lane = 16 q + 4 b + r:
+//   A operand  lane holds A_b[i = r][k = q]      B operand  lane holds B_b[k = q][j = r]
+//   C / D      lane holds D_b[i = q][j = r]
+// so a D register used as B operand is the tile itself, used as A operand its transpose.
+__device__ __forceinline__ double mfma4_f64(double a, double b, double c) {
+  return __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, c, 0, 0, 0);
+}
+
 __device__ __forceinline__ d4 mfma_f64(double a, double b, d4 c) {
   return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
 }

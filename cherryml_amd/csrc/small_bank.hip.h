@@ -20,12 +20,21 @@
 #include "jacobi_wave.hip.h"
 
 #define CB_LS 33  // LDS row stride (doubles) of the 32x32 frames
+#ifndef CB_SMALL_MIN_WGS
+#define CB_SMALL_MIN_WGS 1
+#endif
+
+// in-kernel phase stamps of workgroup 0 (debug: CB_DEBUG_STAMPS), see cb_train_* host code
+__device__ unsigned long long *g_small_stamps = nullptr;
+#define SM_STAMP(i) do { if (g_small_stamps && blockIdx.x == 0 && threadIdx.x == 0) g_small_stamps[i] = __builtin_amdgcn_s_memtime(); } while (0)
 
 struct SmallArgs {
   int S, L, B;        // B = bucket stride of t / Ct / P
   const int *nlive;   // [L] buckets to visit per site (live ones are stored first), or null = B
   const double *t;    // [L,B]
   const double *Ct;   // [L,B,S,S]  (transposed counts)
+  const double *Cq;   // S <= 20: the same counts in quad order [L][nq][TS*TS][64] (see quad_load_counts)
+  int nq;             // quads per site in Cq
   const double *inv_n;  // [L]  1/n_l or 1
   const double *dirsum; // [L,S]  colsum_k - rowsum_k of sum_b C (direct pi term)
   const double *Q;    // [L,S,S]
@@ -47,8 +56,9 @@ struct SmallLds {
   static constexpr int V = G + FRAME;         // eigenvectors (column k at V + k*LS)
   static constexpr int LAM = V + FRAME;       // 32
   static constexpr int D = LAM + 32;          // sqrt(pi)
-  static constexpr int TAB = D + 32;          // per wave: F[32], E[32], H[32]
-  static constexpr int RED = TAB + NW * 96;   // (NW/2) * 1024 reduction slots (min 1)
+  static constexpr int TAB = D + 32;          // per wave: 4 x (F[32], E[32], H[32]) (one set per MFMA block)
+  static constexpr int M4 = TAB + NW * 384;   // per wave: 400 doubles, the M accumulator of the 4x4-tile path
+  static constexpr int RED = M4 + NW * 400;   // (NW/2) * 1024 reduction slots (min 1)
   static constexpr int LOSS = RED + ((NW / 2) > 0 ? (NW / 2) : 1) * 1024;
   static constexpr int LOSSTOT = LOSS + NW;
   static constexpr int TOTAL = LOSSTOT + 1;
@@ -238,6 +248,162 @@ __device__ __forceinline__ void small_bucket(const SmallFrags<NT, KS> &f, int S,
   wave_lds_fence();  // tab is rewritten by the next bucket
 }
 
+// ---- 4x4-tile path (S <= 20): FOUR buckets per wavefront pass, one per MFMA block ---------------
+// With 16x16 tiles a 20-state matrix is padded to 32 x 32 (39 % useful work in the MFMAs and in the
+// log / reciprocal / divided-difference epilogues).  v_mfma_f64_4x4x4f64 multiplies four
+// independent 4x4x4 blocks per instruction: block b of every instruction belongs to bucket
+// 4 quad + b, the TS x TS tiles of a matrix (TS = ceil(S / 4)) live in TS^2 registers (one double
+// per lane), and nothing is padded for S = 20.  Same register chaining as the 16x16 path:
+//   Pt tile (I,J)   = sum_K  A: (U F_b)(I,K)          B: UA[J][K] (= U^T(K,J) in B layout)
+//   epilogue        -> G~^T tile (I,J) in place (counts are stored transposed)
+//   T tile (It,Mt)  = sum_Jt A: g[Jt][It] (used as A = its transpose = G~(It,Jt))   B: U(Jt,Mt)
+//                     stored over the dead g[Mt][It]
+//   W tile (At,Ct)  = sum_It A: U^T(At,It) (= U(It,At) in B layout, same LDS words)  B: g[Ct][It] (= T(It,Ct))
+//   M[At][Ct]      += W o Phi_b
+// Lane = 16 q + 4 b + r: A layout (i = r, k = q), B layout (k = q, j = r), D layout (i = q, j = r).
+// Counts of one quad (4 consecutive live buckets) in the order the lanes consume them:
+// Cq[(I * TS + J) * 64 + lane] = Ct_bucket(4 quad + blk)[4 I + q][4 J + r], zero where the bucket
+// or the row / column does not exist (written once by pack_counts_quad at cb_create): every load
+// is 64 consecutive doubles.
+template <int TS>
+__device__ __forceinline__ void quad_load_counts(double (&cv)[TS][TS], const double *__restrict__ Cq) {
+  const int lane = threadIdx.x & 63;
+#pragma unroll
+  for (int I = 0; I < TS; ++I)
+#pragma unroll
+    for (int J = 0; J < TS; ++J) cv[I][J] = Cq[(I * TS + J) * 64 + lane];
+}
+
+// LANEM: Mw is [TS*TS][64] (every lane owns its slots: no cross-lane traffic); else [TS*TS][16]
+// (the four blocks are summed by shuffles first: a quarter of the LDS).
+template <int TS, bool LANEM>
+__device__ __forceinline__ void small_quad(int S, double tb, const double *__restrict__ Cq, double inv_n,
+                                           const double *sA, const double *sV, double *tabw,
+                                           const double *sLam, double rho, double *Mw, double &lossacc) {
+  const int lane = threadIdx.x & 63, q = lane >> 4, blk = (lane >> 2) & 3, r = lane & 3;
+  // counts of this quad: issued first (coalesced, 64 consecutive doubles per load), consumed by the
+  // epilogue after the table computation and the first MFMA row -- no registers held across quads
+  double cv[TS][TS];
+  quad_load_counts<TS>(cv, Cq);
+  double *tab = tabw + blk * 96;  // this block's F[32], E[32], H[32]
+  const bool split = tb * rho <= 1.0;
+#define Q_STAMP(i) do { if (g_small_stamps && blockIdx.x == 0 && threadIdx.x == 0 && g_small_stamps[15] == 1) g_small_stamps[i] = __builtin_amdgcn_s_memtime(); } while (0)
+  Q_STAMP(8);
+  // spectral tables of the four buckets: 16 lanes per block, lanes (q, r) cover k = 4 q + r and + 16
+  {
+    const int k0 = 4 * q + r;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int k = k0 + 16 * h;
+      const double x = (k < S) ? tb * sLam[k] : 0.0;
+      const double H = exp(0.5 * x);
+      const double E = H * H;
+      tab[k] = split ? phi2(x) : (k < S ? E : 0.0);
+      tab[32 + k] = E;
+      tab[64 + k] = H;
+    }
+  }
+  wave_lds_fence();
+  Q_STAMP(9);
+  // Register budget (2 waves per SIMD = 256 VGPRs): g 2 TS^2 + counts 2 TS^2 + ONE operand form of U
+  // 2 TS^2 at a time.  The two forms are re-read from LDS at the start of their phase (the memory
+  // clobbers keep the compiler from hoisting both out of the bucket loop) and the scheduler is
+  // fenced between tile rows, otherwise it interleaves all TS^2 epilogues and spills ~300 registers.
+  double g[TS][TS];
+  {
+    asm volatile("" ::: "memory");
+    double UA[TS][TS];  // A layout of U(I,K): U[4 I + r][4 K + q]  (= B layout of U^T(K,I))
+#pragma unroll
+    for (int I = 0; I < TS; ++I)
+#pragma unroll
+      for (int K = 0; K < TS; ++K) UA[I][K] = sV[(4 * K + q) * CB_LS + 4 * I + r];
+    double Fk[TS];
+#pragma unroll
+    for (int K = 0; K < TS; ++K) Fk[K] = tab[4 * K + q];
+    const double tsplit = split ? tb : 0.0, isplit = split ? 1.0 : 0.0;
+    // ---- Pt row I, epilogue in place -> g[I][*] = G~^T tiles ---------------------------------
+#pragma unroll
+    for (int I = 0; I < TS; ++I) {
+      double uf[TS];
+#pragma unroll
+      for (int K = 0; K < TS; ++K) uf[K] = UA[I][K] * Fk[K];
+#pragma unroll
+      for (int K = 0; K < TS; ++K)       // K outer: TS independent accumulator chains in flight
+#pragma unroll
+        for (int J = 0; J < TS; ++J) g[I][J] = mfma4_f64(uf[K], UA[J][K], K == 0 ? 0.0 : g[I][J]);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int J = 0; J < TS; ++J) {
+        const int row = 4 * I + q, col = 4 * J + r;
+        const bool valid = (row < S) && (col < S);
+        double pt = g[I][J] + tsplit * sA[min(row, 31) * CB_LS + min(col, 31)] + (row == col ? isplit : 0.0);
+        pt = valid ? pt : 1.0;
+        const double c = cv[I][J];
+        const bool nz = c != 0.0;
+        lossacc = fma(-c, fast_log(nz ? pt : 1.0), lossacc);
+        g[I][J] = nz ? -c * inv_n * fast_rcp(pt) : 0.0;
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  Q_STAMP(10);
+  asm volatile("" ::: "memory");
+  double UB[TS][TS];  // B layout of U(I,K): U[4 I + q][4 K + r]  (= A layout of U^T(K,I))
+#pragma unroll
+  for (int I = 0; I < TS; ++I)
+#pragma unroll
+    for (int K = 0; K < TS; ++K) UB[I][K] = sV[(4 * K + r) * CB_LS + 4 * I + q];
+  // ---- T(It,Mt) = sum_Jt G~(It,Jt) U(Jt,Mt), stored over g[Mt][It] ---------------------------
+#pragma unroll
+  for (int It = 0; It < TS; ++It) {
+    double acc[TS];
+#pragma unroll
+    for (int Jt = 0; Jt < TS; ++Jt)
+#pragma unroll
+      for (int Mt = 0; Mt < TS; ++Mt) acc[Mt] = mfma4_f64(g[Jt][It], UB[Jt][Mt], Jt == 0 ? 0.0 : acc[Mt]);
+#pragma unroll
+    for (int Mt = 0; Mt < TS; ++Mt) g[Mt][It] = acc[Mt];
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  Q_STAMP(11);
+  // ---- W(At,Ct) = sum_It U^T(At,It) T(It,Ct);  M += W o Phi -----------------------------------
+#pragma unroll
+  for (int Ct = 0; Ct < TS; ++Ct) {
+    const int c = min(4 * Ct + r, 31);
+    const double EC = tab[32 + c], HC = tab[64 + c], LC = sLam[c];
+    double acc[TS];
+#pragma unroll
+    for (int It = 0; It < TS; ++It)
+#pragma unroll
+      for (int At = 0; At < TS; ++At) acc[At] = mfma4_f64(UB[It][At], g[Ct][It], It == 0 ? 0.0 : acc[At]);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int At = 0; At < TS; ++At) {
+      const int ra = min(4 * At + q, 31);
+      const double ER = tab[32 + ra], HR = tab[64 + ra];
+      const double dl = sLam[ra] - LC;
+      const double z = 0.5 * tb * dl;
+      const bool near = fabs(z) < 0.5;
+      const double taylor = tb * HR * HC * sinhc_small(near ? z : 0.0);
+      const double quot = (ER - EC) * fast_rcp(near ? 1.0 : dl);
+      double m = acc[At] * (near ? taylor : quot);
+      if (LANEM) {
+        Mw[(At * TS + Ct) * 64 + lane] += m;   // wave-private slot of this lane
+      } else {
+        // sum over the four buckets of this pass, then accumulate in the wave-private LDS array
+        m += __shfl_xor(m, 4);
+        m += __shfl_xor(m, 8);
+        if (blk == 0) Mw[(At * TS + Ct) * 16 + 4 * q + r] += m;
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  wave_lds_fence();  // the tables are rewritten by the next quad
+  Q_STAMP(12);
+  if (g_small_stamps && blockIdx.x == 0 && threadIdx.x == 0 && g_small_stamps[15] == 1) g_small_stamps[15] = 2;
+#undef Q_STAMP
+}
+
 // ---- A = sym(D^1/2 Q D^-1/2) into LDS -----------------------------------------
 __device__ __forceinline__ void small_build_A(int S, const double *__restrict__ Q,
                                               const double *__restrict__ pi, double *sA,
@@ -285,17 +451,20 @@ __device__ __forceinline__ void small_site_eval(double *lds, int S, int B,
                                                 const double *__restrict__ Ct_l, double inv_n,
                                                 const double *__restrict__ dirsum_l,
                                                 double *__restrict__ P_l, bool want_grad,
-                                                int *sweeps_out, bool warm = false) {
+                                                int *sweeps_out, bool warm = false,
+                                                const double *__restrict__ Cq_l = nullptr) {
   using LD = SmallLds<NW>;
   double *sA = lds + LD::A, *sG = lds + LD::G, *sV = lds + LD::V, *sLam = lds + LD::LAM,
          *sD = lds + LD::D;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int lo = lane & 15, hi = lane >> 4;
+  SM_STAMP(1);
   if (wave == 0) {
     const int sweeps = wave_eigh_rate(S, sA, sG, sV, sLam, CB_LS, warm);
     if (lane == 0 && sweeps_out) *sweeps_out = sweeps;
   }
   __syncthreads();
+  SM_STAMP(2);
   // zero padding of the 32 x 32 eigenvector frame and of lam (operands are read unguarded)
   for (int e = threadIdx.x; e < 32 * 32; e += blockDim.x) {
     const int k = e >> 5, i = e & 31;
@@ -303,6 +472,42 @@ __device__ __forceinline__ void small_site_eval(double *lds, int S, int B,
   }
   for (int k = S + threadIdx.x; k < 32; k += blockDim.x) sLam[k] = 0.0;
   __syncthreads();
+  // Gershgorin: |lam| <= 2 max |A_ii| for a symmetrised rate matrix
+  double rho = 0.0;
+  for (int i = lane; i < S; i += 64) rho = fmax(rho, fabs(sA[i * CB_LS + i]));
+  rho = 2.0 * wave_max(rho);
+  double *tab = lds + LD::TAB + wave * 384;
+  double *red = lds + LD::RED;
+  if (MODE == SMALL_LOSSGRAD && KS <= 5) {
+    // ---- 4x4 tiles, four buckets per pass (see small_quad) --------------------------------------
+    constexpr int TS = KS <= 5 ? KS : 1;
+    const int blk = (lane >> 2) & 3;
+    double *Mw = lds + LD::M4 + wave * 400;
+    for (int e = lane; e < 16 * TS * TS; e += 64) Mw[e] = 0.0;
+    wave_lds_fence();
+    double lossacc = 0.0;
+    const int nquads = (B + 3) / 4;
+    for (int qd = wave; qd < nquads; qd += NW) {
+      const int bucket = 4 * qd + blk;
+      const double tb = bucket < B ? t_l[bucket] : 0.0;   // a missing bucket: t = 0, no counts -> contributes nothing
+      small_quad<TS, false>(S, tb, Cq_l + (size_t)qd * (TS * TS * 64), inv_n, sA, sV, tab, sLam, rho, Mw, lossacc);
+    }
+    SM_STAMP(3);
+    lossacc = wave_sum(lossacc);
+    if (lane == 0) lds[LD::LOSS + wave] = lossacc;
+    if (want_grad) {
+      // sum over the waves in a fixed order, into the frame sG[a][c]
+      __syncthreads();
+      for (int e = threadIdx.x; e < 16 * TS * TS; e += blockDim.x) {
+        double tot = 0.0;
+        for (int w = 0; w < NW; ++w) tot += lds[LD::M4 + w * 400 + e];
+        const int tile = e >> 4, At = tile / TS, Ct = tile - At * TS;
+        const int a = 4 * At + ((e >> 2) & 3), c = 4 * Ct + (e & 3);
+        sG[a * CB_LS + c] = tot;
+      }
+    }
+    __syncthreads();
+  } else {
   SmallFrags<NT, KS> f;
   load_frags<NT, KS>(f, sV, sLam, S);
   d4 M[NT][NT];
@@ -311,11 +516,6 @@ __device__ __forceinline__ void small_site_eval(double *lds, int S, int B,
 #pragma unroll
     for (int y = 0; y < NT; ++y) M[x][y] = d4{0.0, 0.0, 0.0, 0.0};
   double lossacc = 0.0;
-  double *tab = lds + LD::TAB + wave * 96;
-  // Gershgorin: |lam| <= 2 max |A_ii| for a symmetrised rate matrix
-  double rho = 0.0;
-  for (int i = lane; i < S; i += 64) rho = fmax(rho, fabs(sA[i * CB_LS + i]));
-  rho = 2.0 * wave_max(rho);
   double cval[NT][NT][4];
   if (MODE == SMALL_LOSSGRAD && wave < B) load_counts<NT, KS>(cval, S, Ct_l + (size_t)wave * S * S);
   for (int b = wave; b < B; b += NW) {
@@ -330,7 +530,6 @@ __device__ __forceinline__ void small_site_eval(double *lds, int S, int B,
   lossacc = wave_sum(lossacc);
   if (lane == 0) lds[LD::LOSS + wave] = lossacc;
   // ---- deterministic tree reduction of M over the waves -----------------------
-  double *red = lds + LD::RED;
   if (want_grad) {
     for (int stride = NW / 2; stride >= 1; stride >>= 1) {
       if (wave >= stride && wave < 2 * stride) {
@@ -368,6 +567,7 @@ __device__ __forceinline__ void small_site_eval(double *lds, int S, int B,
     }
   }
   __syncthreads();
+  }
   if (threadIdx.x == 0) {
     double tot = 0.0;
     for (int w = 0; w < NW; ++w) tot += lds[LD::LOSS + w];
@@ -380,11 +580,13 @@ __device__ __forceinline__ void small_site_eval(double *lds, int S, int B,
     __syncthreads();
     return;
   }
+  SM_STAMP(4);
   small_dA_from_M(S, sG, sV, lds + LD::RED);
+  SM_STAMP(5);
 }
 
 template <int NT, int KS, int NW, int MODE>
-__global__ __launch_bounds__(NW * 64, 2) void small_bank_kernel(SmallArgs a) {
+__global__ __launch_bounds__(NW * 64, CB_SMALL_MIN_WGS) void small_bank_kernel(SmallArgs a) {
   extern __shared__ double lds[];
   using LD = SmallLds<NW>;
   double *sA = lds + LD::A, *sG = lds + LD::G, *sV = lds + LD::V, *sLam = lds + LD::LAM,
@@ -413,7 +615,8 @@ __global__ __launch_bounds__(NW * 64, 2) void small_bank_kernel(SmallArgs a) {
   small_site_eval<NT, KS, NW, MODE>(lds, S, a.nlive ? a.nlive[l] : B, a.t + lb, a.Ct + lb * S * S, a.inv_n[l],
                                     a.dirsum + (size_t)l * S,
                                     MODE == SMALL_EXPM ? a.P + lb * S * S : nullptr,
-                                    a.dQ != nullptr, a.status ? a.status + l : nullptr);
+                                    a.dQ != nullptr, a.status ? a.status + l : nullptr, false,
+                                    a.Cq ? a.Cq + (size_t)l * a.nq * (KS * KS * 64) : nullptr);
   if (MODE == SMALL_EXPM) return;
   if (threadIdx.x == 0) a.loss[l] = lds[LD::LOSSTOT];
   if (a.dQ == nullptr) return;

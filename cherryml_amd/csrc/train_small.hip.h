@@ -26,6 +26,8 @@
 struct TrainArgs {
   int S, L, B, E, kind, do_adam, n_pow2;
   const int *nlive;                 // [L] live buckets per site (stored first); B = stride
+  const double *Cq;                 // S <= 20: counts in quad order (SmallArgs::Cq)
+  int nq;
   const double *t, *Ct, *inv_n, *dirsum;
   double *p_pi, *p_up;              // parameters  [L][S], [L][NUP]
   double *m_pi, *v_pi, *m_up, *v_up;  // Adam moments (zero initialised)
@@ -194,12 +196,12 @@ __device__ __forceinline__ void tr_update(const TrainArgs &a, int l, int epoch, 
 template <int NT, int KS, int NW>
 __device__ __attribute__((noinline)) void small_site_eval_call(double *lds, int S, int B, const double *t_l,
                                                                const double *Ct_l, double inv_n,
-                                                               const double *dirsum_l, bool warm) {
-  small_site_eval<NT, KS, NW, SMALL_LOSSGRAD>(lds, S, B, t_l, Ct_l, inv_n, dirsum_l, nullptr, true, nullptr, warm);
+                                                               const double *dirsum_l, bool warm, const double *Cq_l) {
+  small_site_eval<NT, KS, NW, SMALL_LOSSGRAD>(lds, S, B, t_l, Ct_l, inv_n, dirsum_l, nullptr, true, nullptr, warm, Cq_l);
 }
 
 template <int NT, int KS, int NW>
-__global__ __launch_bounds__(NW * 64, 2) void small_train_kernel(TrainArgs a) {
+__global__ __launch_bounds__(NW * 64, CB_SMALL_MIN_WGS) void small_train_kernel(TrainArgs a) {
   extern __shared__ double lds[];
   using LD = SmallLds<NW>;
   double *sA = lds + LD::A, *sG = lds + LD::G, *sD = lds + LD::D;
@@ -211,15 +213,20 @@ __global__ __launch_bounds__(NW * 64, 2) void small_train_kernel(TrainArgs a) {
   if (threadIdx.x == 0) sFlag[1] = INFINITY;
   double pow_b1 = 1.0, pow_b2 = 1.0;
   for (int epoch = 0; epoch < a.E; ++epoch) {
+    if (epoch == 1) SM_STAMP(0);
+    if (epoch == 1 && g_small_stamps && blockIdx.x == 0 && threadIdx.x == 0) g_small_stamps[15] = 1;  // arm the per-quad stamps
     tr_build(a, l, epoch, sA, sD, sPi);
     // sV still holds the previous epoch's eigenvectors (zero padded): warm start
     small_site_eval_call<NT, KS, NW>(lds, S, a.nlive[l], a.t + lb, a.Ct + lb * S * S, a.inv_n[l],
-                                     a.dirsum + (size_t)l * S, epoch > 0);
+                                     a.dirsum + (size_t)l * S, epoch > 0,
+                                     a.Cq ? a.Cq + (size_t)l * a.nq * (KS * KS * 64) : nullptr);
     // (ends with a barrier: sG = dA, sA = A, LOSSTOT = loss)
     pow_b1 *= a.beta1;
     pow_b2 *= a.beta2;
     tr_update(a, l, epoch, lds[LD::LOSSTOT], 1.0 - pow_b1, sqrt(1.0 - pow_b2), sA, sG, sD, sPi, sGd,
               sFlag, lds + LD::RED, sFlag + 1);
+    if (epoch == 1) SM_STAMP(6);
+    if (epoch == 1 && g_small_stamps && blockIdx.x == 0 && threadIdx.x == 0) g_small_stamps = nullptr;  // one epoch only
   }
 }
 
@@ -305,7 +312,7 @@ __global__ __launch_bounds__(256, 2) void lg_bank(TrainArgs a, LgSplit g) {
   load_counts<NT, KS>(cval, S, a.Ct + (size_t)b * S * S);
   double lossacc = 0.0;
   small_bucket<NT, KS, SMALL_LOSSGRAD>(f, S, a.t[b], cval, nullptr, a.inv_n[0], sA, sD, sV,
-                                        lds + LD::TAB + wave * 96, sLam, rho, M, lossacc, nullptr);
+                                        lds + LD::TAB + wave * 384, sLam, rho, M, lossacc, nullptr);
   lossacc = wave_sum(lossacc);
   double *dst = g.Mpart + (size_t)b * 1024;
 #pragma unroll
@@ -369,4 +376,164 @@ __global__ __launch_bounds__(256) void lg_finish(TrainArgs a, LgSplit g, int epo
   __syncthreads();
   small_dA_from_M(S, sG, sV, lds + LD::RED);
   tr_update(a, 0, epoch, lds[LD::LOSSTOT], bc1, bc2s, sA, sG, sD, sPi, sGd, sFlag, lds + LD::RED, g.best);
+}
+
+// ---------------------------------------------------------------------------------------
+// Site-parallel split trainer (S <= 20, any L, both parameterisations).  In the one-kernel trainer a
+// workgroup owns a site for all epochs: every epoch its wave 0 spends ~70 us in the eigensolver
+// (31 % of the epoch at 20 states) while the other waves wait, and its count streaming cannot
+// overlap anybody else's serial phases.  Here an epoch is three launches over all sites, enqueued
+// back to back without host synchronisation:
+//   sp_prepare : theta -> A, eigh (warm), frames to global     1 workgroup / site, 26 KB of LDS, so
+//                                                              six eigensolves overlap per CU
+//   sp_bank    : 4x4-tile quads (small_quad), partial M, loss  (site, chunk) workgroups
+//   sp_finish  : sum the partials (fixed order), dA, gradients, best iterate, Adam   1 workgroup / site
+// State between the launches lives in HBM / L2 (17.7 KB of frames per site).
+struct SpSplit {
+  double *frames;  // [L][LGS_TOTAL]   A | V | lam | d | pi
+  double *Mpart;   // [L][nchunk][400] partial M of a chunk, [tile][4 q + r]
+  double *lpart;   // [L][nchunk]
+  double *best;    // [L] best loss so far
+  int nchunk, quads_per_chunk;
+};
+#define SPP_A 0
+#define SPP_G (32 * CB_LS)
+#define SPP_V (2 * 32 * CB_LS)
+#define SPP_LAM (3 * 32 * CB_LS)
+#define SPP_D (SPP_LAM + 32)
+#define SPP_PI (SPP_D + 32)
+#define SPP_TOTAL (SPP_PI + 32)
+
+__global__ __launch_bounds__(256) void sp_prepare(TrainArgs a, SpSplit g, int epoch) {
+  extern __shared__ double lds[];
+  double *sA = lds + SPP_A, *sG = lds + SPP_G, *sV = lds + SPP_V, *sLam = lds + SPP_LAM, *sD = lds + SPP_D,
+         *sPi = lds + SPP_PI;
+  const int S = a.S, tid = threadIdx.x, l = blockIdx.x;
+  double *fr = g.frames + (size_t)l * LGS_TOTAL;
+  if (epoch == 0 && tid == 0) g.best[l] = INFINITY;
+  tr_build(a, l, epoch, sA, sD, sPi);
+  if (epoch > 0)  // previous eigenvectors: warm start
+    for (int e = tid; e < 32 * CB_LS; e += 256) sV[e] = fr[LGS_V + e];
+  __syncthreads();
+  if (tid < 64) wave_eigh_rate(S, sA, sG, sV, sLam, CB_LS, epoch > 0);
+  __syncthreads();
+  for (int e = tid; e < 32 * 32; e += 256) {
+    const int k = e >> 5, i = e & 31;
+    if (k >= S || i >= S) sV[k * CB_LS + i] = 0.0;
+  }
+  for (int k = S + tid; k < 32; k += 256) sLam[k] = 0.0;
+  __syncthreads();
+  for (int e = tid; e < 32 * CB_LS; e += 256) {
+    fr[LGS_A + e] = sA[e];
+    fr[LGS_V + e] = sV[e];
+  }
+  if (tid < 32) {
+    fr[LGS_LAM + tid] = sLam[tid];
+    fr[LGS_D + tid] = sD[tid];
+    fr[LGS_PI + tid] = sPi[tid];
+  }
+}
+
+// bank LDS: only the first 24 rows of the A / V frames are touched for S <= 20; Mw = [wave][tile][lane]
+#define SPB_ROWS 24
+#define SPB_A 0
+#define SPB_V (SPB_ROWS * CB_LS)
+#define SPB_LAM (2 * SPB_ROWS * CB_LS)
+#define SPB_TAB (SPB_LAM + 32)
+#define SPB_MW (SPB_TAB + 4 * 384)
+#define SPB_LOSS (SPB_MW + 4 * 1600)
+#define SPB_TOTAL (SPB_LOSS + 8)
+
+template <int TS>
+__global__ __launch_bounds__(256, 2) void sp_bank(TrainArgs a, SpSplit g) {
+  extern __shared__ double lds[];
+  double *sA = lds + SPB_A, *sV = lds + SPB_V, *sLam = lds + SPB_LAM;
+  const int S = a.S, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, blk = (lane >> 2) & 3;
+  const int l = blockIdx.x / g.nchunk, chunk = blockIdx.x - l * g.nchunk;
+  const double *fr = g.frames + (size_t)l * LGS_TOTAL;
+  for (int e = tid; e < SPB_ROWS * CB_LS; e += 256) {
+    sA[e] = fr[LGS_A + e];
+    sV[e] = fr[LGS_V + e];
+  }
+  if (tid < 32) sLam[tid] = fr[LGS_LAM + tid];
+  double *Mw = lds + SPB_MW + wave * 1600;
+  for (int e = lane; e < 64 * TS * TS; e += 64) Mw[e] = 0.0;
+  __syncthreads();
+  const int Bn = a.nlive[l], nquads = (Bn + 3) / 4;
+  const size_t lb = (size_t)l * a.B;
+  const double *t_l = a.t + lb, *Cq_l = a.Cq + (size_t)l * a.nq * (TS * TS * 64);
+  const double inv_n = a.inv_n[l];
+  double rho = 0.0;
+  for (int i = lane; i < S; i += 64) rho = fmax(rho, fabs(sA[i * CB_LS + i]));
+  rho = 2.0 * wave_max(rho);
+  const int q0 = chunk * g.quads_per_chunk, q1 = min(nquads, q0 + g.quads_per_chunk);
+  double lossacc = 0.0;
+  for (int qd = q0 + wave; qd < q1; qd += 4) {
+    const int bucket = 4 * qd + blk;
+    const double tb = bucket < Bn ? t_l[bucket] : 0.0;
+    small_quad<TS, true>(S, tb, Cq_l + (size_t)qd * (TS * TS * 64), inv_n, sA, sV, lds + SPB_TAB + wave * 384, sLam,
+                         rho, Mw, lossacc);
+  }
+  lossacc = wave_sum(lossacc);
+  if (lane == 0) lds[SPB_LOSS + wave] = lossacc;
+  __syncthreads();
+  double *dst = g.Mpart + ((size_t)l * g.nchunk + chunk) * 400;
+  for (int e = tid; e < 16 * TS * TS; e += 256) {   // e = tile * 16 + 4 q + r: sum the 4 blocks of the 4 waves, fixed order
+    const int slot = (e >> 4) * 64 + 16 * ((e >> 2) & 3) + (e & 3);
+    double tot = 0.0;
+    for (int w = 0; w < 4; ++w) {
+      const double *m = lds + SPB_MW + w * 1600 + slot;
+      tot += (m[0] + m[4]) + (m[8] + m[12]);
+    }
+    dst[e] = tot;
+  }
+  if (tid == 0)
+    g.lpart[(size_t)l * g.nchunk + chunk] = (lds[SPB_LOSS] + lds[SPB_LOSS + 1]) + (lds[SPB_LOSS + 2] + lds[SPB_LOSS + 3]);
+}
+
+#define SPF_A 0
+#define SPF_G (32 * CB_LS)
+#define SPF_V (2 * 32 * CB_LS)
+#define SPF_D (3 * 32 * CB_LS)
+#define SPF_PI (SPF_D + 32)
+#define SPF_GD (SPF_PI + 32)
+#define SPF_FLAG (SPF_GD + 32)
+#define SPF_RED (SPF_FLAG + 8)
+#define SPF_TOTAL (SPF_RED + 1056)
+
+template <int TS>
+__global__ __launch_bounds__(256) void sp_finish(TrainArgs a, SpSplit g, int epoch, double bc1, double bc2s) {
+  extern __shared__ double lds[];
+  double *sA = lds + SPF_A, *sG = lds + SPF_G, *sV = lds + SPF_V, *sD = lds + SPF_D, *sPi = lds + SPF_PI,
+         *sGd = lds + SPF_GD, *sFlag = lds + SPF_FLAG, *sRed = lds + SPF_RED;
+  const int S = a.S, tid = threadIdx.x, l = blockIdx.x;
+  const double *fr = g.frames + (size_t)l * LGS_TOTAL;
+  for (int e = tid; e < 32 * CB_LS; e += 256) {
+    sA[e] = fr[LGS_A + e];
+    sV[e] = fr[LGS_V + e];
+    sG[e] = 0.0;
+  }
+  if (tid < 32) {
+    sD[tid] = fr[LGS_D + tid];
+    sPi[tid] = fr[LGS_PI + tid];
+  }
+  __syncthreads();
+  // M = sum over the chunks in a fixed order; entry e = tile * 16 + 4 i + j
+  const double *Mp = g.Mpart + (size_t)l * g.nchunk * 400;
+  for (int e = tid; e < 16 * TS * TS; e += 256) {
+    double tot = 0.0;
+    for (int c = 0; c < g.nchunk; ++c) tot += Mp[(size_t)c * 400 + e];
+    const int tile = e >> 4, At = tile / TS, Ct = tile - At * TS;
+    sG[(4 * At + ((e >> 2) & 3)) * CB_LS + 4 * Ct + (e & 3)] = tot;
+  }
+  if (tid == 0) {
+    double tot = 0.0;
+    for (int c = 0; c < g.nchunk; ++c) tot += g.lpart[(size_t)l * g.nchunk + c];
+    double dir = 0.0;
+    for (int k = 0; k < S; ++k) dir = fma(log(sD[k]), a.dirsum[(size_t)l * S + k], dir);
+    sFlag[2] = (tot - dir) * a.inv_n[l];
+  }
+  __syncthreads();
+  small_dA_from_M(S, sG, sV, sRed);
+  tr_update(a, l, epoch, sFlag[2], bc1, bc2s, sA, sG, sD, sPi, sGd, sFlag, sRed, g.best + l);
 }
