@@ -1213,7 +1213,7 @@ static int run_fused_training(cb_bank *h, int kind, double *pi_param, double *up
         for (int e = 0; e < E && rc == CB_OK; ++e) {
           pow_b1 *= a.beta1;
           pow_b2 *= a.beta2;
-          hipLaunchKernelGGL(sp_prepare, dim3(L), dim3(256), lds_p, h->stream, a, g, e);
+          hipLaunchKernelGGL(sp_prepare, dim3(L), dim3(64), lds_p, h->stream, a, g, e);
           const dim3 gb((unsigned)((size_t)L * g.nchunk));
           const double bc1 = 1.0 - pow_b1, bc2s = std::sqrt(1.0 - pow_b2);
 #define SPK(T)                                                                                         \

@@ -21,7 +21,7 @@
 
 #define CB_LS 33  // LDS row stride (doubles) of the 32x32 frames
 #ifndef CB_SMALL_MIN_WGS
-#define CB_SMALL_MIN_WGS 1
+#define CB_SMALL_MIN_WGS 2
 #endif
 
 // in-kernel phase stamps of workgroup 0 (debug: CB_DEBUG_STAMPS), see cb_train_* host code
@@ -195,6 +195,7 @@ __device__ __forceinline__ void small_bucket(const SmallFrags<NT, KS> &f, int S,
         }
       }
   if (MODE == SMALL_EXPM) return;
+  asm volatile("" : "+v"(lossacc));  // keep the logarithms here (see small_quad)
   // the counts of this bucket are consumed: start fetching the next bucket's
   if (Ct_next) load_counts<NT, KS>(cval, S, Ct_next);
 
@@ -311,26 +312,25 @@ __device__ __forceinline__ void small_quad(int S, double tb, const double *__res
   // fenced between tile rows, otherwise it interleaves all TS^2 epilogues and spills ~300 registers.
   double g[TS][TS];
   {
-    asm volatile("" ::: "memory");
-    double UA[TS][TS];  // A layout of U(I,K): U[4 I + r][4 K + q]  (= B layout of U^T(K,I))
-#pragma unroll
-    for (int I = 0; I < TS; ++I)
-#pragma unroll
-      for (int K = 0; K < TS; ++K) UA[I][K] = sV[(4 * K + q) * CB_LS + 4 * I + r];
     double Fk[TS];
 #pragma unroll
     for (int K = 0; K < TS; ++K) Fk[K] = tab[4 * K + q];
     const double tsplit = split ? tb : 0.0, isplit = split ? 1.0 : 0.0;
     // ---- Pt row I, epilogue in place -> g[I][*] = G~^T tiles ---------------------------------
+    // U tiles in A layout (U(I,K): U[4 I + r][4 K + q] = sV[(4 K + q) LS + 4 I + r]; the same words are
+    // U^T(K,I) in B layout) are re-read from LDS for every row: 30 ds_read_b64 per row are cheap, the
+    // 2 TS^2 registers they would occupy are not (the clobber keeps the compiler from caching them).
 #pragma unroll
     for (int I = 0; I < TS; ++I) {
+      asm volatile("" ::: "memory");
       double uf[TS];
 #pragma unroll
-      for (int K = 0; K < TS; ++K) uf[K] = UA[I][K] * Fk[K];
+      for (int K = 0; K < TS; ++K) uf[K] = sV[(4 * K + q) * CB_LS + 4 * I + r] * Fk[K];
 #pragma unroll
       for (int K = 0; K < TS; ++K)       // K outer: TS independent accumulator chains in flight
 #pragma unroll
-        for (int J = 0; J < TS; ++J) g[I][J] = mfma4_f64(uf[K], UA[J][K], K == 0 ? 0.0 : g[I][J]);
+        for (int J = 0; J < TS; ++J)
+          g[I][J] = mfma4_f64(uf[K], sV[(4 * K + q) * CB_LS + 4 * J + r], K == 0 ? 0.0 : g[I][J]);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int J = 0; J < TS; ++J) {
@@ -343,10 +343,12 @@ __device__ __forceinline__ void small_quad(int S, double tb, const double *__res
         lossacc = fma(-c, fast_log(nz ? pt : 1.0), lossacc);
         g[I][J] = nz ? -c * inv_n * fast_rcp(pt) : 0.0;
       }
+      // pin the loss here: otherwise the compiler sinks all TS^2 logarithms (they feed nothing but
+      // lossacc) to the end of the quad and keeps TS^2 Pt values alive across the T and W phases
+      asm volatile("" : "+v"(lossacc));
       __builtin_amdgcn_sched_barrier(0);
     }
   }
-  Q_STAMP(10);
   asm volatile("" ::: "memory");
   double UB[TS][TS];  // B layout of U(I,K): U[4 I + q][4 K + r]  (= A layout of U^T(K,I))
 #pragma unroll
@@ -388,7 +390,8 @@ __device__ __forceinline__ void small_quad(int S, double tb, const double *__res
       const double quot = (ER - EC) * fast_rcp(near ? 1.0 : dl);
       double m = acc[At] * (near ? taylor : quot);
       if (LANEM) {
-        Mw[(At * TS + Ct) * 64 + lane] += m;   // wave-private slot of this lane
+        // wave-private slot of this lane: one ds_add_f64, nothing to wait for
+        __hip_atomic_fetch_add(&Mw[(At * TS + Ct) * 64 + lane], m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
       } else {
         // sum over the four buckets of this pass, then accumulate in the wave-private LDS array
         m += __shfl_xor(m, 4);

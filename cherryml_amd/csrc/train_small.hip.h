@@ -396,15 +396,18 @@ struct SpSplit {
   double *best;    // [L] best loss so far
   int nchunk, quads_per_chunk;
 };
+#define SP_ROWS 24   // S <= 20: frames of 24 rows (stride CB_LS) suffice
 #define SPP_A 0
-#define SPP_G (32 * CB_LS)
-#define SPP_V (2 * 32 * CB_LS)
-#define SPP_LAM (3 * 32 * CB_LS)
+#define SPP_G (SP_ROWS * CB_LS)
+#define SPP_V (2 * SP_ROWS * CB_LS)
+#define SPP_LAM (3 * SP_ROWS * CB_LS)
 #define SPP_D (SPP_LAM + 32)
 #define SPP_PI (SPP_D + 32)
 #define SPP_TOTAL (SPP_PI + 32)
 
-__global__ __launch_bounds__(256) void sp_prepare(TrainArgs a, SpSplit g, int epoch) {
+// one wavefront per workgroup: only the eigensolver's wave has work for most of the kernel, and
+// 19 KB of LDS lets eight sites overlap per CU
+__global__ __launch_bounds__(64) void sp_prepare(TrainArgs a, SpSplit g, int epoch) {
   extern __shared__ double lds[];
   double *sA = lds + SPP_A, *sG = lds + SPP_G, *sV = lds + SPP_V, *sLam = lds + SPP_LAM, *sD = lds + SPP_D,
          *sPi = lds + SPP_PI;
@@ -413,17 +416,17 @@ __global__ __launch_bounds__(256) void sp_prepare(TrainArgs a, SpSplit g, int ep
   if (epoch == 0 && tid == 0) g.best[l] = INFINITY;
   tr_build(a, l, epoch, sA, sD, sPi);
   if (epoch > 0)  // previous eigenvectors: warm start
-    for (int e = tid; e < 32 * CB_LS; e += 256) sV[e] = fr[LGS_V + e];
+    for (int e = tid; e < SP_ROWS * CB_LS; e += 64) sV[e] = fr[LGS_V + e];
   __syncthreads();
   if (tid < 64) wave_eigh_rate(S, sA, sG, sV, sLam, CB_LS, epoch > 0);
   __syncthreads();
-  for (int e = tid; e < 32 * 32; e += 256) {
+  for (int e = tid; e < SP_ROWS * 32; e += 64) {
     const int k = e >> 5, i = e & 31;
     if (k >= S || i >= S) sV[k * CB_LS + i] = 0.0;
   }
-  for (int k = S + tid; k < 32; k += 256) sLam[k] = 0.0;
+  for (int k = S + tid; k < 32; k += 64) sLam[k] = 0.0;
   __syncthreads();
-  for (int e = tid; e < 32 * CB_LS; e += 256) {
+  for (int e = tid; e < SP_ROWS * CB_LS; e += 64) {
     fr[LGS_A + e] = sA[e];
     fr[LGS_V + e] = sV[e];
   }
@@ -492,9 +495,9 @@ __global__ __launch_bounds__(256, 2) void sp_bank(TrainArgs a, SpSplit g) {
 }
 
 #define SPF_A 0
-#define SPF_G (32 * CB_LS)
-#define SPF_V (2 * 32 * CB_LS)
-#define SPF_D (3 * 32 * CB_LS)
+#define SPF_G (SP_ROWS * CB_LS)
+#define SPF_V (2 * SP_ROWS * CB_LS)
+#define SPF_D (3 * SP_ROWS * CB_LS)
 #define SPF_PI (SPF_D + 32)
 #define SPF_GD (SPF_PI + 32)
 #define SPF_FLAG (SPF_GD + 32)
@@ -508,7 +511,7 @@ __global__ __launch_bounds__(256) void sp_finish(TrainArgs a, SpSplit g, int epo
          *sGd = lds + SPF_GD, *sFlag = lds + SPF_FLAG, *sRed = lds + SPF_RED;
   const int S = a.S, tid = threadIdx.x, l = blockIdx.x;
   const double *fr = g.frames + (size_t)l * LGS_TOTAL;
-  for (int e = tid; e < 32 * CB_LS; e += 256) {
+  for (int e = tid; e < SP_ROWS * CB_LS; e += 256) {
     sA[e] = fr[LGS_A + e];
     sV[e] = fr[LGS_V + e];
     sG[e] = 0.0;
