@@ -332,13 +332,13 @@ def main():
             Lb = wl["C"].shape[0] if wl["kind"] == "sites" else 1
             nbytes = float(Lb) * B_local * S * S * 8  # C streamed once per epoch
             achieved = nbytes / (tm["small"] * 1e-3) / 1e9 if tm["small"] > 0 else 0.0
-            kname = ("lg_prepare + lg_bank + lg_finish (3 launches per epoch)" if wl["kind"] == "single"
-                     else "small_train_kernel")
+            kname = "sp_prepare + sp_bank + sp_finish (3 launches per epoch)"
             roofline = dict(bound="hbm", kernel=kname, achieved=achieved,
                             peak=HBM_PEAK_GBS, unit="GB/s", frac=achieved / HBM_PEAK_GBS,
                             traffic=traffic.get("epoch:" + workload) if world == 1 else None,
                             ms_per_epoch_in_kernel=tm["small"], bytes_per_epoch=nbytes,
-                            note="figures are per epoch (SiteRM: one launch runs all K epochs)")
+                            note="figures are per epoch; the kernels are VALU / MFMA bound (log, reciprocal, divided "
+                                 "differences on every count entry), HBM only streams the counts once")
         out = {
             "metric": "cherry-pairs/sec (whole node) per EM iter",
             "value": n_pairs_total / (dt / steps), "unit": "cherry-pairs/s", "n_gpus": world,

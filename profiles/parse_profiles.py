@@ -26,7 +26,7 @@ names = {"k1_pt_loss_gt": "k1_pt_loss_gt", "k2_t_eq_g_u": "k2_t_eq_g_u", "k3_w_p
          "lg_prepare": "lg_prepare", "lg_bank": "lg_bank", "lg_finish": "lg_finish",
          "count_transitions_lds_kernel": "count_transitions_lds_kernel",
          "count_reduce_slabs": "count_reduce_slabs", "k3_reduce": "k3_reduce", "k4_gemm": "k4_gemm",
-         "sg_gemm": "sg_gemm", "lgx_build": "lgx_build", "ble_branch_lengths_kernel": "ble_branch_lengths_kernel",
+         "sp_prepare": "sp_prepare", "sp_bank": "sp_bank", "sp_finish": "sp_finish", "sg_gemm": "sg_gemm", "lgx_build": "lgx_build", "ble_branch_lengths_kernel": "ble_branch_lengths_kernel",
          "ble_site_rates_kernel": "ble_site_rates_kernel"}
 for w in ["coevo400", "lg20", "siterm", "counting", "ble"]:
     st = glob.glob(f"{root}/gpurun_out/{tag}_trace_{w}/*/*_kernel_stats.csv")
@@ -64,10 +64,9 @@ if "lg_transpose_pad" in out["detail"]:
                           "ratio": 129 * 400 * 400 * 8 / (d["fetch_KB_raw"] * 1024)}
 # per-epoch / per-pass totals of the workloads whose step is more than one launch
 bpl = out["bytes_per_launch"]
-if "small_train_kernel:siterm" in bpl:   # one launch runs all epochs of the PMC run (3)
-    bpl["epoch:siterm"] = bpl["small_train_kernel:siterm"] / 3.0
-if all(f"{k}:lg20" in bpl for k in ("lg_prepare", "lg_bank", "lg_finish")):   # 3 launches per epoch
-    bpl["epoch:lg20"] = sum(bpl[f"{k}:lg20"] for k in ("lg_prepare", "lg_bank", "lg_finish"))
+for w in ("siterm", "lg20"):   # S <= 20: three launches per epoch (sp_prepare / sp_bank / sp_finish)
+    if all(f"{k}:{w}" in bpl for k in ("sp_prepare", "sp_bank", "sp_finish")):
+        bpl[f"epoch:{w}"] = sum(bpl[f"{k}:{w}"] for k in ("sp_prepare", "sp_bank", "sp_finish"))
 if all(f"{k}:counting" in bpl for k in ("count_transitions_lds_kernel", "count_reduce_slabs")):
     bpl["pass:counting"] = bpl["count_transitions_lds_kernel:counting"] + bpl["count_reduce_slabs:counting"]
 json.dump(out, open(f"{here}/pmc_traffic.json", "w"), indent=1)
