@@ -61,7 +61,7 @@ struct cb_bank {
   double *n_dev = nullptr;   // [L]
   double *inv_n = nullptr;   // [L]  1/n
   double *ones = nullptr;    // [L]  1.0
-  double *Cq = nullptr;      // S <= 20: counts in quad order [L][nq][TS*TS][64]
+  double *Cq = nullptr;      // S <= 24: counts in quad order [L][nq][TS*TS][64]
   int nq = 0;
   double *dirsum = nullptr;  // [L,S] colsum - rowsum of sum_b C
   // live buckets (C_b != 0), stored first per site; Bl = max over sites = stride of Ct / t_live
@@ -275,7 +275,7 @@ __global__ void bucket_mass(size_t SS, const double *C, double *mass) {
   if (threadIdx.x == 0) mass[blockIdx.x] = s[0];
 }
 
-// S <= 20: quad order.  Block (l, quad): Cq[(I*TS + J)*64 + lane] = C[l, src[l, 4 quad + blk]][4J + r][4I + q]
+// S <= 24: quad order.  Block (l, quad): Cq[(I*TS + J)*64 + lane] = C[l, src[l, 4 quad + blk]][4J + r][4I + q]
 // (lane = 16 q + 4 blk + r; transposed like Ct), zero where the slot / row / column does not exist.
 __global__ void pack_counts_quad(int S, int B, int Bl, int nq, int TS, const int *nlive, const int *src,
                                  const double *C, double *Cq) {
@@ -432,8 +432,8 @@ extern "C" int cb_create(int device, int S, int L, int B, const double *t, const
                        h->n_dev, h->inv_n, h->ones, h->dirsum);
     hipLaunchKernelGGL(transpose_small, dim3((unsigned)((size_t)L * Bl)), dim3(256), 0, h->stream, S, B, Bl,
                        h->nlive, src_idx, Cdev, h->Ct);
-    if (S <= 20) {
-      const int TS = S <= 4 ? 1 : S <= 8 ? 2 : S <= 16 ? 4 : 5;   // = quad_ts(S), the kernels' instantiation
+    if (S <= 24) {
+      const int TS = S <= 4 ? 1 : S <= 8 ? 2 : S <= 16 ? 4 : S <= 20 ? 5 : 6;   // = quad_ts(S), the kernels' instantiation
       h->nq = (Bl + 3) / 4;
       if ((rc = dev_alloc(h, &h->Cq, (size_t)L * h->nq * TS * TS * 64)) != CB_OK) {
         free_tmp();
@@ -532,7 +532,7 @@ extern "C" int cb_total_counts(cb_handle h, double *n) {
 }
 
 // tiles per side of the 4x4-tile path, as the kernel dispatch instantiates it (S <= 20)
-static int quad_ts(int S) { return S <= 4 ? 1 : S <= 8 ? 2 : S <= 16 ? 4 : 5; }
+static int quad_ts(int S) { return S <= 4 ? 1 : S <= 8 ? 2 : S <= 16 ? 4 : S <= 20 ? 5 : 6; }
 
 // ------------------------------------------------------------- small dispatch
 template <int MODE, int NW>
@@ -1186,7 +1186,7 @@ static int run_fused_training(cb_bank *h, int kind, double *pi_param, double *up
     mark(h, EV_START);
     const char *env_split = getenv("CB_LG_SPLIT");
     const char *env_sp = getenv("CB_SITE_SPLIT");
-    const bool site_split = S <= 20 && !(env_sp && atoi(env_sp) == 0) && !(L == 1 && env_split && atoi(env_split) == 0);
+    const bool site_split = S <= 24 && !(env_sp && atoi(env_sp) == 0) && !(L == 1 && env_split && atoi(env_split) == 0);
     const bool split = !site_split && kind == 0 && L == 1 && !(env_split && atoi(env_split) == 0);
     if (E > 0 && site_split) {
       // three launches per epoch over all sites (train_small.hip.h: sp_prepare / sp_bank / sp_finish)
@@ -1200,12 +1200,12 @@ static int run_fused_training(cb_bank *h, int kind, double *pi_param, double *up
       g.nchunk = (nquads + g.quads_per_chunk - 1) / g.quads_per_chunk;
       g.quads_per_chunk = (nquads + g.nchunk - 1) / g.nchunk;  // even split
       double *buf = nullptr;
-      const size_t nbuf = (size_t)L * LGS_TOTAL + (size_t)L * g.nchunk * 401 + L + 8;
+      const size_t nbuf = (size_t)L * LGS_TOTAL + (size_t)L * g.nchunk * 577 + L + 8;
       if (!alloc(&buf, nbuf)) rc = fail(CB_ENOMEM, "fused training: device allocation failed");
       if (rc == CB_OK) {
         g.frames = buf;
         g.Mpart = buf + (size_t)L * LGS_TOTAL;
-        g.lpart = g.Mpart + (size_t)L * g.nchunk * 400;
+        g.lpart = g.Mpart + (size_t)L * g.nchunk * 576;
         g.best = g.lpart + (size_t)L * g.nchunk;
         const size_t lds_p = SPP_TOTAL * sizeof(double), lds_b = SPB_TOTAL * sizeof(double), lds_f = SPF_TOTAL * sizeof(double);
         const int TS = quad_ts(S);
@@ -1225,7 +1225,8 @@ static int run_fused_training(cb_bank *h, int kind, double *pi_param, double *up
             case 1: SPK(1); break;
             case 2: SPK(2); break;
             case 4: SPK(4); break;
-            default: SPK(5); break;
+            case 5: SPK(5); break;
+            default: SPK(6); break;
           }
 #undef SPK
           if ((e & 63) == 63 && hipGetLastError() != hipSuccess) rc = fail(CB_EHIP, "fused training launch failed");

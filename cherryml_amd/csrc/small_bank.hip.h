@@ -57,8 +57,8 @@ struct SmallLds {
   static constexpr int LAM = V + FRAME;       // 32
   static constexpr int D = LAM + 32;          // sqrt(pi)
   static constexpr int TAB = D + 32;          // per wave: 4 x (F[32], E[32], H[32]) (one set per MFMA block)
-  static constexpr int M4 = TAB + NW * 384;   // per wave: 400 doubles, the M accumulator of the 4x4-tile path
-  static constexpr int RED = M4 + NW * 400;   // (NW/2) * 1024 reduction slots (min 1)
+  static constexpr int M4 = TAB + NW * 384;   // per wave: 16 TS^2 <= 576 doubles, the M accumulator of the 4x4-tile path
+  static constexpr int RED = M4 + NW * 576;   // (NW/2) * 1024 reduction slots (min 1)
   static constexpr int LOSS = RED + ((NW / 2) > 0 ? (NW / 2) : 1) * 1024;
   static constexpr int LOSSTOT = LOSS + NW;
   static constexpr int TOTAL = LOSSTOT + 1;
@@ -249,7 +249,7 @@ __device__ __forceinline__ void small_bucket(const SmallFrags<NT, KS> &f, int S,
   wave_lds_fence();  // tab is rewritten by the next bucket
 }
 
-// ---- 4x4-tile path (S <= 20): FOUR buckets per wavefront pass, one per MFMA block ---------------
+// ---- 4x4-tile path (S <= 24): FOUR buckets per wavefront pass, one per MFMA block ---------------
 // With 16x16 tiles a 20-state matrix is padded to 32 x 32 (39 % useful work in the MFMAs and in the
 // log / reciprocal / divided-difference epilogues).  v_mfma_f64_4x4x4f64 multiplies four
 // independent 4x4x4 blocks per instruction: block b of every instruction belongs to bucket
@@ -481,11 +481,11 @@ __device__ __forceinline__ void small_site_eval(double *lds, int S, int B,
   rho = 2.0 * wave_max(rho);
   double *tab = lds + LD::TAB + wave * 384;
   double *red = lds + LD::RED;
-  if (MODE == SMALL_LOSSGRAD && KS <= 5) {
+  if (MODE == SMALL_LOSSGRAD && KS <= 6) {
     // ---- 4x4 tiles, four buckets per pass (see small_quad) --------------------------------------
-    constexpr int TS = KS <= 5 ? KS : 1;
+    constexpr int TS = KS <= 6 ? KS : 1;
     const int blk = (lane >> 2) & 3;
-    double *Mw = lds + LD::M4 + wave * 400;
+    double *Mw = lds + LD::M4 + wave * 576;
     for (int e = lane; e < 16 * TS * TS; e += 64) Mw[e] = 0.0;
     wave_lds_fence();
     double lossacc = 0.0;
@@ -503,7 +503,7 @@ __device__ __forceinline__ void small_site_eval(double *lds, int S, int B,
       __syncthreads();
       for (int e = threadIdx.x; e < 16 * TS * TS; e += blockDim.x) {
         double tot = 0.0;
-        for (int w = 0; w < NW; ++w) tot += lds[LD::M4 + w * 400 + e];
+        for (int w = 0; w < NW; ++w) tot += lds[LD::M4 + w * 576 + e];
         const int tile = e >> 4, At = tile / TS, Ct = tile - At * TS;
         const int a = 4 * At + ((e >> 2) & 3), c = 4 * Ct + (e & 3);
         sG[a * CB_LS + c] = tot;

@@ -379,7 +379,7 @@ __global__ __launch_bounds__(256) void lg_finish(TrainArgs a, LgSplit g, int epo
 }
 
 // ---------------------------------------------------------------------------------------
-// Site-parallel split trainer (S <= 20, any L, both parameterisations).  In the one-kernel trainer a
+// Site-parallel split trainer (S <= 24, any L, both parameterisations).  In the one-kernel trainer a
 // workgroup owns a site for all epochs: every epoch its wave 0 spends ~70 us in the eigensolver
 // (31 % of the epoch at 20 states) while the other waves wait, and its count streaming cannot
 // overlap anybody else's serial phases.  Here an epoch is three launches over all sites, enqueued
@@ -391,12 +391,12 @@ __global__ __launch_bounds__(256) void lg_finish(TrainArgs a, LgSplit g, int epo
 // State between the launches lives in HBM / L2 (17.7 KB of frames per site).
 struct SpSplit {
   double *frames;  // [L][LGS_TOTAL]   A | V | lam | d | pi
-  double *Mpart;   // [L][nchunk][400] partial M of a chunk, [tile][4 q + r]
+  double *Mpart;   // [L][nchunk][576] partial M of a chunk, [tile][4 q + r]
   double *lpart;   // [L][nchunk]
   double *best;    // [L] best loss so far
   int nchunk, quads_per_chunk;
 };
-#define SP_ROWS 24   // S <= 20: frames of 24 rows (stride CB_LS) suffice
+#define SP_ROWS 24   // S <= 24: frames of 24 rows (stride CB_LS) suffice
 #define SPP_A 0
 #define SPP_G (SP_ROWS * CB_LS)
 #define SPP_V (2 * SP_ROWS * CB_LS)
@@ -444,7 +444,7 @@ __global__ __launch_bounds__(64) void sp_prepare(TrainArgs a, SpSplit g, int epo
 #define SPB_LAM (2 * SPB_ROWS * CB_LS)
 #define SPB_TAB (SPB_LAM + 32)
 #define SPB_MW (SPB_TAB + 4 * 384)
-#define SPB_LOSS (SPB_MW + 4 * 1600)
+#define SPB_LOSS (SPB_MW + 4 * 1600)   // TS <= 5: [tile][64] per wave (1600); TS = 6: [tile][16] (576)
 #define SPB_TOTAL (SPB_LOSS + 8)
 
 template <int TS>
@@ -459,8 +459,10 @@ __global__ __launch_bounds__(256, 2) void sp_bank(TrainArgs a, SpSplit g) {
     sV[e] = fr[LGS_V + e];
   }
   if (tid < 32) sLam[tid] = fr[LGS_LAM + tid];
-  double *Mw = lds + SPB_MW + wave * 1600;
-  for (int e = lane; e < 64 * TS * TS; e += 64) Mw[e] = 0.0;
+  constexpr bool LANEM = TS <= 5;               // per-lane M slots while they fit LDS (2 workgroups per CU)
+  constexpr int MWS = LANEM ? 1600 : 576;       // doubles per wave
+  double *Mw = lds + SPB_MW + wave * MWS;
+  for (int e = lane; e < (LANEM ? 64 : 16) * TS * TS; e += 64) Mw[e] = 0.0;
   __syncthreads();
   const int Bn = a.nlive[l], nquads = (Bn + 3) / 4;
   const size_t lb = (size_t)l * a.B;
@@ -474,19 +476,23 @@ __global__ __launch_bounds__(256, 2) void sp_bank(TrainArgs a, SpSplit g) {
   for (int qd = q0 + wave; qd < q1; qd += 4) {
     const int bucket = 4 * qd + blk;
     const double tb = bucket < Bn ? t_l[bucket] : 0.0;
-    small_quad<TS, true>(S, tb, Cq_l + (size_t)qd * (TS * TS * 64), inv_n, sA, sV, lds + SPB_TAB + wave * 384, sLam,
+    small_quad<TS, LANEM>(S, tb, Cq_l + (size_t)qd * (TS * TS * 64), inv_n, sA, sV, lds + SPB_TAB + wave * 384, sLam,
                          rho, Mw, lossacc);
   }
   lossacc = wave_sum(lossacc);
   if (lane == 0) lds[SPB_LOSS + wave] = lossacc;
   __syncthreads();
-  double *dst = g.Mpart + ((size_t)l * g.nchunk + chunk) * 400;
-  for (int e = tid; e < 16 * TS * TS; e += 256) {   // e = tile * 16 + 4 q + r: sum the 4 blocks of the 4 waves, fixed order
-    const int slot = (e >> 4) * 64 + 16 * ((e >> 2) & 3) + (e & 3);
+  double *dst = g.Mpart + ((size_t)l * g.nchunk + chunk) * 576;
+  for (int e = tid; e < 16 * TS * TS; e += 256) {   // e = tile * 16 + 4 q + r: sum the (4 blocks of the) 4 waves, fixed order
     double tot = 0.0;
-    for (int w = 0; w < 4; ++w) {
-      const double *m = lds + SPB_MW + w * 1600 + slot;
-      tot += (m[0] + m[4]) + (m[8] + m[12]);
+    if (LANEM) {
+      const int slot = (e >> 4) * 64 + 16 * ((e >> 2) & 3) + (e & 3);
+      for (int w = 0; w < 4; ++w) {
+        const double *m = lds + SPB_MW + w * MWS + slot;
+        tot += (m[0] + m[4]) + (m[8] + m[12]);
+      }
+    } else {
+      for (int w = 0; w < 4; ++w) tot += lds[SPB_MW + w * MWS + e];
     }
     dst[e] = tot;
   }
@@ -522,10 +528,10 @@ __global__ __launch_bounds__(256) void sp_finish(TrainArgs a, SpSplit g, int epo
   }
   __syncthreads();
   // M = sum over the chunks in a fixed order; entry e = tile * 16 + 4 i + j
-  const double *Mp = g.Mpart + (size_t)l * g.nchunk * 400;
+  const double *Mp = g.Mpart + (size_t)l * g.nchunk * 576;
   for (int e = tid; e < 16 * TS * TS; e += 256) {
     double tot = 0.0;
-    for (int c = 0; c < g.nchunk; ++c) tot += Mp[(size_t)c * 400 + e];
+    for (int c = 0; c < g.nchunk; ++c) tot += Mp[(size_t)c * 576 + e];
     const int tile = e >> 4, At = tile / TS, Ct = tile - At * TS;
     sG[(4 * At + ((e >> 2) & 3)) * CB_LS + 4 * Ct + (e & 3)] = tot;
   }

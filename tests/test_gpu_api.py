@@ -428,3 +428,31 @@ def test_sharded_bank_from_rank_counts_on_device_tensor():
     assert abs(loss.item() - ref.item()) < 1e-12 * abs(ref.item())
     assert relerr(Q.grad.cpu().numpy(), Qr.grad.numpy()) < 1e-10
     sb.close()
+
+
+@pytest.mark.parametrize("N,B", [(21, 7), (24, 5), (12, 9), (7, 3)])
+def test_siterm_trainer_other_state_counts(N, B):
+    """The 4x4-tile path instantiates 1, 2, 4, 5 and 6 tiles per side (S <= 4, 8, 16, 20, 24): fused SiteRM
+    trainer (site-parallel split) against the oracle for alphabets other than 4 and 20 (21 = amino acids + gap)."""
+    from cherryml_amd import quantized_transitions_mle_vectorized_over_sites as qvec
+    from oracle import ratelearn_oracle as orc
+    rng = np.random.default_rng(N * 10 + B)
+    L, E = 6, 15
+    counts = rng.poisson(3.0, size=(L, B, N, N)).astype(np.float64)
+    counts = counts + counts.transpose(0, 1, 3, 2) + 5.0 * np.eye(N)
+    counts[2, 1] = 0.0                                  # an empty bucket in one site
+    times = np.sort(rng.uniform(0.02, 2.0, size=(L, B)), axis=1)
+    init = np.zeros((L, N, N))
+    for l in range(L):
+        pi = rng.dirichlet(np.full(N, 8.0))
+        R = rng.gamma(2.0, 0.3, size=(N, N))
+        R = np.triu(R, 1)
+        R = R + R.T
+        d = np.sqrt(pi)
+        init[l] = R * d[None, :] / d[:, None]
+        init[l] -= np.diag(init[l].sum(1))
+    ref = orc.siterm_train(counts, times, E, initialization=init)
+    got = qvec(counts, times, num_epochs=E, initialization=init, device="cuda", fused=True)
+    assert np.allclose(got["loss_per_epoch_per_site"], ref["loss_per_epoch_per_site"], rtol=1e-8, atol=0)
+    for l in range(L):
+        assert relerr(got["res"][l], ref["res"][l]) < 1e-6, l

@@ -217,7 +217,7 @@ def test_symmetric_counts_take_the_triangular_tile_path(S, B):
     assert relerr(dQ[0], ref_grad) < 1e-10
 
 
-@pytest.mark.parametrize("S,B", [(2, 3), (5, 1), (17, 4), (32, 5), (33, 3), (48, 2), (100, 3), (161, 2), (415, 2),
+@pytest.mark.parametrize("S,B", [(2, 3), (5, 1), (9, 6), (12, 5), (17, 4), (21, 7), (24, 9), (25, 3), (32, 5), (33, 3), (48, 2), (100, 3), (161, 2), (415, 2),
                                  (640, 1), (1024, 1)])   # 1024 = the documented maximum
 def test_odd_sizes_padding_and_partial_tiles(S, B):
     """S = 33..161 take the large path with LD = ceil16(S) zero padding and partial 80-tiles;
