@@ -20,7 +20,8 @@
 
 // A rotation is skipped when the pair is already orthogonal to rounding; the
 // sweeps stop after the first sweep whose largest PRE-rotation cosine was
-// below CB_JAC_STOP (quadratic convergence: that sweep leaves ~CB_JAC_STOP^2).
+// below CB_JAC_STOP (quadratic convergence: that sweep leaves ~CB_JAC_STOP^2 x sigma/gap; with
+// near-degenerate sites 1e-8 was measured to leave 1e-12 and to drift trajectories by 1e-10).
 #define CB_JAC_SKIP 1e-16
 #define CB_JAC_STOP 1e-11
 #define CB_JAC_MAX_SWEEPS 40
@@ -96,14 +97,15 @@ __device__ int wave_jacobi_columns(int n, double *Gc, double *Vc, int LS, int ma
         const double g2 = g * g;
         if (g2 > ab * (CB_JAC_STOP * CB_JAC_STOP)) off = 1.0;  // "not converged" flag
         if (g2 > ab * (CB_JAC_SKIP * CB_JAC_SKIP)) {
-          // t = tan(theta) = 2 g / (d + sign(d) sqrt(d^2 + 4 g^2)), d = b - a
+          // half-angle form (|theta| <= pi/4): cos 2theta = |d| / h, sin 2theta = sign(d) 2 g / h, d = b - a,
+          // c = sqrt((1 + cos 2theta) / 2), s = sin 2theta / (2 c): two dependent rsqrt
           const double d = b - a;
           const double hh = fma(d, d, 4.0 * g2);   // > 0 here
-          const double h = hh * fast_rsqrt(hh);     // sqrt
-          const double den = d + copysign(h, d);
-          const double t = 2.0 * g * copysign(fast_rcp(fabs(den)), den);
-          const double c = fast_rsqrt(fma(t, t, 1.0));
-          const double s = c * t;
+          const double rh = fast_rsqrt(hh);
+          const double xx = fma(0.5 * fabs(d), rh, 0.5);
+          const double rx = fast_rsqrt(xx);
+          const double c = xx * rx;
+          const double s = copysign(g * rh * rx, g * d);
 #pragma unroll
           for (int i = 0; i < RPL; ++i) {
             const int row = sub + 4 * i;
