@@ -73,6 +73,21 @@ class CherryBank:
         _lib.check(lib.cb_live_buckets(self._h, nl.ctypes.data), "cb_live_buckets")
         self.live_buckets = nl      # non-empty buckets per site: the ones the loss visits
 
+    def allreduce_setup(self, rccl_comm, nccl_allreduce_fn, n_total):
+        """In-library multi-GPU reduction (cb_allreduce_setup): `rccl_comm` an ncclComm_t (int / c_void_p),
+        `nccl_allreduce_fn` the address of ncclAllReduce of the RCCL that owns it, `n_total[L]` the global
+        total counts.  Afterwards loss_grad / loss_grad_general return the sums over the ranks.
+        rccl_comm=None switches it off."""
+        import ctypes as Ct
+        if rccl_comm is None:
+            _lib.check(_lib.load().cb_allreduce_setup(self._h, None, None, None), "cb_allreduce_setup")
+            return
+        n = _as_f64(n_total).reshape(-1)
+        if n.size != self.L:
+            raise ValueError("n_total must have L entries")
+        _lib.check(_lib.load().cb_allreduce_setup(self._h, Ct.c_void_p(int(rccl_comm)), Ct.c_void_p(int(nccl_allreduce_fn)),
+                                                  n.ctypes.data), "cb_allreduce_setup")
+
     # -- lifetime ---------------------------------------------------------
     def close(self):
         if getattr(self, "_h", None) is not None:

@@ -75,6 +75,11 @@ struct cb_bank {
   // large-path workspaces
   double *Gc2 = nullptr, *gx = nullptr;  // second column buffer and 4 LD^2 scratch of the first-order sweep
   int last_light = 0;
+  // in-library all-reduce (cb_allreduce_setup)
+  void *comm = nullptr;
+  int (*allreduce)(const void *, void *, size_t, int, int, void *, hipStream_t) = nullptr;
+  double *inv_n_global = nullptr;  // [L] 1 / n_total
+  std::vector<double> n_global;
   bool sym_counts = false;  // every live bucket has C_b == C_b^T (cherry counts are, by construction)
   int spec_sweeps = 0;  // Jacobi sweeps to enqueue before the first host check (learned from the previous solve)
   double *A = nullptr, *dsq = nullptr, *Gc = nullptr, *Vc = nullptr, *U = nullptr, *lam = nullptr,
@@ -519,6 +524,39 @@ extern "C" int cb_set_stream(cb_handle h, void *hip_stream, int own) {
   return CB_OK;
 }
 
+extern "C" int cb_allreduce_setup(cb_handle h, void *rccl_comm, void *nccl_allreduce_fn, const double *n_total) {
+  if (!h) return fail(CB_EINVAL, "cb_allreduce_setup: NULL handle");
+  if (!rccl_comm) {
+    h->comm = nullptr;
+    h->allreduce = nullptr;
+    return CB_OK;
+  }
+  if (!nccl_allreduce_fn || !n_total) return fail(CB_EINVAL, "cb_allreduce_setup: NULL argument");
+  for (int l = 0; l < h->L; ++l)
+    if (!(n_total[l] > 0.0) || !std::isfinite(n_total[l])) return fail(CB_EINVAL, "cb_allreduce_setup: n_total[%d] = %g", l, n_total[l]);
+  HIP_TRY(hipSetDevice(h->dev));
+  if (!h->inv_n_global) {
+    int rc = dev_alloc(h, &h->inv_n_global, h->L);
+    if (rc != CB_OK) return rc;
+  }
+  std::vector<double> inv(h->L);
+  for (int l = 0; l < h->L; ++l) inv[l] = 1.0 / n_total[l];
+  HIP_TRY(hipMemcpy(h->inv_n_global, inv.data(), h->L * sizeof(double), hipMemcpyHostToDevice));
+  h->n_global.assign(n_total, n_total + h->L);
+  h->comm = rccl_comm;
+  h->allreduce = reinterpret_cast<int (*)(const void *, void *, size_t, int, int, void *, hipStream_t)>(nccl_allreduce_fn);
+  return CB_OK;
+}
+
+// sum (loss[L], dQ[L,S,S]) over the ranks, in place, on the handle's stream (ncclDouble = 8, ncclSum = 0)
+static int allreduce_results(cb_bank *h, double *lossd, double *dQd) {
+  if (!h->comm) return CB_OK;
+  int rc = h->allreduce(lossd, lossd, (size_t)h->L, 8, 0, h->comm, h->stream);
+  if (rc == 0 && dQd) rc = h->allreduce(dQd, dQd, (size_t)h->L * h->S * h->S, 8, 0, h->comm, h->stream);
+  if (rc != 0) return fail(CB_EHIP, "ncclAllReduce failed with code %d", rc);
+  return CB_OK;
+}
+
 extern "C" int cb_live_buckets(cb_handle h, int *nlive) {
   if (!h || !nlive) return fail(CB_EINVAL, "cb_live_buckets: NULL argument");
   memcpy(nlive, h->nlive_host.data(), h->L * sizeof(int));
@@ -746,7 +784,7 @@ static int large_eval(cb_bank *h, bool normalize, double *lossd, double *out, bo
   hipLaunchKernelGGL(lg_tables, dim3((unsigned)(((size_t)B * LD + 255) / 256)), dim3(256), 0,
                      h->stream, LD, B, tb, h->lam, h->sigma, h->F, h->E, h->H);
   const int tm = (LD + LG_TM - 1) / LG_TM, tn = (LD + LG_TN - 1) / LG_TN, tiles = tm * tn;
-  const double inv_n = normalize ? 1.0 / h->n_host[0] : 1.0;
+  const double inv_n = normalize ? 1.0 / (h->comm ? h->n_global[0] : h->n_host[0]) : 1.0;
   K1Args k1{S, LD, B, h->Vc, h->A, tb, h->F, h->sigma, h->Ct, h->Gt, h->loss_part, inv_n, h->dsq, Pd};
   mark(h, EV_END);  // (re-used as "before K1" marker)
   const int tiles_k1 = tn * (tn + 1) / 2;  // Pt is symmetric: upper-triangular tiles only
@@ -827,7 +865,7 @@ extern "C" int cb_loss_grad(cb_handle h, const double *Q, const double *pi, int 
     a.Ct = h->Ct;
     a.Cq = h->Cq;
     a.nq = h->nq;
-    a.inv_n = (flags & CB_NORMALIZE) ? h->inv_n : h->ones;
+    a.inv_n = (flags & CB_NORMALIZE) ? (h->comm ? h->inv_n_global : h->inv_n) : h->ones;
     a.dirsum = h->dirsum;
     a.Q = Qd;
     a.pi = pid;
@@ -838,6 +876,7 @@ extern "C" int cb_loss_grad(cb_handle h, const double *Q, const double *pi, int 
     mark(h, EV_SMALL);
   }
   if (rc != CB_OK) return rc;
+  if ((rc = allreduce_results(h, lossd, dQd)) != CB_OK) return rc;
   if (h->profile) h->t_pending = true;
   if (!devp) {
     HIP_TRY(hipMemcpyAsync(loss, h->loss, h->L * sizeof(double), hipMemcpyDeviceToHost, h->stream));
@@ -975,7 +1014,7 @@ static int general_run(cb_bank *h, const double *Qd, int flags, double *lossd, d
   a.S = h->S; a.L = h->L;
   if (Pd) { a.B = h->B; a.t = h->t; a.nlive = nullptr; }            // expm: every bucket, original order
   else { a.B = h->Bl; a.t = h->t_live; a.nlive = h->nlive; }        // loss: live buckets only
-  a.Ct = h->Ct; a.inv_n = (flags & CB_NORMALIZE) ? h->inv_n : h->ones;
+  a.Ct = h->Ct; a.inv_n = (flags & CB_NORMALIZE) ? (h->comm ? h->inv_n_global : h->inv_n) : h->ones;
   a.Q = Qd; a.loss = lossd; a.dQ = dQd; a.P = Pd;
   a.scratch = h->gn_scratch; a.partial = h->gn_partial;
   if (NW == 8) hipLaunchKernelGGL(general_bank_kernel<8>, dim3(h->L), dim3(512), 0, h->stream, a);
@@ -1000,6 +1039,7 @@ extern "C" int cb_loss_grad_general(cb_handle h, const double *Q, int flags, dou
   }
   int rc = general_run(h, Qd, flags, lossd, dQd, nullptr);
   if (rc != CB_OK) return rc;
+  if ((rc = allreduce_results(h, lossd, dQd)) != CB_OK) return rc;
   if (!devp) {
     HIP_TRY(hipMemcpyAsync(loss, h->loss, h->L * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     if (dQ)

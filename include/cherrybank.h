@@ -219,6 +219,18 @@ int cb_count_co_transitions(int device, int S, int B, const double *grid, const 
                             const cb_count_pair *pairs, int64_t n_pairs, int symmetric, int flags,
                             unsigned long long *counts);
 
+/* ---- multi-GPU inside the library (SURVEY 8b / 8e option 1) ------------------------------------------
+ * After this call cb_loss_grad and cb_loss_grad_general return the sums over all ranks of the
+ * communicator: every rank holds a shard of the buckets (its own cb_create), evaluates its partial
+ * (loss, dL/dQ) normalised by the GLOBAL totals n_total[L] (CB_NORMALIZE) and the library enqueues
+ * ncclAllReduce(sum) on both results on the handle's stream, in place -- S*S + 1 doubles per site per
+ * call, no other traffic.  `rccl_comm` is an ncclComm_t; `nccl_allreduce_fn` is the address of
+ * ncclAllReduce of the RCCL that created it (C/C++: (void *)&ncclAllReduce; Python:
+ * ctypes.cast(librccl.ncclAllReduce, c_void_p)), so the library has no link-time dependency on RCCL.
+ * rccl_comm == NULL switches the reduction off again.  torch.distributed users do not need this
+ * (cherryml_amd/distributed.py all-reduces with torch); it is the hook for non-Python hosts. */
+int cb_allreduce_setup(cb_handle h, void *rccl_comm, void *nccl_allreduce_fn, const double *n_total);
+
 /* ---- SiteRM count / pseudocount assembly of ONE family ----------------------------
  * Replaces the per-transition / per-site Python loops of
  * cherryml/_siterm/_site_specific_rate_matrix.py:189-261 (_get_raw_count_matrices) and :503-567

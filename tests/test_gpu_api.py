@@ -456,3 +456,45 @@ def test_siterm_trainer_other_state_counts(N, B):
     assert np.allclose(got["loss_per_epoch_per_site"], ref["loss_per_epoch_per_site"], rtol=1e-8, atol=0)
     for l in range(L):
         assert relerr(got["res"][l], ref["res"][l]) < 1e-6, l
+
+
+def test_in_library_allreduce_with_a_single_rank_rccl_communicator():
+    """cb_allreduce_setup: a real RCCL communicator (one rank, created through ctypes on torch's own
+    librccl) + the address of its ncclAllReduce.  With one rank the sums equal the local results; the
+    normaliser becomes the global n_total handed over."""
+    import ctypes as C
+    import glob
+    from cherryml_amd import CherryBank
+    from oracle import ratelearn_oracle as orc
+    libs = glob.glob(os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so*"))
+    if not libs:
+        pytest.skip("no librccl next to torch")
+    rccl = C.CDLL(libs[0])
+
+    class UniqueId(C.Structure):
+        _fields_ = [("internal", C.c_char * 128)]
+    uid = UniqueId()
+    assert rccl.ncclGetUniqueId(C.byref(uid)) == 0
+    comm = C.c_void_p()
+    torch.cuda.set_device(0)
+    rccl.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, UniqueId, C.c_int]
+    assert rccl.ncclCommInitRank(C.byref(comm), 1, uid, 0) == 0
+    fn = C.cast(rccl.ncclAllReduce, C.c_void_p).value
+    try:
+        for name in ("traj_lgbank.npz", "eval_s400_mask.npz"):
+            g = load_golden(name)
+            t, Cc = g["t"][:6], g["C"][:6]
+            Q = g["init"] if "init" in g else g["Q_f64"]
+            pi = orc.stationary_distribution(Q)
+            with CherryBank(t, Cc) as bank:
+                l0, d0 = bank.loss_grad(Q, pi)
+                bank.allreduce_setup(comm.value, fn, 2.0 * bank.total_counts)   # pretend the job holds twice the counts
+                l1, d1 = bank.loss_grad(Q, pi)
+                bank.allreduce_setup(None, None, None)
+                l2, d2 = bank.loss_grad(Q, pi)
+            assert np.allclose(l1, 0.5 * l0, rtol=1e-14) and relerr(d1[0], 0.5 * d0[0]) < 1e-14
+            # (the third solve is warm-started, so equal to rounding, not bitwise)
+            assert np.allclose(l2, l0, rtol=1e-13) and relerr(d2[0], d0[0]) < 1e-12
+    finally:
+        rccl.ncclCommDestroy.argtypes = [C.c_void_p]
+        rccl.ncclCommDestroy(comm)
