@@ -181,7 +181,7 @@ def main():
     ap.add_argument("--steps", type=int, default=None)
     ap.add_argument("--warmup", type=int, default=None)
     ap.add_argument("--workload", default="coevo400",
-                    choices=["coevo400", "lg20", "siterm", "counting", "ble"])
+                    choices=["coevo400", "lg20", "siterm", "counting", "ble", "assembly"])
     ap.add_argument("--sites", type=int, default=5000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true")
@@ -371,9 +371,12 @@ def main():
             sys.stdout.write(json.dumps(out) + "\n")
             sys.stdout.flush()
 
-    defaults = {"coevo400": (50, 5), "lg20": (500, 50), "siterm": (5, 1), "counting": (20, 3), "ble": (5, 1)}
+    defaults = {"coevo400": (50, 5), "lg20": (500, 50), "siterm": (5, 1), "counting": (20, 3), "ble": (5, 1), "assembly": (5, 1)}
     steps = args.steps if args.steps is not None else defaults[args.workload][0]
     warmup = args.warmup if args.warmup is not None else defaults[args.workload][1]
+    if args.workload == "assembly":
+        finish(run_assembly(steps, warmup, world, rank, local_rank, fence, world == 1 and not args.no_cpu_baseline))
+        return
     if args.workload == "ble":
         finish(run_ble(steps, warmup, world, rank, local_rank, fence, world == 1 and not args.no_cpu_baseline))
         return
@@ -577,6 +580,72 @@ def run_ble(steps, warmup, world, rank, local_rank, fence, with_cpu):
             out["cpu_baseline"] = dict(value=valid / dtc, unit="cherry-pairs/s", cores=1, kind="reference",
                                        sample=f"the reference's ble() (oracle/_ref/libref_ble.so) on {sub} of {n} "
                                               "cherries, scaled", seconds_per_step=dtc)
+    return out
+
+
+def run_assembly(steps, warmup, world, rank, local_rank, fence, with_cpu):
+    """SiteRM count / pseudocount assembly (cb_siterm_assemble) of one large synthetic family per rank:
+    2048 cherries x 512 sites, 20 states, 129 buckets -> the [512,129,20,20] float64 count tensor
+    (211 MB), left on the device.  A step is one whole assembly (clear + count + pseudocount mix)."""
+    import torch
+    import torch.distributed as dist
+    from cherryml_amd._siterm._assembly import _assemble, get_count_prior_probability_matrices
+    from cherryml_amd.counting._stage import PAIR_DTYPE
+    rng = np.random.default_rng(200 + rank)
+    n, L, S = 2048, 512, 20
+    grid = quantization_grid()
+    Q = lg_matrix()
+    prior = get_count_prior_probability_matrices(Q, list(grid))
+    codes = rng.integers(0, 20, size=(2 * n, L)).astype(np.int8)
+    codes[rng.random(codes.shape) < 0.05] = -1
+    pairs = np.zeros(n, dtype=PAIR_DTYPE)
+    lengths = rng.exponential(0.4, size=n)
+    for k in range(n):
+        pairs[k] = (2 * k * L, (2 * k + 1) * L, 0, L, 0, lengths[k], 0.0)
+    rates = rng.gamma(3.0, 1.0 / 3.0, size=L)
+    prof = {}
+    call = lambda: _assemble(pairs, codes, grid, rates, prior, 0.5, True, S, local_rank, True, profile=prof)  # noqa: E731
+    for _ in range(warmup):
+        call()
+    fence()
+    kms = []
+    for _ in range(steps):
+        out_t = call()
+        kms.append(prof["kernel_ms"])
+    fence()
+    kernel_ms = float(np.mean(kms))
+    if world > 1:
+        tdt = torch.tensor([kernel_ms], dtype=torch.float64, device=torch.device("cuda", local_rank))
+        dist.all_reduce(tdt, op=dist.ReduceOp.MAX)
+        kernel_ms = float(tdt.item())
+    if rank != 0:
+        return None
+    valid = int(((codes[0::2] >= 0) & (codes[1::2] >= 0)).sum())
+    nbytes = float(out_t.numel() * 8 + codes.nbytes)        # the tensor written once + the codes read once
+    out = {
+        "metric": "cherry-pairs/sec (whole node): cherry x site transitions assembled into SiteRM count tensors",
+        "value": valid * world / (kernel_ms * 1e-3), "unit": "cherry-pairs/s", "n_gpus": world, "steps": steps,
+        "warmup": warmup, "ms_per_step": kernel_ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "i8/f64", "data": "synthetic",
+        "config": {"workload": f"SiteRM assembly: {n} cherries x {L} sites per GPU, 20 states, 129 buckets, lambda 0.5",
+                   "sharding": f"families x{world} (no collective)"},
+        "roofline": {"bound": "hbm", "kernel": "memset + siterm_raw_counts_kernel + siterm_mix_kernel", "achieved":
+                     nbytes / (kernel_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": nbytes / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None, "bytes_per_step": nbytes,
+                     "note": "the [L,B,S,S] tensor is cleared (1 write) and its live (site, bucket) matrices rewritten"},
+    }
+    if with_cpu:
+        from oracle import siterm_assembly_oracle as sa
+        sub = 64
+        aa = "ARNDCQEGHILKMFPSTWYV"
+        dec = lambda row: "".join(aa[c] if c >= 0 else "-" for c in row)  # noqa: E731
+        tr = [(dec(codes[2 * k]), dec(codes[2 * k + 1]), float(lengths[k])) for k in range(sub)]
+        t0 = time.perf_counter()
+        sa.raw_count_matrices(tr, list(grid), list(aa), True)
+        dtc = (time.perf_counter() - t0) * (n / sub)
+        out["cpu_baseline"] = dict(value=valid / dtc, unit="cherry-pairs/s", cores=1, kind="port",
+                                   sample=f"oracle raw_count_matrices (the reference's Python loop) on {sub} of {n} cherries, "
+                                          "scaled; pseudocount mix not included", seconds_per_step=dtc)
     return out
 
 

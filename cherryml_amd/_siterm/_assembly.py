@@ -94,7 +94,7 @@ def get_count_prior_probability_matrices(rate_matrix: np.ndarray, quantization_p
     return out
 
 
-def _assemble(pairs, codes, grid, site_rates, prior, lam, reverse, S, device: int, to_torch: bool):
+def _assemble(pairs, codes, grid, site_rates, prior, lam, reverse, S, device: int, to_torch: bool, profile=None):
     L, B = codes.shape[1], len(grid)
     codes = np.ascontiguousarray(codes)
     grid = np.ascontiguousarray(grid, dtype=np.float64)
@@ -111,10 +111,15 @@ def _assemble(pairs, codes, grid, site_rates, prior, lam, reverse, S, device: in
     else:
         out = np.empty((L, B, S, S))
         ptr, flags = out.ctypes.data, 0
+    import ctypes
+    ms = ctypes.c_double(0.0)
     rc = lib.cb_siterm_assemble(device, S, B, L, grid.ctypes.data, codes.ctypes.data, codes.size,
                                 pairs.ctypes.data, len(pairs), rates.ctypes.data, prior.ctypes.data,
-                                float(lam), int(bool(reverse)), flags, ptr)
+                                float(lam), int(bool(reverse)), flags, ptr,
+                                ctypes.addressof(ms) if profile is not None else None)
     _lib.check(rc, "cb_siterm_assemble")
+    if profile is not None:
+        profile["kernel_ms"] = ms.value
     return out
 
 

@@ -1633,7 +1633,7 @@ extern "C" int cb_count_co_transitions(int device, int S, int B, const double *g
 extern "C" int cb_siterm_assemble(int device, int S, int B, int n_sites, const double *grid, const int8_t *seqs,
                                   int64_t seqs_bytes, const cb_count_pair *pairs, int64_t n_pairs,
                                   const double *site_rates, const double *prior, double lambda,
-                                  int include_reverse, int flags, double *counts) {
+                                  int include_reverse, int flags, double *counts, double *kernel_ms) {
   if (!grid || !seqs || !pairs || !site_rates || !prior || !counts)
     return fail(CB_EINVAL, "cb_siterm_assemble: NULL argument");
   if (S < 2 || S > 64 || B < 1 || n_sites < 1 || n_pairs < 0 || seqs_bytes < 0)
@@ -1671,6 +1671,13 @@ extern "C" int cb_siterm_assemble(int device, int S, int B, int n_sites, const d
   TRYA(hipMemcpyAsync(d_pairs, pairs, n_pairs * sizeof(cb_count_pair), hipMemcpyHostToDevice, 0));
   TRYA(hipMemcpyAsync(d_rates, site_rates, n_sites * sizeof(double), hipMemcpyHostToDevice, 0));
   TRYA(hipMemcpyAsync(d_prior, prior, (size_t)B * SS * sizeof(double), hipMemcpyHostToDevice, 0));
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  if (kernel_ms && rc == CB_OK) {
+    TRYA(hipEventCreate(&ev0));
+    TRYA(hipEventCreate(&ev1));
+    TRYA(hipStreamSynchronize(0));
+    TRYA(hipEventRecord(ev0, 0));
+  }
   TRYA(hipMemsetAsync(d_live, 0, nmat * sizeof(int), 0));
   TRYA(hipMemsetAsync(d_counts, 0, ncounts * sizeof(double), 0));
   if (rc == CB_OK) {
@@ -1683,6 +1690,15 @@ extern "C" int cb_siterm_assemble(int device, int S, int B, int n_sites, const d
                        (const int *)d_live, d_counts);
     TRYA(hipGetLastError());
   }
+  if (kernel_ms && rc == CB_OK) {
+    float ms = 0.f;
+    TRYA(hipEventRecord(ev1, 0));
+    TRYA(hipEventSynchronize(ev1));
+    TRYA(hipEventElapsedTime(&ms, ev0, ev1));
+    *kernel_ms = ms;
+  }
+  if (ev0) (void)hipEventDestroy(ev0);
+  if (ev1) (void)hipEventDestroy(ev1);
   if (!(flags & CB_PTR_DEVICE)) TRYA(hipMemcpyAsync(counts, d_counts, ncounts * sizeof(double), hipMemcpyDeviceToHost, 0));
   TRYA(hipStreamSynchronize(0));
 #undef TRYA

@@ -248,7 +248,8 @@ int cb_allreduce_setup(cb_handle h, void *rccl_comm, void *nccl_allreduce_fn, co
 int cb_siterm_assemble(int device, int S, int B, int n_sites, const double *grid, const int8_t *seqs,
                        int64_t seqs_bytes, const cb_count_pair *pairs, int64_t n_pairs,
                        const double *site_rates, const double *prior, double lambda,
-                       int include_reverse, int flags, double *counts);
+                       int include_reverse, int flags, double *counts, double *kernel_ms);
+/* kernel_ms (may be NULL): GPU time of the clear + count + mix kernels, inputs resident, by HIP events. */
 
 /* ---- FastCherries branch lengths / site rates of ONE family -----------------------
  * Replaces cherryml/phylogeny_estimation/FastCherries/branch_length_estimation.cpp

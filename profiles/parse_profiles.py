@@ -27,8 +27,9 @@ names = {"k1_pt_loss_gt": "k1_pt_loss_gt", "k2_t_eq_g_u": "k2_t_eq_g_u", "k3_w_p
          "count_transitions_lds_kernel": "count_transitions_lds_kernel",
          "count_reduce_slabs": "count_reduce_slabs", "k3_reduce": "k3_reduce", "k4_gemm": "k4_gemm",
          "sp_prepare": "sp_prepare", "sp_bank": "sp_bank", "sp_finish": "sp_finish", "sg_gemm": "sg_gemm", "lgx_build": "lgx_build", "ble_branch_lengths_kernel": "ble_branch_lengths_kernel",
-         "ble_site_rates_kernel": "ble_site_rates_kernel"}
-for w in ["coevo400", "lg20", "siterm", "counting", "ble"]:
+         "ble_site_rates_kernel": "ble_site_rates_kernel", "siterm_raw_counts_kernel": "siterm_raw_counts_kernel",
+         "siterm_mix_kernel": "siterm_mix_kernel"}
+for w in ["coevo400", "lg20", "siterm", "counting", "ble", "assembly"]:
     st = glob.glob(f"{root}/gpurun_out/{tag}_trace_{w}/*/*_kernel_stats.csv")
     if st:
         shutil.copy(st[0], f"{here}/r01_{tag}_{w}_kernel_stats.csv")
