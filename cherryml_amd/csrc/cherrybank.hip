@@ -23,6 +23,7 @@
 #include "general_small.hip.h"
 #include "counting.hip.h"
 #include "ble.hip.h"
+#include "likelihood.hip.h"
 
 #define CB_ABI_VERSION 1
 
@@ -80,6 +81,7 @@ struct cb_bank {
   int (*allreduce)(const void *, void *, size_t, int, int, void *, hipStream_t) = nullptr;
   double *inv_n_global = nullptr;  // [L] 1 / n_total
   std::vector<double> n_global;
+  bool expm_only = false;   // created with CB_EXPM_ONLY: no counts, no loss / training entry points
   bool sym_counts = false;  // every live bucket has C_b == C_b^T (cherry counts are, by construction)
   int spec_sweeps = 0;  // Jacobi sweeps to enqueue before the first host check (learned from the previous solve)
   double *A = nullptr, *dsq = nullptr, *Gc = nullptr, *Vc = nullptr, *U = nullptr, *lam = nullptr,
@@ -315,7 +317,8 @@ extern "C" int cb_create(int device, int S, int L, int B, const double *t, const
   if (!out) return fail(CB_EINVAL, "cb_create: out is NULL");
   *out = nullptr;
   if (S < 2 || L < 1 || B < 1) return fail(CB_EINVAL, "cb_create: need S>=2, L>=1, B>=1 (got %d,%d,%d)", S, L, B);
-  if (!t || !C) return fail(CB_EINVAL, "cb_create: t and C must not be NULL");
+  const bool expm_only = (flags & CB_EXPM_ONLY) != 0;
+  if (!t || (!C && !expm_only)) return fail(CB_EINVAL, "cb_create: t and C must not be NULL");
   if (S > 32 && L != 1)
     return fail(CB_EUNSUPPORTED, "cb_create: S > 32 is supported for L == 1 only (got L=%d)", L);
   if (S > 1024) return fail(CB_EUNSUPPORTED, "cb_create: S > 1024 not supported");
@@ -329,6 +332,7 @@ extern "C" int cb_create(int device, int S, int L, int B, const double *t, const
   h->L = L;
   h->B = B;
   h->large = S > 32;
+  h->expm_only = expm_only;
   h->LD = (S + 15) / 16 * 16;
   auto cleanup = [&](int rc) {
     cb_destroy(h);
@@ -362,7 +366,7 @@ extern "C" int cb_create(int device, int S, int L, int B, const double *t, const
   double *Ctmp = nullptr;
   const hipMemcpyKind kind = (flags & CB_PTR_DEVICE) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
   TRY_HIP(hipMemcpyAsync(h->t, t, nmat * sizeof(double), kind, h->stream));
-  if (!(flags & CB_PTR_DEVICE)) {
+  if (!(flags & CB_PTR_DEVICE) && !expm_only) {
     hipError_t e = hipMalloc((void **)&Ctmp, nmat * SS * sizeof(double));
     if (e != hipSuccess) return cleanup(fail(CB_ENOMEM, "hipMalloc(C staging) failed"));
     e = hipMemcpyAsync(Ctmp, C, nmat * SS * sizeof(double), hipMemcpyHostToDevice, h->stream);
@@ -387,9 +391,12 @@ extern "C" int cb_create(int device, int S, int L, int B, const double *t, const
       free_tmp();
       return cleanup(rc);
     }
-    hipLaunchKernelGGL(bucket_mass, dim3((unsigned)nmat), dim3(256), 0, h->stream, SS, Cdev, mass_d);
-    std::vector<double> mass(nmat), th(nmat);
-    hipError_t e = hipMemcpyAsync(mass.data(), mass_d, nmat * sizeof(double), hipMemcpyDeviceToHost, h->stream);
+    std::vector<double> mass(nmat, 1.0), th(nmat);   // expm-only: every bucket "live"
+    hipError_t e = hipSuccess;
+    if (!expm_only) {
+      hipLaunchKernelGGL(bucket_mass, dim3((unsigned)nmat), dim3(256), 0, h->stream, SS, Cdev, mass_d);
+      e = hipMemcpyAsync(mass.data(), mass_d, nmat * sizeof(double), hipMemcpyDeviceToHost, h->stream);
+    }
     if (e == hipSuccess) e = hipMemcpyAsync(th.data(), h->t, nmat * sizeof(double), hipMemcpyDeviceToHost, h->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
     if (e != hipSuccess) {
@@ -428,7 +435,16 @@ extern "C" int cb_create(int device, int S, int L, int B, const double *t, const
     }
   }
   const int Bl = h->Bl;
-  if (!h->large) {
+  if (expm_only) {   // placeholders instead of the count statistics
+    std::vector<double> one(L, 1.0);
+    TRY_HIP(hipMemcpy(h->n_dev, one.data(), L * sizeof(double), hipMemcpyHostToDevice));
+    TRY_HIP(hipMemcpy(h->inv_n, one.data(), L * sizeof(double), hipMemcpyHostToDevice));
+    TRY_HIP(hipMemcpy(h->ones, one.data(), L * sizeof(double), hipMemcpyHostToDevice));
+    TRY_HIP(hipMemset(h->dirsum, 0, (size_t)L * S * sizeof(double)));
+  }
+  if (!h->large && expm_only) {
+    // nothing else: the expm / eigh modes of the small kernels touch no counts
+  } else if (!h->large) {
     if ((rc = dev_alloc(h, &h->Ct, (size_t)L * Bl * SS)) != CB_OK) {
       free_tmp();
       return cleanup(rc);
@@ -453,7 +469,8 @@ extern "C" int cb_create(int device, int S, int L, int B, const double *t, const
     h->k3_chunk = 4;
     h->k3_nchunks = (B + h->k3_chunk - 1) / h->k3_chunk;
     double *tot = nullptr;
-    bool ok = dev_alloc(h, &h->Ct, (size_t)Bl * LL) == CB_OK && dev_alloc(h, &tot, SS) == CB_OK &&
+    const size_t per_bucket = expm_only ? 0 : (size_t)Bl * LL;   // Ct / Gt / T exist for the loss only
+    bool ok = dev_alloc(h, &h->Ct, per_bucket) == CB_OK && dev_alloc(h, &tot, SS) == CB_OK &&
               dev_alloc(h, &h->A, LL) == CB_OK && dev_alloc(h, &h->dsq, h->LD) == CB_OK &&
               dev_alloc(h, &h->Gc, LL) == CB_OK && dev_alloc(h, &h->Vc, LL) == CB_OK &&
               dev_alloc(h, &h->Gc2, LL) == CB_OK && dev_alloc(h, &h->gx, 4 * LL) == CB_OK &&
@@ -462,14 +479,15 @@ extern "C" int cb_create(int device, int S, int L, int B, const double *t, const
               dev_alloc(h, &h->F, (size_t)B * h->LD) == CB_OK &&
               dev_alloc(h, &h->E, (size_t)B * h->LD) == CB_OK &&
               dev_alloc(h, &h->H, (size_t)B * h->LD) == CB_OK &&
-              dev_alloc(h, &h->Gt, (size_t)Bl * LL) == CB_OK &&
-              dev_alloc(h, &h->T, (size_t)Bl * LL) == CB_OK &&
+              dev_alloc(h, &h->Gt, per_bucket) == CB_OK &&
+              dev_alloc(h, &h->T, per_bucket) == CB_OK &&
               dev_alloc(h, &h->Mt, LL) == CB_OK && dev_alloc(h, &h->X, LL) == CB_OK &&
               dev_alloc(h, &h->loss_part, (size_t)B * tiles) == CB_OK;
     if (!ok) {
       free_tmp();
       return cleanup(CB_ENOMEM);
     }
+    if (!expm_only) {
     hipLaunchKernelGGL(prep_counts_large_tot, dim3((unsigned)((SS + 255) / 256)), dim3(256), 0,
                        h->stream, S, B, Cdev, tot);
     hipLaunchKernelGGL(prep_counts_large_fin, dim3(1), dim3(256), 0, h->stream, S, tot, h->n_dev,
@@ -485,6 +503,7 @@ extern "C" int cb_create(int device, int S, int L, int B, const double *t, const
       if (hipMemcpyAsync(&hf, flag, sizeof hf, hipMemcpyDeviceToHost, h->stream) == hipSuccess &&
           hipStreamSynchronize(h->stream) == hipSuccess)
         h->sym_counts = hf == 0 && !getenv("CB_NO_SYM");
+    }
     }
   }
   h->n_host.resize(L);
@@ -835,6 +854,7 @@ static int finish_call(cb_bank *h, int flags) {
 extern "C" int cb_loss_grad(cb_handle h, const double *Q, const double *pi, int flags, double *loss,
                             double *dQ) {
   if (!h || !Q || !pi || !loss) return fail(CB_EINVAL, "cb_loss_grad: NULL argument");
+  if (h->expm_only) return fail(CB_EINVAL, "cb_loss_grad: the handle was created with CB_EXPM_ONLY (no counts)");
   HIP_TRY(hipSetDevice(h->dev));
   const size_t SS = (size_t)h->S * h->S;
   const bool devp = flags & CB_PTR_DEVICE;
@@ -1026,6 +1046,7 @@ static int general_run(cb_bank *h, const double *Qd, int flags, double *lossd, d
 extern "C" int cb_loss_grad_general(cb_handle h, const double *Q, int flags, double *loss,
                                     double *dQ) {
   if (!h || !Q || !loss) return fail(CB_EINVAL, "cb_loss_grad_general: NULL argument");
+  if (h->expm_only) return fail(CB_EINVAL, "cb_loss_grad_general: the handle was created with CB_EXPM_ONLY (no counts)");
   HIP_TRY(hipSetDevice(h->dev));
   const size_t SS = (size_t)h->S * h->S;
   const bool devp = flags & CB_PTR_DEVICE;
@@ -1175,6 +1196,7 @@ static int run_fused_training(cb_bank *h, int kind, double *pi_param, double *up
                               double *loss_curve, double *Q_best, double *Q_last, double *Q_pow2,
                               int n_pow2) {
   if (E < 0) return fail(CB_EINVAL, "fused training: num_epochs < 0");
+  if (h->expm_only) return fail(CB_EINVAL, "fused training: the handle was created with CB_EXPM_ONLY (no counts)");
   if (h->large) {
     if (kind != 0) return fail(CB_EUNSUPPORTED, "fused SiteRM training: S <= 32 only (S = %d)", h->S);
     return run_fused_training_large(h, pi_param, up_param, mask, E, lr, do_adam, flags, loss_curve, Q_best, Q_last,
@@ -1914,3 +1936,149 @@ extern "C" int cb_site_rate_gather(int device, int S, int R, int n, int L, const
   return CB_OK;
 }
 
+
+// ---------------------------------------------------------------- held-out likelihood
+extern "C" int cb_tree_likelihood(int device, int S, int S1, const double *Q, const double *pi_rev,
+                                  const double *pi_root, int n_nodes, const int *postorder, const int *parent,
+                                  const double *length, int n_cats, const double *cat_rate, int n_units,
+                                  const int *unit_cat, const int8_t *code_a, const int8_t *code_b, double *ll,
+                                  double *kernel_ms) {
+  if (!Q || !pi_root || !postorder || !parent || !length || !cat_rate || !unit_cat || !code_a || !ll)
+    return fail(CB_EINVAL, "cb_tree_likelihood: NULL argument");
+  if (S < 2 || S > 16 * 4 * TL_MAXT || n_nodes < 1 || n_cats < 1 || n_units < 1)
+    return fail(CB_EINVAL, "cb_tree_likelihood: bad sizes (S = %d, nodes = %d, categories = %d, units = %d)", S,
+                n_nodes, n_cats, n_units);
+  if (S1 < 0 || (S1 > 0 && (S1 * S1 != S || !code_b)))
+    return fail(CB_EINVAL, "cb_tree_likelihood: pair model needs S = S1 * S1 and code_b");
+  if (S > 64 && n_cats != 1)
+    return fail(CB_EUNSUPPORTED, "cb_tree_likelihood: S > 64 takes one rate category (the reference evaluates pairs "
+                "of sites at rate 1, _likelihood.py:214-230)");
+  const int ndev = cb_device_count();
+  if (ndev <= 0) return fail(CB_EHIP, "cb_tree_likelihood: no HIP device (this path has no CPU fallback)");
+  if (device < 0 || device >= ndev) return fail(CB_EINVAL, "cb_tree_likelihood: device %d of %d", device, ndev);
+  // ---- tree: heights, levels, children in post-order (= the reference's child order, _tree.py traversal)
+  const int root = postorder[n_nodes - 1];
+  std::vector<int> height(n_nodes, 0), nchild(n_nodes, 0), seen(n_nodes, 0);
+  for (int i = 0; i < n_nodes; ++i) {
+    const int v = postorder[i];
+    if (v < 0 || v >= n_nodes || seen[v]) return fail(CB_EINVAL, "cb_tree_likelihood: postorder is not a permutation");
+    seen[v] = 1;
+    const int p = parent[v];
+    if (i == n_nodes - 1) {
+      if (p != -1) return fail(CB_EINVAL, "cb_tree_likelihood: the last node of postorder must be the root (parent -1)");
+      break;
+    }
+    if (p < 0 || p >= n_nodes || seen[p]) return fail(CB_EINVAL, "cb_tree_likelihood: node %d precedes its child %d", p, v);
+    if (!(length[v] >= 0.0) || !std::isfinite(length[v])) return fail(CB_EINVAL, "cb_tree_likelihood: length[%d] = %g", v, length[v]);
+    height[p] = std::max(height[p], height[v] + 1);
+    nchild[p]++;
+  }
+  std::vector<int> child_ptr(n_nodes + 1, 0), child_idx(std::max(n_nodes - 1, 1)), fill(n_nodes, 0);
+  for (int v = 0; v < n_nodes; ++v) child_ptr[v + 1] = child_ptr[v] + nchild[v];
+  for (int i = 0; i + 1 < n_nodes; ++i) {
+    const int v = postorder[i], p = parent[v];
+    child_idx[child_ptr[p] + fill[p]++] = v;
+  }
+  const int n_levels = height[root] + 1;
+  std::vector<int> level_ptr(n_levels + 1, 0), level_nodes(n_nodes);
+  for (int v = 0; v < n_nodes; ++v) level_ptr[height[v] + 1]++;
+  for (int l = 0; l < n_levels; ++l) level_ptr[l + 1] += level_ptr[l];
+  {
+    std::vector<int> at(level_ptr.begin(), level_ptr.end() - 1);
+    for (int i = 0; i < n_nodes; ++i) level_nodes[at[height[postorder[i]]]++] = postorder[i];
+  }
+  for (int u = 0; u < n_units; ++u)
+    if (unit_cat[u] < 0 || unit_cat[u] >= n_cats) return fail(CB_EINVAL, "cb_tree_likelihood: unit_cat[%d] = %d", u, unit_cat[u]);
+  for (int c = 0; c < n_cats; ++c)
+    if (!(cat_rate[c] >= 0.0) || !std::isfinite(cat_rate[c])) return fail(CB_EINVAL, "cb_tree_likelihood: cat_rate[%d] = %g", c, cat_rate[c]);
+  const int alpha = S1 > 0 ? S1 : S;
+  for (int v = 0; v < n_nodes; ++v)
+    if (!nchild[v])
+      for (int u = 0; u < n_units; ++u) {
+        const size_t i = (size_t)v * n_units + u;
+        if (code_a[i] >= alpha || (S1 > 0 && code_b[i] >= alpha)) return fail(CB_EINVAL, "cb_tree_likelihood: state code out of range at node %d unit %d", v, u);
+      }
+  // ---- transition bank expm(rate_c * length_v * Q), [cat][node][S][S], by the bank's own expm kernels
+  const bool large = S > 32;
+  const int L = large ? 1 : n_cats, B = large ? n_cats * n_nodes : n_nodes;
+  std::vector<double> t((size_t)n_cats * n_nodes);
+  for (int c = 0; c < n_cats; ++c)
+    for (int v = 0; v < n_nodes; ++v) t[(size_t)c * n_nodes + v] = v == root ? 0.0 : cat_rate[c] * length[v];
+  cb_handle h = nullptr;
+  int rc = cb_create(device, S, L, B, t.data(), nullptr, CB_EXPM_ONLY, &h);
+  if (rc != CB_OK) return rc;
+  struct Guard {
+    cb_handle h;
+    ~Guard() { cb_destroy(h); }
+  } guard{h};
+  if ((rc = cb_set_stream(h, nullptr, 0)) != CB_OK) return rc;
+  const size_t SS = (size_t)S * S;
+  std::vector<double> Qrep((size_t)L * SS), pirep;
+  for (int l = 0; l < L; ++l) std::copy(Q, Q + SS, Qrep.begin() + (size_t)l * SS);
+  if (pi_rev) {
+    pirep.resize((size_t)L * S);
+    for (int l = 0; l < L; ++l) std::copy(pi_rev, pi_rev + S, pirep.begin() + (size_t)l * S);
+  }
+  BleDev d;
+  const double *dQ = d.up(Qrep.data(), Qrep.size(), rc);
+  const double *dpi = pi_rev ? d.up(pirep.data(), pirep.size(), rc) : nullptr;
+  double *dP = d.up<double>(nullptr, (size_t)n_cats * n_nodes * SS, rc);
+  const int NU = S > 64 ? (n_units + 15) / 16 * 16 : n_units;
+  const size_t msg_count = (size_t)n_nodes * S * NU;
+  double *dmsg = d.up<double>(nullptr, msg_count, rc);
+  double *dll = d.up<double>(nullptr, n_units, rc);
+  const double *dproot = d.up(pi_root, S, rc);
+  const int *dlev = d.up(level_nodes.data(), n_nodes, rc), *dcp = d.up(child_ptr.data(), n_nodes + 1, rc);
+  const int *dci = d.up(child_idx.data(), child_idx.size(), rc), *duc = d.up(unit_cat, n_units, rc);
+  const int8_t *dca = d.up(code_a, (size_t)n_nodes * n_units, rc);
+  const int8_t *dcb = S1 > 0 ? d.up(code_b, (size_t)n_nodes * n_units, rc) : nullptr;
+  if (rc != CB_OK) return rc;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  if (kernel_ms) {
+    HIP_TRY(hipEventCreate(&ev0));
+    HIP_TRY(hipEventCreate(&ev1));
+    HIP_TRY(hipStreamSynchronize(0));   // the timed region starts with resident inputs
+    HIP_TRY(hipEventRecord(ev0, 0));
+  }
+  rc = cb_expm_bank(h, dQ, dpi, CB_PTR_DEVICE | CB_NO_SYNC, dP);
+  if (rc == CB_OK) {
+    TlArgs a{};
+    a.S = S; a.S1 = S1; a.n_nodes = n_nodes; a.n_units = n_units; a.NU = NU; a.root = root;
+    a.child_ptr = dcp; a.child_idx = dci; a.P = dP; a.unit_cat = duc;
+    a.code_a = reinterpret_cast<const signed char *>(dca);
+    a.code_b = reinterpret_cast<const signed char *>(dcb);
+    a.pi_root = dproot; a.msg = dmsg; a.ll = dll;
+    const int nt = (S + 15) / 16, Sp = nt * 16;
+    const size_t lds = ((size_t)(Sp + Sp / 4) * 16 + 64) * sizeof(double);
+    if (S > 64 && hipFuncSetAttribute(reinterpret_cast<const void *>(tl_mfma_kernel),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+      rc = fail(CB_EHIP, "cb_tree_likelihood: cannot reserve %zu bytes of LDS", lds);
+    for (int l = 0; l < n_levels && rc == CB_OK; ++l) {
+      const int nl = level_ptr[l + 1] - level_ptr[l];
+      a.level_nodes = dlev + level_ptr[l];
+      for (int y0 = 0; y0 < nl; y0 += 65535) {   // grid.y limit
+        TlArgs b = a;
+        b.level_nodes = a.level_nodes + y0;
+        const unsigned ny = (unsigned)std::min(65535, nl - y0);
+        if (S > 64)
+          hipLaunchKernelGGL(tl_mfma_kernel, dim3((unsigned)(NU / 16), ny), dim3(256), lds, 0, b);
+        else
+          hipLaunchKernelGGL(tl_group_kernel, dim3((unsigned)((n_units + 64 / S - 1) / (64 / S)), ny), dim3(64), 0, 0, b);
+      }
+    }
+  }
+  if (kernel_ms) {
+    float ms = 0.f;
+    hipError_t e = hipEventRecord(ev1, 0);
+    if (e == hipSuccess) e = hipEventSynchronize(ev1);
+    if (e == hipSuccess) e = hipEventElapsedTime(&ms, ev0, ev1);
+    *kernel_ms = ms;
+    (void)hipEventDestroy(ev0);
+    (void)hipEventDestroy(ev1);
+    if (e != hipSuccess && rc == CB_OK) rc = fail(CB_EHIP, "cb_tree_likelihood: %s", hipGetErrorString(e));
+  }
+  if (rc != CB_OK) return rc;
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpy(ll, dll, n_units * sizeof(double), hipMemcpyDeviceToHost));
+  return CB_OK;
+}

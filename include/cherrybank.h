@@ -46,7 +46,8 @@ enum {
   CB_PTR_DEVICE = 1, /* data pointers of this call are device pointers */
   CB_NORMALIZE = 2,  /* divide each site's loss (and gradient) by its total count
                         (trainer.py:176-177 `loss_normalization`)     */
-  CB_NO_SYNC = 4     /* with CB_PTR_DEVICE: enqueue only, do not wait  */
+  CB_NO_SYNC = 4,    /* with CB_PTR_DEVICE: enqueue only, do not wait  */
+  CB_EXPM_ONLY = 8   /* cb_create: no counts (C may be NULL); the handle serves cb_expm_bank / cb_eigh only */
 };
 
 /* ABI version of the loaded library (bumped on incompatible change). */
@@ -279,6 +280,30 @@ int cb_ble(int device, int S, int T, int R, const double *logP, const int8_t *cx
  * the ascent (first branch-length pass + all iterations), inputs already resident, by HIP events. */
 int cb_site_rate_gather(int device, int S, int R, int n, int L, const double *tens, const int8_t *cx,
                         const int8_t *cy, const double *log_prior, int *best);
+
+/* ---- held-out log-likelihood of ONE family under one model (tail of SURVEY 8f #4) ---------------
+ * Replaces the per-(node, site) python loops of cherryml/evaluation/_likelihood.py:47-327
+ * (`dp_likelihood_computation`: transition matrices :169-236, Felsenstein pruning in log space
+ * :238-296) for one group of "units": independent sites (S1 = 0, S states, unit u evolves at
+ * cat_rate[unit_cat[u]]) or contacting pairs of sites (S1 > 0, S = S1 * S1, pair state a * S1 + b).
+ * All pointers are HOST pointers.
+ *   Q [S][S]; pi_rev [S]: Q is reversible w.r.t. pi_rev -> spectral expm kernels (reference
+ *   `reversible_*` = True); NULL -> general scaling-and-squaring kernels (S <= 32 only);
+ *   pi_root [S]: the root distribution (reference pi_1 / pi_2)
+ *   tree: n_nodes nodes; postorder[n_nodes] lists every node, children before parents (the last
+ *   entry is the root); parent[v] (-1 for the root); length[v] = length of the edge above v.
+ *   A node's children are summed in their postorder order (= the reference's Tree.children order)
+ *   code_a, code_b [n_nodes][n_units] int8: observed state of the unit's (first, second) site at a
+ *   LEAF, -1 = unobserved (gap / unknown symbol: all-ones observation, :105-126); rows of internal
+ *   nodes are ignored (:152-167); code_b only when S1 > 0
+ *   ll [n_units] out: log-likelihood of each unit (a pair's value is for both of its sites)
+ *   kernel_ms (may be NULL): GPU time of bank + pruning, inputs already resident, by HIP events
+ * S <= 448; S > 64 requires n_cats == 1 (the reference evaluates pairs at rate 1). */
+int cb_tree_likelihood(int device, int S, int S1, const double *Q, const double *pi_rev,
+                       const double *pi_root, int n_nodes, const int *postorder, const int *parent,
+                       const double *length, int n_cats, const double *cat_rate, int n_units,
+                       const int *unit_cat, const int8_t *code_a, const int8_t *code_b, double *ll,
+                       double *kernel_ms);
 
 #ifdef __cplusplus
 }

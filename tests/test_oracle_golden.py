@@ -237,3 +237,43 @@ def test_siterm_site_rate_gather_oracle():
     got = bo.compute_optimal_site_rates(z["gather_x"], z["gather_y"], z["gather_tensor"], z["gather_grid"],
                                         z["gather_prior"])
     assert np.array_equal(got, z["gather_expected"])
+
+
+# ---- held-out log-likelihood (evaluation/_likelihood.py) --------------------------------------
+def _likelihood_case(z, c):
+    from cherryml_amd.io._tree import Tree
+    tree = Tree()
+    tree.add_nodes([str(v) for v in z[c + "_nodes"]])
+    for u, v, t in zip(z[c + "_eu"], z[c + "_ev"], z[c + "_et"]):
+        tree.add_edge(str(u), str(v), float(t))
+    msa = {str(k): str(s) for k, s in zip(z[c + "_names"], z[c + "_seqs"])}
+    cm = z[c + "_contact_map"] if bool(z[c + "_has_cm"]) else None
+    return tree, msa, cm, [float(r) for r in z[c + "_rates"]]
+
+
+LIKELIHOOD_CASES = [("wag3", "wag", False), ("wag4", "wag", False), ("wag4_gaps", "wag", False), ("wagxwag3", "wag", True),
+                    ("rand_single", "lg", False), ("rand_pair", "wag", True), ("demo_single", "lg", False)]
+
+
+def _chain_product(Q):
+    """Q x Q: generator of two independent copies (markov_chain: chain_product), state = i1 * S + i2"""
+    n = Q.shape[0]
+    I = np.eye(n)
+    return np.kron(Q, I) + np.kron(I, Q)
+
+
+@pytest.mark.parametrize("case,model,pair", LIKELIHOOD_CASES)
+def test_likelihood_oracle_against_reference(case, model, pair):
+    from oracle import likelihood_oracle as lo
+    z = load_golden("likelihood.npz")
+    tree, msa, cm, rates = _likelihood_case(z, case)
+    aa = [str(a) for a in z["amino_acids"]]
+    Q1, pi1 = z[model], z["pi_" + model]
+    Q2 = _chain_product(Q1) if pair else None
+    pi2 = np.kron(pi1, pi1) if pair else None
+    ll, lls = lo.log_likelihood(tree, msa, cm, rates, aa, pi1, Q1, pi2, Q2)
+    assert abs(ll - float(z[case + "_ll_rev"])) < 1e-9 * abs(ll)
+    assert np.allclose(lls, z[case + "_lls_rev"], rtol=1e-9, atol=1e-12)
+    if case + "_published" in z:   # the value typed into the reference's tests (FastTree-verified, 4 decimals)
+        pub = z[case + "_published"]
+        assert np.allclose(ll if pub.ndim == 0 else lls, pub, atol=1e-4)
