@@ -1945,7 +1945,7 @@ extern "C" int cb_tree_likelihood(int device, int S, int S1, const double *Q, co
                                   double *kernel_ms) {
   if (!Q || !pi_root || !postorder || !parent || !length || !cat_rate || !unit_cat || !code_a || !ll)
     return fail(CB_EINVAL, "cb_tree_likelihood: NULL argument");
-  if (S < 2 || S > 16 * 4 * TL_MAXT || n_nodes < 1 || n_cats < 1 || n_units < 1)
+  if (S < 2 || S > 16 * TL_NW * TL_MAXT || n_nodes < 1 || n_cats < 1 || n_units < 1)
     return fail(CB_EINVAL, "cb_tree_likelihood: bad sizes (S = %d, nodes = %d, categories = %d, units = %d)", S,
                 n_nodes, n_cats, n_units);
   if (S1 < 0 || (S1 > 0 && (S1 * S1 != S || !code_b)))
@@ -2033,14 +2033,16 @@ extern "C" int cb_tree_likelihood(int device, int S, int S1, const double *Q, co
   const int8_t *dca = d.up(code_a, (size_t)n_nodes * n_units, rc);
   const int8_t *dcb = S1 > 0 ? d.up(code_b, (size_t)n_nodes * n_units, rc) : nullptr;
   if (rc != CB_OK) return rc;
-  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr, evm = nullptr;
   if (kernel_ms) {
     HIP_TRY(hipEventCreate(&ev0));
     HIP_TRY(hipEventCreate(&ev1));
+    HIP_TRY(hipEventCreate(&evm));
     HIP_TRY(hipStreamSynchronize(0));   // the timed region starts with resident inputs
     HIP_TRY(hipEventRecord(ev0, 0));
   }
   rc = cb_expm_bank(h, dQ, dpi, CB_PTR_DEVICE | CB_NO_SYNC, dP);
+  if (kernel_ms) (void)hipEventRecord(evm, 0);
   if (rc == CB_OK) {
     TlArgs a{};
     a.S = S; a.S1 = S1; a.n_nodes = n_nodes; a.n_units = n_units; a.NU = NU; a.root = root;
@@ -2049,32 +2051,37 @@ extern "C" int cb_tree_likelihood(int device, int S, int S1, const double *Q, co
     a.code_b = reinterpret_cast<const signed char *>(dcb);
     a.pi_root = dproot; a.msg = dmsg; a.ll = dll;
     const int nt = (S + 15) / 16, Sp = nt * 16;
-    const size_t lds = ((size_t)(Sp + Sp / 4) * 16 + 64) * sizeof(double);
+    const size_t lds = ((size_t)(Sp + Sp / 4) * 16 + TL_NW * 16) * sizeof(double);
     if (S > 64 && hipFuncSetAttribute(reinterpret_cast<const void *>(tl_mfma_kernel),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
       rc = fail(CB_EHIP, "cb_tree_likelihood: cannot reserve %zu bytes of LDS", lds);
     for (int l = 0; l < n_levels && rc == CB_OK; ++l) {
       const int nl = level_ptr[l + 1] - level_ptr[l];
-      a.level_nodes = dlev + level_ptr[l];
-      for (int y0 = 0; y0 < nl; y0 += 65535) {   // grid.y limit
+      a.n_blocks = S > 64 ? NU / 16 : (n_units + 64 / S - 1) / (64 / S);
+      const int per_launch = std::max(1, (1 << 30) / a.n_blocks);   // keep the 1-D grid below 2^30 workgroups
+      for (int y0 = 0; y0 < nl; y0 += per_launch) {
         TlArgs b = a;
-        b.level_nodes = a.level_nodes + y0;
-        const unsigned ny = (unsigned)std::min(65535, nl - y0);
+        b.level_nodes = dlev + level_ptr[l] + y0;
+        b.n_level = std::min(per_launch, nl - y0);
+        const dim3 grid((unsigned)b.n_level * (unsigned)a.n_blocks);
         if (S > 64)
-          hipLaunchKernelGGL(tl_mfma_kernel, dim3((unsigned)(NU / 16), ny), dim3(256), lds, 0, b);
+          hipLaunchKernelGGL(tl_mfma_kernel, grid, dim3(TL_NW * 64), lds, 0, b);
         else
-          hipLaunchKernelGGL(tl_group_kernel, dim3((unsigned)((n_units + 64 / S - 1) / (64 / S)), ny), dim3(64), 0, 0, b);
+          hipLaunchKernelGGL(tl_group_kernel, grid, dim3(64), 0, 0, b);
       }
     }
   }
   if (kernel_ms) {
-    float ms = 0.f;
+    float ms = 0.f, ms_prune = 0.f;
     hipError_t e = hipEventRecord(ev1, 0);
     if (e == hipSuccess) e = hipEventSynchronize(ev1);
     if (e == hipSuccess) e = hipEventElapsedTime(&ms, ev0, ev1);
-    *kernel_ms = ms;
+    if (e == hipSuccess) e = hipEventElapsedTime(&ms_prune, evm, ev1);
+    kernel_ms[0] = ms;
+    kernel_ms[1] = ms_prune;
     (void)hipEventDestroy(ev0);
     (void)hipEventDestroy(ev1);
+    (void)hipEventDestroy(evm);
     if (e != hipSuccess && rc == CB_OK) rc = fail(CB_EHIP, "cb_tree_likelihood: %s", hipGetErrorString(e));
   }
   if (rc != CB_OK) return rc;

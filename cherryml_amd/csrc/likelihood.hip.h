@@ -15,11 +15,12 @@
 //                    v_mfma_f64_16x16x4 tiles (rows x units), W staged in LDS, P streamed from HBM
 #pragma once
 #include "common.hip.h"
+#include "large_bank.hip.h"   // xcd_swizzle
 
 struct TlArgs {
   int S, S1;                   // states; S1 > 0: pair model over an S1-letter alphabet
   int n_nodes, n_units, NU;    // NU: units padded to the message layout's unit stride
-  int root;
+  int root, n_level, n_blocks;  // this launch: nodes of one height x unit blocks (1-D grid)
   const int *level_nodes;      // nodes of the height processed by this launch
   const int *child_ptr, *child_idx;   // CSR children, in the reference's child order
   const double *P;             // [cat][node][S][S] transition matrices of the edge above `node`
@@ -36,15 +37,16 @@ __device__ __forceinline__ bool tl_observed(int S1, int k, int ca, int cb) {
 }
 
 // ------------------------------------------------------------------ S <= 64
-// grid (unit blocks, nodes of the level), 64 threads.  msg layout [node][unit][S].
+// grid = nodes of the level x unit blocks, 64 threads.  msg layout [node][unit][S].
 __global__ __launch_bounds__(64) void tl_group_kernel(TlArgs a) {
   __shared__ double sw[64];
   const int S = a.S, upw = 64 / S;
   const int g = threadIdx.x / S, r = threadIdx.x - g * S;
-  const int u = blockIdx.x * upw + g;
+  const int node_i = blockIdx.x / a.n_blocks, blk = blockIdx.x - node_i * a.n_blocks;
+  const int u = blk * upw + g;
   const bool act = g < upw && u < a.n_units;
   const int uu = act ? u : 0, gb = act ? g * S : 0;
-  const int v = a.level_nodes[blockIdx.y];
+  const int v = a.level_nodes[node_i];
   const int c0 = a.child_ptr[v], c1 = a.child_ptr[v + 1];
   double d = 0.0;
   for (int c = c0; c < c1; ++c) d += a.msg[((size_t)a.child_idx[c] * a.n_units + uu) * S + r];
@@ -72,24 +74,27 @@ __global__ __launch_bounds__(64) void tl_group_kernel(TlArgs a) {
 }
 
 // ------------------------------------------------------------------ S > 64
-// grid (unit blocks of 16, nodes of the level), 256 threads = 4 waves; wave w owns the row tiles
-// w, w + 4, ... (16 rows each, TL_MAXT per wave at most => S <= 448).  msg layout [node][row][NU].
+// grid = nodes of the level x unit blocks of 16 (XCD-swizzled so that the blocks of one node run
+// on one XCD and share P_v in its L2), TL_NW waves; wave w owns the row tiles w, w + TL_NW, ...
+// (16 rows each, TL_MAXT per wave at most => S <= 512).  msg layout [node][row][NU].
 // Lane (lo, hi) owns unit lo and, per tile, rows hi + 4 r -- the D layout of v_mfma_f64_16x16x4,
 // so the lane that produced a message element is the lane that stores it.
-constexpr int TL_MAXT = 7;
+constexpr int TL_NW = 8, TL_MAXT = 4;
 __device__ __forceinline__ int tl_w_index(int k, int lo) { return (k + (k >> 2)) * 16 + lo; }  // bank-spread rows
 
-__global__ __launch_bounds__(256) void tl_mfma_kernel(TlArgs a) {
+__global__ __launch_bounds__(TL_NW * 64, 4) void tl_mfma_kernel(TlArgs a) {
   extern __shared__ double tl_lds[];
   double *sW = tl_lds;                     // [(Sp + Sp / 4)][16]
   const int S = a.S, nt = (S + 15) / 16, Sp = nt * 16;
-  double *sR = sW + (size_t)(Sp + Sp / 4) * 16;   // [4][16] cross-wave reductions
+  double *sR = sW + (size_t)(Sp + Sp / 4) * 16;   // [TL_NW][16] cross-wave reductions
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, lo = lane & 15, hi = lane >> 4;
-  const int u = blockIdx.x * 16 + lo;
+  const int vid = xcd_swizzle(blockIdx.x, gridDim.x);
+  const int node_i = vid / a.n_blocks, blk = vid - node_i * a.n_blocks;
+  const int u = blk * 16 + lo;
   const bool act = u < a.n_units;
-  const int v = a.level_nodes[blockIdx.y];
+  const int v = a.level_nodes[node_i];
   const int c0 = a.child_ptr[v], c1 = a.child_ptr[v + 1];
-  const int my_tiles = wave < nt ? (nt - wave + 3) / 4 : 0;
+  const int my_tiles = wave < nt ? (nt - wave + TL_NW - 1) / TL_NW : 0;
 
   double d[TL_MAXT][4];
 #pragma unroll
@@ -103,7 +108,7 @@ __global__ __launch_bounds__(256) void tl_mfma_kernel(TlArgs a) {
       if (j < my_tiles)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const int row = (wave + 4 * j) * 16 + hi + 4 * r;
+          const int row = (wave + TL_NW * j) * 16 + hi + 4 * r;
           if (row < S && act) d[j][r] += mc[(size_t)row * a.NU];
         }
   }
@@ -114,12 +119,14 @@ __global__ __launch_bounds__(256) void tl_mfma_kernel(TlArgs a) {
     if (j < my_tiles)
 #pragma unroll
       for (int r = 0; r < 4; ++r)
-        if ((wave + 4 * j) * 16 + hi + 4 * r < S) m = fmax(m, d[j][r]);
+        if ((wave + TL_NW * j) * 16 + hi + 4 * r < S) m = fmax(m, d[j][r]);
   m = fmax(m, __shfl_xor(m, 16));
   m = fmax(m, __shfl_xor(m, 32));
   if (hi == 0) sR[wave * 16 + lo] = m;
   __syncthreads();
-  m = fmax(fmax(sR[lo], sR[16 + lo]), fmax(sR[32 + lo], sR[48 + lo]));
+  m = sR[lo];
+#pragma unroll
+  for (int w = 1; w < TL_NW; ++w) m = fmax(m, sR[w * 16 + lo]);
   int ca = -1, cb = -1;
   if (c0 == c1 && act) {
     const size_t ci = (size_t)v * a.n_units + u;
@@ -132,7 +139,7 @@ __global__ __launch_bounds__(256) void tl_mfma_kernel(TlArgs a) {
     if (j < my_tiles)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int row = (wave + 4 * j) * 16 + hi + 4 * r;
+        const int row = (wave + TL_NW * j) * 16 + hi + 4 * r;
         double w = 0.0;
         if (row < S && act && tl_observed(a.S1, row, ca, cb)) w = exp(d[j][r] - m);
         sW[tl_w_index(row, lo)] = w;
@@ -145,7 +152,9 @@ __global__ __launch_bounds__(256) void tl_mfma_kernel(TlArgs a) {
     if (hi == 0) sR[wave * 16 + lo] = root_part;
     __syncthreads();
     if (wave == 0 && hi == 0 && act) {
-      const double arg = (sR[lo] + sR[16 + lo]) + (sR[32 + lo] + sR[48 + lo]);
+      double arg = sR[lo];
+#pragma unroll
+      for (int w = 1; w < TL_NW; ++w) arg += sR[w * 16 + lo];
       a.ll[u] = log(arg < 0.0 ? 0.0 : arg) + m;
     }
     return;
@@ -160,7 +169,7 @@ __global__ __launch_bounds__(256) void tl_mfma_kernel(TlArgs a) {
   for (int j = 0; j < TL_MAXT; ++j) acc[j] = d4{0.0, 0.0, 0.0, 0.0};
   const bool vec = (S & 3) == 0;
   auto load_a = [&](int kk, int j, double (&av)[4]) {
-    int row = (wave + 4 * j) * 16 + lo;
+    int row = (wave + TL_NW * j) * 16 + lo;
     row = row < S ? row : S - 1;             // rows beyond S: results discarded
     const double *p = Pv + (size_t)row * S;
     const int k0 = kk + 4 * hi;
@@ -202,7 +211,7 @@ __global__ __launch_bounds__(256) void tl_mfma_kernel(TlArgs a) {
     if (j < my_tiles)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int row = (wave + 4 * j) * 16 + hi + 4 * r;
+        const int row = (wave + TL_NW * j) * 16 + hi + 4 * r;
         const double arg = acc[j][r];
         if (row < S) mv[(size_t)row * a.NU] = log(arg < 0.0 ? 0.0 : arg) + m;
       }

@@ -21,10 +21,13 @@ def _f64(a):
 
 
 def _stationary_distribution(Q: np.ndarray) -> np.ndarray:
-    """pi with pi Q = 0 (markov_chain `compute_stationary_distribution`): null vector of Q^T."""
-    w, v = np.linalg.eig(Q.T)
-    p = np.real(v[:, np.argmin(np.abs(w))])
-    return p / p.sum()
+    """pi with pi Q = 0, sum(pi) = 1 (markov_chain/_markov_chain.py:11-19 takes the null eigenvector of Q^T;
+    here the same vector from one linear solve, which at 400 states is ~30x cheaper than `eig`)."""
+    A = np.array(Q, dtype=np.float64).T
+    A[-1, :] = 1.0
+    b = np.zeros(A.shape[0])
+    b[-1] = 1.0
+    return np.linalg.solve(A, b)
 
 
 def _tree_arrays(tree: Tree):
@@ -58,7 +61,7 @@ def tree_likelihood(tree: Tree, codes_a: np.ndarray, codes_b: Optional[np.ndarra
     if a.shape[0] != parent.size or rates.size != n_units or (b is not None and b.shape != a.shape):
         raise ValueError("codes must be [n_nodes, n_units] and unit_rates [n_units]")
     pi_rev = _f64(_stationary_distribution(Q)) if reversible else None
-    ll, ms = np.empty(n_units), np.zeros(1)
+    ll, ms = np.empty(n_units), np.zeros(2)
     S1 = 0 if b is None else int(alphabet_size if alphabet_size is not None else round(S ** 0.5))
     rc = _lib.load().cb_tree_likelihood(
         device, S, S1, Q.ctypes.data, None if pi_rev is None else pi_rev.ctypes.data, pi_root.ctypes.data,
@@ -68,6 +71,8 @@ def tree_likelihood(tree: Tree, codes_a: np.ndarray, codes_b: Optional[np.ndarra
     _lib.check(rc, "cb_tree_likelihood")
     if profile is not None:
         profile["kernel_ms"] = profile.get("kernel_ms", 0.0) + float(ms[0])
+        key = "prune_ms_pairs" if b is not None else "prune_ms_sites"
+        profile[key] = profile.get(key, 0.0) + float(ms[1])
     return ll
 
 
@@ -76,7 +81,8 @@ def dp_likelihood_computation(tree: Tree, msa: Dict[str, str], contact_map: Opti
                               fact_1=None, reversible_1: bool = True, device_1=None,
                               pi_2: Optional[np.ndarray] = None, Q_2: Optional[np.ndarray] = None, fact_2=None,
                               reversible_2: Optional[bool] = True, device_2=None,
-                              output_profiling_path: Optional[str] = None, device: int = 0) -> Tuple[float, List[float]]:
+                              output_profiling_path: Optional[str] = None, device: int = 0,
+                              profile: Optional[dict] = None) -> Tuple[float, List[float]]:
     """`dp_likelihood_computation` (_likelihood.py:47-327).  `fact_*` / `device_*` are accepted for
     call compatibility and ignored: the spectral factorisation happens on the GPU."""
     st_all = time.time()
@@ -101,7 +107,7 @@ def dp_likelihood_computation(tree: Tree, msa: Dict[str, str], contact_map: Opti
         if tree.is_leaf(v) and v in msa:
             codes[r] = lut[np.frombuffer(msa[v].encode("latin-1"), dtype=np.uint8)]
     lls = [0.0] * num_sites
-    profile: dict = {}
+    profile = {} if profile is None else profile
     if indep:
         ll1 = tree_likelihood(tree, codes[:, indep], None, Q_1, pi_1, [site_rates[i] for i in indep],
                               reversible=bool(reversible_1), device=device, profile=profile)

@@ -297,8 +297,9 @@ int cb_site_rate_gather(int device, int S, int R, int n, int L, const double *te
  *   LEAF, -1 = unobserved (gap / unknown symbol: all-ones observation, :105-126); rows of internal
  *   nodes are ignored (:152-167); code_b only when S1 > 0
  *   ll [n_units] out: log-likelihood of each unit (a pair's value is for both of its sites)
- *   kernel_ms (may be NULL): GPU time of bank + pruning, inputs already resident, by HIP events
- * S <= 448; S > 64 requires n_cats == 1 (the reference evaluates pairs at rate 1). */
+ *   kernel_ms (may be NULL) [2] out: GPU ms of {transition bank + pruning, pruning alone}, inputs
+ *   already resident, by HIP events
+ * S <= 512; S > 64 requires n_cats == 1 (the reference evaluates pairs at rate 1). */
 int cb_tree_likelihood(int device, int S, int S1, const double *Q, const double *pi_rev,
                        const double *pi_root, int n_nodes, const int *postorder, const int *parent,
                        const double *length, int n_cats, const double *cat_rate, int n_units,

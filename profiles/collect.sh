@@ -10,7 +10,7 @@ cd /tmp && export TMPDIR=/tmp
 TAG=${1:-final}
 # plain (unprofiled) default bench line first, on the fresh box, as the driver runs it
 python3 $R/bench.py > $R/gpurun_out/${TAG}_bench_default.log 2>&1
-for w in coevo400 lg20 siterm counting ble assembly; do
+for w in coevo400 lg20 siterm counting ble assembly likelihood; do
   rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${TAG}_trace_$w -- \
     python3 $R/bench.py --workload $w --no-cpu-baseline --no-secondary > $R/gpurun_out/${TAG}_bench_$w.log 2>&1
   for c in FETCH_SIZE WRITE_SIZE; do

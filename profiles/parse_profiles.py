@@ -29,7 +29,7 @@ names = {"k1_pt_loss_gt": "k1_pt_loss_gt", "k2_t_eq_g_u": "k2_t_eq_g_u", "k3_w_p
          "sp_prepare": "sp_prepare", "sp_bank": "sp_bank", "sp_finish": "sp_finish", "sg_gemm": "sg_gemm", "lgx_build": "lgx_build", "ble_branch_lengths_kernel": "ble_branch_lengths_kernel",
          "ble_site_rates_kernel": "ble_site_rates_kernel", "siterm_raw_counts_kernel": "siterm_raw_counts_kernel",
          "siterm_mix_kernel": "siterm_mix_kernel"}
-for w in ["coevo400", "lg20", "siterm", "counting", "ble", "assembly"]:
+for w in ["coevo400", "lg20", "siterm", "counting", "ble", "assembly", "likelihood"]:
     st = glob.glob(f"{root}/gpurun_out/{tag}_trace_{w}/*/*_kernel_stats.csv")
     if st:
         shutil.copy(st[0], f"{here}/r01_{tag}_{w}_kernel_stats.csv")
