@@ -74,7 +74,7 @@ struct cb_bank {
   double *Q = nullptr, *pi = nullptr, *loss = nullptr, *dQ = nullptr;
   int *status = nullptr;
   // large-path workspaces
-  double *Gc2 = nullptr, *gx = nullptr;  // second column buffer and 4 LD^2 scratch of the first-order sweep
+  double *Gc2 = nullptr, *gx = nullptr;  // second column buffer and 10 LD^2 scratch of the first-order / hybrid sweeps
   int last_light = 0;
   // in-library all-reduce (cb_allreduce_setup)
   void *comm = nullptr;
@@ -473,7 +473,7 @@ extern "C" int cb_create(int device, int S, int L, int B, const double *t, const
     bool ok = dev_alloc(h, &h->Ct, per_bucket) == CB_OK && dev_alloc(h, &tot, SS) == CB_OK &&
               dev_alloc(h, &h->A, LL) == CB_OK && dev_alloc(h, &h->dsq, h->LD) == CB_OK &&
               dev_alloc(h, &h->Gc, LL) == CB_OK && dev_alloc(h, &h->Vc, LL) == CB_OK &&
-              dev_alloc(h, &h->Gc2, LL) == CB_OK && dev_alloc(h, &h->gx, 4 * LL) == CB_OK &&
+              dev_alloc(h, &h->Gc2, LL) == CB_OK && dev_alloc(h, &h->gx, 10 * LL) == CB_OK &&
               dev_alloc(h, &h->U, LL) == CB_OK && dev_alloc(h, &h->lam, h->LD) == CB_OK &&
               dev_alloc(h, &h->sigma, 8) == CB_OK && dev_alloc(h, &h->off_bits, 64) == CB_OK &&
               dev_alloc(h, &h->F, (size_t)B * h->LD) == CB_OK &&
@@ -622,21 +622,22 @@ static int launch_small(cb_bank *h, const SmallArgs &a) {
 }
 
 // --------------------------------------------------------------- large path
-static void launch_sg(cb_bank *h, const K4Args &g, int ns) {
+static void launch_sg(cb_bank *h, const K4Args &g, int ns, double alpha = 0.0, double beta = 0.0) {
   if (getenv("CB_OLD_K4") && !ns) {
     const int t = (h->LD + LG_TM - 1) / LG_TM;
     hipLaunchKernelGGL(k4_gemm, dim3(t * t), dim3(LG_THREADS), 0, h->stream, g);
     return;
   }
   const unsigned nwg = (unsigned)((h->LD / 16) * ((h->LD + 79) / 80));
-  hipLaunchKernelGGL(sg_gemm, dim3(nwg), dim3(256), 0, h->stream, g, ns);
+  hipLaunchKernelGGL(sg_gemm, dim3(nwg), dim3(256), 0, h->stream, g, ns, alpha, beta);
 }
 
 static int large_eigh(cb_bank *h, bool warm) {
   const int LD = h->LD;
   const size_t LL = (size_t)LD * LD;
   hipLaunchKernelGGL(lgj_sigma, dim3(1), dim3(256), 0, h->stream, LD, h->A, h->sigma);
-  if (warm && h->have_prev && !getenv("CB_NO_WARM")) {
+  const bool warm_started = warm && h->have_prev && !getenv("CB_NO_WARM");
+  if (warm_started) {
     // Warm start: Jacobi from the previous epoch's orthonormal basis V0 = U_prev,
     //   G0 = A' V0 :  Gc[k][r] = sum_j U_prev[j][k] A[j][r] - sigma Ut_prev[k][r]
     // (A changes by one optimiser step, so G0's columns are nearly orthogonal already).
@@ -680,38 +681,103 @@ static int large_eigh(cb_bank *h, bool warm) {
     // a sweep that STARTS below 1e-8 ends at rounding level (quadratic convergence)
     hipLaunchKernelGGL(lgj_check, dim3(1), dim3(64), 0, h->stream, h->off_bits, 1e-8);
   };
-  // First-order sweep (jacobi_block.hip.h, lgx_*): returns 1 when applied and final (solve
-  // finished), 2 when applied but another one is needed, 0 when its preconditions do not hold
+  // First-order sweep (jacobi_block.hip.h, lgx_*): Gamma = G^T G, X_ij = Gamma_ij / (Gamma_jj - Gamma_ii),
+  // G <- G exp(X).  Returns 1 when applied and final (solve finished), 2 when applied but another one
+  // is needed, 3 when applied to the FAR pairs only (hybrid sweep: the caller now rotates the pairs
+  // within `band` blocks exactly, by banded Jacobi rounds), 0 when its preconditions do not hold
   // (nothing changed), < 0 on error.
-  auto light_sweep = [&]() -> int {
-    double *Gr = h->gx, *Gam = h->gx + LL, *X = h->gx + 2 * LL, *R = h->gx + 3 * LL;
+  //   exp(X): |X| <= 1e-5 second order, <= 2e-3 fourth order, else 8th order (Paterson-Stockmeyer,
+  //   4 products) on X / 2^s + s squarings + one Newton-Schulz step (the squarings amplify rounding).
+  const int band = getenv("CB_HYBRID_BAND") ? atoi(getenv("CB_HYBRID_BAND")) : 3;
+  const bool dbg_e = getenv("CB_DEBUG") != nullptr;
+  auto light_sweep = [&](bool hybrid_ok, double trigger) -> int {
+    double *Gr = h->gx, *Gam = h->gx + LL, *X = h->gx + 2 * LL, *Xf = h->gx + 3 * LL, *P4 = h->gx + 4 * LL,
+           *lo = h->gx + 5 * LL, *hiT = h->gx + 6 * LL, *R = h->gx + 7 * LL, *Rt = h->gx + 8 * LL, *R2 = h->gx + 9 * LL;
     const int nt32 = (LD + 31) / 32;
-    HIP_TRY(hipMemsetAsync(h->off_bits + 4, 0, 2 * sizeof(unsigned long long), h->stream));
+    const unsigned nel = (unsigned)((LL + 255) / 256);
+    HIP_TRY(hipMemsetAsync(h->off_bits + 4, 0, 3 * sizeof(unsigned long long), h->stream));
     hipLaunchKernelGGL(lgx_transpose, dim3(nt32, nt32), dim3(32, 8), 0, h->stream, LD, h->Gc, Gr);
     launch_sg(h, K4Args{h->S, LD, Gr, Gr, Gam, nullptr, nullptr, nullptr}, 0);
-    hipLaunchKernelGGL(lgx_build, dim3(LD), dim3(256), 0, h->stream, LD, Gam, X, h->off_bits);
-    unsigned long long m[2] = {};
+    hipLaunchKernelGGL(lgx_build, dim3(LD), dim3(256), 0, h->stream, LD, Gam, X, Xf, band, h->off_bits);
+    unsigned long long m[3] = {};
     HIP_TRY(hipMemcpyAsync(m, h->off_bits + 4, sizeof m, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
-    double cosmax, rowsum;
+    double cosmax, rowsum, rowsum_far;
     memcpy(&cosmax, &m[0], sizeof cosmax);
     memcpy(&rowsum, &m[1], sizeof rowsum);
-    if (getenv("CB_DEBUG"))
-      fprintf(stderr, "[cherrybank] eigh first-order sweep: max cosine %.3e, |X| <= %.3e\n", cosmax, rowsum);
+    memcpy(&rowsum_far, &m[2], sizeof rowsum_far);
+    if (dbg_e)
+      fprintf(stderr, "[cherrybank] eigh first-order sweep: max cosine %.3e, |X| <= %.3e (far pairs: %.3e)\n", cosmax,
+              rowsum, rowsum_far);
     if (!(cosmax == cosmax) || !(rowsum == rowsum)) return fail(CB_ENUMERIC, "eigensolver: non-finite input");
-    if (rowsum > 2e-3) return 0;
+    bool masked = false;
+    if (hybrid_ok) {
+      // all pairs at once only when the state is close enough for the small-angle limit to hold for
+      // the near-degenerate neighbours too
+      if (cosmax > trigger || rowsum > 0.5) {
+        masked = true;
+        rowsum = rowsum_far;
+        if (rowsum > 12.0) return 0;
+      }
+    } else if (rowsum > 2e-3) {
+      return 0;
+    }
+    const double *Xu = masked ? Xf : X;
+    double *Rfin = R;
     if (rowsum <= 1e-5) {
-      launch_sg(h, K4Args{h->S, LD, X, X, R, nullptr, X, nullptr}, 1);      // R = I + X - X^T X / 2
+      launch_sg(h, K4Args{h->S, LD, Xu, Xu, R, nullptr, Xu, nullptr}, 1);      // R = I + X - X^T X / 2
     } else {
       double *P2 = Gr, *P3 = Gam;                                            // both free by now
-      launch_sg(h, K4Args{h->S, LD, X, X, P2, nullptr, nullptr, nullptr}, 0);    // X^T X   = -X^2
-      launch_sg(h, K4Args{h->S, LD, X, P2, P3, nullptr, nullptr, nullptr}, 0);   // X^T P2  =  X^3
-      launch_sg(h, K4Args{h->S, LD, P2, P2, R, nullptr, nullptr, nullptr}, 0);   // P2^T P2 =  X^4
-      hipLaunchKernelGGL(lgx_combine, dim3((unsigned)((LL + 255) / 256)), dim3(256), 0, h->stream, LD, X, P2, P3, R);
+      launch_sg(h, K4Args{h->S, LD, Xu, Xu, P2, nullptr, nullptr, nullptr}, 0);    // X^T X   = -X^2
+      launch_sg(h, K4Args{h->S, LD, Xu, P2, P3, nullptr, nullptr, nullptr}, 0);   // X^T P2  =  X^3
+      if (rowsum <= 2e-3) {
+        launch_sg(h, K4Args{h->S, LD, P2, P2, R, nullptr, nullptr, nullptr}, 0);   // P2^T P2 =  X^4
+        hipLaunchKernelGGL(lgx_combine, dim3(nel), dim3(256), 0, h->stream, LD, Xu, P2, P3, R);
+      } else {
+        int sq = 0;
+        double sc = 1.0;
+        while (rowsum * sc > 0.075) {
+          sc *= 0.5;
+          ++sq;
+        }
+        launch_sg(h, K4Args{h->S, LD, P2, P2, P4, nullptr, nullptr, nullptr}, 0);
+        hipLaunchKernelGGL(lgx_poly8, dim3(nel), dim3(256), 0, h->stream, LD, sc, Xu, P2, P3, P4, lo, hiT);
+        const double sc2 = sc * sc;
+        launch_sg(h, K4Args{h->S, LD, hiT, P4, R, nullptr, lo, nullptr}, 2, sc2 * sc2, 1.0);  // R = lo + hi Y^4
+        double *cur = R, *nxt = R2;
+        for (int q = 0; q < sq; ++q) {                                        // R <- R R
+          hipLaunchKernelGGL(lgx_transpose, dim3(nt32, nt32), dim3(32, 8), 0, h->stream, LD, cur, Rt);
+          launch_sg(h, K4Args{h->S, LD, Rt, cur, nxt, nullptr, nullptr, nullptr}, 0);
+          std::swap(cur, nxt);
+        }
+        if (sq > 0) {                                                         // R <- R (3 I - R^T R) / 2
+          double *N = lo;                                                     // free by now
+          hipLaunchKernelGGL(lgx_transpose, dim3(nt32, nt32), dim3(32, 8), 0, h->stream, LD, cur, Rt);
+          launch_sg(h, K4Args{h->S, LD, cur, cur, N, nullptr, nullptr, nullptr}, 0);
+          launch_sg(h, K4Args{h->S, LD, Rt, N, nxt, nullptr, cur, nullptr}, 2, -0.5, 1.5);
+          std::swap(cur, nxt);
+        }
+        Rfin = cur;
+      }
     }
-    launch_sg(h, K4Args{h->S, LD, R, h->Gc, h->Gc2, nullptr, nullptr, nullptr}, 0);  // Gc2[c'][r] = sum_c R[c][c'] Gc[c][r]
+    launch_sg(h, K4Args{h->S, LD, Rfin, h->Gc, h->Gc2, nullptr, nullptr, nullptr}, 0);  // Gc2[c'][r] = sum_c R[c][c'] Gc[c][r]
     std::swap(h->Gc, h->Gc2);
+    if (masked) return 3;
     return cosmax <= 1e-8 ? 1 : 2;
+  };
+  // Banded Jacobi pass of the hybrid sweep: every column pair at most `band` blocks apart is rotated
+  // exactly -- distance <= 1 by the two within passes (16-column groups, both alignments, to
+  // convergence), distance k = 2..band by two rounds of disjoint block pairs (i, i + k).
+  auto band_pass = [&](int shift) {
+    for (int w = 0; w < 2; ++w)
+      hipLaunchKernelGGL(lgj_round, dim3(nb / 2), dim3(JB_THREADS), lds, h->stream, LD,
+                         ((shift + w) & 1) && nb > 2 ? -2 : -1, within, h->Gc, h->off_bits,
+                         (unsigned long long *)nullptr);
+    for (int k = 2; k <= band && k < nb; ++k)
+      for (int par = 0; par < 2; ++par)
+        hipLaunchKernelGGL(lgj_round, dim3((unsigned)(((nb + 2 * k - 1) / (2 * k)) * k)), dim3(JB_THREADS), lds,
+                           h->stream, LD, -(10 + 2 * (k - 2) + par), 0, h->Gc, h->off_bits,
+                           (unsigned long long *)nullptr);
   };
   // Sweeps are enqueued without waiting for the host: as many as the previous (warm) solve needed,
   // then one at a time.  Launches after convergence return immediately.  Once a sweep started
@@ -724,7 +790,30 @@ static int large_eigh(cb_bank *h, bool warm) {
   int batch = speculate ? std::max(1, h->spec_sweeps) : 1;
   bool converged = false;
   int light_done = 0;
-  for (;;) {
+  // Hybrid solve (warm start only): the per-epoch perturbation mixes eigenvectors whose eigenvalues
+  // are close (a few blocks apart in the sorted order) by large angles and all others by small ones.
+  // So a sweep = ONE first-order rotation of all far pairs (GEMMs) + `reps` banded Jacobi passes
+  // over the near pairs (2 * band launches each) instead of LD/8 + 1 tournament rounds; it
+  // converges like a full Jacobi sweep.  Falls through to the Jacobi loop below when it refuses.
+  const int hybrid_reps = getenv("CB_HYBRID_REPS") ? atoi(getenv("CB_HYBRID_REPS")) : 2;
+  int hybrid_iters = 0;
+  if (warm_started && use_light && nb >= 8 && !getenv("CB_NO_HYBRID")) {
+    for (int it = 0; it < 12; ++it) {
+      const int lr = light_sweep(true, light_trigger);
+      if (lr < 0) return lr;
+      if (lr == 0) break;
+      ++hybrid_iters;
+      if (lr == 3)
+        for (int rep = 0; rep < hybrid_reps; ++rep) band_pass(it + rep);
+      if (lr == 1) {
+        converged = true;
+        light_done = 1;
+        break;
+      }
+    }
+    if (!converged) HIP_TRY(hipMemsetAsync(h->off_bits, 0, 8 * sizeof(unsigned long long), h->stream));
+  }
+  for (; !converged;) {
     for (int i = 0; i < batch && enq < max_sweeps; ++i) enqueue_sweep(enq++);
     HIP_TRY(hipMemcpyAsync(st, h->off_bits, sizeof st, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
@@ -743,7 +832,7 @@ static int large_eigh(cb_bank *h, bool warm) {
     }
     if (use_light && c_last <= light_trigger) {
       int lr = 2, guard = 0;
-      while (lr == 2 && guard++ < 4) lr = light_sweep();
+      while (lr == 2 && guard++ < 4) lr = light_sweep(false, light_trigger);
       if (lr < 0) return lr;
       if (lr == 1) {
         converged = true;
@@ -770,7 +859,7 @@ static int large_eigh(cb_bank *h, bool warm) {
       }
     h->spec_sweeps = need;
   }
-  h->last_sweeps = sweep;
+  h->last_sweeps = sweep + hybrid_iters;
   if (dbg_stamps) {
     unsigned long long st[8];
     HIP_TRY(hipMemcpy(st, dbg_stamps, sizeof st, hipMemcpyDeviceToHost));

@@ -49,6 +49,9 @@ __device__ __forceinline__ int jb_rowstride(int LD) { return LD + ((2 - LD % 32 
 // round <  0: the "within" pass: workgroup w takes blocks 2w, 2w+1 and rotates only
 //             the pairs inside each block.  One sweep = the LD/8 - 1 rounds + 1 within
 //             pass visits every column pair exactly once.
+// round <= -10: banded round of the hybrid sweep (large_eigh): code = -round - 10, k = code / 2 + 2,
+//             parity = code & 1: block pairs (i, i + k) with (i / k) % 2 == parity, cross pairs once
+//             (the eigen-columns are kept sorted, so near-degenerate columns are a few blocks apart).
 __global__ __launch_bounds__(JB_THREADS) void lgj_round(int LD, int round, int inner_sweeps,
                                                         double *Gc, unsigned long long *off_bits,
                                                         unsigned long long *stamps,
@@ -71,6 +74,11 @@ __global__ __launch_bounds__(JB_THREADS) void lgj_round(int LD, int round, int i
   int bi, bj;
   if (round >= 0) {
     rr_pair(nb, round, blockIdx.x, bi, bj);
+  } else if (round <= -10) {
+    const int code = -round - 10, k = code / 2 + 2, par = code & 1, w = blockIdx.x;
+    bi = (w / k) * 2 * k + par * k + (w % k);
+    bj = bi + k;
+    if (bj >= nb) return;
   } else if (round == -1) {
     bi = 2 * blockIdx.x;
     bj = bi + 1;
@@ -154,7 +162,7 @@ __global__ __launch_bounds__(JB_THREADS) void lgj_round(int LD, int round, int i
       wave_rotation_spd16(sGam, sR, 17, inner_sweeps);
     } else {
       double off2;
-      if (round >= 0) {
+      if (round >= 0 || round <= -10) {
         JB_STAMP(3)
         off2 = wave_rotation_cross16_regs(sGam, sR, 17);
       } else {
@@ -267,12 +275,15 @@ __global__ void lgx_transpose(int LD, const double *Gc, double *Gr) {
   }
 }
 
-// one workgroup (256 threads) per row i; state[4] = max cosine (bits), state[5] = max row sum (bits)
-__global__ __launch_bounds__(256) void lgx_build(int LD, const double *Gam, double *X, unsigned long long *state) {
-  __shared__ double s0[256], s1[256];
+// one workgroup (256 threads) per row i; state[4] = max cosine (bits), state[5] = max row sum (bits).
+// Xf = X with the pairs at block distance <= band zeroed (the hybrid sweep rotates those exactly,
+// by banded Jacobi rounds); state[6] = its max row sum.
+__global__ __launch_bounds__(256) void lgx_build(int LD, const double *Gam, double *X, double *Xf, int band,
+                                                 unsigned long long *state) {
+  __shared__ double s0[256], s1[256], s2[256];
   const int i = blockIdx.x;
   const double gii = Gam[(size_t)i * LD + i];
-  double mc2 = 0.0, rs = 0.0;
+  double mc2 = 0.0, rs = 0.0, rsf = 0.0;
   for (int j = threadIdx.x; j < LD; j += 256) {
     double x = 0.0;
     if (j != i) {
@@ -286,21 +297,45 @@ __global__ __launch_bounds__(256) void lgx_build(int LD, const double *Gam, doub
       }
     }
     X[(size_t)i * LD + j] = x;
+    const int bd = i / JB_W - j / JB_W;
+    const bool far = bd > band || -bd > band;
+    Xf[(size_t)i * LD + j] = far ? x : 0.0;
+    rsf += far ? fabs(x) : 0.0;
   }
   s0[threadIdx.x] = mc2;
   s1[threadIdx.x] = rs;
+  s2[threadIdx.x] = rsf;
   __syncthreads();
   for (int st = 128; st >= 1; st >>= 1) {
     if ((int)threadIdx.x < st) {
       s0[threadIdx.x] = fmax(s0[threadIdx.x], s0[threadIdx.x + st]);
       s1[threadIdx.x] += s1[threadIdx.x + st];
+      s2[threadIdx.x] += s2[threadIdx.x + st];
     }
     __syncthreads();
   }
   if (threadIdx.x == 0) {
     atomicMax(state + 4, dbl_bits(sqrt(s0[0])));
     atomicMax(state + 5, dbl_bits(s1[0]));
+    atomicMax(state + 6, dbl_bits(s2[0]));
   }
+}
+
+// exp(Y), Y = sc X, to 8th order by Paterson-Stockmeyer:  exp(Y) ~ lo + hi Y^4,
+//   lo = I + Y + Y^2/2 + Y^3/6,  hi = I/4! + Y/5! + Y^2/6! + Y^3/7! + Y^4/8!.
+// In: X (antisymmetric), P2 = X^T X = -X^2, P3 = X^T P2 = X^3, P4 = P2^T P2 = X^4.
+// Out: lo and hi^T (X, P3 change sign under transposition, P2, P4 do not); the caller forms
+// R = lo + sc^4 (hi^T)^T P4 with one more sg_gemm.  |Y| <= 0.075 keeps the remainder |Y|^9/9! < 1e-15.
+__global__ void lgx_poly8(int LD, double sc, const double *X, const double *P2, const double *P3, const double *P4,
+                          double *lo, double *hiT) {
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (size_t)LD * LD) return;
+  const int i = idx / LD, j = idx - (size_t)i * LD;
+  const double dl = i == j ? 1.0 : 0.0;
+  const double s2 = sc * sc;
+  const double y1 = sc * X[idx], y2 = -s2 * P2[idx], y3 = s2 * sc * P3[idx], y4 = s2 * s2 * P4[idx];
+  lo[idx] = dl + y1 + 0.5 * y2 + y3 * (1.0 / 6.0);
+  hiT[idx] = dl * (1.0 / 24.0) - y1 * (1.0 / 120.0) + y2 * (1.0 / 720.0) - y3 * (1.0 / 5040.0) + y4 * (1.0 / 40320.0);
 }
 
 // R = I + X - P2/2 + P3/6 + P4/24  (= exp(X) to 4th order: P2 = X^T X = -X^2, P3 = X^T P2 = X^3,

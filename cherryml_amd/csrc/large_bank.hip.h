@@ -347,8 +347,10 @@ __global__ __launch_bounds__(LG_THREADS) void k4_gemm(K4Args a) {
 // straight from L2 in MFMA layout (no LDS staging: the matrices are 1.3 MB), the four partial
 // strips are summed through LDS in a fixed order.  (LD/16) x ceil(LD/80) = 125 workgroups.
 // Same argument block and epilogues as k4_gemm, plus:
-//   ns != 0 :  out = (row == col) + sub[row][col] - acc / 2      (R = I + X + X^2/2, X^2 = -X^T X)
-__global__ __launch_bounds__(256) void sg_gemm(K4Args a, int ns) {
+//   ns == 1 :  out = (row == col) + sub[row][col] - acc / 2      (R = I + X + X^2/2, X^2 = -X^T X)
+//   ns == 2 :  out = alpha * acc + beta * sub[row][col]          (polynomial / Newton-Schulz steps of the
+//                                                                 first-order sweeps, jacobi_block.hip.h)
+__global__ __launch_bounds__(256) void sg_gemm(K4Args a, int ns, double alpha, double beta) {
   __shared__ double sRed[4][5][256];
   const int LD = a.LD, tilesN = (LD + 79) / 80;
   const int tm = blockIdx.x / tilesN, tn = blockIdx.x - tm * tilesN;
@@ -396,7 +398,8 @@ __global__ __launch_bounds__(256) void sg_gemm(K4Args a, int ns) {
       if (row < a.S && col < a.S) a.out[(size_t)row * a.S + col] = a.dsq[row] * v / a.dsq[col];
     } else {
       const size_t idx = (size_t)row * LD + col;
-      if (ns) a.out[idx] = (row == col ? 1.0 : 0.0) + a.sub[idx] - 0.5 * v;
+      if (ns == 1) a.out[idx] = (row == col ? 1.0 : 0.0) + a.sub[idx] - 0.5 * v;
+      else if (ns == 2) a.out[idx] = fma(alpha, v, beta * a.sub[idx]);
       else a.out[idx] = a.sub ? v - (*a.sub_scale) * a.sub[idx] : v;
     }
   }
