@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdarg>
@@ -74,7 +75,7 @@ struct cb_bank {
   double *Q = nullptr, *pi = nullptr, *loss = nullptr, *dQ = nullptr;
   int *status = nullptr;
   // large-path workspaces
-  double *Gc2 = nullptr, *gx = nullptr;  // second column buffer and 10 LD^2 scratch of the first-order / hybrid sweeps
+  double *Gc2 = nullptr, *gx = nullptr;  // second column buffer and 12 LD^2 + LD scratch of the first-order / hybrid sweeps
   int last_light = 0;
   // in-library all-reduce (cb_allreduce_setup)
   void *comm = nullptr;
@@ -88,6 +89,8 @@ struct cb_bank {
          *sigma = nullptr, *F = nullptr, *E = nullptr, *H = nullptr, *Gt = nullptr, *T = nullptr,
          *Mt_part = nullptr, *Mt = nullptr, *X = nullptr, *loss_part = nullptr;
   unsigned long long *off_bits = nullptr;
+  unsigned long long *poll = nullptr;      // 8 words of coherent pinned host memory the first-order sweep publishes to
+  unsigned long long poll_seq = 0;
   int k3_chunk = 0, k3_nchunks = 0;
   int last_sweeps = 0;
   double *gn_scratch = nullptr, *gn_partial = nullptr;  // general path, allocated on first use
@@ -473,7 +476,7 @@ extern "C" int cb_create(int device, int S, int L, int B, const double *t, const
     bool ok = dev_alloc(h, &h->Ct, per_bucket) == CB_OK && dev_alloc(h, &tot, SS) == CB_OK &&
               dev_alloc(h, &h->A, LL) == CB_OK && dev_alloc(h, &h->dsq, h->LD) == CB_OK &&
               dev_alloc(h, &h->Gc, LL) == CB_OK && dev_alloc(h, &h->Vc, LL) == CB_OK &&
-              dev_alloc(h, &h->Gc2, LL) == CB_OK && dev_alloc(h, &h->gx, 10 * LL) == CB_OK &&
+              dev_alloc(h, &h->Gc2, LL) == CB_OK && dev_alloc(h, &h->gx, 12 * LL + (size_t)h->LD + 8) == CB_OK &&
               dev_alloc(h, &h->U, LL) == CB_OK && dev_alloc(h, &h->lam, h->LD) == CB_OK &&
               dev_alloc(h, &h->sigma, 8) == CB_OK && dev_alloc(h, &h->off_bits, 64) == CB_OK &&
               dev_alloc(h, &h->F, (size_t)B * h->LD) == CB_OK &&
@@ -533,6 +536,7 @@ extern "C" void cb_destroy(cb_handle h) {
   for (double *p : h->ws_ptr)
     if (p) (void)hipFree(p);
   if (h->pin) (void)hipHostFree(h->pin);
+  if (h->poll) (void)hipHostFree(h->poll);
   if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
   delete h;
 }
@@ -629,7 +633,10 @@ static void launch_sg(cb_bank *h, const K4Args &g, int ns, double alpha = 0.0, d
     return;
   }
   const unsigned nwg = (unsigned)((h->LD / 16) * ((h->LD + 79) / 80));
-  hipLaunchKernelGGL(sg_gemm, dim3(nwg), dim3(256), 0, h->stream, g, ns, alpha, beta);
+  static const int variant = getenv("CB_SG_VARIANT") ? atoi(getenv("CB_SG_VARIANT")) : 1;
+  if (variant == 0) hipLaunchKernelGGL((sg_gemm<4, 4>), dim3(nwg), dim3(256), 0, h->stream, g, ns, alpha, beta);
+  else if (variant == 1) hipLaunchKernelGGL((sg_gemm<8, 4>), dim3(nwg), dim3(512), 0, h->stream, g, ns, alpha, beta);
+  else hipLaunchKernelGGL((sg_gemm<8, 7>), dim3(nwg), dim3(512), 0, h->stream, g, ns, alpha, beta);
 }
 
 static int large_eigh(cb_bank *h, bool warm) {
@@ -665,7 +672,9 @@ static int large_eigh(cb_bank *h, bool warm) {
   unsigned long long *dbg_stamps = nullptr;
   if (getenv("CB_DEBUG_STAMPS")) HIP_TRY(hipMalloc((void **)&dbg_stamps, 8 * sizeof(unsigned long long)));
   HIP_TRY(hipMemsetAsync(h->off_bits, 0, 64 * sizeof(unsigned long long), h->stream));
+  bool gr_valid = false;   // the row-major copy of G (first-order sweeps) is current
   auto enqueue_sweep = [&](int sweep) {
+    gr_valid = false;
     if (inner_sweeps == 0) {
       // within passes: each 16-column group fully diagonalised (all 120 pairs, to convergence);
       // the group alignment alternates so that the groups overlap by one block
@@ -689,19 +698,61 @@ static int large_eigh(cb_bank *h, bool warm) {
   //   exp(X): |X| <= 1e-5 second order, <= 2e-3 fourth order, else 8th order (Paterson-Stockmeyer,
   //   4 products) on X / 2^s + s squarings + one Newton-Schulz step (the squarings amplify rounding).
   const int band = getenv("CB_HYBRID_BAND") ? atoi(getenv("CB_HYBRID_BAND")) : 3;
+  const int ns_from = getenv("CB_HYBRID_NS_FROM") ? atoi(getenv("CB_HYBRID_NS_FROM")) : 2;  // squarings without a polish
   const bool dbg_e = getenv("CB_DEBUG") != nullptr;
   auto light_sweep = [&](bool hybrid_ok, double trigger) -> int {
     double *Gr = h->gx, *Gam = h->gx + LL, *X = h->gx + 2 * LL, *Xf = h->gx + 3 * LL, *P4 = h->gx + 4 * LL,
-           *lo = h->gx + 5 * LL, *hiT = h->gx + 6 * LL, *R = h->gx + 7 * LL, *Rt = h->gx + 8 * LL, *R2 = h->gx + 9 * LL;
+           *lo = h->gx + 5 * LL, *hiT = h->gx + 6 * LL, *R = h->gx + 7 * LL, *Rt = h->gx + 8 * LL, *R2 = h->gx + 9 * LL, *Rt2 = h->gx + 10 * LL, *dg = h->gx + 11 * LL;
     const int nt32 = (LD + 31) / 32;
     const unsigned nel = (unsigned)((LL + 255) / 256);
-    HIP_TRY(hipMemsetAsync(h->off_bits + 4, 0, 3 * sizeof(unsigned long long), h->stream));
-    hipLaunchKernelGGL(lgx_transpose, dim3(nt32, nt32), dim3(32, 8), 0, h->stream, LD, h->Gc, Gr);
-    launch_sg(h, K4Args{h->S, LD, Gr, Gr, Gam, nullptr, nullptr, nullptr}, 0);
-    hipLaunchKernelGGL(lgx_build, dim3(LD), dim3(256), 0, h->stream, LD, Gam, X, Xf, band, h->off_bits);
+    // Gr = G row-major: from the previous sweep's last product when nothing touched G since
+    // (Grn then holds it), else by a transposition
+    double *Grn = h->gx + 11 * LL + (size_t)((LD + 7) & ~7);
+    if (gr_valid) {
+      Gr = Grn;
+      HIP_TRY(hipMemsetAsync(h->off_bits + 4, 0, 4 * sizeof(unsigned long long), h->stream));
+    } else {
+      hipLaunchKernelGGL(lgx_transpose, dim3(nt32, nt32), dim3(32, 8), 0, h->stream, LD, h->Gc, Gr, h->off_bits + 4);
+    }
+    gr_valid = false;
+    launch_sg(h, K4Args{h->S, LD, Gr, Gr, Gam, nullptr, nullptr, nullptr, nullptr, dg}, 0);
+    if (!h->poll && !getenv("CB_NO_POLL")) {
+      void *q = nullptr;
+      if (hipHostMalloc(&q, 8 * sizeof(unsigned long long), hipHostMallocCoherent | hipHostMallocMapped) == hipSuccess) {
+        h->poll = (unsigned long long *)q;
+        memset(q, 0, 8 * sizeof(unsigned long long));
+      } else {
+        (void)hipGetLastError();
+      }
+    }
+    const unsigned long long seq = ++h->poll_seq;
+    hipLaunchKernelGGL(lgx_build, dim3((LD + 3) / 4), dim3(256), 0, h->stream, LD, Gam, dg, X, Xf, band, h->off_bits,
+                       (volatile unsigned long long *)h->poll, seq);
     unsigned long long m[3] = {};
-    HIP_TRY(hipMemcpyAsync(m, h->off_bits + 4, sizeof m, hipMemcpyDeviceToHost, h->stream));
-    HIP_TRY(hipStreamSynchronize(h->stream));
+    bool got = false;
+    if (h->poll) {
+      // spin on the pinned words (a few microseconds after the kernel's last workgroup); give up
+      // after 20 ms and take the ordinary route
+      volatile unsigned long long *pl = h->poll;
+      const auto t_spin = std::chrono::steady_clock::now();
+      for (unsigned it = 0;; ++it) {
+        if (pl[0] == seq) {
+          std::atomic_thread_fence(std::memory_order_acquire);
+          m[0] = pl[1];
+          m[1] = pl[2];
+          m[2] = pl[3];
+          got = true;
+          break;
+        }
+        if ((it & 1023u) == 1023u &&
+            std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_spin).count() > 20.0)
+          break;
+      }
+    }
+    if (!got) {
+      HIP_TRY(hipMemcpyAsync(m, h->off_bits + 4, sizeof m, hipMemcpyDeviceToHost, h->stream));
+      HIP_TRY(hipStreamSynchronize(h->stream));
+    }
     double cosmax, rowsum, rowsum_far;
     memcpy(&cosmax, &m[0], sizeof cosmax);
     memcpy(&rowsum, &m[1], sizeof rowsum);
@@ -743,35 +794,39 @@ static int large_eigh(cb_bank *h, bool warm) {
         launch_sg(h, K4Args{h->S, LD, P2, P2, P4, nullptr, nullptr, nullptr}, 0);
         hipLaunchKernelGGL(lgx_poly8, dim3(nel), dim3(256), 0, h->stream, LD, sc, Xu, P2, P3, P4, lo, hiT);
         const double sc2 = sc * sc;
-        launch_sg(h, K4Args{h->S, LD, hiT, P4, R, nullptr, lo, nullptr}, 2, sc2 * sc2, 1.0);  // R = lo + hi Y^4
-        double *cur = R, *nxt = R2;
+        // (every product also writes its transpose: the next step needs R^T as the k-major operand)
+        launch_sg(h, K4Args{h->S, LD, hiT, P4, R, nullptr, lo, nullptr, sq > 0 ? Rt : nullptr}, 2, sc2 * sc2, 1.0);  // R = lo + hi Y^4
+        double *cur = R, *nxt = R2, *curT = Rt, *nxtT = Rt2;
         for (int q = 0; q < sq; ++q) {                                        // R <- R R
-          hipLaunchKernelGGL(lgx_transpose, dim3(nt32, nt32), dim3(32, 8), 0, h->stream, LD, cur, Rt);
-          launch_sg(h, K4Args{h->S, LD, Rt, cur, nxt, nullptr, nullptr, nullptr}, 0);
+          launch_sg(h, K4Args{h->S, LD, curT, cur, nxt, nullptr, nullptr, nullptr, nxtT}, 0);
           std::swap(cur, nxt);
+          std::swap(curT, nxtT);
         }
-        if (sq > 0) {                                                         // R <- R (3 I - R^T R) / 2
+        if (sq > ns_from) {                                                   // R <- R (3 I - R^T R) / 2
           double *N = lo;                                                     // free by now
-          hipLaunchKernelGGL(lgx_transpose, dim3(nt32, nt32), dim3(32, 8), 0, h->stream, LD, cur, Rt);
           launch_sg(h, K4Args{h->S, LD, cur, cur, N, nullptr, nullptr, nullptr}, 0);
-          launch_sg(h, K4Args{h->S, LD, Rt, N, nxt, nullptr, cur, nullptr}, 2, -0.5, 1.5);
+          launch_sg(h, K4Args{h->S, LD, curT, N, nxt, nullptr, cur, nullptr}, 2, -0.5, 1.5);
           std::swap(cur, nxt);
         }
         Rfin = cur;
       }
     }
-    launch_sg(h, K4Args{h->S, LD, Rfin, h->Gc, h->Gc2, nullptr, nullptr, nullptr}, 0);  // Gc2[c'][r] = sum_c R[c][c'] Gc[c][r]
+    // Gc2[c'][r] = sum_c R[c][c'] Gc[c][r]  (+ its transpose for the next sweep's Gram product)
+    launch_sg(h, K4Args{h->S, LD, Rfin, h->Gc, h->Gc2, nullptr, nullptr, nullptr, masked ? nullptr : Grn}, 0);
     std::swap(h->Gc, h->Gc2);
+    gr_valid = !masked;
     if (masked) return 3;
     return cosmax <= 1e-8 ? 1 : 2;
   };
   // Banded Jacobi pass of the hybrid sweep: every column pair at most `band` blocks apart is rotated
   // exactly -- distance <= 1 by the two within passes (16-column groups, both alignments, to
   // convergence), distance k = 2..band by two rounds of disjoint block pairs (i, i + k).
+  const int hybrid_within = getenv("CB_HYBRID_WITHIN") ? atoi(getenv("CB_HYBRID_WITHIN")) : 3;
   auto band_pass = [&](int shift) {
+    gr_valid = false;
     for (int w = 0; w < 2; ++w)
       hipLaunchKernelGGL(lgj_round, dim3(nb / 2), dim3(JB_THREADS), lds, h->stream, LD,
-                         ((shift + w) & 1) && nb > 2 ? -2 : -1, within, h->Gc, h->off_bits,
+                         ((shift + w) & 1) && nb > 2 ? -2 : -1, hybrid_within, h->Gc, h->off_bits,
                          (unsigned long long *)nullptr);
     for (int k = 2; k <= band && k < nb; ++k)
       for (int par = 0; par < 2; ++par)
@@ -795,7 +850,7 @@ static int large_eigh(cb_bank *h, bool warm) {
   // So a sweep = ONE first-order rotation of all far pairs (GEMMs) + `reps` banded Jacobi passes
   // over the near pairs (2 * band launches each) instead of LD/8 + 1 tournament rounds; it
   // converges like a full Jacobi sweep.  Falls through to the Jacobi loop below when it refuses.
-  const int hybrid_reps = getenv("CB_HYBRID_REPS") ? atoi(getenv("CB_HYBRID_REPS")) : 2;
+  const int hybrid_reps = getenv("CB_HYBRID_REPS") ? atoi(getenv("CB_HYBRID_REPS")) : 1;
   int hybrid_iters = 0;
   if (warm_started && use_light && nb >= 8 && !getenv("CB_NO_HYBRID")) {
     for (int it = 0; it < 12; ++it) {

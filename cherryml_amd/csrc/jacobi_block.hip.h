@@ -261,8 +261,10 @@ __global__ void lgj_check(unsigned long long *state, double tol) {
 //   |X|^5 / 120 < 1e-15);  larger: the caller runs an ordinary Jacobi sweep instead.
 // The sweep is the last one when it started with c <= 1e-8 (it ends at rounding level, like a
 // Jacobi sweep); otherwise the residual is ~ |X| c and another first-order sweep follows.
-__global__ void lgx_transpose(int LD, const double *Gc, double *Gr) {
+__global__ void lgx_transpose(int LD, const double *Gc, double *Gr, unsigned long long *zero4 = nullptr) {
   __shared__ double tile[32][33];
+  // (also clears the four statistics words lgx_build accumulates into: saves the memset launches)
+  if (zero4 && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.y == 0 && threadIdx.x < 4) zero4[threadIdx.x] = 0ull;
   const int i0 = blockIdx.y * 32, j0 = blockIdx.x * 32;
   for (int r = threadIdx.y; r < 32; r += blockDim.y) {
     const int i = i0 + r, j = j0 + threadIdx.x;
@@ -275,49 +277,62 @@ __global__ void lgx_transpose(int LD, const double *Gc, double *Gr) {
   }
 }
 
-// one workgroup (256 threads) per row i; state[4] = max cosine (bits), state[5] = max row sum (bits).
+// One wavefront per row i (4 rows per workgroup); state[4] = max cosine (bits), state[5] = max row sum (bits).
 // Xf = X with the pairs at block distance <= band zeroed (the hybrid sweep rotates those exactly,
-// by banded Jacobi rounds); state[6] = its max row sum.
-__global__ __launch_bounds__(256) void lgx_build(int LD, const double *Gam, double *X, double *Xf, int band,
-                                                 unsigned long long *state) {
-  __shared__ double s0[256], s1[256], s2[256];
-  const int i = blockIdx.x;
-  const double gii = Gam[(size_t)i * LD + i];
+// by banded Jacobi rounds); state[6] = its max row sum.  state[7] counts finished workgroups: the
+// last one publishes the three statistics + `seq` to `poll` (coherent pinned host memory), where the
+// host is spinning -- a hipStreamSynchronize round trip costs ~30 us of idle GPU per sweep.
+__global__ __launch_bounds__(256) void lgx_build(int LD, const double *Gam, const double *dg, double *X, double *Xf,
+                                                 int band, unsigned long long *state,
+                                                 volatile unsigned long long *poll, unsigned long long seq) {
+  __shared__ double s0[4], s1[4], s2[4];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int i = blockIdx.x * 4 + wave;
   double mc2 = 0.0, rs = 0.0, rsf = 0.0;
-  for (int j = threadIdx.x; j < LD; j += 256) {
-    double x = 0.0;
-    if (j != i) {
-      const double g = Gam[(size_t)i * LD + j], gjj = Gam[(size_t)j * LD + j];
-      const double g2 = g * g, ab = gii * gjj;
-      if (g2 > ab * (CB_JAC_SKIP * CB_JAC_SKIP)) {
-        mc2 = fmax(mc2, g2 / ab);
-        const double d = gjj - gii;
-        x = d != 0.0 ? g / d : (g > 0.0 ? 1.0 : -1.0);  // exactly degenerate and coupled: refuse (huge row sum)
-        rs += fabs(x);
+  if (i < LD) {
+    const double gii = dg[i];   // diagonal of Gam, written by the Gram product's epilogue
+    for (int j = lane; j < LD; j += 64) {
+      double x = 0.0;
+      if (j != i) {
+        const double g = Gam[(size_t)i * LD + j], gjj = dg[j];
+        const double g2 = g * g, ab = gii * gjj;
+        if (g2 > ab * (CB_JAC_SKIP * CB_JAC_SKIP)) {
+          mc2 = fmax(mc2, g2 / ab);
+          const double d = gjj - gii;
+          x = d != 0.0 ? g / d : (g > 0.0 ? 1.0 : -1.0);  // exactly degenerate and coupled: refuse (huge row sum)
+          rs += fabs(x);
+        }
       }
+      X[(size_t)i * LD + j] = x;
+      const int bd = i / JB_W - j / JB_W;
+      const bool far = bd > band || -bd > band;
+      Xf[(size_t)i * LD + j] = far ? x : 0.0;
+      rsf += far ? fabs(x) : 0.0;
     }
-    X[(size_t)i * LD + j] = x;
-    const int bd = i / JB_W - j / JB_W;
-    const bool far = bd > band || -bd > band;
-    Xf[(size_t)i * LD + j] = far ? x : 0.0;
-    rsf += far ? fabs(x) : 0.0;
   }
-  s0[threadIdx.x] = mc2;
-  s1[threadIdx.x] = rs;
-  s2[threadIdx.x] = rsf;
+  mc2 = wave_max(mc2);
+  rs = wave_sum(rs);
+  rsf = wave_sum(rsf);
+  if (lane == 0) {
+    s0[wave] = mc2;
+    s1[wave] = rs;
+    s2[wave] = rsf;
+  }
   __syncthreads();
-  for (int st = 128; st >= 1; st >>= 1) {
-    if ((int)threadIdx.x < st) {
-      s0[threadIdx.x] = fmax(s0[threadIdx.x], s0[threadIdx.x + st]);
-      s1[threadIdx.x] += s1[threadIdx.x + st];
-      s2[threadIdx.x] += s2[threadIdx.x + st];
-    }
-    __syncthreads();
-  }
   if (threadIdx.x == 0) {
-    atomicMax(state + 4, dbl_bits(sqrt(s0[0])));
-    atomicMax(state + 5, dbl_bits(s1[0]));
-    atomicMax(state + 6, dbl_bits(s2[0]));
+    atomicMax(state + 4, dbl_bits(sqrt(fmax(fmax(s0[0], s0[1]), fmax(s0[2], s0[3])))));
+    atomicMax(state + 5, dbl_bits(fmax(fmax(s1[0], s1[1]), fmax(s1[2], s1[3]))));
+    atomicMax(state + 6, dbl_bits(fmax(fmax(s2[0], s2[1]), fmax(s2[2], s2[3]))));
+    __threadfence();
+    const unsigned long long done = atomicAdd(state + 7, 1ull);
+    if (poll && done == gridDim.x - 1) {
+      poll[1] = atomicAdd(state + 4, 0ull);
+      poll[2] = atomicAdd(state + 5, 0ull);
+      poll[3] = atomicAdd(state + 6, 0ull);
+      __threadfence_system();
+      poll[0] = seq;
+      __threadfence_system();
+    }
   }
 }
 

@@ -312,6 +312,8 @@ struct K4Args {
   const double *dsq;        // non-null => out = dQ[i][j] = d_i * acc / d_j, unpadded S x S
   const double *sub;        // non-null => out = acc - (*sub_scale) * sub[row][col]
   const double *sub_scale;
+  double *outT = nullptr;   // sg_gemm only: also write the transpose of the result
+  double *diag = nullptr;   // sg_gemm only: also write the diagonal of the result
 };
 
 __global__ __launch_bounds__(LG_THREADS) void k4_gemm(K4Args a) {
@@ -350,7 +352,8 @@ __global__ __launch_bounds__(LG_THREADS) void k4_gemm(K4Args a) {
 //   ns == 1 :  out = (row == col) + sub[row][col] - acc / 2      (R = I + X + X^2/2, X^2 = -X^T X)
 //   ns == 2 :  out = alpha * acc + beta * sub[row][col]          (polynomial / Newton-Schulz steps of the
 //                                                                 first-order sweeps, jacobi_block.hip.h)
-__global__ __launch_bounds__(256) void sg_gemm(K4Args a, int ns, double alpha, double beta) {
+template <int NW, int UU>
+__global__ __launch_bounds__(NW * 64) void sg_gemm(K4Args a, int ns, double alpha, double beta) {
   __shared__ double sRed[4][5][256];
   const int LD = a.LD, tilesN = (LD + 79) / 80;
   const int tm = blockIdx.x / tilesN, tn = blockIdx.x - tm * tilesN;
@@ -364,29 +367,49 @@ __global__ __launch_bounds__(256) void sg_gemm(K4Args a, int ns, double alpha, d
   for (int j = 0; j < 5; ++j) ncol[j] = min(n0 + 16 * j + lo, LD - 1);  // clamped: tiles past LD are discarded
   const int nsteps = LD / 4;
   const double *Ap = a.Aop + m0 + lo, *Bp = a.Bop;
-  for (int s0 = wave; s0 < nsteps; s0 += 16) {   // 4 k-steps of this wave in flight
-    double av[4], bv[4][5];
+  for (int s0 = wave; s0 < nsteps; s0 += UU * NW) {   // UU k-steps of this wave in flight
+    double av[UU], bv[UU][5];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int s = min(s0 + 4 * u, nsteps - 1);
+    for (int u = 0; u < UU; ++u) {
+      const int s = min(s0 + NW * u, nsteps - 1);
       const size_t krow = (size_t)(4 * s + hi) * LD;
       av[u] = Ap[krow];
 #pragma unroll
       for (int j = 0; j < 5; ++j) bv[u][j] = Bp[krow + ncol[j]];
     }
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      if (s0 + 4 * u < nsteps) {
+    for (int u = 0; u < UU; ++u) {
+      if (s0 + NW * u < nsteps) {
 #pragma unroll
         for (int j = 0; j < 5; ++j) acc[j] = mfma_f64(av[u], bv[u][j], acc[j]);
       }
     }
   }
+  // K was split over the NW waves: fold the upper waves into the lower four, then sum those
+  for (int half = NW / 2; half >= 4; half >>= 1) {
+    if (wave >= half && wave < 2 * half) {
 #pragma unroll
-  for (int j = 0; j < 5; ++j)
+      for (int j = 0; j < 5; ++j)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) sRed[wave][j][r * 64 + lane] = acc[j][r];
+        for (int r = 0; r < 4; ++r) sRed[wave - half][j][r * 64 + lane] = acc[j][r];
+    }
+    __syncthreads();
+    if (wave < half) {
+#pragma unroll
+      for (int j = 0; j < 5; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[j][r] += sRed[wave][j][r * 64 + lane];
+    }
+    __syncthreads();
+  }
+  if (wave < 4) {
+#pragma unroll
+    for (int j = 0; j < 5; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) sRed[wave][j][r * 64 + lane] = acc[j][r];
+  }
   __syncthreads();
+  if (threadIdx.x >= 256) return;
   const int t = threadIdx.x, r = t >> 6, l = t & 63;
   const int row = m0 + (l >> 4) + 4 * r;
 #pragma unroll
@@ -398,9 +421,13 @@ __global__ __launch_bounds__(256) void sg_gemm(K4Args a, int ns, double alpha, d
       if (row < a.S && col < a.S) a.out[(size_t)row * a.S + col] = a.dsq[row] * v / a.dsq[col];
     } else {
       const size_t idx = (size_t)row * LD + col;
-      if (ns == 1) a.out[idx] = (row == col ? 1.0 : 0.0) + a.sub[idx] - 0.5 * v;
-      else if (ns == 2) a.out[idx] = fma(alpha, v, beta * a.sub[idx]);
-      else a.out[idx] = a.sub ? v - (*a.sub_scale) * a.sub[idx] : v;
+      double o;
+      if (ns == 1) o = (row == col ? 1.0 : 0.0) + a.sub[idx] - 0.5 * v;
+      else if (ns == 2) o = fma(alpha, v, beta * a.sub[idx]);
+      else o = a.sub ? v - (*a.sub_scale) * a.sub[idx] : v;
+      a.out[idx] = o;
+      if (a.outT) a.outT[(size_t)col * LD + row] = o;       // transposed copy (the squarings need R^T)
+      if (a.diag && row == col) a.diag[row] = o;
     }
   }
 }
