@@ -186,7 +186,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true")
     ap.add_argument("--force-sharded", action="store_true",
-                    help="run the multi-GPU code path (torch glue + ShardedBank + collectives) even at N = 1")
+                    help="run the multi-GPU code path (ShardedBank + collectives) even at N = 1")
+    ap.add_argument("--torch-glue", action="store_true",
+                    help="multi-GPU co-evolution: keep theta->Q / Adam in torch and the collective in "
+                         "torch.distributed instead of the C-driven loop with the in-library ncclAllReduce")
     args = ap.parse_args()
 
     import torch
@@ -235,33 +238,61 @@ def main():
             sharded = ShardedBank.from_rank_counts(wl["t"], torch.tensor(own["C"], device=dev))
             del own
             bank = sharded.bank
-            opt = torch.optim.Adam(module.parameters(), lr=0.1)
             n_pairs_total, scaling = sharded.total_count, "weak"
             sharding = (f"families x{world} -> reduce-scatter of the counts over buckets (once), "
-                        f"buckets x{world}, all-reduce(loss, dL/dQ) per epoch")
-            glue = "theta->Q and Adam in torch, loss + dL/dQ in HIP"
+                        f"buckets x{world}, all-reduce(loss, dL/dA) per epoch")
             B_local = len(sharded.local_buckets)
+            in_library = not args.torch_glue
+            if in_library:
+                try:
+                    sharded.enable_in_library_allreduce()
+                except Exception as exc:  # no raw RCCL communicator: keep torch.distributed's
+                    print(f"warning: in-library all-reduce unavailable ({exc}); torch glue", file=sys.stderr)
+                    in_library = False
+            if in_library:
+                # ---- the whole sharded loop from C on every rank: theta->A, replicated eigensolve,
+                #      this rank's buckets, ncclAllReduce(loss, dL/dA) on the handle's stream, Adam
+                glue = ("whole loop on the device, driven from C on every rank (theta->A, eigh, own buckets, "
+                        "in-library ncclAllReduce, Adam in HIP)")
+                u0 = module.upper_diag.detach().cpu().numpy().copy()
+                p0 = module._pi.detach().cpu().numpy().copy()
+                call = lambda E: sharded.train_pande_reversible(u0, p0, mask=wl["mask"], num_epochs=E, lr=0.1)  # noqa: E731
+                if warmup > 0:
+                    call(warmup)
+                bank.profile(True)
+                fence()
+                t0 = time.perf_counter()
+                r = call(steps)
+                fence()
+                dt = time.perf_counter() - t0
+                tm = bank.timing_means()
+                bank.profile(False)
+                final_loss = float(r["loss"][-1])
+            else:
+                opt = torch.optim.Adam(module.parameters(), lr=0.1)
+                glue = "theta->Q and Adam in torch, loss + dL/dQ in HIP"
 
-            def step():
-                opt.zero_grad()
-                loss = sharded.loss(module(), module.stationary(), normalize=True)[0]
-                loss.backward()
-                opt.step()
-                return loss
+                def step():
+                    opt.zero_grad()
+                    loss = sharded.loss(module(), module.stationary(), normalize=True)[0]
+                    loss.backward()
+                    opt.step()
+                    return loss
 
-            for _ in range(warmup):
-                step()
-            bank.profile(True)
-            fence()
-            t0 = time.perf_counter()
-            for _ in range(steps):
-                last = step()
-            fence()
-            dt = time.perf_counter() - t0
-            tm = bank.timing_means()
-            bank.profile(False)
-            final_loss = float(last.item())
+                for _ in range(warmup):
+                    step()
+                bank.profile(True)
+                fence()
+                t0 = time.perf_counter()
+                for _ in range(steps):
+                    last = step()
+                fence()
+                dt = time.perf_counter() - t0
+                tm = bank.timing_means()
+                bank.profile(False)
+                final_loss = float(last.item())
             kernel_ms = None
+            bank = sharded   # closed below (bank + communicator)
         else:
             # ---- the WHOLE epoch loop on the device (cb_train_pande_reversible /
             #      cb_train_siterm): K steps = K epochs of it, no torch in the loop.

@@ -66,6 +66,7 @@ struct cb_bank {
   double *Cq = nullptr;      // S <= 24: counts in quad order [L][nq][TS*TS][64]
   int nq = 0;
   double *dirsum = nullptr;  // [L,S] colsum - rowsum of sum_b C
+  double *dirsum_g = nullptr;  // the same summed over the ranks (cb_allreduce_setup; the trainers' direct pi term)
   // live buckets (C_b != 0), stored first per site; Bl = max over sites = stride of Ct / t_live
   int Bl = 0;
   double *t_live = nullptr;  // [L,Bl]
@@ -568,6 +569,16 @@ extern "C" int cb_allreduce_setup(cb_handle h, void *rccl_comm, void *nccl_allre
   h->n_global.assign(n_total, n_total + h->L);
   h->comm = rccl_comm;
   h->allreduce = reinterpret_cast<int (*)(const void *, void *, size_t, int, int, void *, hipStream_t)>(nccl_allreduce_fn);
+  // the direct (log pi) term of the trainers' parameter gradient needs the job-wide count margins
+  const size_t nd = (size_t)h->L * h->S;
+  if (!h->dirsum_g) {
+    int rc = dev_alloc(h, &h->dirsum_g, nd);
+    if (rc != CB_OK) return rc;
+  }
+  HIP_TRY(hipMemcpyAsync(h->dirsum_g, h->dirsum, nd * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+  if (h->allreduce(h->dirsum_g, h->dirsum_g, nd, 8, 0, h->comm, h->stream) != 0)
+    return fail(CB_EHIP, "cb_allreduce_setup: ncclAllReduce failed");
+  HIP_TRY(hipStreamSynchronize(h->stream));
   return CB_OK;
 }
 
@@ -1284,8 +1295,11 @@ static int run_fused_training_large(cb_bank *h, double *pi_param, double *up_par
   a.m_pi = d_mom; a.v_pi = d_mom + S; a.m_up = d_mom + 2 * (size_t)S; a.v_up = a.m_up + nup;
   a.mask = d_mask; a.lr = lr; a.beta1 = 0.9; a.beta2 = 0.999; a.eps = 1e-8;
   a.pi = d_vec; a.gd = d_vec + LD; a.state = d_vec + LD + S;
-  a.dsq = h->dsq; a.A = h->A; a.G = h->Mt; a.loss = h->loss; a.dirsum = h->dirsum;
-  a.inv_n = (flags & CB_NORMALIZE) ? 1.0 / h->n_host[0] : 1.0;
+  a.dsq = h->dsq; a.A = h->A; a.G = h->Mt; a.loss = h->loss;
+  // sharded job (cb_allreduce_setup): this rank's buckets give partial sums; (loss, dL/dA) are
+  // all-reduced every epoch below, the count margins and the normaliser are the job-wide ones
+  a.dirsum = h->comm ? h->dirsum_g : h->dirsum;
+  a.inv_n = (flags & CB_NORMALIZE) ? 1.0 / (h->comm ? h->n_global[0] : h->n_host[0]) : 1.0;
   a.loss_curve = d_loss; a.Q_last = d_Ql; a.Q_best = d_Qb; a.Q_pow2 = d_Qp;
   if (dbg) fprintf(stderr, "[cherrybank] large trainer: copies enqueued after %.2f ms\n", now() - t_enter);
   TRYH(h2d_staged(h, a.state, init_state, sizeof init_state));
@@ -1302,6 +1316,14 @@ static int run_fused_training_large(cb_bank *h, double *pi_param, double *up_par
     mark(h, EV_START);
     rc = large_eval(h, flags & CB_NORMALIZE, h->loss, h->Mt, true, nullptr);
     if (rc != CB_OK) break;
+    if (h->comm) {  // one all-reduce of LD^2 + 1 doubles per epoch (RCCL, on this stream); identical Adam steps follow
+      int ar = h->allreduce(h->loss, h->loss, 1, 8, 0, h->comm, h->stream);
+      if (ar == 0) ar = h->allreduce(h->Mt, h->Mt, (size_t)LD * LD, 8, 0, h->comm, h->stream);
+      if (ar != 0) {
+        rc = fail(CB_EHIP, "ncclAllReduce failed with code %d", ar);
+        break;
+      }
+    }
     if (h->profile) h->t_pending = true;
     pow_b1 *= a.beta1;
     pow_b2 *= a.beta2;
@@ -1346,6 +1368,9 @@ static int run_fused_training(cb_bank *h, int kind, double *pi_param, double *up
     return run_fused_training_large(h, pi_param, up_param, mask, E, lr, do_adam, flags, loss_curve, Q_best, Q_last,
                                     Q_pow2, n_pow2);
   }
+  if (h->comm)
+    return fail(CB_EUNSUPPORTED, "fused training with cb_allreduce_setup: S > 32 only (a small bank does not shard; "
+                                 "sites are independent)");
   HIP_TRY(hipSetDevice(h->dev));
   const int S = h->S, L = h->L;
   const size_t SS = (size_t)S * S, nup = kind == 0 ? (size_t)S * (S - 1) / 2 : SS;

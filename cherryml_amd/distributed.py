@@ -26,6 +26,51 @@ def bucket_shard(num_buckets: int, rank: int, world: int) -> np.ndarray:
     return np.arange(rank, num_buckets, world)
 
 
+class RcclCommunicator:
+    """A raw RCCL communicator for the in-library all-reduce (`cb_allreduce_setup`): created through
+    ctypes on the librccl that torch itself loaded, one rank per process / GPU; the unique id travels
+    through `torch.distributed` (any backend).  Without an initialised process group it is a
+    single-rank communicator.  `comm` is the ncclComm_t, `allreduce_fn` the address of ncclAllReduce."""
+
+    def __init__(self, group=None):
+        import ctypes as C
+        import glob
+        import os
+        libs = sorted(glob.glob(os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so*")))
+        if not libs:
+            raise RuntimeError("RcclCommunicator: no librccl next to torch")
+        self._rccl = rccl = C.CDLL(libs[0])
+
+        class UniqueId(C.Structure):
+            _fields_ = [("internal", C.c_char * 128)]
+
+        on = dist.is_available() and dist.is_initialized()
+        rank = dist.get_rank(group) if on else 0
+        world = dist.get_world_size(group) if on else 1
+        uid = UniqueId()
+        if rank == 0 and rccl.ncclGetUniqueId(C.byref(uid)) != 0:
+            raise RuntimeError("ncclGetUniqueId failed")
+        if on and world > 1:
+            box = [bytes(uid.internal) if rank == 0 else None]
+            dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+            C.memmove(C.byref(uid), box[0], 128)
+        comm = C.c_void_p()
+        rccl.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, UniqueId, C.c_int]
+        rc = rccl.ncclCommInitRank(C.byref(comm), world, uid, rank)
+        if rc != 0 or not comm.value:
+            raise RuntimeError(f"ncclCommInitRank failed with code {rc}")
+        self.comm = comm.value
+        self.allreduce_fn = C.cast(rccl.ncclAllReduce, C.c_void_p).value
+        self.rank, self.world = rank, world
+
+    def destroy(self):
+        if getattr(self, "comm", None):
+            import ctypes as C
+            self._rccl.ncclCommDestroy.argtypes = [C.c_void_p]
+            self._rccl.ncclCommDestroy(C.c_void_p(self.comm))
+            self.comm = None
+
+
 class _ShardedLoss(torch.autograd.Function):
     @staticmethod
     def forward(ctx, Q, pi, evaluate, inv_n, group):
@@ -130,6 +175,28 @@ class ShardedBank:
         inv_n = 1.0 / self.total_count if normalize else 1.0
         return _ShardedLoss.apply(Q, pi, ev, inv_n, self.group)
 
+    def enable_in_library_allreduce(self):
+        """Hand a raw RCCL communicator to the bank (`cb_allreduce_setup`): from then on the bank's own
+        entry points return job-wide sums, and `train_pande_reversible` runs the WHOLE sharded epoch
+        loop from C -- theta -> A, replicated eigensolve, this rank's buckets, one ncclAllReduce of
+        (loss, dL/dA) on the handle's stream, identical Adam steps -- with no torch in the loop.
+        Collective: every rank of the group must call it."""
+        self.rccl = RcclCommunicator(self.group)
+        self.bank.allreduce_setup(self.rccl.comm, self.rccl.allreduce_fn, [self.total_count])
+        return self
+
+    def train_pande_reversible(self, upper_diag, log_pi, mask=None, num_epochs=2000, lr=0.1, do_adam=True,
+                               normalize=True):
+        """The reference loop (trainer.py:156-218) over the sharded bank, driven from C on every rank
+        (needs `enable_in_library_allreduce()`); every rank returns the same result."""
+        if getattr(self, "rccl", None) is None:
+            raise RuntimeError("ShardedBank.train_pande_reversible: call enable_in_library_allreduce() first")
+        return self.bank.train_pande_reversible(upper_diag, log_pi, mask=mask, num_epochs=num_epochs, lr=lr,
+                                                do_adam=do_adam, normalize=normalize)
+
     def close(self):
         if hasattr(self.bank, "close"):
             self.bank.close()
+        if getattr(self, "rccl", None) is not None:
+            self.rccl.destroy()
+            self.rccl = None

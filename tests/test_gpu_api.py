@@ -498,3 +498,48 @@ def test_in_library_allreduce_with_a_single_rank_rccl_communicator():
     finally:
         rccl.ncclCommDestroy.argtypes = [C.c_void_p]
         rccl.ncclCommDestroy(comm)
+
+
+def test_c_driven_sharded_trainer_with_a_single_rank_communicator():
+    """ShardedBank.enable_in_library_allreduce + train_pande_reversible: the whole sharded epoch loop
+    from C (eigh, own buckets, ncclAllReduce of (loss, dL/dA) on the handle's stream, Adam).  One rank:
+    the sums are the local values, so the run must reproduce the unsharded C-driven loop and the oracle;
+    asymmetric counts make the direct log-pi term (job-wide count margins) non-zero."""
+    from cherryml_amd import CherryBank
+    from cherryml_amd.distributed import ShardedBank
+    from oracle import ratelearn_oracle as orc
+    rng = np.random.default_rng(11)
+    S, B, E = 50, 7, 12
+    t = np.sort(rng.uniform(0.02, 2.0, size=B))
+    C = rng.poisson(4.0, size=(B, S, S)).astype(np.float64)
+    C[3] = 0.0
+    mask = np.ones((S, S)) - np.eye(S)
+    u0 = rng.normal(0.0, 0.3, size=S * (S - 1) // 2)
+    p0 = rng.normal(0.0, 0.2, size=S)
+    ref = orc.train(t, C, mask, upper_diag=u0, log_pi=p0, num_epochs=E, dtype=torch.float64)
+    with CherryBank(t, C) as bank:
+        plain = bank.train_pande_reversible(u0, p0, mask=mask, num_epochs=E, lr=0.1)
+    torch.cuda.set_device(0)
+    sharded = ShardedBank.from_rank_counts(t, torch.tensor(C, device="cuda:0"))
+    try:
+        with pytest.raises(RuntimeError):
+            sharded.train_pande_reversible(u0, p0, mask=mask, num_epochs=1)
+        sharded.enable_in_library_allreduce()
+        assert sharded.rccl.world == 1
+        r = sharded.train_pande_reversible(u0, p0, mask=mask, num_epochs=E, lr=0.1)
+    finally:
+        sharded.close()
+    assert np.allclose(r["loss"], ref["loss"], rtol=1e-9, atol=0)
+    assert np.allclose(r["loss"], plain["loss"], rtol=1e-12, atol=0)
+    assert relerr(r["Q_best"], ref["Q_best"]) < 1e-6
+    assert relerr(r["Q_best"], plain["Q_best"]) < 1e-9
+    # a small bank does not shard: the fused small-state trainers refuse a handle with a communicator
+    g = load_golden("traj_lgbank.npz")
+    sh = ShardedBank.from_rank_counts(g["t"], torch.tensor(g["C"], device="cuda:0"))
+    try:
+        sh.enable_in_library_allreduce()
+        S2 = g["C"].shape[-1]
+        with pytest.raises(Exception):
+            sh.train_pande_reversible(np.zeros(S2 * (S2 - 1) // 2), np.zeros(S2), num_epochs=2)
+    finally:
+        sh.close()
