@@ -14,6 +14,7 @@ partial dL/dQ of its own buckets, and ONE all-reduce (RCCL over xGMI with the
 them (option 1).  The parameters and the optimiser are
 replicated: identical inputs -> identical Adam steps, no broadcast needed.
 Counts (C) never cross GPUs during the epochs."""
+import ctypes
 from typing import Callable, Optional
 
 import numpy as np
@@ -24,6 +25,23 @@ import torch.distributed as dist
 def bucket_shard(num_buckets: int, rank: int, world: int) -> np.ndarray:
     """Indices of the buckets owned by `rank`."""
     return np.arange(rank, num_buckets, world)
+
+
+class _NcclUniqueId(ctypes.Structure):
+    _fields_ = [("internal", ctypes.c_char * 128)]
+
+
+def _uid_to_bytes(uid: "_NcclUniqueId") -> bytes:
+    """All 128 bytes (attribute access on a c_char array stops at the first NUL)."""
+    return ctypes.string_at(ctypes.byref(uid), ctypes.sizeof(uid))
+
+
+def _uid_from_bytes(raw: bytes) -> "_NcclUniqueId":
+    if len(raw) != ctypes.sizeof(_NcclUniqueId):
+        raise ValueError("ncclUniqueId must be 128 bytes")
+    uid = _NcclUniqueId()
+    ctypes.memmove(ctypes.byref(uid), raw, len(raw))
+    return uid
 
 
 class RcclCommunicator:
@@ -40,10 +58,7 @@ class RcclCommunicator:
         if not libs:
             raise RuntimeError("RcclCommunicator: no librccl next to torch")
         self._rccl = rccl = C.CDLL(libs[0])
-
-        class UniqueId(C.Structure):
-            _fields_ = [("internal", C.c_char * 128)]
-
+        UniqueId = _NcclUniqueId
         on = dist.is_available() and dist.is_initialized()
         rank = dist.get_rank(group) if on else 0
         world = dist.get_world_size(group) if on else 1
@@ -51,9 +66,9 @@ class RcclCommunicator:
         if rank == 0 and rccl.ncclGetUniqueId(C.byref(uid)) != 0:
             raise RuntimeError("ncclGetUniqueId failed")
         if on and world > 1:
-            box = [bytes(uid.internal) if rank == 0 else None]
+            box = [_uid_to_bytes(uid) if rank == 0 else None]
             dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
-            C.memmove(C.byref(uid), box[0], 128)
+            uid = _uid_from_bytes(box[0])
         comm = C.c_void_p()
         rccl.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, UniqueId, C.c_int]
         rc = rccl.ncclCommInitRank(C.byref(comm), world, uid, rank)

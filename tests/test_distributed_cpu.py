@@ -3,6 +3,8 @@ The local evaluator is an oracle-backed stand-in with the CherryBank interface
 (tests may use the oracle as the checker); what is under test is the sharding,
 the all-reduce and the autograd plumbing."""
 import os
+
+import pytest
 import socket
 
 import numpy as np
@@ -129,3 +131,15 @@ def test_bucket_shard_partition():
         parts = [bucket_shard(129, r, world) for r in range(world)]
         assert sorted(np.concatenate(parts)) == list(range(129))
         assert max(len(p) for p in parts) - min(len(p) for p in parts) <= 1
+
+
+def test_nccl_unique_id_travels_whole():
+    """The id handed to the other ranks must be all 128 bytes, NULs included."""
+    from cherryml_amd.distributed import _NcclUniqueId, _uid_from_bytes, _uid_to_bytes
+    raw = bytes([7, 0, 0, 9] + [0] * 60 + list(range(64)))
+    uid = _uid_from_bytes(raw)
+    assert _uid_to_bytes(uid) == raw and len(raw) == 128
+    assert bytes(uid.internal) != raw          # the tempting spelling truncates at the first NUL
+    with pytest.raises(ValueError):
+        _uid_from_bytes(raw[:100])
+    assert isinstance(uid, _NcclUniqueId)
