@@ -228,8 +228,15 @@ int cb_count_co_transitions(int device, int S, int B, const double *grid, const 
  * call, no other traffic.  `rccl_comm` is an ncclComm_t; `nccl_allreduce_fn` is the address of
  * ncclAllReduce of the RCCL that created it (C/C++: (void *)&ncclAllReduce; Python:
  * ctypes.cast(librccl.ncclAllReduce, c_void_p)), so the library has no link-time dependency on RCCL.
- * rccl_comm == NULL switches the reduction off again.  torch.distributed users do not need this
- * (cherryml_amd/distributed.py all-reduces with torch); it is the hook for non-Python hosts. */
+ * rccl_comm == NULL switches the reduction off again.
+ * cb_train_pande_reversible on such a handle (S > 32) runs the WHOLE sharded epoch loop from C: the
+ * eigensolve is replicated, this rank's buckets give partial (loss, dL/dA), two ncclAllReduce calls per
+ * epoch (1 and LD*LD doubles) sum them on the handle's stream, and every rank takes the identical Adam
+ * step; the call itself is collective (it all-reduces the count margins of the direct log-pi term once)
+ * and so is every later training call.  The fused small-state trainers (S <= 32) refuse such a handle
+ * (CB_EUNSUPPORTED): a small bank does not shard, sites are independent.
+ * Python: ShardedBank.enable_in_library_allreduce() (cherryml_amd/distributed.py) creates the
+ * communicator through ctypes; torch.distributed's own collective is the fallback. */
 int cb_allreduce_setup(cb_handle h, void *rccl_comm, void *nccl_allreduce_fn, const double *n_total);
 
 /* ---- SiteRM count / pseudocount assembly of ONE family ----------------------------
