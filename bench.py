@@ -341,6 +341,7 @@ def main():
             dist.all_reduce(tdt, op=dist.ReduceOp.MAX)
             dt = float(tdt.item())
         if rank != 0:
+            bank.close()   # every rank releases its handle (and its RCCL communicator)
             return None
         traffic = _pmc_traffic()
         if S > 32:
