@@ -111,7 +111,21 @@ struct cb_bank {
   double t_sum[CB_T_COUNT] = {};
   int t_calls = 0;
   bool t_pending = false;  // last profiled call not yet folded into t_sum
+  // second event set: the C-driven trainer alternates between the two, so that folding an epoch's
+  // phase times never waits for the epoch just enqueued (that wait starved the queue: ~30 us of
+  // launch gaps at the start of every profiled epoch)
+  hipEvent_t ev2[CB_T_COUNT + 1] = {};
+  bool ev_rec2[CB_T_COUNT + 1] = {};
+  bool t_pending2 = false;
 };
+
+static void swap_event_sets(cb_bank *h) {
+  for (int i = 0; i <= CB_T_COUNT; ++i) {
+    std::swap(h->ev[i], h->ev2[i]);
+    std::swap(h->ev_rec[i], h->ev_rec2[i]);
+  }
+  std::swap(h->t_pending, h->t_pending2);
+}
 
 static void fold_pending(cb_bank *h);
 // event i marks the END of phase i-1 .. see mark()
@@ -532,6 +546,8 @@ extern "C" void cb_destroy(cb_handle h) {
   (void)hipSetDevice(h->dev);
   if (h->own_stream) (void)hipStreamSynchronize(h->own_stream);
   for (hipEvent_t e : h->ev)
+    if (e) (void)hipEventDestroy(e);
+  for (hipEvent_t e : h->ev2)
     if (e) (void)hipEventDestroy(e);
   for (void *p : h->allocs) (void)hipFree(p);
   for (double *p : h->ws_ptr)
@@ -1309,7 +1325,10 @@ static int run_fused_training_large(cb_bank *h, double *pi_param, double *up_par
   if (dbg) fprintf(stderr, "[cherrybank] large trainer: parameters uploaded after %.2f ms\n", now() - t_enter);
   double pow_b1 = 1.0, pow_b2 = 1.0;
   for (int e = 0; e < E && rc == CB_OK; ++e) {
-    if (h->profile) fold_pending(h);  // the previous epoch's phase events, before they are re-recorded
+    if (h->profile) {  // fold the epoch before the previous one (its events are long complete), then re-record that set
+      swap_event_sets(h);
+      fold_pending(h);
+    }
     for (bool &b : h->ev_rec) b = false;
     hipLaunchKernelGGL(lt_pi, dim3(1), dim3(256), 0, h->stream, a);
     hipLaunchKernelGGL(lt_build, dim3(LD), dim3(256), 0, h->stream, a, e);
@@ -1333,6 +1352,11 @@ static int run_fused_training_large(cb_bank *h, double *pi_param, double *up_par
     if (hipGetLastError() != hipSuccess) rc = fail(CB_EHIP, "fused training launch failed");
   }
   TRYH(hipStreamSynchronize(h->stream));
+  if (h->profile) {  // the older of the two event sets; the newest stays pending (cb_last_timings reads it)
+    swap_event_sets(h);
+    fold_pending(h);
+    swap_event_sets(h);
+  }
   h->pin_off = 0;  // uploads are consumed
   char *s_pi = nullptr, *s_up = nullptr, *s_loss = nullptr, *s_Qb = nullptr, *s_Ql = nullptr, *s_Qp = nullptr;
   TRYH(d2h_staged(h, d_pi, S * sizeof(double), &s_pi));
@@ -1594,6 +1618,7 @@ extern "C" int cb_profile(cb_handle h, int enable) {
   for (double &x : h->t_sum) x = 0.0;
   h->t_calls = 0;
   h->t_pending = false;
+  h->t_pending2 = false;
   return CB_OK;
 }
 

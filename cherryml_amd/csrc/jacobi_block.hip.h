@@ -291,23 +291,34 @@ __global__ __launch_bounds__(256) void lgx_build(int LD, const double *Gam, cons
   double mc2 = 0.0, rs = 0.0, rsf = 0.0;
   if (i < LD) {
     const double gii = dg[i];   // diagonal of Gam, written by the Gram product's epilogue
-    for (int j = lane; j < LD; j += 64) {
-      double x = 0.0;
-      if (j != i) {
-        const double g = Gam[(size_t)i * LD + j], gjj = dg[j];
-        const double g2 = g * g, ab = gii * gjj;
-        if (g2 > ab * (CB_JAC_SKIP * CB_JAC_SKIP)) {
-          mc2 = fmax(mc2, g2 / ab);
-          const double d = gjj - gii;
-          x = d != 0.0 ? g / d : (g > 0.0 ? 1.0 : -1.0);  // exactly degenerate and coupled: refuse (huge row sum)
+    const int bi = i / JB_W;
+    for (int j0 = lane; j0 < LD; j0 += 256) {   // four column chunks in flight
+      double g[4], gj[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int j = min(j0 + 64 * u, LD - 1);
+        g[u] = Gam[(size_t)i * LD + j];
+        gj[u] = dg[j];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int j = j0 + 64 * u;
+        if (j >= LD) continue;
+        double x = 0.0;
+        const double g2 = g[u] * g[u], ab = gii * gj[u];
+        if (j != i && g2 > ab * (CB_JAC_SKIP * CB_JAC_SKIP)) {
+          mc2 = fmax(mc2, g2 * fast_rcp(ab));
+          const double d = gj[u] - gii;
+          // (fast_rcp is odd in its argument, so X stays exactly antisymmetric)
+          x = d != 0.0 ? g[u] * fast_rcp(d) : (g[u] > 0.0 ? 1.0 : -1.0);  // exactly degenerate and coupled: refuse (huge row sum)
           rs += fabs(x);
         }
+        X[(size_t)i * LD + j] = x;
+        const int bd = bi - j / JB_W;
+        const bool far = bd > band || -bd > band;
+        Xf[(size_t)i * LD + j] = far ? x : 0.0;
+        rsf += far ? fabs(x) : 0.0;
       }
-      X[(size_t)i * LD + j] = x;
-      const int bd = i / JB_W - j / JB_W;
-      const bool far = bd > band || -bd > band;
-      Xf[(size_t)i * LD + j] = far ? x : 0.0;
-      rsf += far ? fabs(x) : 0.0;
     }
   }
   mc2 = wave_max(mc2);
