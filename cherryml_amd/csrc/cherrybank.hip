@@ -994,7 +994,7 @@ static int large_eval(cb_bank *h, bool normalize, double *lossd, double *out, bo
     hipLaunchKernelGGL(k3_w_phi, dim3((h->sym_counts ? tiles_k1 : tiles) * B), dim3(LG_THREADS), 0, h->stream, k3);
     mark(h, EV_K3);
     hipLaunchKernelGGL(k3_reduce, dim3((unsigned)((LL + 255) / 256)), dim3(256), 0, h->stream,
-                       h->Gt, B, LL, h->Mt);
+                       h->Gt, B, LL, h->Mt, h->sym_counts ? LD : 0);
     K4Args k4a{S, LD, h->Mt, h->Vc, h->X, nullptr, nullptr, nullptr};
     launch_sg(h, k4a, 0);
     K4Args k4b{S, LD, h->Vc, h->X, dQd, dA_padded ? nullptr : h->dsq, nullptr, nullptr};
