@@ -4,7 +4,7 @@ from . import caching, counting, io  # noqa: F401
 from .counting import count_co_transitions, count_transitions  # noqa: F401
 from .estimation_end_to_end import (coevolution_end_to_end_with_cherryml_optimizer,  # noqa: F401
                                     lg_end_to_end_with_cherryml_optimizer)
-from ._siterm import quantized_transitions_mle_vectorized_over_sites  # noqa: F401
+from ._siterm import learn_site_specific_rate_matrices, quantized_transitions_mle_vectorized_over_sites  # noqa: F401
 from .bank import CherryBank  # noqa: F401
 from .estimation import (RateMatrix, RateMatrixLearner, jtt_ipw, quantized_transitions_mle,  # noqa: F401
                          train_quantization)
@@ -12,6 +12,7 @@ from .estimation import (RateMatrix, RateMatrixLearner, jtt_ipw, quantized_trans
 __all__ = [
     "CherryBank", "RateMatrix", "RateMatrixLearner", "train_quantization",
     "quantized_transitions_mle", "quantized_transitions_mle_vectorized_over_sites", "jtt_ipw",
+    "learn_site_specific_rate_matrices",
     "io", "caching", "counting", "count_transitions", "count_co_transitions",
     "lg_end_to_end_with_cherryml_optimizer", "coevolution_end_to_end_with_cherryml_optimizer",
 ]

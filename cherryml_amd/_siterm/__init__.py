@@ -7,3 +7,9 @@ from ._assembly import (  # noqa: F401
     get_raw_count_matrices,
 )
 from ._site_rates import compute_optimal_site_rates  # noqa: F401
+from ._learn import (  # noqa: F401
+    get_standard_site_rate_grid,
+    get_standard_site_rate_prior,
+    learn_site_rate_matrices,
+    learn_site_specific_rate_matrices,
+)

@@ -10,4 +10,4 @@ from ._formats import (  # noqa: F401
     write_probability_distribution,
     write_rate_matrix,
 )
-from ._tree import Tree, read_tree, write_tree  # noqa: F401,E402
+from ._tree import Tree, convert_newick_to_CherryML_Tree, read_tree, write_tree  # noqa: F401,E402

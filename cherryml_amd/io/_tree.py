@@ -129,3 +129,93 @@ def write_tree(tree: Tree, tree_path: str, scaling_factor: float = 1.0, node_nam
     out += [f"{node_name_prefix}{u} {node_name_prefix}{v} {length * scaling_factor}\n" for u, v, length in tree.edges()]
     with open(tree_path, "w") as f:
         f.write("".join(out))
+
+
+def convert_newick_to_CherryML_Tree(tree_newick: str) -> Tree:
+    """Newick string -> Tree, as the reference's helper of the same name (io/_tree.py:313-320, which goes
+    through ete3 with its default format 0): labels after a closing parenthesis are support values, not
+    names, so every internal node is named `internal-<k>` in pre-order (the root is `internal-1`);
+    a missing branch length is 1.0; children keep the order of the string (cherry++ pairing depends
+    on it).  Own parser: ete3 is not a dependency here."""
+    s = tree_newick.strip()
+    pos = 0
+
+    def skip_ws():
+        nonlocal pos
+        while pos < len(s) and (s[pos].isspace() or s[pos] == "["):
+            if s[pos] == "[":
+                end = s.find("]", pos)
+                if end < 0:
+                    raise ValueError("newick: unterminated comment")
+                pos = end + 1
+            else:
+                pos += 1
+
+    def label() -> str:
+        nonlocal pos
+        skip_ws()
+        if pos < len(s) and s[pos] in "'\"":
+            q = s[pos]
+            end = s.find(q, pos + 1)
+            if end < 0:
+                raise ValueError("newick: unterminated quoted label")
+            out = s[pos + 1:end]
+            pos = end + 1
+            return out
+        start = pos
+        while pos < len(s) and s[pos] not in "():,;[" and not s[pos].isspace():
+            pos += 1
+        return s[start:pos]
+
+    def node():
+        """returns (name, length, children)"""
+        nonlocal pos
+        skip_ws()
+        children = []
+        if pos < len(s) and s[pos] == "(":
+            pos += 1
+            while True:
+                children.append(node())
+                skip_ws()
+                if pos >= len(s):
+                    raise ValueError("newick: unbalanced parentheses")
+                if s[pos] == ",":
+                    pos += 1
+                    continue
+                if s[pos] == ")":
+                    pos += 1
+                    break
+                raise ValueError(f"newick: unexpected {s[pos]!r} at {pos}")
+        name = label()
+        if children:
+            name = ""              # ete3 format 0: an internal label is a support value
+        length = None
+        skip_ws()
+        if pos < len(s) and s[pos] == ":":
+            pos += 1
+            skip_ws()
+            length = float(label())
+        return name, length, children
+
+    root = node()
+    skip_ws()
+    if pos < len(s) and s[pos] == ";":
+        pos += 1
+    skip_ws()
+    if pos != len(s):
+        raise ValueError(f"newick: trailing characters at {pos}")
+    tree = Tree()
+    counter = [0]
+    # pre-order, iteratively: name, add node, add edge from the parent, then the children in order
+    stack = [(None, root)]
+    while stack:
+        parent, (name, length, children) = stack.pop()
+        if name == "":
+            counter[0] += 1
+            name = f"internal-{counter[0]}"
+        tree.add_node(name)
+        if parent is not None:
+            tree.add_edge(parent, name, 1.0 if length is None else length)
+        for child in reversed(children):
+            stack.append((name, child))
+    return tree

@@ -1,0 +1,80 @@
+"""SiteRM callers (`learn_site_rate_matrices`, `learn_site_specific_rate_matrices`) on the GPU against
+vectors produced by the reference itself (tests/golden/make_golden_siterm_learn.py), including the known
+answer typed into the reference's own public-API test (site rate 0.6231236)."""
+import numpy as np
+import pytest
+
+from conftest import load_golden, relerr
+
+pytestmark = pytest.mark.gpu
+
+
+def _tree(g, case):
+    from cherryml_amd.io import Tree
+    t = Tree()
+    nodes = []
+    for u, v in zip(g[f"{case}_edges_u"], g[f"{case}_edges_v"]):
+        for x in (str(u), str(v)):
+            if x not in nodes:
+                nodes.append(x)
+    t.add_nodes(nodes)
+    t.add_edges([(str(u), str(v), float(w)) for u, v, w in
+                 zip(g[f"{case}_edges_u"], g[f"{case}_edges_v"], g[f"{case}_edges_t"])])
+    return t
+
+
+def _msa(g, case):
+    return {str(n): str(s) for n, s in zip(g[f"{case}_msa_names"], g[f"{case}_msa_seqs"])}
+
+
+@pytest.mark.parametrize("case", ["pub", "rand"])
+def test_learn_site_rate_matrices_matches_reference(case):
+    import pandas as pd
+    from cherryml_amd._siterm import learn_site_rate_matrices
+    g = load_golden("siterm_learn.npz")
+    alphabet = [str(a) for a in g[f"{case}_alphabet"]]
+    sr_alphabet = [str(a) for a in g[f"{case}_sr_alphabet"]]
+    Q0 = pd.DataFrame(g[f"{case}_Q0"], index=alphabet, columns=alphabet)
+    srQ = pd.DataFrame(g[f"{case}_sr_Q"], index=sr_alphabet, columns=sr_alphabet)
+    r = learn_site_rate_matrices(
+        tree=_tree(g, case), leaf_states=_msa(g, case), alphabet=alphabet, regularization_rate_matrix=Q0,
+        regularization_strength=float(g[f"{case}_lambda"]), use_vectorized_implementation=True,
+        vectorized_implementation_device="cuda", site_rate_grid=list(g[f"{case}_grid"]),
+        site_rate_prior=list(g[f"{case}_prior"]), alphabet_for_site_rate_estimation=sr_alphabet,
+        rate_matrix_for_site_rate_estimation=srQ, num_epochs=int(g[f"{case}_epochs"]),
+        quantization_grid_num_steps=int(g[f"{case}_qsteps"]))
+    assert np.array_equal(np.asarray(r["learnt_site_rates"]), g[f"{case}_site_rates"])   # grid values: exact
+    want = g[f"{case}_res"]
+    assert r["learnt_rate_matrices"].shape == want.shape
+    for l in range(want.shape[0]):
+        assert relerr(r["learnt_rate_matrices"][l], want[l]) < 1e-6, l
+    assert r["learnt_tree"] is not None and "time_estimate_site_rate" in r and "time_optimization" in r
+
+
+def test_public_api_known_answer_and_errors():
+    """The reference's own test of the public entry point (_siterm_public_api.py:175-209)."""
+    import pandas as pd
+    import cherryml_amd
+    from cherryml_amd.io import convert_newick_to_CherryML_Tree
+    dna = ["A", "C", "G", "T"]
+    Q = pd.DataFrame([[-3.0, 1.0, 1.0, 1.0], [1.0, -3.0, 1.0, 1.0], [1.0, 1.0, -3.0, 1.0], [1.0, 1.0, 1.0, -3.0]],
+                     index=dna, columns=dna) / 3.0
+    tree = convert_newick_to_CherryML_Tree("(((leaf_1:1.0,leaf_2:1.0):1.0):1.0,((leaf_3:1.0,leaf_4:1.0):1.0):1.0);")
+    msa = {"leaf_1": "C", "leaf_2": "C", "leaf_3": "C", "leaf_4": "G"}
+    r = cherryml_amd.learn_site_specific_rate_matrices(tree=tree, msa=msa, alphabet=dna,
+                                                      regularization_rate_matrix=Q, regularization_strength=0.5)
+    np.testing.assert_almost_equal(r["learnt_site_rates"], [0.6231236])
+    np.testing.assert_array_almost_equal(
+        r["learnt_rate_matrices"][0],
+        np.array([[-0.48, 0.03, 0.24, 0.21], [0.01, -0.62, 0.6, 0.01], [0.12, 1.22, -1.47, 0.12],
+                  [0.21, 0.03, 0.24, -0.48]]), decimal=1)
+    g = load_golden("siterm_learn.npz")
+    assert relerr(r["learnt_rate_matrices"][0], g["pub_res"][0]) < 1e-6
+    with pytest.raises(NotImplementedError):
+        cherryml_amd.learn_site_specific_rate_matrices(tree=None, msa=msa, alphabet=dna, regularization_rate_matrix=Q)
+    with pytest.raises(NotImplementedError):
+        cherryml_amd.learn_site_specific_rate_matrices(tree=tree, msa=msa, alphabet=dna,
+                                                      regularization_rate_matrix=Q, device="cpu")
+    with pytest.raises(ValueError):
+        cherryml_amd.learn_site_specific_rate_matrices(tree=tree, msa=msa, alphabet=dna,
+                                                      regularization_rate_matrix=Q, just_run_fast_cherries=True)

@@ -185,3 +185,25 @@ def test_jtt_ipw_reference_goldens(tmp_path):
         np.testing.assert_almost_equal(got, g[key], decimal=7)
         np.testing.assert_almost_equal(got, orc.jtt_ipw(
             g["t"], g["C"], g["mask"].astype(float) if mp else None, use_ipw=ipw), decimal=12)
+
+
+def test_newick_conversion_and_standard_site_rate_grid():
+    """convert_newick_to_CherryML_Tree names internal nodes in pre-order like the reference
+    (io/_tree.py:266-320, whose own test expects `internal-2` for the inner node); the standard
+    site-rate grid / prior of the SiteRM public API (_learn_site_rate_matrix.py:933-952)."""
+    from cherryml_amd.io import convert_newick_to_CherryML_Tree
+    from cherryml_amd._siterm import get_standard_site_rate_grid, get_standard_site_rate_prior
+    t = convert_newick_to_CherryML_Tree("((Homo_sapiens:0.00655,Pan_troglodytes:0.00684):0.00422);")
+    assert t.root() == "internal-1"
+    assert t.edges() == [("internal-1", "internal-2", 0.00422), ("internal-2", "Homo_sapiens", 0.00655),
+                         ("internal-2", "Pan_troglodytes", 0.00684)]
+    t = convert_newick_to_CherryML_Tree("((a:1,'b c':2)90:0.5,(d,e)x:3)root;")
+    assert t.leaves() == ["a", "b c", "d", "e"] and t.root() == "internal-1"
+    assert t.children("internal-3") == [("d", 1.0), ("e", 1.0)]      # missing lengths are 1.0 (ete3's default)
+    with pytest.raises(ValueError):
+        convert_newick_to_CherryML_Tree("((a,b);")
+    g = get_standard_site_rate_grid(20)
+    assert len(g) == 20 and abs(g[0] - 0.05) < 1e-15 and abs(g[-1] - 20.0) < 1e-12
+    assert all(g[i] < g[i + 1] for i in range(19))
+    golden = load_golden("siterm_learn.npz")
+    assert np.allclose(g, golden["pub_grid"], rtol=1e-15) and np.allclose(get_standard_site_rate_prior(20), golden["pub_prior"], rtol=1e-13)
