@@ -8,11 +8,11 @@ result keys.  Every numerical step runs on the GPU through libcherrybank:
   count tensors   `cb_siterm_assemble`          (cherry++ transitions, pseudocounts; bit-exact)
   optimiser       `cb_train_siterm`             (all sites, all epochs, one call)
 
-What is NOT here: tree estimation.  `tree=None` asks the reference for FastCherries' divide-and-conquer
-pairing (a seeded C++ program, phylogeny_estimation/FastCherries/pairing_algorithms.cpp); this build has
-FastCherries' likelihood kernels (cherryml_amd/phylogeny_estimation) but not its pairing, so a tree must
-be given (`NotImplementedError` otherwise).  The non-vectorised per-site CPU loop of the reference
-(`use_vectorized_implementation=False`) has no counterpart either: there is no CPU path."""
+`tree=None` runs FastCherries (cherryml_amd/phylogeny_estimation/_fast_cherries.py: the reference's seeded
+divide-and-conquer pairing on the host, branch lengths and site rates on the GPU) exactly as the reference
+does here -- 20 rate categories, 50 iterations, seed 1234, the default 129-point grid, sequences in sorted
+name order -- and takes its site rates.  The non-vectorised per-site CPU loop of the reference
+(`use_vectorized_implementation=False`) has no counterpart: there is no CPU path."""
 import time
 from typing import Dict, List, Optional
 
@@ -119,8 +119,8 @@ def learn_site_rate_matrices(
     just_run_fast_cherries: bool = False,
 ) -> Dict:
     """:1109-1282.  Returns {"learnt_rate_matrices": [L,S,S], "learnt_site_rates": [L], "learnt_tree": tree,
-    "time_*": seconds}.  Differences from the reference, all loud: `tree` is required, the device must be
-    "cuda", and only the vectorised implementation with the fast site-rate estimator exists."""
+    "time_*": seconds}.  Differences from the reference, all loud: the device must be "cuda", and only the
+    vectorised implementation with the fast site-rate estimator exists."""
     if vectorized_implementation_device != "cuda":
         raise NotImplementedError("this build computes on the GPU only: device must be 'cuda'")
     if not use_vectorized_implementation:
@@ -138,18 +138,31 @@ def learn_site_rate_matrices(
     site_rate_grid, site_rate_prior = list(site_rate_grid), list(site_rate_prior)
     prof["time_init_learn_site_rate_matrices"] = time.time() - st
     st = time.time()
+    import torch
+    dev = torch.cuda.current_device()
+    site_rates_fast_cherries = None
     if tree is None:
-        raise NotImplementedError(
-            "tree=None (FastCherries tree estimation) is not built: estimate the tree with the reference's "
-            "FastCherries / FastTree and pass it (cherryml_amd.io.read_tree)")
-    if just_run_fast_cherries:
+        # :1196-1228 (there through temporary files): FastCherries with the site-rate matrix / alphabet
+        from ..phylogeny_estimation._fast_cherries import cherries_to_tree, fast_cherries_family
+        names = sorted(leaf_states.keys())
+        cherries, lengths, rates = fast_cherries_family(
+            names, [leaf_states[n] for n in names], Qsr, sr_states, num_rate_categories=20, max_iters=50,
+            seed=1234, device=dev)
+        tree = cherries_to_tree(names, cherries, lengths)
+        site_rates_fast_cherries = [float(r) for r in rates]
+    elif just_run_fast_cherries:
         raise ValueError("If just_run_fast_cherries is True, then tree must be None.")
     time_estimate_tree = time.time() - st
     st = time.time()
-    import torch
-    dev = torch.cuda.current_device()
-    site_rates = _estimate_site_rates_fast(tree, leaf_states, site_rate_grid, site_rate_prior, Qsr, sr_states, device=dev)
+    if site_rates_fast_cherries is not None:
+        site_rates = site_rates_fast_cherries
+    else:
+        site_rates = _estimate_site_rates_fast(tree, leaf_states, site_rate_grid, site_rate_prior, Qsr, sr_states,
+                                               device=dev)
     time_estimate_site_rate = time.time() - st
+    if just_run_fast_cherries:
+        return {"learnt_rate_matrices": None, "learnt_site_rates": site_rates, "learnt_tree": tree,
+                "time_estimate_tree": time_estimate_tree, "time_estimate_site_rate": time_estimate_site_rate}
     # :650-716 `_learn_site_rate_matrices_given_site_rates_too`: the grid keeps its span, 2n+1 points
     st = time.time()
     step = QUANTIZATION_GRID_STEP ** (QUANTIZATION_GRID_NUM_STEPS / quantization_grid_num_steps)

@@ -1,10 +1,18 @@
-"""FastCherries' branch-length / site-rate estimation on the GPU.  Only the
-likelihood kernels of FastCherries are here (log-transition bank, the two bisection passes, their
-coordinate ascent); its cherry-pairing heuristics and tree writing are not part of this build."""
+"""FastCherries: branch-length / site-rate estimation on the GPU (log-transition bank, the
+two bisection passes, their coordinate ascent) and, around it, the reference's seeded divide-and-conquer
+cherry pairing (host) and tree / site-rate files (`fast_cherries`, `fast_cherries_family`)."""
 from ._ble import (  # noqa: F401
     branch_lengths,
     compute_log_transition_matrices,
     estimate_branch_lengths_and_site_rates,
     rate_priors,
     site_rates,
+)
+from ._fast_cherries import (  # noqa: F401,E402
+    cherries_to_tree,
+    divide_and_pair,
+    fast_cherries,
+    fast_cherries_family,
+    get_weights_for_initial_site_rates,
+    rate_categories_ble,
 )

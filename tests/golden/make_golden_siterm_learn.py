@@ -5,7 +5,7 @@ made by RUNNING THE REFERENCE in the build container (same scratch recipe as mak
 Trees are built through the reference's own Tree API (its newick helper needs ete3, absent here).
 
 Written: tests/golden/siterm_learn.npz with, per case <c>:
-  inputs   <c>_edges_u / _edges_v / _edges_t, <c>_msa_names / _msa_seqs, <c>_alphabet, <c>_Q0, <c>_lambda,
+  inputs   <c>_edges_u / _edges_v / _edges_t (case "fc" = tree=None: the edges of the FastCherries tree, see below), <c>_msa_names / _msa_seqs, <c>_alphabet, <c>_Q0, <c>_lambda,
            <c>_sr_alphabet, <c>_sr_Q, <c>_grid, <c>_prior, <c>_epochs, <c>_qsteps
   outputs  <c>_site_rates (learnt_site_rates), <c>_res (learnt_rate_matrices [L,S,S])
 
@@ -110,6 +110,50 @@ def main():
         msa[leaf] = "".join(chars)
     # (nodes that are internal in `internals` but childless were renamed leaves above; give them sequences)
     record("rand", edges, msa, alpha5, equ(alpha5), 0.3, dna, equ(dna, 1.3), 8, 25, 8)
+    # 3. tree=None: FastCherries estimates the cherries and the site rates (20 categories, seed 1234)
+    n_leaves, L = 21, 40
+    base = rng.integers(0, 4, size=L)
+    msa3 = {}
+    for i in range(n_leaves):
+        seq = base.copy()
+        flip = rng.random(L) < (0.1 + 0.3 * (i % 3))
+        seq[flip] = rng.integers(0, 4, size=int(flip.sum()))
+        chars = np.array(list("ACGT"))[seq]
+        chars[rng.random(L) < 0.05] = "-"
+        msa3[f"t{i:02d}"] = "".join(chars)
+    # The reference's wrapper assembles the star-of-cherries tree with ete3 (absent here), so this case is
+    # glued from the reference's two halves: its C++ PROGRAM (oracle/_ref/libref_fc.so, as in
+    # make_golden_fast_cherries.py; arguments as learn_site_rate_matrices passes them, :1212-1223: 20
+    # categories, 50 iterations, seed 1234, sequences in sorted order as write_msa writes them) and its
+    # `_learn_site_rate_matrices_given_site_rates_too` (:650-716), with the tree rule of
+    # _fast_cherries.py:116-131 restated in between (root -> internal-<i> at 1.0 -> two leaves at d/2 each;
+    # the odd sequence out under the root at 1.0).
+    import ctypes as C
+    from make_golden_fast_cherries import run_program
+    lib = C.CDLL(os.path.join(os.path.dirname(os.path.dirname(HERE)), "oracle", "_ref", "libref_fc.so"))
+    names3 = sorted(msa3)
+    ch, le, ra = run_program(lib, names3, [msa3[n] for n in names3], equ(dna).to_numpy(), dna, 20, 50, 1234)
+    edges3, paired = [], set()
+    for i, ((a, b), d) in enumerate(zip(ch, le)):
+        edges3 += [("root", f"internal-{i}", 1.0), (f"internal-{i}", str(a), float(d) / 2.0),
+                   (f"internal-{i}", str(b), float(d) / 2.0)]
+        paired |= {str(a), str(b)}
+    missing = [n for n in names3 if n not in paired]
+    if len(missing) & 1:
+        edges3.append(("root", missing[-1], 1.0))
+    r3 = M._learn_site_rate_matrices_given_site_rates_too(
+        tree=make_tree(edges3), site_rates=[float(x) for x in ra], leaf_states=msa3, alphabet=alpha5,
+        regularization_rate_matrix=equ(alpha5), regularization_strength=0.5,
+        use_vectorized_cherryml_implementation=True, vectorized_cherryml_implementation_device="cpu",
+        vectorized_cherryml_implementation_num_cores=1, num_epochs=20, quantization_grid_num_steps=16)
+    out["fc_msa_names"] = np.array(names3)
+    out["fc_msa_seqs"] = np.array([msa3[n] for n in names3])
+    out["fc_edges_u"] = np.array([e[0] for e in edges3])
+    out["fc_edges_v"] = np.array([e[1] for e in edges3])
+    out["fc_edges_t"] = np.array([e[2] for e in edges3], dtype=np.float64)
+    out["fc_site_rates"] = np.array(ra, dtype=np.float64)
+    out["fc_res"] = np.array(r3["res"], dtype=np.float64)
+    print("fc", len(ch), "cherries; site rates", np.round(ra[:5], 4), "res", out["fc_res"].shape)
     np.savez_compressed(os.path.join(HERE, "siterm_learn.npz"), **out)
     print("wrote siterm_learn.npz")
 

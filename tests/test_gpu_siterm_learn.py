@@ -71,8 +71,6 @@ def test_public_api_known_answer_and_errors():
     g = load_golden("siterm_learn.npz")
     assert relerr(r["learnt_rate_matrices"][0], g["pub_res"][0]) < 1e-6
     with pytest.raises(NotImplementedError):
-        cherryml_amd.learn_site_specific_rate_matrices(tree=None, msa=msa, alphabet=dna, regularization_rate_matrix=Q)
-    with pytest.raises(NotImplementedError):
         cherryml_amd.learn_site_specific_rate_matrices(tree=tree, msa=msa, alphabet=dna,
                                                       regularization_rate_matrix=Q, device="cpu")
     with pytest.raises(ValueError):
