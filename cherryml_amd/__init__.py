@@ -6,13 +6,14 @@ from .estimation_end_to_end import (coevolution_end_to_end_with_cherryml_optimiz
                                     lg_end_to_end_with_cherryml_optimizer)
 from ._siterm import learn_site_specific_rate_matrices, quantized_transitions_mle_vectorized_over_sites  # noqa: F401
 from .bank import CherryBank  # noqa: F401
+from ._cherryml_public_api import cherryml_public_api  # noqa: F401,E402
 from .estimation import (RateMatrix, RateMatrixLearner, jtt_ipw, quantized_transitions_mle,  # noqa: F401
                          train_quantization)
 
 __all__ = [
     "CherryBank", "RateMatrix", "RateMatrixLearner", "train_quantization",
     "quantized_transitions_mle", "quantized_transitions_mle_vectorized_over_sites", "jtt_ipw",
-    "learn_site_specific_rate_matrices",
+    "learn_site_specific_rate_matrices", "cherryml_public_api",
     "io", "caching", "counting", "count_transitions", "count_co_transitions",
     "lg_end_to_end_with_cherryml_optimizer", "coevolution_end_to_end_with_cherryml_optimizer",
 ]

@@ -311,6 +311,11 @@ def _read_msa_file(path: str) -> Tuple[List[str], List[str]]:
     return names, seqs
 
 
+from ..caching import cached_computation  # noqa: E402
+
+
+@cached_computation(output_dirs=["output_tree_dir", "output_site_rates_dir", "output_likelihood_dir"],
+                    exclude_args=["num_processes", "verbose", "remake"])
 def fast_cherries(msa_dir: str, families: List[str], rate_matrix_path: str, num_rate_categories: int,
                   max_iters: int, num_processes: int = 1, _version="2", output_tree_dir: Optional[str] = None,
                   output_site_rates_dir: Optional[str] = None, output_likelihood_dir: Optional[str] = None,
@@ -319,7 +324,10 @@ def fast_cherries(msa_dir: str, families: List[str], rate_matrix_path: str, num_
     """The reference's stage function (same keywords, same files): per family `<tree_dir>/<family>.txt`
     (CherryML tree format), `<site_rates_dir>/<family>.txt`, `<likelihood_dir>/<family>.txt` ("0.0", as
     the reference) and `<tree_dir>/<family>.profiling`.  `num_processes` / `remake` are accepted and
-    ignored: families run one after the other on the GPU."""
+    ignored: families run one after the other on the GPU.  Keyword arguments only, and with a cache
+    directory set the three output directories default into the cache and the call returns
+    {"output_tree_dir": ..., ...} -- the reference's caching convention, which is how the end-to-end
+    pipelines use it as their `tree_estimator`."""
     from ..io import read_rate_matrix
     if output_tree_dir is None or output_site_rates_dir is None or output_likelihood_dir is None:
         raise ValueError("output_tree_dir, output_site_rates_dir and output_likelihood_dir are required")

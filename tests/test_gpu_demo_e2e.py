@@ -83,3 +83,50 @@ def test_coevolution_pipeline_on_demo_data(tmp_path):
     print(f"co-evolution demo_data: to the f64 reference {relerr(learned, z['co_Q_best_f64']):.2e}, "
           f"to the reference's float32 result {d32:.2e}")
     assert d32 < 1e-3
+
+
+def test_public_api_lg_with_given_trees_and_with_fast_cherries(tmp_path):
+    """`cherryml_public_api` (what `python -m cherryml` calls).  With the demo trees handed over it is the
+    LG pipeline above (same golden, same tolerance).  With `tree_estimator_name="FastCherries"` and two
+    iterations every stage runs on this package's own code (pairing, branch lengths / site rates,
+    counting, JTT-IPW, optimiser; the second iteration re-estimates the trees under the matrix learned
+    in the first): no reference run exists for that chain (its wrapper needs ete3 and FastTree), so the
+    checks are structural -- a valid reversible rate matrix close to LG-like behaviour, the cache
+    holding one tree / count / rate-matrix directory per iteration."""
+    import cherryml_amd
+    from cherryml_amd._cherryml_public_api import cherryml_public_api
+    from cherryml_amd.io import read_rate_matrix, write_rate_matrix
+    z = load_golden("demo_e2e.npz")
+    dirs, fams = _materialise(tmp_path, z)
+    out1 = str(tmp_path / "learned_given_trees.txt")
+    prof = cherryml_public_api(output_path=out1, model_name="LG", msa_dir=dirs["msa"], tree_dir=dirs["tree"],
+                               site_rates_dir=dirs["site_rates"], cache_dir=str(tmp_path / "cache1"),
+                               num_epochs=int(z["lg_epochs"]), families=fams, tree_estimator_name="FastTree")
+    assert "time_optimization" in prof
+    assert relerr(read_rate_matrix(out1).to_numpy(), z["lg_Q_best_f64"]) < 1e-6
+    with pytest.raises(NotImplementedError):      # FastTree itself is an external program: not built
+        cherryml_public_api(output_path=out1, model_name="LG", msa_dir=dirs["msa"], cache_dir=str(tmp_path / "c"),
+                            initial_tree_estimator_rate_matrix_path=out1, families=fams, tree_estimator_name="FastTree")
+    with pytest.raises(ValueError):
+        cherryml_public_api(output_path=out1, model_name="WAG", msa_dir=dirs["msa"])
+    with pytest.raises(ValueError):
+        cherryml_public_api(output_path=out1, model_name="co-evolution", msa_dir=dirs["msa"], num_iterations=2,
+                            tree_dir=dirs["tree"], contact_map_dir=dirs["contact_map"], families=fams)
+    # FastCherries, two iterations, starting from the matrix learned above
+    out2 = str(tmp_path / "learned_fast_cherries.txt")
+    cache2 = tmp_path / "cache2"
+    cherryml_public_api(output_path=out2, model_name="LG", msa_dir=dirs["msa"], cache_dir=str(cache2),
+                        initial_tree_estimator_rate_matrix_path=out1, num_iterations=2, num_epochs=40,
+                        families=fams, tree_estimator_name="FastCherries", num_rate_categories=4)
+    Q = read_rate_matrix(out2).to_numpy()
+    assert Q.shape == (20, 20) and np.all(np.isfinite(Q)) and np.allclose(Q.sum(1), 0.0, atol=1e-9)
+    assert np.all(Q - np.diag(np.diag(Q)) >= 0.0) and np.all(np.diag(Q) < 0.0)
+    w, v = np.linalg.eig(Q.T)
+    pi = np.real(v[:, np.argmin(np.abs(w))])
+    pi /= pi.sum()
+    flux = pi[:, None] * Q
+    assert np.all(pi > 0) and np.allclose(flux, flux.T, atol=1e-9)           # reversible
+    assert len(os.listdir(cache2 / "fast_cherries")) == 2                    # one tree estimation per iteration
+    for fam in fams:
+        tdirs = [cache2 / "fast_cherries" / h / "output_tree_dir" for h in os.listdir(cache2 / "fast_cherries")]
+        assert all((d / f"{fam}.txt").exists() and (d / "result.success").exists() for d in tdirs)
