@@ -543,3 +543,33 @@ def test_c_driven_sharded_trainer_with_a_single_rank_communicator():
             sh.train_pande_reversible(np.zeros(S2 * (S2 - 1) // 2), np.zeros(S2), num_epochs=2)
     finally:
         sh.close()
+
+
+def test_hybrid_and_tournament_eigensolvers_agree_on_a_degenerate_spectrum(monkeypatch):
+    """Warm-started solves of the C-driven trainer: the hybrid sweeps (far pairs by one GEMM-based
+    rotation, near pairs by banded Jacobi passes) against the full tournament sweeps they replaced
+    (CB_NO_HYBRID=1), started from an exact product model Q (x) I + I (x) Q -- its spectrum
+    lambda_i + lambda_j has exactly degenerate pairs, the case in which the first-order formula divides
+    by zero and the band has to take over."""
+    import bench
+    from cherryml_amd import CherryBank, RateMatrix
+    rng = np.random.default_rng(0)
+    wl = bench.make_workload("coevo400", 0, rng)
+    lg = bench.lg_matrix()
+    pi1 = bench.stationary(lg)
+    Q0 = np.kron(lg, np.eye(20)) + np.kron(np.eye(20), lg)
+    mod = RateMatrix(num_states=400, mode="pande_reversible", mask=torch.tensor(wl["mask"]),
+                     pi=torch.tensor(np.kron(pi1, pi1)), pi_requires_grad=True, initialization=Q0)
+    u0, p0 = mod.upper_diag.detach().numpy().copy(), mod._pi.detach().numpy().copy()
+    runs = {}
+    for name, env in (("hybrid", None), ("tournament", "1")):
+        if env is None:
+            monkeypatch.delenv("CB_NO_HYBRID", raising=False)
+        else:
+            monkeypatch.setenv("CB_NO_HYBRID", env)
+        with CherryBank(wl["t"][::4], wl["C"][::4]) as bank:
+            runs[name] = bank.train_pande_reversible(u0, p0, mask=wl["mask"], num_epochs=8, lr=0.1)
+    a, b = runs["hybrid"], runs["tournament"]
+    assert np.all(np.isfinite(a["loss"])) and a["loss"][-1] < a["loss"][0]
+    assert np.allclose(a["loss"], b["loss"], rtol=1e-11, atol=0)
+    assert relerr(a["Q_last"], b["Q_last"]) < 1e-8 and relerr(a["Q_best"], b["Q_best"]) < 1e-8
