@@ -36,10 +36,13 @@ struct GemmOperands {
 
 // Loads one K-step (16 rows) of an 80-wide panel into registers:
 // 16 rows x 40 16-byte chunks = 640 chunks, 2 per thread.
+// SCALE is a template parameter and `sc` a reference to a register array: a `double *sc` that may be
+// null made the compiler keep the two scales in SCRATCH memory (a store and a load per K-step on the
+// critical path of K1's prefetch; 0.415 -> see DESIGN for the time after the change).
+template <bool SCALE>
 __device__ __forceinline__ void lg_load_panel(const double *__restrict__ P, int ld, int rows_total,
                                               int cols_total, int k0, int c0, double2 (&reg)[2],
-                                              const double *__restrict__ kscale = nullptr,
-                                              double *sc = nullptr) {
+                                              const double *__restrict__ kscale, double (&sc)[2]) {
 #pragma unroll
   for (int u = 0; u < 2; ++u) {
     const int chunk = threadIdx.x + u * LG_THREADS;  // 0..639
@@ -51,18 +54,18 @@ __device__ __forceinline__ void lg_load_panel(const double *__restrict__ P, int 
       reg[u] = double2{0.0, 0.0};
     // the row scale travels with the panel (fetching it at LDS-store time exposed a
     // global-load latency in every K-step)
-    if (kscale) sc[u] = (k < rows_total) ? kscale[k] : 0.0;
+    if (SCALE) sc[u] = (k < rows_total) ? kscale[k] : 0.0;
   }
 }
 
-__device__ __forceinline__ void lg_store_panel(double *s, const double2 (&reg)[2],
-                                               const double *sc /* null: unscaled */) {
+template <bool SCALE>
+__device__ __forceinline__ void lg_store_panel(double *s, const double2 (&reg)[2], const double (&sc)[2]) {
 #pragma unroll
   for (int u = 0; u < 2; ++u) {
     const int chunk = threadIdx.x + u * LG_THREADS;
     const int kr = chunk / 40, cc = (chunk - kr * 40) * 2;
     double2 v = reg[u];
-    if (sc) {
+    if (SCALE) {
       v.x *= sc[u];
       v.y *= sc[u];
     }
@@ -73,6 +76,7 @@ __device__ __forceinline__ void lg_store_panel(double *s, const double2 (&reg)[2
 // acc[j] (j = 0..4): tile rows m0 + 16*wave + (l>>4) + 4r, cols n0 + 16*j + (l&15)
 // sA / sB hold TWO K-steps each (double buffer): one barrier per K-step; the
 // global loads of step k+1 are in flight during the MFMAs of step k.
+template <bool SCALE = false>
 __device__ __forceinline__ void lg_gemm_tile(const GemmOperands &g, int m0, int n0, double *sA,
                                              double *sB, d4 (&acc)[5]) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -80,20 +84,19 @@ __device__ __forceinline__ void lg_gemm_tile(const GemmOperands &g, int m0, int 
 #pragma unroll
   for (int j = 0; j < 5; ++j) acc[j] = d4{0.0, 0.0, 0.0, 0.0};
   double2 ra[2], rb[2];
-  double sc[2];
-  double *scp = g.kscale ? sc : nullptr;
+  double sc[2] = {1.0, 1.0}, one[2] = {1.0, 1.0};
   const int nk = g.K / LG_KT;
-  lg_load_panel(g.A, g.lda, g.K, g.M, 0, m0, ra, g.kscale, sc);
-  lg_load_panel(g.B, g.ldb, g.K, g.N, 0, n0, rb);
+  lg_load_panel<SCALE>(g.A, g.lda, g.K, g.M, 0, m0, ra, g.kscale, sc);
+  lg_load_panel<false>(g.B, g.ldb, g.K, g.N, 0, n0, rb, nullptr, one);
   __syncthreads();  // the previous tile's readers of buffer 0 are done
-  lg_store_panel(sA, ra, scp);
-  lg_store_panel(sB, rb, nullptr);
+  lg_store_panel<SCALE>(sA, ra, sc);
+  lg_store_panel<false>(sB, rb, one);
   __syncthreads();
   for (int kt = 0; kt < nk; ++kt) {
     const double *cA = sA + (kt & 1) * (LG_KT * LG_TM), *cB = sB + (kt & 1) * (LG_KT * LG_TN);
     if (kt + 1 < nk) {
-      lg_load_panel(g.A, g.lda, g.K, g.M, (kt + 1) * LG_KT, m0, ra, g.kscale, sc);
-      lg_load_panel(g.B, g.ldb, g.K, g.N, (kt + 1) * LG_KT, n0, rb);
+      lg_load_panel<SCALE>(g.A, g.lda, g.K, g.M, (kt + 1) * LG_KT, m0, ra, g.kscale, sc);
+      lg_load_panel<false>(g.B, g.ldb, g.K, g.N, (kt + 1) * LG_KT, n0, rb, nullptr, one);
     }
 #pragma unroll
     for (int s = 0; s < LG_KT / 4; ++s) {
@@ -106,8 +109,8 @@ __device__ __forceinline__ void lg_gemm_tile(const GemmOperands &g, int m0, int 
     }
     if (kt + 1 < nk) {
       // buffer (kt+1)&1 was last read in step kt-1; every wave passed the barrier since
-      lg_store_panel(sA + ((kt + 1) & 1) * (LG_KT * LG_TM), ra, scp);
-      lg_store_panel(sB + ((kt + 1) & 1) * (LG_KT * LG_TN), rb, nullptr);
+      lg_store_panel<SCALE>(sA + ((kt + 1) & 1) * (LG_KT * LG_TM), ra, sc);
+      lg_store_panel<false>(sB + ((kt + 1) & 1) * (LG_KT * LG_TN), rb, one);
     }
     __syncthreads();
   }
@@ -143,7 +146,7 @@ struct K1Args {
 // Pt_b is symmetric: only the tilesN (tilesN + 1) / 2 tiles with tm <= tn run the main loop; an
 // off-diagonal tile serves both (row, col) and (col, row) in its epilogue (same Pt value, its own
 // count and its own Gt^T entry).  40 % fewer MFMAs than the full grid at LD = 400.
-__global__ __launch_bounds__(LG_THREADS) void k1_pt_loss_gt(K1Args a) {
+__global__ __launch_bounds__(LG_THREADS, 5) void k1_pt_loss_gt(K1Args a) {  // 5 waves per SIMD = 4 workgroups per CU: at most 96 VGPRs
   __shared__ double sA[2 * LG_KT * LG_TM];
   __shared__ double sB[2 * LG_KT * LG_TN];
   const int tilesN = (a.LD + LG_TN - 1) / LG_TN, tiles = tilesN * (tilesN + 1) / 2;
@@ -161,7 +164,7 @@ __global__ __launch_bounds__(LG_THREADS) void k1_pt_loss_gt(K1Args a) {
   const size_t boff = (size_t)b * a.LD * a.LD;
   GemmOperands g{a.Ut, a.Ut, a.LD, a.LD, a.LD, a.LD, a.LD, a.F + (size_t)b * a.LD};
   d4 acc[5];
-  lg_gemm_tile(g, m0, n0, sA, sB, acc);
+  lg_gemm_tile<true>(g, m0, n0, sA, sB, acc);
 
   const double tb = a.t[b];
   const bool split = tb * 2.0 * (*a.sigma) <= 1.0;  // see small_bank.hip.h
