@@ -671,12 +671,15 @@ static int large_eigh(cb_bank *h, bool warm) {
   const size_t LL = (size_t)LD * LD;
   hipLaunchKernelGGL(lgj_sigma, dim3(1), dim3(256), 0, h->stream, LD, h->A, h->sigma);
   const bool warm_started = warm && h->have_prev && !getenv("CB_NO_WARM");
+  bool gr_valid = false;   // the row-major copy of G (first-order sweeps) is current
   if (warm_started) {
     // Warm start: Jacobi from the previous epoch's orthonormal basis V0 = U_prev,
     //   G0 = A' V0 :  Gc[k][r] = sum_j U_prev[j][k] A[j][r] - sigma Ut_prev[k][r]
     // (A changes by one optimiser step, so G0's columns are nearly orthogonal already).
     const int tm = (LD + LG_TM - 1) / LG_TM, tn = (LD + LG_TN - 1) / LG_TN;
     K4Args g0{h->S, LD, h->U, h->A, h->Gc, nullptr, h->Vc, h->sigma};
+    g0.outT = h->gx + 11 * LL + (size_t)((LD + 7) & ~7);   // row-major copy for the first sweep's Gram product
+    gr_valid = true;
     (void)tm; (void)tn;
     launch_sg(h, g0, 0);
   } else {
@@ -699,7 +702,7 @@ static int large_eigh(cb_bank *h, bool warm) {
   unsigned long long *dbg_stamps = nullptr;
   if (getenv("CB_DEBUG_STAMPS")) HIP_TRY(hipMalloc((void **)&dbg_stamps, 8 * sizeof(unsigned long long)));
   HIP_TRY(hipMemsetAsync(h->off_bits, 0, 64 * sizeof(unsigned long long), h->stream));
-  bool gr_valid = false;   // the row-major copy of G (first-order sweeps) is current
+  double prev_cos = 1.0;     // largest cosine seen by the previous first-order sweep of this solve
   auto enqueue_sweep = [&](int sweep) {
     gr_valid = false;
     if (inner_sweeps == 0) {
@@ -737,7 +740,8 @@ static int large_eigh(cb_bank *h, bool warm) {
     double *Grn = h->gx + 11 * LL + (size_t)((LD + 7) & ~7);
     if (gr_valid) {
       Gr = Grn;
-      HIP_TRY(hipMemsetAsync(h->off_bits + 4, 0, 4 * sizeof(unsigned long long), h->stream));
+      // (with the pinned-memory route lgx_build's last workgroup re-zeroes its statistics itself)
+      if (!h->poll) HIP_TRY(hipMemsetAsync(h->off_bits + 4, 0, 4 * sizeof(unsigned long long), h->stream));
     } else {
       hipLaunchKernelGGL(lgx_transpose, dim3(nt32, nt32), dim3(32, 8), 0, h->stream, LD, h->Gc, Gr, h->off_bits + 4);
     }
@@ -754,8 +758,26 @@ static int large_eigh(cb_bank *h, bool warm) {
     }
     const unsigned long long seq = ++h->poll_seq;
     hipLaunchKernelGGL(lgx_build, dim3((LD + 3) / 4), dim3(256), 0, h->stream, LD, Gam, dg, X, Xf, band, h->off_bits,
-                       (volatile unsigned long long *)h->poll, seq);
-    unsigned long long m[3] = {};
+                       (volatile unsigned long long *)h->poll, seq, hybrid_ok ? 1 : 0, trigger);
+    // Speculation: the powers of X do not depend on anything the host decides except WHICH X, and
+    // lgx_build's last workgroup has left that choice in off_bits[3] for sg_gemm to read.  So they are
+    // enqueued now and run while the statistics travel to the host (that round trip was a 14-19 us
+    // hole in every sweep).  X^3 and X^4 only when the sweep is expected to need them.
+    double *P2 = Gr, *P3 = Gam;                                            // both free once lgx_build has run
+    const bool spec = h->poll != nullptr && !getenv("CB_NO_SPECULATE");
+    const bool spec_deep = spec && !(prev_cos <= 1e-4);
+    bool have_p2 = false, have_p34 = false;
+    if (spec) {
+      const unsigned long long *sel = h->off_bits + 3;
+      launch_sg(h, K4Args{h->S, LD, X, X, P2, nullptr, nullptr, nullptr, nullptr, nullptr, sel, Xf, Xf}, 0);   // X^T X   = -X^2
+      have_p2 = true;
+      if (spec_deep) {
+        launch_sg(h, K4Args{h->S, LD, X, P2, P3, nullptr, nullptr, nullptr, nullptr, nullptr, sel, Xf, nullptr}, 0);  // X^T P2 = X^3
+        launch_sg(h, K4Args{h->S, LD, P2, P2, P4, nullptr, nullptr, nullptr}, 0);                                      // P2^T P2 = X^4
+        have_p34 = true;
+      }
+    }
+    unsigned long long m[4] = {};
     bool got = false;
     if (h->poll) {
       // spin on the pinned words (a few microseconds after the kernel's last workgroup); give up
@@ -768,6 +790,7 @@ static int large_eigh(cb_bank *h, bool warm) {
           m[0] = pl[1];
           m[1] = pl[2];
           m[2] = pl[3];
+          m[3] = pl[4];
           got = true;
           break;
         }
@@ -776,8 +799,19 @@ static int large_eigh(cb_bank *h, bool warm) {
           break;
       }
     }
+    if (!got && h->poll) {   // a long queue ahead of the sweep: wait for the stream, the words are there then
+      HIP_TRY(hipStreamSynchronize(h->stream));
+      volatile unsigned long long *pl = h->poll;
+      if (pl[0] != seq) return fail(CB_EHIP, "eigensolver: the sweep statistics never reached the host");
+      std::atomic_thread_fence(std::memory_order_acquire);
+      m[0] = pl[1];
+      m[1] = pl[2];
+      m[2] = pl[3];
+      m[3] = pl[4];
+      got = true;
+    }
     if (!got) {
-      HIP_TRY(hipMemcpyAsync(m, h->off_bits + 4, sizeof m, hipMemcpyDeviceToHost, h->stream));
+      HIP_TRY(hipMemcpyAsync(m, h->off_bits + 4, 3 * sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
       HIP_TRY(hipStreamSynchronize(h->stream));
     }
     double cosmax, rowsum, rowsum_far;
@@ -788,29 +822,33 @@ static int large_eigh(cb_bank *h, bool warm) {
       fprintf(stderr, "[cherrybank] eigh first-order sweep: max cosine %.3e, |X| <= %.3e (far pairs: %.3e)\n", cosmax,
               rowsum, rowsum_far);
     if (!(cosmax == cosmax) || !(rowsum == rowsum)) return fail(CB_ENUMERIC, "eigensolver: non-finite input");
+    prev_cos = cosmax;
     bool masked = false;
     if (hybrid_ok) {
       // all pairs at once only when the state is close enough for the small-angle limit to hold for
-      // the near-degenerate neighbours too
+      // the near-degenerate neighbours too (the same rule, on the same numbers, as lgx_build's)
       if (cosmax > trigger || rowsum > 0.5) {
         masked = true;
         rowsum = rowsum_far;
         if (rowsum > 12.0) return 0;
       }
+      if (got && masked != (m[3] != 0ull)) return fail(CB_ENUMERIC, "eigensolver: host and device disagree on the sweep kind");
     } else if (rowsum > 2e-3) {
       return 0;
     }
     const double *Xu = masked ? Xf : X;
     double *Rfin = R;
+    if (!have_p2) launch_sg(h, K4Args{h->S, LD, Xu, Xu, P2, nullptr, nullptr, nullptr}, 0);    // X^T X = -X^2
     if (rowsum <= 1e-5) {
-      launch_sg(h, K4Args{h->S, LD, Xu, Xu, R, nullptr, Xu, nullptr}, 1);      // R = I + X - X^T X / 2
+      hipLaunchKernelGGL(lgx_combine, dim3(nel), dim3(256), 0, h->stream, LD, Xu, P2, (const double *)nullptr,
+                         (const double *)nullptr, R);                                              // R = I + X + X^2 / 2
     } else {
-      double *P2 = Gr, *P3 = Gam;                                            // both free by now
-      launch_sg(h, K4Args{h->S, LD, Xu, Xu, P2, nullptr, nullptr, nullptr}, 0);    // X^T X   = -X^2
-      launch_sg(h, K4Args{h->S, LD, Xu, P2, P3, nullptr, nullptr, nullptr}, 0);   // X^T P2  =  X^3
+      if (!have_p34) {
+        launch_sg(h, K4Args{h->S, LD, Xu, P2, P3, nullptr, nullptr, nullptr}, 0);   // X^T P2  =  X^3
+        launch_sg(h, K4Args{h->S, LD, P2, P2, P4, nullptr, nullptr, nullptr}, 0);   // P2^T P2 =  X^4
+      }
       if (rowsum <= 2e-3) {
-        launch_sg(h, K4Args{h->S, LD, P2, P2, R, nullptr, nullptr, nullptr}, 0);   // P2^T P2 =  X^4
-        hipLaunchKernelGGL(lgx_combine, dim3(nel), dim3(256), 0, h->stream, LD, Xu, P2, P3, R);
+        hipLaunchKernelGGL(lgx_combine, dim3(nel), dim3(256), 0, h->stream, LD, Xu, P2, P3, P4, R);
       } else {
         int sq = 0;
         double sc = 1.0;
@@ -818,7 +856,6 @@ static int large_eigh(cb_bank *h, bool warm) {
           sc *= 0.5;
           ++sq;
         }
-        launch_sg(h, K4Args{h->S, LD, P2, P2, P4, nullptr, nullptr, nullptr}, 0);
         hipLaunchKernelGGL(lgx_poly8, dim3(nel), dim3(256), 0, h->stream, LD, sc, Xu, P2, P3, P4, lo, hiT);
         const double sc2 = sc * sc;
         // (every product also writes its transpose: the next step needs R^T as the k-major operand)

@@ -284,7 +284,8 @@ __global__ void lgx_transpose(int LD, const double *Gc, double *Gr, unsigned lon
 // host is spinning -- a hipStreamSynchronize round trip costs ~30 us of idle GPU per sweep.
 __global__ __launch_bounds__(256) void lgx_build(int LD, const double *Gam, const double *dg, double *X, double *Xf,
                                                  int band, unsigned long long *state,
-                                                 volatile unsigned long long *poll, unsigned long long seq) {
+                                                 volatile unsigned long long *poll, unsigned long long seq,
+                                                 int hybrid_ok, double trigger) {
   __shared__ double s0[4], s1[4], s2[4];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int i = blockIdx.x * 4 + wave;
@@ -337,12 +338,22 @@ __global__ __launch_bounds__(256) void lgx_build(int LD, const double *Gam, cons
     __threadfence();
     const unsigned long long done = atomicAdd(state + 7, 1ull);
     if (poll && done == gridDim.x - 1) {
-      poll[1] = atomicAdd(state + 4, 0ull);
-      poll[2] = atomicAdd(state + 5, 0ull);
+      const unsigned long long c = atomicAdd(state + 4, 0ull), r = atomicAdd(state + 5, 0ull);
+      // which X the sweep rotates with (the host applies the same rule to the same numbers): far
+      // pairs only while the state is too far for the small-angle limit to hold for near neighbours
+      double cosmax, rowsum;
+      memcpy(&cosmax, &c, sizeof cosmax);
+      memcpy(&rowsum, &r, sizeof rowsum);
+      const unsigned long long sel = (hybrid_ok && (cosmax > trigger || rowsum > 0.5)) ? 1ull : 0ull;
+      state[3] = sel;              // read by the products enqueued behind this kernel (K4Args::sel)
+      poll[1] = c;
+      poll[2] = r;
       poll[3] = atomicAdd(state + 6, 0ull);
+      poll[4] = sel;
       __threadfence_system();
       poll[0] = seq;
       __threadfence_system();
+      state[4] = state[5] = state[6] = state[7] = 0ull;   // ready for the next sweep (no memset launch)
     }
   }
 }
@@ -365,12 +376,14 @@ __global__ void lgx_poly8(int LD, double sc, const double *X, const double *P2, 
 }
 
 // R = I + X - P2/2 + P3/6 + P4/24  (= exp(X) to 4th order: P2 = X^T X = -X^2, P3 = X^T P2 = X^3,
-// P4 = P2^T P2 = X^4); P4 arrives in R and is overwritten.
-__global__ void lgx_combine(int LD, const double *X, const double *P2, const double *P3, double *R) {
+// P4 = P2^T P2 = X^4); P3 == nullptr: second order, R = I + X - P2/2.
+__global__ void lgx_combine(int LD, const double *X, const double *P2, const double *P3, const double *P4, double *R) {
   const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= (size_t)LD * LD) return;
   const int i = idx / LD, j = idx - (size_t)i * LD;
-  R[idx] = (i == j ? 1.0 : 0.0) + X[idx] - 0.5 * P2[idx] + P3[idx] * (1.0 / 6.0) + R[idx] * (1.0 / 24.0);
+  double v = (i == j ? 1.0 : 0.0) + X[idx] - 0.5 * P2[idx];
+  if (P3) v += P3[idx] * (1.0 / 6.0) + P4[idx] * (1.0 / 24.0);
+  R[idx] = v;
 }
 
 // |g_k| per column (one wave per column)

@@ -330,6 +330,11 @@ struct K4Args {
   const double *sub_scale;
   double *outT = nullptr;   // sg_gemm only: also write the transpose of the result
   double *diag = nullptr;   // sg_gemm only: also write the diagonal of the result
+  // sg_gemm only: operands chosen ON THE DEVICE -- when *sel != 0 the non-null alternatives replace
+  // Aop / Bop.  Lets the host enqueue the products of a first-order sweep before it knows which X
+  // (all pairs or far pairs only) lgx_build decided on.
+  const unsigned long long *sel = nullptr;
+  const double *Aalt = nullptr, *Balt = nullptr;
 };
 
 __global__ __launch_bounds__(LG_THREADS) void k4_gemm(K4Args a) {
@@ -382,7 +387,8 @@ __global__ __launch_bounds__(NW * 64) void sg_gemm(K4Args a, int ns, double alph
 #pragma unroll
   for (int j = 0; j < 5; ++j) ncol[j] = min(n0 + 16 * j + lo, LD - 1);  // clamped: tiles past LD are discarded
   const int nsteps = LD / 4;
-  const double *Ap = a.Aop + m0 + lo, *Bp = a.Bop;
+  const bool alt = a.sel && *a.sel != 0ull;
+  const double *Ap = (alt && a.Aalt ? a.Aalt : a.Aop) + m0 + lo, *Bp = alt && a.Balt ? a.Balt : a.Bop;
   for (int s0 = wave; s0 < nsteps; s0 += UU * NW) {   // UU k-steps of this wave in flight
     double av[UU], bv[UU][5];
 #pragma unroll
