@@ -669,7 +669,7 @@ static void launch_sg(cb_bank *h, const K4Args &g, int ns, double alpha = 0.0, d
 static int large_eigh(cb_bank *h, bool warm) {
   const int LD = h->LD;
   const size_t LL = (size_t)LD * LD;
-  hipLaunchKernelGGL(lgj_sigma, dim3(1), dim3(256), 0, h->stream, LD, h->A, h->sigma);
+  hipLaunchKernelGGL(lgj_sigma, dim3(1), dim3(256), 0, h->stream, LD, h->A, h->sigma, h->off_bits);
   const bool warm_started = warm && h->have_prev && !getenv("CB_NO_WARM");
   bool gr_valid = false;   // the row-major copy of G (first-order sweeps) is current
   if (warm_started) {
@@ -701,7 +701,7 @@ static int large_eigh(cb_bank *h, bool warm) {
   const int passes = env_passes ? atoi(env_passes) : 2;
   unsigned long long *dbg_stamps = nullptr;
   if (getenv("CB_DEBUG_STAMPS")) HIP_TRY(hipMalloc((void **)&dbg_stamps, 8 * sizeof(unsigned long long)));
-  HIP_TRY(hipMemsetAsync(h->off_bits, 0, 64 * sizeof(unsigned long long), h->stream));
+  // (h->off_bits[0..63] were zeroed by lgj_sigma, the first kernel of the solve)
   double prev_cos = 1.0;     // largest cosine seen by the previous first-order sweep of this solve
   auto enqueue_sweep = [&](int sweep) {
     gr_valid = false;

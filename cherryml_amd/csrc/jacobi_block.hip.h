@@ -21,8 +21,9 @@
 #define JB_THREADS 512
 #define JB_WAVES (JB_THREADS / 64)
 
-__global__ void lgj_sigma(int LD, const double *A, double *sigma) {
+__global__ void lgj_sigma(int LD, const double *A, double *sigma, unsigned long long *zero64 = nullptr) {
   __shared__ double s[256];
+  if (zero64 && threadIdx.x < 64) zero64[threadIdx.x] = 0ull;   // the solve's state words (saves a memset launch)
   double m = 0.0;
   for (int i = threadIdx.x; i < LD; i += 256) m = fmax(m, fabs(A[(size_t)i * LD + i]));
   s[threadIdx.x] = m;
