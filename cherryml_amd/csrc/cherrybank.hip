@@ -1015,7 +1015,10 @@ static int large_eval(cb_bank *h, bool normalize, double *lossd, double *out, bo
   K1Args k1{S, LD, B, h->Vc, h->A, tb, h->F, h->sigma, h->Ct, h->Gt, h->loss_part, inv_n, h->dsq, Pd};
   mark(h, EV_END);  // (re-used as "before K1" marker)
   const int tiles_k1 = tn * (tn + 1) / 2;  // Pt is symmetric: upper-triangular tiles only
-  hipLaunchKernelGGL(k1_pt_loss_gt, dim3(tiles_k1 * B), dim3(LG_THREADS), 0, h->stream, k1);
+  // four waves per workgroup (one per SIMD) unless CB_FIVE_WAVES asks for the strip-per-wave kernels
+  static const bool five = getenv("CB_FIVE_WAVES") != nullptr;
+  if (five) hipLaunchKernelGGL(k1_pt_loss_gt<5>, dim3(tiles_k1 * B), dim3(LG_THREADS), 0, h->stream, k1);
+  else hipLaunchKernelGGL(k1_pt_loss_gt<4>, dim3(tiles_k1 * B), dim3(LG4_THREADS), 0, h->stream, k1);
   mark(h, EV_K1);
   if (Pd) {
     HIP_TRY(hipGetLastError());
@@ -1025,10 +1028,12 @@ static int large_eval(cb_bank *h, bool normalize, double *lossd, double *out, bo
                      h->dsq, h->dirsum, inv_n, lossd);
   if (dQd) {
     K2Args k2{LD, h->Gt, h->U, h->T};
-    hipLaunchKernelGGL(k2_t_eq_g_u, dim3(tiles * B), dim3(LG_THREADS), 0, h->stream, k2);
+    if (five) hipLaunchKernelGGL(k2_t_eq_g_u<5>, dim3(tiles * B), dim3(LG_THREADS), 0, h->stream, k2);
+    else hipLaunchKernelGGL(k2_t_eq_g_u<4>, dim3(tiles * B), dim3(LG4_THREADS), 0, h->stream, k2);
     mark(h, EV_K2);
     K3Args k3{LD, B, h->T, h->U, tb, h->lam, h->E, h->H, h->Gt, h->sym_counts ? 1 : 0};
-    hipLaunchKernelGGL(k3_w_phi, dim3((h->sym_counts ? tiles_k1 : tiles) * B), dim3(LG_THREADS), 0, h->stream, k3);
+    if (five) hipLaunchKernelGGL(k3_w_phi<5>, dim3((h->sym_counts ? tiles_k1 : tiles) * B), dim3(LG_THREADS), 0, h->stream, k3);
+    else hipLaunchKernelGGL(k3_w_phi<4>, dim3((h->sym_counts ? tiles_k1 : tiles) * B), dim3(LG4_THREADS), 0, h->stream, k3);
     mark(h, EV_K3);
     hipLaunchKernelGGL(k3_reduce, dim3((unsigned)((LL + 255) / 256)), dim3(256), 0, h->stream,
                        h->Gt, B, LL, h->Mt, h->sym_counts ? LD : 0);

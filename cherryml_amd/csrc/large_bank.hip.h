@@ -116,6 +116,111 @@ __device__ __forceinline__ void lg_gemm_tile(const GemmOperands &g, int m0, int 
   }
 }
 
+// ---- the same tile with FOUR waves per workgroup, one per SIMD ------------------------------------
+// A 5-wave workgroup puts two of its waves on one SIMD (which one rotates from workgroup to workgroup,
+// profiles/tools/simd_probe), so with four workgroups on a CU the SIMDs carry 4..7 waves and the busiest
+// one sets the pace.  Here the 25 MFMA tiles of the 80 x 80 tile are dealt 7/6/6/6: wave w owns strip w
+// (acc[0..4]) and tile (4, w) of the fifth strip (ax0); wave 0 also tile (4, 4) (ax1).  Every workgroup
+// then loads the four SIMDs equally: K2 0.378 -> 0.330 ms at LD = 400.
+#define LG4_THREADS 256
+template <bool SCALE>
+__device__ __forceinline__ void lg4_load_panel(const double *__restrict__ P, int ld, int rows_total, int cols_total,
+                                               int k0, int c0, double2 (&reg)[3],
+                                               const double *__restrict__ kscale, double (&sc)[3]) {
+#pragma unroll
+  for (int u = 0; u < 3; ++u) {
+    const int chunk = threadIdx.x + u * LG4_THREADS;  // 0..767, 640 used
+    const int kr = chunk / 40, cc = (chunk - kr * 40) * 2;
+    const int k = k0 + kr, c = c0 + cc;
+    if (chunk < 640 && k < rows_total && c < cols_total)
+      reg[u] = *reinterpret_cast<const double2 *>(P + (size_t)k * ld + c);
+    else
+      reg[u] = double2{0.0, 0.0};
+    if (SCALE) sc[u] = (chunk < 640 && k < rows_total) ? kscale[k] : 0.0;
+  }
+}
+template <bool SCALE>
+__device__ __forceinline__ void lg4_store_panel(double *s, const double2 (&reg)[3], const double (&sc)[3]) {
+#pragma unroll
+  for (int u = 0; u < 3; ++u) {
+    const int chunk = threadIdx.x + u * LG4_THREADS;
+    const int kr = chunk / 40, cc = (chunk - kr * 40) * 2;
+    double2 v = reg[u];
+    if (SCALE) {
+      v.x *= sc[u];
+      v.y *= sc[u];
+    }
+    if (chunk < 640) *reinterpret_cast<double2 *>(s + kr * LG_TM + cc) = v;
+  }
+}
+template <bool SCALE = false>
+__device__ __forceinline__ void lg4_gemm_tile(const GemmOperands &g, int m0, int n0, double *sA, double *sB,
+                                              d4 (&acc)[5], d4 &ax0, d4 &ax1) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, lo = lane & 15, hi = lane >> 4;
+#pragma unroll
+  for (int j = 0; j < 5; ++j) acc[j] = d4{0.0, 0.0, 0.0, 0.0};
+  ax0 = d4{0.0, 0.0, 0.0, 0.0};
+  ax1 = ax0;
+  double2 ra[3], rb[3];
+  double sc[3] = {1.0, 1.0, 1.0}, one[3] = {1.0, 1.0, 1.0};
+  const int nk = g.K / LG_KT;
+  lg4_load_panel<SCALE>(g.A, g.lda, g.K, g.M, 0, m0, ra, g.kscale, sc);
+  lg4_load_panel<false>(g.B, g.ldb, g.K, g.N, 0, n0, rb, nullptr, one);
+  __syncthreads();  // the previous tile's readers of buffer 0 are done
+  lg4_store_panel<SCALE>(sA, ra, sc);
+  lg4_store_panel<false>(sB, rb, one);
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    const double *cA = sA + (kt & 1) * (LG_KT * LG_TM), *cB = sB + (kt & 1) * (LG_KT * LG_TN);
+    if (kt + 1 < nk) {
+      lg4_load_panel<SCALE>(g.A, g.lda, g.K, g.M, (kt + 1) * LG_KT, m0, ra, g.kscale, sc);
+      lg4_load_panel<false>(g.B, g.ldb, g.K, g.N, (kt + 1) * LG_KT, n0, rb, nullptr, one);
+    }
+#pragma unroll
+    for (int s = 0; s < LG_KT / 4; ++s) {
+      const double av = cA[(4 * s + hi) * LG_TM + 16 * wave + lo];
+      const double a4 = cA[(4 * s + hi) * LG_TM + 64 + lo];
+      double bv[5];
+#pragma unroll
+      for (int j = 0; j < 5; ++j) bv[j] = cB[(4 * s + hi) * LG_TN + 16 * j + lo];
+#pragma unroll
+      for (int j = 0; j < 5; ++j) acc[j] = mfma_f64(av, bv[j], acc[j]);
+      // tile (4, wave): column block `wave` (a wave-uniform choice among registers)
+      const double bx = wave == 0 ? bv[0] : wave == 1 ? bv[1] : wave == 2 ? bv[2] : bv[3];
+      ax0 = mfma_f64(a4, bx, ax0);
+      if (wave == 0) ax1 = mfma_f64(a4, bv[4], ax1);
+    }
+    if (kt + 1 < nk) {
+      lg4_store_panel<SCALE>(sA + ((kt + 1) & 1) * (LG_KT * LG_TM), ra, sc);
+      lg4_store_panel<false>(sB + ((kt + 1) & 1) * (LG_KT * LG_TN), rb, one);
+    }
+    __syncthreads();
+  }
+}
+
+// f(row, col, value) for every element of the tile this lane owns (either wave layout)
+template <int NW, typename F>
+__device__ __forceinline__ void lg_for_each(int m0, int n0, const d4 (&acc)[5], const d4 &ax0, const d4 &ax1, F &&f) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, lo = lane & 15, hi = lane >> 4;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int row = m0 + 16 * wave + hi + 4 * r;
+#pragma unroll
+    for (int j = 0; j < 5; ++j) f(row, n0 + 16 * j + lo, acc[j][r]);
+    if (NW == 4) {
+      const int row4 = m0 + 64 + hi + 4 * r;
+      f(row4, n0 + 16 * wave + lo, ax0[r]);
+      if (wave == 0) f(row4, n0 + 64 + lo, ax1[r]);
+    }
+  }
+}
+template <int NW, bool SCALE>
+__device__ __forceinline__ void lg_tile(const GemmOperands &g, int m0, int n0, double *sA, double *sB, d4 (&acc)[5],
+                                        d4 &ax0, d4 &ax1) {
+  if (NW == 4) lg4_gemm_tile<SCALE>(g, m0, n0, sA, sB, acc, ax0, ax1);
+  else lg_gemm_tile<SCALE>(g, m0, n0, sA, sB, acc);
+}
+
 // XCD-aware block id: hardware deals consecutive workgroup ids round-robin over the 8
 // XCDs (ids i and i + 8 share an L2).  Remap so that each XCD walks a CONTIGUOUS range
 // of virtual ids: the 25 tiles of one bucket then run on one XCD and share its L2 for
@@ -146,7 +251,8 @@ struct K1Args {
 // Pt_b is symmetric: only the tilesN (tilesN + 1) / 2 tiles with tm <= tn run the main loop; an
 // off-diagonal tile serves both (row, col) and (col, row) in its epilogue (same Pt value, its own
 // count and its own Gt^T entry).  40 % fewer MFMAs than the full grid at LD = 400.
-__global__ __launch_bounds__(LG_THREADS, 5) void k1_pt_loss_gt(K1Args a) {  // 5 waves per SIMD = 4 workgroups per CU: at most 96 VGPRs
+template <int NW>   // 5: one wave per 16-row strip; 4: one wave per SIMD (lg4_gemm_tile)
+__global__ __launch_bounds__(NW * 64, NW == 4 ? 4 : 5) void k1_pt_loss_gt(K1Args a) {  // four workgroups per CU (96 / 128 VGPRs)
   __shared__ double sA[2 * LG_KT * LG_TM];
   __shared__ double sB[2 * LG_KT * LG_TN];
   const int tilesN = (a.LD + LG_TN - 1) / LG_TN, tiles = tilesN * (tilesN + 1) / 2;
@@ -163,8 +269,8 @@ __global__ __launch_bounds__(LG_THREADS, 5) void k1_pt_loss_gt(K1Args a) {  // 5
   const int lo = lane & 15, hi = lane >> 4;
   const size_t boff = (size_t)b * a.LD * a.LD;
   GemmOperands g{a.Ut, a.Ut, a.LD, a.LD, a.LD, a.LD, a.LD, a.F + (size_t)b * a.LD};
-  d4 acc[5];
-  lg_gemm_tile<true>(g, m0, n0, sA, sB, acc);
+  d4 acc[5], ax0, ax1;
+  lg_tile<NW, true>(g, m0, n0, sA, sB, acc, ax0, ax1);
 
   const double tb = a.t[b];
   const bool split = tb * 2.0 * (*a.sigma) <= 1.0;  // see small_bank.hip.h
@@ -182,25 +288,20 @@ __global__ __launch_bounds__(LG_THREADS, 5) void k1_pt_loss_gt(K1Args a) {  // 5
       a.Gt[boff + idx] = nz ? -c * a.inv_n * fast_rcp(pt) : 0.0;
     }
   };
-#pragma unroll
-  for (int j = 0; j < 5; ++j)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int row = m0 + 16 * wave + hi + 4 * r, col = n0 + 16 * j + lo;
-      if (row < a.LD && col < a.LD) {
-        double pt = acc[j][r];
-        if (split) pt += tb * a.A[(size_t)row * a.LD + col] + (row == col ? 1.0 : 0.0);
-        else if (row >= a.S || col >= a.S) pt = 1.0;  // pad (never used: C = 0 there)
-        emit(row, col, pt);
-        if (mirror) emit(col, row, pt);
-      }
+  lg_for_each<NW>(m0, n0, acc, ax0, ax1, [&](int row, int col, double pt) {
+    if (row < a.LD && col < a.LD) {
+      if (split) pt += tb * a.A[(size_t)row * a.LD + col] + (row == col ? 1.0 : 0.0);
+      else if (row >= a.S || col >= a.S) pt = 1.0;  // pad (never used: C = 0 there)
+      emit(row, col, pt);
+      if (mirror) emit(col, row, pt);
     }
+  });
   if (a.P) return;
   lossacc = wave_sum(lossacc);
-  // sA is free after the K loop (lg_gemm_tile ends with a barrier)
+  // sA is free after the K loop (the tile routine ends with a barrier)
   if (lane == 0) sA[wave] = lossacc;
   __syncthreads();
-  if (threadIdx.x == 0) a.loss_part[vid] = sA[0] + sA[1] + sA[2] + sA[3] + sA[4];
+  if (threadIdx.x == 0) a.loss_part[vid] = sA[0] + sA[1] + sA[2] + sA[3] + (NW == 5 ? sA[4] : 0.0);
 }
 
 // ------------------------------------------------------------------ K2
@@ -211,7 +312,8 @@ struct K2Args {
   double *T;         // [B][LD][LD]
 };
 
-__global__ __launch_bounds__(LG_THREADS) void k2_t_eq_g_u(K2Args a) {
+template <int NW>
+__global__ __launch_bounds__(NW * 64, NW == 4 ? 4 : 5) void k2_t_eq_g_u(K2Args a) {
   __shared__ double sA[2 * LG_KT * LG_TM];
   __shared__ double sB[2 * LG_KT * LG_TN];
   const int tilesN = (a.LD + LG_TN - 1) / LG_TN, tiles = tilesN * tilesN;
@@ -221,17 +323,11 @@ __global__ __launch_bounds__(LG_THREADS) void k2_t_eq_g_u(K2Args a) {
   const int m0 = tm * LG_TM, n0 = tn * LG_TN;
   const size_t boff = (size_t)b * a.LD * a.LD;
   GemmOperands g{a.Gt + boff, a.U, a.LD, a.LD, a.LD, a.LD, a.LD, nullptr};
-  d4 acc[5];
-  lg_gemm_tile(g, m0, n0, sA, sB, acc);
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int lo = lane & 15, hi = lane >> 4;
-#pragma unroll
-  for (int j = 0; j < 5; ++j)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int row = m0 + 16 * wave + hi + 4 * r, col = n0 + 16 * j + lo;
-      if (row < a.LD && col < a.LD) a.T[boff + (size_t)row * a.LD + col] = acc[j][r];
-    }
+  d4 acc[5], ax0, ax1;
+  lg_tile<NW, false>(g, m0, n0, sA, sB, acc, ax0, ax1);
+  lg_for_each<NW>(m0, n0, acc, ax0, ax1, [&](int row, int col, double v) {
+    if (row < a.LD && col < a.LD) a.T[boff + (size_t)row * a.LD + col] = v;
+  });
 }
 
 // ------------------------------------------------------------------ K3
@@ -251,7 +347,8 @@ struct K3Args {
   int sym;               // counts symmetric => Gt_b, hence W_b, symmetric: upper-triangular tiles only
 };
 
-__global__ __launch_bounds__(LG_THREADS) void k3_w_phi(K3Args a) {
+template <int NW>
+__global__ __launch_bounds__(NW * 64, NW == 4 ? 4 : 5) void k3_w_phi(K3Args a) {
   __shared__ double sA[2 * LG_KT * LG_TM];
   __shared__ double sB[2 * LG_KT * LG_TN];
   const int tilesN = (a.LD + LG_TN - 1) / LG_TN;
@@ -275,25 +372,16 @@ __global__ __launch_bounds__(LG_THREADS) void k3_w_phi(K3Args a) {
   const int lo = lane & 15, hi = lane >> 4;
   const size_t boff = (size_t)b * a.LD * a.LD;
   GemmOperands g{a.T + boff, a.U, a.LD, a.LD, a.LD, a.LD, a.LD, nullptr};
-  d4 acc[5];
-  lg_gemm_tile(g, m0, n0, sA, sB, acc);
+  d4 acc[5], ax0, ax1;
+  lg_tile<NW, false>(g, m0, n0, sA, sB, acc, ax0, ax1);
   const double tb = a.t[b];
   const double *Eb = a.E + (size_t)b * a.LD, *Hb = a.H + (size_t)b * a.LD;
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const int row = m0 + 16 * wave + hi + 4 * r;
-    if (row >= a.LD) continue;
-    const double lr = a.lam[row], er = Eb[row], hr = Hb[row];
-#pragma unroll
-    for (int j = 0; j < 5; ++j) {
-      const int col = n0 + 16 * j + lo;
-      if (col < a.LD) {
-        const double ph = divdiff_fast(tb, lr, a.lam[col], er, Eb[col], hr, Hb[col]);
-        const double w = acc[j][r] * ph;
-        a.W[boff + (size_t)row * a.LD + col] = w;   // (symmetric case: k3_reduce mirrors the sum, not every bucket)
-      }
+  lg_for_each<NW>(m0, n0, acc, ax0, ax1, [&](int row, int col, double v) {
+    if (row < a.LD && col < a.LD) {
+      const double ph = divdiff_fast(tb, a.lam[row], a.lam[col], Eb[row], Eb[col], Hb[row], Hb[col]);
+      a.W[boff + (size_t)row * a.LD + col] = v * ph;   // (symmetric case: k3_reduce mirrors the sum, not every bucket)
     }
-  }
+  });
 }
 
 // Mt = sum over chunks (fixed order => bitwise reproducible).  sym (LD > 0): only the 80x80 tiles on
