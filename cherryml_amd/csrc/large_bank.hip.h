@@ -121,7 +121,8 @@ __device__ __forceinline__ void lg_gemm_tile(const GemmOperands &g, int m0, int 
 // profiles/tools/simd_probe), so with four workgroups on a CU the SIMDs carry 4..7 waves and the busiest
 // one sets the pace.  Here the 25 MFMA tiles of the 80 x 80 tile are dealt 7/6/6/6: wave w owns strip w
 // (acc[0..4]) and tile (4, w) of the fifth strip (ax0); wave 0 also tile (4, 4) (ax1).  Every workgroup
-// then loads the four SIMDs equally: K2 0.378 -> 0.330 ms at LD = 400.
+// then loads the four SIMDs equally: K2 0.378 -> 0.330 ms at LD = 400.  (Tile (4, 4) itself is split
+// over K among the four waves, see the loop.)
 #define LG4_THREADS 256
 template <bool SCALE>
 __device__ __forceinline__ void lg4_load_panel(const double *__restrict__ P, int ld, int rows_total, int cols_total,
@@ -188,7 +189,9 @@ __device__ __forceinline__ void lg4_gemm_tile(const GemmOperands &g, int m0, int
       // tile (4, wave): column block `wave` (a wave-uniform choice among registers)
       const double bx = wave == 0 ? bv[0] : wave == 1 ? bv[1] : wave == 2 ? bv[2] : bv[3];
       ax0 = mfma_f64(a4, bx, ax0);
-      if (wave == 0) ax1 = mfma_f64(a4, bv[4], ax1);
+      // tile (4, 4): its K range is dealt round-robin to the four waves (6.25 MFMA tiles each
+      // instead of 7/6/6/6); the partial sums meet in wave 0 below
+      if ((kt & 3) == wave) ax1 = mfma_f64(a4, bv[4], ax1);
     }
     if (kt + 1 < nk) {
       lg4_store_panel<SCALE>(sA + ((kt + 1) & 1) * (LG_KT * LG_TM), ra, sc);
@@ -196,6 +199,16 @@ __device__ __forceinline__ void lg4_gemm_tile(const GemmOperands &g, int m0, int
     }
     __syncthreads();
   }
+  if (wave != 0) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) sA[(wave - 1) * 256 + r * 64 + lane] = ax1[r];
+  }
+  __syncthreads();
+  if (wave == 0) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) ax1[r] += (sA[r * 64 + lane] + sA[256 + r * 64 + lane]) + sA[512 + r * 64 + lane];
+  }
+  __syncthreads();   // sA is free again (callers reuse it)
 }
 
 // f(row, col, value) for every element of the tile this lane owns (either wave layout)
