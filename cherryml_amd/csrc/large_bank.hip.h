@@ -124,34 +124,40 @@ __device__ __forceinline__ void lg_gemm_tile(const GemmOperands &g, int m0, int 
 // then loads the four SIMDs equally: K2 0.378 -> 0.330 ms at LD = 400.  (Tile (4, 4) itself is split
 // over K among the four waves, see the loop.)
 #define LG4_THREADS 256
+// Panel loads: thread -> (row tid / 16 of the 16-row K-step, 16-byte chunks tid % 16, + 16, + 32 of that
+// row's 40), so the three loads of a thread share ONE row pointer and ONE row scale.  (A flat
+// chunk = tid + 256 u mapping needed three pointers and three scales per operand: 18 loop-invariant
+// registers, which the compiler spilled to scratch and re-loaded in every K-step: +170 MB of traffic
+// in K1.)
 template <bool SCALE>
 __device__ __forceinline__ void lg4_load_panel(const double *__restrict__ P, int ld, int rows_total, int cols_total,
                                                int k0, int c0, double2 (&reg)[3],
-                                               const double *__restrict__ kscale, double (&sc)[3]) {
+                                               const double *__restrict__ kscale, double &sc) {
+  const int kr = threadIdx.x >> 4, cq = threadIdx.x & 15;
+  const int k = k0 + kr;
+  const double *row = P + (size_t)k * ld + c0 + 2 * cq;
 #pragma unroll
   for (int u = 0; u < 3; ++u) {
-    const int chunk = threadIdx.x + u * LG4_THREADS;  // 0..767, 640 used
-    const int kr = chunk / 40, cc = (chunk - kr * 40) * 2;
-    const int k = k0 + kr, c = c0 + cc;
-    if (chunk < 640 && k < rows_total && c < cols_total)
-      reg[u] = *reinterpret_cast<const double2 *>(P + (size_t)k * ld + c);
+    const int c = c0 + 2 * (cq + 16 * u);
+    if ((u < 2 || cq < 8) && k < rows_total && c < cols_total)
+      reg[u] = *reinterpret_cast<const double2 *>(row + 32 * u);
     else
       reg[u] = double2{0.0, 0.0};
-    if (SCALE) sc[u] = (chunk < 640 && k < rows_total) ? kscale[k] : 0.0;
   }
+  if (SCALE) sc = k < rows_total ? kscale[k] : 0.0;
 }
 template <bool SCALE>
-__device__ __forceinline__ void lg4_store_panel(double *s, const double2 (&reg)[3], const double (&sc)[3]) {
+__device__ __forceinline__ void lg4_store_panel(double *s, const double2 (&reg)[3], double sc) {
+  const int kr = threadIdx.x >> 4, cq = threadIdx.x & 15;
+  double *row = s + kr * LG_TM + 2 * cq;
 #pragma unroll
   for (int u = 0; u < 3; ++u) {
-    const int chunk = threadIdx.x + u * LG4_THREADS;
-    const int kr = chunk / 40, cc = (chunk - kr * 40) * 2;
     double2 v = reg[u];
     if (SCALE) {
-      v.x *= sc[u];
-      v.y *= sc[u];
+      v.x *= sc;
+      v.y *= sc;
     }
-    if (chunk < 640) *reinterpret_cast<double2 *>(s + kr * LG_TM + cc) = v;
+    if (u < 2 || cq < 8) *reinterpret_cast<double2 *>(row + 32 * u) = v;
   }
 }
 template <bool SCALE = false>
@@ -163,7 +169,7 @@ __device__ __forceinline__ void lg4_gemm_tile(const GemmOperands &g, int m0, int
   ax0 = d4{0.0, 0.0, 0.0, 0.0};
   ax1 = ax0;
   double2 ra[3], rb[3];
-  double sc[3] = {1.0, 1.0, 1.0}, one[3] = {1.0, 1.0, 1.0};
+  double sc = 1.0, one = 1.0;
   const int nk = g.K / LG_KT;
   lg4_load_panel<SCALE>(g.A, g.lda, g.K, g.M, 0, m0, ra, g.kscale, sc);
   lg4_load_panel<false>(g.B, g.ldb, g.K, g.N, 0, n0, rb, nullptr, one);
