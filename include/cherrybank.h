@@ -141,7 +141,8 @@ int cb_last_timings(cb_handle h, double *ms, int n);
 /* Sums over all profiled cb_loss_grad calls since cb_profile(h, 1) was last
  * called: ms_sum[CB_T_*] and the number of calls (averages = sum / calls). */
 int cb_timing_sums(cb_handle h, double *ms_sum, int n, int *calls);
-/* sweeps used by the last large-path eigendecomposition */
+/* sweeps used by the last large-path eigendecomposition: tournament (Jacobi) sweeps of the cold path
+ * + hybrid / first-order sweeps of a warm-started solve */
 int cb_last_sweeps(cb_handle h);
 
 /*
