@@ -916,7 +916,8 @@ static int large_eigh(cb_bank *h, bool warm) {
   // converges like a full Jacobi sweep.  Falls through to the Jacobi loop below when it refuses.
   const int hybrid_reps = getenv("CB_HYBRID_REPS") ? atoi(getenv("CB_HYBRID_REPS")) : 1;
   int hybrid_iters = 0;
-  if (warm_started && use_light && nb >= 8 && !getenv("CB_NO_HYBRID")) {
+  auto run_hybrid = [&]() -> int {   // 1: converged; 0: gave up, G is valid, carry on with tournament sweeps; < 0: error
+    prev_cos = 1.0;
     for (int it = 0; it < 12; ++it) {
       const int lr = light_sweep(true, light_trigger);
       if (lr < 0) return lr;
@@ -924,14 +925,24 @@ static int large_eigh(cb_bank *h, bool warm) {
       ++hybrid_iters;
       if (lr == 3)
         for (int rep = 0; rep < hybrid_reps; ++rep) band_pass(it + rep);
-      if (lr == 1) {
-        converged = true;
-        light_done = 1;
-        break;
-      }
+      if (lr == 1) return 1;
     }
-    if (!converged) HIP_TRY(hipMemsetAsync(h->off_bits, 0, 8 * sizeof(unsigned long long), h->stream));
+    HIP_TRY(hipMemsetAsync(h->off_bits, 0, sizeof(unsigned long long), h->stream));   // the sweep's running maximum
+    return 0;
+  };
+  const bool hybrid_on = use_light && nb >= 8 && !getenv("CB_NO_HYBRID");
+  if (warm_started && hybrid_on) {
+    const int hr = run_hybrid();
+    if (hr < 0) return hr;
+    if (hr == 1) {
+      converged = true;
+      light_done = 1;
+    }
   }
+  // A COLD solve takes tournament sweeps until one of them started below `cold_switch`, then sorts its
+  // columns by norm (the eigenvalue order the hybrid sweep relies on) and finishes with hybrid sweeps.
+  bool cold_hybrid_pending = !warm_started && hybrid_on && !getenv("CB_NO_COLD_HYBRID");
+  const double cold_switch = getenv("CB_COLD_SWITCH") ? atof(getenv("CB_COLD_SWITCH")) : 3e-2;
   for (; !converged;) {
     for (int i = 0; i < batch && enq < max_sweeps; ++i) enqueue_sweep(enq++);
     HIP_TRY(hipMemcpyAsync(st, h->off_bits, sizeof st, hipMemcpyDeviceToHost, h->stream));
@@ -948,6 +959,22 @@ static int large_eigh(cb_bank *h, bool warm) {
     if (st[1] == 1ull) {
       converged = true;
       break;
+    }
+    if (cold_hybrid_pending && c_last <= cold_switch) {
+      cold_hybrid_pending = false;
+      hipLaunchKernelGGL(lgj_norms, dim3((LD + 3) / 4), dim3(256), 0, h->stream, LD, h->Gc, h->X);
+      hipLaunchKernelGGL(lgj_sort_columns, dim3((LD + 3) / 4), dim3(256), 0, h->stream, LD, h->Gc, h->X, h->Gc2);
+      std::swap(h->Gc, h->Gc2);
+      gr_valid = false;
+      const int iters_before = hybrid_iters;
+      const int hr = run_hybrid();
+      if (hr < 0) return hr;
+      if (hr == 1) {
+        converged = true;
+        light_done = 1;
+        break;
+      }
+      if (hybrid_iters == iters_before) cold_hybrid_pending = true;   // refused outright (still too far): ask again after the next sweep
     }
     if (use_light && c_last <= light_trigger) {
       int lr = 2, guard = 0;

@@ -401,6 +401,23 @@ __global__ void lgj_norms(int LD, const double *Gc, double *nrm) {
   if (lane == 0) nrm[k] = sqrt(nn);
 }
 
+// Columns re-ordered by descending norm (= ascending eigenvalue once the columns are nearly orthogonal):
+// a cold solve switches from tournament sweeps to hybrid sweeps through this, because the hybrid
+// sweep finds the near-degenerate pairs by their distance in that order.
+__global__ void lgj_sort_columns(int LD, const double *Gc, const double *nrm, double *out) {
+  const int k = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (k >= LD) return;
+  const double mine = nrm[k];
+  int before = 0;
+  for (int j = lane; j < LD; j += 64) {
+    const double o = nrm[j];
+    before += (o > mine || (o == mine && j < k)) ? 1 : 0;
+  }
+  const int pos = (int)wave_sum((double)before);
+  for (int r = lane; r < LD; r += 64) out[(size_t)pos * LD + r] = Gc[(size_t)k * LD + r];
+}
+
 // lam = sigma - |g_k| ; Ut[pos][r] = U[r][pos] = -g_k[r] / |g_k|   (A' negative definite), with
 // pos = rank of |g_k| in descending order (eigenvalues ascending).  Sorted output keeps
 // near-degenerate eigenvectors in neighbouring columns, i.e. inside one 16-column group of the
