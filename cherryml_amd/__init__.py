@@ -6,6 +6,8 @@ from .estimation_end_to_end import (coevolution_end_to_end_with_cherryml_optimiz
                                     lg_end_to_end_with_cherryml_optimizer)
 from ._siterm import learn_site_specific_rate_matrices, quantized_transitions_mle_vectorized_over_sites  # noqa: F401
 from .bank import CherryBank  # noqa: F401
+from .evaluation import compute_log_likelihoods  # noqa: F401,E402
+from .phylogeny_estimation import fast_cherries  # noqa: F401,E402
 from ._cherryml_public_api import cherryml_public_api  # noqa: F401,E402
 from .estimation import (RateMatrix, RateMatrixLearner, jtt_ipw, quantized_transitions_mle,  # noqa: F401
                          train_quantization)
@@ -13,7 +15,7 @@ from .estimation import (RateMatrix, RateMatrixLearner, jtt_ipw, quantized_trans
 __all__ = [
     "CherryBank", "RateMatrix", "RateMatrixLearner", "train_quantization",
     "quantized_transitions_mle", "quantized_transitions_mle_vectorized_over_sites", "jtt_ipw",
-    "learn_site_specific_rate_matrices", "cherryml_public_api",
+    "learn_site_specific_rate_matrices", "cherryml_public_api", "compute_log_likelihoods", "fast_cherries",
     "io", "caching", "counting", "count_transitions", "count_co_transitions",
     "lg_end_to_end_with_cherryml_optimizer", "coevolution_end_to_end_with_cherryml_optimizer",
 ]
