@@ -653,376 +653,7 @@ static int launch_small(cb_bank *h, const SmallArgs &a) {
 }
 
 // --------------------------------------------------------------- large path
-static void launch_sg(cb_bank *h, const K4Args &g, int ns, double alpha = 0.0, double beta = 0.0) {
-  if (getenv("CB_OLD_K4") && !ns) {
-    const int t = (h->LD + LG_TM - 1) / LG_TM;
-    hipLaunchKernelGGL(k4_gemm, dim3(t * t), dim3(LG_THREADS), 0, h->stream, g);
-    return;
-  }
-  const unsigned nwg = (unsigned)((h->LD / 16) * ((h->LD + 79) / 80));
-  static const int variant = getenv("CB_SG_VARIANT") ? atoi(getenv("CB_SG_VARIANT")) : 1;
-  if (variant == 0) hipLaunchKernelGGL((sg_gemm<4, 4>), dim3(nwg), dim3(256), 0, h->stream, g, ns, alpha, beta);
-  else if (variant == 1) hipLaunchKernelGGL((sg_gemm<8, 4>), dim3(nwg), dim3(512), 0, h->stream, g, ns, alpha, beta);
-  else hipLaunchKernelGGL((sg_gemm<8, 7>), dim3(nwg), dim3(512), 0, h->stream, g, ns, alpha, beta);
-}
-
-static int large_eigh(cb_bank *h, bool warm) {
-  const int LD = h->LD;
-  const size_t LL = (size_t)LD * LD;
-  hipLaunchKernelGGL(lgj_sigma, dim3(1), dim3(256), 0, h->stream, LD, h->A, h->sigma, h->off_bits);
-  const bool warm_started = warm && h->have_prev && !getenv("CB_NO_WARM");
-  bool gr_valid = false;   // the row-major copy of G (first-order sweeps) is current
-  if (warm_started) {
-    // Warm start: Jacobi from the previous epoch's orthonormal basis V0 = U_prev,
-    //   G0 = A' V0 :  Gc[k][r] = sum_j U_prev[j][k] A[j][r] - sigma Ut_prev[k][r]
-    // (A changes by one optimiser step, so G0's columns are nearly orthogonal already).
-    const int tm = (LD + LG_TM - 1) / LG_TM, tn = (LD + LG_TN - 1) / LG_TN;
-    K4Args g0{h->S, LD, h->U, h->A, h->Gc, nullptr, h->Vc, h->sigma};
-    g0.outT = h->gx + 11 * LL + (size_t)((LD + 7) & ~7);   // row-major copy for the first sweep's Gram product
-    gr_valid = true;
-    (void)tm; (void)tn;
-    launch_sg(h, g0, 0);
-  } else {
-    hipLaunchKernelGGL(lgj_init, dim3((unsigned)((LL + 255) / 256)), dim3(256), 0, h->stream, LD,
-                       h->A, h->sigma, h->Gc);
-  }
-  h->have_prev = false;
-  const int nb = LD / JB_W;
-  const int RS = LD + ((2 - LD % 32 + 32) % 32);
-  const size_t lds = (size_t)(16 * RS + 3 * 16 * 17 + JB_WAVES * 256) * sizeof(double);
-  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(lgj_round),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  const int max_sweeps = 40;
-  const char *env_inner = getenv("CB_INNER_SWEEPS");
-  const int inner_sweeps = env_inner ? atoi(env_inner) : 0;  // 0 = each pair once per sweep
-  const char *env_within = getenv("CB_WITHIN_SWEEPS");
-  const char *env_passes = getenv("CB_WITHIN_PASSES");
-  const int within = env_within ? atoi(env_within) : 6;
-  const int passes = env_passes ? atoi(env_passes) : 2;
-  unsigned long long *dbg_stamps = nullptr;
-  if (getenv("CB_DEBUG_STAMPS")) HIP_TRY(hipMalloc((void **)&dbg_stamps, 8 * sizeof(unsigned long long)));
-  // (h->off_bits[0..63] were zeroed by lgj_sigma, the first kernel of the solve)
-  double prev_cos = 1.0;     // largest cosine seen by the previous first-order sweep of this solve
-  auto enqueue_sweep = [&](int sweep) {
-    gr_valid = false;
-    if (inner_sweeps == 0) {
-      // within passes: each 16-column group fully diagonalised (all 120 pairs, to convergence);
-      // the group alignment alternates so that the groups overlap by one block
-      for (int w = 0; w < passes; ++w)
-        hipLaunchKernelGGL(lgj_round, dim3(nb / 2), dim3(JB_THREADS), lds, h->stream, LD,
-                           ((sweep + w) & 1) && nb > 2 ? -2 : -1, within, h->Gc, h->off_bits,
-                           (unsigned long long *)nullptr);
-    }
-    for (int r = 0; r < nb - 1; ++r)
-      hipLaunchKernelGGL(lgj_round, dim3(nb / 2), dim3(JB_THREADS), lds, h->stream, LD, r,
-                         inner_sweeps, h->Gc, h->off_bits,
-                         (dbg_stamps && sweep == 2 && r == 5) ? dbg_stamps : nullptr);
-    // a sweep that STARTS below 1e-8 ends at rounding level (quadratic convergence)
-    hipLaunchKernelGGL(lgj_check, dim3(1), dim3(64), 0, h->stream, h->off_bits, 1e-8);
-  };
-  // First-order sweep (jacobi_block.hip.h, lgx_*): Gamma = G^T G, X_ij = Gamma_ij / (Gamma_jj - Gamma_ii),
-  // G <- G exp(X).  Returns 1 when applied and final (solve finished), 2 when applied but another one
-  // is needed, 3 when applied to the FAR pairs only (hybrid sweep: the caller now rotates the pairs
-  // within `band` blocks exactly, by banded Jacobi rounds), 0 when its preconditions do not hold
-  // (nothing changed), < 0 on error.
-  //   exp(X): |X| <= 1e-5 second order, <= 2e-3 fourth order, else 8th order (Paterson-Stockmeyer,
-  //   4 products) on X / 2^s + s squarings + one Newton-Schulz step (the squarings amplify rounding).
-  const int band = getenv("CB_HYBRID_BAND") ? atoi(getenv("CB_HYBRID_BAND")) : 3;
-  const int ns_from = getenv("CB_HYBRID_NS_FROM") ? atoi(getenv("CB_HYBRID_NS_FROM")) : 2;  // squarings without a polish
-  const bool dbg_e = getenv("CB_DEBUG") != nullptr;
-  auto light_sweep = [&](bool hybrid_ok, double trigger) -> int {
-    double *Gr = h->gx, *Gam = h->gx + LL, *X = h->gx + 2 * LL, *Xf = h->gx + 3 * LL, *P4 = h->gx + 4 * LL,
-           *lo = h->gx + 5 * LL, *hiT = h->gx + 6 * LL, *R = h->gx + 7 * LL, *Rt = h->gx + 8 * LL, *R2 = h->gx + 9 * LL, *Rt2 = h->gx + 10 * LL, *dg = h->gx + 11 * LL;
-    const int nt32 = (LD + 31) / 32;
-    const unsigned nel = (unsigned)((LL + 255) / 256);
-    // Gr = G row-major: from the previous sweep's last product when nothing touched G since
-    // (Grn then holds it), else by a transposition
-    double *Grn = h->gx + 11 * LL + (size_t)((LD + 7) & ~7);
-    if (gr_valid) {
-      Gr = Grn;
-      // (with the pinned-memory route lgx_build's last workgroup re-zeroes its statistics itself)
-      if (!h->poll) HIP_TRY(hipMemsetAsync(h->off_bits + 4, 0, 4 * sizeof(unsigned long long), h->stream));
-    } else {
-      hipLaunchKernelGGL(lgx_transpose, dim3(nt32, nt32), dim3(32, 8), 0, h->stream, LD, h->Gc, Gr, h->off_bits + 4);
-    }
-    gr_valid = false;
-    launch_sg(h, K4Args{h->S, LD, Gr, Gr, Gam, nullptr, nullptr, nullptr, nullptr, dg}, 0);
-    if (!h->poll && !getenv("CB_NO_POLL")) {
-      void *q = nullptr;
-      if (hipHostMalloc(&q, 8 * sizeof(unsigned long long), hipHostMallocCoherent | hipHostMallocMapped) == hipSuccess) {
-        h->poll = (unsigned long long *)q;
-        memset(q, 0, 8 * sizeof(unsigned long long));
-      } else {
-        (void)hipGetLastError();
-      }
-    }
-    const unsigned long long seq = ++h->poll_seq;
-    hipLaunchKernelGGL(lgx_build, dim3((LD + 3) / 4), dim3(256), 0, h->stream, LD, Gam, dg, X, Xf, band, h->off_bits,
-                       (volatile unsigned long long *)h->poll, seq, hybrid_ok ? 1 : 0, trigger);
-    // Speculation: the powers of X do not depend on anything the host decides except WHICH X, and
-    // lgx_build's last workgroup has left that choice in off_bits[3] for sg_gemm to read.  So they are
-    // enqueued now and run while the statistics travel to the host (that round trip was a 14-19 us
-    // hole in every sweep).  X^3 and X^4 only when the sweep is expected to need them.
-    double *P2 = Gr, *P3 = Gam;                                            // both free once lgx_build has run
-    const bool spec = h->poll != nullptr && !getenv("CB_NO_SPECULATE");
-    const bool spec_deep = spec && !(prev_cos <= 1e-4);
-    bool have_p2 = false, have_p34 = false;
-    if (spec) {
-      const unsigned long long *sel = h->off_bits + 3;
-      launch_sg(h, K4Args{h->S, LD, X, X, P2, nullptr, nullptr, nullptr, nullptr, nullptr, sel, Xf, Xf}, 0);   // X^T X   = -X^2
-      have_p2 = true;
-      if (spec_deep) {
-        launch_sg(h, K4Args{h->S, LD, X, P2, P3, nullptr, nullptr, nullptr, nullptr, nullptr, sel, Xf, nullptr}, 0);  // X^T P2 = X^3
-        launch_sg(h, K4Args{h->S, LD, P2, P2, P4, nullptr, nullptr, nullptr}, 0);                                      // P2^T P2 = X^4
-        have_p34 = true;
-      }
-    }
-    unsigned long long m[4] = {};
-    bool got = false;
-    if (h->poll) {
-      // spin on the pinned words (a few microseconds after the kernel's last workgroup); give up
-      // after 20 ms and take the ordinary route
-      volatile unsigned long long *pl = h->poll;
-      const auto t_spin = std::chrono::steady_clock::now();
-      for (unsigned it = 0;; ++it) {
-        if (pl[0] == seq) {
-          std::atomic_thread_fence(std::memory_order_acquire);
-          m[0] = pl[1];
-          m[1] = pl[2];
-          m[2] = pl[3];
-          m[3] = pl[4];
-          got = true;
-          break;
-        }
-        if ((it & 1023u) == 1023u &&
-            std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_spin).count() > 20.0)
-          break;
-      }
-    }
-    if (!got && h->poll) {   // a long queue ahead of the sweep: wait for the stream, the words are there then
-      HIP_TRY(hipStreamSynchronize(h->stream));
-      volatile unsigned long long *pl = h->poll;
-      if (pl[0] != seq) return fail(CB_EHIP, "eigensolver: the sweep statistics never reached the host");
-      std::atomic_thread_fence(std::memory_order_acquire);
-      m[0] = pl[1];
-      m[1] = pl[2];
-      m[2] = pl[3];
-      m[3] = pl[4];
-      got = true;
-    }
-    if (!got) {
-      HIP_TRY(hipMemcpyAsync(m, h->off_bits + 4, 3 * sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
-      HIP_TRY(hipStreamSynchronize(h->stream));
-    }
-    double cosmax, rowsum, rowsum_far;
-    memcpy(&cosmax, &m[0], sizeof cosmax);
-    memcpy(&rowsum, &m[1], sizeof rowsum);
-    memcpy(&rowsum_far, &m[2], sizeof rowsum_far);
-    if (dbg_e)
-      fprintf(stderr, "[cherrybank] eigh first-order sweep: max cosine %.3e, |X| <= %.3e (far pairs: %.3e)\n", cosmax,
-              rowsum, rowsum_far);
-    if (!(cosmax == cosmax) || !(rowsum == rowsum)) return fail(CB_ENUMERIC, "eigensolver: non-finite input");
-    prev_cos = cosmax;
-    bool masked = false;
-    if (hybrid_ok) {
-      // all pairs at once only when the state is close enough for the small-angle limit to hold for
-      // the near-degenerate neighbours too (the same rule, on the same numbers, as lgx_build's)
-      if (cosmax > trigger || rowsum > 0.5) {
-        masked = true;
-        rowsum = rowsum_far;
-        if (rowsum > 12.0) return 0;
-      }
-      if (got && masked != (m[3] != 0ull)) return fail(CB_ENUMERIC, "eigensolver: host and device disagree on the sweep kind");
-    } else if (rowsum > 2e-3) {
-      return 0;
-    }
-    const double *Xu = masked ? Xf : X;
-    double *Rfin = R;
-    if (!have_p2) launch_sg(h, K4Args{h->S, LD, Xu, Xu, P2, nullptr, nullptr, nullptr}, 0);    // X^T X = -X^2
-    if (rowsum <= 1e-5) {
-      hipLaunchKernelGGL(lgx_combine, dim3(nel), dim3(256), 0, h->stream, LD, Xu, P2, (const double *)nullptr,
-                         (const double *)nullptr, R);                                              // R = I + X + X^2 / 2
-    } else {
-      if (!have_p34) {
-        launch_sg(h, K4Args{h->S, LD, Xu, P2, P3, nullptr, nullptr, nullptr}, 0);   // X^T P2  =  X^3
-        launch_sg(h, K4Args{h->S, LD, P2, P2, P4, nullptr, nullptr, nullptr}, 0);   // P2^T P2 =  X^4
-      }
-      if (rowsum <= 2e-3) {
-        hipLaunchKernelGGL(lgx_combine, dim3(nel), dim3(256), 0, h->stream, LD, Xu, P2, P3, P4, R);
-      } else {
-        int sq = 0;
-        double sc = 1.0;
-        while (rowsum * sc > 0.075) {
-          sc *= 0.5;
-          ++sq;
-        }
-        hipLaunchKernelGGL(lgx_poly8, dim3(nel), dim3(256), 0, h->stream, LD, sc, Xu, P2, P3, P4, lo, hiT);
-        const double sc2 = sc * sc;
-        // (every product also writes its transpose: the next step needs R^T as the k-major operand)
-        launch_sg(h, K4Args{h->S, LD, hiT, P4, R, nullptr, lo, nullptr, sq > 0 ? Rt : nullptr}, 2, sc2 * sc2, 1.0);  // R = lo + hi Y^4
-        double *cur = R, *nxt = R2, *curT = Rt, *nxtT = Rt2;
-        for (int q = 0; q < sq; ++q) {                                        // R <- R R
-          launch_sg(h, K4Args{h->S, LD, curT, cur, nxt, nullptr, nullptr, nullptr, nxtT}, 0);
-          std::swap(cur, nxt);
-          std::swap(curT, nxtT);
-        }
-        if (sq > ns_from) {                                                   // R <- R (3 I - R^T R) / 2
-          double *N = lo;                                                     // free by now
-          launch_sg(h, K4Args{h->S, LD, cur, cur, N, nullptr, nullptr, nullptr}, 0);
-          launch_sg(h, K4Args{h->S, LD, curT, N, nxt, nullptr, cur, nullptr}, 2, -0.5, 1.5);
-          std::swap(cur, nxt);
-        }
-        Rfin = cur;
-      }
-    }
-    // Gc2[c'][r] = sum_c R[c][c'] Gc[c][r]  (+ its transpose for the next sweep's Gram product)
-    launch_sg(h, K4Args{h->S, LD, Rfin, h->Gc, h->Gc2, nullptr, nullptr, nullptr, masked ? nullptr : Grn}, 0);
-    std::swap(h->Gc, h->Gc2);
-    gr_valid = !masked;
-    if (masked) return 3;
-    return cosmax <= 1e-8 ? 1 : 2;
-  };
-  // Banded Jacobi pass of the hybrid sweep: every column pair at most `band` blocks apart is rotated
-  // exactly -- distance <= 1 by the two within passes (16-column groups, both alignments, to
-  // convergence), distance k = 2..band by two rounds of disjoint block pairs (i, i + k).
-  const int hybrid_within = getenv("CB_HYBRID_WITHIN") ? atoi(getenv("CB_HYBRID_WITHIN")) : 3;
-  auto band_pass = [&](int shift) {
-    gr_valid = false;
-    for (int w = 0; w < 2; ++w)
-      hipLaunchKernelGGL(lgj_round, dim3(nb / 2), dim3(JB_THREADS), lds, h->stream, LD,
-                         ((shift + w) & 1) && nb > 2 ? -2 : -1, hybrid_within, h->Gc, h->off_bits,
-                         (unsigned long long *)nullptr);
-    for (int k = 2; k <= band && k < nb; ++k)
-      for (int par = 0; par < 2; ++par)
-        hipLaunchKernelGGL(lgj_round, dim3((unsigned)(((nb + 2 * k - 1) / (2 * k)) * k)), dim3(JB_THREADS), lds,
-                           h->stream, LD, -(10 + 2 * (k - 2) + par), 0, h->Gc, h->off_bits,
-                           (unsigned long long *)nullptr);
-  };
-  // Sweeps are enqueued without waiting for the host: as many as the previous (warm) solve needed,
-  // then one at a time.  Launches after convergence return immediately.  Once a sweep started
-  // below 2e-5 the state is expected below 1e-8 and the first-order sweep is tried.
-  int sweep = 0, enq = 0;
-  unsigned long long st[64] = {};
-  const bool use_light = !getenv("CB_NO_LIGHT");
-  const double light_trigger = getenv("CB_LIGHT_TRIGGER") ? atof(getenv("CB_LIGHT_TRIGGER")) : 3e-4;
-  const bool speculate = warm && h->last_sweeps > 1 && !getenv("CB_NO_SPECULATE");
-  int batch = speculate ? std::max(1, h->spec_sweeps) : 1;
-  bool converged = false;
-  int light_done = 0;
-  // Hybrid solve (warm start only): the per-epoch perturbation mixes eigenvectors whose eigenvalues
-  // are close (a few blocks apart in the sorted order) by large angles and all others by small ones.
-  // So a sweep = ONE first-order rotation of all far pairs (GEMMs) + `reps` banded Jacobi passes
-  // over the near pairs (2 * band launches each) instead of LD/8 + 1 tournament rounds; it
-  // converges like a full Jacobi sweep.  Falls through to the Jacobi loop below when it refuses.
-  const int hybrid_reps = getenv("CB_HYBRID_REPS") ? atoi(getenv("CB_HYBRID_REPS")) : 1;
-  int hybrid_iters = 0;
-  auto run_hybrid = [&]() -> int {   // 1: converged; 0: gave up, G is valid, carry on with tournament sweeps; < 0: error
-    prev_cos = 1.0;
-    for (int it = 0; it < 12; ++it) {
-      const int lr = light_sweep(true, light_trigger);
-      if (lr < 0) return lr;
-      if (lr == 0) break;
-      ++hybrid_iters;
-      if (lr == 3)
-        for (int rep = 0; rep < hybrid_reps; ++rep) band_pass(it + rep);
-      if (lr == 1) return 1;
-    }
-    HIP_TRY(hipMemsetAsync(h->off_bits, 0, sizeof(unsigned long long), h->stream));   // the sweep's running maximum
-    return 0;
-  };
-  const bool hybrid_on = use_light && nb >= 8 && !getenv("CB_NO_HYBRID");
-  if (warm_started && hybrid_on) {
-    const int hr = run_hybrid();
-    if (hr < 0) return hr;
-    if (hr == 1) {
-      converged = true;
-      light_done = 1;
-    }
-  }
-  // A COLD solve takes tournament sweeps until one of them started below `cold_switch`, then sorts its
-  // columns by norm (the eigenvalue order the hybrid sweep relies on) and finishes with hybrid sweeps.
-  bool cold_hybrid_pending = !warm_started && hybrid_on && !getenv("CB_NO_COLD_HYBRID");
-  const double cold_switch = getenv("CB_COLD_SWITCH") ? atof(getenv("CB_COLD_SWITCH")) : 3e-2;
-  for (; !converged;) {
-    for (int i = 0; i < batch && enq < max_sweeps; ++i) enqueue_sweep(enq++);
-    HIP_TRY(hipMemcpyAsync(st, h->off_bits, sizeof st, hipMemcpyDeviceToHost, h->stream));
-    HIP_TRY(hipStreamSynchronize(h->stream));
-    sweep = (int)st[2];
-    double c_last = 1.0;
-    for (int k = 0; k < sweep && k < 48; ++k) {
-      double off;
-      memcpy(&off, &st[8 + k], sizeof off);
-      if (k == sweep - 1) c_last = off;
-      if (getenv("CB_DEBUG") && k >= sweep - batch) fprintf(stderr, "[cherrybank] eigh sweep %d: max cosine %.3e\n", k, off);
-    }
-    if (st[1] == 2ull) return fail(CB_ENUMERIC, "eigensolver: non-finite input");
-    if (st[1] == 1ull) {
-      converged = true;
-      break;
-    }
-    if (cold_hybrid_pending && c_last <= cold_switch) {
-      cold_hybrid_pending = false;
-      hipLaunchKernelGGL(lgj_norms, dim3((LD + 3) / 4), dim3(256), 0, h->stream, LD, h->Gc, h->X);
-      hipLaunchKernelGGL(lgj_sort_columns, dim3((LD + 3) / 4), dim3(256), 0, h->stream, LD, h->Gc, h->X, h->Gc2);
-      std::swap(h->Gc, h->Gc2);
-      gr_valid = false;
-      const int iters_before = hybrid_iters;
-      const int hr = run_hybrid();
-      if (hr < 0) return hr;
-      if (hr == 1) {
-        converged = true;
-        light_done = 1;
-        break;
-      }
-      if (hybrid_iters == iters_before) cold_hybrid_pending = true;   // refused outright (still too far): ask again after the next sweep
-    }
-    if (use_light && c_last <= light_trigger) {
-      int lr = 2, guard = 0;
-      while (lr == 2 && guard++ < 4) lr = light_sweep(false, light_trigger);
-      if (lr < 0) return lr;
-      if (lr == 1) {
-        converged = true;
-        light_done = 1;
-        break;
-      }
-    }
-    if (enq >= max_sweeps) break;
-    batch = 1;
-  }
-  h->last_light = light_done;
-  {
-    // how many Jacobi sweeps would have been enough: up to the first one that started below the
-    // first-order trigger (then first-order sweeps finish), else all but the verification sweep
-    int need = std::max(1, sweep - 1);
-    if (use_light)
-      for (int k = 0; k < sweep && k < 48; ++k) {
-        double off;
-        memcpy(&off, &st[8 + k], sizeof off);
-        if (off <= light_trigger) {
-          need = k + 1;
-          break;
-        }
-      }
-    h->spec_sweeps = need;
-  }
-  h->last_sweeps = sweep + hybrid_iters;
-  if (dbg_stamps) {
-    unsigned long long st[8];
-    HIP_TRY(hipMemcpy(st, dbg_stamps, sizeof st, hipMemcpyDeviceToHost));
-    (void)hipFree(dbg_stamps);
-    const char *names[] = {"stage", "gram", "reduce+sync", "offmeasure", "inner", "NS+sync", "apply"};
-    for (int i = 0; i < 6; ++i)
-      fprintf(stderr, "[cherrybank] lgj_round %-12s %6llu ticks (100 MHz)\n", names[i == 2 ? 3 : (i > 2 ? i + 1 : i)],
-              st[i + 1] - st[i]);
-  }
-  if (!converged) return fail(CB_ENUMERIC, "block Jacobi did not converge in %d sweeps", max_sweeps);
-  hipLaunchKernelGGL(lgj_norms, dim3((LD + 3) / 4), dim3(256), 0, h->stream, LD, h->Gc, h->X);
-  hipLaunchKernelGGL(lgj_finish, dim3((LD + 3) / 4), dim3(256), 0, h->stream, LD, h->Gc, h->X, h->sigma,
-                     h->lam, h->U, h->Vc);
-  HIP_TRY(hipGetLastError());
-  h->have_prev = true;
-  return CB_OK;
-}
+#include "eigh_large_host.hip.h"   // launch_sg, large_eigh
 
 // h->A (padded, symmetric) and h->dsq are filled.  Output: dQ (S x S, dQ = D^1/2 dA D^-1/2) when
 // `dA_padded` is false, else dL/dA itself as a padded LD x LD matrix.
