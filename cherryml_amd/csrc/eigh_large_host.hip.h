@@ -12,8 +12,9 @@ static void launch_sg(cb_bank *h, const K4Args &g, int ns, double alpha = 0.0, d
     hipLaunchKernelGGL(k4_gemm, dim3(t * t), dim3(LG_THREADS), 0, h->stream, g);
     return;
   }
-  const unsigned nwg = (unsigned)((h->LD / 16) * ((h->LD + 79) / 80));
   static const int variant = getenv("CB_SG_VARIANT") ? atoi(getenv("CB_SG_VARIANT")) : 1;
+  // (narrower strips -- sg_gemm's NJ = 1 or 2, 2.5-5x the workgroups -- were measured slower: eigh 0.60 -> 0.62-1.01 ms)
+  const unsigned nwg = (unsigned)((h->LD / 16) * ((h->LD + 79) / 80));
   if (variant == 0) hipLaunchKernelGGL((sg_gemm<4, 4>), dim3(nwg), dim3(256), 0, h->stream, g, ns, alpha, beta);
   else if (variant == 1) hipLaunchKernelGGL((sg_gemm<8, 4>), dim3(nwg), dim3(512), 0, h->stream, g, ns, alpha, beta);
   else hipLaunchKernelGGL((sg_gemm<8, 7>), dim3(nwg), dim3(512), 0, h->stream, g, ns, alpha, beta);

@@ -480,37 +480,39 @@ __global__ __launch_bounds__(LG_THREADS) void k4_gemm(K4Args a) {
 //   ns == 1 :  out = (row == col) + sub[row][col] - acc / 2      (R = I + X + X^2/2, X^2 = -X^T X)
 //   ns == 2 :  out = alpha * acc + beta * sub[row][col]          (polynomial / Newton-Schulz steps of the
 //                                                                 first-order sweeps, jacobi_block.hip.h)
-template <int NW, int UU>
+// NJ = 16-column tiles per workgroup (strip 16 x 16 NJ): fewer -> more workgroups and shorter waves
+// (these single 400^3 products are latency bound, not MFMA bound).
+template <int NW, int UU, int NJ = 5>
 __global__ __launch_bounds__(NW * 64) void sg_gemm(K4Args a, int ns, double alpha, double beta) {
-  __shared__ double sRed[4][5][256];
-  const int LD = a.LD, tilesN = (LD + 79) / 80;
+  __shared__ double sRed[4][NJ][256];
+  const int LD = a.LD, tilesN = (LD + 16 * NJ - 1) / (16 * NJ);
   const int tm = blockIdx.x / tilesN, tn = blockIdx.x - tm * tilesN;
-  const int m0 = tm * 16, n0 = tn * 80;
+  const int m0 = tm * 16, n0 = tn * 16 * NJ;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, lo = lane & 15, hi = lane >> 4;
-  d4 acc[5];
+  d4 acc[NJ];
 #pragma unroll
-  for (int j = 0; j < 5; ++j) acc[j] = d4{0.0, 0.0, 0.0, 0.0};
-  int ncol[5];
+  for (int j = 0; j < NJ; ++j) acc[j] = d4{0.0, 0.0, 0.0, 0.0};
+  int ncol[NJ];
 #pragma unroll
-  for (int j = 0; j < 5; ++j) ncol[j] = min(n0 + 16 * j + lo, LD - 1);  // clamped: tiles past LD are discarded
+  for (int j = 0; j < NJ; ++j) ncol[j] = min(n0 + 16 * j + lo, LD - 1);  // clamped: tiles past LD are discarded
   const int nsteps = LD / 4;
   const bool alt = a.sel && *a.sel != 0ull;
   const double *Ap = (alt && a.Aalt ? a.Aalt : a.Aop) + m0 + lo, *Bp = alt && a.Balt ? a.Balt : a.Bop;
   for (int s0 = wave; s0 < nsteps; s0 += UU * NW) {   // UU k-steps of this wave in flight
-    double av[UU], bv[UU][5];
+    double av[UU], bv[UU][NJ];
 #pragma unroll
     for (int u = 0; u < UU; ++u) {
       const int s = min(s0 + NW * u, nsteps - 1);
       const size_t krow = (size_t)(4 * s + hi) * LD;
       av[u] = Ap[krow];
 #pragma unroll
-      for (int j = 0; j < 5; ++j) bv[u][j] = Bp[krow + ncol[j]];
+      for (int j = 0; j < NJ; ++j) bv[u][j] = Bp[krow + ncol[j]];
     }
 #pragma unroll
     for (int u = 0; u < UU; ++u) {
       if (s0 + NW * u < nsteps) {
 #pragma unroll
-        for (int j = 0; j < 5; ++j) acc[j] = mfma_f64(av[u], bv[u][j], acc[j]);
+        for (int j = 0; j < NJ; ++j) acc[j] = mfma_f64(av[u], bv[u][j], acc[j]);
       }
     }
   }
@@ -518,14 +520,14 @@ __global__ __launch_bounds__(NW * 64) void sg_gemm(K4Args a, int ns, double alph
   for (int half = NW / 2; half >= 4; half >>= 1) {
     if (wave >= half && wave < 2 * half) {
 #pragma unroll
-      for (int j = 0; j < 5; ++j)
+      for (int j = 0; j < NJ; ++j)
 #pragma unroll
         for (int r = 0; r < 4; ++r) sRed[wave - half][j][r * 64 + lane] = acc[j][r];
     }
     __syncthreads();
     if (wave < half) {
 #pragma unroll
-      for (int j = 0; j < 5; ++j)
+      for (int j = 0; j < NJ; ++j)
 #pragma unroll
         for (int r = 0; r < 4; ++r) acc[j][r] += sRed[wave][j][r * 64 + lane];
     }
@@ -533,7 +535,7 @@ __global__ __launch_bounds__(NW * 64) void sg_gemm(K4Args a, int ns, double alph
   }
   if (wave < 4) {
 #pragma unroll
-    for (int j = 0; j < 5; ++j)
+    for (int j = 0; j < NJ; ++j)
 #pragma unroll
       for (int r = 0; r < 4; ++r) sRed[wave][j][r * 64 + lane] = acc[j][r];
   }
@@ -542,7 +544,7 @@ __global__ __launch_bounds__(NW * 64) void sg_gemm(K4Args a, int ns, double alph
   const int t = threadIdx.x, r = t >> 6, l = t & 63;
   const int row = m0 + (l >> 4) + 4 * r;
 #pragma unroll
-  for (int j = 0; j < 5; ++j) {
+  for (int j = 0; j < NJ; ++j) {
     const int col = n0 + 16 * j + (l & 15);
     if (col >= LD) continue;
     const double v = (sRed[0][j][t] + sRed[1][j][t]) + (sRed[2][j][t] + sRed[3][j][t]);
