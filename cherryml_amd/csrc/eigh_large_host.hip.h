@@ -13,7 +13,8 @@ static void launch_sg(cb_bank *h, const K4Args &g, int ns, double alpha = 0.0, d
     return;
   }
   static const int variant = getenv("CB_SG_VARIANT") ? atoi(getenv("CB_SG_VARIANT")) : 1;
-  // (narrower strips -- sg_gemm's NJ = 1 or 2, 2.5-5x the workgroups -- were measured slower: eigh 0.60 -> 0.62-1.01 ms)
+  // (both neighbours of this shape were measured slower: narrower strips -- NJ = 1 or 2, 2.5-5x the workgroups, more
+  // L2 -> CU panel traffic -- eigh 0.60 -> 0.62-1.01 ms; two row tiles per workgroup -- half the workgroups -- 0.74-0.77 ms)
   const unsigned nwg = (unsigned)((h->LD / 16) * ((h->LD + 79) / 80));
   if (variant == 0) hipLaunchKernelGGL((sg_gemm<4, 4>), dim3(nwg), dim3(256), 0, h->stream, g, ns, alpha, beta);
   else if (variant == 1) hipLaunchKernelGGL((sg_gemm<8, 4>), dim3(nwg), dim3(512), 0, h->stream, g, ns, alpha, beta);
