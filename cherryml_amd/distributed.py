@@ -54,7 +54,9 @@ class RcclCommunicator:
         import ctypes as C
         import glob
         import os
-        libs = sorted(glob.glob(os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so*")))
+        # the RCCL torch itself uses (one library, one set of kernels); CHERRYML_AMD_RCCL_LIB overrides
+        libs = ([os.environ["CHERRYML_AMD_RCCL_LIB"]] if os.environ.get("CHERRYML_AMD_RCCL_LIB") else
+                sorted(glob.glob(os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so*"))))
         if not libs:
             raise RuntimeError("RcclCommunicator: no librccl next to torch")
         self._rccl = rccl = C.CDLL(libs[0])

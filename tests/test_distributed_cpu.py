@@ -143,3 +143,41 @@ def test_nccl_unique_id_travels_whole():
     with pytest.raises(ValueError):
         _uid_from_bytes(raw[:100])
     assert isinstance(uid, _NcclUniqueId)
+
+
+def _rccl_worker(rank, world, port, lib, outdir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), CHERRYML_AMD_RCCL_LIB=lib, FAKE_RCCL_OUT=outdir)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from cherryml_amd.distributed import RcclCommunicator
+        comm = RcclCommunicator()
+        assert comm.rank == rank and comm.world == world and comm.comm and comm.allreduce_fn
+        comm.destroy()
+        assert comm.comm is None
+    finally:
+        dist.destroy_process_group()
+
+
+def test_rccl_communicator_control_flow_two_ranks(tmp_path):
+    """RcclCommunicator on two gloo ranks with a test double for librccl (tests/fixtures/fake_rccl.c, built
+    here with gcc): rank 0 makes the unique id, every rank's ncclCommInitRank gets all 128 bytes of it
+    (embedded NULs included), its own rank and the world size.  The real thing (RCCL over xGMI) needs GPUs."""
+    import shutil
+    import subprocess
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    from conftest import ROOT
+    lib = str(tmp_path / "libfake_rccl.so")
+    subprocess.check_call(["gcc", "-shared", "-fPIC", "-O1", "-o", lib, os.path.join(ROOT, "tests", "fixtures", "fake_rccl.c")])
+    out = tmp_path / "out"
+    out.mkdir()
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_rccl_worker, args=(2, port, lib, str(out)), nprocs=2, join=True)
+    want = bytes([42, 0, 0, 7] + [((i * 37 + 11) & 0xff) for i in range(4, 128)])
+    want = want[:64] + b"\0" + want[65:]
+    for rank in range(2):
+        raw = (out / f"rank{rank}.bin").read_bytes()
+        assert int.from_bytes(raw[0:4], "little") == 2 and int.from_bytes(raw[4:8], "little") == rank
+        assert raw[8:] == want
