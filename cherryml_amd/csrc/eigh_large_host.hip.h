@@ -96,7 +96,7 @@ static int large_eigh(cb_bank *h, bool warm) {
     if (gr_valid) {
       Gr = Grn;
       // (with the pinned-memory route lgx_build's last workgroup re-zeroes its statistics itself)
-      if (!h->poll) HIP_TRY(hipMemsetAsync(h->off_bits + 4, 0, 4 * sizeof(unsigned long long), h->stream));
+      // (lgx_build's last workgroup leaves its counter at zero: nothing to clear)
     } else {
       hipLaunchKernelGGL(lgx_transpose, dim3(nt32, nt32), dim3(32, 8), 0, h->stream, LD, h->Gc, Gr, h->off_bits + 4);
     }
@@ -113,7 +113,8 @@ static int large_eigh(cb_bank *h, bool warm) {
     }
     const unsigned long long seq = ++h->poll_seq;
     hipLaunchKernelGGL(lgx_build, dim3((LD + 3) / 4), dim3(256), 0, h->stream, LD, Gam, dg, X, Xf, band, h->off_bits,
-                       (volatile unsigned long long *)h->poll, seq, hybrid_ok ? 1 : 0, trigger);
+                       (volatile unsigned long long *)h->poll, seq, hybrid_ok ? 1 : 0, trigger,
+                       (unsigned long long *)(h->gx + 12 * LL + (size_t)((LD + 7) & ~7) + 8));
     // Speculation: the powers of X do not depend on anything the host decides except WHICH X, and
     // lgx_build's last workgroup has left that choice in off_bits[3] for sg_gemm to read.  So they are
     // enqueued now and run while the statistics travel to the host (that round trip was a 14-19 us
@@ -176,7 +177,8 @@ static int large_eigh(cb_bank *h, bool warm) {
     if (dbg_e)
       fprintf(stderr, "[cherrybank] eigh first-order sweep: max cosine %.3e, |X| <= %.3e (far pairs: %.3e)\n", cosmax,
               rowsum, rowsum_far);
-    if (!(cosmax == cosmax) || !(rowsum == rowsum)) return fail(CB_ENUMERIC, "eigensolver: non-finite input");
+    if (!(cosmax == cosmax) || !(rowsum == rowsum) || cosmax > 1e300 || rowsum > 1e300)
+      return fail(CB_ENUMERIC, "eigensolver: non-finite input");
     prev_cos = cosmax;
     bool masked = false;
     if (hybrid_ok) {

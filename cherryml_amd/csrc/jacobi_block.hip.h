@@ -286,8 +286,9 @@ __global__ void lgx_transpose(int LD, const double *Gc, double *Gr, unsigned lon
 __global__ __launch_bounds__(256) void lgx_build(int LD, const double *Gam, const double *dg, double *X, double *Xf,
                                                  int band, unsigned long long *state,
                                                  volatile unsigned long long *poll, unsigned long long seq,
-                                                 int hybrid_ok, double trigger) {
-  __shared__ double s0[4], s1[4], s2[4];
+                                                 int hybrid_ok, double trigger, unsigned long long *part) {
+  __shared__ double s0[256], s1[256], s2[256];
+  __shared__ int s_last;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int i = blockIdx.x * 4 + wave;
   double mc2 = 0.0, rs = 0.0, rsf = 0.0;
@@ -308,6 +309,7 @@ __global__ __launch_bounds__(256) void lgx_build(int LD, const double *Gam, cons
         if (j >= LD) continue;
         double x = 0.0;
         const double g2 = g[u] * g[u], ab = gii * gj[u];
+        if (!(g2 == g2) || !(ab == ab)) mc2 = INFINITY;   // NaN in G: reported as an infinite cosine (fmax drops NaNs)
         if (j != i && g2 > ab * (CB_JAC_SKIP * CB_JAC_SKIP)) {
           mc2 = fmax(mc2, g2 * fast_rcp(ab));
           const double d = gj[u] - gii;
@@ -332,29 +334,62 @@ __global__ __launch_bounds__(256) void lgx_build(int LD, const double *Gam, cons
     s2[wave] = rsf;
   }
   __syncthreads();
+  // Per-workgroup maxima go to `part` (plain stores), ONE atomic per workgroup counts them in, and the
+  // last workgroup reduces the array with all its threads (three atomicMax per workgroup on the same
+  // words were serialised across the XCDs: most of this kernel's 12 us).
   if (threadIdx.x == 0) {
-    atomicMax(state + 4, dbl_bits(sqrt(fmax(fmax(s0[0], s0[1]), fmax(s0[2], s0[3])))));
-    atomicMax(state + 5, dbl_bits(fmax(fmax(s1[0], s1[1]), fmax(s1[2], s1[3]))));
-    atomicMax(state + 6, dbl_bits(fmax(fmax(s2[0], s2[1]), fmax(s2[2], s2[3]))));
+    part[3 * blockIdx.x + 0] = dbl_bits(fmax(fmax(s0[0], s0[1]), fmax(s0[2], s0[3])));
+    part[3 * blockIdx.x + 1] = dbl_bits(fmax(fmax(s1[0], s1[1]), fmax(s1[2], s1[3])));
+    part[3 * blockIdx.x + 2] = dbl_bits(fmax(fmax(s2[0], s2[1]), fmax(s2[2], s2[3])));
     __threadfence();
-    const unsigned long long done = atomicAdd(state + 7, 1ull);
-    if (poll && done == gridDim.x - 1) {
-      const unsigned long long c = atomicAdd(state + 4, 0ull), r = atomicAdd(state + 5, 0ull);
-      // which X the sweep rotates with (the host applies the same rule to the same numbers): far
-      // pairs only while the state is too far for the small-angle limit to hold for near neighbours
-      double cosmax, rowsum;
-      memcpy(&cosmax, &c, sizeof cosmax);
-      memcpy(&rowsum, &r, sizeof rowsum);
-      const unsigned long long sel = (hybrid_ok && (cosmax > trigger || rowsum > 0.5)) ? 1ull : 0ull;
-      state[3] = sel;              // read by the products enqueued behind this kernel (K4Args::sel)
-      poll[1] = c;
-      poll[2] = r;
-      poll[3] = atomicAdd(state + 6, 0ull);
+    s_last = atomicAdd(state + 7, 1ull) == gridDim.x - 1 ? 1 : 0;
+  }
+  __syncthreads();
+  if (!s_last) return;
+  __threadfence();
+  double m0 = 0.0, m1 = 0.0, m2 = 0.0;
+  for (int w = threadIdx.x; w < (int)gridDim.x; w += 256) {   // agent-scope loads: the other XCDs' stores
+    const unsigned long long b0 = __hip_atomic_load(part + 3 * w + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned long long b1 = __hip_atomic_load(part + 3 * w + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned long long b2 = __hip_atomic_load(part + 3 * w + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    double v0, v1, v2;
+    memcpy(&v0, &b0, 8);
+    memcpy(&v1, &b1, 8);
+    memcpy(&v2, &b2, 8);
+    m0 = fmax(m0, v0);
+    m1 = fmax(m1, v1);
+    m2 = fmax(m2, v2);
+  }
+  s0[threadIdx.x] = m0;
+  s1[threadIdx.x] = m1;
+  s2[threadIdx.x] = m2;
+  __syncthreads();
+  for (int st = 128; st >= 1; st >>= 1) {
+    if ((int)threadIdx.x < st) {
+      s0[threadIdx.x] = fmax(s0[threadIdx.x], s0[threadIdx.x + st]);
+      s1[threadIdx.x] = fmax(s1[threadIdx.x], s1[threadIdx.x + st]);
+      s2[threadIdx.x] = fmax(s2[threadIdx.x], s2[threadIdx.x + st]);
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    const double cosmax = sqrt(s0[0]), rowsum = s1[0];
+    // which X the sweep rotates with (the host applies the same rule to the same numbers): far
+    // pairs only while the state is too far for the small-angle limit to hold for near neighbours
+    const unsigned long long sel = (hybrid_ok && (cosmax > trigger || rowsum > 0.5)) ? 1ull : 0ull;
+    state[3] = sel;              // read by the products enqueued behind this kernel (K4Args::sel)
+    state[4] = dbl_bits(cosmax);   // (the copy route of CB_NO_POLL reads these three)
+    state[5] = dbl_bits(rowsum);
+    state[6] = dbl_bits(s2[0]);
+    state[7] = 0ull;             // the counter, ready for the next sweep
+    if (poll) {
+      poll[1] = dbl_bits(cosmax);
+      poll[2] = dbl_bits(rowsum);
+      poll[3] = dbl_bits(s2[0]);
       poll[4] = sel;
       __threadfence_system();
       poll[0] = seq;
       __threadfence_system();
-      state[4] = state[5] = state[6] = state[7] = 0ull;   // ready for the next sweep (no memset launch)
     }
   }
 }
