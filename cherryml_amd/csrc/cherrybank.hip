@@ -1983,3 +1983,6 @@ extern "C" int cb_tree_likelihood(int device, int S, int S1, const double *Q, co
   HIP_TRY(hipMemcpy(ll, dll, n_units * sizeof(double), hipMemcpyDeviceToHost));
   return CB_OK;
 }
+
+// ---------------------------------------------------------------- host-side text formats
+#include "host_io.hip.h"

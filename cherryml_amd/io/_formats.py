@@ -19,9 +19,9 @@ import pandas as pd
 
 def read_count_matrices_arrays(path: str) -> Tuple[np.ndarray, np.ndarray, List[str]]:
     """-> (q[B], C[B,S,S], states) as float64 arrays."""
-    with open(path, "r") as f:
-        head1 = f.readline().strip().split(" ")
-        head2 = f.readline().strip().split(" ")
+    with open(path, "rb") as f:     # bytes: the native parser takes them as they are (no decode / encode of 84 MB)
+        head1 = f.readline().decode("utf-8").strip().split(" ")
+        head2 = f.readline().decode("utf-8").strip().split(" ")
         body = f.read()
     if len(head1) != 2 or head1[1] != "matrices":
         raise Exception(f"In file {path}, expected line '[num_matrices] matrices', "
@@ -30,7 +30,10 @@ def read_count_matrices_arrays(path: str) -> Tuple[np.ndarray, np.ndarray, List[
         raise Exception(f"In file {path}, expected line '[num_states] states', "
                         f"but found: '{' '.join(head2)}'")
     B, S = int(head1[0]), int(head2[0])
-    tok = body.split()
+    native = _parse_native(path, body, B, S)
+    if native is not None:
+        return native
+    tok = body.decode("utf-8").split()
     per = 1 + S + S * (S + 1)
     if len(tok) != B * per:
         raise Exception(f"Error reading count matrices file: {path}\nExpected {B} blocks of "
@@ -44,6 +47,29 @@ def read_count_matrices_arrays(path: str) -> Tuple[np.ndarray, np.ndarray, List[
             raise Exception(f"Error reading count matrices file: {path}: state labels of "
                             f"matrix {b} differ from the first matrix")
     C = grid[:, :, 1:].astype(np.float64)
+    return q, C, states
+
+
+def _parse_native(path: str, raw: bytes, B: int, S: int):
+    """The body through libcherrybank's host-side parser (cb_parse_count_matrices: all host threads, exact
+    decimal -> double conversion; no GPU needed).  None when the library is not there (then the Python
+    tokeniser below does the same job, ~30x slower at 400 states)."""
+    try:
+        from .. import _lib
+        lib = _lib.load()
+    except Exception:
+        return None
+    q = np.empty(B, dtype=np.float64)
+    C = np.empty((B, S, S), dtype=np.float64)
+    off = np.zeros(S, dtype=np.int64)
+    ln = np.zeros(S, dtype=np.int32)
+    rc = lib.cb_parse_count_matrices(raw, len(raw), B, S, q.ctypes.data, C.ctypes.data, off.ctypes.data,
+                                     ln.ctypes.data, 0)
+    if rc != 0:
+        msg = lib.cb_last_error()
+        msg = msg.decode() if isinstance(msg, bytes) else str(msg)
+        raise Exception(f"Error reading count matrices file: {path}\n{msg}")
+    states = [raw[o:o + n].decode("utf-8") for o, n in zip(off, ln)]
     return q, C, states
 
 

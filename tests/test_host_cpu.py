@@ -207,3 +207,48 @@ def test_newick_conversion_and_standard_site_rate_grid():
     assert all(g[i] < g[i + 1] for i in range(19))
     golden = load_golden("siterm_learn.npz")
     assert np.allclose(g, golden["pub_grid"], rtol=1e-15) and np.allclose(get_standard_site_rate_prior(20), golden["pub_prior"], rtol=1e-13)
+
+
+def test_native_count_matrix_parser_equals_python_float(tmp_path, monkeypatch):
+    """cb_parse_count_matrices (host threads, Clinger fast path + strtod) against the Python tokeniser it
+    replaces: awkward numbers, ragged whitespace, and the reference's error cases."""
+    import cherryml_amd.io._formats as F
+    rng = np.random.default_rng(5)
+    S, B = 7, 5
+    states = ["A", "R", "N", "D", "gap-", "X1", "Zz"]
+    specials = ["0.0", "0", "1e-05", "1.5e+16", "-3.25", "123456789012345678", "0.1234567890123456789", "4.9e-324",
+                "1.7976931348623157e+308", "2.5E3", "+7", ".5", "5.", "1e22", "1e23", "9007199254740993", "0.30000000000000004",
+                "1e-300", "123.456e-2", "inf", "nan"]
+    toks = []
+    path = tmp_path / "cm.txt"
+    with open(path, "w") as f:
+        f.write(f"{B} matrices\n{S} states\n")
+        for b in range(B):
+            f.write(f"{0.03 * 1.1 ** b!r}\n" if b != 2 else "  6.729e-05 \r\n")
+            f.write("\t" + "\t".join(states) + ("\n" if b % 2 else "   \n\n"))
+            for r in range(S):
+                row = [specials[int(rng.integers(len(specials)))] if rng.random() < 0.5 else repr(float(rng.normal() * 10.0 ** int(rng.integers(-8, 8))))
+                       for _ in range(S)]
+                toks.append(row)
+                f.write(states[r] + ("\t" if r % 2 else "  ") + ("\t" if b % 2 else " ").join(row) + "\n")
+    q, C, st = F.read_count_matrices_arrays(str(path))
+    want = np.array([[float(t) for t in row] for row in toks]).reshape(B, S, S)
+    assert st == states and q[2] == 6.729e-05 and q[0] == 0.03
+    assert np.array_equal(C, want, equal_nan=True)                    # bit-identical to Python's float()
+    monkeypatch.setattr(F, "_parse_native", lambda *a: None)          # the pure-Python route gives the same
+    q2, C2, st2 = F.read_count_matrices_arrays(str(path))
+    assert np.array_equal(q, q2) and np.array_equal(C, C2, equal_nan=True) and st == st2
+    monkeypatch.undo()
+    text = open(path).read()
+    bad = tmp_path / "bad.txt"
+    bad.write_text(text.replace("\nX1", "\nX2", 1).replace("\tX1\t", "\tX1\t", 1))    # a row label of one matrix differs
+    with pytest.raises(Exception, match="state labels"):
+        F.read_count_matrices_arrays(str(bad))
+    bad.write_text(text + " 1.0\n")                                                     # one token too many
+    with pytest.raises(Exception, match="tokens"):
+        F.read_count_matrices_arrays(str(bad))
+    lines = text.split("\n")
+    lines[5] = lines[5].replace(lines[5].split()[1], "12..5", 1)                        # not a number
+    bad.write_text("\n".join(lines))
+    with pytest.raises(Exception, match="not a number"):
+        F.read_count_matrices_arrays(str(bad))
