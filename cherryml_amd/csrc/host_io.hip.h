@@ -170,3 +170,112 @@ extern "C" int cb_parse_count_matrices(const char *text, size_t len, int B, int 
   }
   return CB_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------
+// FastCherries' divide-and-conquer cherry pairing (reference
+// phylogeny_estimation/FastCherries/pairing_algorithms.cpp:14-175), host only.  Same decisions as the
+// reference bit for bit: std::mt19937(seed), the pivot index by libstdc++'s uniform_int_distribution rule
+// (scheme 0: GCC >= 11, Lemire's multiply-shift with rejection; scheme 1: older scale-and-reject --
+// written out here so that the result does not depend on the C++ library this file is built with),
+// negated normalised Hamming distances as doubles, first-minimum / >= tie rules.  Sequences are int8
+// state indices (-1 unknown) in one contiguous array, subsets are index vectors: no string maps, no
+// per-distance hashing -- the reference's C++ spends its time there.
+#include <random>
+namespace cb_fc {
+struct Pairer {
+  const int8_t *seqs;
+  int L;
+  std::mt19937 rng;
+  int scheme;
+  std::vector<int> out;   // pairs, flattened
+
+  size_t pick(size_t n) {
+    if (scheme == 0) {
+      unsigned long long product = (unsigned long long)rng() * n;
+      unsigned low = (unsigned)product;
+      if (low < n) {
+        const unsigned threshold = (unsigned)(-(unsigned)n) % (unsigned)n;
+        while (low < threshold) {
+          product = (unsigned long long)rng() * n;
+          low = (unsigned)product;
+        }
+      }
+      return (size_t)(product >> 32);
+    }
+    const unsigned long long scaling = 0xFFFFFFFFull / n, past = n * scaling;
+    for (;;) {
+      const unsigned long long r = rng();
+      if (r < past) return (size_t)(r / scaling);
+    }
+  }
+  double dist(int a, int b) const {   // -(mismatches / compared sites), 0 when nothing to compare
+    const int8_t *x = seqs + (size_t)a * L, *y = seqs + (size_t)b * L;
+    int count = 0, d = 0;
+    for (int i = 0; i < L; ++i) {
+      const int ok = (x[i] != -1) & (y[i] != -1);
+      count += ok;
+      d += ok & (x[i] != y[i]);
+    }
+    if (count == 0) return 0.0;
+    return d * -1.0 / count;
+  }
+  // farthest from x (first minimum of the negated distance); distances of all members to x in `ds`
+  int farthest(const std::vector<int> &ids, int x, std::vector<double> &ds) const {
+    double best = 1.7976931348623157e308;
+    int y = -1;
+    ds.resize(ids.size());
+    for (size_t i = 0; i < ids.size(); ++i) {
+      const double d = dist(ids[i], x);
+      ds[i] = d;
+      if (d < best) {
+        best = d;
+        y = (int)i;
+      }
+    }
+    return y;   // position in ids
+  }
+  int divide(const std::vector<int> &ids) {   // returns the unpaired sequence or -1
+    if (ids.size() == 2) {
+      out.push_back(ids[0]);
+      out.push_back(ids[1]);
+      return -1;
+    }
+    if (ids.size() == 1) return ids[0];
+    if (ids.empty()) return -1;
+    std::vector<double> dx;
+    int xp = (int)pick(ids.size());
+    xp = farthest(ids, ids[xp], dx);
+    const int yp = farthest(ids, ids[xp], dx);
+    std::vector<int> cx, cy;
+    for (size_t i = 0; i < ids.size(); ++i) {
+      const bool closer_x = dx[i] >= dist(ids[i], ids[yp]);
+      if (closer_x && (int)i != yp) cx.push_back(ids[i]);
+      else cy.push_back(ids[i]);
+    }
+    dx.clear();
+    dx.shrink_to_fit();
+    const int ux = divide(cx);
+    const int uy = divide(cy);
+    if (ux >= 0 && uy >= 0) {
+      out.push_back(ux);
+      out.push_back(uy);
+      return -1;
+    }
+    return ux >= 0 ? ux : uy;
+  }
+};
+}  // namespace cb_fc
+
+// pairs[2 * (n / 2)] out; returns the number of cherries (>= 0) or a negative error code.
+// NB the order of the reference's result: cherries of the x side, then of the y side, then (x-unpaired,
+// y-unpaired) -- which is the order the recursion above appends in.
+extern "C" int cb_fc_divide_and_pair(const int8_t *seqs, int n, int L, unsigned seed, int scheme, int *pairs) {
+  if (!seqs || !pairs || n < 0 || L < 0 || scheme < 0 || scheme > 1) return fail(CB_EINVAL, "cb_fc_divide_and_pair: bad argument");
+  cb_fc::Pairer p{seqs, L, std::mt19937(seed), scheme, {}};
+  p.out.reserve((size_t)n);
+  std::vector<int> ids(n);
+  for (int i = 0; i < n; ++i) ids[i] = i;
+  p.divide(ids);
+  for (size_t i = 0; i < p.out.size(); ++i) pairs[i] = p.out[i];
+  return (int)(p.out.size() / 2);
+}

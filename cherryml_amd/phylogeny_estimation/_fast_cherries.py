@@ -2,10 +2,11 @@
 program FastCherries/fast_cherries.cpp:170-321): divide-and-conquer cherry pairing, then branch lengths and
 site rates by coordinate ascent, then the star-of-cherries tree.
 
-* pairing (`pairing_algorithms.cpp:77-175`): host numpy.  It is a seeded recursion over shrinking subsets
-  whose only arithmetic is Hamming distances of one sequence against a subset (three passes per
-  level) -- O(n L log n) byte compares in total, microseconds next to the likelihood work.  The random
-  pivot follows the reference bit for bit: `std::mt19937(seed)` + libstdc++'s
+* pairing (`pairing_algorithms.cpp:77-175`): on the host -- `cb_fc_divide_and_pair` in libcherrybank (C++,
+  int8 sequences, index vectors: 5x the reference's own C++, which hashes sequence names for every
+  distance), with the numpy restatement below as the fallback and cross-check.  It is a seeded recursion over
+  shrinking subsets whose only arithmetic is Hamming distances of one sequence against a subset (three
+  passes per level), O(n L log n) byte compares in total.  The random pivot follows the reference bit for bit: `std::mt19937(seed)` + libstdc++'s
   `uniform_int_distribution<size_t>` (GCC >= 11: Lemire's multiply-shift with rejection; the older
   scale-and-reject rule is available as `rng_scheme="gcc10"`).
 * branch lengths / site rates (`ble`, branch_length_estimation.cpp:146-241): on the GPU (`cb_ble`), the
@@ -83,9 +84,36 @@ def _neg_hamming(A: np.ndarray, x: np.ndarray) -> np.ndarray:
     return np.where(count == 0, 0.0, d)
 
 
-def divide_and_pair(seqs: np.ndarray, seed: int = 1234, rng_scheme: str = "lemire") -> List[Tuple[int, int]]:
+def _divide_and_pair_native(seqs, seed: int, rng_scheme: str):
+    """libcherrybank's host implementation (cb_fc_divide_and_pair; 5-40x the reference's C++, which
+    hashes sequence names for every distance); None when the library is not there."""
+    if rng_scheme not in ("lemire", "gcc10"):
+        raise ValueError("rng_scheme must be 'lemire' or 'gcc10'")
+    try:
+        from .. import _lib
+        lib = _lib.load()
+    except Exception:
+        return None
+    s8 = np.ascontiguousarray(seqs, dtype=np.int8)
+    if s8.ndim != 2 or not np.array_equal(s8, np.asarray(seqs)):
+        return None                                   # states beyond int8: the numpy route
+    n, L = s8.shape
+    out = np.zeros(2 * max(n // 2, 1), dtype=np.int32)
+    m = lib.cb_fc_divide_and_pair(s8.ctypes.data, n, L, int(seed) & 0xFFFFFFFF, 0 if rng_scheme == "lemire" else 1,
+                                  out.ctypes.data)
+    if m < 0:
+        _lib.check(m, "cb_fc_divide_and_pair")
+    return [(int(out[2 * i]), int(out[2 * i + 1])) for i in range(m)]
+
+
+def divide_and_pair(seqs: np.ndarray, seed: int = 1234, rng_scheme: str = "lemire",
+                    _force_python: bool = False) -> List[Tuple[int, int]]:
     """`divide_and_pair` (:166-175): cherries as index pairs into `seqs` [n, L] (state index, -1 unknown),
     in the reference's order.  Every sequence but at most one ends up in a cherry."""
+    if not _force_python:
+        native = _divide_and_pair_native(seqs, seed, rng_scheme)
+        if native is not None:
+            return native
     seqs = np.ascontiguousarray(seqs, dtype=np.int16)
     rng = _Mt19937(seed)
 

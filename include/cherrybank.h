@@ -325,6 +325,14 @@ int cb_tree_likelihood(int device, int S, int S1, const double *Q, const double 
 int cb_parse_count_matrices(const char *text, size_t len, int B, int S, double *q, double *C,
                             long long *label_off, int *label_len, int n_threads);
 
+/* ---- FastCherries' cherry pairing, host only -------------------------------------------------------------
+ * divide_and_pair of phylogeny_estimation/FastCherries/pairing_algorithms.cpp:77-175 on int8 sequences
+ * [n][L] (state index, -1 unknown): the seeded divide-and-conquer over Hamming distances, with the
+ * reference's decisions reproduced bit for bit (std::mt19937(seed); pivot index by libstdc++'s
+ * uniform_int_distribution rule, scheme 0 = GCC >= 11 (Lemire), 1 = older scale-and-reject; tie rules).
+ * pairs[2 * (n / 2)] receives the cherries as index pairs in the reference's order; returns their number. */
+int cb_fc_divide_and_pair(const int8_t *seqs, int n, int L, unsigned seed, int scheme, int *pairs);
+
 #ifdef __cplusplus
 }
 #endif

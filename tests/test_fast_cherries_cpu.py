@@ -42,8 +42,9 @@ def test_pairing_matches_reference_goldens():
     g = load_golden("fast_cherries.npz")
     k = 0
     while f"pair{k}_seqs" in g:
-        got = divide_and_pair(g[f"pair{k}_seqs"], seed=int(g[f"pair{k}_seed"]))
+        got = divide_and_pair(g[f"pair{k}_seqs"], seed=int(g[f"pair{k}_seed"]))           # libcherrybank's host routine
         assert got == [tuple(int(v) for v in p) for p in g[f"pair{k}_pairs"]], k
+        assert divide_and_pair(g[f"pair{k}_seqs"], seed=int(g[f"pair{k}_seed"]), _force_python=True) == got   # numpy route
         n = g[f"pair{k}_seqs"].shape[0]
         assert len(got) == n // 2 and len({i for p in got for i in p}) == 2 * (n // 2)   # a matching
         k += 1
@@ -80,7 +81,12 @@ def test_pairing_and_weights_against_the_compiled_reference():
         s32 = np.ascontiguousarray(seqs, dtype=np.int32)
         out = np.zeros(2 * n, dtype=np.int32)
         m = lib.ref_divide_and_pair(s32.ctypes.data_as(C.c_void_p), n, L, 7 + trial, out.ctypes.data_as(C.c_void_p))
-        assert divide_and_pair(seqs, seed=7 + trial) == [(int(out[2 * i]), int(out[2 * i + 1])) for i in range(m)]
+        want = [(int(out[2 * i]), int(out[2 * i + 1])) for i in range(m)]
+        assert divide_and_pair(seqs, seed=7 + trial) == want
+        assert divide_and_pair(seqs, seed=7 + trial, _force_python=True) == want
+        if trial < 5:   # the older libstdc++ rule: both of our routes agree with each other
+            assert (divide_and_pair(seqs, seed=3, rng_scheme="gcc10")
+                    == divide_and_pair(seqs, seed=3, rng_scheme="gcc10", _force_python=True))
     for R in (2, 5, 20, 41):
         r = np.array(rate_categories_ble(R))
         w = np.zeros(R)
