@@ -25,6 +25,7 @@ SIGNATURES = {
     "cb_total_counts": (C.c_int, [_vp, _vp]),
     "cb_live_buckets": (C.c_int, [_vp, _vp]),
     "cb_allreduce_setup": (C.c_int, [_vp, _vp, _vp, _vp]),
+    "cb_format_matrix_rows": (C.c_int, [_vp, C.c_int, C.c_int, C.c_char_p, _vp, _vp, _vp, C.c_size_t, _vp]),
     "cb_fc_divide_and_pair": (C.c_int, [_vp, C.c_int, C.c_int, C.c_uint, C.c_int, _vp]),
     "cb_parse_count_matrices": (C.c_int, [C.c_char_p, C.c_size_t, C.c_int, C.c_int, _vp, _vp, _vp, _vp, C.c_int]),
     "cb_loss_grad": (C.c_int, [_vp, _vp, _vp, C.c_int, _vp, _vp]),

@@ -279,3 +279,96 @@ extern "C" int cb_fc_divide_and_pair(const int8_t *seqs, int n, int L, unsigned 
   for (size_t i = 0; i < p.out.size(); ++i) pairs[i] = p.out[i];
   return (int)(p.out.size() / 2);
 }
+
+// ---------------------------------------------------------------------------------------------------
+// Writer side of the same format (cherryml/io/_count_matrices.py:66-81 writes every value with Python's
+// repr): rows "<label>\tv\t...\tv\n" with the shortest digits that round-trip (std::to_chars) laid out
+// by Python's rule -- fixed notation while -4 < decimal point position <= 16, else d.ddde+XX; integers
+// get a ".0" -- so the bytes equal what "\t".join(map(repr, row)) produces.
+#include <charconv>
+namespace cb_io {
+inline char *put_repr(char *p, double v) {
+  if (v == 0.0) {
+    if (std::signbit(v)) *p++ = '-';
+    *p++ = '0'; *p++ = '.'; *p++ = '0';
+    return p;
+  }
+  if (v != v) { *p++ = 'n'; *p++ = 'a'; *p++ = 'n'; return p; }
+  if (v - v != 0.0) {   // +-inf
+    if (v < 0) *p++ = '-';
+    *p++ = 'i'; *p++ = 'n'; *p++ = 'f';
+    return p;
+  }
+  char buf[40];
+  auto r = std::to_chars(buf, buf + sizeof buf, v, std::chars_format::scientific);   // [-]d[.ddd]e[+-]XX, shortest
+  const char *s = buf, *end = r.ptr;
+  if (*s == '-') { *p++ = '-'; ++s; }
+  char digits[24];
+  int nd = 0;
+  const char *e = s;
+  while (e < end && *e != 'e') {
+    if (*e != '.') digits[nd++] = *e;
+    ++e;
+  }
+  int ex = 0;
+  {
+    const char *q = e + 1;
+    bool neg = false;
+    if (*q == '-' || *q == '+') neg = *q++ == '-';
+    while (q < end) ex = ex * 10 + (*q++ - '0');
+    if (neg) ex = -ex;
+  }
+  const int decpt = ex + 1;
+  if (decpt > -4 && decpt <= 16) {
+    if (decpt <= 0) {
+      *p++ = '0'; *p++ = '.';
+      for (int i = 0; i < -decpt; ++i) *p++ = '0';
+      for (int i = 0; i < nd; ++i) *p++ = digits[i];
+    } else if (decpt >= nd) {
+      for (int i = 0; i < nd; ++i) *p++ = digits[i];
+      for (int i = nd; i < decpt; ++i) *p++ = '0';
+      *p++ = '.'; *p++ = '0';
+    } else {
+      for (int i = 0; i < decpt; ++i) *p++ = digits[i];
+      *p++ = '.';
+      for (int i = decpt; i < nd; ++i) *p++ = digits[i];
+    }
+    return p;
+  }
+  *p++ = digits[0];
+  if (nd > 1) {
+    *p++ = '.';
+    for (int i = 1; i < nd; ++i) *p++ = digits[i];
+  }
+  *p++ = 'e';
+  *p++ = ex < 0 ? '-' : '+';
+  const int ax = ex < 0 ? -ex : ex;
+  if (ax >= 100) *p++ = (char)('0' + ax / 100);
+  *p++ = (char)('0' + (ax / 10) % 10);
+  *p++ = (char)('0' + ax % 10);
+  return p;
+}
+}  // namespace cb_io
+
+// `rows` x `cols` values, row r prefixed by label r (bytes labels[label_off[r] .. + label_len[r])).
+// out must hold rows * (max label + 1 + cols * 26) bytes; *written = bytes produced.
+extern "C" int cb_format_matrix_rows(const double *M, int rows, int cols, const char *labels, const long long *label_off,
+                                     const int *label_len, char *out, size_t cap, size_t *written) {
+  if (!M || !labels || !label_off || !label_len || !out || !written || rows < 0 || cols < 0)
+    return fail(CB_EINVAL, "cb_format_matrix_rows: bad argument");
+  char *p = out;
+  for (int r = 0; r < rows; ++r) {
+    if ((size_t)(p - out) + (size_t)label_len[r] + 2 + (size_t)cols * 26 > cap)
+      return fail(CB_EINVAL, "cb_format_matrix_rows: output buffer too small");
+    memcpy(p, labels + label_off[r], (size_t)label_len[r]);
+    p += label_len[r];
+    const double *row = M + (size_t)r * cols;
+    for (int c = 0; c < cols; ++c) {
+      *p++ = '\t';
+      p = cb_io::put_repr(p, row[c]);
+    }
+    *p++ = '\n';
+  }
+  *written = (size_t)(p - out);
+  return CB_OK;
+}

@@ -80,20 +80,51 @@ def read_count_matrices(path: str) -> List[Tuple[float, pd.DataFrame]]:
             for b in range(len(q))]
 
 
+def _format_rows_native(M: np.ndarray, labels: List[str]):
+    """bytes of "".join(label + "\t" + "\t".join(map(repr, row)) + "\n") through libcherrybank
+    (cb_format_matrix_rows); None when the library is not there."""
+    try:
+        from .. import _lib
+        lib = _lib.load()
+    except Exception:
+        return None
+    import ctypes
+    M = np.ascontiguousarray(M, dtype=np.float64)
+    rows, cols = M.shape
+    enc = [str(x).encode("utf-8") for x in labels]
+    blob = b"".join(enc)
+    ln = np.array([len(e) for e in enc], dtype=np.int32)
+    off = np.zeros(rows, dtype=np.int64)
+    if rows > 1:
+        off[1:] = np.cumsum(ln[:-1])
+    cap = rows * (int(ln.max(initial=0)) + 2 + 26 * cols) + 16
+    out = ctypes.create_string_buffer(cap)
+    written = ctypes.c_size_t(0)
+    rc = lib.cb_format_matrix_rows(M.ctypes.data, rows, cols, blob, off.ctypes.data, ln.ctypes.data,
+                                   ctypes.addressof(out), cap, ctypes.addressof(written))
+    if rc != 0:
+        return None
+    return out.raw[:written.value]
+
+
 def write_count_matrices(count_matrices: List[Tuple[float, pd.DataFrame]], path: str) -> None:
     d = os.path.dirname(path)
     if d != "" and not os.path.exists(d):
         os.makedirs(d)
     B = len(count_matrices)
     S = len(count_matrices[0][1])
-    with open(path, "w") as out:
-        out.write(f"{B} matrices\n{S} states\n")
+    with open(path, "wb") as out:
+        out.write(f"{B} matrices\n{S} states\n".encode("utf-8"))
         for q, m in count_matrices:
-            out.write(f"{q}\n")
+            out.write(f"{q}\n".encode("utf-8"))
             cols = [str(c) for c in m.columns]
-            out.write("\t" + "\t".join(cols) + "\n")
-            vals = np.asarray(m.to_numpy(), dtype=np.float64).tolist()   # Python floats: repr = shortest round trip
-            out.write("".join(str(name) + "\t" + "\t".join(map(repr, row)) + "\n" for name, row in zip(m.index, vals)))
+            out.write(("\t" + "\t".join(cols) + "\n").encode("utf-8"))
+            vals = np.asarray(m.to_numpy(), dtype=np.float64)
+            body = _format_rows_native(vals, list(m.index))       # the bytes of repr(), formatted natively
+            if body is None:    # Python floats: repr = shortest round trip
+                body = "".join(str(name) + "\t" + "\t".join(map(repr, row)) + "\n"
+                               for name, row in zip(m.index, vals.tolist())).encode("utf-8")
+            out.write(body)
 
 
 def _read_table(path: str) -> pd.DataFrame:
@@ -129,10 +160,13 @@ def write_rate_matrix(rate_matrix: np.ndarray, states: List[str], path: str) -> 
         return
     # the same bytes as DataFrame.to_csv (repr of every float), five times faster at 400 states -- the
     # co-evolution stage writes a dozen of these files (result, best, last, the 2^k snapshots)
-    rows = M.tolist()
-    with open(path, "w") as out:
-        out.write("\t" + "\t".join(str(c) for c in states) + "\n")
-        out.write("".join(str(name) + "\t" + "\t".join(map(repr, row)) + "\n" for name, row in zip(states, rows)))
+    with open(path, "wb") as out:
+        out.write(("\t" + "\t".join(str(c) for c in states) + "\n").encode("utf-8"))
+        body = _format_rows_native(M, list(states))
+        if body is None:
+            body = "".join(str(name) + "\t" + "\t".join(map(repr, row)) + "\n"
+                           for name, row in zip(states, M.tolist())).encode("utf-8")
+        out.write(body)
 
 
 def write_probability_distribution(p: np.ndarray, states: List[str], path: str) -> None:

@@ -333,6 +333,13 @@ int cb_parse_count_matrices(const char *text, size_t len, int B, int S, double *
  * pairs[2 * (n / 2)] receives the cherries as index pairs in the reference's order; returns their number. */
 int cb_fc_divide_and_pair(const int8_t *seqs, int n, int L, unsigned seed, int scheme, int *pairs);
 
+/* ---- writer side of the text formats, host only (io/_count_matrices.py:66-81, io/_rate_matrix.py) ----------
+ * rows x cols values as "<label>\tv\t...\tv\n" lines, every value with the bytes of Python's repr()
+ * (shortest round-trip digits, fixed notation while -4 < decimal point <= 16, ".0" on integers).
+ * out needs rows * (longest label + 2 + 26 * cols) bytes. */
+int cb_format_matrix_rows(const double *M, int rows, int cols, const char *labels, const long long *label_off,
+                          const int *label_len, char *out, size_t cap, size_t *written);
+
 #ifdef __cplusplus
 }
 #endif

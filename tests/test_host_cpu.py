@@ -252,3 +252,36 @@ def test_native_count_matrix_parser_equals_python_float(tmp_path, monkeypatch):
     bad.write_text("\n".join(lines))
     with pytest.raises(Exception, match="not a number"):
         F.read_count_matrices_arrays(str(bad))
+
+
+def test_native_formatter_writes_the_bytes_of_repr(tmp_path):
+    """cb_format_matrix_rows (std::to_chars digits laid out by Python's rule) against
+    "\\t".join(map(repr, row)) on random bit patterns, the notation boundaries (1e16, 1e-4), signed zeros,
+    denormals and infinities; and the two writers that use it round-trip through the readers."""
+    import cherryml_amd.io._formats as F
+    rng = np.random.default_rng(2)
+    bits = rng.integers(0, 2 ** 63, size=60000, dtype=np.int64).astype(np.uint64) | \
+        (rng.integers(0, 2, size=60000).astype(np.uint64) << np.uint64(63))
+    v = bits.view(np.float64)
+    v = v[~np.isnan(v)]
+    spec = np.array([0.0, -0.0, 1.0, 12.0, 1e16, 1e15, 9999999999999998.0, 1e-4, 1e-5, 0.00012, 123456.789, 5e-324,
+                     1.7976931348623157e308, 2.5, 1e22, 1e23, -3.5e-7, float("inf"), float("-inf"), 100.0,
+                     1234567890123456.0, 12345678901234567.0, 0.1, 0.30000000000000004, 99999999999999.98])
+    decs = rng.normal(size=20000) * 10.0 ** rng.integers(-10, 10, size=20000)
+    allv = np.concatenate([v, spec, decs, np.round(decs, 3), rng.integers(0, 1000, size=3000) * 0.25])
+    M = allv[:(allv.size // 9) * 9].reshape(-1, 9)
+    labels = [f"row {i}" if i % 3 else "Ä" for i in range(M.shape[0])]
+    got = F._format_rows_native(M, labels)
+    want = "".join(l + "\t" + "\t".join(map(repr, row)) + "\n" for l, row in zip(labels, M.tolist())).encode("utf-8")
+    assert got == want
+    states = ["A", "C", "G", "T"]
+    Q = rng.normal(size=(4, 4)) * 1e-3
+    F.write_rate_matrix(Q, states, str(tmp_path / "q.txt"))
+    assert np.array_equal(F.read_rate_matrix(str(tmp_path / "q.txt")).to_numpy(), Q)
+    assert open(tmp_path / "q.txt", "rb").read() == pd.DataFrame(Q, index=states, columns=states).to_csv(sep="\t").encode()
+    cm = [(0.03, pd.DataFrame(rng.integers(0, 9, size=(4, 4)) * 0.5, index=states, columns=states)),
+          (6.729e-05, pd.DataFrame(rng.random((4, 4)), index=states, columns=states))]
+    F.write_count_matrices(cm, str(tmp_path / "c.txt"))
+    q, C, st = F.read_count_matrices_arrays(str(tmp_path / "c.txt"))
+    assert st == states and list(q) == [0.03, 6.729e-05]
+    assert np.array_equal(C[0], cm[0][1].to_numpy()) and np.array_equal(C[1], cm[1][1].to_numpy())
