@@ -26,6 +26,20 @@ def _snapshot(Q: torch.Tensor) -> np.ndarray:
     return Q.detach().cpu().numpy().copy()
 
 
+class LazyOptimizer:
+    """The reference's optimiser choice (`ratelearner.py:123-130`: Adam or plain SGD, default
+    hyper-parameters) as a description.  The device-side loop only needs `kind` and `lr`; a real
+    torch optimiser is built by `materialize()` when the torch loop runs (constructing torch.optim.Adam
+    imports torch._dynamo: 0.6 s of a 2.8 s co-evolution stage)."""
+
+    def __init__(self, params, lr: float, do_adam: bool):
+        self.params, self.lr, self.do_adam = list(params), float(lr), bool(do_adam)
+
+    def materialize(self):
+        cls = torch.optim.Adam if self.do_adam else torch.optim.SGD
+        return cls(params=self.params, lr=self.lr)
+
+
 def _fusable(rate_module, optimizer, Q_true, m) -> bool:
     """The whole loop can run on the device without torch (cb_train_pande_reversible: one kernel
     for S <= 32, a C-driven kernel sequence for larger S) when nothing but the reference's
@@ -34,6 +48,8 @@ def _fusable(rate_module, optimizer, Q_true, m) -> bool:
         return False
     if Q_true is not None or m != 1.0 or not rate_module._pi.requires_grad:
         return False
+    if isinstance(optimizer, LazyOptimizer):
+        return True
     if len(optimizer.param_groups) != 1 or optimizer.state:
         return False
     g = optimizer.param_groups[0]
@@ -47,12 +63,15 @@ def _fusable(rate_module, optimizer, Q_true, m) -> bool:
 
 
 def _train_fused(rate_module, bank, optimizer, num_epochs, loss_normalization, return_best_iter):
-    g = optimizer.param_groups[0]
+    if isinstance(optimizer, LazyOptimizer):
+        lr, do_adam = optimizer.lr, optimizer.do_adam
+    else:
+        lr, do_adam = optimizer.param_groups[0]["lr"], isinstance(optimizer, torch.optim.Adam)
     start = time.time()
     r = bank.train_pande_reversible(
         rate_module.upper_diag.detach().cpu().numpy(), rate_module._pi.detach().cpu().numpy(),
-        mask=rate_module.mask.detach().cpu().numpy(), num_epochs=num_epochs, lr=g["lr"],
-        do_adam=isinstance(optimizer, torch.optim.Adam), normalize=loss_normalization)
+        mask=rate_module.mask.detach().cpu().numpy(), num_epochs=num_epochs, lr=lr,
+        do_adam=do_adam, normalize=loss_normalization)
     elapsed = time.time() - start
     with torch.no_grad():  # leave the module at the final parameters, like the torch loop does
         rate_module.upper_diag.copy_(torch.as_tensor(r["upper_diag"]))
@@ -114,6 +133,8 @@ def train_quantization(rate_module, quantized_dataset, m=1.0, lr=1e-1, num_epoch
             num_epochs_torch = 0
         else:
             num_epochs_torch = num_epochs
+            if isinstance(optimizer, LazyOptimizer):
+                optimizer = optimizer.materialize()
         for epoch in range(num_epochs_torch):
             optimizer.zero_grad()
             Q = rate_module()

@@ -11,7 +11,7 @@ import torch
 from torch.utils.data import TensorDataset
 
 from ...io import write_rate_matrix
-from ._epoch_loop import train_quantization
+from ._epoch_loop import LazyOptimizer, train_quantization
 from ._rate_matrix import RateMatrix
 
 
@@ -73,8 +73,7 @@ class RateMatrixLearner:
             pi_requires_grad=src is None, initialization=self.initialization,
             mask=self.mask_mat).to(device="cuda")
         self.lr, self.do_adam = lr, do_adam
-        opt_cls = torch.optim.Adam if do_adam else torch.optim.SGD
-        optim = opt_cls(params=self.mat_module.parameters(), lr=lr)
+        optim = LazyOptimizer(self.mat_module.parameters(), lr=lr, do_adam=do_adam)   # torch's, built only if the torch loop runs
         self.df_res, self.Q_dict = train_quantization(
             rate_module=self.mat_module, quantized_dataset=self.quantized_data,
             num_epochs=num_epochs, Q_true=None, optimizer=optim,
