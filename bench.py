@@ -150,12 +150,12 @@ def cpu_baseline(wl, name):
     cores = torch.get_num_threads()
     if wl["kind"] == "single":
         B = wl["C"].shape[0]
-        nb = {400: 6, 20: 129}[wl["S"]]
+        nb = {400: 32, 20: 129}[wl["S"]]   # ~10-20 s of host work either way
         sel = np.linspace(0, B - 1, nb).round().astype(int)
         t, C = wl["t"][sel], wl["C"][sel]
         init = jtt_ipw_from_arrays(wl["t"], wl["C"], wl["mask"])
         u, p = orc.invert_pande_reversible(init, wl["mask"])
-        reps = 1 if wl["S"] == 400 else 20
+        reps = 1 if wl["S"] == 400 else 200
         orc.evaluate(u, p, wl["mask"], t[:1], C[:1], torch.float32)  # warm up
         t0 = time.time()
         for _ in range(reps):
