@@ -242,7 +242,7 @@ static int large_eigh(cb_bank *h, bool warm) {
   // Banded Jacobi pass of the hybrid sweep: every column pair at most `band` blocks apart is rotated
   // exactly -- distance <= 1 by the two within passes (16-column groups, both alignments, to
   // convergence), distance k = 2..band by two rounds of disjoint block pairs (i, i + k).
-  const int hybrid_within = getenv("CB_HYBRID_WITHIN") ? atoi(getenv("CB_HYBRID_WITHIN")) : 3;
+  const int hybrid_within = getenv("CB_HYBRID_WITHIN") ? atoi(getenv("CB_HYBRID_WITHIN")) : 2;
   auto band_pass = [&](int shift) {
     gr_valid = false;
     for (int w = 0; w < 2; ++w)

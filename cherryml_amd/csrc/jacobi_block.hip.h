@@ -160,7 +160,19 @@ __global__ __launch_bounds__(JB_THREADS) void lgj_round(int LD, int round, int i
       }
       off = wave_max(off);
       JB_STAMP(3)
-      wave_rotation_spd16(sGam, sR, 17, inner_sweeps);
+      if (inner_sweeps >= 100) {
+        wave_rotation_spd16(sGam, sR, 17, inner_sweeps - 100);   // (the 4-lanes-per-pair cyclic solver, for comparison)
+      } else {
+        // a sweep over all 120 pairs = the 64 cross pairs + the 2 x 28 pairs inside the blocks, 8 lanes
+        // per pair (all 64 lanes busy; the cyclic solver above keeps 32 busy and takes 1.6x as long)
+        for (int e = lane; e < 256; e += 64) sR[(e >> 4) * 17 + (e & 15)] = ((e >> 4) == (e & 15)) ? 1.0 : 0.0;
+        wave_lds_fence();
+        for (int s = 0; s < inner_sweeps; ++s) {
+          const double o1 = wave_rotation_spd16_blockpairs(sGam, sR, 17, true);
+          const double o2 = wave_rotation_spd16_blockpairs(sGam, sR, 17, false);
+          if (fmax(o1, o2) <= CB_JAC_STOP * CB_JAC_STOP) break;
+        }
+      }
     } else {
       double off2;
       if (round >= 0 || round <= -10) {
