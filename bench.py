@@ -17,9 +17,10 @@ Workloads (BASELINE.json configs):
   counting  the stage that PRODUCES the LG bank: 1000 families x 64 cherries
             x 200 sites, step = one histogram pass over all cherries, inputs resident in HBM
 
-N > 1 (one process per GPU, torch.distributed/RCCL): coevo400 / lg20 shard the
-129 buckets over the ranks and all-reduce (loss, dL/dQ) each epoch -- strong
-scaling of one bank; siterm shards the sites (no collective) -- weak scaling.
+N > 1 (one process per GPU, torch.distributed/RCCL): coevo400 shards the buckets of ONE bank
+over the ranks and all-reduces (loss, dL/dA) each epoch -- strong scaling, `value` = the bank's
+pairs / epoch time; lg20 does not shard (replicas only); siterm shards the sites (no
+collective) -- weak scaling.
 """
 import argparse
 import json
@@ -230,21 +231,21 @@ def main():
                 num_states=S, mode="pande_reversible", mask=torch.tensor(wl["mask"]),
                 pi=torch.ones(S, dtype=torch.float64) / S, pi_requires_grad=True,
                 initialization=init).to(dev)
-            # families are sharded (weak scaling: every GPU brings the sufficient statistics of
-            # its own 1,057,194 cherry x contact pairs -- its own draw of the synthetic bank);
-            # ONE reduce-scatter over the buckets sums them and leaves each rank with the
-            # buckets it owns; then per epoch one all-reduce of S^2 + 1 doubles
-            own = make_workload(workload, args.sites, np.random.default_rng(1000 + rank))
-            sharded = ShardedBank.from_rank_counts(wl["t"], torch.tensor(own["C"], device=dev))
-            del own
+            # STRONG scaling of ONE bank: the same 1,057,194 cherry x contact pairs whatever N is (the
+            # epoch's cost does not depend on the pair count, SURVEY 8d, so "every GPU brings its own
+            # pairs" would grow `value` N-fold by construction).  Families are sharded: every rank holds
+            # the sufficient statistics of its 1/N of the families (here: 1/N of the bank's counts); ONE
+            # reduce-scatter over the non-empty buckets sums them and leaves each rank with the buckets
+            # it owns; then per epoch one all-reduce of S^2 + 1 doubles.
+            sharded = ShardedBank.from_rank_counts(wl["t"], torch.tensor(wl["C"] / world, device=dev))
             bank = sharded.bank
-            n_pairs_total, scaling = sharded.total_count, "weak"
-            sharding = (f"families x{world} -> reduce-scatter of the counts over buckets (once), "
-                        f"buckets x{world}, all-reduce(loss, dL/dA) per epoch")
+            n_pairs_total, scaling = wl["n_pairs"], "strong"
+            sharding = (f"one bank; families x{world} -> reduce-scatter of the counts over buckets (once), "
+                        f"buckets x{world}, all-reduce(loss, dL/dA) per epoch; eigensolver replicated")
             B_local = len(sharded.local_buckets)
             in_library = not args.torch_glue
             if in_library:
-                try:
+                try:   # raises on EVERY rank when any rank cannot make its communicator (distributed.py)
                     sharded.enable_in_library_allreduce()
                 except Exception as exc:  # no raw RCCL communicator: keep torch.distributed's
                     print(f"warning: in-library all-reduce unavailable ({exc}); torch glue", file=sys.stderr)
@@ -352,8 +353,14 @@ def main():
             achieved = flops / (tm[dom] * 1e-3) / 1e12 if tm[dom] > 0 else 0.0
             tn_ = -(-S // 80)
             tri = (tn_ * (tn_ + 1) / 2) / float(tn_ * tn_)   # share of 80x80 tiles actually multiplied
+            # whole epoch: SURVEY 8d's algorithmic flops of one epoch (6 B S^3 bank + ~13 S^3 eigensolver
+            # and back-rotation; 49.6 GFLOP at S = 400, B = 129) over the WALL time of one step
+            epoch_flops = 6.0 * wl["C"].shape[0] * S ** 3 + 13.0 * S ** 3
+            epoch_tflops = epoch_flops / (dt / steps) / 1e12
             roofline = dict(bound="mfma", kernel=names[dom], achieved=achieved,
                             peak=F64_PEAK_TFLOPS, unit="TFLOP/s", frac=achieved / F64_PEAK_TFLOPS,
+                            epoch_frac=epoch_tflops / (F64_PEAK_TFLOPS * world), epoch_tflops=epoch_tflops,
+                            epoch_flops=epoch_flops,
                             traffic=traffic.get(names[dom]) if world == 1 else None,
                             ms_per_launch=tm[dom], flops_per_launch=flops,
                             note="achieved = algorithmic 2 S^3 B flops (SURVEY 8d) / launch time; k1 (Pt symmetric) "
@@ -422,9 +429,9 @@ def main():
         finish(out)
         return
     out = run(args.workload, steps, warmup, world == 1 and not args.no_cpu_baseline)
-    if (rank == 0 and world == 1 and args.workload == "coevo400" and not args.no_secondary
-            and args.steps is None):
-        # BASELINE.json's metric names both sizes: also report the 20x20 LG configuration
+    if rank == 0 and world == 1 and args.workload == "coevo400" and not args.no_secondary:
+        # BASELINE.json's metric names both sizes: the line always carries the 20x20 LG configuration
+        # too (its own epoch counts: an LG epoch takes 0.09 ms)
         sec = run("lg20", *defaults["lg20"], not args.no_cpu_baseline)
         out["secondary"] = {k: sec[k] for k in ("value", "unit", "ms_per_step", "steps", "config",
                                                 "roofline", "cpu_baseline") if k in sec}

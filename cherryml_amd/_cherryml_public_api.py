@@ -105,7 +105,7 @@ def cherryml_public_api(
                 coevolution_mask_path=coevolution_mask_path, use_maximal_matching=use_maximal_matching, **common)
         learned = read_rate_matrix(outputs["learned_rate_matrix_path"])
         write_rate_matrix(learned.to_numpy(), list(learned.columns), output_path)
-        return outputs["profiling_str"]
+        return outputs.get("profiling_str", "")
     finally:
         if keep is not None:
             caching.set_cache_dir(None)

@@ -26,9 +26,52 @@ def _digest(func_name: str, items) -> str:
     return hashlib.sha512(text.encode("utf-8")).hexdigest()[:_HASH_LEN]
 
 
+def _dist_state():
+    """(rank, world) of the default torch.distributed group, (0, 1) without one."""
+    try:
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            return dist.get_rank(), dist.get_world_size()
+    except ImportError:  # pragma: no cover
+        pass
+    return 0, 1
+
+
+def _agree(value):
+    """rank 0's `value` on every rank (one process: the value itself)."""
+    rank, world = _dist_state()
+    if world == 1:
+        return value
+    import torch.distributed as dist
+    box = [value if rank == 0 else None]
+    dist.broadcast_object_list(box, src=0)
+    return box[0]
+
+
+def _raise_together(error: Optional[str], func_name: str):
+    """Every rank learns whether ANY rank failed and raises then (a rank that failed alone would
+    leave its peers waiting in the next collective)."""
+    rank, world = _dist_state()
+    if world == 1:
+        return
+    import torch.distributed as dist
+    errs = [None] * world
+    dist.all_gather_object(errs, error)
+    bad = [(r, e) for r, e in enumerate(errs) if e is not None]
+    if bad:
+        raise RuntimeError(f"{func_name} failed on rank {bad[0][0]}: {bad[0][1]}")
+
+
 def cached_computation(output_dirs: List[str], exclude_args: Optional[List[str]] = None,
-                       write_extra_log_files: bool = False):
+                       write_extra_log_files: bool = False, collective: bool = False):
     """Decorator for a stage function whose outputs are directories.
+
+    Under torch.distributed (world > 1) the ranks share the cache directory: rank 0 decides
+    whether the stage has to run (its view of the success tokens is broadcast), a `collective`
+    stage runs on every rank (it shards its work and reduces inside, and writes its files on rank
+    0 only), any other stage runs on rank 0 alone; failures are exchanged so that all ranks raise
+    together; the success tokens are written by rank 0 between two barriers, so no rank reads an
+    output another rank is still writing.
 
     * positional arguments are refused (CacheUsageError), as in the reference;
     * with no cache directory set, the call goes straight through and returns
@@ -65,21 +108,36 @@ def cached_computation(output_dirs: List[str], exclude_args: Optional[List[str]]
                     full[name] = os.path.join(_CACHE_DIR, func.__name__, h, name)
                 chosen[name] = full[name]
             tokens = [os.path.join(d, "result.success") for d in chosen.values()]
-            if all(os.path.exists(tk) for tk in tokens):
+            rank, world = _dist_state()
+            if _agree(all(os.path.exists(tk) for tk in tokens)):
                 return chosen
-            for d in chosen.values():
-                os.makedirs(d, exist_ok=True)
-                tk = os.path.join(d, "result.success")
-                if os.path.exists(tk):
-                    os.remove(tk)
-            func(**full)
-            for d in chosen.values():
-                if write_extra_log_files:
-                    with open(os.path.join(d, "_function_binding.log"), "w") as f:
-                        f.write(func.__name__ + "\n" +
-                                "\n".join(f"{k}={v!r}" for k, v in key_items) + "\n")
-                with open(os.path.join(d, "result.success"), "w") as f:
-                    f.write("SUCCESS\n")
+            if rank == 0:
+                for d in chosen.values():
+                    os.makedirs(d, exist_ok=True)
+                    tk = os.path.join(d, "result.success")
+                    if os.path.exists(tk):
+                        os.remove(tk)
+            if world > 1:
+                _agree(None)   # the directories exist / stale tokens are gone before any rank starts
+                error = None
+                if collective or rank == 0:
+                    try:
+                        func(**full)
+                    except Exception as exc:  # exchanged below: all ranks raise together
+                        error = f"{type(exc).__name__}: {exc}"
+                _raise_together(error, func.__name__)
+            else:
+                func(**full)
+            if rank == 0:
+                for d in chosen.values():
+                    if write_extra_log_files:
+                        with open(os.path.join(d, "_function_binding.log"), "w") as f:
+                            f.write(func.__name__ + "\n" +
+                                    "\n".join(f"{k}={v!r}" for k, v in key_items) + "\n")
+                    with open(os.path.join(d, "result.success"), "w") as f:
+                        f.write("SUCCESS\n")
+            if world > 1:
+                _agree(None)   # tokens are on disk before any rank moves on to read the outputs
             return chosen
 
         return wrapper

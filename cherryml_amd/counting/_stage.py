@@ -99,18 +99,50 @@ def _gather(tree_dir, msa_dir, families, amino_acids, mode, aux_dir, aux_reader)
     return np.ascontiguousarray(seqs), aux_chunks, pairs
 
 
+def _rank() -> int:
+    try:
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized():
+            return dist.get_rank()
+    except ImportError:  # pragma: no cover
+        pass
+    return 0
+
+
+def _run_local_then_agree(local, name):
+    """Run the rank-local part; under torch.distributed exchange success before the all-reduce,
+    so a rank whose files are broken makes EVERY rank raise instead of stranding its peers."""
+    from ..caching._cached import _dist_state, _raise_together
+    if _dist_state()[1] == 1:
+        local()
+        return
+    error = None
+    try:
+        local()
+    except Exception as exc:
+        error = f"{type(exc).__name__}: {exc}"
+    _raise_together(error, name)
+
+
 def _write(output_dir, grid, counts, unit, states, start, num_processes):
+    """Rank 0 only (every rank holds the same all-reduced counts); files appear atomically."""
+    if _rank() != 0:
+        return
     C = counts.astype(np.float64) * unit
+    tmp = os.path.join(output_dir, "result.txt.tmp")
     write_count_matrices([(float(q), pd.DataFrame(C[b], index=states, columns=states))
-                          for b, q in enumerate(grid)], os.path.join(output_dir, "result.txt"))
-    with open(os.path.join(output_dir, "profiling.txt"), "w") as f:
+                          for b, q in enumerate(grid)], tmp)
+    os.replace(tmp, os.path.join(output_dir, "result.txt"))
+    tmp = os.path.join(output_dir, "profiling.txt.tmp")
+    with open(tmp, "w") as f:
         f.write(f"Total time: {time.time() - start} seconds with {num_processes} processes.\n")
+    os.replace(tmp, os.path.join(output_dir, "profiling.txt"))
 
 
 @caching.cached_computation(
     exclude_args=["num_processes", "use_cpp_implementation", "cpp_command_line_prefix",
                   "cpp_command_line_suffix"],
-    output_dirs=["output_count_matrices_dir"], write_extra_log_files=True)
+    output_dirs=["output_count_matrices_dir"], write_extra_log_files=True, collective=True)
 def count_transitions(
     tree_dir: str,
     msa_dir: str,
@@ -128,7 +160,8 @@ def count_transitions(
     start = time.time()
     logging.getLogger(__name__).info(f"Starting on {len(families)} families")
     mode = _normalise_mode(edge_or_cherry)
-    os.makedirs(output_count_matrices_dir, exist_ok=True)
+    if _rank() == 0:
+        os.makedirs(output_count_matrices_dir, exist_ok=True)
     grid = np.array(sorted(float(q) for q in quantization_points), dtype=np.float64)
     S, B = len(amino_acids), len(grid)
 
@@ -138,14 +171,18 @@ def count_transitions(
             raise Exception(f"{path}: {len(r)} site rates for an MSA of {L} sites")
         return r, L, len(r)
 
-    seqs, aux_chunks, pairs = _gather(tree_dir, msa_dir, _my_families(families), amino_acids, mode,
-                                      site_rates_dir, rates_reader)
-    rates = np.ascontiguousarray(np.concatenate(aux_chunks)) if aux_chunks else np.zeros(0)
     counts = np.zeros((B, S, S), dtype=np.uint64)
-    rc = _lib.load().cb_count_transitions(
-        _device_index(), S, B, grid.ctypes.data, seqs.ctypes.data, seqs.size, rates.ctypes.data,
-        rates.size, pairs.ctypes.data, len(pairs), int(mode != "edge"), 0, counts.ctypes.data)
-    _lib.check(rc, "cb_count_transitions")
+
+    def local():   # this rank's families; no collective inside
+        seqs, aux_chunks, pairs = _gather(tree_dir, msa_dir, _my_families(families), amino_acids, mode,
+                                          site_rates_dir, rates_reader)
+        rates = np.ascontiguousarray(np.concatenate(aux_chunks)) if aux_chunks else np.zeros(0)
+        rc = _lib.load().cb_count_transitions(
+            _device_index(), S, B, grid.ctypes.data, seqs.ctypes.data, seqs.size, rates.ctypes.data,
+            rates.size, pairs.ctypes.data, len(pairs), int(mode != "edge"), 0, counts.ctypes.data)
+        _lib.check(rc, "cb_count_transitions")
+
+    _run_local_then_agree(local, "count_transitions")
     counts = _all_reduce_counts(counts)
     _write(output_count_matrices_dir, grid, counts, 1.0 if mode == "edge" else 0.5,
            list(amino_acids), start, num_processes)
@@ -154,7 +191,7 @@ def count_transitions(
 @caching.cached_computation(
     exclude_args=["num_processes", "use_cpp_implementation", "cpp_command_line_prefix",
                   "cpp_command_line_suffix"],
-    output_dirs=["output_count_matrices_dir"], write_extra_log_files=True)
+    output_dirs=["output_count_matrices_dir"], write_extra_log_files=True, collective=True)
 def count_co_transitions(
     tree_dir: str,
     msa_dir: str,
@@ -173,7 +210,8 @@ def count_co_transitions(
     start = time.time()
     logging.getLogger(__name__).info(f"Starting on {len(families)} families")
     mode = _normalise_mode(edge_or_cherry)
-    os.makedirs(output_count_matrices_dir, exist_ok=True)
+    if _rank() == 0:
+        os.makedirs(output_count_matrices_dir, exist_ok=True)
     grid = np.array(sorted(float(q) for q in quantization_points), dtype=np.float64)
     S, B = len(amino_acids), len(grid)
     mdnc = int(minimum_distance_for_nontrivial_contact)
@@ -187,15 +225,19 @@ def count_co_transitions(
             raise Exception(f"{path}: contact map larger than the MSA ({L} sites)")
         return ij.reshape(-1), ij.shape[0], ij.shape[0]
 
-    seqs, aux_chunks, pairs = _gather(tree_dir, msa_dir, _my_families(families), amino_acids, mode,
-                                      contact_map_dir, contacts_reader)
-    contacts = np.ascontiguousarray(np.concatenate(aux_chunks)) if aux_chunks else np.zeros(0, dtype=np.int32)
-    contacts = contacts.astype(np.int32)
     counts = np.zeros((B, S * S, S * S), dtype=np.uint64)
-    rc = _lib.load().cb_count_co_transitions(
-        _device_index(), S, B, grid.ctypes.data, seqs.ctypes.data, seqs.size, contacts.ctypes.data,
-        contacts.size // 2, pairs.ctypes.data, len(pairs), int(mode != "edge"), 0, counts.ctypes.data)
-    _lib.check(rc, "cb_count_co_transitions")
+
+    def local():   # this rank's families; no collective inside
+        seqs, aux_chunks, pairs = _gather(tree_dir, msa_dir, _my_families(families), amino_acids, mode,
+                                          contact_map_dir, contacts_reader)
+        contacts = np.ascontiguousarray(np.concatenate(aux_chunks)) if aux_chunks else np.zeros(0, dtype=np.int32)
+        contacts = contacts.astype(np.int32)
+        rc = _lib.load().cb_count_co_transitions(
+            _device_index(), S, B, grid.ctypes.data, seqs.ctypes.data, seqs.size, contacts.ctypes.data,
+            contacts.size // 2, pairs.ctypes.data, len(pairs), int(mode != "edge"), 0, counts.ctypes.data)
+        _lib.check(rc, "cb_count_co_transitions")
+
+    _run_local_then_agree(local, "count_co_transitions")
     counts = _all_reduce_counts(counts)
     states = [a + b for a in amino_acids for b in amino_acids]
     _write(output_count_matrices_dir, grid, counts, 0.5 if mode == "edge" else 0.25, states, start,

@@ -46,7 +46,7 @@ __global__ __launch_bounds__(256) void ble_branch_lengths_kernel(
 // cxT / cyT are the SITE-major copies [L][n] of the cherries, so that the lanes (consecutive
 // cherries of one site) read consecutive bytes.
 __global__ __launch_bounds__(256) void ble_site_rates_kernel(
-    int S, int T, int R, int n, int L, const double *__restrict__ logP, const int8_t *__restrict__ cxT,
+    int S, int /*T*/, int R, int n, int L, const double *__restrict__ logP, const int8_t *__restrict__ cxT,
     const int8_t *__restrict__ cyT, const int *__restrict__ lengths_index, const double *__restrict__ priors,
     int *__restrict__ out) {
   const int s = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;

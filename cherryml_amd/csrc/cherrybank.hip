@@ -766,6 +766,15 @@ extern "C" int cb_loss_grad(cb_handle h, const double *Q, const double *pi, int 
     rc = launch_small<SMALL_LOSSGRAD>(h, a);
     mark(h, EV_SMALL);
   }
+  if (rc != CB_OK && h->comm) {   // keep this rank's place in the collective (NaN payload): the peers get NaN, not a hang
+    const std::string first_error = g_err;
+    (void)hipMemsetAsync(lossd, 0xFF, h->L * sizeof(double), h->stream);
+    if (dQd) (void)hipMemsetAsync(dQd, 0xFF, h->L * SS * sizeof(double), h->stream);
+    (void)allreduce_results(h, lossd, dQd);
+    (void)hipStreamSynchronize(h->stream);
+    g_err = first_error;
+    return rc;
+  }
   if (rc != CB_OK) return rc;
   if ((rc = allreduce_results(h, lossd, dQd)) != CB_OK) return rc;
   if (h->profile) h->t_pending = true;
@@ -1034,6 +1043,23 @@ static int run_fused_training_large(cb_bank *h, double *pi_param, double *up_par
     hipLaunchKernelGGL(lt_build, dim3(LD), dim3(256), 0, h->stream, a, e);
     mark(h, EV_START);
     rc = large_eval(h, flags & CB_NORMALIZE, h->loss, h->Mt, true, nullptr);
+    if (rc != CB_OK && h->comm) {
+      // A rank that fails alone (its eigensolver met a non-finite matrix, say) must not leave its peers
+      // waiting in this epoch's ncclAllReduce -- and a host-side status exchange per epoch would cost a
+      // stream synchronisation.  So it keeps its place in EVERY remaining collective with NaN payloads:
+      // the peers' parameters turn NaN with the next step, their own eigensolver reports "non-finite
+      // input", they do the same, and all ranks return an error after the same number of collectives.
+      const std::string first_error = g_err;
+      for (int e2 = e; e2 < E; ++e2) {
+        (void)hipMemsetAsync(h->loss, 0xFF, sizeof(double), h->stream);
+        (void)hipMemsetAsync(h->Mt, 0xFF, (size_t)LD * LD * sizeof(double), h->stream);
+        if (h->allreduce(h->loss, h->loss, 1, 8, 0, h->comm, h->stream) != 0 ||
+            h->allreduce(h->Mt, h->Mt, (size_t)LD * LD, 8, 0, h->comm, h->stream) != 0)
+          break;
+      }
+      g_err = first_error + " (this rank sent NaN to the remaining all-reduces so that its peers fail too)";
+      break;
+    }
     if (rc != CB_OK) break;
     if (h->comm) {  // one all-reduce of LD^2 + 1 doubles per epoch (RCCL, on this stream); identical Adam steps follow
       int ar = h->allreduce(h->loss, h->loss, 1, 8, 0, h->comm, h->stream);

@@ -83,7 +83,7 @@ template <int NW>
 __global__ __launch_bounds__(NW * 64) void general_bank_kernel(GeneralArgs a) {
   __shared__ double sNorm;
   const int l = blockIdx.x, S = a.S, B = a.B;
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, lo = lane & 15, hi = lane >> 4;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const double *Q = a.Q + (size_t)l * S * S;
   double *st = a.scratch + ((size_t)l * NW + wave) * GN_SLOTS * GN_MAT;
   // slot map

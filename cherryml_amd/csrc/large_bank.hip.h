@@ -285,7 +285,6 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 4 : 5) void k1_pt_loss_gt(K1Args
   const int tn = tm + tile;
   const int m0 = tm * LG_TM, n0 = tn * LG_TN;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int lo = lane & 15, hi = lane >> 4;
   const size_t boff = (size_t)b * a.LD * a.LD;
   GemmOperands g{a.Ut, a.Ut, a.LD, a.LD, a.LD, a.LD, a.LD, a.F + (size_t)b * a.LD};
   d4 acc[5], ax0, ax1;
@@ -387,8 +386,6 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 4 : 5) void k3_w_phi(K3Args a) {
     tn = tile - tm * tilesN;
   }
   const int m0 = tm * LG_TM, n0 = tn * LG_TN;
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int lo = lane & 15, hi = lane >> 4;
   const size_t boff = (size_t)b * a.LD * a.LD;
   GemmOperands g{a.T + boff, a.U, a.LD, a.LD, a.LD, a.LD, a.LD, nullptr};
   d4 acc[5], ax0, ax1;

@@ -83,7 +83,7 @@ __device__ __forceinline__ double ub(const double *sV, int x, int s, int lo, int
 
 template <int NT, int KS>
 __device__ __forceinline__ void load_frags(SmallFrags<NT, KS> &f, const double *sV,
-                                           const double *sLam, int S) {
+                                           const double * /*sLam*/, int S) {
   const int lane = threadIdx.x & 63;
   const int lo = lane & 15, hi = lane >> 4;
 #pragma unroll

@@ -128,7 +128,7 @@ __global__ __launch_bounds__(256) void lt_step_pi(LargeTrain a, int epoch, doubl
   if (threadIdx.x == 0) {
     const double loss = *a.loss;
     a.loss_curve[epoch] = loss;
-    const bool better = loss < a.state[0];  // strict <, trainer.py:179
+    const bool better = epoch == 0 || loss < a.state[0];  // strict <, first iterate always taken (trainer.py:179)
     a.state[1] = better ? 1.0 : 0.0;
     if (better) a.state[0] = loss;
   }

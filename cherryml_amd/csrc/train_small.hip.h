@@ -131,7 +131,9 @@ __device__ __forceinline__ void tr_update(const TrainArgs &a, int l, int epoch, 
   const double *dirsum = a.dirsum + (size_t)l * S;
   if (tid == 0) {
     a.loss_curve[(size_t)epoch * a.L + l] = loss;
-    const bool better = loss < *best;  // strict <, as trainer.py:179
+    // strict <, as trainer.py:179; there the first iterate is always taken (`best_loss is None`), also
+    // when its loss is NaN; the SiteRM loop starts from +inf instead (_cherryml_vectorized.py:366)
+    const bool better = (a.kind == 0 && epoch == 0) || loss < *best;
     sFlag[0] = better ? 1.0 : 0.0;
     if (better) *best = loss;
   }

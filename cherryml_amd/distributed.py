@@ -7,8 +7,8 @@ Two ways to build the sharded bank:
   buckets sums them and leaves each rank with exactly the buckets it owns -- no rank ever holds
   the summed [B,S,S] tensor.
 
-Then, per epoch: the bank's buckets are dealt round-robin to the ranks
-(bucket b -> rank b mod world), every rank evaluates the partial loss and
+Then, per epoch: the bank's NON-EMPTY buckets are dealt round-robin to the ranks
+(k-th non-empty bucket -> rank k mod world), every rank evaluates the partial loss and
 partial dL/dQ of its own buckets, and ONE all-reduce (RCCL over xGMI with the
 "nccl" backend; gloo in the CPU tests) of S*S + 1 float64 values per epoch sums
 them (option 1).  The parameters and the optimiser are
@@ -55,22 +55,34 @@ class RcclCommunicator:
         import glob
         import os
         # the RCCL torch itself uses (one library, one set of kernels); CHERRYML_AMD_RCCL_LIB overrides
-        libs = ([os.environ["CHERRYML_AMD_RCCL_LIB"]] if os.environ.get("CHERRYML_AMD_RCCL_LIB") else
-                sorted(glob.glob(os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so*"))))
-        if not libs:
-            raise RuntimeError("RcclCommunicator: no librccl next to torch")
-        self._rccl = rccl = C.CDLL(libs[0])
-        UniqueId = _NcclUniqueId
         on = dist.is_available() and dist.is_initialized()
         rank = dist.get_rank(group) if on else 0
         world = dist.get_world_size(group) if on else 1
+        UniqueId = _NcclUniqueId
         uid = UniqueId()
-        if rank == 0 and rccl.ncclGetUniqueId(C.byref(uid)) != 0:
-            raise RuntimeError("ncclGetUniqueId failed")
+        error, rccl = None, None
+        try:   # the rank-local part; its outcome is exchanged before the first blocking RCCL call
+            libs = ([os.environ["CHERRYML_AMD_RCCL_LIB"]] if os.environ.get("CHERRYML_AMD_RCCL_LIB") else
+                    sorted(glob.glob(os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so*"))))
+            if not libs:
+                raise RuntimeError("RcclCommunicator: no librccl next to torch")
+            rccl = C.CDLL(libs[0])
+            if rank == 0 and rccl.ncclGetUniqueId(C.byref(uid)) != 0:
+                raise RuntimeError("ncclGetUniqueId failed")
+        except Exception as exc:
+            if not (on and world > 1):
+                raise
+            error = f"{type(exc).__name__}: {exc}"
         if on and world > 1:
-            box = [_uid_to_bytes(uid) if rank == 0 else None]
-            dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
-            uid = _uid_from_bytes(box[0])
+            # one exchange carries rank 0's id and every rank's status: ncclCommInitRank blocks until all
+            # ranks have called it, so no rank may enter it while another one has already given up
+            boxes = [None] * world
+            dist.all_gather_object(boxes, (error, _uid_to_bytes(uid) if rank == 0 and error is None else None), group=group)
+            bad = [(r, e) for r, (e, _) in enumerate(boxes) if e is not None]
+            if bad:
+                raise RuntimeError(f"RcclCommunicator: rank {bad[0][0]} failed: {bad[0][1]}")
+            uid = _uid_from_bytes(boxes[0][1])
+        self._rccl = rccl
         comm = C.c_void_p()
         rccl.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, UniqueId, C.c_int]
         rc = rccl.ncclCommInitRank(C.byref(comm), world, uid, rank)
@@ -90,10 +102,12 @@ class RcclCommunicator:
 
 class _ShardedLoss(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, Q, pi, evaluate, inv_n, group):
+    def forward(ctx, Q, pi, evaluate, inv_n, group, already_reduced=False):
         loss, dQ = evaluate(Q.detach(), pi.detach())  # unnormalised partial sums
         packed = torch.cat([loss.reshape(-1), dQ.reshape(-1)]).to(torch.float64)
-        if dist.is_available() and dist.is_initialized():
+        # after enable_in_library_allreduce() the bank's own entry points return job-wide sums
+        # (cb_loss_grad all-reduces on its stream): reducing again would multiply by the world size
+        if not already_reduced and dist.is_available() and dist.is_initialized():
             dist.all_reduce(packed, op=dist.ReduceOp.SUM, group=group)
         packed = packed * inv_n
         nl = loss.numel()
@@ -103,7 +117,7 @@ class _ShardedLoss(torch.autograd.Function):
     @staticmethod
     def backward(ctx, grad_loss):
         (dQ,) = ctx.saved_tensors
-        return (dQ * grad_loss.reshape(-1, 1, 1)).reshape(dQ.shape), None, None, None, None
+        return (dQ * grad_loss.reshape(-1, 1, 1)).reshape(dQ.shape), None, None, None, None, None
 
 
 class ShardedBank:
@@ -128,9 +142,9 @@ class ShardedBank:
         live = np.flatnonzero(np.any(C.reshape(C.shape[0], -1) != 0.0, axis=1))
         if live.size == 0:
             raise ValueError("the bank has no counts")
+        if live.size < self.world:   # known to every rank alike: all raise, none is left waiting in a collective
+            raise ValueError(f"{live.size} non-empty buckets < world={self.world}: some rank would own no bucket")
         mine = live[bucket_shard(live.size, self.rank, self.world)]
-        if mine.size == 0:
-            raise ValueError(f"rank {self.rank} owns no bucket ({live.size} non-empty buckets < world={self.world})")
         self.total_count = float(C.sum())  # every rank sees the full host array here
         self.local_buckets = mine
         self.bank = self._make(make_bank)(t[mine], C[mine])
@@ -146,8 +160,8 @@ class ShardedBank:
     @classmethod
     def from_rank_counts(cls, t, C_rank, make_bank: Optional[Callable] = None, group=None):
         """`C_rank` [B,S,S] (numpy, or a torch tensor already on this rank's GPU): the counts of
-        the families THIS rank counted.  Bucket b belongs to rank b mod world; the tensor is laid
-        out owner-major (zero padded to equal chunks) and reduce-scattered, so rank r receives
+        the families THIS rank counted.  The k-th globally non-empty bucket belongs to rank
+        k mod world; those are laid out owner-major (zero padded to equal chunks) and reduce-scattered, so rank r receives
         sum_over_ranks C[b] for its own buckets only.  The grand total (the loss normaliser) is
         one scalar all-reduce."""
         self = cls.__new__(cls)
@@ -160,10 +174,21 @@ class ShardedBank:
         if Ct.ndim != 3 or Ct.shape[0] != t.size:
             raise ValueError("from_rank_counts: C_rank must be [B,S,S] with B = len(t)")
         B, S = Ct.shape[0], Ct.shape[1]
-        chunk = -(-B // self.world)
-        owner_major = [bucket_shard(B, r, self.world) for r in range(self.world)]
+        # Only non-empty buckets cost anything (cb_create drops the others) and a rank left with empty
+        # buckets only could not even build its bank: deal the GLOBALLY non-empty ones.  Their masses
+        # (B doubles) and the grand total (the loss normaliser) travel in one small all-reduce.
+        stats = torch.cat([Ct.abs().reshape(B, -1).sum(dim=1), Ct.sum().reshape(1)])
+        if on:
+            dist.all_reduce(stats, op=dist.ReduceOp.SUM, group=group)
+        stats = stats.cpu().numpy()
+        live = np.flatnonzero(stats[:B] != 0.0)
+        if live.size == 0:
+            raise ValueError("the bank has no counts")
+        if live.size < self.world:   # the same numbers on every rank: all raise together
+            raise ValueError(f"{live.size} non-empty buckets < world={self.world}: some rank would own no bucket")
+        chunk = -(-live.size // self.world)
+        owner_major = [live[bucket_shard(live.size, r, self.world)] for r in range(self.world)]
         mine = owner_major[self.rank]
-        total = Ct.sum().reshape(1)
         if on:
             packed = torch.zeros((self.world * chunk, S, S), dtype=torch.float64, device=Ct.device)
             for r, idx in enumerate(owner_major):
@@ -175,13 +200,10 @@ class ShardedBank:
                 got = torch.empty((chunk, S, S), dtype=torch.float64, device=Ct.device)
                 dist.reduce_scatter_tensor(got, packed, op=dist.ReduceOp.SUM, group=group)
             del packed
-            dist.all_reduce(total, op=dist.ReduceOp.SUM, group=group)
             C_mine = got[:mine.size]
         else:
-            C_mine = Ct
-        if mine.size == 0:
-            raise ValueError(f"rank {self.rank} owns no bucket (B={B} < world={self.world})")
-        self.total_count = float(total.item())
+            C_mine = Ct[torch.as_tensor(mine, device=Ct.device)]
+        self.total_count = float(stats[B])
         self.local_buckets = mine
         self.bank = cls._make(make_bank)(t[mine], C_mine if C_mine.is_cuda else C_mine.numpy())
         return self
@@ -190,7 +212,7 @@ class ShardedBank:
         """Differentiable (in Q) loss of the WHOLE bank; every rank gets the same value."""
         ev = lambda q, p: self.bank.loss_grad_torch(q, p, normalize=False, want_grad=True)  # noqa: E731
         inv_n = 1.0 / self.total_count if normalize else 1.0
-        return _ShardedLoss.apply(Q, pi, ev, inv_n, self.group)
+        return _ShardedLoss.apply(Q, pi, ev, inv_n, self.group, getattr(self, "rccl", None) is not None)
 
     def enable_in_library_allreduce(self):
         """Hand a raw RCCL communicator to the bank (`cb_allreduce_setup`): from then on the bank's own
@@ -198,7 +220,20 @@ class ShardedBank:
         loop from C -- theta -> A, replicated eigensolve, this rank's buckets, one ncclAllReduce of
         (loss, dL/dA) on the handle's stream, identical Adam steps -- with no torch in the loop.
         Collective: every rank of the group must call it."""
-        self.rccl = RcclCommunicator(self.group)
+        error, rccl = None, None
+        try:
+            rccl = RcclCommunicator(self.group)
+        except Exception as exc:   # exchanged below: a rank failing alone would mix torch and RCCL collectives
+            error = f"{type(exc).__name__}: {exc}"
+        if self.world > 1:
+            errs = [None] * self.world
+            dist.all_gather_object(errs, error, group=self.group)
+            error = next((f"rank {r}: {e}" for r, e in enumerate(errs) if e is not None), None)
+        if error is not None:
+            if rccl is not None:
+                rccl.destroy()
+            raise RuntimeError(f"enable_in_library_allreduce: no raw RCCL communicator ({error})")
+        self.rccl = rccl
         self.bank.allreduce_setup(self.rccl.comm, self.rccl.allreduce_fn, [self.total_count])
         return self
 

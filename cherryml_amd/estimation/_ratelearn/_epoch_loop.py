@@ -77,7 +77,10 @@ def _train_fused(rate_module, bank, optimizer, num_epochs, loss_normalization, r
         rate_module.upper_diag.copy_(torch.as_tensor(r["upper_diag"]))
         rate_module._pi.copy_(torch.as_tensor(r["log_pi"]))
     E = num_epochs
-    rows = [(0.0, 0.0, float(r["loss"][e]), elapsed * (e + 1) / max(E, 1), e, 0.0, 0.0)
+    # `time`: the loop never returns to the host between epochs, so there are no per-epoch timestamps
+    # to record (the reference's column is seconds since the start, trainer.py:213); only the last
+    # row carries a measurement -- the wall time of all E epochs -- the others are NaN, not invented
+    rows = [(0.0, 0.0, float(r["loss"][e]), elapsed if e == E - 1 else float("nan"), e, 0.0, 0.0)
             for e in range(E)]
     Q_dict = {f"Q_{k}": v.copy() for k, v in r["Q_pow2"].items()}
     if E > 0:

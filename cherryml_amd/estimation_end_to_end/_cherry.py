@@ -253,4 +253,13 @@ def coevolution_end_to_end_with_cherryml_optimizer(
         OPENBLAS_NUM_THREADS=num_processes_optimization)["output_rate_matrix_dir"]
     res["rate_matrix_dir_0"] = rate_dir
     res["learned_rate_matrix_path"] = os.path.join(rate_dir, "result.txt")
+    # (the reference's co-evolution pipeline reports no timings, _cherry.py:449-584; these keys are extra)
+    t_count = _runtime(os.path.join(count_dir, "profiling.txt"))
+    t_jtt = _runtime(os.path.join(jtt_dir, "profiling.txt"))
+    t_opt = _runtime(os.path.join(rate_dir, "profiling.txt"))
+    res["time_counting"], res["time_jtt_ipw"], res["time_optimization"] = t_count, t_jtt, t_opt
+    res["profiling_str"] = (
+        "CherryML runtimes:\n"
+        f"time_counting: {t_count}\ntime_jtt_ipw: {t_jtt}\ntime_optimization: {t_opt}\n"
+        f"total_cpu_time: {t_count + t_jtt + t_opt}\n")
     return res

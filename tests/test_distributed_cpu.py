@@ -101,7 +101,13 @@ def _worker_family(rank, world, port, out):
     part = np.floor(C / 3.0) if rank == 0 else C - np.floor(C / 3.0)
     sb = ShardedBank.from_rank_counts(t, part, make_bank=lambda tt, CC: OracleBank(tt, CC))
     assert abs(sb.total_count - float(C.sum())) <= 1e-12 * float(C.sum())
-    assert np.array_equal(sb.bank.C.numpy(), C[rank::world])   # summed counts of MY buckets only
+    live = np.flatnonzero(C.reshape(len(t), -1).any(axis=1))
+    assert live.size < len(t)                                       # the fixture has empty buckets
+    mine = live[rank::world]                                        # only globally non-empty buckets are dealt
+    assert list(sb.local_buckets) == list(mine)
+    assert np.array_equal(sb.bank.C.numpy(), C[mine])               # summed counts of MY buckets only
+    sizes = [live[r::world].size for r in range(world)]
+    assert max(sizes) - min(sizes) <= 1                             # balanced over the LIVE buckets
     Q = torch.tensor(g["init"], dtype=torch.float64, requires_grad=True)
     pi = torch.full((20,), 0.05, dtype=torch.float64)
     loss = sb.loss(Q, pi, normalize=True)[0]
@@ -181,3 +187,97 @@ def test_rccl_communicator_control_flow_two_ranks(tmp_path):
         raw = (out / f"rank{rank}.bin").read_bytes()
         assert int.from_bytes(raw[0:4], "little") == 2 and int.from_bytes(raw[4:8], "little") == rank
         assert raw[8:] == want
+
+
+class LibraryReducingBank(OracleBank):
+    """Stand-in for a CherryBank after cb_allreduce_setup: its own entry point returns job-wide sums."""
+    reduced = False
+
+    def allreduce_setup(self, comm, fn, n_total):
+        assert comm and fn and len(n_total) == 1
+        self.reduced = True
+
+    def loss_grad_torch(self, Q, pi, normalize=False, want_grad=True):
+        loss, dQ = super().loss_grad_torch(Q, pi, normalize=normalize, want_grad=want_grad)
+        if self.reduced:
+            dist.all_reduce(loss)
+            dist.all_reduce(dQ)
+        return loss, dQ
+
+
+def _inlib_worker(rank, world, port, lib, outdir, break_rank):
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, here)
+    sys.path.insert(0, os.path.dirname(here))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), FAKE_RCCL_OUT=outdir,
+                      CHERRYML_AMD_RCCL_LIB=(lib + ".missing") if rank == break_rank else lib)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from cherryml_amd.distributed import ShardedBank
+        g = load_golden("traj_lgbank.npz")
+        t, C = g["t"][::8], g["C"][::8]
+        sb = ShardedBank(t, C, make_bank=lambda tt, CC: LibraryReducingBank(tt, CC))
+        res = {}
+        try:
+            sb.enable_in_library_allreduce()
+            Q = torch.tensor(g["init"], dtype=torch.float64, requires_grad=True)
+            loss = sb.loss(Q, torch.full((20,), 0.05, dtype=torch.float64), normalize=True)[0]
+            loss.backward()
+            res = dict(loss=loss.item(), grad=Q.grad)
+        except RuntimeError as exc:
+            res = dict(error=str(exc))
+        torch.save(res, os.path.join(outdir, f"i{rank}.pt"))
+        sb.close()
+    finally:
+        dist.destroy_process_group()
+
+
+def _fake_rccl(tmp_path):
+    import shutil
+    import subprocess
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    from conftest import ROOT
+    lib = str(tmp_path / "libfake_rccl.so")
+    subprocess.check_call(["gcc", "-shared", "-fPIC", "-O1", "-o", lib, os.path.join(ROOT, "tests", "fixtures", "fake_rccl.c")])
+    return lib
+
+
+def test_in_library_allreduce_is_not_reduced_twice(tmp_path):
+    """after enable_in_library_allreduce() the bank itself returns job-wide sums, so
+    ShardedBank.loss must not all-reduce them again (the loss came out world times too large)."""
+    from oracle import ratelearn_oracle as orc
+    lib = _fake_rccl(tmp_path)
+    out = tmp_path / "out"
+    out.mkdir()
+    mp.spawn(_inlib_worker, args=(2, _free_port(), lib, str(out), -1), nprocs=2, join=True)
+    r0, r1 = torch.load(out / "i0.pt"), torch.load(out / "i1.pt")
+    g = load_golden("traj_lgbank.npz")
+    Q = torch.tensor(g["init"], dtype=torch.float64, requires_grad=True)
+    ref = orc.bank_loss(Q, torch.tensor(g["t"][::8]), torch.tensor(g["C"][::8]))
+    ref.backward()
+    assert r0["loss"] == r1["loss"]
+    assert abs(r0["loss"] - ref.item()) < 1e-12 * abs(ref.item())
+    assert relerr(r0["grad"].numpy(), Q.grad.numpy()) < 1e-11
+
+
+def test_communicator_failure_on_one_rank_raises_on_all(tmp_path):
+    """A rank that cannot make its RCCL communicator must not strand its peers in ncclCommInitRank or
+    leave the job mixing torch and in-library collectives: every rank raises."""
+    lib = _fake_rccl(tmp_path)
+    out = tmp_path / "out"
+    out.mkdir()
+    mp.spawn(_inlib_worker, args=(2, _free_port(), lib, str(out), 1), nprocs=2, join=True)
+    for r in range(2):
+        res = torch.load(out / f"i{r}.pt")
+        assert "error" in res and "rank 1" in res["error"], res
+
+
+def test_too_few_live_buckets_raises_on_every_rank():
+    from cherryml_amd.distributed import ShardedBank
+    C = np.zeros((4, 3, 3))
+    with pytest.raises(ValueError, match="no counts"):
+        ShardedBank(np.arange(1.0, 5.0), C, make_bank=lambda tt, CC: OracleBank(tt, CC))
+    with pytest.raises(ValueError, match="no counts"):
+        ShardedBank.from_rank_counts(np.arange(1.0, 5.0), C, make_bank=lambda tt, CC: OracleBank(tt, CC))

@@ -573,3 +573,41 @@ def test_hybrid_and_tournament_eigensolvers_agree_on_a_degenerate_spectrum(monke
     assert np.all(np.isfinite(a["loss"])) and a["loss"][-1] < a["loss"][0]
     assert np.allclose(a["loss"], b["loss"], rtol=1e-11, atol=0)
     assert relerr(a["Q_last"], b["Q_last"]) < 1e-8 and relerr(a["Q_best"], b["Q_best"]) < 1e-8
+
+
+def test_failing_rank_keeps_its_place_in_every_collective():
+    """VERDICT r1 (multi-GPU): a rank whose epoch fails must not strand its peers in ncclAllReduce.
+    The all-reduce handed to cb_allreduce_setup is a counting callback here (one rank: the in-place sum
+    is the identity).  A step size of 1e300 makes the parameters non-finite after the first step, so the
+    eigensolver of epoch 1 refuses its input: the call returns an error AND has still entered both
+    collectives of every one of the E epochs (with NaN payloads, which make the peers fail the same way)."""
+    import ctypes as C
+    from cherryml_amd import CherryBank
+    rng = np.random.default_rng(5)
+    S, B, E = 48, 5, 6
+    t = np.sort(rng.uniform(0.05, 1.5, size=B))
+    Cc = rng.poisson(3.0, size=(B, S, S)).astype(np.float64)
+    Cc = Cc + Cc.transpose(0, 2, 1)
+    calls = []
+    proto = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_void_p)
+    cb = proto(lambda s, r, n, dt, op, comm, stream: (calls.append(int(n)), 0)[1])
+    fn = C.cast(cb, C.c_void_p).value
+    u0 = rng.normal(0.0, 0.3, size=S * (S - 1) // 2)
+    p0 = rng.normal(0.0, 0.2, size=S)
+    with CherryBank(t, Cc) as bank:
+        bank.allreduce_setup(0xC0FFEE, fn, bank.total_counts)
+        assert calls == [S]                                    # the count margins, once
+        del calls[:]
+        ok = bank.train_pande_reversible(u0, p0, num_epochs=E, lr=0.1)
+        LD = -(-S // 16) * 16
+        assert calls == [1, LD * LD] * E and np.all(np.isfinite(ok["loss"]))
+        del calls[:]
+        with pytest.raises(ValueError, match="non-finite"):
+            bank.train_pande_reversible(u0, p0, num_epochs=E, lr=1e300)
+        assert calls == [1, LD * LD] * E, calls               # every epoch's two collectives were entered
+        # single evaluations: a failing call still enters its collective
+        del calls[:]
+        Q = np.full((S, S), np.nan)
+        with pytest.raises(ValueError):
+            bank.loss_grad(Q, np.full(S, 1.0 / S))
+        assert calls == [1, S * S]

@@ -130,3 +130,26 @@ def test_public_api_lg_with_given_trees_and_with_fast_cherries(tmp_path):
     for fam in fams:
         tdirs = [cache2 / "fast_cherries" / h / "output_tree_dir" for h in os.listdir(cache2 / "fast_cherries")]
         assert all((d / f"{fam}.txt").exists() and (d / "result.success").exists() for d in tdirs)
+
+
+def test_public_api_coevolution_runs_to_completion(tmp_path):
+    """`cherryml_public_api(model_name="co-evolution")` end to end (reference
+    `_cherryml_public_api.py:207-247`): same golden and tolerance as the pipeline test above; the reference
+    returns nothing for this model, this build returns its (extra) profiling string."""
+    from cherryml_amd._cherryml_public_api import cherryml_public_api
+    from cherryml_amd.io import read_rate_matrix
+    z = load_golden("demo_e2e.npz")
+    dirs, fams = _materialise(tmp_path, z)
+    pairs = [a + b for a in AA for b in AA]
+    mask = np.unpackbits(z["co_mask_packed"])[:160000].reshape(400, 400)
+    mpath = str(tmp_path / "mask.txt")
+    pd.DataFrame(mask, index=pairs, columns=pairs).to_csv(mpath, sep=" ")
+    out = str(tmp_path / "learned_co.txt")
+    prof = cherryml_public_api(output_path=out, model_name="co-evolution", msa_dir=dirs["msa"],
+                               contact_map_dir=dirs["contact_map"], tree_dir=dirs["tree"],
+                               cache_dir=str(tmp_path / "cache"), num_epochs=int(z["co_epochs"]), families=fams,
+                               coevolution_mask_path=mpath, tree_estimator_name="FastTree")
+    assert isinstance(prof, str) and "time_optimization" in prof
+    learned = read_rate_matrix(out)
+    assert list(learned.columns) == pairs
+    assert relerr(learned.to_numpy(), z["co_Q_best_f64"]) < 1e-6
