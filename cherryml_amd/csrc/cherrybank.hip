@@ -766,6 +766,8 @@ extern "C" int cb_loss_grad(cb_handle h, const double *Q, const double *pi, int 
     rc = launch_small<SMALL_LOSSGRAD>(h, a);
     mark(h, EV_SMALL);
   }
+  if (rc == CB_OK && getenv("CB_FAULT_INJECT") && atoi(getenv("CB_FAULT_INJECT")) == -1)
+    rc = fail(CB_ENUMERIC, "injected fault (CB_FAULT_INJECT)");
   if (rc != CB_OK && h->comm) {   // keep this rank's place in the collective (NaN payload): the peers get NaN, not a hang
     const std::string first_error = g_err;
     (void)hipMemsetAsync(lossd, 0xFF, h->L * sizeof(double), h->stream);
@@ -1033,6 +1035,8 @@ static int run_fused_training_large(cb_bank *h, double *pi_param, double *up_par
   if (h->profile) fold_pending(h);
   if (dbg) fprintf(stderr, "[cherrybank] large trainer: parameters uploaded after %.2f ms\n", now() - t_enter);
   double pow_b1 = 1.0, pow_b2 = 1.0;
+  // fault injection for the tests of the collective failure protocol: this rank's evaluation "fails" at that epoch
+  const int fault_epoch = getenv("CB_FAULT_INJECT") ? atoi(getenv("CB_FAULT_INJECT")) : -1000;
   for (int e = 0; e < E && rc == CB_OK; ++e) {
     if (h->profile) {  // fold the epoch before the previous one (its events are long complete), then re-record that set
       swap_event_sets(h);
@@ -1043,6 +1047,7 @@ static int run_fused_training_large(cb_bank *h, double *pi_param, double *up_par
     hipLaunchKernelGGL(lt_build, dim3(LD), dim3(256), 0, h->stream, a, e);
     mark(h, EV_START);
     rc = large_eval(h, flags & CB_NORMALIZE, h->loss, h->Mt, true, nullptr);
+    if (rc == CB_OK && fault_epoch == e) rc = fail(CB_ENUMERIC, "injected fault at epoch %d (CB_FAULT_INJECT)", e);
     if (rc != CB_OK && h->comm) {
       // A rank that fails alone (its eigensolver met a non-finite matrix, say) must not leave its peers
       // waiting in this epoch's ncclAllReduce -- and a host-side status exchange per epoch would cost a
