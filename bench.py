@@ -35,6 +35,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8.0 TB/s spec
 F64_PEAK_TFLOPS = 78.6     # 256 CU x 4 SIMD x 32 flop/clk x 2.4 GHz (f64 MFMA = f64 vector rate)
+F32_PEAK_TFLOPS = 157.3    # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 / 32x32x2, 64 flop/clk/SIMD (exact f32)
 
 
 # --------------------------------------------------------------------- inputs
@@ -184,6 +185,8 @@ def main():
     ap.add_argument("--workload", default="coevo400",
                     choices=["coevo400", "lg20", "siterm", "counting", "ble", "assembly", "likelihood"])
     ap.add_argument("--sites", type=int, default=5000)
+    ap.add_argument("--dtype", default="f64", choices=["f64", "f32"],
+                    help="element type of the bank products (coevo400 only): f32 = float32 MFMA (cb_create dtype CB_F32)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true")
     ap.add_argument("--force-sharded", action="store_true",
@@ -222,6 +225,7 @@ def main():
         rng = np.random.default_rng(0)
         wl = make_workload(workload, args.sites, rng)
         S = wl["S"]
+        bank_dtype = args.dtype if S > 32 else "f64"   # the small-state kernels are float64
         if wl["kind"] == "single" and S > 32 and (world > 1 or args.force_sharded):
             # ---- co-evolution on N > 1 GPUs: torch keeps theta -> Q and Adam (the collective is
             #      torch.distributed's), HIP does loss + dL/dQ; buckets sharded over the ranks,
@@ -237,7 +241,7 @@ def main():
             # the sufficient statistics of its 1/N of the families (here: 1/N of the bank's counts); ONE
             # reduce-scatter over the non-empty buckets sums them and leaves each rank with the buckets
             # it owns; then per epoch one all-reduce of S^2 + 1 doubles.
-            sharded = ShardedBank.from_rank_counts(wl["t"], torch.tensor(wl["C"] / world, device=dev))
+            sharded = ShardedBank.from_rank_counts(wl["t"], torch.tensor(wl["C"] / world, device=dev), dtype=bank_dtype)
             bank = sharded.bank
             n_pairs_total, scaling = wl["n_pairs"], "strong"
             sharding = (f"one bank; families x{world} -> reduce-scatter of the counts over buckets (once), "
@@ -300,7 +304,7 @@ def main():
             #      co-evolution on one GPU: C-driven kernel sequence (train_large.hip.h);
             #      LG: one 0.4 MB bank does not shard -> N independent replicas;
             #      SiteRM: every rank owns its own `--sites` sites (no collective).
-            bank = cherryml_amd.CherryBank(wl["t"], wl["C"], device=local_rank)
+            bank = cherryml_amd.CherryBank(wl["t"], wl["C"], device=local_rank, dtype=bank_dtype)
             n_pairs_total, scaling = wl["n_pairs"] * world, "weak"
             B_local = wl["C"].shape[-3]
             glue = ("whole loop on the device, driven from C (theta->A, eigh, bank, grads, Adam in HIP)" if S > 32
@@ -357,11 +361,12 @@ def main():
             # and back-rotation; 49.6 GFLOP at S = 400, B = 129) over the WALL time of one step
             epoch_flops = 6.0 * wl["C"].shape[0] * S ** 3 + 13.0 * S ** 3
             epoch_tflops = epoch_flops / (dt / steps) / 1e12
-            roofline = dict(bound="mfma", kernel=names[dom], achieved=achieved,
-                            peak=F64_PEAK_TFLOPS, unit="TFLOP/s", frac=achieved / F64_PEAK_TFLOPS,
-                            epoch_frac=epoch_tflops / (F64_PEAK_TFLOPS * world), epoch_tflops=epoch_tflops,
+            peak = F32_PEAK_TFLOPS if bank_dtype == "f32" else F64_PEAK_TFLOPS
+            roofline = dict(bound="mfma", kernel=names[dom] + ("<float>" if bank_dtype == "f32" else "<double>"),
+                            achieved=achieved, peak=peak, unit="TFLOP/s", frac=achieved / peak,
+                            epoch_frac=epoch_tflops / (peak * world), epoch_tflops=epoch_tflops,
                             epoch_flops=epoch_flops,
-                            traffic=traffic.get(names[dom]) if world == 1 else None,
+                            traffic=traffic.get(names[dom] + ("_f32" if bank_dtype == "f32" else "")) if world == 1 else None,
                             ms_per_launch=tm[dom], flops_per_launch=flops,
                             note="achieved = algorithmic 2 S^3 B flops (SURVEY 8d) / launch time; k1 (Pt symmetric) "
                                  f"and k3 (symmetric counts) multiply only the upper-triangular tiles, {tri:.2f} of "
@@ -382,10 +387,13 @@ def main():
             "metric": "cherry-pairs/sec (whole node) per EM iter",
             "value": n_pairs_total / (dt / steps), "unit": "cherry-pairs/s", "n_gpus": world,
             "steps": steps, "warmup": warmup, "ms_per_step": dt / steps * 1e3,
-            "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": "f64",
+            "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": bank_dtype,
             "data": "synthetic",
             "config": {"workload": wl["desc"], "states": S, "buckets": 129, "sharding": sharding,
-                       "epoch": glue},
+                       "epoch": glue,
+                       **({"arithmetic": "float32 operands + float32 MFMA accumulation in P_b, G_b U, (T_b^T U) o Phi_b; "
+                                         "eigensolver, loss sums, divided differences, bucket sum, Adam in float64"}
+                          if bank_dtype == "f32" else {})},
             "roofline": roofline,
             "epochs_per_s": steps / dt,   # the epoch's cost does not depend on the pair count
             "phase_ms": {k: round(v, 4) for k, v in tm.items()},

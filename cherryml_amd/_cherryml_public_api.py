@@ -4,7 +4,7 @@ stages behind it are this package's: FastCherries (`tree_estimator_name="FastChe
 the host, branch lengths / site rates on the GPU) or trees handed over in `tree_dir` (+ `site_rates_dir`),
 GPU counting, JTT-IPW, and the optimiser of the hot path.  FastTree / PhyML are external programs the
 reference shells out to; they are not built here (give `tree_dir`, or use FastCherries).  The optimiser
-runs on the GPU whatever `optimizer_device` says except "cpu", which is refused like everywhere else."""
+runs on the MI355X whatever `optimizer_device` says ("cpu", the reference's default, or "cuda": cherryml_amd/_device.py)."""
 import os
 import tempfile
 from functools import partial
@@ -40,7 +40,7 @@ def cherryml_public_api(
     quantization_grid_step: float = 1.1,
     quantization_grid_num_steps: int = 64,
     use_cpp_counting_implementation: bool = True,
-    optimizer_device: str = "cuda",
+    optimizer_device: str = "cpu",
     learning_rate: float = 1e-1,
     num_epochs: int = 500,
     minimum_distance_for_nontrivial_contact: int = 7,

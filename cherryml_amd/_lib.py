@@ -8,6 +8,7 @@ from ._build import LIB
 CB_PTR_DEVICE = 1
 CB_NORMALIZE = 2
 CB_NO_SYNC = 4
+CB_F64, CB_F32 = 0, 1
 
 CB_EINVAL, CB_EHIP, CB_ENOMEM, CB_ENUMERIC, CB_EUNSUPPORTED = -1, -2, -3, -4, -5
 
@@ -19,7 +20,7 @@ SIGNATURES = {
     "cb_version": (C.c_int, []),
     "cb_last_error": (C.c_char_p, []),
     "cb_device_count": (C.c_int, []),
-    "cb_create": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, C.c_int, C.POINTER(_vp)]),
+    "cb_create": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, C.c_int, C.POINTER(_vp)]),
     "cb_destroy": (None, [_vp]),
     "cb_set_stream": (C.c_int, [_vp, _vp, C.c_int]),
     "cb_total_counts": (C.c_int, [_vp, _vp]),

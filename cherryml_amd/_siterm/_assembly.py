@@ -146,15 +146,15 @@ def estimate_site_specific_rate_matrices_given_tree_and_site_rates(
     transitions_strategy: str = "cherry++", include_reverse_transitions: bool = True,
     rate_matrix_parameterization: str = "pande_reversible", log_dir: Optional[str] = None,
     plot_site_specific_rate_matrices: int = 0, use_vectorized_cherryml_implementation: bool = True,
-    vectorized_cherryml_implementation_device: str = "cuda",
+    vectorized_cherryml_implementation_device: str = "cpu",
     vectorized_cherryml_implementation_num_cores: int = 1,
 ) -> Dict:
     """:442-731 (`_estimate_site_specific_rate_matrices_given_tree_and_site_rates`), vectorised path:
     {"res": [L,S,S] site-specific rate matrices, "time_*": seconds per sub-step}.  Sites without
     any count (e.g. all gaps) get the prior `Q0 * rate_l`, like the reference's per-site path
     (:655-658)."""
-    if vectorized_cherryml_implementation_device != "cuda":
-        raise NotImplementedError("this build computes on the GPU only: device must be 'cuda'")
+    from .._device import resolve_device
+    resolve_device(vectorized_cherryml_implementation_device, "estimate_site_specific_rate_matrices_given_tree_and_site_rates")
     if rate_matrix_parameterization != "pande_reversible":
         raise NotImplementedError("only the reference's default parameterisation 'pande_reversible'")
     import torch

@@ -107,7 +107,7 @@ def learn_site_rate_matrices(
     regularization_rate_matrix,
     regularization_strength: float,
     use_vectorized_implementation: bool = True,
-    vectorized_implementation_device: str = "cuda",
+    vectorized_implementation_device: str = "cpu",
     vectorized_implementation_num_cores: int = 1,
     site_rate_grid: List[float] = [2.0 ** i for i in range(-10, 10)],
     site_rate_prior: List[float] = [1.0 for i in range(-10, 10)],
@@ -121,8 +121,8 @@ def learn_site_rate_matrices(
     """:1109-1282.  Returns {"learnt_rate_matrices": [L,S,S], "learnt_site_rates": [L], "learnt_tree": tree,
     "time_*": seconds}.  Differences from the reference, all loud: the device must be "cuda", and only the
     vectorised implementation with the fast site-rate estimator exists."""
-    if vectorized_implementation_device != "cuda":
-        raise NotImplementedError("this build computes on the GPU only: device must be 'cuda'")
+    from .._device import resolve_device
+    vectorized_implementation_device = resolve_device(vectorized_implementation_device, "learn_site_rate_matrices")
     if not use_vectorized_implementation:
         raise NotImplementedError("the per-site CPU loop of the reference is not built: use_vectorized_implementation=True")
     prof = {}
@@ -187,7 +187,7 @@ def learn_site_specific_rate_matrices(
     alphabet: List[str],
     regularization_rate_matrix,
     regularization_strength: float = 0.5,
-    device: str = "cuda",
+    device: str = "cpu",
     num_rate_categories: int = 20,
     alphabet_for_site_rate_estimation: Optional[List[str]] = None,
     rate_matrix_for_site_rate_estimation=None,
@@ -197,8 +197,8 @@ def learn_site_specific_rate_matrices(
     just_run_fast_cherries: bool = False,
 ) -> Dict:
     """The SiteRM public entry point (cherryml/_siterm_public_api.py:21-172): standard site-rate grid and
-    Gamma(3, 1/3) prior, fast site-rate estimator, vectorised optimiser.  `device` defaults to "cuda" here
-    (the reference's default "cpu" is refused: there is no CPU path)."""
+    Gamma(3, 1/3) prior, fast site-rate estimator, vectorised optimiser.  `device` keeps the reference's
+    default "cpu"; either spelling runs on the MI355X (cherryml_amd/_device.py)."""
     return learn_site_rate_matrices(
         tree=tree, leaf_states=msa, alphabet=alphabet, regularization_rate_matrix=regularization_rate_matrix,
         regularization_strength=regularization_strength,

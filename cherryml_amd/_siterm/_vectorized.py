@@ -68,9 +68,8 @@ def quantized_transitions_mle_vectorized_over_sites(
     prof = {}
     st = time.time()
     logger = logging.getLogger(__name__)
-    if device != "cuda":
-        raise NotImplementedError(
-            "cherryml_amd runs this on the MI355X only: pass device='cuda' (no CPU fallback)")
+    from .._device import resolve_device
+    resolve_device(device, "quantized_transitions_mle_vectorized_over_sites")   # "cpu" and "cuda": the MI355X
     if not torch.cuda.is_available():
         raise ValueError("device=cuda requested but device not available.")
     dev = torch.device("cuda")

@@ -20,8 +20,15 @@ class CherryBank:
     uploaded once to `device` and kept there (the reference re-uploads them
     every epoch: cherryml/estimation/_ratelearn/trainer.py:164-167)."""
 
-    def __init__(self, t, C, device: int = 0):
+    def __init__(self, t, C, device: int = 0, dtype: str = "f64"):
+        """dtype: element type of the bank products (cb_create's `dtype`): "f64", or "f32" -- the
+        reference's own arithmetic, ratelearner.py:98,107 -- for S > 32 (float32 MFMA; the
+        eigendecomposition, loss accumulation and everything crossing the ABI stay float64)."""
         self._h = None
+        if dtype not in ("f64", "f32"):
+            raise ValueError(f'dtype must be "f64" or "f32", got {dtype!r}')
+        self.dtype = dtype
+        code = _lib.CB_F32 if dtype == "f32" else _lib.CB_F64
         lib = _lib.load()
         if lib.cb_device_count() <= 0:
             raise _lib.CherryBankError("no HIP device visible; cherryml_amd has no CPU fallback")
@@ -50,7 +57,7 @@ class CherryBank:
             if td.numel() != self.L * self.B:
                 raise ValueError("t must have L*B (or B) entries")
             torch.cuda.synchronize(Cd.device)
-            rc = lib.cb_create(Cd.device.index or 0, self.S, self.L, self.B, td.data_ptr(),
+            rc = lib.cb_create(Cd.device.index or 0, self.S, self.L, self.B, code, td.data_ptr(),
                                Cd.data_ptr(), CB_PTR_DEVICE, Ct.byref(h))
             self.device = Cd.device.index or 0
         else:
@@ -62,7 +69,7 @@ class CherryBank:
                 raise ValueError("t must have L*B (or B) entries")
             if not (np.all(np.isfinite(Cn)) and np.all(np.isfinite(tn))):
                 raise ValueError("non-finite counts or branch lengths")
-            rc = lib.cb_create(self.device, self.S, self.L, self.B, tn.ctypes.data, Cn.ctypes.data,
+            rc = lib.cb_create(self.device, self.S, self.L, self.B, code, tn.ctypes.data, Cn.ctypes.data,
                                0, Ct.byref(h))
         _lib.check(rc, "cb_create")
         self._h = h

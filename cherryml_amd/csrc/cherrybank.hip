@@ -26,7 +26,7 @@
 #include "ble.hip.h"
 #include "likelihood.hip.h"
 
-#define CB_ABI_VERSION 1
+#define CB_ABI_VERSION 2
 
 // ------------------------------------------------------------------ errors
 static thread_local std::string g_err;
@@ -52,6 +52,7 @@ static int fail(int code, const char *fmt, ...) {
 // ------------------------------------------------------------------ handle
 struct cb_bank {
   int dev = 0, S = 0, L = 0, B = 0;
+  int dtype = CB_F64;   // element type of the bank products (large path): CB_F64 or CB_F32
   int LD = 0;           // large path: padded leading dimension
   bool large = false;
   hipStream_t own_stream = nullptr, stream = nullptr;
@@ -89,6 +90,8 @@ struct cb_bank {
   double *A = nullptr, *dsq = nullptr, *Gc = nullptr, *Vc = nullptr, *U = nullptr, *lam = nullptr,
          *sigma = nullptr, *F = nullptr, *E = nullptr, *H = nullptr, *Gt = nullptr, *T = nullptr,
          *Mt_part = nullptr, *Mt = nullptr, *X = nullptr, *loss_part = nullptr;
+  // CB_F32 (large path): counts, Gt / W, T and the per-epoch operand copies in float32
+  float *Ct32 = nullptr, *Gt32 = nullptr, *T32 = nullptr, *Uf = nullptr, *Utf = nullptr, *Af = nullptr, *Ff = nullptr;
   unsigned long long *off_bits = nullptr;
   unsigned long long *poll = nullptr;      // 8 words of coherent pinned host memory the first-order sweep publishes to
   unsigned long long poll_seq = 0;
@@ -330,10 +333,14 @@ __global__ void transpose_small(int S, int B, int Bl, const int *nlive, const in
   }
 }
 
-extern "C" int cb_create(int device, int S, int L, int B, const double *t, const double *C,
+extern "C" int cb_create(int device, int S, int L, int B, int dtype, const double *t, const double *C,
                          int flags, cb_handle *out) {
   if (!out) return fail(CB_EINVAL, "cb_create: out is NULL");
   *out = nullptr;
+  if (dtype != CB_F64 && dtype != CB_F32) return fail(CB_EINVAL, "cb_create: dtype must be CB_F64 or CB_F32 (got %d)", dtype);
+  if (dtype == CB_F32 && S <= 32)
+    return fail(CB_EUNSUPPORTED, "cb_create: CB_F32 is built for the MFMA-bound large path only (S > 32; got S=%d): "
+                                 "the small-state kernels are float64", S);
   if (S < 2 || L < 1 || B < 1) return fail(CB_EINVAL, "cb_create: need S>=2, L>=1, B>=1 (got %d,%d,%d)", S, L, B);
   const bool expm_only = (flags & CB_EXPM_ONLY) != 0;
   if (!t || (!C && !expm_only)) return fail(CB_EINVAL, "cb_create: t and C must not be NULL");
@@ -350,6 +357,7 @@ extern "C" int cb_create(int device, int S, int L, int B, const double *t, const
   h->L = L;
   h->B = B;
   h->large = S > 32;
+  h->dtype = expm_only ? CB_F64 : dtype;   // a counts-free handle has no bank products to narrow
   h->expm_only = expm_only;
   h->LD = (S + 15) / 16 * 16;
   auto cleanup = [&](int rc) {
@@ -487,8 +495,14 @@ extern "C" int cb_create(int device, int S, int L, int B, const double *t, const
     h->k3_chunk = 4;
     h->k3_nchunks = (B + h->k3_chunk - 1) / h->k3_chunk;
     double *tot = nullptr;
-    const size_t per_bucket = expm_only ? 0 : (size_t)Bl * LL;   // Ct / Gt / T exist for the loss only
+    const bool f32 = h->dtype == CB_F32;
+    const size_t per_bucket = (expm_only || f32) ? 0 : (size_t)Bl * LL;   // Ct / Gt / T exist for the loss only
+    const size_t per_bucket32 = f32 ? (size_t)Bl * LL : 0;
     bool ok = dev_alloc(h, &h->Ct, per_bucket) == CB_OK && dev_alloc(h, &tot, SS) == CB_OK &&
+              dev_alloc(h, &h->Ct32, per_bucket32) == CB_OK && dev_alloc(h, &h->Gt32, per_bucket32) == CB_OK &&
+              dev_alloc(h, &h->T32, per_bucket32) == CB_OK && dev_alloc(h, &h->Uf, f32 ? LL : 0) == CB_OK &&
+              dev_alloc(h, &h->Utf, f32 ? LL : 0) == CB_OK && dev_alloc(h, &h->Af, f32 ? LL : 0) == CB_OK &&
+              dev_alloc(h, &h->Ff, f32 ? (size_t)B * h->LD : 0) == CB_OK &&
               dev_alloc(h, &h->A, LL) == CB_OK && dev_alloc(h, &h->dsq, h->LD) == CB_OK &&
               dev_alloc(h, &h->Gc, LL) == CB_OK && dev_alloc(h, &h->Vc, LL) == CB_OK &&
               dev_alloc(h, &h->Gc2, LL) == CB_OK && dev_alloc(h, &h->gx, 12 * LL + (size_t)h->LD + 16 + 3 * 256 + 8) == CB_OK &&
@@ -511,12 +525,15 @@ extern "C" int cb_create(int device, int S, int L, int B, const double *t, const
     hipLaunchKernelGGL(prep_counts_large_fin, dim3(1), dim3(256), 0, h->stream, S, tot, h->n_dev,
                        h->inv_n, h->ones, h->dirsum);
     const int nt32 = (h->LD + 31) / 32;
-    hipLaunchKernelGGL(lg_transpose_pad, dim3(nt32, nt32, Bl), dim3(32, 8), 0, h->stream, S, h->LD,
-                       Cdev, h->Ct, src_idx);
+    if (f32) hipLaunchKernelGGL(lg_transpose_pad<float>, dim3(nt32, nt32, Bl), dim3(32, 8), 0, h->stream, S, h->LD,
+                                Cdev, h->Ct32, src_idx);
+    else hipLaunchKernelGGL(lg_transpose_pad<double>, dim3(nt32, nt32, Bl), dim3(32, 8), 0, h->stream, S, h->LD,
+                            Cdev, h->Ct, src_idx);
     {
       int *flag = reinterpret_cast<int *>(h->status);  // [L] ints, unused by the large path
       (void)hipMemsetAsync(flag, 0, sizeof(int), h->stream);
-      hipLaunchKernelGGL(lg_sym_check, dim3(nt32, nt32, Bl), dim3(32, 32), 0, h->stream, h->LD, h->Ct, flag);
+      if (f32) hipLaunchKernelGGL(lg_sym_check<float>, dim3(nt32, nt32, Bl), dim3(32, 32), 0, h->stream, h->LD, h->Ct32, flag);
+      else hipLaunchKernelGGL(lg_sym_check<double>, dim3(nt32, nt32, Bl), dim3(32, 32), 0, h->stream, h->LD, h->Ct, flag);
       int hf = 1;
       if (hipMemcpyAsync(&hf, flag, sizeof hf, hipMemcpyDeviceToHost, h->stream) == hipSuccess &&
           hipStreamSynchronize(h->stream) == hipSuccess)
@@ -670,13 +687,22 @@ static int large_eval(cb_bank *h, bool normalize, double *lossd, double *out, bo
                      h->stream, LD, B, tb, h->lam, h->sigma, h->F, h->E, h->H);
   const int tm = (LD + LG_TM - 1) / LG_TM, tn = (LD + LG_TN - 1) / LG_TN, tiles = tm * tn;
   const double inv_n = normalize ? 1.0 / (h->comm ? h->n_global[0] : h->n_host[0]) : 1.0;
-  K1Args k1{S, LD, B, h->Vc, h->A, tb, h->F, h->sigma, h->Ct, h->Gt, h->loss_part, inv_n, h->dsq, Pd};
-  mark(h, EV_END);  // (re-used as "before K1" marker)
   const int tiles_k1 = tn * (tn + 1) / 2;  // Pt is symmetric: upper-triangular tiles only
-  // four waves per workgroup (one per SIMD) unless CB_FIVE_WAVES asks for the strip-per-wave kernels
-  static const bool five = getenv("CB_FIVE_WAVES") != nullptr;
-  if (five) hipLaunchKernelGGL(k1_pt_loss_gt<5>, dim3(tiles_k1 * B), dim3(LG_THREADS), 0, h->stream, k1);
-  else hipLaunchKernelGGL(k1_pt_loss_gt<4>, dim3(tiles_k1 * B), dim3(LG4_THREADS), 0, h->stream, k1);
+  const int tiles_k3 = h->sym_counts ? tiles_k1 : tiles;
+  // float32 bank (cb_create(dtype = CB_F32)): the loss / gradient products run on the f32 MFMA from f32
+  // copies of this epoch's U, U^T, A and F; cb_expm_bank (Pd) always takes the float64 kernels
+  const bool f32 = h->dtype == CB_F32 && !Pd;
+  if (f32)
+    hipLaunchKernelGGL(lg_cast_f32, dim3((unsigned)((std::max(LL, (size_t)B * LD) + 255) / 256)), dim3(256), 0, h->stream, LL,
+                       (size_t)B * LD, h->U, h->Vc, h->A, h->F, h->Uf, h->Utf, h->Af, h->Ff);
+  mark(h, EV_END);  // (re-used as "before K1" marker)
+  if (f32) {
+    K1Args<float> k1{S, LD, B, h->Utf, h->Af, tb, h->Ff, h->sigma, h->Ct32, h->Gt32, h->loss_part, inv_n, h->dsq, nullptr};
+    hipLaunchKernelGGL(k1_pt_loss_gt<float>, dim3(tiles_k1 * B), dim3(LG4_THREADS), 0, h->stream, k1);
+  } else {
+    K1Args<double> k1{S, LD, B, h->Vc, h->A, tb, h->F, h->sigma, h->Ct, h->Gt, h->loss_part, inv_n, h->dsq, Pd};
+    hipLaunchKernelGGL(k1_pt_loss_gt<double>, dim3(tiles_k1 * B), dim3(LG4_THREADS), 0, h->stream, k1);
+  }
   mark(h, EV_K1);
   if (Pd) {
     HIP_TRY(hipGetLastError());
@@ -685,16 +711,25 @@ static int large_eval(cb_bank *h, bool normalize, double *lossd, double *out, bo
   hipLaunchKernelGGL(lg_finish_loss, dim3(1), dim3(256), 0, h->stream, h->loss_part, B * tiles_k1, S,
                      h->dsq, h->dirsum, inv_n, lossd);
   if (dQd) {
-    K2Args k2{LD, h->Gt, h->U, h->T};
-    if (five) hipLaunchKernelGGL(k2_t_eq_g_u<5>, dim3(tiles * B), dim3(LG_THREADS), 0, h->stream, k2);
-    else hipLaunchKernelGGL(k2_t_eq_g_u<4>, dim3(tiles * B), dim3(LG4_THREADS), 0, h->stream, k2);
-    mark(h, EV_K2);
-    K3Args k3{LD, B, h->T, h->U, tb, h->lam, h->E, h->H, h->Gt, h->sym_counts ? 1 : 0};
-    if (five) hipLaunchKernelGGL(k3_w_phi<5>, dim3((h->sym_counts ? tiles_k1 : tiles) * B), dim3(LG_THREADS), 0, h->stream, k3);
-    else hipLaunchKernelGGL(k3_w_phi<4>, dim3((h->sym_counts ? tiles_k1 : tiles) * B), dim3(LG4_THREADS), 0, h->stream, k3);
-    mark(h, EV_K3);
-    hipLaunchKernelGGL(k3_reduce, dim3((unsigned)((LL + 255) / 256)), dim3(256), 0, h->stream,
-                       h->Gt, B, LL, h->Mt, h->sym_counts ? LD : 0);
+    if (f32) {
+      K2Args<float> k2{LD, h->Gt32, h->Uf, h->T32};
+      hipLaunchKernelGGL(k2_t_eq_g_u<float>, dim3(tiles * B), dim3(LG4_THREADS), 0, h->stream, k2);
+      mark(h, EV_K2);
+      K3Args<float> k3{LD, B, h->T32, h->Uf, tb, h->lam, h->E, h->H, h->Gt32, h->sym_counts ? 1 : 0};
+      hipLaunchKernelGGL(k3_w_phi<float>, dim3(tiles_k3 * B), dim3(LG4_THREADS), 0, h->stream, k3);
+      mark(h, EV_K3);
+      hipLaunchKernelGGL(k3_reduce<float>, dim3((unsigned)((LL + 255) / 256)), dim3(256), 0, h->stream,
+                         h->Gt32, B, LL, h->Mt, h->sym_counts ? LD : 0);
+    } else {
+      K2Args<double> k2{LD, h->Gt, h->U, h->T};
+      hipLaunchKernelGGL(k2_t_eq_g_u<double>, dim3(tiles * B), dim3(LG4_THREADS), 0, h->stream, k2);
+      mark(h, EV_K2);
+      K3Args<double> k3{LD, B, h->T, h->U, tb, h->lam, h->E, h->H, h->Gt, h->sym_counts ? 1 : 0};
+      hipLaunchKernelGGL(k3_w_phi<double>, dim3(tiles_k3 * B), dim3(LG4_THREADS), 0, h->stream, k3);
+      mark(h, EV_K3);
+      hipLaunchKernelGGL(k3_reduce<double>, dim3((unsigned)((LL + 255) / 256)), dim3(256), 0, h->stream,
+                         h->Gt, B, LL, h->Mt, h->sym_counts ? LD : 0);
+    }
     K4Args k4a{S, LD, h->Mt, h->Vc, h->X, nullptr, nullptr, nullptr};
     launch_sg(h, k4a, 0);
     K4Args k4b{S, LD, h->Vc, h->X, dQd, dA_padded ? nullptr : h->dsq, nullptr, nullptr};
@@ -1664,7 +1699,7 @@ extern "C" int cb_ble_log_bank(int device, int S, int T, int R, const double *Q,
   for (int t = 0; t < T; ++t)
     for (int r = 0; r < R; ++r) tt[(size_t)t * R + r] = grid[t] * rates[r];   // as io_helpers.cpp:161
   cb_handle h = nullptr;
-  int rc = cb_create(device, S, 1, (int)nb, tt.data(), ones.data(), 0, &h);
+  int rc = cb_create(device, S, 1, (int)nb, CB_F64, tt.data(), ones.data(), 0, &h);
   if (rc != CB_OK) return rc;
   rc = cb_expm_bank(h, Q, pi, 0, logP);
   cb_destroy(h);
@@ -1930,7 +1965,7 @@ extern "C" int cb_tree_likelihood(int device, int S, int S1, const double *Q, co
   for (int c = 0; c < n_cats; ++c)
     for (int v = 0; v < n_nodes; ++v) t[(size_t)c * n_nodes + v] = v == root ? 0.0 : cat_rate[c] * length[v];
   cb_handle h = nullptr;
-  int rc = cb_create(device, S, L, B, t.data(), nullptr, CB_EXPM_ONLY, &h);
+  int rc = cb_create(device, S, L, B, CB_F64, t.data(), nullptr, CB_EXPM_ONLY, &h);
   if (rc != CB_OK) return rc;
   struct Guard {
     cb_handle h;

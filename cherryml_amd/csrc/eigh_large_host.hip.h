@@ -7,11 +7,6 @@
 
 // --------------------------------------------------------------- large path
 static void launch_sg(cb_bank *h, const K4Args &g, int ns, double alpha = 0.0, double beta = 0.0) {
-  if (getenv("CB_OLD_K4") && !ns) {
-    const int t = (h->LD + LG_TM - 1) / LG_TM;
-    hipLaunchKernelGGL(k4_gemm, dim3(t * t), dim3(LG_THREADS), 0, h->stream, g);
-    return;
-  }
   static const int variant = getenv("CB_SG_VARIANT") ? atoi(getenv("CB_SG_VARIANT")) : 1;
   // (both neighbours of this shape were measured slower: narrower strips -- NJ = 1 or 2, 2.5-5x the workgroups, more
   // L2 -> CU panel traffic -- eigh 0.60 -> 0.62-1.01 ms; two row tiles per workgroup -- half the workgroups -- 0.74-0.77 ms)

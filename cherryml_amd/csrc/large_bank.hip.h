@@ -15,193 +15,150 @@
 //   K4a X      = M U^T                                   Aop = Mt,    Bop = Ut
 //   K4b dA     = U X  -> dQ = D^1/2 dA D^-1/2            Aop = Ut,    Bop = X
 //
-// Tile: 80 x 80 per workgroup of 5 wavefronts (400 = 5 * 80); wave w owns the
-// 16-row strip w and five 16x16 f64 accumulators.  K is staged through LDS in
-// steps of 16 with register prefetch of the next step.
+// Tile: 80 x 80 per workgroup of 4 wavefronts (400 = 5 * 80), one wave per SIMD; K is staged through
+// LDS in steps of 16 with register prefetch of the next step.  K1..K3 are templates over the element
+// type: float64, or float32 operands with float32 MFMA accumulation (cb_create(dtype = CB_F32): twice
+// the MFMA rate, half the bytes; loss partials, the divided differences and the bucket sum stay float64).
 #pragma once
 #include "common.hip.h"
 
 #define LG_TM 80
 #define LG_TN 80
 #define LG_KT 16
-#define LG_THREADS 320
+#define LG4_THREADS 256
 
+// Element type of the bank products: double (v_mfma_f64_16x16x4_f64, 78.6 TFLOP/s) or float
+// (v_mfma_f32_16x16x4_f32, 157 TFLOP/s; cb_create(dtype = CB_F32)).  A / B operand lane maps are the
+// same for both (lane l: A[i = l & 15][k = l >> 4], B[k = l >> 4][j = l & 15]); the C / D maps differ:
+// register r of lane l is row (l >> 4) + 4 r in f64 and row 4 (l >> 4) + r in f32 (guide 3, "C/D layout").
+typedef float f4 __attribute__((ext_vector_type(4)));
+template <typename T> struct Mfma;
+template <> struct Mfma<double> {
+  typedef d4 acc_t;
+  typedef double2 vec_t;                      // one 16-byte chunk of a panel row
+  static constexpr int VEC = 2;
+  static __device__ __forceinline__ acc_t mma(double a, double b, acc_t c) { return mfma_f64(a, b, c); }
+  static __device__ __forceinline__ int row(int hi, int r) { return hi + 4 * r; }
+};
+template <> struct Mfma<float> {
+  typedef f4 acc_t;
+  typedef float4 vec_t;
+  static constexpr int VEC = 4;
+  static __device__ __forceinline__ acc_t mma(float a, float b, acc_t c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+  }
+  static __device__ __forceinline__ int row(int hi, int r) { return 4 * hi + r; }
+};
+__device__ __forceinline__ void vec_scale(double2 &v, double s) { v.x *= s; v.y *= s; }
+__device__ __forceinline__ void vec_scale(float4 &v, float s) { v.x *= s; v.y *= s; v.z *= s; v.w *= s; }
+
+template <typename T>
 struct GemmOperands {
-  const double *A;   // [K][lda] k-major
-  const double *B;   // [K][ldb]
+  const T *A;   // [K][lda] k-major
+  const T *B;   // [K][ldb]
   int lda, ldb;
   int M, N, K;       // all multiples of 16
-  const double *kscale;  // optional [K] multiplier applied to rows of Aop
+  const T *kscale;  // optional [K] multiplier applied to rows of Aop
 };
 
-// Loads one K-step (16 rows) of an 80-wide panel into registers:
-// 16 rows x 40 16-byte chunks = 640 chunks, 2 per thread.
-// SCALE is a template parameter and `sc` a reference to a register array: a `double *sc` that may be
-// null made the compiler keep the two scales in SCRATCH memory (a store and a load per K-step on the
-// critical path of K1's prefetch; 0.415 -> see DESIGN for the time after the change).
-template <bool SCALE>
-__device__ __forceinline__ void lg_load_panel(const double *__restrict__ P, int ld, int rows_total,
-                                              int cols_total, int k0, int c0, double2 (&reg)[2],
-                                              const double *__restrict__ kscale, double (&sc)[2]) {
-#pragma unroll
-  for (int u = 0; u < 2; ++u) {
-    const int chunk = threadIdx.x + u * LG_THREADS;  // 0..639
-    const int kr = chunk / 40, cc = (chunk - kr * 40) * 2;
-    const int k = k0 + kr, c = c0 + cc;
-    if (k < rows_total && c < cols_total)
-      reg[u] = *reinterpret_cast<const double2 *>(P + (size_t)k * ld + c);
-    else
-      reg[u] = double2{0.0, 0.0};
-    // the row scale travels with the panel (fetching it at LDS-store time exposed a
-    // global-load latency in every K-step)
-    if (SCALE) sc[u] = (k < rows_total) ? kscale[k] : 0.0;
-  }
-}
-
-template <bool SCALE>
-__device__ __forceinline__ void lg_store_panel(double *s, const double2 (&reg)[2], const double (&sc)[2]) {
-#pragma unroll
-  for (int u = 0; u < 2; ++u) {
-    const int chunk = threadIdx.x + u * LG_THREADS;
-    const int kr = chunk / 40, cc = (chunk - kr * 40) * 2;
-    double2 v = reg[u];
-    if (SCALE) {
-      v.x *= sc[u];
-      v.y *= sc[u];
-    }
-    *reinterpret_cast<double2 *>(s + kr * LG_TM + cc) = v;
-  }
-}
-
-// acc[j] (j = 0..4): tile rows m0 + 16*wave + (l>>4) + 4r, cols n0 + 16*j + (l&15)
-// sA / sB hold TWO K-steps each (double buffer): one barrier per K-step; the
-// global loads of step k+1 are in flight during the MFMAs of step k.
-template <bool SCALE = false>
-__device__ __forceinline__ void lg_gemm_tile(const GemmOperands &g, int m0, int n0, double *sA,
-                                             double *sB, d4 (&acc)[5]) {
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int lo = lane & 15, hi = lane >> 4;
-#pragma unroll
-  for (int j = 0; j < 5; ++j) acc[j] = d4{0.0, 0.0, 0.0, 0.0};
-  double2 ra[2], rb[2];
-  double sc[2] = {1.0, 1.0}, one[2] = {1.0, 1.0};
-  const int nk = g.K / LG_KT;
-  lg_load_panel<SCALE>(g.A, g.lda, g.K, g.M, 0, m0, ra, g.kscale, sc);
-  lg_load_panel<false>(g.B, g.ldb, g.K, g.N, 0, n0, rb, nullptr, one);
-  __syncthreads();  // the previous tile's readers of buffer 0 are done
-  lg_store_panel<SCALE>(sA, ra, sc);
-  lg_store_panel<false>(sB, rb, one);
-  __syncthreads();
-  for (int kt = 0; kt < nk; ++kt) {
-    const double *cA = sA + (kt & 1) * (LG_KT * LG_TM), *cB = sB + (kt & 1) * (LG_KT * LG_TN);
-    if (kt + 1 < nk) {
-      lg_load_panel<SCALE>(g.A, g.lda, g.K, g.M, (kt + 1) * LG_KT, m0, ra, g.kscale, sc);
-      lg_load_panel<false>(g.B, g.ldb, g.K, g.N, (kt + 1) * LG_KT, n0, rb, nullptr, one);
-    }
-#pragma unroll
-    for (int s = 0; s < LG_KT / 4; ++s) {
-      const double av = cA[(4 * s + hi) * LG_TM + 16 * wave + lo];
-#pragma unroll
-      for (int j = 0; j < 5; ++j) {
-        const double bv = cB[(4 * s + hi) * LG_TN + 16 * j + lo];
-        acc[j] = mfma_f64(av, bv, acc[j]);
-      }
-    }
-    if (kt + 1 < nk) {
-      // buffer (kt+1)&1 was last read in step kt-1; every wave passed the barrier since
-      lg_store_panel<SCALE>(sA + ((kt + 1) & 1) * (LG_KT * LG_TM), ra, sc);
-      lg_store_panel<false>(sB + ((kt + 1) & 1) * (LG_KT * LG_TN), rb, one);
-    }
-    __syncthreads();
-  }
-}
-
-// ---- the same tile with FOUR waves per workgroup, one per SIMD ------------------------------------
-// A 5-wave workgroup puts two of its waves on one SIMD (which one rotates from workgroup to workgroup,
-// profiles/tools/simd_probe), so with four workgroups on a CU the SIMDs carry 4..7 waves and the busiest
-// one sets the pace.  Here the 25 MFMA tiles of the 80 x 80 tile are dealt 7/6/6/6: wave w owns strip w
-// (acc[0..4]) and tile (4, w) of the fifth strip (ax0); wave 0 also tile (4, 4) (ax1).  Every workgroup
-// then loads the four SIMDs equally: K2 0.378 -> 0.330 ms at LD = 400.  (Tile (4, 4) itself is split
-// over K among the four waves, see the loop.)
-#define LG4_THREADS 256
+// ---- the 80 x 80 tile with FOUR waves per workgroup, one per SIMD ----------------------------------
+// (A 5-wave workgroup -- one wave per 16-row strip -- puts two of its waves on one SIMD, which one
+// rotates from workgroup to workgroup, profiles/tools/simd_probe; with four workgroups on a CU the
+// SIMDs then carry 4..7 waves and the busiest one sets the pace.)  The 25 MFMA tiles of the 80 x 80
+// tile are dealt 7/6/6/6: wave w owns strip w (acc[0..4]) and tile (4, w) of the fifth strip (ax0);
+// tile (4, 4) (ax1) is split over K among the four waves (6.25 tiles each), see the loop.
 // Panel loads: thread -> (row tid / 16 of the 16-row K-step, 16-byte chunks tid % 16, + 16, + 32 of that
-// row's 40), so the three loads of a thread share ONE row pointer and ONE row scale.  (A flat
+// row's 40 (f64) or 20 (f32)), so the loads of a thread share ONE row pointer and ONE row scale.  (A flat
 // chunk = tid + 256 u mapping needed three pointers and three scales per operand: 18 loop-invariant
 // registers, which the compiler spilled to scratch and re-loaded in every K-step: +170 MB of traffic
-// in K1.)
-template <bool SCALE>
-__device__ __forceinline__ void lg4_load_panel(const double *__restrict__ P, int ld, int rows_total, int cols_total,
-                                               int k0, int c0, double2 (&reg)[3],
-                                               const double *__restrict__ kscale, double &sc) {
+// in K1.)  SCALE is a template parameter and the scale a register: a nullable `const T *` made the
+// compiler keep it in SCRATCH memory (a store and a load per K-step on the critical path).
+template <typename T> struct Panel {
+  static constexpr int VEC = Mfma<T>::VEC;
+  static constexpr int CH = LG_TM / VEC;           // 16-byte chunks per panel row: 40 / 20
+  static constexpr int NL = (CH + 15) / 16;        // loads per thread: 3 / 2
+  static constexpr int LAST = CH - 16 * (NL - 1);  // threads (of 16 per row) that take part in the last one: 8 / 4
+};
+template <typename T, bool SCALE>
+__device__ __forceinline__ void lg4_load_panel(const T *__restrict__ P, int ld, int rows_total, int cols_total,
+                                               int k0, int c0, typename Mfma<T>::vec_t (&reg)[Panel<T>::NL],
+                                               const T *__restrict__ kscale, T &sc) {
+  typedef typename Mfma<T>::vec_t vec_t;
+  constexpr int VEC = Panel<T>::VEC, NL = Panel<T>::NL, LAST = Panel<T>::LAST;
   const int kr = threadIdx.x >> 4, cq = threadIdx.x & 15;
   const int k = k0 + kr;
-  const double *row = P + (size_t)k * ld + c0 + 2 * cq;
+  const T *row = P + (size_t)k * ld + c0 + VEC * cq;
 #pragma unroll
-  for (int u = 0; u < 3; ++u) {
-    const int c = c0 + 2 * (cq + 16 * u);
-    if ((u < 2 || cq < 8) && k < rows_total && c < cols_total)
-      reg[u] = *reinterpret_cast<const double2 *>(row + 32 * u);
+  for (int u = 0; u < NL; ++u) {
+    const int c = c0 + VEC * (cq + 16 * u);
+    if ((u < NL - 1 || cq < LAST) && k < rows_total && c < cols_total)
+      reg[u] = *reinterpret_cast<const vec_t *>(row + 16 * VEC * u);
     else
-      reg[u] = double2{0.0, 0.0};
+      reg[u] = vec_t{};
   }
-  if (SCALE) sc = k < rows_total ? kscale[k] : 0.0;
+  if (SCALE) sc = k < rows_total ? kscale[k] : T(0);
 }
-template <bool SCALE>
-__device__ __forceinline__ void lg4_store_panel(double *s, const double2 (&reg)[3], double sc) {
+template <typename T, bool SCALE>
+__device__ __forceinline__ void lg4_store_panel(T *s, const typename Mfma<T>::vec_t (&reg)[Panel<T>::NL], T sc) {
+  typedef typename Mfma<T>::vec_t vec_t;
+  constexpr int VEC = Panel<T>::VEC, NL = Panel<T>::NL, LAST = Panel<T>::LAST;
   const int kr = threadIdx.x >> 4, cq = threadIdx.x & 15;
-  double *row = s + kr * LG_TM + 2 * cq;
+  T *row = s + kr * LG_TM + VEC * cq;
 #pragma unroll
-  for (int u = 0; u < 3; ++u) {
-    double2 v = reg[u];
-    if (SCALE) {
-      v.x *= sc;
-      v.y *= sc;
-    }
-    if (u < 2 || cq < 8) *reinterpret_cast<double2 *>(row + 32 * u) = v;
+  for (int u = 0; u < NL; ++u) {
+    vec_t v = reg[u];
+    if (SCALE) vec_scale(v, sc);
+    if (u < NL - 1 || cq < LAST) *reinterpret_cast<vec_t *>(row + 16 * VEC * u) = v;
   }
 }
-template <bool SCALE = false>
-__device__ __forceinline__ void lg4_gemm_tile(const GemmOperands &g, int m0, int n0, double *sA, double *sB,
-                                              d4 (&acc)[5], d4 &ax0, d4 &ax1) {
+// sA / sB hold TWO K-steps each (double buffer): one barrier per K-step; the global loads of step
+// k+1 are in flight during the MFMAs of step k.  LDS row stride 80 elements is conflict-free for the
+// operand reads in both widths (f64: 2 * 80 mod 64 = 32; f32: 80 mod 64 = 16, four k rows per read).
+template <typename T, bool SCALE>
+__device__ __forceinline__ void lg4_gemm_tile(const GemmOperands<T> &g, int m0, int n0, T *sA, T *sB,
+                                              typename Mfma<T>::acc_t (&acc)[5], typename Mfma<T>::acc_t &ax0,
+                                              typename Mfma<T>::acc_t &ax1) {
+  typedef typename Mfma<T>::acc_t acc_t;
+  typedef typename Mfma<T>::vec_t vec_t;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, lo = lane & 15, hi = lane >> 4;
 #pragma unroll
-  for (int j = 0; j < 5; ++j) acc[j] = d4{0.0, 0.0, 0.0, 0.0};
-  ax0 = d4{0.0, 0.0, 0.0, 0.0};
-  ax1 = ax0;
-  double2 ra[3], rb[3];
-  double sc = 1.0, one = 1.0;
+  for (int j = 0; j < 5; ++j) acc[j] = acc_t{};
+  ax0 = acc_t{};
+  ax1 = acc_t{};
+  vec_t ra[Panel<T>::NL], rb[Panel<T>::NL];
+  T sc = T(1), one = T(1);
   const int nk = g.K / LG_KT;
-  lg4_load_panel<SCALE>(g.A, g.lda, g.K, g.M, 0, m0, ra, g.kscale, sc);
-  lg4_load_panel<false>(g.B, g.ldb, g.K, g.N, 0, n0, rb, nullptr, one);
+  lg4_load_panel<T, SCALE>(g.A, g.lda, g.K, g.M, 0, m0, ra, g.kscale, sc);
+  lg4_load_panel<T, false>(g.B, g.ldb, g.K, g.N, 0, n0, rb, nullptr, one);
   __syncthreads();  // the previous tile's readers of buffer 0 are done
-  lg4_store_panel<SCALE>(sA, ra, sc);
-  lg4_store_panel<false>(sB, rb, one);
+  lg4_store_panel<T, SCALE>(sA, ra, sc);
+  lg4_store_panel<T, false>(sB, rb, one);
   __syncthreads();
   for (int kt = 0; kt < nk; ++kt) {
-    const double *cA = sA + (kt & 1) * (LG_KT * LG_TM), *cB = sB + (kt & 1) * (LG_KT * LG_TN);
+    const T *cA = sA + (kt & 1) * (LG_KT * LG_TM), *cB = sB + (kt & 1) * (LG_KT * LG_TN);
     if (kt + 1 < nk) {
-      lg4_load_panel<SCALE>(g.A, g.lda, g.K, g.M, (kt + 1) * LG_KT, m0, ra, g.kscale, sc);
-      lg4_load_panel<false>(g.B, g.ldb, g.K, g.N, (kt + 1) * LG_KT, n0, rb, nullptr, one);
+      lg4_load_panel<T, SCALE>(g.A, g.lda, g.K, g.M, (kt + 1) * LG_KT, m0, ra, g.kscale, sc);
+      lg4_load_panel<T, false>(g.B, g.ldb, g.K, g.N, (kt + 1) * LG_KT, n0, rb, nullptr, one);
     }
 #pragma unroll
     for (int s = 0; s < LG_KT / 4; ++s) {
-      const double av = cA[(4 * s + hi) * LG_TM + 16 * wave + lo];
-      const double a4 = cA[(4 * s + hi) * LG_TM + 64 + lo];
-      double bv[5];
+      const T av = cA[(4 * s + hi) * LG_TM + 16 * wave + lo];
+      const T a4 = cA[(4 * s + hi) * LG_TM + 64 + lo];
+      T bv[5];
 #pragma unroll
       for (int j = 0; j < 5; ++j) bv[j] = cB[(4 * s + hi) * LG_TN + 16 * j + lo];
 #pragma unroll
-      for (int j = 0; j < 5; ++j) acc[j] = mfma_f64(av, bv[j], acc[j]);
+      for (int j = 0; j < 5; ++j) acc[j] = Mfma<T>::mma(av, bv[j], acc[j]);
       // tile (4, wave): column block `wave` (a wave-uniform choice among registers)
-      const double bx = wave == 0 ? bv[0] : wave == 1 ? bv[1] : wave == 2 ? bv[2] : bv[3];
-      ax0 = mfma_f64(a4, bx, ax0);
+      const T bx = wave == 0 ? bv[0] : wave == 1 ? bv[1] : wave == 2 ? bv[2] : bv[3];
+      ax0 = Mfma<T>::mma(a4, bx, ax0);
       // tile (4, 4): its K range is dealt round-robin to the four waves (6.25 MFMA tiles each
       // instead of 7/6/6/6); the partial sums meet in wave 0 below
-      if ((kt & 3) == wave) ax1 = mfma_f64(a4, bv[4], ax1);
+      if ((kt & 3) == wave) ax1 = Mfma<T>::mma(a4, bv[4], ax1);
     }
     if (kt + 1 < nk) {
-      lg4_store_panel<SCALE>(sA + ((kt + 1) & 1) * (LG_KT * LG_TM), ra, sc);
-      lg4_store_panel<false>(sB + ((kt + 1) & 1) * (LG_KT * LG_TN), rb, one);
+      lg4_store_panel<T, SCALE>(sA + ((kt + 1) & 1) * (LG_KT * LG_TM), ra, sc);
+      lg4_store_panel<T, false>(sB + ((kt + 1) & 1) * (LG_KT * LG_TN), rb, one);
     }
     __syncthreads();
   }
@@ -217,27 +174,22 @@ __device__ __forceinline__ void lg4_gemm_tile(const GemmOperands &g, int m0, int
   __syncthreads();   // sA is free again (callers reuse it)
 }
 
-// f(row, col, value) for every element of the tile this lane owns (either wave layout)
-template <int NW, typename F>
-__device__ __forceinline__ void lg_for_each(int m0, int n0, const d4 (&acc)[5], const d4 &ax0, const d4 &ax1, F &&f) {
+// f(row, col, value) for every element of the tile this lane owns
+template <typename T, typename F>
+__device__ __forceinline__ void lg_for_each(int m0, int n0, const typename Mfma<T>::acc_t (&acc)[5],
+                                            const typename Mfma<T>::acc_t &ax0, const typename Mfma<T>::acc_t &ax1,
+                                            F &&f) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, lo = lane & 15, hi = lane >> 4;
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
-    const int row = m0 + 16 * wave + hi + 4 * r;
+    const int rr = Mfma<T>::row(hi, r);
+    const int row = m0 + 16 * wave + rr;
 #pragma unroll
     for (int j = 0; j < 5; ++j) f(row, n0 + 16 * j + lo, acc[j][r]);
-    if (NW == 4) {
-      const int row4 = m0 + 64 + hi + 4 * r;
-      f(row4, n0 + 16 * wave + lo, ax0[r]);
-      if (wave == 0) f(row4, n0 + 64 + lo, ax1[r]);
-    }
+    const int row4 = m0 + 64 + rr;
+    f(row4, n0 + 16 * wave + lo, ax0[r]);
+    if (wave == 0) f(row4, n0 + 64 + lo, ax1[r]);
   }
-}
-template <int NW, bool SCALE>
-__device__ __forceinline__ void lg_tile(const GemmOperands &g, int m0, int n0, double *sA, double *sB, d4 (&acc)[5],
-                                        d4 &ax0, d4 &ax1) {
-  if (NW == 4) lg4_gemm_tile<SCALE>(g, m0, n0, sA, sB, acc, ax0, ax1);
-  else lg_gemm_tile<SCALE>(g, m0, n0, sA, sB, acc);
 }
 
 // XCD-aware block id: hardware deals consecutive workgroup ids round-robin over the 8
@@ -251,29 +203,38 @@ __device__ __forceinline__ int xcd_swizzle(int id, int n) {
   return base + k;
 }
 
+// elementwise pieces of the K1 epilogue in the bank's element type (the loss itself is always
+// accumulated in float64)
+__device__ __forceinline__ double k1_log(double x) { return fast_log(x); }
+__device__ __forceinline__ double k1_rcp(double x) { return fast_rcp(x); }
+__device__ __forceinline__ float k1_log(float x) { return logf(x); }
+__device__ __forceinline__ float k1_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+
 // ------------------------------------------------------------------ K1
+template <typename T>
 struct K1Args {
   int S, LD, B;
-  const double *Ut;      // [LD][LD]  Ut[k][i] = U[i][k]
-  const double *A;       // [LD][LD]  symmetric
+  const T *Ut;           // [LD][LD]  Ut[k][i] = U[i][k]
+  const T *A;            // [LD][LD]  symmetric
   const double *t;       // [B]
-  const double *F;       // [B][LD]   phi2(t_b lam_k) (split) or exp(t_b lam_k)
+  const T *F;            // [B][LD]   phi2(t_b lam_k) (split) or exp(t_b lam_k)
   const double *sigma;   // max |A_ii|: bucket uses the split form iff 2 sigma t_b <= 1
-  const double *Ct;      // [B][LD][LD] transposed counts (padded)
-  double *Gt;            // [B][LD][LD] out: Gt^T
+  const T *Ct;           // [B][LD][LD] transposed counts (padded)
+  T *Gt;                 // [B][LD][LD] out: Gt^T
   double *loss_part;     // [B * tiles] out
   double inv_n;
   const double *dsq;     // [LD] sqrt(pi) (expm mode)
-  double *P;             // [B][S][S] (expm mode) or null
+  double *P;             // [B][S][S] (expm mode, T = double only) or null
 };
 
 // Pt_b is symmetric: only the tilesN (tilesN + 1) / 2 tiles with tm <= tn run the main loop; an
 // off-diagonal tile serves both (row, col) and (col, row) in its epilogue (same Pt value, its own
 // count and its own Gt^T entry).  40 % fewer MFMAs than the full grid at LD = 400.
-template <int NW>   // 5: one wave per 16-row strip; 4: one wave per SIMD (lg4_gemm_tile)
-__global__ __launch_bounds__(NW * 64, NW == 4 ? 4 : 5) void k1_pt_loss_gt(K1Args a) {  // four workgroups per CU (96 / 128 VGPRs)
-  __shared__ double sA[2 * LG_KT * LG_TM];
-  __shared__ double sB[2 * LG_KT * LG_TN];
+template <typename T>
+__global__ __launch_bounds__(LG4_THREADS, 4) void k1_pt_loss_gt(K1Args<T> a) {  // four workgroups per CU
+  __shared__ T sA[2 * LG_KT * LG_TM];
+  __shared__ T sB[2 * LG_KT * LG_TN];
+  typedef typename Mfma<T>::acc_t acc_t;
   const int tilesN = (a.LD + LG_TN - 1) / LG_TN, tiles = tilesN * (tilesN + 1) / 2;
   const int vid = xcd_swizzle(blockIdx.x, gridDim.x);
   const int b = vid / tiles;
@@ -286,30 +247,31 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 4 : 5) void k1_pt_loss_gt(K1Args
   const int m0 = tm * LG_TM, n0 = tn * LG_TN;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const size_t boff = (size_t)b * a.LD * a.LD;
-  GemmOperands g{a.Ut, a.Ut, a.LD, a.LD, a.LD, a.LD, a.LD, a.F + (size_t)b * a.LD};
-  d4 acc[5], ax0, ax1;
-  lg_tile<NW, true>(g, m0, n0, sA, sB, acc, ax0, ax1);
+  GemmOperands<T> g{a.Ut, a.Ut, a.LD, a.LD, a.LD, a.LD, a.LD, a.F + (size_t)b * a.LD};
+  acc_t acc[5], ax0, ax1;
+  lg4_gemm_tile<T, true>(g, m0, n0, sA, sB, acc, ax0, ax1);
 
   const double tb = a.t[b];
+  const T tbT = (T)tb, inv_nT = (T)a.inv_n;
   const bool split = tb * 2.0 * (*a.sigma) <= 1.0;  // see small_bank.hip.h
   const bool mirror = tm != tn;
   double lossacc = 0.0;
-  auto emit = [&](int row, int col, double pt) {
+  auto emit = [&](int row, int col, T pt) {
     const size_t idx = (size_t)row * a.LD + col;
     if (a.P) {
       if (row < a.S && col < a.S)
-        a.P[(size_t)b * a.S * a.S + (size_t)row * a.S + col] = pt * a.dsq[col] / a.dsq[row];
+        a.P[(size_t)b * a.S * a.S + (size_t)row * a.S + col] = (double)pt * a.dsq[col] / a.dsq[row];
     } else {
-      const double c = a.Ct[boff + idx];
-      const bool nz = c != 0.0;
-      lossacc = fma(-c, fast_log(nz ? pt : 1.0), lossacc);
-      a.Gt[boff + idx] = nz ? -c * a.inv_n * fast_rcp(pt) : 0.0;
+      const T c = a.Ct[boff + idx];
+      const bool nz = c != T(0);
+      lossacc = fma(-(double)c, (double)k1_log(nz ? pt : T(1)), lossacc);
+      a.Gt[boff + idx] = nz ? -c * inv_nT * k1_rcp(pt) : T(0);
     }
   };
-  lg_for_each<NW>(m0, n0, acc, ax0, ax1, [&](int row, int col, double pt) {
+  lg_for_each<T>(m0, n0, acc, ax0, ax1, [&](int row, int col, T pt) {
     if (row < a.LD && col < a.LD) {
-      if (split) pt += tb * a.A[(size_t)row * a.LD + col] + (row == col ? 1.0 : 0.0);
-      else if (row >= a.S || col >= a.S) pt = 1.0;  // pad (never used: C = 0 there)
+      if (split) pt += tbT * a.A[(size_t)row * a.LD + col] + (row == col ? T(1) : T(0));
+      else if (row >= a.S || col >= a.S) pt = T(1);  // pad (never used: C = 0 there)
       emit(row, col, pt);
       if (mirror) emit(col, row, pt);
     }
@@ -317,34 +279,37 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 4 : 5) void k1_pt_loss_gt(K1Args
   if (a.P) return;
   lossacc = wave_sum(lossacc);
   // sA is free after the K loop (the tile routine ends with a barrier)
-  if (lane == 0) sA[wave] = lossacc;
+  double *sRed = reinterpret_cast<double *>(sA);
+  if (lane == 0) sRed[wave] = lossacc;
   __syncthreads();
-  if (threadIdx.x == 0) a.loss_part[vid] = sA[0] + sA[1] + sA[2] + sA[3] + (NW == 5 ? sA[4] : 0.0);
+  if (threadIdx.x == 0) a.loss_part[vid] = (sRed[0] + sRed[1]) + (sRed[2] + sRed[3]);
 }
 
 // ------------------------------------------------------------------ K2
+template <typename T>
 struct K2Args {
   int LD;
-  const double *Gt;  // [B][LD][LD]
-  const double *U;   // [LD][LD]
-  double *T;         // [B][LD][LD]
+  const T *Gt;  // [B][LD][LD]
+  const T *U;   // [LD][LD]
+  T *Tm;        // [B][LD][LD]
 };
 
-template <int NW>
-__global__ __launch_bounds__(NW * 64, NW == 4 ? 4 : 5) void k2_t_eq_g_u(K2Args a) {
-  __shared__ double sA[2 * LG_KT * LG_TM];
-  __shared__ double sB[2 * LG_KT * LG_TN];
+template <typename T>
+__global__ __launch_bounds__(LG4_THREADS, 4) void k2_t_eq_g_u(K2Args<T> a) {
+  __shared__ T sA[2 * LG_KT * LG_TM];
+  __shared__ T sB[2 * LG_KT * LG_TN];
+  typedef typename Mfma<T>::acc_t acc_t;
   const int tilesN = (a.LD + LG_TN - 1) / LG_TN, tiles = tilesN * tilesN;
   const int vid = xcd_swizzle(blockIdx.x, gridDim.x);
   const int b = vid / tiles, tile = vid - b * tiles;
   const int tm = tile / tilesN, tn = tile - tm * tilesN;
   const int m0 = tm * LG_TM, n0 = tn * LG_TN;
   const size_t boff = (size_t)b * a.LD * a.LD;
-  GemmOperands g{a.Gt + boff, a.U, a.LD, a.LD, a.LD, a.LD, a.LD, nullptr};
-  d4 acc[5], ax0, ax1;
-  lg_tile<NW, false>(g, m0, n0, sA, sB, acc, ax0, ax1);
-  lg_for_each<NW>(m0, n0, acc, ax0, ax1, [&](int row, int col, double v) {
-    if (row < a.LD && col < a.LD) a.T[boff + (size_t)row * a.LD + col] = v;
+  GemmOperands<T> g{a.Gt + boff, a.U, a.LD, a.LD, a.LD, a.LD, a.LD, nullptr};
+  acc_t acc[5], ax0, ax1;
+  lg4_gemm_tile<T, false>(g, m0, n0, sA, sB, acc, ax0, ax1);
+  lg_for_each<T>(m0, n0, acc, ax0, ax1, [&](int row, int col, T v) {
+    if (row < a.LD && col < a.LD) a.Tm[boff + (size_t)row * a.LD + col] = v;
   });
 }
 
@@ -353,22 +318,24 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 4 : 5) void k2_t_eq_g_u(K2Args a
 // written over Gt_b (dead once K2 has produced T_b); k3_reduce then sums the buckets
 // in a fixed order.  (A version that kept the running sum over a chunk of buckets in
 // registers needed 2 accumulator sets: 256 VGPRs, one workgroup per CU.)
+template <typename T>
 struct K3Args {
   int LD, B;
-  const double *T;       // [B][LD][LD]
-  const double *U;       // [LD][LD]
+  const T *Tm;           // [B][LD][LD]
+  const T *U;            // [LD][LD]
   const double *t;       // [B]
   const double *lam;     // [LD]
   const double *E;       // [B][LD] exp(t lam)
   const double *H;       // [B][LD] exp(t lam / 2)
-  double *W;             // [B][LD][LD] out (aliases the Gt buffer)
+  T *W;                  // [B][LD][LD] out (aliases the Gt buffer)
   int sym;               // counts symmetric => Gt_b, hence W_b, symmetric: upper-triangular tiles only
 };
 
-template <int NW>
-__global__ __launch_bounds__(NW * 64, NW == 4 ? 4 : 5) void k3_w_phi(K3Args a) {
-  __shared__ double sA[2 * LG_KT * LG_TM];
-  __shared__ double sB[2 * LG_KT * LG_TN];
+template <typename T>
+__global__ __launch_bounds__(LG4_THREADS, 4) void k3_w_phi(K3Args<T> a) {
+  __shared__ T sA[2 * LG_KT * LG_TM];
+  __shared__ T sB[2 * LG_KT * LG_TN];
+  typedef typename Mfma<T>::acc_t acc_t;
   const int tilesN = (a.LD + LG_TN - 1) / LG_TN;
   const int tiles = a.sym ? tilesN * (tilesN + 1) / 2 : tilesN * tilesN;
   const int vid = xcd_swizzle(blockIdx.x, gridDim.x);
@@ -387,23 +354,25 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 4 : 5) void k3_w_phi(K3Args a) {
   }
   const int m0 = tm * LG_TM, n0 = tn * LG_TN;
   const size_t boff = (size_t)b * a.LD * a.LD;
-  GemmOperands g{a.T + boff, a.U, a.LD, a.LD, a.LD, a.LD, a.LD, nullptr};
-  d4 acc[5], ax0, ax1;
-  lg_tile<NW, false>(g, m0, n0, sA, sB, acc, ax0, ax1);
+  GemmOperands<T> g{a.Tm + boff, a.U, a.LD, a.LD, a.LD, a.LD, a.LD, nullptr};
+  acc_t acc[5], ax0, ax1;
+  lg4_gemm_tile<T, false>(g, m0, n0, sA, sB, acc, ax0, ax1);
   const double tb = a.t[b];
   const double *Eb = a.E + (size_t)b * a.LD, *Hb = a.H + (size_t)b * a.LD;
-  lg_for_each<NW>(m0, n0, acc, ax0, ax1, [&](int row, int col, double v) {
+  lg_for_each<T>(m0, n0, acc, ax0, ax1, [&](int row, int col, T v) {
     if (row < a.LD && col < a.LD) {
+      // (the divided difference is evaluated in float64 in both widths: its cancellation-free form needs it)
       const double ph = divdiff_fast(tb, a.lam[row], a.lam[col], Eb[row], Eb[col], Hb[row], Hb[col]);
-      a.W[boff + (size_t)row * a.LD + col] = v * ph;   // (symmetric case: k3_reduce mirrors the sum, not every bucket)
+      a.W[boff + (size_t)row * a.LD + col] = (T)((double)v * ph);   // (symmetric case: k3_reduce mirrors the sum, not every bucket)
     }
   });
 }
 
-// Mt = sum over chunks (fixed order => bitwise reproducible).  sym (LD > 0): only the 80x80 tiles on
-// or above the diagonal were written by k3_w_phi; sum those and mirror the SUM into the lower tiles
-// (40 % less to read, and no mirrored stores per bucket).
-__global__ void k3_reduce(const double *part, int nchunks, size_t n, double *out, int LD = 0) {
+// Mt = sum over chunks (fixed order => bitwise reproducible), always accumulated in float64.  sym
+// (LD > 0): only the 80x80 tiles on or above the diagonal were written by k3_w_phi; sum those and
+// mirror the SUM into the lower tiles (40 % less to read, and no mirrored stores per bucket).
+template <typename T>
+__global__ void k3_reduce(const T *part, int nchunks, size_t n, double *out, int LD = 0) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   int row = 0, col = 0;
@@ -415,10 +384,10 @@ __global__ void k3_reduce(const double *part, int nchunks, size_t n, double *out
   double s0 = 0.0, s1 = 0.0;   // two interleaved partial sums: twice the loads in flight
   int c = 0;
   for (; c + 1 < nchunks; c += 2) {
-    s0 += part[(size_t)c * n + i];
-    s1 += part[(size_t)(c + 1) * n + i];
+    s0 += (double)part[(size_t)c * n + i];
+    s1 += (double)part[(size_t)(c + 1) * n + i];
   }
-  if (c < nchunks) s0 += part[(size_t)c * n + i];
+  if (c < nchunks) s0 += (double)part[(size_t)c * n + i];
   const double s = s0 + s1;
   out[i] = s;
   if (LD > 0 && row / LG_TM < col / LG_TN) out[(size_t)col * LD + row] = s;
@@ -440,32 +409,6 @@ struct K4Args {
   const unsigned long long *sel = nullptr;
   const double *Aalt = nullptr, *Balt = nullptr;
 };
-
-__global__ __launch_bounds__(LG_THREADS) void k4_gemm(K4Args a) {
-  __shared__ double sA[2 * LG_KT * LG_TM];
-  __shared__ double sB[2 * LG_KT * LG_TN];
-  const int tilesN = (a.LD + LG_TN - 1) / LG_TN;
-  const int tm = blockIdx.x / tilesN, tn = blockIdx.x - tm * tilesN;
-  const int m0 = tm * LG_TM, n0 = tn * LG_TN;
-  GemmOperands g{a.Aop, a.Bop, a.LD, a.LD, a.LD, a.LD, a.LD, nullptr};
-  d4 acc[5];
-  lg_gemm_tile(g, m0, n0, sA, sB, acc);
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int lo = lane & 15, hi = lane >> 4;
-#pragma unroll
-  for (int j = 0; j < 5; ++j)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int row = m0 + 16 * wave + hi + 4 * r, col = n0 + 16 * j + lo;
-      if (a.dsq) {
-        if (row < a.S && col < a.S)
-          a.out[(size_t)row * a.S + col] = a.dsq[row] * acc[j][r] / a.dsq[col];
-      } else if (row < a.LD && col < a.LD) {
-        const size_t idx = (size_t)row * a.LD + col;
-        a.out[idx] = a.sub ? acc[j][r] - (*a.sub_scale) * a.sub[idx] : acc[j][r];
-      }
-    }
-}
 
 // Single-matrix products (K4a, K4b, the warm-start G0 = A' U_prev, the first-order eigen
 // correction): one LD^3 GEMM is only (LD/80)^2 = 25 of the 80x80 tiles, i.e. 25 of 256 CUs and
@@ -607,15 +550,18 @@ __global__ void lg_finish_loss(const double *part, int nparts, int S, const doub
 }
 
 // flag[0] |= 1 when some live bucket has C_b != C_b^T
-__global__ void lg_sym_check(int LD, const double *Ct, int *flag) {
+template <typename T>
+__global__ void lg_sym_check(int LD, const T *Ct, int *flag) {
   const size_t boff = (size_t)blockIdx.z * LD * LD;
   const int i = blockIdx.y * blockDim.y + threadIdx.y, j = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < LD && j < i && Ct[boff + (size_t)i * LD + j] != Ct[boff + (size_t)j * LD + i]) atomicOr(flag, 1);
 }
 
-// pad + transpose counts at create time: Ct[b][j][i] = C[b][i][j]
+// pad + transpose counts at create time: Ct[b][j][i] = C[b][i][j]  (rounded to the bank's element type:
+// counts are multiples of 1/4 and stay exact in float32 up to 2^22)
 // destination bucket z holds source bucket src[z] (live buckets only, see cb_create)
-__global__ void lg_transpose_pad(int S, int LD, const double *C, double *Ct, const int *src) {
+template <typename T>
+__global__ void lg_transpose_pad(int S, int LD, const double *C, T *Ct, const int *src) {
   __shared__ double tile[32][33];
   const int b = src[blockIdx.z];
   const int i0 = blockIdx.y * 32, j0 = blockIdx.x * 32;
@@ -626,6 +572,18 @@ __global__ void lg_transpose_pad(int S, int LD, const double *C, double *Ct, con
   __syncthreads();
   for (int r = threadIdx.y; r < 32; r += blockDim.y) {
     const int j = j0 + r, i = i0 + threadIdx.x;
-    if (j < LD && i < LD) Ct[(size_t)blockIdx.z * LD * LD + (size_t)j * LD + i] = tile[threadIdx.x][r];
+    if (j < LD && i < LD) Ct[(size_t)blockIdx.z * LD * LD + (size_t)j * LD + i] = (T)tile[threadIdx.x][r];
   }
+}
+
+// float32 copies of the per-epoch operands of the CB_F32 bank kernels: U, U^T, A [LD][LD] and F [B][LD]
+__global__ void lg_cast_f32(size_t LL, size_t BL, const double *U, const double *Ut, const double *A, const double *F,
+                            float *Uf, float *Utf, float *Af, float *Ff) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < LL) {
+    Uf[i] = (float)U[i];
+    Utf[i] = (float)Ut[i];
+    Af[i] = (float)A[i];
+  }
+  if (i < BL) Ff[i] = (float)F[i];
 }

@@ -127,7 +127,7 @@ class ShardedBank:
     this rank's GPU; the CPU tests inject an oracle-backed stand-in with the
     same `loss_grad_torch` method)."""
 
-    def __init__(self, t, C, make_bank: Optional[Callable] = None, group=None):
+    def __init__(self, t, C, make_bank: Optional[Callable] = None, group=None, dtype: str = "f64"):
         t = np.asarray(t, dtype=np.float64).reshape(-1)
         C = np.asarray(C, dtype=np.float64)
         if C.ndim != 3:
@@ -147,18 +147,18 @@ class ShardedBank:
         mine = live[bucket_shard(live.size, self.rank, self.world)]
         self.total_count = float(C.sum())  # every rank sees the full host array here
         self.local_buckets = mine
-        self.bank = self._make(make_bank)(t[mine], C[mine])
+        self.bank = self._make(make_bank, dtype)(t[mine], C[mine])
 
     @staticmethod
-    def _make(make_bank):
+    def _make(make_bank, dtype="f64"):
         if make_bank is not None:
             return make_bank
         from .bank import CherryBank
         dev = torch.cuda.current_device()
-        return lambda tt, CC: CherryBank(tt, CC, device=dev)
+        return lambda tt, CC: CherryBank(tt, CC, device=dev, dtype=dtype)
 
     @classmethod
-    def from_rank_counts(cls, t, C_rank, make_bank: Optional[Callable] = None, group=None):
+    def from_rank_counts(cls, t, C_rank, make_bank: Optional[Callable] = None, group=None, dtype: str = "f64"):
         """`C_rank` [B,S,S] (numpy, or a torch tensor already on this rank's GPU): the counts of
         the families THIS rank counted.  The k-th globally non-empty bucket belongs to rank
         k mod world; those are laid out owner-major (zero padded to equal chunks) and reduce-scattered, so rank r receives
@@ -205,7 +205,7 @@ class ShardedBank:
             C_mine = Ct[torch.as_tensor(mine, device=Ct.device)]
         self.total_count = float(stats[B])
         self.local_buckets = mine
-        self.bank = cls._make(make_bank)(t[mine], C_mine if C_mine.is_cuda else C_mine.numpy())
+        self.bank = cls._make(make_bank, dtype)(t[mine], C_mine if C_mine.is_cuda else C_mine.numpy())
         return self
 
     def loss(self, Q: torch.Tensor, pi: torch.Tensor, normalize: bool = True) -> torch.Tensor:

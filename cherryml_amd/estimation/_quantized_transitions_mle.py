@@ -36,7 +36,11 @@ def quantized_transitions_mle(
     OMP_NUM_THREADS: Optional[int] = 1,
     OPENBLAS_NUM_THREADS: Optional[int] = 1,
     return_best_iter: bool = True,
+    bank_dtype: str = "f64",
 ):
+    """`bank_dtype` is the one argument the reference does not have: "f64" (default; parity with the
+    reference run in float64 to 1e-6) or "f32" -- the reference's own arithmetic (float32 matrix_exp,
+    ratelearner.py:98,107) on the float32 MFMA, for more than 32 states."""
     start_time = time.time()
     logger = logging.getLogger(__name__)
     logger.info("Starting")
@@ -55,7 +59,7 @@ def quantized_transitions_mle(
             branches=[float(x) for x in q], mats=[C[b] for b in range(C.shape[0])], states=states,
             output_dir=output_rate_matrix_dir, stationnary_distribution=stationary,
             mask=mask2_path, rate_matrix_parameterization=rate_matrix_parameterization,
-            device=device, initialization=init)
+            device=device, initialization=init, bank_dtype=bank_dtype)
         learner.train(lr=learning_rate, num_epochs=num_epochs, do_adam=do_adam,
                       loss_normalization=loss_normalization, return_best_iter=return_best_iter)
     logger.info("Done!")

@@ -94,12 +94,14 @@ def train_quantization(rate_module, quantized_dataset, m=1.0, lr=1e-1, num_epoch
                        Q_true=None, optimizer=None, loss_normalization: bool = True,
                        return_best_iter: bool = True,
                        bank: Optional[CherryBank] = None,
-                       fused: Optional[bool] = None) -> Tuple[pd.DataFrame, Dict]:
+                       fused: Optional[bool] = None, bank_dtype: str = "f64") -> Tuple[pd.DataFrame, Dict]:
     """Full-batch optimisation of `rate_module` on a TensorDataset(qtimes, cmats).
 
     Returns (df_res, Q_dict) exactly like the reference: per-epoch rows
     (nuc_norm, frob_norm, loss, time, epoch, frob_norm_diag, frob_norm_offdiag)
     and Q at epochs 1,2,4,..., "Q_best", "Q_last", "result".
+    `bank_dtype` ("f64" / "f32", num_states > 32 only): element type of the bank products when the
+    bank is built here (CherryBank's `dtype`; the reference computes them in float32).
     """
     logger = logging.getLogger(__name__)
     params = [p for p in rate_module.parameters()]
@@ -119,7 +121,7 @@ def train_quantization(rate_module, quantized_dataset, m=1.0, lr=1e-1, num_epoch
         qtimes, cmats = quantized_dataset.tensors
         bank = CherryBank(qtimes.detach().cpu().numpy().astype(np.float64),
                           cmats.detach().cpu().numpy().astype(np.float64),
-                          device=device.index or 0)
+                          device=device.index or 0, dtype=bank_dtype)
     logger.info(f"Training for {num_epochs} epochs")
     Q_dict: Dict[str, np.ndarray] = {}
     rows = []

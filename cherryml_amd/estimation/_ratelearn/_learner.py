@@ -20,7 +20,7 @@ class RateMatrixLearner:
                  output_dir: str, stationnary_distribution: str, device: str, mask: str = None,
                  rate_matrix_parameterization="pande_reversible",
                  initialization: Optional[np.ndarray] = None,
-                 skip_writing_to_output_dir: bool = False):
+                 skip_writing_to_output_dir: bool = False, bank_dtype: str = "f64"):
         self.branches = branches
         self.mats = mats
         self.states = states
@@ -31,6 +31,7 @@ class RateMatrixLearner:
         self.device = device
         self.initialization = initialization
         self.skip_writing_to_output_dir = skip_writing_to_output_dir
+        self.bank_dtype = bank_dtype   # extra to the reference: "f32" = its own float32 arithmetic on the f32 MFMA (S > 32)
         self.lr = None
         self.do_adam = None
         self.df_res = None
@@ -41,10 +42,8 @@ class RateMatrixLearner:
               loss_normalization: bool = False, return_best_iter: bool = True):
         logger = logging.getLogger(__name__)
         logger.info(f"Starting, outdir: {self.output_dir}")
-        if self.device != "cuda":
-            raise NotImplementedError(
-                "cherryml_amd evaluates the likelihood bank on the MI355X only; call with "
-                "device='cuda' (on ROCm torch the HIP device is named 'cuda'). No CPU fallback.")
+        from ..._device import resolve_device
+        resolve_device(self.device, "RateMatrixLearner")   # "cpu" and "cuda" both mean the MI355X (see _device.py)
         torch.manual_seed(0)  # ratelearner.py:77
         if not self.skip_writing_to_output_dir:
             os.makedirs(self.output_dir, exist_ok=True)
@@ -77,7 +76,8 @@ class RateMatrixLearner:
         self.df_res, self.Q_dict = train_quantization(
             rate_module=self.mat_module, quantized_dataset=self.quantized_data,
             num_epochs=num_epochs, Q_true=None, optimizer=optim,
-            loss_normalization=loss_normalization, return_best_iter=return_best_iter)
+            loss_normalization=loss_normalization, return_best_iter=return_best_iter,
+            bank_dtype=self.bank_dtype)
         self.trained = True
         if not self.skip_writing_to_output_dir:
             self.process_results()

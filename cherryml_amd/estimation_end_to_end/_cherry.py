@@ -59,7 +59,7 @@ def lg_end_to_end_with_cherryml_optimizer(
     quantization_grid_step: float = 1.1,
     quantization_grid_num_steps: int = 64,
     use_cpp_counting_implementation: bool = True,
-    optimizer_device: str = "cuda",
+    optimizer_device: str = "cpu",
     learning_rate: float = 1e-1,
     num_epochs: int = 2000,
     do_adam: bool = True,
@@ -189,7 +189,7 @@ def coevolution_end_to_end_with_cherryml_optimizer(
     quantization_grid_step: float = 1.1,
     quantization_grid_num_steps: int = 64,
     use_cpp_counting_implementation: bool = True,
-    optimizer_device: str = "cuda",
+    optimizer_device: str = "cpu",
     learning_rate: float = 1e-1,
     num_epochs: int = 500,
     do_adam: bool = True,

@@ -42,6 +42,8 @@ enum {
   CB_EUNSUPPORTED = -5
 };
 
+enum { CB_F64 = 0, CB_F32 = 1 }; /* cb_create: element type of the bank products */
+
 enum {
   CB_PTR_DEVICE = 1, /* data pointers of this call are device pointers */
   CB_NORMALIZE = 2,  /* divide each site's loss (and gradient) by its total count
@@ -66,8 +68,13 @@ int cb_device_count(void);
  * ratelearner.py:147-152 / _siterm/_cherryml_vectorized.py:297-299: the
  * counts stay resident in HBM (stored transposed per bucket, the layout the
  * kernels stream) for the life of the handle.
+ * dtype = element type of the bank products P_b, G_b U, (T_b^T U) o Phi_b: CB_F64, or CB_F32
+ * -- the reference's own arithmetic (ratelearner.py:98,107: float32 parameters, Q and matrix_exp; float64
+ * counts and loss, :147-152) -- for S > 32: float32 operands and MFMA accumulation at twice the float64
+ * matrix rate and half the bytes; the eigendecomposition, the loss accumulation, the divided differences,
+ * the sum over buckets and every vector / matrix crossing this ABI stay float64.  S <= 32: CB_F64 only.
  */
-int cb_create(int device, int S, int L, int B, const double *t, const double *C,
+int cb_create(int device, int S, int L, int B, int dtype, const double *t, const double *C,
               int flags, cb_handle *out);
 
 void cb_destroy(cb_handle h);

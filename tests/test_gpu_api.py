@@ -28,9 +28,12 @@ def _write_inputs(tmp_path, g, states, with_init=True):
     return cpath, ipath, mpath
 
 
+@pytest.mark.parametrize("device", ["cuda", "cpu"])
 @pytest.mark.parametrize("case,states", [("toy3_init", list("ABC")), ("toy3_mask", list("ABC"))])
-def test_stage_function_matches_reference_trajectory(case, states, tmp_path):
-    """quantized_transitions_mle (files in, files out) vs the reference's f64 recipe."""
+def test_stage_function_matches_reference_trajectory(case, states, device, tmp_path):
+    """quantized_transitions_mle (files in, files out) vs the reference's f64 recipe.  device="cpu" is the
+    reference's default and what its own tests pass (tests/estimation_tests/quantized_transitions_mle_test.py):
+    accepted, same result -- this package has one execution target (cherryml_amd/_device.py)."""
     import cherryml_amd
     from cherryml_amd.io import read_rate_matrix
     e = load_golden(f"eval_{case}.npz")
@@ -40,7 +43,7 @@ def test_stage_function_matches_reference_trajectory(case, states, tmp_path):
     ret = cherryml_amd.quantized_transitions_mle(
         count_matrices_path=cpath, initialization_path=ipath, mask_path=mpath,
         output_rate_matrix_dir=out, stationary_distribution_path=None,
-        rate_matrix_parameterization="pande_reversible", device="cuda", learning_rate=1e-1,
+        rate_matrix_parameterization="pande_reversible", device=device, learning_rate=1e-1,
         num_epochs=int(g["num_epochs"]), do_adam=True)
     assert ret is None  # no cache dir set: straight call, like the reference
     have = set(os.listdir(out))

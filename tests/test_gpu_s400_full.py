@@ -1,0 +1,188 @@
+"""Parity WHERE THE HEADLINE NUMBER IS MEASURED: 400 states, B = 129, trajectories of
+50-60 epochs -- against outputs of the reference itself (tests/golden/make_golden_s400_full.py: the
+reference's `coevolution_end_to_end_with_cherryml_optimizer` on all 32 demo_data families, and its
+`train_quantization` / epoch body in float64 on the demo bank and on the dense bank bench.py times).
+This is the first place the warm-started hybrid eigensolver is checked against the reference beyond
+epoch 3.  Tolerances: loss 1e-12, dL/dQ 1e-10, learned Q 1e-6 relative Frobenius (BASELINE.json).
+Also the float32 bank (cb_create(dtype = CB_F32)): the cfg-5 fp64 / fp32 sweep.  Needs an MI355X."""
+import numpy as np
+import pytest
+
+from conftest import load_golden, relerr
+
+pytestmark = pytest.mark.gpu
+
+
+def _mask_of(z):
+    return np.unpackbits(z["mask_packed"])[:160000].reshape(400, 400).astype(np.float64)
+
+
+def _from_support(vals, mask):
+    keep = (mask != 0) | np.eye(len(mask), dtype=bool)
+    Q = np.zeros(mask.shape)
+    Q[keep] = vals
+    return Q
+
+
+def _demo_bank(z):
+    C = np.zeros(tuple(z["C_shape"]))
+    C[z["C_b"].astype(np.int64), z["C_i"].astype(np.int64), z["C_j"].astype(np.int64)] = z["C_quarters"] * 0.25
+    return z["t"], C
+
+
+def _pi_of(log_pi):
+    p = np.exp(log_pi - log_pi.max())
+    return p / p.sum()
+
+
+@pytest.fixture(scope="module")
+def demo():
+    z = load_golden("coevo_demo_full.npz")
+    t, C = _demo_bank(z)
+    assert C.sum() == 1057194.0 and np.count_nonzero(C) == 730864
+    return z, t, C, _mask_of(z)
+
+
+@pytest.fixture(scope="module")
+def dense():
+    import bench
+    wl = bench.make_workload("coevo400", 0, np.random.default_rng(0))
+    return wl
+
+
+def _check_bank_is_the_goldens(wl, z):
+    """the 165 MB dense bank is regenerated from its seed: make sure it is the one the reference saw"""
+    C = wl["C"]
+    assert np.allclose(C.sum(), z["C_sum"], rtol=1e-13)
+    assert np.allclose(C.reshape(C.shape[0], -1).sum(1), z["C_bucket_sums"], rtol=1e-12)
+    assert np.allclose(C[::16, ::37, ::41], z["C_probe"], rtol=1e-11, atol=1e-300)
+
+
+@pytest.mark.parametrize("dtype,tol_loss,tol_grad", [("f64", 1e-12, 1e-10), ("f32", 2e-6, 2e-4)])
+def test_demo_bank_single_evaluation_vs_reference(demo, dtype, tol_loss, tol_grad):
+    """(loss, dL/dQ) on the REAL config-3 bank (all 32 families, 43 live buckets, 3.5 % dense) at the
+    JTT-IPW initialisation; float32 bank: the stated f32 tolerance."""
+    from cherryml_amd import CherryBank
+    z, t, C, mask = demo
+    Q = _from_support(z["Q_support_f64"], mask)
+    with CherryBank(t, C, dtype=dtype) as bank:
+        assert int(bank.live_buckets[0]) == 43
+        loss, dQ = bank.loss_grad(Q, _pi_of(z["log_pi"]))
+    el, eg = abs(loss[0] - float(z["loss_f64"])) / abs(float(z["loss_f64"])), relerr(dQ[0], z["dQ_f64"])
+    print(f"demo bank {dtype}: loss rel. err {el:.2e}, dL/dQ rel. Frobenius {eg:.2e}")
+    assert el < tol_loss and eg < tol_grad
+
+
+@pytest.mark.parametrize("dtype,tol_loss,tol_grad", [("f64", 1e-12, 1e-10), ("f32", 2e-6, 2e-4)])
+def test_dense_bench_bank_single_evaluation_vs_reference(dense, dtype, tol_loss, tol_grad):
+    """the bank bench.py times (B = 129, every bucket populated)"""
+    from cherryml_amd import CherryBank
+    z = load_golden("coevo_dense_eval.npz")
+    _check_bank_is_the_goldens(dense, z)
+    Q = _from_support(z["Q_support_f64"], dense["mask"])
+    with CherryBank(dense["t"], dense["C"], dtype=dtype) as bank:
+        loss, dQ = bank.loss_grad(Q, _pi_of(z["log_pi"]))
+    el, eg = abs(loss[0] - float(z["loss_f64"])) / abs(float(z["loss_f64"])), relerr(dQ[0], z["dQ_f64"])
+    print(f"dense bank {dtype}: loss rel. err {el:.2e}, dL/dQ rel. Frobenius {eg:.2e}")
+    assert el < tol_loss and eg < tol_grad
+
+
+def _train(t, C, mask, u0, p0, E, dtype="f64"):
+    from cherryml_amd import CherryBank
+    with CherryBank(t, C, dtype=dtype) as bank:
+        return bank.train_pande_reversible(u0, p0, mask=mask, num_epochs=E, lr=0.1)
+
+
+def test_demo_bank_50_epoch_trajectory_vs_reference(demo):
+    """50 epochs of the reference's `train_quantization` (float64) on the real bank: loss curve, Q_1, Q_2,
+    Q_best, Q_last.  49 warm-started eigensolves in a row, checked against torch.matrix_exp + autograd."""
+    z, t, C, mask = demo
+    E = int(z["epochs"])
+    r = _train(t, C, mask, z["upper_diag"], z["log_pi"], E)
+    assert np.allclose(r["loss"], z["traj_loss_f64"], rtol=1e-9, atol=0)
+    for key, got in (("Q_1", r["Q_pow2"][1]), ("Q_2", r["Q_pow2"][2]), ("Q_best", r["Q_best"]), ("Q_last", r["Q_last"])):
+        want = _from_support(z[f"traj_{key}_support_f64"], mask)
+        e = relerr(got, want)
+        print(f"demo bank, {E} epochs: {key} rel. Frobenius {e:.2e}")
+        assert e < 1e-6, key
+
+
+def test_dense_bank_60_epoch_trajectories_vs_reference(dense):
+    """8 buckets of the bench bank, 60 epochs: float64 against the reference in float64 (1e-6), and the
+    float32 bank against BOTH reference runs (its own float32 arithmetic, and float64) -- the distances
+    the cfg-5 sweep reports."""
+    z = load_golden("coevo_dense_traj.npz")
+    _check_bank_is_the_goldens(dense, z)
+    sel, E, mask = z["sel"], int(z["epochs"]), dense["mask"]
+    t, C = dense["t"][sel], dense["C"][sel]
+    r64 = _train(t, C, mask, z["upper_diag0"], z["log_pi0"], E)
+    assert np.allclose(r64["loss"], z["loss_f64"], rtol=1e-9, atol=0)
+    for key in ("Q_best", "Q_last"):
+        e = relerr(r64[key], _from_support(z[f"{key}_support_f64"], mask))
+        print(f"dense sub-bank f64: {key} to the f64 reference {e:.2e}")
+        assert e < 1e-6
+    r32 = _train(t, C, mask, z["upper_diag0"], z["log_pi0"], E, dtype="f32")
+    assert np.allclose(r32["loss"], z["loss_f64"], rtol=5e-6, atol=0)
+    d_ref = relerr(_from_support(z["Q_last_support_f32"], mask), _from_support(z["Q_last_support_f64"], mask))
+    for key in ("Q_best", "Q_last"):
+        e64 = relerr(r32[key], _from_support(z[f"{key}_support_f64"], mask))
+        e32 = relerr(r32[key], _from_support(z[f"{key}_support_f32"], mask))
+        print(f"dense sub-bank f32 bank: {key} to the f64 reference {e64:.2e}, to the reference's own float32 run "
+              f"{e32:.2e} (reference f32 vs f64: {d_ref:.2e})")
+    # Q_last follows the trajectory itself (Q_best also depends on which epoch wins a flat argmin)
+    assert relerr(r32["Q_last"], _from_support(z["Q_last_support_f64"], mask)) < 1e-3
+    assert relerr(r32["Q_last"], _from_support(z["Q_last_support_f32"], mask)) < 1e-3
+
+
+def test_dense_bank_full_60_epoch_trajectory_vs_reference(dense):
+    """THE bench configuration: all 129 buckets, 60 epochs, against the reference in float64."""
+    z = load_golden("coevo_dense_traj_full.npz")
+    _check_bank_is_the_goldens(dense, z)
+    E, mask = int(z["epochs"]), dense["mask"]
+    r = _train(dense["t"], dense["C"], mask, z["upper_diag0"], z["log_pi0"], E)
+    assert np.allclose(r["loss"], z["loss_f64"], rtol=1e-9, atol=0)
+    for key, got in (("Q_1", r["Q_pow2"][1]), ("Q_2", r["Q_pow2"][2]), ("Q_best", r["Q_best"]), ("Q_last", r["Q_last"])):
+        e = relerr(got, _from_support(z[f"{key}_support_f64"], mask))
+        print(f"dense bank B = 129, {E} epochs: {key} rel. Frobenius {e:.2e}")
+        assert e < 1e-6, key
+
+
+def test_cfg5_fp64_vs_fp32_sweep():
+    """BASELINE.json config 5: co-evolution 400 x 400, 10k synthetic families (sum C ~ 1e8, B = 129), the
+    same optimisation in both dtypes.  Reported: rel. Frobenius(Q_f32, Q_f64) along the trajectory; asserted:
+    the loss curves agree to float32 accuracy and the learned matrices to 1e-3 (the reference's own float32
+    arithmetic sits 1e-5 .. 1e-3 from its float64 run)."""
+    import bench
+    rng = np.random.default_rng(5)
+    Q, pi, mask = bench.coevolution_truth(rng)
+    t, C = bench.reversible_bank(Q, pi, 1.0e8, rng)
+    from cherryml_amd import CherryBank, RateMatrix
+    from cherryml_amd.estimation import jtt_ipw_from_arrays
+    import torch
+    init = jtt_ipw_from_arrays(t, C, mask)
+    mod = RateMatrix(num_states=400, mode="pande_reversible", mask=torch.tensor(mask),
+                     pi=torch.ones(400, dtype=torch.float64) / 400, pi_requires_grad=True, initialization=init)
+    u0, p0 = mod.upper_diag.detach().numpy().copy(), mod._pi.detach().numpy().copy()
+    E = 100
+    runs = {}
+    for dtype in ("f64", "f32"):
+        with CherryBank(t, C, dtype=dtype) as bank:
+            runs[dtype] = bank.train_pande_reversible(u0, p0, mask=mask, num_epochs=E, lr=0.1)
+    a, b = runs["f64"], runs["f32"]
+    assert a["loss"][-1] < a["loss"][0] and np.all(np.isfinite(b["loss"]))
+    dl = np.max(np.abs(a["loss"] - b["loss"]) / np.abs(a["loss"]))
+    sweep = {k: relerr(b["Q_pow2"][k], a["Q_pow2"][k]) for k in sorted(a["Q_pow2"])}
+    print(f"cfg-5 sweep (sum C = 1e8, {E} epochs): max rel. loss difference {dl:.2e}; rel. Frobenius(Q_f32, Q_f64) at "
+          f"epochs {sweep}; Q_last {relerr(b['Q_last'], a['Q_last']):.2e}, Q_best {relerr(b['Q_best'], a['Q_best']):.2e}; "
+          f"to the generating Q: f64 {relerr(a['Q_best'], Q):.3e}, f32 {relerr(b['Q_best'], Q):.3e}")
+    assert dl < 5e-6
+    assert relerr(b["Q_last"], a["Q_last"]) < 1e-3 and relerr(b["Q_best"], a["Q_best"]) < 1e-3
+
+
+def test_f32_dtype_is_refused_for_small_state_spaces():
+    from cherryml_amd import CherryBank
+    g = load_golden("eval_s20_symmask.npz")
+    with pytest.raises(NotImplementedError):
+        CherryBank(g["t"], g["C"], dtype="f32")
+    with pytest.raises(ValueError):
+        CherryBank(g["t"], g["C"], dtype="bf16")

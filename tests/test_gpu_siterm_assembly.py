@@ -80,9 +80,14 @@ def test_all_gap_site_gets_the_prior_and_bad_arguments_raise():
         est(tree=a["tree"], site_rates=[2.0, 0.5], msa=a["msa"], alphabet=alphabet, regularization_strength=0.5,
             regularization_rate_matrix=Q0, quantization_points=a["grid"], optimization_num_epochs=5,
             transitions_strategy="nope")
-    with pytest.raises(NotImplementedError):
+    # the reference's default spelling "cpu" is accepted (same result: there is one execution target, the GPU)
+    r_cpu = est(tree=a["tree"], site_rates=[2.0, 0.5], msa=a["msa"], alphabet=alphabet, regularization_strength=0.5,
+                regularization_rate_matrix=Q0, quantization_points=a["grid"], optimization_num_epochs=5,
+                vectorized_cherryml_implementation_device="cpu")
+    assert np.array_equal(r_cpu["res"], r["res"])
+    with pytest.raises(ValueError):
         est(tree=a["tree"], site_rates=[2.0, 0.5], msa=a["msa"], alphabet=alphabet, regularization_strength=0.5,
             regularization_rate_matrix=Q0, quantization_points=a["grid"], optimization_num_epochs=5,
-            vectorized_cherryml_implementation_device="cpu")
+            vectorized_cherryml_implementation_device="tpu")
     with pytest.raises(ValueError):   # unsorted grid is refused by the C ABI
         get_raw_count_matrices([("AD", "DA", 0.1)], [0.2, 0.1], ["A", "D"])

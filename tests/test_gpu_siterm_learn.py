@@ -70,9 +70,9 @@ def test_public_api_known_answer_and_errors():
                   [0.21, 0.03, 0.24, -0.48]]), decimal=1)
     g = load_golden("siterm_learn.npz")
     assert relerr(r["learnt_rate_matrices"][0], g["pub_res"][0]) < 1e-6
-    with pytest.raises(NotImplementedError):
-        cherryml_amd.learn_site_specific_rate_matrices(tree=tree, msa=msa, alphabet=dna,
-                                                      regularization_rate_matrix=Q, device="cpu")
+    r_cuda = cherryml_amd.learn_site_specific_rate_matrices(tree=tree, msa=msa, alphabet=dna, regularization_strength=0.5,
+                                                           regularization_rate_matrix=Q, device="cuda")
+    assert np.array_equal(r_cuda["learnt_rate_matrices"], r["learnt_rate_matrices"])   # "cpu" (default) == "cuda"
     with pytest.raises(ValueError):
         cherryml_amd.learn_site_specific_rate_matrices(tree=tree, msa=msa, alphabet=dna,
                                                       regularization_rate_matrix=Q, just_run_fast_cherries=True)

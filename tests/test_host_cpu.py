@@ -36,19 +36,29 @@ def test_no_gpu_means_loud_failure_not_fallback():
         cherryml_amd.CherryBank(np.ones(2), np.ones((2, 3, 3)))
 
 
-def test_device_cpu_is_refused(tmp_path):
+def test_no_gpu_fails_loudly_whatever_the_device_argument_says(tmp_path):
+    """`device` keeps the reference's spellings and default ("cpu"), but there is ONE execution target:
+    without an MI355X every entry point raises CherryBankError -- never a CPU fallback.  (With a GPU,
+    "cpu" runs there and warns: tests/test_gpu_api.py.)"""
+    from cherryml_amd import _lib
+    if _lib.load().cb_device_count() > 0:
+        pytest.skip("a GPU is visible")
     g = load_golden("eval_toy3_init.npz")
     states = list("ABC")
     cpath = str(tmp_path / "c.txt")
     write_count_matrices([(float(t), pd.DataFrame(C, index=states, columns=states))
                           for t, C in zip(g["t"], g["C"])], cpath)
-    with pytest.raises(NotImplementedError):
-        cherryml_amd.quantized_transitions_mle(
-            count_matrices_path=cpath, initialization_path=None, mask_path=None,
-            output_rate_matrix_dir=str(tmp_path / "out"), device="cpu", num_epochs=1)
-    with pytest.raises(NotImplementedError):
+    for device in ("cpu", "cuda"):
+        with pytest.raises(_lib.CherryBankError, match="no CPU fallback"):
+            cherryml_amd.quantized_transitions_mle(
+                count_matrices_path=cpath, initialization_path=None, mask_path=None,
+                output_rate_matrix_dir=str(tmp_path / "out"), device=device, num_epochs=1)
+        with pytest.raises(_lib.CherryBankError, match="no CPU fallback"):
+            cherryml_amd.quantized_transitions_mle_vectorized_over_sites(
+                np.ones((1, 1, 4, 4)), np.ones((1, 1)), 1, device=device)
+    with pytest.raises(ValueError):
         cherryml_amd.quantized_transitions_mle_vectorized_over_sites(
-            np.ones((1, 1, 4, 4)), np.ones((1, 1)), 1, device="cpu")
+            np.ones((1, 1, 4, 4)), np.ones((1, 1)), 1, device="tpu")
 
 
 def test_positional_arguments_refused():
