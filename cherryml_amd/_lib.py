@@ -8,7 +8,7 @@ from ._build import LIB
 CB_PTR_DEVICE = 1
 CB_NORMALIZE = 2
 CB_NO_SYNC = 4
-CB_F64, CB_F32 = 0, 1
+CB_F64, CB_F32, CB_MIXED = 0, 1, 2
 
 CB_EINVAL, CB_EHIP, CB_ENOMEM, CB_ENUMERIC, CB_EUNSUPPORTED = -1, -2, -3, -4, -5
 

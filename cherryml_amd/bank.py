@@ -21,14 +21,16 @@ class CherryBank:
     every epoch: cherryml/estimation/_ratelearn/trainer.py:164-167)."""
 
     def __init__(self, t, C, device: int = 0, dtype: str = "f64"):
-        """dtype: element type of the bank products (cb_create's `dtype`): "f64", or "f32" -- the
+        """dtype: element type of the bank products (cb_create's `dtype`): "f64"; "f32" -- the
         reference's own arithmetic, ratelearner.py:98,107 -- for S > 32 (float32 MFMA; the
-        eigendecomposition, loss accumulation and everything crossing the ABI stay float64)."""
+        eigendecomposition, loss accumulation and everything crossing the ABI stay float64); or "mixed":
+        P_b, loss and G_b in float64, the two contractions of the gradient on the float32 MFMA."""
         self._h = None
-        if dtype not in ("f64", "f32"):
-            raise ValueError(f'dtype must be "f64" or "f32", got {dtype!r}')
+        codes = {"f64": _lib.CB_F64, "f32": _lib.CB_F32, "mixed": _lib.CB_MIXED}
+        if dtype not in codes:
+            raise ValueError(f'dtype must be "f64", "f32" or "mixed", got {dtype!r}')
         self.dtype = dtype
-        code = _lib.CB_F32 if dtype == "f32" else _lib.CB_F64
+        code = codes[dtype]
         lib = _lib.load()
         if lib.cb_device_count() <= 0:
             raise _lib.CherryBankError("no HIP device visible; cherryml_amd has no CPU fallback")

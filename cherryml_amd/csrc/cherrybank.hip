@@ -337,9 +337,10 @@ extern "C" int cb_create(int device, int S, int L, int B, int dtype, const doubl
                          int flags, cb_handle *out) {
   if (!out) return fail(CB_EINVAL, "cb_create: out is NULL");
   *out = nullptr;
-  if (dtype != CB_F64 && dtype != CB_F32) return fail(CB_EINVAL, "cb_create: dtype must be CB_F64 or CB_F32 (got %d)", dtype);
-  if (dtype == CB_F32 && S <= 32)
-    return fail(CB_EUNSUPPORTED, "cb_create: CB_F32 is built for the MFMA-bound large path only (S > 32; got S=%d): "
+  if (dtype != CB_F64 && dtype != CB_F32 && dtype != CB_MIXED)
+    return fail(CB_EINVAL, "cb_create: dtype must be CB_F64, CB_F32 or CB_MIXED (got %d)", dtype);
+  if (dtype != CB_F64 && S <= 32)
+    return fail(CB_EUNSUPPORTED, "cb_create: CB_F32 / CB_MIXED are built for the MFMA-bound large path only (S > 32; got S=%d): "
                                  "the small-state kernels are float64", S);
   if (S < 2 || L < 1 || B < 1) return fail(CB_EINVAL, "cb_create: need S>=2, L>=1, B>=1 (got %d,%d,%d)", S, L, B);
   const bool expm_only = (flags & CB_EXPM_ONLY) != 0;
@@ -495,14 +496,14 @@ extern "C" int cb_create(int device, int S, int L, int B, int dtype, const doubl
     h->k3_chunk = 4;
     h->k3_nchunks = (B + h->k3_chunk - 1) / h->k3_chunk;
     double *tot = nullptr;
-    const bool f32 = h->dtype == CB_F32;
-    const size_t per_bucket = (expm_only || f32) ? 0 : (size_t)Bl * LL;   // Ct / Gt / T exist for the loss only
-    const size_t per_bucket32 = f32 ? (size_t)Bl * LL : 0;
-    bool ok = dev_alloc(h, &h->Ct, per_bucket) == CB_OK && dev_alloc(h, &tot, SS) == CB_OK &&
-              dev_alloc(h, &h->Ct32, per_bucket32) == CB_OK && dev_alloc(h, &h->Gt32, per_bucket32) == CB_OK &&
-              dev_alloc(h, &h->T32, per_bucket32) == CB_OK && dev_alloc(h, &h->Uf, f32 ? LL : 0) == CB_OK &&
-              dev_alloc(h, &h->Utf, f32 ? LL : 0) == CB_OK && dev_alloc(h, &h->Af, f32 ? LL : 0) == CB_OK &&
-              dev_alloc(h, &h->Ff, f32 ? (size_t)B * h->LD : 0) == CB_OK &&
+    const bool f32 = h->dtype == CB_F32, mixed = h->dtype == CB_MIXED, narrow = f32 || mixed;
+    const size_t per_bucket = (expm_only || narrow) ? 0 : (size_t)Bl * LL;   // Ct / Gt / T exist for the loss only
+    const size_t per_bucket32 = narrow ? (size_t)Bl * LL : 0;
+    bool ok = dev_alloc(h, &h->Ct, mixed ? (size_t)Bl * LL : per_bucket) == CB_OK && dev_alloc(h, &tot, SS) == CB_OK &&
+              dev_alloc(h, &h->Ct32, f32 ? per_bucket32 : 0) == CB_OK && dev_alloc(h, &h->Gt32, per_bucket32) == CB_OK &&
+              dev_alloc(h, &h->T32, per_bucket32) == CB_OK && dev_alloc(h, &h->Uf, narrow ? LL : 0) == CB_OK &&
+              dev_alloc(h, &h->Utf, narrow ? LL : 0) == CB_OK && dev_alloc(h, &h->Af, narrow ? LL : 0) == CB_OK &&
+              dev_alloc(h, &h->Ff, narrow ? (size_t)B * h->LD : 0) == CB_OK &&
               dev_alloc(h, &h->A, LL) == CB_OK && dev_alloc(h, &h->dsq, h->LD) == CB_OK &&
               dev_alloc(h, &h->Gc, LL) == CB_OK && dev_alloc(h, &h->Vc, LL) == CB_OK &&
               dev_alloc(h, &h->Gc2, LL) == CB_OK && dev_alloc(h, &h->gx, 12 * LL + (size_t)h->LD + 16 + 3 * 256 + 8) == CB_OK &&
@@ -691,17 +692,23 @@ static int large_eval(cb_bank *h, bool normalize, double *lossd, double *out, bo
   const int tiles_k3 = h->sym_counts ? tiles_k1 : tiles;
   // float32 bank (cb_create(dtype = CB_F32)): the loss / gradient products run on the f32 MFMA from f32
   // copies of this epoch's U, U^T, A and F; cb_expm_bank (Pd) always takes the float64 kernels
-  const bool f32 = h->dtype == CB_F32 && !Pd;
-  if (f32)
+  // CB_MIXED: P_b, the loss and G_b in float64 (the O(t^2) entries of P_b keep their relative accuracy),
+  // G_b rounded to float32 once, the two contractions on the float32 MFMA
+  const bool f32 = h->dtype == CB_F32 && !Pd, mixed = h->dtype == CB_MIXED && !Pd;
+  if (f32 || mixed)
     hipLaunchKernelGGL(lg_cast_f32, dim3((unsigned)((std::max(LL, (size_t)B * LD) + 255) / 256)), dim3(256), 0, h->stream, LL,
                        (size_t)B * LD, h->U, h->Vc, h->A, h->F, h->Uf, h->Utf, h->Af, h->Ff);
   mark(h, EV_END);  // (re-used as "before K1" marker)
   if (f32) {
     K1Args<float> k1{S, LD, B, h->Utf, h->Af, tb, h->Ff, h->sigma, h->Ct32, h->Gt32, h->loss_part, inv_n, h->dsq, nullptr};
     hipLaunchKernelGGL(k1_pt_loss_gt<float>, dim3(tiles_k1 * B), dim3(LG4_THREADS), 0, h->stream, k1);
+  } else if (mixed) {
+    K1Args<double, float> k1{S, LD, B, h->Vc, h->A, tb, h->F, h->sigma, h->Ct, h->Gt32, h->loss_part, inv_n, h->dsq, nullptr};
+    hipLaunchKernelGGL((k1_pt_loss_gt<double, float>), dim3(tiles_k1 * B), dim3(LG4_THREADS), 0, h->stream, k1);
   } else {
     K1Args<double> k1{S, LD, B, h->Vc, h->A, tb, h->F, h->sigma, h->Ct, h->Gt, h->loss_part, inv_n, h->dsq, Pd};
-    hipLaunchKernelGGL(k1_pt_loss_gt<double>, dim3(tiles_k1 * B), dim3(LG4_THREADS), 0, h->stream, k1);
+    if (Pd) hipLaunchKernelGGL((k1_pt_loss_gt<double, double, true>), dim3(tiles_k1 * B), dim3(LG4_THREADS), 0, h->stream, k1);
+    else hipLaunchKernelGGL((k1_pt_loss_gt<double, double, false>), dim3(tiles_k1 * B), dim3(LG4_THREADS), 0, h->stream, k1);
   }
   mark(h, EV_K1);
   if (Pd) {
@@ -711,7 +718,7 @@ static int large_eval(cb_bank *h, bool normalize, double *lossd, double *out, bo
   hipLaunchKernelGGL(lg_finish_loss, dim3(1), dim3(256), 0, h->stream, h->loss_part, B * tiles_k1, S,
                      h->dsq, h->dirsum, inv_n, lossd);
   if (dQd) {
-    if (f32) {
+    if (f32 || mixed) {
       K2Args<float> k2{LD, h->Gt32, h->Uf, h->T32};
       hipLaunchKernelGGL(k2_t_eq_g_u<float>, dim3(tiles * B), dim3(LG4_THREADS), 0, h->stream, k2);
       mark(h, EV_K2);

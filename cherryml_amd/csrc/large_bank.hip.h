@@ -211,7 +211,7 @@ __device__ __forceinline__ float k1_log(float x) { return logf(x); }
 __device__ __forceinline__ float k1_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 
 // ------------------------------------------------------------------ K1
-template <typename T>
+template <typename T, typename TG = T>   // TG: element type Gt^T is written in (CB_MIXED: T = double, TG = float)
 struct K1Args {
   int S, LD, B;
   const T *Ut;           // [LD][LD]  Ut[k][i] = U[i][k]
@@ -220,7 +220,7 @@ struct K1Args {
   const T *F;            // [B][LD]   phi2(t_b lam_k) (split) or exp(t_b lam_k)
   const double *sigma;   // max |A_ii|: bucket uses the split form iff 2 sigma t_b <= 1
   const T *Ct;           // [B][LD][LD] transposed counts (padded)
-  T *Gt;                 // [B][LD][LD] out: Gt^T
+  TG *Gt;                // [B][LD][LD] out: Gt^T
   double *loss_part;     // [B * tiles] out
   double inv_n;
   const double *dsq;     // [LD] sqrt(pi) (expm mode)
@@ -230,8 +230,8 @@ struct K1Args {
 // Pt_b is symmetric: only the tilesN (tilesN + 1) / 2 tiles with tm <= tn run the main loop; an
 // off-diagonal tile serves both (row, col) and (col, row) in its epilogue (same Pt value, its own
 // count and its own Gt^T entry).  40 % fewer MFMAs than the full grid at LD = 400.
-template <typename T>
-__global__ __launch_bounds__(LG4_THREADS, 4) void k1_pt_loss_gt(K1Args<T> a) {  // four workgroups per CU
+template <typename T, typename TG = T, bool EXPM = false>   // EXPM: write P_b (cb_expm_bank) instead of loss / Gt
+__global__ __launch_bounds__(LG4_THREADS, 4) void k1_pt_loss_gt(K1Args<T, TG> a) {  // four workgroups per CU
   __shared__ T sA[2 * LG_KT * LG_TM];
   __shared__ T sB[2 * LG_KT * LG_TN];
   typedef typename Mfma<T>::acc_t acc_t;
@@ -256,27 +256,74 @@ __global__ __launch_bounds__(LG4_THREADS, 4) void k1_pt_loss_gt(K1Args<T> a) {  
   const bool split = tb * 2.0 * (*a.sigma) <= 1.0;  // see small_bank.hip.h
   const bool mirror = tm != tn;
   double lossacc = 0.0;
-  auto emit = [&](int row, int col, T pt) {
-    const size_t idx = (size_t)row * a.LD + col;
-    if (a.P) {
-      if (row < a.S && col < a.S)
-        a.P[(size_t)b * a.S * a.S + (size_t)row * a.S + col] = (double)pt * a.dsq[col] / a.dsq[row];
-    } else {
-      const T c = a.Ct[boff + idx];
-      const bool nz = c != T(0);
-      lossacc = fma(-(double)c, (double)k1_log(nz ? pt : T(1)), lossacc);
-      a.Gt[boff + idx] = nz ? -c * inv_nT * k1_rcp(pt) : T(0);
+  const int lo = lane & 15, hi = lane >> 4;
+  const T *__restrict__ Ct = a.Ct + boff;
+  const T *__restrict__ Am = a.A;
+  TG *__restrict__ Gt = a.Gt + boff;
+  // One 16 x 16 MFMA tile at a time, in three phases: ALL its loads (counts, mirrored counts, I + tA),
+  // then the arithmetic, then ALL its stores.  Written element by element (load, log, store, next
+  // element) the epilogue compiled to 25 chains of global_load -> s_waitcnt vmcnt(0) -> ... -> store,
+  // i.e. 25 exposed HBM latencies per wave (the counts are streamed, never cached): 40 % of K1's time.
+  // log(Pt) and 1 / Pt are shared by the (row, col) and the mirrored (col, row) entry.
+  auto tile_epilogue = [&](int rbase, int cbase, const acc_t &v) {   // wave-uniform tile origin
+    if (rbase >= a.LD || cbase >= a.LD) return;
+    const int col = cbase + lo;
+    int row[4], idx[4], idm[4];          // LD <= 1024: offsets inside one matrix fit an int
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      row[r] = rbase + Mfma<T>::row(hi, r);
+      idx[r] = row[r] * a.LD + col;
+      idm[r] = col * a.LD + row[r];
+    }
+    T c1[4], c2[4], av[4], pt[4];
+    if (!EXPM) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) c1[r] = Ct[idx[r]];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) c2[r] = mirror ? Ct[idm[r]] : T(0);
+    }
+    if (split) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) av[r] = Am[idx[r]];
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      pt[r] = v[r];
+      if (split) pt[r] += tbT * av[r] + (row[r] == col ? T(1) : T(0));
+      else if (row[r] >= a.S || col >= a.S) pt[r] = T(1);  // pad (never used: C = 0 there)
+    }
+    if (EXPM) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        if (row[r] < a.S && col < a.S) {
+          a.P[(size_t)b * a.S * a.S + (size_t)row[r] * a.S + col] = (double)pt[r] * a.dsq[col] / a.dsq[row[r]];
+          if (mirror) a.P[(size_t)b * a.S * a.S + (size_t)col * a.S + row[r]] = (double)pt[r] * a.dsq[row[r]] / a.dsq[col];
+        }
+      }
+      return;
+    }
+    TG g1[4], g2[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const bool nz1 = c1[r] != T(0), nz2 = c2[r] != T(0);
+      const T lg = k1_log((nz1 || nz2) ? pt[r] : T(1));
+      const T rc = inv_nT * k1_rcp(pt[r]);
+      lossacc = fma(-((double)c1[r] + (double)c2[r]), (double)lg, lossacc);
+      g1[r] = (TG)(nz1 ? -c1[r] * rc : T(0));
+      g2[r] = (TG)(nz2 ? -c2[r] * rc : T(0));
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) Gt[idx[r]] = g1[r];
+    if (mirror) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) Gt[idm[r]] = g2[r];
     }
   };
-  lg_for_each<T>(m0, n0, acc, ax0, ax1, [&](int row, int col, T pt) {
-    if (row < a.LD && col < a.LD) {
-      if (split) pt += tbT * a.A[(size_t)row * a.LD + col] + (row == col ? T(1) : T(0));
-      else if (row >= a.S || col >= a.S) pt = T(1);  // pad (never used: C = 0 there)
-      emit(row, col, pt);
-      if (mirror) emit(col, row, pt);
-    }
-  });
-  if (a.P) return;
+#pragma unroll
+  for (int j = 0; j < 5; ++j) tile_epilogue(m0 + 16 * wave, n0 + 16 * j, acc[j]);
+  tile_epilogue(m0 + 64, n0 + 16 * wave, ax0);
+  if (wave == 0) tile_epilogue(m0 + 64, n0 + 64, ax1);
+  if (EXPM) return;
   lossacc = wave_sum(lossacc);
   // sA is free after the K loop (the tile routine ends with a barrier)
   double *sRed = reinterpret_cast<double *>(sA);
@@ -308,8 +355,9 @@ __global__ __launch_bounds__(LG4_THREADS, 4) void k2_t_eq_g_u(K2Args<T> a) {
   GemmOperands<T> g{a.Gt + boff, a.U, a.LD, a.LD, a.LD, a.LD, a.LD, nullptr};
   acc_t acc[5], ax0, ax1;
   lg4_gemm_tile<T, false>(g, m0, n0, sA, sB, acc, ax0, ax1);
+  T *__restrict__ Tm = a.Tm + boff;
   lg_for_each<T>(m0, n0, acc, ax0, ax1, [&](int row, int col, T v) {
-    if (row < a.LD && col < a.LD) a.Tm[boff + (size_t)row * a.LD + col] = v;
+    if (row < a.LD && col < a.LD) Tm[(size_t)row * a.LD + col] = v;
   });
 }
 
@@ -358,14 +406,36 @@ __global__ __launch_bounds__(LG4_THREADS, 4) void k3_w_phi(K3Args<T> a) {
   acc_t acc[5], ax0, ax1;
   lg4_gemm_tile<T, false>(g, m0, n0, sA, sB, acc, ax0, ax1);
   const double tb = a.t[b];
-  const double *Eb = a.E + (size_t)b * a.LD, *Hb = a.H + (size_t)b * a.LD;
-  lg_for_each<T>(m0, n0, acc, ax0, ax1, [&](int row, int col, T v) {
-    if (row < a.LD && col < a.LD) {
-      // (the divided difference is evaluated in float64 in both widths: its cancellation-free form needs it)
-      const double ph = divdiff_fast(tb, a.lam[row], a.lam[col], Eb[row], Eb[col], Hb[row], Hb[col]);
-      a.W[boff + (size_t)row * a.LD + col] = (T)((double)v * ph);   // (symmetric case: k3_reduce mirrors the sum, not every bucket)
+  const double *__restrict__ Eb = a.E + (size_t)b * a.LD, *__restrict__ Hb = a.H + (size_t)b * a.LD;
+  const double *__restrict__ lam = a.lam;
+  T *__restrict__ W = a.W + boff;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, lo = lane & 15, hi = lane >> 4;
+  // per MFMA tile: the spectral tables of its rows and column first (all loads of the tile in flight
+  // together; element by element they compiled to load -> wait -> store chains), then Phi, then the stores.
+  // (the divided difference is evaluated in float64 in both widths: its cancellation-free form needs it)
+  auto tile_epilogue = [&](int rbase, int cbase, const acc_t &v) {   // wave-uniform tile origin
+    if (rbase >= a.LD || cbase >= a.LD) return;
+    const int col = cbase + lo;
+    const double lc = lam[col], ec = Eb[col], hc = Hb[col];
+    double lr[4], er[4], hr[4];
+    int row[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      row[r] = rbase + Mfma<T>::row(hi, r);
+      lr[r] = lam[row[r]];
+      er[r] = Eb[row[r]];
+      hr[r] = Hb[row[r]];
     }
-  });
+    T w[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) w[r] = (T)((double)v[r] * divdiff_fast(tb, lr[r], lc, er[r], ec, hr[r], hc));
+#pragma unroll
+    for (int r = 0; r < 4; ++r) W[(size_t)row[r] * a.LD + col] = w[r];   // (symmetric case: k3_reduce mirrors the sum, not every bucket)
+  };
+#pragma unroll
+  for (int j = 0; j < 5; ++j) tile_epilogue(m0 + 16 * wave, n0 + 16 * j, acc[j]);
+  tile_epilogue(m0 + 64, n0 + 16 * wave, ax0);
+  if (wave == 0) tile_epilogue(m0 + 64, n0 + 64, ax1);
 }
 
 // Mt = sum over chunks (fixed order => bitwise reproducible), always accumulated in float64.  sym

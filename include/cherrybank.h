@@ -42,7 +42,7 @@ enum {
   CB_EUNSUPPORTED = -5
 };
 
-enum { CB_F64 = 0, CB_F32 = 1 }; /* cb_create: element type of the bank products */
+enum { CB_F64 = 0, CB_F32 = 1, CB_MIXED = 2 }; /* cb_create: element type of the bank products */
 
 enum {
   CB_PTR_DEVICE = 1, /* data pointers of this call are device pointers */
@@ -72,7 +72,10 @@ int cb_device_count(void);
  * -- the reference's own arithmetic (ratelearner.py:98,107: float32 parameters, Q and matrix_exp; float64
  * counts and loss, :147-152) -- for S > 32: float32 operands and MFMA accumulation at twice the float64
  * matrix rate and half the bytes; the eigendecomposition, the loss accumulation, the divided differences,
- * the sum over buckets and every vector / matrix crossing this ABI stay float64.  S <= 32: CB_F64 only.
+ * the sum over buckets and every vector / matrix crossing this ABI stay float64.  CB_MIXED keeps P_b, the
+ * loss and G_b = -C_b / P_b in float64 too (the O(t^2) entries of P_b, which divide counts, keep their
+ * relative accuracy), rounds G_b to float32 once and runs the two contractions G_b U and (T_b^T U) o Phi_b
+ * on the float32 MFMA.  S <= 32: CB_F64 only.
  */
 int cb_create(int device, int S, int L, int B, int dtype, const double *t, const double *C,
               int flags, cb_handle *out);
