@@ -152,7 +152,9 @@ def estimate_site_specific_rate_matrices_given_tree_and_site_rates(
     """:442-731 (`_estimate_site_specific_rate_matrices_given_tree_and_site_rates`), vectorised path:
     {"res": [L,S,S] site-specific rate matrices, "time_*": seconds per sub-step}.  Sites without
     any count (e.g. all gaps) get the prior `Q0 * rate_l`, like the reference's per-site path
-    (:655-658)."""
+    (:655-658).  `use_vectorized_cherryml_implementation=False` selects the reference's per-site
+    semantics (the pande_reversible parameterisation of `_quantized_transitions_mle`, :43-84) -- batched
+    over the sites on the device all the same."""
     from .._device import resolve_device
     resolve_device(vectorized_cherryml_implementation_device, "estimate_site_specific_rate_matrices_given_tree_and_site_rates")
     if rate_matrix_parameterization != "pande_reversible":
@@ -186,9 +188,30 @@ def estimate_site_specific_rate_matrices_given_tree_and_site_rates(
         idx = np.flatnonzero(has)
         sub = counts if has.all() else counts[torch.as_tensor(idx, device=counts.device)]
         times = np.tile(np.asarray(grid, dtype=np.float64), (len(idx), 1))
-        th0, Th0 = _invert(init[idx])
-        with CherryBank(times, sub) as bank:
-            r = bank.train_siterm(th0, Th0, int(optimization_num_epochs), lr=0.1)
-        res[idx] = r["res"]
+        if use_vectorized_cherryml_implementation:
+            th0, Th0 = _invert(init[idx])
+            with CherryBank(times, sub) as bank:
+                r = bank.train_siterm(th0, Th0, int(optimization_num_epochs), lr=0.1)
+            res[idx] = r["res"]
+        else:
+            # The reference's per-site loop (:659-684): every site with counts goes through
+            # `_quantized_transitions_mle` (:43-84) = RateMatrixLearner with the "pande_reversible"
+            # parameterisation (rate.py:61-95: pi and the upper-triangular logits recovered from the
+            # initialisation Q0 * rate_l), no mask, learned pi, Adam lr 0.1, normalised loss, best iterate.
+            # Here: the same L optimisations as ONE batched device loop (cb_train_pande_reversible, L > 1).
+            from ..estimation._ratelearn._rate_matrix import solve_stationery_dist
+            p0 = solve_stationery_dist(Q0)        # scaling by rate_l leaves the stationary distribution alone
+            if np.any(np.abs(p0) < 1e-8):
+                raise ValueError("Stationary distribution of initialization is degenerate.")
+            root = np.sqrt(p0)
+            sym = (root[:, None] * Q0) / root[None, :]
+            iu = np.triu_indices(S, k=1)
+            with np.errstate(divide="ignore"):
+                up0 = np.log(np.expm1(sym[iu][None, :] * rates[idx, None]))   # softplus^-1, per site
+            lp0 = np.tile(np.log(p0), (len(idx), 1))
+            with CherryBank(times, sub) as bank:
+                r = bank.train_pande_reversible(up0, lp0, mask=None, num_epochs=int(optimization_num_epochs), lr=0.1,
+                                                do_adam=True, normalize=True)
+            res[idx] = r["Q_best"].reshape(len(idx), S, S) if int(optimization_num_epochs) > 0 else init[idx]
     prof["time_optimization"] = time.time() - st
     return {"res": res, **prof}

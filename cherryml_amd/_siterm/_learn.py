@@ -119,12 +119,11 @@ def learn_site_rate_matrices(
     just_run_fast_cherries: bool = False,
 ) -> Dict:
     """:1109-1282.  Returns {"learnt_rate_matrices": [L,S,S], "learnt_site_rates": [L], "learnt_tree": tree,
-    "time_*": seconds}.  Differences from the reference, all loud: the device must be "cuda", and only the
-    vectorised implementation with the fast site-rate estimator exists."""
+    "time_*": seconds}.  `use_vectorized_implementation=False` keeps the reference's per-site semantics
+    (pande_reversible parameterisation per site) but still runs all sites as one batched device loop; only the
+    fast site-rate estimator exists."""
     from .._device import resolve_device
     vectorized_implementation_device = resolve_device(vectorized_implementation_device, "learn_site_rate_matrices")
-    if not use_vectorized_implementation:
-        raise NotImplementedError("the per-site CPU loop of the reference is not built: use_vectorized_implementation=True")
     prof = {}
     st = time.time()
     if alphabet_for_site_rate_estimation is None:
@@ -174,7 +173,8 @@ def learn_site_rate_matrices(
         regularization_strength=regularization_strength, regularization_rate_matrix=Qreg,
         quantization_points=points, optimization_num_epochs=num_epochs, transitions_strategy="cherry++",
         include_reverse_transitions=True, rate_matrix_parameterization="pande_reversible",
-        use_vectorized_cherryml_implementation=True, vectorized_cherryml_implementation_device="cuda",
+        use_vectorized_cherryml_implementation=bool(use_vectorized_implementation),
+        vectorized_cherryml_implementation_device="cuda",
         vectorized_cherryml_implementation_num_cores=vectorized_implementation_num_cores)
     prof.update({k: v for k, v in r.items() if k.startswith("time_")})
     return {"learnt_rate_matrices": r["res"], "learnt_site_rates": site_rates, "learnt_tree": tree,

@@ -198,20 +198,23 @@ class CherryBank:
     # -- fused device-side optimisers (pande_reversible: any S; SiteRM: S <= 32) -----
     def train_pande_reversible(self, upper_diag, log_pi, mask=None, num_epochs=2000, lr=0.1,
                                do_adam=True, normalize=True):
-        """All epochs of the reference loop (trainer.py:156-218) in one kernel launch.
-        Returns dict(loss[E], Q_best, Q_last, Q_pow2 {epoch: Q}, upper_diag, log_pi)."""
-        S, E = self.S, int(num_epochs)
-        up = _as_f64(upper_diag, (S * (S - 1) // 2,)).copy()
-        lp = _as_f64(log_pi, (S,)).copy()
+        """All epochs of the reference loop (trainer.py:156-218) on the device.
+        L == 1: returns dict(loss[E], Q_best, Q_last, Q_pow2 {epoch: Q}, upper_diag, log_pi).
+        L > 1 (S <= 32): L independent problems in one batched launch sequence -- upper_diag [L, S(S-1)/2],
+        log_pi [L, S] -> loss [E, L], Q_best / Q_last [L, S, S] (no power-of-two snapshots)."""
+        S, E, L = self.S, int(num_epochs), self.L
+        nup = S * (S - 1) // 2
+        up = _as_f64(upper_diag, (nup,) if L == 1 else (L, nup)).copy()
+        lp = _as_f64(log_pi, (S,) if L == 1 else (L, S)).copy()
         mk = None if mask is None else _as_f64(mask, (S, S))
-        n_pow2 = max(E, 1).bit_length() if E > 0 else 0
-        loss = np.zeros(E)
-        Qb, Ql = np.zeros((S, S)), np.zeros((S, S))
+        n_pow2 = (max(E, 1).bit_length() if E > 0 else 0) if L == 1 else 0
+        loss = np.zeros(E) if L == 1 else np.zeros((E, L))
+        Qb, Ql = (np.zeros((S, S)), np.zeros((S, S))) if L == 1 else (np.zeros((L, S, S)), np.zeros((L, S, S)))
         Qp = np.zeros((max(n_pow2, 1), S, S))
         rc = _lib.load().cb_train_pande_reversible(
             self._h, up.ctypes.data, lp.ctypes.data, None if mk is None else mk.ctypes.data, E,
             float(lr), int(bool(do_adam)), CB_NORMALIZE if normalize else 0, loss.ctypes.data,
-            Qb.ctypes.data, Ql.ctypes.data, Qp.ctypes.data, n_pow2)
+            Qb.ctypes.data, Ql.ctypes.data, Qp.ctypes.data if n_pow2 else None, n_pow2)
         _lib.check(rc, "cb_train_pande_reversible")
         snaps = {1 << i: Qp[i] for i in range(n_pow2) if (1 << i) <= E}
         return dict(loss=loss, Q_best=Qb, Q_last=Ql, Q_pow2=snaps, upper_diag=up, log_pi=lp)

@@ -1353,7 +1353,11 @@ extern "C" int cb_train_pande_reversible(cb_handle h, double *upper_diag, double
                                          int flags, double *loss_curve, double *Q_best,
                                          double *Q_last, double *Q_pow2, int n_pow2) {
   if (!h || !upper_diag || !log_pi) return fail(CB_EINVAL, "cb_train_pande_reversible: NULL argument");
-  if (h->L != 1) return fail(CB_EUNSUPPORTED, "cb_train_pande_reversible: L == 1 banks only");
+  // L > 1: L independent problems with the reference's pande_reversible parameterisation each -- the
+  // per-site SiteRM loop (_site_specific_rate_matrix.py:43-84, 659-684) as one batched launch;
+  // upper_diag [L][S(S-1)/2], log_pi [L][S], loss_curve [E][L], Q_best / Q_last [L][S][S], one shared mask
+  if (h->L != 1 && (Q_pow2 || n_pow2 > 0))
+    return fail(CB_EUNSUPPORTED, "cb_train_pande_reversible: power-of-two snapshots exist for L == 1 only");
   if (mask)
     for (int i = 0; i < h->S; ++i)
       for (int j = 0; j < i; ++j)

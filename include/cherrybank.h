@@ -162,13 +162,15 @@ int cb_last_sweeps(cb_handle h);
  *   Adam / SGD step
  * entirely on the device (trainer.py:156-218 + torch.optim.Adam as configured
  * in ratelearner.py:123-130: betas (0.9, 0.999), eps 1e-8, no weight decay).
- * Only for S <= 32 and L == 1 banks (LG-sized problems are launch-latency
- * bound, so the whole epoch is one kernel).
- *   upper_diag[S(S-1)/2], log_pi[S]  in: initial parameters, out: final ones
- *   mask[S*S]                        0/1 (symmetric), NULL = all ones
- *   loss_curve[num_epochs]           loss of every epoch (pre-step)
- *   Q_best[S*S], Q_last[S*S]         as trainer.py:179-181,237-242
- *   Q_pow2[n_pow2*S*S]               Q at epochs 1,2,4,... (trainer.py:183-184); may be NULL
+ * S <= 32: one to three launches per epoch (LG-sized problems are launch-latency bound), any L;
+ * S > 32: L == 1, the epoch driven from C over the whole chip (train_large.hip.h).
+ * L > 1 = L independent problems, each with its own parameters (the reference's per-site SiteRM
+ * loop, _siterm/_site_specific_rate_matrix.py:43-84, 659-684, as ONE batched launch sequence):
+ *   upper_diag[L*S(S-1)/2], log_pi[L*S]  in: initial parameters, out: final ones
+ *   mask[S*S]                        0/1 (symmetric), NULL = all ones; shared by the L problems
+ *   loss_curve[num_epochs*L]         loss of every epoch (pre-step), [epoch][l]
+ *   Q_best[L*S*S], Q_last[L*S*S]     as trainer.py:179-181,237-242
+ *   Q_pow2[n_pow2*S*S]               Q at epochs 1,2,4,... (trainer.py:183-184); may be NULL; L == 1 only
  * All pointers are host pointers.
  */
 int cb_train_pande_reversible(cb_handle h, double *upper_diag, double *log_pi,

@@ -91,3 +91,33 @@ def test_all_gap_site_gets_the_prior_and_bad_arguments_raise():
             vectorized_cherryml_implementation_device="tpu")
     with pytest.raises(ValueError):   # unsorted grid is refused by the C ABI
         get_raw_count_matrices([("AD", "DA", 0.1)], [0.2, 0.1], ["A", "D"])
+
+
+@pytest.mark.parametrize("case", ["t2_eq_cherry", "t2_some_missing", "rand_cherry"])
+def test_per_site_dispatch_matches_reference(case):
+    """`use_vectorized_cherryml_implementation=False`: the reference's per-site loop
+    (_site_specific_rate_matrix.py:43-84, 659-684: RateMatrixLearner per site, "pande_reversible",
+    initialisation Q0 * rate_l) -- here one batched device loop (cb_train_pande_reversible with L > 1).
+    Golden: tests/golden/make_golden_siterm_persite.py (the reference per site, as is in float32 and
+    through its float64 recipe).  Stated tolerance 1e-6 to the float64 run."""
+    from cherryml_amd._siterm import estimate_site_specific_rate_matrices_given_tree_and_site_rates as est
+    z = load_golden("siterm_assembly.npz")
+    g = load_golden("siterm_persite.npz")
+    a = _inputs(z, case)
+    r = est(tree=a["tree"], site_rates=list(a["rates"]), msa=a["msa"], alphabet=a["alphabet"],
+            regularization_strength=a["lam"], regularization_rate_matrix=a["Q0"], quantization_points=a["grid"],
+            optimization_num_epochs=a["epochs"], transitions_strategy=a["strategy"],
+            include_reverse_transitions=a["reverse"], use_vectorized_cherryml_implementation=False)
+    want64, want32 = g[case + "_res_f64"], g[case + "_res_f32"]
+    assert r["res"].shape == want64.shape
+    e64 = [relerr(r["res"][l], want64[l]) for l in range(len(want64))]
+    e32 = [relerr(r["res"][l], want32[l]) for l in range(len(want64))]
+    print(f"{case}: per-site path, max rel. Frobenius to the f64 reference {max(e64):.2e}, to its float32 run {max(e32):.2e}")
+    assert max(e64) < 1e-6
+    assert max(e32) < 5e-3      # (the float32 run itself sits up to 1.3e-3 from the float64 one at the extreme site rates)
+    # and it is a different estimator from the vectorised one (other parameterisation, same optimum family)
+    rv = est(tree=a["tree"], site_rates=list(a["rates"]), msa=a["msa"], alphabet=a["alphabet"],
+             regularization_strength=a["lam"], regularization_rate_matrix=a["Q0"], quantization_points=a["grid"],
+             optimization_num_epochs=a["epochs"], transitions_strategy=a["strategy"],
+             include_reverse_transitions=a["reverse"], use_vectorized_cherryml_implementation=True)
+    assert rv["res"].shape == r["res"].shape
