@@ -12,6 +12,9 @@ with the bank resident in HBM.  metric = cherry-pairs/s = sum(C) / t_epoch
 Workloads (BASELINE.json configs):
   coevo400  co-evolution 400x400, B = 129 dense bank, sum C = 1,057,194 (the size of
             the reference's demo_data co-evolution bank)   [default]
+  coevo400_demo  the reference's REAL demo_data co-evolution bank (all 32 families, counted by the
+            reference: 43 of 129 buckets non-empty, 3.5 % dense); roofline denominators use the
+            non-empty buckets
   lg20      LG 20x20, 1000 families x 200 sites x 64 cherries: sum C = 1.28e7
   siterm    SiteRM per-site 20x20, L sites (--sites, default 5000), B = 129
   counting  the stage that PRODUCES the LG bank: 1000 families x 64 cherries
@@ -131,6 +134,18 @@ def make_workload(name, sites, rng):
         return dict(kind="single", t=t, C=C, mask=mask, S=400, n_pairs=n_pairs,
                     desc="co-evolution 400x400, B=129 dense synthetic bank, sum C = 1,057,194 "
                          "(= reference demo_data co-evolution bank)")
+    if name == "coevo400_demo":
+        # BASELINE.json config 3 as it really is: the co-evolution bank of ALL 32 demo_data families,
+        # counted by the reference itself (tests/golden/coevo_demo_full.npz, made by
+        # tests/golden/make_golden_s400_full.py; stored sparse): 43 of 129 buckets non-empty, 3.5 % dense
+        z = np.load(os.path.join(ROOT, "tests", "golden", "coevo_demo_full.npz"))
+        C = np.zeros(tuple(z["C_shape"]))
+        C[z["C_b"].astype(np.int64), z["C_i"].astype(np.int64), z["C_j"].astype(np.int64)] = z["C_quarters"] * 0.25
+        mask = np.unpackbits(z["mask_packed"])[:160000].reshape(400, 400).astype(np.float64)
+        live = int(np.count_nonzero(C.reshape(C.shape[0], -1).any(axis=1)))
+        return dict(kind="single", t=z["t"], C=C, mask=mask, S=400, n_pairs=float(C.sum()), live=live,
+                    desc=f"co-evolution 400x400, the reference's demo_data bank (32 families): B=129 of which {live} non-empty, "
+                         f"{100.0 * np.count_nonzero(C) / C.size:.1f} % dense, sum C = {int(C.sum()):,}")
     if name == "lg20":
         Q = lg_matrix()
         n_pairs = 1000 * 200 * 64.0
@@ -171,6 +186,8 @@ def cpu_baseline(wl, name):
     if wl["kind"] == "single":
         B = wl["C"].shape[0]
         nb = {400: 32, 20: 129}[wl["S"]]   # ~10-20 s of host work either way
+        if "live" in wl:   # (the reference exponentiates all 129 buckets, empty or not: trainer.py:170)
+            nb = min(nb, B)
         sel = np.linspace(0, B - 1, nb).round().astype(int)
         t, C = wl["t"][sel], wl["C"][sel]
         init = jtt_ipw_from_arrays(wl["t"], wl["C"], wl["mask"])
@@ -201,7 +218,7 @@ def main():
     ap.add_argument("--steps", type=int, default=None)
     ap.add_argument("--warmup", type=int, default=None)
     ap.add_argument("--workload", default="coevo400",
-                    choices=["coevo400", "lg20", "siterm", "counting", "ble", "assembly", "likelihood"])
+                    choices=["coevo400", "coevo400_demo", "lg20", "siterm", "counting", "ble", "assembly", "likelihood"])
     ap.add_argument("--sites", type=int, default=5000)
     ap.add_argument("--dtype", default="f64", choices=["f64", "f32", "mixed"],
                     help="element type of the bank products (coevo400 only): f32 = float32 MFMA (cb_create dtype CB_F32)")
@@ -324,7 +341,7 @@ def main():
             #      SiteRM: every rank owns its own `--sites` sites (no collective).
             bank = cherryml_amd.CherryBank(wl["t"], wl["C"], device=local_rank, dtype=bank_dtype)
             n_pairs_total, scaling = wl["n_pairs"] * world, "weak"
-            B_local = wl["C"].shape[-3]
+            B_local = wl.get("live", wl["C"].shape[-3])   # empty buckets cost nothing (B_ne in the formulas)
             glue = ("whole loop on the device, driven from C (theta->A, eigh, bank, grads, Adam in HIP)" if S > 32
                     else "whole loop fused in one HIP kernel (theta->Q, eigh, bank, grads, Adam)")
             if wl["kind"] == "single":
@@ -377,7 +394,7 @@ def main():
             tri = (tn_ * (tn_ + 1) / 2) / float(tn_ * tn_)   # share of 80x80 tiles actually multiplied
             # whole epoch: SURVEY 8d's algorithmic flops of one epoch (6 B S^3 bank + ~13 S^3 eigensolver
             # and back-rotation; 49.6 GFLOP at S = 400, B = 129) over the WALL time of one step
-            epoch_flops = 6.0 * wl["C"].shape[0] * S ** 3 + 13.0 * S ** 3
+            epoch_flops = 6.0 * wl.get("live", wl["C"].shape[0]) * S ** 3 + 13.0 * S ** 3
             epoch_tflops = epoch_flops / (dt / steps) / 1e12
             # (mixed: the dominant kernel is then K1 in float64; K2 / K3 run on the f32 MFMA)
             dom_f32 = bank_dtype == "f32" or (bank_dtype == "mixed" and dom != "k1")
@@ -409,7 +426,8 @@ def main():
             "steps": steps, "warmup": warmup, "ms_per_step": dt / steps * 1e3,
             "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": bank_dtype,
             "data": "synthetic",
-            "config": {"workload": wl["desc"], "states": S, "buckets": 129, "sharding": sharding,
+            "config": {"workload": wl["desc"], "states": S, "buckets": 129,
+                       **({"non_empty_buckets": wl["live"]} if "live" in wl else {}), "sharding": sharding,
                        "epoch": glue,
                        **({"arithmetic": "float32 operands + float32 MFMA accumulation in P_b, G_b U, (T_b^T U) o Phi_b; "
                                          "eigensolver, loss sums, divided differences, bucket sum, Adam in float64"}
@@ -438,7 +456,7 @@ def main():
             sys.stdout.write(json.dumps(out) + "\n")
             sys.stdout.flush()
 
-    defaults = {"coevo400": (200, 5), "lg20": (500, 50), "siterm": (20, 2), "counting": (20, 3), "ble": (5, 1), "assembly": (5, 1),
+    defaults = {"coevo400": (200, 5), "coevo400_demo": (200, 5), "lg20": (500, 50), "siterm": (20, 2), "counting": (20, 3), "ble": (5, 1), "assembly": (5, 1),
                 "likelihood": (5, 1)}
     steps = args.steps if args.steps is not None else defaults[args.workload][0]
     warmup = args.warmup if args.warmup is not None else defaults[args.workload][1]

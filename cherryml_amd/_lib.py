@@ -49,6 +49,8 @@ SIGNATURES = {
     "cb_ble_site_rates": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, C.c_int, C.c_int, _vp, _vp, _vp]),
     "cb_ble": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, C.c_int, C.c_int, _vp, C.c_int, _vp, _vp,
                          C.c_int, _vp, _vp, _vp, _vp]),
+    "cb_ble_batch": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, _vp, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
+                               C.c_int, _vp, _vp, _vp, _vp]),
     "cb_site_rate_gather": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp]),
     "cb_tree_likelihood": (C.c_int, [C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, C.c_int, _vp, _vp, _vp, C.c_int, _vp,
                                      C.c_int, _vp, _vp, _vp, _vp, _vp]),

@@ -6,14 +6,17 @@
 #pragma once
 
 // --------------------------------------------------------------- large path
-static void launch_sg(cb_bank *h, const K4Args &g, int ns, double alpha = 0.0, double beta = 0.0) {
+// `second`: an independent product of the same kind (ns, alpha, beta) enqueued in the same launch (grid.y = 2)
+static void launch_sg(cb_bank *h, const K4Args &g, int ns, double alpha = 0.0, double beta = 0.0,
+                      const K4Args *second = nullptr) {
   static const int variant = getenv("CB_SG_VARIANT") ? atoi(getenv("CB_SG_VARIANT")) : 1;
   // (both neighbours of this shape were measured slower: narrower strips -- NJ = 1 or 2, 2.5-5x the workgroups, more
   // L2 -> CU panel traffic -- eigh 0.60 -> 0.62-1.01 ms; two row tiles per workgroup -- half the workgroups -- 0.74-0.77 ms)
-  const unsigned nwg = (unsigned)((h->LD / 16) * ((h->LD + 79) / 80));
-  if (variant == 0) hipLaunchKernelGGL((sg_gemm<4, 4>), dim3(nwg), dim3(256), 0, h->stream, g, ns, alpha, beta);
-  else if (variant == 1) hipLaunchKernelGGL((sg_gemm<8, 4>), dim3(nwg), dim3(512), 0, h->stream, g, ns, alpha, beta);
-  else hipLaunchKernelGGL((sg_gemm<8, 7>), dim3(nwg), dim3(512), 0, h->stream, g, ns, alpha, beta);
+  const dim3 nwg((unsigned)((h->LD / 16) * ((h->LD + 79) / 80)), second ? 2 : 1);
+  const K4Args &g2 = second ? *second : g;
+  if (variant == 0) hipLaunchKernelGGL((sg_gemm<4, 4>), nwg, dim3(256), 0, h->stream, g, g2, ns, alpha, beta);
+  else if (variant == 1) hipLaunchKernelGGL((sg_gemm<8, 4>), nwg, dim3(512), 0, h->stream, g, g2, ns, alpha, beta);
+  else hipLaunchKernelGGL((sg_gemm<8, 7>), nwg, dim3(512), 0, h->stream, g, g2, ns, alpha, beta);
 }
 
 static int large_eigh(cb_bank *h, bool warm) {
@@ -122,9 +125,10 @@ static int large_eigh(cb_bank *h, bool warm) {
       const unsigned long long *sel = h->off_bits + 3;
       launch_sg(h, K4Args{h->S, LD, X, X, P2, nullptr, nullptr, nullptr, nullptr, nullptr, sel, Xf, Xf}, 0);   // X^T X   = -X^2
       have_p2 = true;
-      if (spec_deep) {
-        launch_sg(h, K4Args{h->S, LD, X, P2, P3, nullptr, nullptr, nullptr, nullptr, nullptr, sel, Xf, nullptr}, 0);  // X^T P2 = X^3
-        launch_sg(h, K4Args{h->S, LD, P2, P2, P4, nullptr, nullptr, nullptr}, 0);                                      // P2^T P2 = X^4
+      if (spec_deep) {   // X^T P2 = X^3 and P2^T P2 = X^4: independent of each other, one launch
+        const K4Args p3{h->S, LD, X, P2, P3, nullptr, nullptr, nullptr, nullptr, nullptr, sel, Xf, nullptr};
+        const K4Args p4{h->S, LD, P2, P2, P4, nullptr, nullptr, nullptr};
+        launch_sg(h, p3, 0, 0.0, 0.0, &p4);
         have_p34 = true;
       }
     }
@@ -195,9 +199,10 @@ static int large_eigh(cb_bank *h, bool warm) {
       hipLaunchKernelGGL(lgx_combine, dim3(nel), dim3(256), 0, h->stream, LD, Xu, P2, (const double *)nullptr,
                          (const double *)nullptr, R);                                              // R = I + X + X^2 / 2
     } else {
-      if (!have_p34) {
-        launch_sg(h, K4Args{h->S, LD, Xu, P2, P3, nullptr, nullptr, nullptr}, 0);   // X^T P2  =  X^3
-        launch_sg(h, K4Args{h->S, LD, P2, P2, P4, nullptr, nullptr, nullptr}, 0);   // P2^T P2 =  X^4
+      if (!have_p34) {   // X^T P2 = X^3 and P2^T P2 = X^4 in one launch
+        const K4Args p3{h->S, LD, Xu, P2, P3, nullptr, nullptr, nullptr};
+        const K4Args p4{h->S, LD, P2, P2, P4, nullptr, nullptr, nullptr};
+        launch_sg(h, p3, 0, 0.0, 0.0, &p4);
       }
       if (rowsum <= 2e-3) {
         hipLaunchKernelGGL(lgx_combine, dim3(nel), dim3(256), 0, h->stream, LD, Xu, P2, P3, P4, R);

@@ -492,9 +492,13 @@ struct K4Args {
 //                                                                 first-order sweeps, jacobi_block.hip.h)
 // NJ = 16-column tiles per workgroup (strip 16 x 16 NJ): fewer -> more workgroups and shorter waves
 // (these single 400^3 products are latency bound, not MFMA bound).
+// gridDim.y == 2: two independent products in one launch (blockIdx.y == 1 takes `a2`): these launches
+// are latency bound (2.6 us of launch floor + ~7 us of load -> MFMA -> reduce chain on half the CUs), so
+// a pair costs what one does -- X^3 and X^4 of the first-order sweeps.
 template <int NW, int UU, int NJ = 5>
-__global__ __launch_bounds__(NW * 64) void sg_gemm(K4Args a, int ns, double alpha, double beta) {
-  __shared__ double sRed[4][NJ][256];
+__global__ __launch_bounds__(NW * 64) void sg_gemm(K4Args a1, K4Args a2, int ns, double alpha, double beta) {
+  __shared__ double sRed[NW / 2 > 4 ? NW / 2 : 4][NJ][256];
+  const K4Args &a = blockIdx.y ? a2 : a1;
   const int LD = a.LD, tilesN = (LD + 16 * NJ - 1) / (16 * NJ);
   const int tm = blockIdx.x / tilesN, tn = blockIdx.x - tm * tilesN;
   const int m0 = tm * 16, n0 = tn * 16 * NJ;

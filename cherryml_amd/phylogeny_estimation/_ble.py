@@ -107,3 +107,49 @@ def estimate_branch_lengths_and_site_rates(cx, cy, all_sequences, log_transition
     if profile is not None:
         profile["iterations"], profile["kernel_ms"] = iters.value, ms.value
     return grid[li], rates[ri]
+
+
+def estimate_branch_lengths_and_site_rates_batch(families, log_transition_matrices, quantization_points: Sequence[float],
+                                                 rate_categories: Sequence[float],
+                                                 weights_for_initial_site_rates: Sequence[float], max_iters: int,
+                                                 device: int = 0, profile: Optional[dict] = None):
+    """`ble` (:146-241) for MANY families in one call (`cb_ble_batch`): `families` = [(cx, cy, all_sequences), ...]
+    with per-family shapes [n_f, L_f], [n_f, L_f], [n_seqs_f, L_f]; the bank `log_transition_matrices` is shared
+    (one rate matrix for the whole stage, as in the reference's `fast_cherries`) and uploaded once.  Returns
+    [(cherry lengths [n_f], site rates [L_f]), ...], family by family what
+    `estimate_branch_lengths_and_site_rates` returns."""
+    import ctypes
+    if not families:
+        return []
+    logP = _f64(log_transition_matrices)
+    if logP.ndim != 4 or logP.shape[2] != logP.shape[3]:
+        raise ValueError("log_transition_matrices must be [T,R,S,S]")
+    T, R, S, _ = logP.shape
+    grid, rates, w = _f64(quantization_points), _f64(rate_categories), _f64(weights_for_initial_site_rates)
+    if grid.size != T or rates.size != R or w.size != R:
+        raise ValueError("inconsistent shapes")
+    xs, ys, ss, ns, Ls, nseq = [], [], [], [], [], []
+    for cx, cy, seqs in families:
+        cx, cy, seqs = _i8(cx), _i8(cy), _i8(seqs)
+        if cx.ndim != 2 or cx.shape != cy.shape or seqs.ndim != 2 or seqs.shape[1] != cx.shape[1]:
+            raise ValueError("every family needs cx, cy [n, L] and all_sequences [n_seqs, L]")
+        xs.append(cx.reshape(-1)); ys.append(cy.reshape(-1)); ss.append(seqs.reshape(-1))
+        ns.append(cx.shape[0]); Ls.append(cx.shape[1]); nseq.append(seqs.shape[0])
+    X, Y, A = (np.ascontiguousarray(np.concatenate(v)) for v in (xs, ys, ss))
+    n_arr, L_arr, q_arr = (np.ascontiguousarray(v, dtype=np.int32) for v in (ns, Ls, nseq))
+    li, ri = np.zeros(int(n_arr.sum()), dtype=np.int32), np.zeros(int(L_arr.sum()), dtype=np.int32)
+    it = np.zeros(len(families), dtype=np.int32)
+    ms = ctypes.c_double(0.0)
+    rc = _lib.load().cb_ble_batch(device, S, T, R, logP.ctypes.data, len(families), n_arr.ctypes.data, L_arr.ctypes.data,
+                                  X.ctypes.data, Y.ctypes.data, A.ctypes.data, q_arr.ctypes.data, rates.ctypes.data,
+                                  w.ctypes.data, int(max_iters), li.ctypes.data, ri.ctypes.data, it.ctypes.data,
+                                  ctypes.addressof(ms) if profile is not None else None)
+    _lib.check(rc, "cb_ble_batch")
+    if profile is not None:
+        profile["iterations"], profile["kernel_ms"] = it.tolist(), ms.value
+    out, on, oL = [], 0, 0
+    for n, L in zip(ns, Ls):
+        out.append((grid[li[on:on + n]], rates[ri[oL:oL + L]]))
+        on += n
+        oL += L
+    return out

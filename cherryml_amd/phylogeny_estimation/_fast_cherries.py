@@ -254,7 +254,33 @@ def _through_text(values) -> np.ndarray:
     return np.array([float("%.17f" % v) for v in np.asarray(values, dtype=np.float64)], dtype=np.float64)
 
 
-# ----------------------------------------------------------------------------- one family, in memory
+# ----------------------------------------------------------------------------- families, in memory
+def _encode_and_pair(sequences: Sequence[str], alphabet: Sequence[str], seed: int, rng_scheme: str):
+    code = np.full(256, -1, dtype=np.int8)
+    for i, s in enumerate(alphabet):
+        if len(s) != 1 or ord(s) >= 256:
+            raise ValueError("FastCherries reads one byte per state (io_helpers.cpp:12-16)")
+        code[ord(s)] = i
+    if len(set(len(s) for s in sequences)) > 1:
+        raise ValueError("sequences of one MSA must have equal length")
+    seqs = np.stack([code[np.frombuffer(s.encode("latin-1"), dtype=np.uint8)] for s in sequences])
+    pairs = divide_and_pair(seqs, seed=seed, rng_scheme=rng_scheme)
+    if not pairs:
+        raise ValueError("FastCherries needs at least two sequences")
+    return seqs, pairs
+
+
+def _normalise(lengths, site_rates):
+    """fast_cherries.cpp:262-304: lengths multiplied and rates divided by the mean rate, both through the
+    reference's 17-decimal text files."""
+    mean_rate = 0.0
+    for r in site_rates:                    # the reference's left-to-right sum
+        mean_rate += float(r)
+    mean_rate /= len(site_rates)
+    return (_through_text(np.array([float(x) * mean_rate for x in lengths])),
+            _through_text(np.array([float(r) / mean_rate for r in site_rates])))
+
+
 def fast_cherries_family(names: Sequence[str], sequences: Sequence[str], rate_matrix: np.ndarray,
                          alphabet: Sequence[str], num_rate_categories: int = 20, max_iters: int = 50,
                          seed: int = 1234, quantization_grid_center: float = 0.03,
@@ -264,39 +290,54 @@ def fast_cherries_family(names: Sequence[str], sequences: Sequence[str], rate_ma
     length of each cherry --, site_rates [L]), lengths multiplied and rates divided by the mean rate and
     both rounded through the reference's text files (fast_cherries.cpp:262-304)."""
     Q = np.ascontiguousarray(rate_matrix, dtype=np.float64)
-    S = Q.shape[0]
-    code = np.full(256, -1, dtype=np.int8)
-    for i, s in enumerate(alphabet):
-        if len(s) != 1 or ord(s) >= 256:
-            raise ValueError("FastCherries reads one byte per state (io_helpers.cpp:12-16)")
-        code[ord(s)] = i
-    if len(set(len(s) for s in sequences)) > 1:
-        raise ValueError("sequences of one MSA must have equal length")
-    seqs = np.stack([code[np.frombuffer(s.encode("latin-1"), dtype=np.uint8)] for s in sequences])
     st = time.time()
-    pairs = divide_and_pair(seqs, seed=seed, rng_scheme=rng_scheme)
+    seqs, pairs = _encode_and_pair(sequences, alphabet, seed, rng_scheme)
     t_pair = time.time() - st
     grid = quantization_points_ble(quantization_grid_center, quantization_grid_step, quantization_grid_num_steps)
     rates = rate_categories_ble(num_rate_categories)
     weights = get_weights_for_initial_site_rates(rates)
     st = time.time()
     logP = compute_log_transition_matrices(Q, grid, rates, device=device)
-    if pairs:
-        cx = seqs[[a for a, _ in pairs]]
-        cy = seqs[[b for _, b in pairs]]
-        lengths, site_rates = estimate_branch_lengths_and_site_rates(
-            cx, cy, seqs, logP, grid, rates, weights, max_iters, device=device, profile=profile)
-    else:
-        raise ValueError("FastCherries needs at least two sequences")
-    mean_rate = 0.0
-    for r in site_rates:                    # the reference's left-to-right sum
-        mean_rate += float(r)
-    mean_rate /= len(site_rates)
-    lengths = _through_text(np.array([float(x) * mean_rate for x in lengths]))
-    site_rates = _through_text(np.array([float(r) / mean_rate for r in site_rates]))
+    cx = seqs[[a for a, _ in pairs]]
+    cy = seqs[[b for _, b in pairs]]
+    lengths, site_rates = estimate_branch_lengths_and_site_rates(
+        cx, cy, seqs, logP, grid, rates, weights, max_iters, device=device, profile=profile)
+    lengths, site_rates = _normalise(lengths, site_rates)
     if profile is not None:
         profile["pairing_time"], profile["ble_time"] = t_pair, time.time() - st
     return [(names[a], names[b]) for a, b in pairs], lengths, site_rates
+
+
+def fast_cherries_families(msas: Sequence[Tuple[Sequence[str], Sequence[str]]], rate_matrix: np.ndarray,
+                           alphabet: Sequence[str], num_rate_categories: int = 20, max_iters: int = 50,
+                           seed: int = 1234, quantization_grid_center: float = 0.03,
+                           quantization_grid_step: float = 1.1, quantization_grid_num_steps: int = 64,
+                           device: int = 0, rng_scheme: str = "lemire", profile: Optional[dict] = None):
+    """MANY MSAs through FastCherries in one device call (the reference maps families over a process pool,
+    _fast_cherries.py:185-281 / utils.py:59-67): `msas` = [(names, sequences), ...].  The pairing of every
+    family runs on the host first, the log-transition bank is computed ONCE (one rate matrix for all
+    families) and `cb_ble_batch` runs all coordinate ascents in lockstep.  Returns, family by family, exactly
+    what `fast_cherries_family` returns."""
+    Q = np.ascontiguousarray(rate_matrix, dtype=np.float64)
+    st = time.time()
+    enc = [_encode_and_pair(sequences, alphabet, seed, rng_scheme) for _, sequences in msas]
+    t_pair = time.time() - st
+    grid = quantization_points_ble(quantization_grid_center, quantization_grid_step, quantization_grid_num_steps)
+    rates = rate_categories_ble(num_rate_categories)
+    weights = get_weights_for_initial_site_rates(rates)
+    st = time.time()
+    logP = compute_log_transition_matrices(Q, grid, rates, device=device)
+    fams = [(seqs[[a for a, _ in pairs]], seqs[[b for _, b in pairs]], seqs) for seqs, pairs in enc]
+    from ._ble import estimate_branch_lengths_and_site_rates_batch
+    res = estimate_branch_lengths_and_site_rates_batch(fams, logP, grid, rates, weights, max_iters, device=device,
+                                                       profile=profile)
+    out = []
+    for (names, _), (_, pairs), (lengths, site_rates) in zip(msas, enc, res):
+        lengths, site_rates = _normalise(lengths, site_rates)
+        out.append(([(names[a], names[b]) for a, b in pairs], lengths, site_rates))
+    if profile is not None:
+        profile["pairing_time"], profile["ble_time"] = t_pair, time.time() - st
+    return out
 
 
 def cherries_to_tree(names: Sequence[str], cherries: Sequence[Tuple[str, str]], lengths: Sequence[float]) -> Tree:
@@ -352,7 +393,7 @@ def fast_cherries(msa_dir: str, families: List[str], rate_matrix_path: str, num_
     """The reference's stage function (same keywords, same files): per family `<tree_dir>/<family>.txt`
     (CherryML tree format), `<site_rates_dir>/<family>.txt`, `<likelihood_dir>/<family>.txt` ("0.0", as
     the reference) and `<tree_dir>/<family>.profiling`.  `num_processes` / `remake` are accepted and
-    ignored: families run one after the other on the GPU.  Keyword arguments only, and with a cache
+    ignored: the reference's pool over families is ONE batched device call here (`cb_ble_batch`).  Keyword arguments only, and with a cache
     directory set the three output directories default into the cache and the call returns
     {"output_tree_dir": ..., ...} -- the reference's caching convention, which is how the end-to-end
     pipelines use it as their `tree_estimator`."""
@@ -366,19 +407,20 @@ def fast_cherries(msa_dir: str, families: List[str], rate_matrix_path: str, num_
     Q = rm.to_numpy()
     import torch
     dev = torch.cuda.current_device()
-    for family in families:
-        st = time.time()
-        names, seqs = _read_msa_file(os.path.join(msa_dir, family + ".txt"))
-        prof: Dict[str, float] = {}
-        cherries, lengths, site_rates = fast_cherries_family(
-            names, seqs, Q, alphabet, num_rate_categories=num_rate_categories, max_iters=max_iters, seed=seed,
-            quantization_grid_center=quantization_grid_center, quantization_grid_step=quantization_grid_step,
-            quantization_grid_num_steps=quantization_grid_num_steps, device=dev, profile=prof)
+    st = time.time()
+    msas = [_read_msa_file(os.path.join(msa_dir, family + ".txt")) for family in families]
+    prof: Dict[str, float] = {}
+    results = fast_cherries_families(
+        msas, Q, alphabet, num_rate_categories=num_rate_categories, max_iters=max_iters, seed=seed,
+        quantization_grid_center=quantization_grid_center, quantization_grid_step=quantization_grid_step,
+        quantization_grid_num_steps=quantization_grid_num_steps, device=dev, profile=prof)
+    per_family = (time.time() - st) / max(len(families), 1)
+    for family, (names, _), (cherries, lengths, site_rates) in zip(families, msas, results):
         write_tree(cherries_to_tree(names, cherries, lengths), os.path.join(output_tree_dir, family + ".txt"))
         with open(os.path.join(output_site_rates_dir, family + ".txt"), "w") as f:
             f.write(f"{len(site_rates)} sites\n" + " ".join(repr(float(r)) for r in site_rates))
         with open(os.path.join(output_likelihood_dir, family + ".txt"), "w") as f:
             f.write(str(0.0))
-        with open(os.path.join(output_tree_dir, family + ".profiling"), "w") as f:
-            f.write(f"pairing_time: {prof.get('pairing_time', 0.0)}\nble_time: {prof.get('ble_time', 0.0)}\n"
-                    f"total_time: {time.time() - st}")
+        with open(os.path.join(output_tree_dir, family + ".profiling"), "w") as f:   # (all families run as ONE batch: shares)
+            f.write(f"pairing_time: {prof.get('pairing_time', 0.0) / max(len(families), 1)}\n"
+                    f"ble_time: {prof.get('ble_time', 0.0) / max(len(families), 1)}\ntotal_time: {per_family}")

@@ -298,6 +298,17 @@ int cb_ble(int device, int S, int T, int R, const double *logP, const int8_t *cx
            int max_iters, int *lengths_index, int *rate_index, int *iterations, double *kernel_ms);
 /* iterations (may be NULL): coordinate-ascent iterations run; kernel_ms (may be NULL): GPU time of
  * the ascent (first branch-length pass + all iterations), inputs already resident, by HIP events. */
+/* cb_ble for MANY families in one call -- the reference maps families over a process pool
+ * (cherryml/utils.py:59-67, phylogeny_estimation/_fast_cherries.py:185-281); here the bank is uploaded
+ * once, the sequences in one transfer, and the ascents advance in lockstep with ONE read-back of all
+ * convergence flags per round.  Family f has n[f] cherries and n_seqs[f] sequences of L[f] sites; cx, cy
+ * ([n[f]][L[f]]) and all_seqs ([n_seqs[f]][L[f]]) are the families' arrays concatenated in order, and so
+ * are the outputs lengths_index (sum n) and rate_index (sum L); iterations[n_fam] may be NULL.
+ * Results equal cb_ble's family by family. */
+int cb_ble_batch(int device, int S, int T, int R, const double *logP, int n_fam, const int *n,
+                 const int *L, const int8_t *cx, const int8_t *cy, const int8_t *all_seqs,
+                 const int *n_seqs, const double *rates, const double *weights, int max_iters,
+                 int *lengths_index, int *rate_index, int *iterations, double *kernel_ms);
 int cb_site_rate_gather(int device, int S, int R, int n, int L, const double *tens, const int8_t *cx,
                         const int8_t *cy, const double *log_prior, int *best);
 

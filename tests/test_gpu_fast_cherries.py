@@ -96,3 +96,57 @@ def test_public_api_just_run_fast_cherries():
     assert r["learnt_site_rates"] is not None and len(r["learnt_site_rates"]) == 4
     assert r["learnt_tree"] is not None and sorted(r["learnt_tree"].leaves()) == ["leaf_1", "leaf_2", "leaf_3", "leaf_4"]
     assert r["learnt_rate_matrices"] is None
+
+
+def test_many_families_in_one_call_equal_the_per_family_calls(tmp_path):
+    """`cb_ble_batch` / `fast_cherries_families` (the reference's pool over families as ONE device call: shared
+    bank uploaded once, lockstep coordinate ascents, one flag read-back per round): family by family bit-identical
+    to `fast_cherries_family` -- ragged sizes, a family of two identical sequences (converges at once), the three
+    golden families of the reference's own program -- and the stage writes one file set per family."""
+    from cherryml_amd.io import write_rate_matrix
+    from cherryml_amd.phylogeny_estimation import fast_cherries, fast_cherries_families, fast_cherries_family
+    g = load_golden("fast_cherries.npz")
+    alphabet = [str(a) for a in g["alphabet"]]
+    rng = np.random.default_rng(17)
+    msas = [([str(n) for n in g[f"fam{k}_names"]], [str(s) for s in g[f"fam{k}_seqs"]]) for k in range(3)]
+    for n, L in ((2, 9), (7, 33), (40, 120), (13, 5)):
+        base = rng.integers(0, len(alphabet), size=L)
+        seqs = []
+        for _ in range(n):
+            s = base.copy()
+            flip = rng.random(L) < 0.25
+            s[flip] = rng.integers(0, len(alphabet), size=int(flip.sum()))
+            txt = [alphabet[c] for c in s]
+            for j in np.flatnonzero(rng.random(L) < 0.05):
+                txt[j] = "-"
+            seqs.append("".join(txt))
+        msas.append(([f"s{n}_{i}" for i in range(n)], seqs))
+    msas.append((["a", "b"], ["".join(alphabet[:8]), "".join(alphabet[:8])]))
+    kw = dict(num_rate_categories=20, max_iters=50, seed=1234)
+    prof = {}
+    batch = fast_cherries_families(msas, g["Q"], alphabet, profile=prof, **kw)
+    assert len(batch) == len(msas) and len(prof["iterations"]) == len(msas) and prof["kernel_ms"] > 0
+    for (names, seqs), (ch, le, ra) in zip(msas, batch):
+        one_prof = {}
+        ch1, le1, ra1 = fast_cherries_family(names, seqs, g["Q"], alphabet, profile=one_prof, **kw)
+        assert ch == ch1 and np.array_equal(le, le1) and np.array_equal(ra, ra1)
+    # the golden family whose settings these are reproduces the reference program through the batch too
+    for k in range(3):
+        if int(g[f"fam{k}_rcat"]) == 20 and int(g[f"fam{k}_seed"]) == 1234 and int(g[f"fam{k}_iters"]) == 50:
+            assert np.array_equal(batch[k][1], g[f"fam{k}_lengths"]) and np.array_equal(batch[k][2], g[f"fam{k}_site_rates"])
+    # the stage function: all families through one batch, one file set each
+    msa_dir = tmp_path / "msas"
+    msa_dir.mkdir()
+    fams = [f"fam{i}" for i in range(len(msas))]
+    for fam, (names, seqs) in zip(fams, msas):
+        with open(msa_dir / f"{fam}.txt", "w") as f:
+            f.write("".join(f">{n}\n{s}\n" for n, s in zip(names, seqs)))
+    qpath = str(tmp_path / "Q.txt")
+    write_rate_matrix(g["Q"], alphabet, qpath)
+    out = {d: str(tmp_path / d) for d in ("trees", "rates", "lls")}
+    fast_cherries(msa_dir=str(msa_dir), families=fams, rate_matrix_path=qpath, num_processes=4, output_tree_dir=out["trees"],
+                  output_site_rates_dir=out["rates"], output_likelihood_dir=out["lls"], verbose=False, **kw)
+    for fam, (_, _, ra) in zip(fams, batch):
+        lines = open(os.path.join(out["rates"], fam + ".txt")).read().split("\n")
+        assert np.array_equal(np.array([float(x) for x in lines[1].split()]), ra)
+        assert os.path.exists(os.path.join(out["trees"], fam + ".txt"))
