@@ -9,11 +9,31 @@
 // `second`: an independent product of the same kind (ns, alpha, beta) enqueued in the same launch (grid.y = 2)
 static void launch_sg(cb_bank *h, const K4Args &g, int ns, double alpha = 0.0, double beta = 0.0,
                       const K4Args *second = nullptr) {
-  static const int variant = getenv("CB_SG_VARIANT") ? atoi(getenv("CB_SG_VARIANT")) : 1;
-  // (both neighbours of this shape were measured slower: narrower strips -- NJ = 1 or 2, 2.5-5x the workgroups, more
-  // L2 -> CU panel traffic -- eigh 0.60 -> 0.62-1.01 ms; two row tiles per workgroup -- half the workgroups -- 0.74-0.77 ms)
+  // Shapes measured in situ (200 epochs of the bench bank, eigh ms per epoch): 16 x 80 strips, 8 waves x 4 k-steps in
+  // flight (variant 1) 0.343; 16 x 48 strips (3) 0.320; 16 x 32, 7 in flight (7) 0.332; ONE 16 x 16 tile per workgroup,
+  // K split over its 8 waves, 7 k-steps in flight (4, the default) 0.300; the same with 16 waves (5) 0.324, with 4 (6)
+  // 0.310.  These launches are latency chains (launch floor 2.6 us + load -> MFMA -> LDS reduce), not bandwidth: the
+  // 16 x 16 shape reads 64 MB from L2 per product against 38 MB for the strips and is still the fastest.
+  static const int variant = getenv("CB_SG_VARIANT") ? atoi(getenv("CB_SG_VARIANT")) : 4;
   const dim3 nwg((unsigned)((h->LD / 16) * ((h->LD + 79) / 80)), second ? 2 : 1);
   const K4Args &g2 = second ? *second : g;
+  if (variant == 3) {
+    const dim3 n3((unsigned)((h->LD / 16) * ((h->LD + 47) / 48)), second ? 2 : 1);
+    hipLaunchKernelGGL((sg_gemm<8, 4, 3>), n3, dim3(512), 0, h->stream, g, g2, ns, alpha, beta);
+    return;
+  }
+  if (variant >= 4 && variant <= 6) {
+    const dim3 n1((unsigned)((h->LD / 16) * ((h->LD + 15) / 16)), second ? 2 : 1);
+    if (variant == 4) hipLaunchKernelGGL((sg_gemm<8, 7, 1>), n1, dim3(512), 0, h->stream, g, g2, ns, alpha, beta);
+    else if (variant == 5) hipLaunchKernelGGL((sg_gemm<16, 7, 1>), n1, dim3(1024), 0, h->stream, g, g2, ns, alpha, beta);
+    else hipLaunchKernelGGL((sg_gemm<4, 7, 1>), n1, dim3(256), 0, h->stream, g, g2, ns, alpha, beta);
+    return;
+  }
+  if (variant == 7) {
+    const dim3 n2((unsigned)((h->LD / 16) * ((h->LD + 31) / 32)), second ? 2 : 1);
+    hipLaunchKernelGGL((sg_gemm<8, 7, 2>), n2, dim3(512), 0, h->stream, g, g2, ns, alpha, beta);
+    return;
+  }
   if (variant == 0) hipLaunchKernelGGL((sg_gemm<4, 4>), nwg, dim3(256), 0, h->stream, g, g2, ns, alpha, beta);
   else if (variant == 1) hipLaunchKernelGGL((sg_gemm<8, 4>), nwg, dim3(512), 0, h->stream, g, g2, ns, alpha, beta);
   else hipLaunchKernelGGL((sg_gemm<8, 7>), nwg, dim3(512), 0, h->stream, g, g2, ns, alpha, beta);
