@@ -403,7 +403,8 @@ def main():
                             achieved=achieved, peak=peak, unit="TFLOP/s", frac=achieved / peak,
                             epoch_frac=epoch_tflops / (peak * world), epoch_tflops=epoch_tflops,
                             epoch_flops=epoch_flops,
-                            traffic=traffic.get(names[dom] + ("_f32" if bank_dtype == "f32" else "")) if world == 1 else None,
+                            traffic=traffic.get(names[dom] + ("_f32" if dom_f32 else "_mixed" if bank_dtype == "mixed" else ""))
+                            if world == 1 else None,
                             ms_per_launch=tm[dom], flops_per_launch=flops,
                             note="achieved = algorithmic 2 S^3 B flops (SURVEY 8d) / launch time; k1 (Pt symmetric) "
                                  f"and k3 (symmetric counts) multiply only the upper-triangular tiles, {tri:.2f} of "

@@ -21,6 +21,7 @@
 // the MFMA rate, half the bytes; loss partials, the divided differences and the bucket sum stay float64).
 #pragma once
 #include "common.hip.h"
+#include <type_traits>
 
 #define LG_TM 80
 #define LG_TN 80
@@ -39,6 +40,7 @@ template <> struct Mfma<double> {
   static constexpr int VEC = 2;
   static __device__ __forceinline__ acc_t mma(double a, double b, acc_t c) { return mfma_f64(a, b, c); }
   static __device__ __forceinline__ int row(int hi, int r) { return hi + 4 * r; }
+  static constexpr int RSTEP = 4;             // row(hi, r) = row(hi, 0) + RSTEP * r
 };
 template <> struct Mfma<float> {
   typedef f4 acc_t;
@@ -48,6 +50,7 @@ template <> struct Mfma<float> {
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
   }
   static __device__ __forceinline__ int row(int hi, int r) { return 4 * hi + r; }
+  static constexpr int RSTEP = 1;
 };
 __device__ __forceinline__ void vec_scale(double2 &v, double s) { v.x *= s; v.y *= s; }
 __device__ __forceinline__ void vec_scale(float4 &v, float s) { v.x *= s; v.y *= s; v.z *= s; v.w *= s; }
@@ -203,6 +206,11 @@ __device__ __forceinline__ int xcd_swizzle(int id, int n) {
   return base + k;
 }
 
+__device__ __forceinline__ void lg_wave_lds_fence() {   // LDS visibility inside ONE wavefront (no workgroup barrier)
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+
 // elementwise pieces of the K1 epilogue in the bank's element type (the loss itself is always
 // accumulated in float64)
 __device__ __forceinline__ double k1_log(double x) { return fast_log(x); }
@@ -232,8 +240,8 @@ struct K1Args {
 // count and its own Gt^T entry).  40 % fewer MFMAs than the full grid at LD = 400.
 template <typename T, typename TG = T, bool EXPM = false>   // EXPM: write P_b (cb_expm_bank) instead of loss / Gt
 __global__ __launch_bounds__(LG4_THREADS, 4) void k1_pt_loss_gt(K1Args<T, TG> a) {  // four workgroups per CU
-  __shared__ T sA[2 * LG_KT * LG_TM];
-  __shared__ T sB[2 * LG_KT * LG_TN];
+  __shared__ T sAB[4 * LG_KT * LG_TM];   // A panels | B panels (two K-steps each); after the K loop: the transposition buffer
+  T *sA = sAB, *sB = sAB + 2 * LG_KT * LG_TM;
   typedef typename Mfma<T>::acc_t acc_t;
   const int tilesN = (a.LD + LG_TN - 1) / LG_TN, tiles = tilesN * (tilesN + 1) / 2;
   const int vid = xcd_swizzle(blockIdx.x, gridDim.x);
@@ -260,27 +268,43 @@ __global__ __launch_bounds__(LG4_THREADS, 4) void k1_pt_loss_gt(K1Args<T, TG> a)
   const T *__restrict__ Ct = a.Ct + boff;
   const T *__restrict__ Am = a.A;
   TG *__restrict__ Gt = a.Gt + boff;
-  // One 16 x 16 MFMA tile at a time, in three phases: ALL its loads (counts, mirrored counts, I + tA),
-  // then the arithmetic, then ALL its stores.  Written element by element (load, log, store, next
-  // element) the epilogue compiled to 25 chains of global_load -> s_waitcnt vmcnt(0) -> ... -> store,
-  // i.e. 25 exposed HBM latencies per wave (the counts are streamed, never cached): 40 % of K1's time.
-  // log(Pt) and 1 / Pt are shared by the (row, col) and the mirrored (col, row) entry.
+  // One 16 x 16 MFMA tile at a time, in three phases: ALL its loads (counts, mirrored counts, I + tA), then
+  // the arithmetic, then ALL its stores.  Written element by element (load, log, store, next element) the
+  // epilogue compiled to 25 chains of global_load -> s_waitcnt vmcnt(0) -> ... -> store, i.e. 25 exposed HBM
+  // latencies per wave (the counts are streamed, never cached): 40 % of K1's time.
+  // The MIRRORED entries (col, row) of an off-diagonal tile -- same Pt value, their own count and Gt^T entry:
+  // in the accumulator layout their addresses are 32-byte pieces of 64 different rows (K1 moved 1.8x its
+  // algorithmic bytes).  So every wave transposes the tile's Pt values through a private 16 x 17 patch of
+  // LDS (the panel buffers are free after the K loop; no workgroup barrier, the four waves stay independent)
+  // and handles the mirrored entries with the lanes running along THEIR rows: 128-byte runs, like the
+  // direct entries.  (Staging whole 80 x 48 parts through LDS with barriers in between gave the same
+  // traffic, 400 MB, but serialised the waves: 0.245 -> 0.262 ms.)
+  T *sW = sAB + wave * (16 * 17);
   auto tile_epilogue = [&](int rbase, int cbase, const acc_t &v) {   // wave-uniform tile origin
     if (rbase >= a.LD || cbase >= a.LD) return;
     const int col = cbase + lo;
-    int row[4], idx[4], idm[4];          // LD <= 1024: offsets inside one matrix fit an int
+    // register r of the tile is row rl0 + RSTEP r: one base offset + a constant stride per index array
+    // (LD <= 1024: offsets inside one matrix fit an int)
+    constexpr int RS = Mfma<T>::RSTEP;
+    const int rl0 = Mfma<T>::row(hi, 0), step = RS * a.LD;
+    const int idx0 = (rbase + rl0) * a.LD + col;
+    const int idm0 = (cbase + rl0) * a.LD + rbase + lo;   // mirrored entry (cbase + rl, rbase + lo): lanes run along its row
+    int rl[4], row[4], idx[4], idm[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      row[r] = rbase + Mfma<T>::row(hi, r);
-      idx[r] = row[r] * a.LD + col;
-      idm[r] = col * a.LD + row[r];
+      rl[r] = rl0 + RS * r;
+      row[r] = rbase + rl[r];
+      idx[r] = idx0 + r * step;
+      idm[r] = idm0 + r * step;
     }
     T c1[4], c2[4], av[4], pt[4];
     if (!EXPM) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) c1[r] = Ct[idx[r]];
+      if (mirror) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) c2[r] = mirror ? Ct[idm[r]] : T(0);
+        for (int r = 0; r < 4; ++r) c2[r] = Ct[idm[r]];
+      }
     }
     if (split) {
 #pragma unroll
@@ -302,19 +326,30 @@ __global__ __launch_bounds__(LG4_THREADS, 4) void k1_pt_loss_gt(K1Args<T, TG> a)
       }
       return;
     }
-    TG g1[4], g2[4];
+    TG g1[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const bool nz1 = c1[r] != T(0), nz2 = c2[r] != T(0);
-      const T lg = k1_log((nz1 || nz2) ? pt[r] : T(1));
-      const T rc = inv_nT * k1_rcp(pt[r]);
-      lossacc = fma(-((double)c1[r] + (double)c2[r]), (double)lg, lossacc);
-      g1[r] = (TG)(nz1 ? -c1[r] * rc : T(0));
-      g2[r] = (TG)(nz2 ? -c2[r] * rc : T(0));
+      const bool nz = c1[r] != T(0);
+      lossacc = fma(-(double)c1[r], (double)k1_log(nz ? pt[r] : T(1)), lossacc);
+      g1[r] = (TG)(nz ? -c1[r] * inv_nT * k1_rcp(pt[r]) : T(0));
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) Gt[idx[r]] = g1[r];
     if (mirror) {
+      // Pt(row = rbase + rl[r], col = cbase + lo) -> patch[lo][rl[r]]; read back patch[rl[r]][lo] =
+      // Pt(row = rbase + lo, col = cbase + rl[r]), the value of the mirrored entry this lane now owns
+      lg_wave_lds_fence();   // the previous tile's reads of the patch are done
+#pragma unroll
+      for (int r = 0; r < 4; ++r) sW[lo * 17 + rl[r]] = pt[r];
+      lg_wave_lds_fence();
+      TG g2[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const T pm = sW[rl[r] * 17 + lo];
+        const bool nz = c2[r] != T(0);
+        lossacc = fma(-(double)c2[r], (double)k1_log(nz ? pm : T(1)), lossacc);
+        g2[r] = (TG)(nz ? -c2[r] * inv_nT * k1_rcp(pm) : T(0));
+      }
 #pragma unroll
       for (int r = 0; r < 4; ++r) Gt[idm[r]] = g2[r];
     }
@@ -324,9 +359,10 @@ __global__ __launch_bounds__(LG4_THREADS, 4) void k1_pt_loss_gt(K1Args<T, TG> a)
   tile_epilogue(m0 + 64, n0 + 16 * wave, ax0);
   if (wave == 0) tile_epilogue(m0 + 64, n0 + 64, ax1);
   if (EXPM) return;
+  __syncthreads();   // the patches are read no more: the loss partials reuse the buffer
   lossacc = wave_sum(lossacc);
-  // sA is free after the K loop (the tile routine ends with a barrier)
-  double *sRed = reinterpret_cast<double *>(sA);
+  // the LDS panels are free after the K loop (the tile routine ends with a barrier)
+  double *sRed = reinterpret_cast<double *>(sAB);
   if (lane == 0) sRed[wave] = lossacc;
   __syncthreads();
   if (threadIdx.x == 0) a.loss_part[vid] = (sRed[0] + sRed[1]) + (sRed[2] + sRed[3]);

@@ -1,20 +1,27 @@
 #!/bin/bash
-# Run ON THE GPU BOX (via gpurun) from the repo root.  Writes raw rocprofv3 output
-# under gpurun_out/ (scratch); profiles/parse_profiles.py turns it into the
-# committed summaries.  PMC passes are separate from --kernel-trace/--stats runs
-# and FETCH_SIZE / WRITE_SIZE are collected in separate passes (TCC slot budget),
-# as MI355X_MICROARCH.md prescribes.
+# Run ON THE GPU BOX (via gpurun) from the repo root:  bash profiles/collect.sh [tag]
+# Writes raw rocprofv3 output under gpurun_out/ (scratch); profiles/parse_profiles.py turns it into the
+# committed summaries (profiles/<round>_<tag>_*).  PMC passes are separate from --kernel-trace/--stats
+# runs; FETCH_SIZE / WRITE_SIZE are collected in separate passes (TCC slot budget) and the SQ counters
+# (MFMA busy cycles, wave cycles, waits) in one pass of 8, as MI355X_MICROARCH.md prescribes.
 set -u
 R=${GRAFT_REPO_ROOT:-$PWD}
 cd /tmp && export TMPDIR=/tmp
 TAG=${1:-final}
-# plain (unprofiled) default bench line first, on the fresh box, as the driver runs it
+# plain (unprofiled) lines first, on the fresh box, as the driver runs them
+python3 $R/bench.py --steps 20 --warmup 5 > $R/gpurun_out/${TAG}_bench_driver.log 2>&1
 python3 $R/bench.py > $R/gpurun_out/${TAG}_bench_default.log 2>&1
-for w in coevo400 lg20 siterm counting ble assembly likelihood; do
-  rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${TAG}_trace_$w -- \
-    python3 $R/bench.py --workload $w --no-cpu-baseline --no-secondary > $R/gpurun_out/${TAG}_bench_$w.log 2>&1
+for v in "coevo400 f64" "coevo400 mixed" "coevo400 f32" "coevo400_demo f64" "lg20 f64" "siterm f64" "counting f64" "ble f64" "assembly f64" "likelihood f64"; do
+  set -- $v; w=$1; dt=$2; name=$w; [ "$dt" != "f64" ] && name=${w}_$dt
+  rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${TAG}_trace_$name -- \
+    python3 $R/bench.py --workload $w --dtype $dt --no-cpu-baseline --no-secondary > $R/gpurun_out/${TAG}_bench_$name.log 2>&1
   for c in FETCH_SIZE WRITE_SIZE; do
-    rocprofv3 --pmc $c --output-format csv -d $R/gpurun_out/${TAG}_pmc_${w}_$c -- \
-      python3 $R/bench.py --workload $w --steps 3 --warmup 1 --no-cpu-baseline --no-secondary > /dev/null 2>&1
+    rocprofv3 --pmc $c --output-format csv -d $R/gpurun_out/${TAG}_pmc_${name}_$c -- \
+      python3 $R/bench.py --workload $w --dtype $dt --steps 3 --warmup 1 --no-cpu-baseline --no-secondary > /dev/null 2>&1
   done
+done
+for dt in f64 mixed f32; do
+  rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA \
+    --output-format csv -d $R/gpurun_out/${TAG}_pmc_sq_$dt -- \
+    python3 $R/bench.py --dtype $dt --steps 3 --warmup 1 --no-cpu-baseline --no-secondary > /dev/null 2>&1
 done

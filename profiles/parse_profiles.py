@@ -1,12 +1,15 @@
 #!/usr/bin/env python3
-"""Summarise gpurun_out/<tag>_* (written by profiles/collect.sh) into profiles/:
-  r01_<tag>_<workload>_kernel_stats.csv   rocprofv3 --kernel-trace --stats summary
-  r01_<tag>_<workload>_bench.json         the bench line of that profiled run
-  pmc_traffic.json                        HBM-side bytes per launch per kernel:
-        2 x FETCH_SIZE + WRITE_SIZE  [KB -> bytes]
-     (gfx950: FETCH_SIZE reports half of the bytes of a streaming read -- calibrated here on
-      lg_transpose_pad, which reads exactly the 165.12 MB count tensor once; WRITE_SIZE is exact)
-"""
+"""Summarise gpurun_out/<tag>_* (written by profiles/collect.sh) into profiles/, named per round:
+  <round>_<tag>_<workload>_kernel_stats.csv   rocprofv3 --kernel-trace --stats summary
+  <round>_<tag>_<workload>_bench.json         the bench line of that profiled run
+  <round>_<tag>_bench_default.json / _bench_driver.json   unprofiled lines (default flags; the driver's --steps 20 --warmup 5)
+  pmc_traffic.json       HBM-side bytes per launch per kernel: 2 x FETCH_SIZE + WRITE_SIZE  [KB -> bytes]
+                         (gfx950: FETCH_SIZE reports half of the bytes of a streaming read -- calibrated here on
+                         lg_transpose_pad, which reads exactly the 165.12 MB count tensor once; WRITE_SIZE is exact)
+  mfma_util.json         MFMA utilisation of the bank kernels: SQ_VALU_MFMA_BUSY_CYCLES (cycles an MFMA pipe is busy,
+                         summed over the 1024 SIMDs) / (1024 x kernel duration x 2.4 GHz), with the wave-cycle split
+                         (SQ_WAIT_ANY / SQ_WAIT_INST_ANY / SQ_ACTIVE_INST_ANY over SQ_WAVE_CYCLES)
+usage: python profiles/parse_profiles.py [tag] [round]"""
 import collections
 import csv
 import glob
@@ -16,28 +19,40 @@ import shutil
 import sys
 
 tag = sys.argv[1] if len(sys.argv) > 1 else "final"
+rnd = sys.argv[2] if len(sys.argv) > 2 else "r02"
 here = os.path.dirname(os.path.abspath(__file__))
 root = os.path.dirname(here)
 out = {"bytes_per_launch": {}, "detail": {}, "calibration": {},
        "source": f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), gpurun_out/{tag}_pmc_*"}
-names = {"k1_pt_loss_gt": "k1_pt_loss_gt", "k2_t_eq_g_u": "k2_t_eq_g_u", "k3_w_phi": "k3_w_phi",
-         "lgj_round": "lgj_round", "lg_transpose_pad": "lg_transpose_pad",
-         "small_train_kernel": "small_train_kernel", "small_bank_kernel": "small_bank_kernel",
-         "lg_prepare": "lg_prepare", "lg_bank": "lg_bank", "lg_finish": "lg_finish",
-         "count_transitions_lds_kernel": "count_transitions_lds_kernel",
-         "count_reduce_slabs": "count_reduce_slabs", "k3_reduce": "k3_reduce", "k4_gemm": "k4_gemm",
-         "sp_prepare": "sp_prepare", "sp_bank": "sp_bank", "sp_finish": "sp_finish", "sg_gemm": "sg_gemm", "lgx_build": "lgx_build", "ble_branch_lengths_kernel": "ble_branch_lengths_kernel",
-         "ble_site_rates_kernel": "ble_site_rates_kernel", "siterm_raw_counts_kernel": "siterm_raw_counts_kernel",
-         "siterm_mix_kernel": "siterm_mix_kernel"}
-for w in ["coevo400", "lg20", "siterm", "counting", "ble", "assembly", "likelihood"]:
+NAMES = ["k1_pt_loss_gt", "k2_t_eq_g_u", "k3_w_phi", "lgj_round", "lg_transpose_pad", "small_train_kernel", "small_bank_kernel",
+         "lg_prepare", "lg_bank", "lg_finish", "count_transitions_lds_kernel", "count_reduce_slabs", "k3_reduce", "sp_prepare",
+         "sp_bank", "sp_finish", "sg_gemm", "lgx_build", "ble_branch_lengths_kernel", "ble_site_rates_kernel",
+         "siterm_raw_counts_kernel", "siterm_mix_kernel", "tl_mfma_kernel", "tl_group_kernel", "lg_cast_f32"]
+WORKLOADS = ["coevo400", "coevo400_mixed", "coevo400_f32", "coevo400_demo", "lg20", "siterm", "counting", "ble", "assembly", "likelihood"]
+
+
+def kshort(full):
+    """kernel family + element type of the templated bank kernels (k2_t_eq_g_u<float> -> k2_t_eq_g_u_f32)"""
+    for short in NAMES:
+        if short in full:
+            if short in ("k1_pt_loss_gt", "k2_t_eq_g_u", "k3_w_phi", "k3_reduce"):
+                if "<float" in full:
+                    return short + "_f32"
+                if short == "k1_pt_loss_gt" and "<double, float" in full:
+                    return short + "_mixed"
+            return short
+    return None
+
+
+for w in WORKLOADS:
     st = glob.glob(f"{root}/gpurun_out/{tag}_trace_{w}/*/*_kernel_stats.csv")
     if st:
-        shutil.copy(st[0], f"{here}/r01_{tag}_{w}_kernel_stats.csv")
+        shutil.copy(st[0], f"{here}/{rnd}_{tag}_{w}_kernel_stats.csv")
     log = f"{root}/gpurun_out/{tag}_bench_{w}.log"
     if os.path.exists(log):
         line = [l for l in open(log) if l.startswith("{")]
         if line:
-            open(f"{here}/r01_{tag}_{w}_bench.json", "w").write(line[-1])
+            open(f"{here}/{rnd}_{tag}_{w}_bench.json", "w").write(line[-1])
     vals = collections.defaultdict(dict)
     for c in ["FETCH_SIZE", "WRITE_SIZE"]:
         fs = glob.glob(f"{root}/gpurun_out/{tag}_pmc_{w}_{c}/*/*counter_collection.csv")
@@ -47,23 +62,21 @@ for w in ["coevo400", "lg20", "siterm", "counting", "ble", "assembly", "likeliho
         for r in csv.DictReader(open(fs[0])):
             agg[r["Kernel_Name"]].append(float(r["Counter_Value"]))
         for k, v in agg.items():
-            for short in names:
-                if short in k:
-                    vals[short][c] = sum(v) / len(v)
-                    vals[short][c + "_launches"] = len(v)
+            short = kshort(k)
+            if short:
+                vals[short][c] = sum(v) / len(v)
+                vals[short][c + "_launches"] = len(v)
     for k, d in vals.items():
         if "FETCH_SIZE" in d and "WRITE_SIZE" in d:
-            key = k if w == "coevo400" else f"{k}:{w}"
+            key = k if w.startswith("coevo400") and w != "coevo400_demo" else f"{k}:{w}"
             b = (2.0 * d["FETCH_SIZE"] + d["WRITE_SIZE"]) * 1024.0
-            out["detail"][key] = {"fetch_KB_raw": d["FETCH_SIZE"], "write_KB": d["WRITE_SIZE"],
-                                  "bytes": b, "launches_seen": d["FETCH_SIZE_launches"]}
+            out["detail"][key] = {"fetch_KB_raw": d["FETCH_SIZE"], "write_KB": d["WRITE_SIZE"], "bytes": b,
+                                  "launches_seen": d["FETCH_SIZE_launches"], "workload": w}
             out["bytes_per_launch"][key] = b
 if "lg_transpose_pad" in out["detail"]:
     d = out["detail"]["lg_transpose_pad"]
     out["calibration"] = {"kernel": "lg_transpose_pad", "true_read_bytes": 129 * 400 * 400 * 8,
-                          "FETCH_SIZE_x1024": d["fetch_KB_raw"] * 1024,
-                          "ratio": 129 * 400 * 400 * 8 / (d["fetch_KB_raw"] * 1024)}
-# per-epoch / per-pass totals of the workloads whose step is more than one launch
+                          "FETCH_SIZE_x1024": d["fetch_KB_raw"] * 1024, "ratio": 129 * 400 * 400 * 8 / (d["fetch_KB_raw"] * 1024)}
 bpl = out["bytes_per_launch"]
 for w in ("siterm", "lg20"):   # S <= 20: three launches per epoch (sp_prepare / sp_bank / sp_finish)
     if all(f"{k}:{w}" in bpl for k in ("sp_prepare", "sp_bank", "sp_finish")):
@@ -71,9 +84,42 @@ for w in ("siterm", "lg20"):   # S <= 20: three launches per epoch (sp_prepare /
 if all(f"{k}:counting" in bpl for k in ("count_transitions_lds_kernel", "count_reduce_slabs")):
     bpl["pass:counting"] = bpl["count_transitions_lds_kernel:counting"] + bpl["count_reduce_slabs:counting"]
 json.dump(out, open(f"{here}/pmc_traffic.json", "w"), indent=1)
-d = f"{root}/gpurun_out/{tag}_bench_default.log"
-if os.path.exists(d):
-    line = [l for l in open(d) if l.startswith("{")]
-    if line:
-        open(f"{here}/r01_{tag}_bench_default.json", "w").write(line[-1])
+for name in ("bench_default", "bench_driver"):
+    d = f"{root}/gpurun_out/{tag}_{name}.log"
+    if os.path.exists(d):
+        line = [l for l in open(d) if l.startswith("{")]
+        if line:
+            open(f"{here}/{rnd}_{tag}_{name}.json", "w").write(line[-1])
+
+# ---- MFMA utilisation (north_star: "rocprof HBM GB/s and MFMA utilisation vs gfx950 peak")
+util = {"source": f"rocprofv3 --pmc SQ_* (one pass of 8 counters), gpurun_out/{tag}_pmc_sq_*; durations from the "
+                  "--kernel-trace --stats summaries of the same workloads", "simds": 1024, "clock_GHz": 2.4, "kernels": {}}
+for dt, w in (("f64", "coevo400"), ("mixed", "coevo400_mixed"), ("f32", "coevo400_f32")):
+    fs = glob.glob(f"{root}/gpurun_out/{tag}_pmc_sq_{dt}/*/*counter_collection.csv")
+    st = glob.glob(f"{root}/gpurun_out/{tag}_trace_{w}/*/*_kernel_stats.csv")
+    if not fs or not st:
+        continue
+    dur = {}
+    for r in csv.DictReader(open(st[0])):
+        short = kshort(r["Name"])
+        if short:
+            dur[short] = float(r["AverageNs"])
+    agg = collections.defaultdict(lambda: collections.defaultdict(list))
+    for r in csv.DictReader(open(fs[0])):
+        short = kshort(r["Kernel_Name"])
+        if short and short.startswith(("k1_", "k2_", "k3_w")):
+            agg[short][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    for k, d in agg.items():
+        m = {c: sum(v) / len(v) for c, v in d.items()}
+        if k not in dur or "SQ_VALU_MFMA_BUSY_CYCLES" not in m:
+            continue
+        wc = m.get("SQ_WAVE_CYCLES", 0.0) or 1.0
+        util["kernels"][f"{k}:{dt}"] = {
+            "avg_duration_us": dur[k] / 1e3, "mfma_busy_cycles": m["SQ_VALU_MFMA_BUSY_CYCLES"], "mfma_instructions": m.get("SQ_INSTS_MFMA"),
+            "mfma_util": m["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024 * dur[k] * 2.4),
+            "wave_cycles_split": {"waiting_waitcnt_or_barrier": m.get("SQ_WAIT_ANY", 0.0) / wc, "issue_stalled": m.get("SQ_WAIT_INST_ANY", 0.0) / wc,
+                                  "issuing": m.get("SQ_ACTIVE_INST_ANY", 0.0) / wc, "lds_issue_stalled": m.get("SQ_WAIT_INST_LDS", 0.0) / wc},
+            "mean_resident_waves": 4.0 * m.get("SQ_WAVE_CYCLES", 0.0) / (dur[k] * 2.4)}
+json.dump(util, open(f"{here}/mfma_util.json", "w"), indent=1)
 print(json.dumps(out["bytes_per_launch"], indent=1))
+print(json.dumps({k: round(v["mfma_util"], 3) for k, v in util["kernels"].items()}, indent=1))
