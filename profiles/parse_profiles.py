@@ -18,6 +18,12 @@ import os
 import shutil
 import sys
 
+def newest(pattern):
+    """the most recent match (gpurun merges every call's files into gpurun_out/: an older run of the same tag may linger)"""
+    fs = sorted(glob.glob(pattern), key=os.path.getmtime)
+    return fs[-1:]
+
+
 tag = sys.argv[1] if len(sys.argv) > 1 else "final"
 rnd = sys.argv[2] if len(sys.argv) > 2 else "r02"
 here = os.path.dirname(os.path.abspath(__file__))
@@ -45,7 +51,7 @@ def kshort(full):
 
 
 for w in WORKLOADS:
-    st = glob.glob(f"{root}/gpurun_out/{tag}_trace_{w}/*/*_kernel_stats.csv")
+    st = newest(f"{root}/gpurun_out/{tag}_trace_{w}/*/*_kernel_stats.csv")
     if st:
         shutil.copy(st[0], f"{here}/{rnd}_{tag}_{w}_kernel_stats.csv")
     log = f"{root}/gpurun_out/{tag}_bench_{w}.log"
@@ -55,7 +61,7 @@ for w in WORKLOADS:
             open(f"{here}/{rnd}_{tag}_{w}_bench.json", "w").write(line[-1])
     vals = collections.defaultdict(dict)
     for c in ["FETCH_SIZE", "WRITE_SIZE"]:
-        fs = glob.glob(f"{root}/gpurun_out/{tag}_pmc_{w}_{c}/*/*counter_collection.csv")
+        fs = newest(f"{root}/gpurun_out/{tag}_pmc_{w}_{c}/*/*counter_collection.csv")
         if not fs:
             continue
         agg = collections.defaultdict(list)
@@ -95,8 +101,8 @@ for name in ("bench_default", "bench_driver"):
 util = {"source": f"rocprofv3 --pmc SQ_* (one pass of 8 counters), gpurun_out/{tag}_pmc_sq_*; durations from the "
                   "--kernel-trace --stats summaries of the same workloads", "simds": 1024, "clock_GHz": 2.4, "kernels": {}}
 for dt, w in (("f64", "coevo400"), ("mixed", "coevo400_mixed"), ("f32", "coevo400_f32")):
-    fs = glob.glob(f"{root}/gpurun_out/{tag}_pmc_sq_{dt}/*/*counter_collection.csv")
-    st = glob.glob(f"{root}/gpurun_out/{tag}_trace_{w}/*/*_kernel_stats.csv")
+    fs = newest(f"{root}/gpurun_out/{tag}_pmc_sq_{dt}/*/*counter_collection.csv")
+    st = newest(f"{root}/gpurun_out/{tag}_trace_{w}/*/*_kernel_stats.csv")
     if not fs or not st:
         continue
     dur = {}
