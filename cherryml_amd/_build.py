@@ -4,7 +4,10 @@ import shutil
 import subprocess
 
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
-SRC = os.path.join(PKG_DIR, "csrc", "cherrybank.hip")
+CSRC = os.path.join(PKG_DIR, "csrc")
+# one translation unit per subsystem (kernels live in the *.hip.h headers each of them includes)
+SRCS = [os.path.join(CSRC, f) for f in ("cherrybank.hip", "cb_counting.hip", "cb_ble.hip", "cb_likelihood.hip",
+                                        "cb_host_io.hip")]
 LIB = os.path.join(PKG_DIR, "libcherrybank.so")
 
 
@@ -28,8 +31,21 @@ def build(force: bool = False, verbose: bool = False) -> str:
     if not force and not needs_build():
         return LIB
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-Wall", "-Wextra",
-           SRC, "-o", LIB + ".tmp"]
+    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wextra"]
+    objdir = os.path.join(PKG_DIR, "build")
+    os.makedirs(objdir, exist_ok=True)
+    # compile the translation units side by side, then link
+    procs = []
+    for src in SRCS:
+        obj = os.path.join(objdir, os.path.basename(src) + ".o")
+        cmd = [hipcc] + flags + ["-c", src, "-o", obj]
+        if verbose:
+            print(" ".join(cmd))
+        procs.append((obj, cmd, subprocess.Popen(cmd)))
+    for obj, cmd, proc in procs:
+        if proc.wait() != 0:
+            raise subprocess.CalledProcessError(proc.returncode, cmd)
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + [obj for obj, _, _ in procs] + ["-o", LIB + ".tmp"]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

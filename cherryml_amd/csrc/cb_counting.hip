@@ -1,0 +1,256 @@
+// libcherrybank: transition counting and SiteRM count assembly.
+#include "cb_internal.hip.h"
+#include "common.hip.h"
+#include "counting.hip.h"
+
+// ------------------------------------------------------------------------ counting
+// Replica scratch of the resident (device-pointer) form, kept per device for the life of the
+// process (the only process-wide state of the library; never holds results between calls).
+static int count_scratch(int device, size_t elems, unsigned long long **out) {
+  static unsigned long long *buf[64] = {};
+  static size_t cap[64] = {};
+  if (device < 0 || device >= 64) return fail(CB_EINVAL, "counting: device %d out of range", device);
+  if (cap[device] < elems) {
+    if (buf[device]) (void)hipFree(buf[device]);
+    buf[device] = nullptr;
+    cap[device] = 0;
+    hipError_t e = hipMalloc((void **)&buf[device], elems * sizeof(unsigned long long));
+    if (e != hipSuccess) return fail(CB_ENOMEM, "counting: replica scratch allocation failed");
+    cap[device] = elems;
+  }
+  *out = buf[device];
+  return CB_OK;
+}
+
+// device-pointer launch of the single-site counter: adds into counts[B*S*S].
+// max_sites = largest pair.n (0 = unknown -> replica path).
+static int launch_count_transitions(int device, int S, int B, const double *grid, const int8_t *seqs,
+                                    const double *rates, const cb_count_pair *pairs, int64_t n_pairs,
+                                    int symmetric, int max_sites, unsigned long long *counts) {
+  const size_t nb = (size_t)B * S * S;
+  const int words = (int)((nb + 1) / 2);
+  const size_t lds = (size_t)((words + 1) & ~1) * sizeof(unsigned) + (size_t)B * sizeof(double);
+  int chunk = max_sites > 0 ? 65535 / (2 * max_sites) : 0;
+  if (chunk >= 8 && lds <= 150 * 1024) {
+    // keep at least ~2 workgroups per CU worth of slabs when there is enough work
+    const int64_t want = (n_pairs + 511) / 512;
+    if (want < chunk) chunk = (int)(want > 8 ? want : 8);
+    const int64_t nwg = (n_pairs + chunk - 1) / chunk;
+    unsigned long long *scratch = nullptr;
+    int rc = count_scratch(device, ((size_t)nwg * words + 1) / 2 + 1, &scratch);
+    if (rc != CB_OK) return rc;
+    unsigned *slabs = reinterpret_cast<unsigned *>(scratch);
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(count_transitions_lds_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(count_transitions_lds_kernel, dim3((unsigned)nwg), dim3(CNT_LDS_THREADS), lds, 0, S, B,
+                       grid, seqs, rates, pairs, (long long)n_pairs, symmetric, chunk, slabs, words);
+    hipLaunchKernelGGL(count_reduce_slabs, dim3((unsigned)((words + 63) / 64)), dim3(256), 0, 0, slabs, (int)nwg,
+                       words, nb, counts);
+  } else {
+    unsigned long long *rep = nullptr;
+    int rc = count_scratch(device, nb * CNT_REPLICAS, &rep);
+    if (rc != CB_OK) return rc;
+    HIP_TRY(hipMemsetAsync(rep, 0, nb * CNT_REPLICAS * sizeof(unsigned long long), 0));
+    const unsigned blocks = (unsigned)((n_pairs + 3) / 4);
+    hipLaunchKernelGGL(count_transitions_kernel, dim3(blocks), dim3(256), 0, 0, S, B, grid, seqs, rates, pairs,
+                       (long long)n_pairs, symmetric, rep, CNT_REPLICAS);
+    hipLaunchKernelGGL(count_reduce_replicas, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, 0, rep,
+                       CNT_REPLICAS, nb, counts);
+  }
+  HIP_TRY(hipGetLastError());
+  return CB_OK;
+}
+
+static int count_common(int device, int S, int B, const double *grid, const int8_t *seqs,
+                        int64_t seqs_bytes, const void *aux, size_t aux_bytes,
+                        const cb_count_pair *pairs, int64_t n_pairs, int symmetric, int flags,
+                        unsigned long long *counts, bool co) {
+  if (S < 1 || B < 1 || !grid || !counts) return fail(CB_EINVAL, "counting: bad S/B/grid/counts");
+  if (flags & CB_PTR_DEVICE) {  // resident form: enqueue only, add into counts
+    if (n_pairs < 0 || (n_pairs > 0 && (!pairs || !seqs))) return fail(CB_EINVAL, "counting: bad pairs");
+    HIP_TRY(hipSetDevice(device));
+    if (n_pairs > 0) {
+      const unsigned blocks = (unsigned)((n_pairs + 3) / 4);
+      if (co)
+        hipLaunchKernelGGL(count_co_transitions_kernel, dim3(blocks), dim3(256), 0, 0, S, B, grid, seqs,
+                           (const int32_t *)aux, pairs, (long long)n_pairs, symmetric, counts);
+      else {
+        // resident form: the caller states the largest pair.n in flags bits 8..23 (0 = unknown)
+        int rc = launch_count_transitions(device, S, B, grid, seqs, (const double *)aux, pairs, n_pairs,
+                                          symmetric, (flags >> 8) & 0xFFFF, counts);
+        if (rc != CB_OK) return rc;
+      }
+      HIP_TRY(hipGetLastError());
+    }
+    return CB_OK;
+  }
+  if (n_pairs < 0 || (n_pairs > 0 && (!pairs || !seqs))) return fail(CB_EINVAL, "counting: bad pairs");
+  for (int b = 1; b < B; ++b)
+    if (!(grid[b] > grid[b - 1])) return fail(CB_EINVAL, "counting: quantization points must be sorted");
+  int ndev = cb_device_count();
+  if (ndev <= 0) return fail(CB_EHIP, "counting: no HIP device visible");
+  if (device < 0 || device >= ndev) return fail(CB_EINVAL, "counting: device %d out of range", device);
+  // validate offsets on the host: the kernels trust them
+  const size_t nbins = co ? (size_t)B * S * S * S * S : (size_t)B * S * S;
+  for (int64_t p = 0; p < n_pairs; ++p) {
+    const cb_count_pair &pr = pairs[p];
+    const int64_t span = co ? 1 : pr.n;  // co: sites are indexed through the contact list
+    if (pr.n < 0 || pr.seq_a < 0 || pr.seq_b < 0 || pr.aux < 0 || pr.seq_a + span > seqs_bytes ||
+        pr.seq_b + span > seqs_bytes)
+      return fail(CB_EINVAL, "counting: pair %lld has offsets outside the sequence buffer", (long long)p);
+    const size_t need = co ? ((size_t)pr.aux + pr.n) * 2 * sizeof(int32_t) : ((size_t)pr.aux + pr.n) * sizeof(double);
+    if (need > aux_bytes) return fail(CB_EINVAL, "counting: pair %lld reads past its rates/contacts", (long long)p);
+  }
+  HIP_TRY(hipSetDevice(device));
+  double *d_grid = nullptr;
+  int8_t *d_seqs = nullptr;
+  void *d_aux = nullptr;
+  cb_count_pair *d_pairs = nullptr;
+  unsigned long long *d_counts = nullptr;
+  int rc = CB_OK;
+  auto freeall = [&]() {
+    (void)hipFree(d_grid); (void)hipFree(d_seqs); (void)hipFree(d_aux); (void)hipFree(d_pairs); (void)hipFree(d_counts);
+  };
+#define TRYC(expr)                                                                       \
+  if (rc == CB_OK) {                                                                     \
+    hipError_t e_ = (expr);                                                              \
+    if (e_ != hipSuccess) rc = fail(e_ == hipErrorOutOfMemory ? CB_ENOMEM : CB_EHIP, "%s failed: %s", #expr, hipGetErrorString(e_)); \
+  }
+  TRYC(hipMalloc((void **)&d_grid, B * sizeof(double)));
+  TRYC(hipMalloc((void **)&d_seqs, seqs_bytes > 0 ? seqs_bytes : 1));
+  TRYC(hipMalloc(&d_aux, aux_bytes > 0 ? aux_bytes : 1));
+  TRYC(hipMalloc((void **)&d_pairs, (n_pairs > 0 ? n_pairs : 1) * sizeof(cb_count_pair)));
+  TRYC(hipMalloc((void **)&d_counts, nbins * sizeof(unsigned long long)));
+  TRYC(hipMemcpy(d_grid, grid, B * sizeof(double), hipMemcpyHostToDevice));
+  if (seqs_bytes > 0) TRYC(hipMemcpy(d_seqs, seqs, seqs_bytes, hipMemcpyHostToDevice));
+  if (aux_bytes > 0) TRYC(hipMemcpy(d_aux, aux, aux_bytes, hipMemcpyHostToDevice));
+  if (n_pairs > 0) TRYC(hipMemcpy(d_pairs, pairs, n_pairs * sizeof(cb_count_pair), hipMemcpyHostToDevice));
+  TRYC(hipMemset(d_counts, 0, nbins * sizeof(unsigned long long)));
+  if (rc == CB_OK && n_pairs > 0) {
+    const unsigned blocks = (unsigned)((n_pairs + 3) / 4);
+    if (co)
+      hipLaunchKernelGGL(count_co_transitions_kernel, dim3(blocks), dim3(256), 0, 0, S, B, d_grid, d_seqs,
+                         (const int32_t *)d_aux, d_pairs, (long long)n_pairs, symmetric, d_counts);
+    else {
+      int max_sites = 0;
+      for (int64_t p = 0; p < n_pairs; ++p) max_sites = pairs[p].n > max_sites ? pairs[p].n : max_sites;
+      if (rc == CB_OK)
+        rc = launch_count_transitions(device, S, B, d_grid, d_seqs, (const double *)d_aux, d_pairs, n_pairs,
+                                      symmetric, max_sites < 32768 ? max_sites : 0, d_counts);
+    }
+    TRYC(hipGetLastError());
+    TRYC(hipDeviceSynchronize());
+  }
+  TRYC(hipMemcpy(counts, d_counts, nbins * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+#undef TRYC
+  freeall();
+  return rc;
+}
+
+extern "C" int cb_count_transitions(int device, int S, int B, const double *grid, const int8_t *seqs,
+                                    int64_t seqs_bytes, const double *rates, int64_t n_rates,
+                                    const cb_count_pair *pairs, int64_t n_pairs, int symmetric,
+                                    int flags, unsigned long long *counts) {
+  if (S > 127) return fail(CB_EINVAL, "cb_count_transitions: at most 127 states (int8 codes)");
+  return count_common(device, S, B, grid, seqs, seqs_bytes, rates, (size_t)(n_rates > 0 ? n_rates : 0) * sizeof(double),
+                      pairs, n_pairs, symmetric, flags, counts, false);
+}
+
+extern "C" int cb_count_co_transitions(int device, int S, int B, const double *grid, const int8_t *seqs,
+                                       int64_t seqs_bytes, const int32_t *contacts, int64_t n_contacts,
+                                       const cb_count_pair *pairs, int64_t n_pairs, int symmetric,
+                                       int flags, unsigned long long *counts) {
+  if (S > 127) return fail(CB_EINVAL, "cb_count_co_transitions: at most 127 states (int8 codes)");
+  // contact indices must address sites inside the sequences: checked per pair on the host
+  for (int64_t p = 0; !(flags & CB_PTR_DEVICE) && p < n_pairs && pairs && contacts; ++p) {
+    const cb_count_pair &pr = pairs[p];
+    if (pr.aux < 0 || pr.n < 0 || pr.aux + pr.n > n_contacts)
+      return fail(CB_EINVAL, "cb_count_co_transitions: pair %lld contact range outside the list", (long long)p);
+    for (int c = 0; c < pr.n; ++c) {
+      const int32_t i = contacts[2 * (pr.aux + c)], j = contacts[2 * (pr.aux + c) + 1];
+      if (i < 0 || j < 0 || pr.seq_a + i >= seqs_bytes || pr.seq_a + j >= seqs_bytes ||
+          pr.seq_b + i >= seqs_bytes || pr.seq_b + j >= seqs_bytes)
+        return fail(CB_EINVAL, "cb_count_co_transitions: contact site outside the sequence buffer");
+    }
+  }
+  return count_common(device, S, B, grid, seqs, seqs_bytes, contacts,
+                      (size_t)(n_contacts > 0 ? n_contacts : 0) * 2 * sizeof(int32_t), pairs, n_pairs, symmetric,
+                      flags, counts, true);
+}
+
+extern "C" int cb_siterm_assemble(int device, int S, int B, int n_sites, const double *grid, const int8_t *seqs,
+                                  int64_t seqs_bytes, const cb_count_pair *pairs, int64_t n_pairs,
+                                  const double *site_rates, const double *prior, double lambda,
+                                  int include_reverse, int flags, double *counts, double *kernel_ms) {
+  if (!grid || !seqs || !pairs || !site_rates || !prior || !counts)
+    return fail(CB_EINVAL, "cb_siterm_assemble: NULL argument");
+  if (S < 2 || S > 64 || B < 1 || n_sites < 1 || n_pairs < 0 || seqs_bytes < 0)
+    return fail(CB_EINVAL, "cb_siterm_assemble: bad sizes (S=%d, B=%d, n_sites=%d)", S, B, n_sites);
+  if (!(lambda >= 0.0 && lambda <= 1.0)) return fail(CB_EINVAL, "cb_siterm_assemble: lambda must be in [0, 1]");
+  for (int b = 1; b < B; ++b)
+    if (!(grid[b] > grid[b - 1])) return fail(CB_EINVAL, "cb_siterm_assemble: grid must be strictly increasing");
+  for (int64_t p = 0; p < n_pairs; ++p)
+    if (pairs[p].seq_a < 0 || pairs[p].seq_b < 0 || pairs[p].seq_a + n_sites > seqs_bytes ||
+        pairs[p].seq_b + n_sites > seqs_bytes)
+      return fail(CB_EINVAL, "cb_siterm_assemble: pair %lld points outside seqs", (long long)p);
+  const int ndev = cb_device_count();
+  if (ndev <= 0) return fail(CB_EHIP, "cb_siterm_assemble: no HIP device visible");
+  if (device < 0 || device >= ndev) return fail(CB_EINVAL, "cb_siterm_assemble: device %d out of range", device);
+  HIP_TRY(hipSetDevice(device));
+  const size_t SS = (size_t)S * S, nmat = (size_t)n_sites * B, ncounts = nmat * SS;
+  void *d_grid = nullptr, *d_seqs = nullptr, *d_pairs = nullptr, *d_rates = nullptr, *d_prior = nullptr,
+       *d_live = nullptr, *d_counts_own = nullptr;
+  int rc = CB_OK;
+#define TRYA(expr) \
+  if (rc == CB_OK && (expr) != hipSuccess) rc = fail(CB_EHIP, "cb_siterm_assemble: %s failed", #expr)
+  TRYA(hipMalloc(&d_grid, B * sizeof(double)));
+  TRYA(hipMalloc(&d_seqs, seqs_bytes > 0 ? seqs_bytes : 1));
+  TRYA(hipMalloc(&d_pairs, (n_pairs > 0 ? n_pairs : 1) * sizeof(cb_count_pair)));
+  TRYA(hipMalloc(&d_rates, n_sites * sizeof(double)));
+  TRYA(hipMalloc(&d_prior, (size_t)B * SS * sizeof(double)));
+  TRYA(hipMalloc(&d_live, nmat * sizeof(int)));
+  double *d_counts = counts;
+  if (!(flags & CB_PTR_DEVICE)) {
+    TRYA(hipMalloc(&d_counts_own, ncounts * sizeof(double)));
+    d_counts = static_cast<double *>(d_counts_own);
+  }
+  TRYA(hipMemcpyAsync(d_grid, grid, B * sizeof(double), hipMemcpyHostToDevice, 0));
+  TRYA(hipMemcpyAsync(d_seqs, seqs, seqs_bytes, hipMemcpyHostToDevice, 0));
+  TRYA(hipMemcpyAsync(d_pairs, pairs, n_pairs * sizeof(cb_count_pair), hipMemcpyHostToDevice, 0));
+  TRYA(hipMemcpyAsync(d_rates, site_rates, n_sites * sizeof(double), hipMemcpyHostToDevice, 0));
+  TRYA(hipMemcpyAsync(d_prior, prior, (size_t)B * SS * sizeof(double), hipMemcpyHostToDevice, 0));
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  if (kernel_ms && rc == CB_OK) {
+    TRYA(hipEventCreate(&ev0));
+    TRYA(hipEventCreate(&ev1));
+    TRYA(hipStreamSynchronize(0));
+    TRYA(hipEventRecord(ev0, 0));
+  }
+  TRYA(hipMemsetAsync(d_live, 0, nmat * sizeof(int), 0));
+  TRYA(hipMemsetAsync(d_counts, 0, ncounts * sizeof(double), 0));
+  if (rc == CB_OK) {
+    if (n_pairs > 0)
+      hipLaunchKernelGGL(siterm_raw_counts_kernel, dim3((unsigned)((n_pairs + 3) / 4)), dim3(256), 0, 0, S, B, n_sites,
+                         (const double *)d_grid, (const int8_t *)d_seqs, (const cb_count_pair *)d_pairs,
+                         (long long)n_pairs, d_counts, (int *)d_live);
+    hipLaunchKernelGGL(siterm_mix_kernel, dim3((unsigned)nmat), dim3(64), 0, 0, S, B, (const double *)d_grid,
+                       (const double *)d_rates, (const double *)d_prior, lambda, include_reverse,
+                       (const int *)d_live, d_counts);
+    TRYA(hipGetLastError());
+  }
+  if (kernel_ms && rc == CB_OK) {
+    float ms = 0.f;
+    TRYA(hipEventRecord(ev1, 0));
+    TRYA(hipEventSynchronize(ev1));
+    TRYA(hipEventElapsedTime(&ms, ev0, ev1));
+    *kernel_ms = ms;
+  }
+  if (ev0) (void)hipEventDestroy(ev0);
+  if (ev1) (void)hipEventDestroy(ev1);
+  if (!(flags & CB_PTR_DEVICE)) TRYA(hipMemcpyAsync(counts, d_counts, ncounts * sizeof(double), hipMemcpyDeviceToHost, 0));
+  TRYA(hipStreamSynchronize(0));
+#undef TRYA
+  for (void *q : {d_grid, d_seqs, d_pairs, d_rates, d_prior, d_live, d_counts_own})
+    if (q) (void)hipFree(q);
+  return rc;
+}

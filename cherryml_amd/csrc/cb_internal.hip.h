@@ -1,0 +1,52 @@
+// Shared by the translation units of libcherrybank: error reporting and small host-side helpers.
+// (cherrybank.hip: handle, bank entry points, trainers; cb_counting.hip; cb_ble.hip; cb_likelihood.hip;
+// cb_host_io.hip.)
+#pragma once
+#include "../../include/cherrybank.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+// sets the thread-local message cb_last_error() returns; returns `code` (defined in cherrybank.hip)
+int cb_fail(int code, const char *fmt, ...);
+#define fail cb_fail
+
+#define HIP_TRY(expr)                                                                   \
+  do {                                                                                  \
+    hipError_t e_ = (expr);                                                             \
+    if (e_ != hipSuccess)                                                               \
+      return fail(e_ == hipErrorOutOfMemory ? CB_ENOMEM : CB_EHIP, "%s failed: %s (%s:%d)", \
+                  #expr, hipGetErrorString(e_), __FILE__, __LINE__);                    \
+  } while (0)
+
+// device buffers of one call of the per-family entry points (uploaded on the default stream, freed on return)
+struct CbDevBufs {
+  std::vector<void *> ptrs;
+  ~CbDevBufs() {
+    for (void *p : ptrs)
+      if (p) (void)hipFree(p);
+  }
+  template <typename T>
+  T *up(const T *host, size_t count, int &rc) {
+    void *q = nullptr;
+    if (rc != CB_OK) return nullptr;
+    if (hipMalloc(&q, (count ? count : 1) * sizeof(T)) != hipSuccess) {
+      rc = fail(CB_ENOMEM, "device allocation failed");
+      return nullptr;
+    }
+    ptrs.push_back(q);
+    if (host && count && hipMemcpyAsync(q, host, count * sizeof(T), hipMemcpyHostToDevice, 0) != hipSuccess)
+      rc = fail(CB_EHIP, "upload failed");
+    return static_cast<T *>(q);
+  }
+};

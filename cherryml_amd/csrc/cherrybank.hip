@@ -1,18 +1,5 @@
 // libcherrybank: C ABI (include/cherrybank.h) over the gfx950 kernels.
-#include "../../include/cherrybank.h"
-
-#include <hip/hip_runtime.h>
-
-#include <algorithm>
-#include <atomic>
-#include <chrono>
-#include <cmath>
-#include <cstdarg>
-#include <cstdio>
-#include <cstdlib>
-#include <cstring>
-#include <string>
-#include <vector>
+#include "cb_internal.hip.h"
 
 #include "common.hip.h"
 #include "jacobi_block.hip.h"
@@ -22,16 +9,13 @@
 #include "train_small.hip.h"
 #include "train_large.hip.h"
 #include "general_small.hip.h"
-#include "counting.hip.h"
-#include "ble.hip.h"
-#include "likelihood.hip.h"
 
 #define CB_ABI_VERSION 2
 
 // ------------------------------------------------------------------ errors
 static thread_local std::string g_err;
 
-static int fail(int code, const char *fmt, ...) {
+int cb_fail(int code, const char *fmt, ...) {
   char buf[512];
   va_list ap;
   va_start(ap, fmt);
@@ -40,14 +24,6 @@ static int fail(int code, const char *fmt, ...) {
   g_err = buf;
   return code;
 }
-
-#define HIP_TRY(expr)                                                                   \
-  do {                                                                                  \
-    hipError_t e_ = (expr);                                                             \
-    if (e_ != hipSuccess)                                                               \
-      return fail(e_ == hipErrorOutOfMemory ? CB_ENOMEM : CB_EHIP, "%s failed: %s (%s:%d)", \
-                  #expr, hipGetErrorString(e_), __FILE__, __LINE__);                    \
-  } while (0)
 
 // ------------------------------------------------------------------ handle
 struct cb_bank {
@@ -1447,719 +1423,3 @@ static int read_phase_times(cb_bank *h, double (&v)[CB_T_COUNT]) {
   }
   return CB_OK;
 }
-
-// ------------------------------------------------------------------------ counting
-// Replica scratch of the resident (device-pointer) form, kept per device for the life of the
-// process (the only process-wide state of the library; never holds results between calls).
-static int count_scratch(int device, size_t elems, unsigned long long **out) {
-  static unsigned long long *buf[64] = {};
-  static size_t cap[64] = {};
-  if (device < 0 || device >= 64) return fail(CB_EINVAL, "counting: device %d out of range", device);
-  if (cap[device] < elems) {
-    if (buf[device]) (void)hipFree(buf[device]);
-    buf[device] = nullptr;
-    cap[device] = 0;
-    hipError_t e = hipMalloc((void **)&buf[device], elems * sizeof(unsigned long long));
-    if (e != hipSuccess) return fail(CB_ENOMEM, "counting: replica scratch allocation failed");
-    cap[device] = elems;
-  }
-  *out = buf[device];
-  return CB_OK;
-}
-
-// device-pointer launch of the single-site counter: adds into counts[B*S*S].
-// max_sites = largest pair.n (0 = unknown -> replica path).
-static int launch_count_transitions(int device, int S, int B, const double *grid, const int8_t *seqs,
-                                    const double *rates, const cb_count_pair *pairs, int64_t n_pairs,
-                                    int symmetric, int max_sites, unsigned long long *counts) {
-  const size_t nb = (size_t)B * S * S;
-  const int words = (int)((nb + 1) / 2);
-  const size_t lds = (size_t)((words + 1) & ~1) * sizeof(unsigned) + (size_t)B * sizeof(double);
-  int chunk = max_sites > 0 ? 65535 / (2 * max_sites) : 0;
-  if (chunk >= 8 && lds <= 150 * 1024) {
-    // keep at least ~2 workgroups per CU worth of slabs when there is enough work
-    const int64_t want = (n_pairs + 511) / 512;
-    if (want < chunk) chunk = (int)(want > 8 ? want : 8);
-    const int64_t nwg = (n_pairs + chunk - 1) / chunk;
-    unsigned long long *scratch = nullptr;
-    int rc = count_scratch(device, ((size_t)nwg * words + 1) / 2 + 1, &scratch);
-    if (rc != CB_OK) return rc;
-    unsigned *slabs = reinterpret_cast<unsigned *>(scratch);
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(count_transitions_lds_kernel),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(count_transitions_lds_kernel, dim3((unsigned)nwg), dim3(CNT_LDS_THREADS), lds, 0, S, B,
-                       grid, seqs, rates, pairs, (long long)n_pairs, symmetric, chunk, slabs, words);
-    hipLaunchKernelGGL(count_reduce_slabs, dim3((unsigned)((words + 63) / 64)), dim3(256), 0, 0, slabs, (int)nwg,
-                       words, nb, counts);
-  } else {
-    unsigned long long *rep = nullptr;
-    int rc = count_scratch(device, nb * CNT_REPLICAS, &rep);
-    if (rc != CB_OK) return rc;
-    HIP_TRY(hipMemsetAsync(rep, 0, nb * CNT_REPLICAS * sizeof(unsigned long long), 0));
-    const unsigned blocks = (unsigned)((n_pairs + 3) / 4);
-    hipLaunchKernelGGL(count_transitions_kernel, dim3(blocks), dim3(256), 0, 0, S, B, grid, seqs, rates, pairs,
-                       (long long)n_pairs, symmetric, rep, CNT_REPLICAS);
-    hipLaunchKernelGGL(count_reduce_replicas, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, 0, rep,
-                       CNT_REPLICAS, nb, counts);
-  }
-  HIP_TRY(hipGetLastError());
-  return CB_OK;
-}
-
-static int count_common(int device, int S, int B, const double *grid, const int8_t *seqs,
-                        int64_t seqs_bytes, const void *aux, size_t aux_bytes,
-                        const cb_count_pair *pairs, int64_t n_pairs, int symmetric, int flags,
-                        unsigned long long *counts, bool co) {
-  if (S < 1 || B < 1 || !grid || !counts) return fail(CB_EINVAL, "counting: bad S/B/grid/counts");
-  if (flags & CB_PTR_DEVICE) {  // resident form: enqueue only, add into counts
-    if (n_pairs < 0 || (n_pairs > 0 && (!pairs || !seqs))) return fail(CB_EINVAL, "counting: bad pairs");
-    HIP_TRY(hipSetDevice(device));
-    if (n_pairs > 0) {
-      const unsigned blocks = (unsigned)((n_pairs + 3) / 4);
-      if (co)
-        hipLaunchKernelGGL(count_co_transitions_kernel, dim3(blocks), dim3(256), 0, 0, S, B, grid, seqs,
-                           (const int32_t *)aux, pairs, (long long)n_pairs, symmetric, counts);
-      else {
-        // resident form: the caller states the largest pair.n in flags bits 8..23 (0 = unknown)
-        int rc = launch_count_transitions(device, S, B, grid, seqs, (const double *)aux, pairs, n_pairs,
-                                          symmetric, (flags >> 8) & 0xFFFF, counts);
-        if (rc != CB_OK) return rc;
-      }
-      HIP_TRY(hipGetLastError());
-    }
-    return CB_OK;
-  }
-  if (n_pairs < 0 || (n_pairs > 0 && (!pairs || !seqs))) return fail(CB_EINVAL, "counting: bad pairs");
-  for (int b = 1; b < B; ++b)
-    if (!(grid[b] > grid[b - 1])) return fail(CB_EINVAL, "counting: quantization points must be sorted");
-  int ndev = cb_device_count();
-  if (ndev <= 0) return fail(CB_EHIP, "counting: no HIP device visible");
-  if (device < 0 || device >= ndev) return fail(CB_EINVAL, "counting: device %d out of range", device);
-  // validate offsets on the host: the kernels trust them
-  const size_t nbins = co ? (size_t)B * S * S * S * S : (size_t)B * S * S;
-  for (int64_t p = 0; p < n_pairs; ++p) {
-    const cb_count_pair &pr = pairs[p];
-    const int64_t span = co ? 1 : pr.n;  // co: sites are indexed through the contact list
-    if (pr.n < 0 || pr.seq_a < 0 || pr.seq_b < 0 || pr.aux < 0 || pr.seq_a + span > seqs_bytes ||
-        pr.seq_b + span > seqs_bytes)
-      return fail(CB_EINVAL, "counting: pair %lld has offsets outside the sequence buffer", (long long)p);
-    const size_t need = co ? ((size_t)pr.aux + pr.n) * 2 * sizeof(int32_t) : ((size_t)pr.aux + pr.n) * sizeof(double);
-    if (need > aux_bytes) return fail(CB_EINVAL, "counting: pair %lld reads past its rates/contacts", (long long)p);
-  }
-  HIP_TRY(hipSetDevice(device));
-  double *d_grid = nullptr;
-  int8_t *d_seqs = nullptr;
-  void *d_aux = nullptr;
-  cb_count_pair *d_pairs = nullptr;
-  unsigned long long *d_counts = nullptr;
-  int rc = CB_OK;
-  auto freeall = [&]() {
-    (void)hipFree(d_grid); (void)hipFree(d_seqs); (void)hipFree(d_aux); (void)hipFree(d_pairs); (void)hipFree(d_counts);
-  };
-#define TRYC(expr)                                                                       \
-  if (rc == CB_OK) {                                                                     \
-    hipError_t e_ = (expr);                                                              \
-    if (e_ != hipSuccess) rc = fail(e_ == hipErrorOutOfMemory ? CB_ENOMEM : CB_EHIP, "%s failed: %s", #expr, hipGetErrorString(e_)); \
-  }
-  TRYC(hipMalloc((void **)&d_grid, B * sizeof(double)));
-  TRYC(hipMalloc((void **)&d_seqs, seqs_bytes > 0 ? seqs_bytes : 1));
-  TRYC(hipMalloc(&d_aux, aux_bytes > 0 ? aux_bytes : 1));
-  TRYC(hipMalloc((void **)&d_pairs, (n_pairs > 0 ? n_pairs : 1) * sizeof(cb_count_pair)));
-  TRYC(hipMalloc((void **)&d_counts, nbins * sizeof(unsigned long long)));
-  TRYC(hipMemcpy(d_grid, grid, B * sizeof(double), hipMemcpyHostToDevice));
-  if (seqs_bytes > 0) TRYC(hipMemcpy(d_seqs, seqs, seqs_bytes, hipMemcpyHostToDevice));
-  if (aux_bytes > 0) TRYC(hipMemcpy(d_aux, aux, aux_bytes, hipMemcpyHostToDevice));
-  if (n_pairs > 0) TRYC(hipMemcpy(d_pairs, pairs, n_pairs * sizeof(cb_count_pair), hipMemcpyHostToDevice));
-  TRYC(hipMemset(d_counts, 0, nbins * sizeof(unsigned long long)));
-  if (rc == CB_OK && n_pairs > 0) {
-    const unsigned blocks = (unsigned)((n_pairs + 3) / 4);
-    if (co)
-      hipLaunchKernelGGL(count_co_transitions_kernel, dim3(blocks), dim3(256), 0, 0, S, B, d_grid, d_seqs,
-                         (const int32_t *)d_aux, d_pairs, (long long)n_pairs, symmetric, d_counts);
-    else {
-      int max_sites = 0;
-      for (int64_t p = 0; p < n_pairs; ++p) max_sites = pairs[p].n > max_sites ? pairs[p].n : max_sites;
-      if (rc == CB_OK)
-        rc = launch_count_transitions(device, S, B, d_grid, d_seqs, (const double *)d_aux, d_pairs, n_pairs,
-                                      symmetric, max_sites < 32768 ? max_sites : 0, d_counts);
-    }
-    TRYC(hipGetLastError());
-    TRYC(hipDeviceSynchronize());
-  }
-  TRYC(hipMemcpy(counts, d_counts, nbins * sizeof(unsigned long long), hipMemcpyDeviceToHost));
-#undef TRYC
-  freeall();
-  return rc;
-}
-
-extern "C" int cb_count_transitions(int device, int S, int B, const double *grid, const int8_t *seqs,
-                                    int64_t seqs_bytes, const double *rates, int64_t n_rates,
-                                    const cb_count_pair *pairs, int64_t n_pairs, int symmetric,
-                                    int flags, unsigned long long *counts) {
-  if (S > 127) return fail(CB_EINVAL, "cb_count_transitions: at most 127 states (int8 codes)");
-  return count_common(device, S, B, grid, seqs, seqs_bytes, rates, (size_t)(n_rates > 0 ? n_rates : 0) * sizeof(double),
-                      pairs, n_pairs, symmetric, flags, counts, false);
-}
-
-extern "C" int cb_count_co_transitions(int device, int S, int B, const double *grid, const int8_t *seqs,
-                                       int64_t seqs_bytes, const int32_t *contacts, int64_t n_contacts,
-                                       const cb_count_pair *pairs, int64_t n_pairs, int symmetric,
-                                       int flags, unsigned long long *counts) {
-  if (S > 127) return fail(CB_EINVAL, "cb_count_co_transitions: at most 127 states (int8 codes)");
-  // contact indices must address sites inside the sequences: checked per pair on the host
-  for (int64_t p = 0; !(flags & CB_PTR_DEVICE) && p < n_pairs && pairs && contacts; ++p) {
-    const cb_count_pair &pr = pairs[p];
-    if (pr.aux < 0 || pr.n < 0 || pr.aux + pr.n > n_contacts)
-      return fail(CB_EINVAL, "cb_count_co_transitions: pair %lld contact range outside the list", (long long)p);
-    for (int c = 0; c < pr.n; ++c) {
-      const int32_t i = contacts[2 * (pr.aux + c)], j = contacts[2 * (pr.aux + c) + 1];
-      if (i < 0 || j < 0 || pr.seq_a + i >= seqs_bytes || pr.seq_a + j >= seqs_bytes ||
-          pr.seq_b + i >= seqs_bytes || pr.seq_b + j >= seqs_bytes)
-        return fail(CB_EINVAL, "cb_count_co_transitions: contact site outside the sequence buffer");
-    }
-  }
-  return count_common(device, S, B, grid, seqs, seqs_bytes, contacts,
-                      (size_t)(n_contacts > 0 ? n_contacts : 0) * 2 * sizeof(int32_t), pairs, n_pairs, symmetric,
-                      flags, counts, true);
-}
-
-extern "C" int cb_siterm_assemble(int device, int S, int B, int n_sites, const double *grid, const int8_t *seqs,
-                                  int64_t seqs_bytes, const cb_count_pair *pairs, int64_t n_pairs,
-                                  const double *site_rates, const double *prior, double lambda,
-                                  int include_reverse, int flags, double *counts, double *kernel_ms) {
-  if (!grid || !seqs || !pairs || !site_rates || !prior || !counts)
-    return fail(CB_EINVAL, "cb_siterm_assemble: NULL argument");
-  if (S < 2 || S > 64 || B < 1 || n_sites < 1 || n_pairs < 0 || seqs_bytes < 0)
-    return fail(CB_EINVAL, "cb_siterm_assemble: bad sizes (S=%d, B=%d, n_sites=%d)", S, B, n_sites);
-  if (!(lambda >= 0.0 && lambda <= 1.0)) return fail(CB_EINVAL, "cb_siterm_assemble: lambda must be in [0, 1]");
-  for (int b = 1; b < B; ++b)
-    if (!(grid[b] > grid[b - 1])) return fail(CB_EINVAL, "cb_siterm_assemble: grid must be strictly increasing");
-  for (int64_t p = 0; p < n_pairs; ++p)
-    if (pairs[p].seq_a < 0 || pairs[p].seq_b < 0 || pairs[p].seq_a + n_sites > seqs_bytes ||
-        pairs[p].seq_b + n_sites > seqs_bytes)
-      return fail(CB_EINVAL, "cb_siterm_assemble: pair %lld points outside seqs", (long long)p);
-  const int ndev = cb_device_count();
-  if (ndev <= 0) return fail(CB_EHIP, "cb_siterm_assemble: no HIP device visible");
-  if (device < 0 || device >= ndev) return fail(CB_EINVAL, "cb_siterm_assemble: device %d out of range", device);
-  HIP_TRY(hipSetDevice(device));
-  const size_t SS = (size_t)S * S, nmat = (size_t)n_sites * B, ncounts = nmat * SS;
-  void *d_grid = nullptr, *d_seqs = nullptr, *d_pairs = nullptr, *d_rates = nullptr, *d_prior = nullptr,
-       *d_live = nullptr, *d_counts_own = nullptr;
-  int rc = CB_OK;
-#define TRYA(expr) \
-  if (rc == CB_OK && (expr) != hipSuccess) rc = fail(CB_EHIP, "cb_siterm_assemble: %s failed", #expr)
-  TRYA(hipMalloc(&d_grid, B * sizeof(double)));
-  TRYA(hipMalloc(&d_seqs, seqs_bytes > 0 ? seqs_bytes : 1));
-  TRYA(hipMalloc(&d_pairs, (n_pairs > 0 ? n_pairs : 1) * sizeof(cb_count_pair)));
-  TRYA(hipMalloc(&d_rates, n_sites * sizeof(double)));
-  TRYA(hipMalloc(&d_prior, (size_t)B * SS * sizeof(double)));
-  TRYA(hipMalloc(&d_live, nmat * sizeof(int)));
-  double *d_counts = counts;
-  if (!(flags & CB_PTR_DEVICE)) {
-    TRYA(hipMalloc(&d_counts_own, ncounts * sizeof(double)));
-    d_counts = static_cast<double *>(d_counts_own);
-  }
-  TRYA(hipMemcpyAsync(d_grid, grid, B * sizeof(double), hipMemcpyHostToDevice, 0));
-  TRYA(hipMemcpyAsync(d_seqs, seqs, seqs_bytes, hipMemcpyHostToDevice, 0));
-  TRYA(hipMemcpyAsync(d_pairs, pairs, n_pairs * sizeof(cb_count_pair), hipMemcpyHostToDevice, 0));
-  TRYA(hipMemcpyAsync(d_rates, site_rates, n_sites * sizeof(double), hipMemcpyHostToDevice, 0));
-  TRYA(hipMemcpyAsync(d_prior, prior, (size_t)B * SS * sizeof(double), hipMemcpyHostToDevice, 0));
-  hipEvent_t ev0 = nullptr, ev1 = nullptr;
-  if (kernel_ms && rc == CB_OK) {
-    TRYA(hipEventCreate(&ev0));
-    TRYA(hipEventCreate(&ev1));
-    TRYA(hipStreamSynchronize(0));
-    TRYA(hipEventRecord(ev0, 0));
-  }
-  TRYA(hipMemsetAsync(d_live, 0, nmat * sizeof(int), 0));
-  TRYA(hipMemsetAsync(d_counts, 0, ncounts * sizeof(double), 0));
-  if (rc == CB_OK) {
-    if (n_pairs > 0)
-      hipLaunchKernelGGL(siterm_raw_counts_kernel, dim3((unsigned)((n_pairs + 3) / 4)), dim3(256), 0, 0, S, B, n_sites,
-                         (const double *)d_grid, (const int8_t *)d_seqs, (const cb_count_pair *)d_pairs,
-                         (long long)n_pairs, d_counts, (int *)d_live);
-    hipLaunchKernelGGL(siterm_mix_kernel, dim3((unsigned)nmat), dim3(64), 0, 0, S, B, (const double *)d_grid,
-                       (const double *)d_rates, (const double *)d_prior, lambda, include_reverse,
-                       (const int *)d_live, d_counts);
-    TRYA(hipGetLastError());
-  }
-  if (kernel_ms && rc == CB_OK) {
-    float ms = 0.f;
-    TRYA(hipEventRecord(ev1, 0));
-    TRYA(hipEventSynchronize(ev1));
-    TRYA(hipEventElapsedTime(&ms, ev0, ev1));
-    *kernel_ms = ms;
-  }
-  if (ev0) (void)hipEventDestroy(ev0);
-  if (ev1) (void)hipEventDestroy(ev1);
-  if (!(flags & CB_PTR_DEVICE)) TRYA(hipMemcpyAsync(counts, d_counts, ncounts * sizeof(double), hipMemcpyDeviceToHost, 0));
-  TRYA(hipStreamSynchronize(0));
-#undef TRYA
-  for (void *q : {d_grid, d_seqs, d_pairs, d_rates, d_prior, d_live, d_counts_own})
-    if (q) (void)hipFree(q);
-  return rc;
-}
-
-// ----------------------------------------------------------------- FastCherries BLE (8f #3)
-extern "C" int cb_ble_log_bank(int device, int S, int T, int R, const double *Q, const double *pi,
-                               const double *grid, const double *rates, double *logP) {
-  if (!Q || !grid || !rates || !logP) return fail(CB_EINVAL, "cb_ble_log_bank: NULL argument");
-  if (S < 2 || T < 1 || R < 1) return fail(CB_EINVAL, "cb_ble_log_bank: bad sizes");
-  const size_t nb = (size_t)T * R, SS = (size_t)S * S;
-  std::vector<double> tt(nb), ones(nb * SS, 1.0);
-  for (int t = 0; t < T; ++t)
-    for (int r = 0; r < R; ++r) tt[(size_t)t * R + r] = grid[t] * rates[r];   // as io_helpers.cpp:161
-  cb_handle h = nullptr;
-  int rc = cb_create(device, S, 1, (int)nb, CB_F64, tt.data(), ones.data(), 0, &h);
-  if (rc != CB_OK) return rc;
-  rc = cb_expm_bank(h, Q, pi, 0, logP);
-  cb_destroy(h);
-  if (rc != CB_OK) return rc;
-  for (size_t i = 0; i < nb * SS; ++i) logP[i] = std::log(logP[i]);
-  return CB_OK;
-}
-
-namespace {
-struct BleDev {
-  std::vector<void *> ptrs;
-  ~BleDev() {
-    for (void *p : ptrs)
-      if (p) (void)hipFree(p);
-  }
-  template <typename T>
-  T *up(const T *host, size_t count, int &rc) {
-    void *q = nullptr;
-    if (rc != CB_OK) return nullptr;
-    if (hipMalloc(&q, (count ? count : 1) * sizeof(T)) != hipSuccess) {
-      rc = fail(CB_ENOMEM, "ble: device allocation failed");
-      return nullptr;
-    }
-    ptrs.push_back(q);
-    if (host && count && hipMemcpyAsync(q, host, count * sizeof(T), hipMemcpyHostToDevice, 0) != hipSuccess)
-      rc = fail(CB_EHIP, "ble: upload failed");
-    return static_cast<T *>(q);
-  }
-};
-std::vector<int8_t> ble_transposed(const int8_t *c, int n, int L) {
-  std::vector<int8_t> t((size_t)n * L);
-  for (int i = 0; i < n; ++i)
-    for (int s = 0; s < L; ++s) t[(size_t)s * n + i] = c[(size_t)i * L + s];
-  return t;
-}
-int ble_check(int device, int S, int T, int R, int n, int L, const int8_t *cx, const int8_t *cy) {
-  if (S < 2 || S > 127 || T < 1 || R < 1 || n < 1 || L < 1) return fail(CB_EINVAL, "ble: bad sizes");
-  const int ndev = cb_device_count();
-  if (ndev <= 0) return fail(CB_EHIP, "ble: no HIP device visible");
-  if (device < 0 || device >= ndev) return fail(CB_EINVAL, "ble: device %d out of range", device);
-  for (size_t i = 0; i < (size_t)n * L; ++i)
-    if (cx[i] >= S || cy[i] >= S) return fail(CB_EINVAL, "ble: state code out of range");
-  return CB_OK;
-}
-}  // namespace
-
-extern "C" int cb_ble_branch_lengths(int device, int S, int T, int R, const double *logP, const int8_t *cx,
-                                     const int8_t *cy, int n, int L, const int *site_to_rate, int *lengths_index) {
-  if (!logP || !cx || !cy || !site_to_rate || !lengths_index) return fail(CB_EINVAL, "cb_ble_branch_lengths: NULL argument");
-  int rc = ble_check(device, S, T, R, n, L, cx, cy);
-  if (rc != CB_OK) return rc;
-  for (int i = 0; i < L; ++i)
-    if (site_to_rate[i] < 0 || site_to_rate[i] >= R) return fail(CB_EINVAL, "cb_ble_branch_lengths: rate index out of range");
-  HIP_TRY(hipSetDevice(device));
-  BleDev d;
-  const double *dP = d.up(logP, (size_t)T * R * S * S, rc);
-  const int8_t *dx = d.up(cx, (size_t)n * L, rc), *dy = d.up(cy, (size_t)n * L, rc);
-  const int *ds = d.up(site_to_rate, L, rc);
-  int *dout = d.up<int>(nullptr, n, rc);
-  if (rc != CB_OK) return rc;
-  hipLaunchKernelGGL(ble_branch_lengths_kernel, dim3((n + 3) / 4), dim3(256), 0, 0, S, T, R, n, L, dP, dx, dy, ds,
-                     (const int *)nullptr, dout, (int *)nullptr);
-  HIP_TRY(hipGetLastError());
-  HIP_TRY(hipMemcpy(lengths_index, dout, n * sizeof(int), hipMemcpyDeviceToHost));
-  return CB_OK;
-}
-
-extern "C" int cb_ble_site_rates(int device, int S, int T, int R, const double *logP, const int8_t *cx,
-                                 const int8_t *cy, int n, int L, const int *lengths_index, const double *priors,
-                                 int *rate_index) {
-  if (!logP || !cx || !cy || !lengths_index || !priors || !rate_index) return fail(CB_EINVAL, "cb_ble_site_rates: NULL argument");
-  int rc = ble_check(device, S, T, R, n, L, cx, cy);
-  if (rc != CB_OK) return rc;
-  for (int i = 0; i < n; ++i)
-    if (lengths_index[i] < 0 || lengths_index[i] >= T) return fail(CB_EINVAL, "cb_ble_site_rates: length index out of range");
-  HIP_TRY(hipSetDevice(device));
-  BleDev d;
-  const std::vector<int8_t> xT = ble_transposed(cx, n, L), yT = ble_transposed(cy, n, L);
-  const double *dP = d.up(logP, (size_t)T * R * S * S, rc), *dpr = d.up(priors, R, rc);
-  const int8_t *dxT = d.up(xT.data(), (size_t)n * L, rc), *dyT = d.up(yT.data(), (size_t)n * L, rc);
-  const int *dl = d.up(lengths_index, n, rc);
-  int *dout = d.up<int>(nullptr, L, rc);
-  if (rc != CB_OK) return rc;
-  HIP_TRY(hipStreamSynchronize(0));  // xT / yT are locals
-  hipLaunchKernelGGL(ble_site_rates_kernel, dim3((L + 3) / 4), dim3(256), 0, 0, S, T, R, n, L, dP, dxT, dyT, dl, dpr, dout);
-  HIP_TRY(hipGetLastError());
-  HIP_TRY(hipMemcpy(rate_index, dout, L * sizeof(int), hipMemcpyDeviceToHost));
-  return CB_OK;
-}
-
-// initial site-rate bins (branch_length_estimation.cpp:10-58): sites ordered by the number of
-// differing sequence pairs (ties: site index); the i-th site of that order gets category rc,
-// rc advancing while i >= round(weights[rc] * L)
-static int ble_initial_bins(const int8_t *all_seqs, int n_seqs, int L, int S, int R, const double *weights, int *s2r) {
-  std::vector<long long> cnt((size_t)L * S, 0);
-  for (int i = 0; i < n_seqs; ++i)
-    for (int j = 0; j < L; ++j) {
-      const int v = all_seqs[(size_t)i * L + j];
-      if (v >= S) return fail(CB_EINVAL, "cb_ble: state code out of range");
-      if (v >= 0) cnt[(size_t)j * S + v] += 1;
-    }
-  std::vector<std::pair<long long, int>> order(L);
-  for (int j = 0; j < L; ++j) {
-    long long non_missing = 0, total = 0;
-    for (int k = 0; k < S; ++k) non_missing += cnt[(size_t)j * S + k];
-    for (int k = 0; k < S; ++k) total += (non_missing - cnt[(size_t)j * S + k]) * cnt[(size_t)j * S + k];
-    order[j] = {total, j};
-  }
-  std::sort(order.begin(), order.end());
-  std::vector<long long> w(R);
-  for (int r = 0; r < R; ++r) w[r] = (long long)std::llround(weights[r] * L);
-  int cat = 0;
-  for (int i = 0; i < L; ++i) {
-    if (cat < R && i >= w[cat]) ++cat;
-    s2r[order[i].second] = cat < R ? cat : R - 1;
-  }
-  return CB_OK;
-}
-
-extern "C" int cb_ble(int device, int S, int T, int R, const double *logP, const int8_t *cx, const int8_t *cy, int n,
-                      int L, const int8_t *all_seqs, int n_seqs, const double *rates, const double *weights,
-                      int max_iters, int *lengths_index, int *rate_index, int *iterations, double *kernel_ms) {
-  if (!logP || !cx || !cy || !all_seqs || !rates || !weights || !lengths_index || !rate_index)
-    return fail(CB_EINVAL, "cb_ble: NULL argument");
-  int rc = ble_check(device, S, T, R, n, L, cx, cy);
-  if (rc != CB_OK) return rc;
-  if (n_seqs < 1 || max_iters < 0) return fail(CB_EINVAL, "cb_ble: bad sizes");
-  std::vector<int> s2r(L, 0);
-  if ((rc = ble_initial_bins(all_seqs, n_seqs, L, S, R, weights, s2r.data())) != CB_OK) return rc;
-  std::vector<double> priors(R);
-  for (int r = 0; r < R; ++r) priors[r] = 2 * std::log(rates[r]) - 3 * rates[r];   // :199-203
-  HIP_TRY(hipSetDevice(device));
-  BleDev d;
-  const double *dP = d.up(logP, (size_t)T * R * S * S, rc), *dpr = d.up(priors.data(), R, rc);
-  const std::vector<int8_t> xT = ble_transposed(cx, n, L), yT = ble_transposed(cy, n, L);
-  const int8_t *dx = d.up(cx, (size_t)n * L, rc), *dy = d.up(cy, (size_t)n * L, rc);
-  const int8_t *dxT = d.up(xT.data(), (size_t)n * L, rc), *dyT = d.up(yT.data(), (size_t)n * L, rc);
-  int *ds = d.up(s2r.data(), L, rc);
-  int *dl0 = d.up<int>(nullptr, n, rc), *dl1 = d.up<int>(nullptr, n, rc), *dflag = d.up<int>(nullptr, 1, rc);
-  if (rc != CB_OK) return rc;
-  const dim3 gb((n + 3) / 4), gs((L + 3) / 4), blk(256);
-  hipEvent_t ev0 = nullptr, ev1 = nullptr;
-  if (kernel_ms) {
-    HIP_TRY(hipEventCreate(&ev0));
-    HIP_TRY(hipEventCreate(&ev1));
-    HIP_TRY(hipStreamSynchronize(0));  // uploads done: the timed region starts with resident inputs
-    HIP_TRY(hipEventRecord(ev0, 0));
-  }
-  hipLaunchKernelGGL(ble_branch_lengths_kernel, gb, blk, 0, 0, S, T, R, n, L, dP, dx, dy, (const int *)ds,
-                     (const int *)nullptr, dl0, (int *)nullptr);
-  bool match = false;
-  int iters = 0;
-  while (!match && max_iters) {
-    ++iters;
-    HIP_TRY(hipMemsetAsync(dflag, 0, sizeof(int), 0));
-    hipLaunchKernelGGL(ble_site_rates_kernel, gs, blk, 0, 0, S, T, R, n, L, dP, dxT, dyT, (const int *)dl0, dpr, ds);
-    hipLaunchKernelGGL(ble_branch_lengths_kernel, gb, blk, 0, 0, S, T, R, n, L, dP, dx, dy, (const int *)ds,
-                       (const int *)dl0, dl1, dflag);
-    int flag = 0;
-    HIP_TRY(hipMemcpy(&flag, dflag, sizeof flag, hipMemcpyDeviceToHost));
-    match = flag == 0;
-    std::swap(dl0, dl1);
-    --max_iters;
-  }
-  if (kernel_ms) {
-    float ms = 0.f;
-    HIP_TRY(hipEventRecord(ev1, 0));
-    HIP_TRY(hipEventSynchronize(ev1));
-    HIP_TRY(hipEventElapsedTime(&ms, ev0, ev1));
-    *kernel_ms = ms;
-    (void)hipEventDestroy(ev0);
-    (void)hipEventDestroy(ev1);
-  }
-  if (iterations) *iterations = iters;
-  HIP_TRY(hipGetLastError());
-  HIP_TRY(hipMemcpy(lengths_index, dl0, n * sizeof(int), hipMemcpyDeviceToHost));
-  HIP_TRY(hipMemcpy(rate_index, ds, L * sizeof(int), hipMemcpyDeviceToHost));
-  return CB_OK;
-}
-
-// Many families in one call (the reference maps families over a process pool, utils.py:59-67): the
-// log-transition bank is uploaded ONCE, all sequences in one transfer, and the coordinate ascents run
-// in lockstep -- per round two launches per still-moving family and ONE read-back of all the
-// convergence flags (cb_ble: a synchronising read-back per family per iteration, and 8 MB of bank per
-// family).  A converged family is a fixed point of the ascent, so results are those of cb_ble.
-extern "C" int cb_ble_batch(int device, int S, int T, int R, const double *logP, int n_fam, const int *n,
-                            const int *L, const int8_t *cx, const int8_t *cy, const int8_t *all_seqs,
-                            const int *n_seqs, const double *rates, const double *weights, int max_iters,
-                            int *lengths_index, int *rate_index, int *iterations, double *kernel_ms) {
-  if (!logP || !n || !L || !cx || !cy || !all_seqs || !n_seqs || !rates || !weights || !lengths_index || !rate_index)
-    return fail(CB_EINVAL, "cb_ble_batch: NULL argument");
-  if (n_fam < 1 || max_iters < 0) return fail(CB_EINVAL, "cb_ble_batch: bad sizes");
-  std::vector<size_t> off_c(n_fam + 1, 0), off_n(n_fam + 1, 0), off_L(n_fam + 1, 0), off_s(n_fam + 1, 0);
-  for (int f = 0; f < n_fam; ++f) {
-    if (n[f] < 1 || L[f] < 1 || n_seqs[f] < 1) return fail(CB_EINVAL, "cb_ble_batch: family %d has bad sizes", f);
-    off_c[f + 1] = off_c[f] + (size_t)n[f] * L[f];
-    off_n[f + 1] = off_n[f] + n[f];
-    off_L[f + 1] = off_L[f] + L[f];
-    off_s[f + 1] = off_s[f] + (size_t)n_seqs[f] * L[f];
-  }
-  int rc = CB_OK;
-  std::vector<int> s2r(off_L[n_fam], 0);
-  std::vector<int8_t> xT(off_c[n_fam]), yT(off_c[n_fam]);
-  for (int f = 0; f < n_fam; ++f) {
-    if ((rc = ble_check(device, S, T, R, n[f], L[f], cx + off_c[f], cy + off_c[f])) != CB_OK) return rc;
-    if ((rc = ble_initial_bins(all_seqs + off_s[f], n_seqs[f], L[f], S, R, weights, s2r.data() + off_L[f])) != CB_OK) return rc;
-    for (int i = 0; i < n[f]; ++i)
-      for (int k = 0; k < L[f]; ++k) {
-        xT[off_c[f] + (size_t)k * n[f] + i] = cx[off_c[f] + (size_t)i * L[f] + k];
-        yT[off_c[f] + (size_t)k * n[f] + i] = cy[off_c[f] + (size_t)i * L[f] + k];
-      }
-  }
-  std::vector<double> priors(R);
-  for (int r = 0; r < R; ++r) priors[r] = 2 * std::log(rates[r]) - 3 * rates[r];   // :199-203
-  HIP_TRY(hipSetDevice(device));
-  BleDev d;
-  const double *dP = d.up(logP, (size_t)T * R * S * S, rc), *dpr = d.up(priors.data(), R, rc);
-  const int8_t *dx = d.up(cx, off_c[n_fam], rc), *dy = d.up(cy, off_c[n_fam], rc);
-  const int8_t *dxT = d.up(xT.data(), off_c[n_fam], rc), *dyT = d.up(yT.data(), off_c[n_fam], rc);
-  int *ds = d.up(s2r.data(), off_L[n_fam], rc);
-  int *dl0 = d.up<int>(nullptr, off_n[n_fam], rc), *dl1 = d.up<int>(nullptr, off_n[n_fam], rc);
-  int *dflag = d.up<int>(nullptr, n_fam, rc);
-  if (rc != CB_OK) return rc;
-  hipEvent_t ev0 = nullptr, ev1 = nullptr;
-  if (kernel_ms) {
-    HIP_TRY(hipEventCreate(&ev0));
-    HIP_TRY(hipEventCreate(&ev1));
-    HIP_TRY(hipStreamSynchronize(0));  // uploads done: the timed region starts with resident inputs
-    HIP_TRY(hipEventRecord(ev0, 0));
-  }
-  const dim3 blk(256);
-  // cur[f]: which of the two length buffers holds family f's current lengths
-  std::vector<int *> cur(n_fam), nxt(n_fam);
-  for (int f = 0; f < n_fam; ++f) {
-    cur[f] = dl0 + off_n[f];
-    nxt[f] = dl1 + off_n[f];
-    hipLaunchKernelGGL(ble_branch_lengths_kernel, dim3((n[f] + 3) / 4), blk, 0, 0, S, T, R, n[f], L[f], dP, dx + off_c[f],
-                       dy + off_c[f], (const int *)(ds + off_L[f]), (const int *)nullptr, cur[f], (int *)nullptr);
-  }
-  std::vector<int> active(n_fam), iters(n_fam, 0), flags(n_fam);
-  for (int f = 0; f < n_fam; ++f) active[f] = f;
-  for (int round = 0; round < max_iters && !active.empty(); ++round) {
-    HIP_TRY(hipMemsetAsync(dflag, 0, n_fam * sizeof(int), 0));
-    for (int f : active) {
-      hipLaunchKernelGGL(ble_site_rates_kernel, dim3((L[f] + 3) / 4), blk, 0, 0, S, T, R, n[f], L[f], dP, dxT + off_c[f],
-                         dyT + off_c[f], (const int *)cur[f], dpr, ds + off_L[f]);
-      hipLaunchKernelGGL(ble_branch_lengths_kernel, dim3((n[f] + 3) / 4), blk, 0, 0, S, T, R, n[f], L[f], dP, dx + off_c[f],
-                         dy + off_c[f], (const int *)(ds + off_L[f]), (const int *)cur[f], nxt[f], dflag + f);
-    }
-    HIP_TRY(hipMemcpy(flags.data(), dflag, n_fam * sizeof(int), hipMemcpyDeviceToHost));
-    std::vector<int> still;
-    for (int f : active) {
-      ++iters[f];
-      std::swap(cur[f], nxt[f]);
-      if (flags[f] != 0) still.push_back(f);
-    }
-    active.swap(still);
-  }
-  if (kernel_ms) {
-    float ms = 0.f;
-    HIP_TRY(hipEventRecord(ev1, 0));
-    HIP_TRY(hipEventSynchronize(ev1));
-    HIP_TRY(hipEventElapsedTime(&ms, ev0, ev1));
-    *kernel_ms = ms;
-    (void)hipEventDestroy(ev0);
-    (void)hipEventDestroy(ev1);
-  }
-  HIP_TRY(hipGetLastError());
-  for (int f = 0; f < n_fam; ++f) {
-    HIP_TRY(hipMemcpyAsync(lengths_index + off_n[f], cur[f], n[f] * sizeof(int), hipMemcpyDeviceToHost, 0));
-    if (iterations) iterations[f] = iters[f];
-  }
-  HIP_TRY(hipMemcpyAsync(rate_index, ds, off_L[n_fam] * sizeof(int), hipMemcpyDeviceToHost, 0));
-  HIP_TRY(hipStreamSynchronize(0));
-  return CB_OK;
-}
-
-extern "C" int cb_site_rate_gather(int device, int S, int R, int n, int L, const double *tens, const int8_t *cx,
-                                   const int8_t *cy, const double *log_prior, int *best) {
-  if (!tens || !cx || !cy || !log_prior || !best) return fail(CB_EINVAL, "cb_site_rate_gather: NULL argument");
-  int rc = ble_check(device, S, 1, R, n, L, cx, cy);
-  if (rc != CB_OK) return rc;
-  for (size_t i = 0; i < (size_t)n * L; ++i)
-    if (cx[i] < 0 || cy[i] < 0) return fail(CB_EINVAL, "cb_site_rate_gather: negative state code (map gaps to a state)");
-  HIP_TRY(hipSetDevice(device));
-  BleDev d;
-  const double *dt = d.up(tens, (size_t)R * n * S * S, rc), *dpr = d.up(log_prior, R, rc);
-  const int8_t *dx = d.up(cx, (size_t)n * L, rc), *dy = d.up(cy, (size_t)n * L, rc);
-  int *dout = d.up<int>(nullptr, L, rc);
-  if (rc != CB_OK) return rc;
-  hipLaunchKernelGGL(site_rate_gather_kernel, dim3((L + 3) / 4), dim3(256), 0, 0, S, R, n, L, dt, dx, dy, dpr, dout);
-  HIP_TRY(hipGetLastError());
-  HIP_TRY(hipMemcpy(best, dout, L * sizeof(int), hipMemcpyDeviceToHost));
-  return CB_OK;
-}
-
-
-// ---------------------------------------------------------------- held-out likelihood
-extern "C" int cb_tree_likelihood(int device, int S, int S1, const double *Q, const double *pi_rev,
-                                  const double *pi_root, int n_nodes, const int *postorder, const int *parent,
-                                  const double *length, int n_cats, const double *cat_rate, int n_units,
-                                  const int *unit_cat, const int8_t *code_a, const int8_t *code_b, double *ll,
-                                  double *kernel_ms) {
-  if (!Q || !pi_root || !postorder || !parent || !length || !cat_rate || !unit_cat || !code_a || !ll)
-    return fail(CB_EINVAL, "cb_tree_likelihood: NULL argument");
-  if (S < 2 || S > 16 * TL_NW * TL_MAXT || n_nodes < 1 || n_cats < 1 || n_units < 1)
-    return fail(CB_EINVAL, "cb_tree_likelihood: bad sizes (S = %d, nodes = %d, categories = %d, units = %d)", S,
-                n_nodes, n_cats, n_units);
-  if (S1 < 0 || (S1 > 0 && (S1 * S1 != S || !code_b)))
-    return fail(CB_EINVAL, "cb_tree_likelihood: pair model needs S = S1 * S1 and code_b");
-  if (S > 64 && n_cats != 1)
-    return fail(CB_EUNSUPPORTED, "cb_tree_likelihood: S > 64 takes one rate category (the reference evaluates pairs "
-                "of sites at rate 1, _likelihood.py:214-230)");
-  const int ndev = cb_device_count();
-  if (ndev <= 0) return fail(CB_EHIP, "cb_tree_likelihood: no HIP device (this path has no CPU fallback)");
-  if (device < 0 || device >= ndev) return fail(CB_EINVAL, "cb_tree_likelihood: device %d of %d", device, ndev);
-  // ---- tree: heights, levels, children in post-order (= the reference's child order, _tree.py traversal)
-  const int root = postorder[n_nodes - 1];
-  std::vector<int> height(n_nodes, 0), nchild(n_nodes, 0), seen(n_nodes, 0);
-  for (int i = 0; i < n_nodes; ++i) {
-    const int v = postorder[i];
-    if (v < 0 || v >= n_nodes || seen[v]) return fail(CB_EINVAL, "cb_tree_likelihood: postorder is not a permutation");
-    seen[v] = 1;
-    const int p = parent[v];
-    if (i == n_nodes - 1) {
-      if (p != -1) return fail(CB_EINVAL, "cb_tree_likelihood: the last node of postorder must be the root (parent -1)");
-      break;
-    }
-    if (p < 0 || p >= n_nodes || seen[p]) return fail(CB_EINVAL, "cb_tree_likelihood: node %d precedes its child %d", p, v);
-    if (!(length[v] >= 0.0) || !std::isfinite(length[v])) return fail(CB_EINVAL, "cb_tree_likelihood: length[%d] = %g", v, length[v]);
-    height[p] = std::max(height[p], height[v] + 1);
-    nchild[p]++;
-  }
-  std::vector<int> child_ptr(n_nodes + 1, 0), child_idx(std::max(n_nodes - 1, 1)), fill(n_nodes, 0);
-  for (int v = 0; v < n_nodes; ++v) child_ptr[v + 1] = child_ptr[v] + nchild[v];
-  for (int i = 0; i + 1 < n_nodes; ++i) {
-    const int v = postorder[i], p = parent[v];
-    child_idx[child_ptr[p] + fill[p]++] = v;
-  }
-  const int n_levels = height[root] + 1;
-  std::vector<int> level_ptr(n_levels + 1, 0), level_nodes(n_nodes);
-  for (int v = 0; v < n_nodes; ++v) level_ptr[height[v] + 1]++;
-  for (int l = 0; l < n_levels; ++l) level_ptr[l + 1] += level_ptr[l];
-  {
-    std::vector<int> at(level_ptr.begin(), level_ptr.end() - 1);
-    for (int i = 0; i < n_nodes; ++i) level_nodes[at[height[postorder[i]]]++] = postorder[i];
-  }
-  for (int u = 0; u < n_units; ++u)
-    if (unit_cat[u] < 0 || unit_cat[u] >= n_cats) return fail(CB_EINVAL, "cb_tree_likelihood: unit_cat[%d] = %d", u, unit_cat[u]);
-  for (int c = 0; c < n_cats; ++c)
-    if (!(cat_rate[c] >= 0.0) || !std::isfinite(cat_rate[c])) return fail(CB_EINVAL, "cb_tree_likelihood: cat_rate[%d] = %g", c, cat_rate[c]);
-  const int alpha = S1 > 0 ? S1 : S;
-  for (int v = 0; v < n_nodes; ++v)
-    if (!nchild[v])
-      for (int u = 0; u < n_units; ++u) {
-        const size_t i = (size_t)v * n_units + u;
-        if (code_a[i] >= alpha || (S1 > 0 && code_b[i] >= alpha)) return fail(CB_EINVAL, "cb_tree_likelihood: state code out of range at node %d unit %d", v, u);
-      }
-  // ---- transition bank expm(rate_c * length_v * Q), [cat][node][S][S], by the bank's own expm kernels
-  const bool large = S > 32;
-  const int L = large ? 1 : n_cats, B = large ? n_cats * n_nodes : n_nodes;
-  std::vector<double> t((size_t)n_cats * n_nodes);
-  for (int c = 0; c < n_cats; ++c)
-    for (int v = 0; v < n_nodes; ++v) t[(size_t)c * n_nodes + v] = v == root ? 0.0 : cat_rate[c] * length[v];
-  cb_handle h = nullptr;
-  int rc = cb_create(device, S, L, B, CB_F64, t.data(), nullptr, CB_EXPM_ONLY, &h);
-  if (rc != CB_OK) return rc;
-  struct Guard {
-    cb_handle h;
-    ~Guard() { cb_destroy(h); }
-  } guard{h};
-  if ((rc = cb_set_stream(h, nullptr, 0)) != CB_OK) return rc;
-  const size_t SS = (size_t)S * S;
-  std::vector<double> Qrep((size_t)L * SS), pirep;
-  for (int l = 0; l < L; ++l) std::copy(Q, Q + SS, Qrep.begin() + (size_t)l * SS);
-  if (pi_rev) {
-    pirep.resize((size_t)L * S);
-    for (int l = 0; l < L; ++l) std::copy(pi_rev, pi_rev + S, pirep.begin() + (size_t)l * S);
-  }
-  BleDev d;
-  const double *dQ = d.up(Qrep.data(), Qrep.size(), rc);
-  const double *dpi = pi_rev ? d.up(pirep.data(), pirep.size(), rc) : nullptr;
-  double *dP = d.up<double>(nullptr, (size_t)n_cats * n_nodes * SS, rc);
-  const int NU = S > 64 ? (n_units + 15) / 16 * 16 : n_units;
-  const size_t msg_count = (size_t)n_nodes * S * NU;
-  double *dmsg = d.up<double>(nullptr, msg_count, rc);
-  double *dll = d.up<double>(nullptr, n_units, rc);
-  const double *dproot = d.up(pi_root, S, rc);
-  const int *dlev = d.up(level_nodes.data(), n_nodes, rc), *dcp = d.up(child_ptr.data(), n_nodes + 1, rc);
-  const int *dci = d.up(child_idx.data(), child_idx.size(), rc), *duc = d.up(unit_cat, n_units, rc);
-  const int8_t *dca = d.up(code_a, (size_t)n_nodes * n_units, rc);
-  const int8_t *dcb = S1 > 0 ? d.up(code_b, (size_t)n_nodes * n_units, rc) : nullptr;
-  if (rc != CB_OK) return rc;
-  hipEvent_t ev0 = nullptr, ev1 = nullptr, evm = nullptr;
-  if (kernel_ms) {
-    HIP_TRY(hipEventCreate(&ev0));
-    HIP_TRY(hipEventCreate(&ev1));
-    HIP_TRY(hipEventCreate(&evm));
-    HIP_TRY(hipStreamSynchronize(0));   // the timed region starts with resident inputs
-    HIP_TRY(hipEventRecord(ev0, 0));
-  }
-  rc = cb_expm_bank(h, dQ, dpi, CB_PTR_DEVICE | CB_NO_SYNC, dP);
-  if (kernel_ms) (void)hipEventRecord(evm, 0);
-  if (rc == CB_OK) {
-    TlArgs a{};
-    a.S = S; a.S1 = S1; a.n_nodes = n_nodes; a.n_units = n_units; a.NU = NU; a.root = root;
-    a.child_ptr = dcp; a.child_idx = dci; a.P = dP; a.unit_cat = duc;
-    a.code_a = reinterpret_cast<const signed char *>(dca);
-    a.code_b = reinterpret_cast<const signed char *>(dcb);
-    a.pi_root = dproot; a.msg = dmsg; a.ll = dll;
-    const int nt = (S + 15) / 16, Sp = nt * 16;
-    const size_t lds = ((size_t)(Sp + Sp / 4) * 16 + TL_NW * 16) * sizeof(double);
-    if (S > 64 && hipFuncSetAttribute(reinterpret_cast<const void *>(tl_mfma_kernel),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-      rc = fail(CB_EHIP, "cb_tree_likelihood: cannot reserve %zu bytes of LDS", lds);
-    for (int l = 0; l < n_levels && rc == CB_OK; ++l) {
-      const int nl = level_ptr[l + 1] - level_ptr[l];
-      a.n_blocks = S > 64 ? NU / 16 : (n_units + 64 / S - 1) / (64 / S);
-      const int per_launch = std::max(1, (1 << 30) / a.n_blocks);   // keep the 1-D grid below 2^30 workgroups
-      for (int y0 = 0; y0 < nl; y0 += per_launch) {
-        TlArgs b = a;
-        b.level_nodes = dlev + level_ptr[l] + y0;
-        b.n_level = std::min(per_launch, nl - y0);
-        const dim3 grid((unsigned)b.n_level * (unsigned)a.n_blocks);
-        if (S > 64)
-          hipLaunchKernelGGL(tl_mfma_kernel, grid, dim3(TL_NW * 64), lds, 0, b);
-        else
-          hipLaunchKernelGGL(tl_group_kernel, grid, dim3(64), 0, 0, b);
-      }
-    }
-  }
-  if (kernel_ms) {
-    float ms = 0.f, ms_prune = 0.f;
-    hipError_t e = hipEventRecord(ev1, 0);
-    if (e == hipSuccess) e = hipEventSynchronize(ev1);
-    if (e == hipSuccess) e = hipEventElapsedTime(&ms, ev0, ev1);
-    if (e == hipSuccess) e = hipEventElapsedTime(&ms_prune, evm, ev1);
-    kernel_ms[0] = ms;
-    kernel_ms[1] = ms_prune;
-    (void)hipEventDestroy(ev0);
-    (void)hipEventDestroy(ev1);
-    (void)hipEventDestroy(evm);
-    if (e != hipSuccess && rc == CB_OK) rc = fail(CB_EHIP, "cb_tree_likelihood: %s", hipGetErrorString(e));
-  }
-  if (rc != CB_OK) return rc;
-  HIP_TRY(hipGetLastError());
-  HIP_TRY(hipMemcpy(ll, dll, n_units * sizeof(double), hipMemcpyDeviceToHost));
-  return CB_OK;
-}
-
-// ---------------------------------------------------------------- host-side text formats
-#include "host_io.hip.h"

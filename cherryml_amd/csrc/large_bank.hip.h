@@ -195,17 +195,6 @@ __device__ __forceinline__ void lg_for_each(int m0, int n0, const typename Mfma<
   }
 }
 
-// XCD-aware block id: hardware deals consecutive workgroup ids round-robin over the 8
-// XCDs (ids i and i + 8 share an L2).  Remap so that each XCD walks a CONTIGUOUS range
-// of virtual ids: the 25 tiles of one bucket then run on one XCD and share its L2 for
-// the operand panels (measured before: 5.4x the algorithmic bytes left L2).  Bijective
-// for any grid size (guide 5.5 T1).  Speed only, never correctness.
-__device__ __forceinline__ int xcd_swizzle(int id, int n) {
-  const int q = n >> 3, r = n & 7, xcd = id & 7, k = id >> 3;
-  const int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
-  return base + k;
-}
-
 __device__ __forceinline__ void lg_wave_lds_fence() {   // LDS visibility inside ONE wavefront (no workgroup barrier)
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   __builtin_amdgcn_wave_barrier();

@@ -15,7 +15,7 @@
 //                    v_mfma_f64_16x16x4 tiles (rows x units), W staged in LDS, P streamed from HBM
 #pragma once
 #include "common.hip.h"
-#include "large_bank.hip.h"   // xcd_swizzle
+#include "common.hip.h"   // xcd_swizzle, mfma_f64
 
 struct TlArgs {
   int S, S1;                   // states; S1 > 0: pair model over an S1-letter alphabet
