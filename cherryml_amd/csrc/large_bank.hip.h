@@ -117,17 +117,22 @@ __device__ __forceinline__ void lg4_store_panel(T *s, const typename Mfma<T>::ve
 // sA / sB hold TWO K-steps each (double buffer): one barrier per K-step; the global loads of step
 // k+1 are in flight during the MFMAs of step k.  LDS row stride 80 elements is conflict-free for the
 // operand reads in both widths (f64: 2 * 80 mod 64 = 32; f32: 80 mod 64 = 16, four k rows per read).
-template <typename T, bool SCALE>
+// ZERO = false: accumulate onto the tile the registers already hold (a second operand pair of the same
+// output tile: general_large.hip.h); ax1 must then be complete in wave 0 and ZERO elsewhere on entry, which
+// is how this routine leaves it.
+template <typename T, bool SCALE, bool ZERO = true>
 __device__ __forceinline__ void lg4_gemm_tile(const GemmOperands<T> &g, int m0, int n0, T *sA, T *sB,
                                               typename Mfma<T>::acc_t (&acc)[5], typename Mfma<T>::acc_t &ax0,
                                               typename Mfma<T>::acc_t &ax1) {
   typedef typename Mfma<T>::acc_t acc_t;
   typedef typename Mfma<T>::vec_t vec_t;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, lo = lane & 15, hi = lane >> 4;
+  if (ZERO) {
 #pragma unroll
-  for (int j = 0; j < 5; ++j) acc[j] = acc_t{};
-  ax0 = acc_t{};
-  ax1 = acc_t{};
+    for (int j = 0; j < 5; ++j) acc[j] = acc_t{};
+    ax0 = acc_t{};
+    ax1 = acc_t{};
+  }
   vec_t ra[Panel<T>::NL], rb[Panel<T>::NL];
   T sc = T(1), one = T(1);
   const int nk = g.K / LG_KT;
@@ -173,6 +178,8 @@ __device__ __forceinline__ void lg4_gemm_tile(const GemmOperands<T> &g, int m0, 
   if (wave == 0) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) ax1[r] += (sA[r * 64 + lane] + sA[256 + r * 64 + lane]) + sA[512 + r * 64 + lane];
+  } else {
+    ax1 = acc_t{};     // (the partial sums now live in wave 0)
   }
   __syncthreads();   // sA is free again (callers reuse it)
 }

@@ -110,10 +110,6 @@ def train_quantization(rate_module, quantized_dataset, m=1.0, lr=1e-1, num_epoch
         raise RuntimeError("cherryml_amd.train_quantization runs on the MI355X only: move the "
                            "rate module to device='cuda' (there is no CPU fallback)")
     reversible = rate_module.is_reversible()
-    if not reversible and rate_module.num_states > 32:
-        raise NotImplementedError(
-            f"mode={rate_module.mode!r} with this mask gives a non-reversible Q; the general "
-            "(scaling-and-squaring) HIP path covers num_states <= 32 only in this build")
     if optimizer is None:
         optimizer = torch.optim.SGD(rate_module.parameters(), lr=lr, momentum=0.0, weight_decay=0)
     own_bank = bank is None

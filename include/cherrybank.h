@@ -117,6 +117,9 @@ int cb_loss_grad(cb_handle h, const double *Q, const double *pi, int flags,
  * parameterisation under a non-symmetric mask (rate.py:182): scaling and
  * squaring with a Taylor polynomial forward, its exact adjoint backward
  * (the algorithm class of torch.matrix_exp, trainer.py:170-172,186).
+ * S <= 32: one workgroup per site, everything in its LDS / L2 scratch; S > 32 (L == 1): the same algebra
+ * as batched 80 x 80-tile float64 MFMA products over the buckets (about 50 + 3 s products per bucket with s
+ * squarings -- ~17x the arithmetic of the spectral path; CB_F64 / CB_MIXED handles).
  */
 int cb_loss_grad_general(cb_handle h, const double *Q, int flags, double *loss,
                          double *dQ);
@@ -319,7 +322,7 @@ int cb_site_rate_gather(int device, int S, int R, int n, int L, const double *te
  * cat_rate[unit_cat[u]]) or contacting pairs of sites (S1 > 0, S = S1 * S1, pair state a * S1 + b).
  * All pointers are HOST pointers.
  *   Q [S][S]; pi_rev [S]: Q is reversible w.r.t. pi_rev -> spectral expm kernels (reference
- *   `reversible_*` = True); NULL -> general scaling-and-squaring kernels (S <= 32 only);
+ *   `reversible_*` = True); NULL -> general scaling-and-squaring kernels;
  *   pi_root [S]: the root distribution (reference pi_1 / pi_2)
  *   tree: n_nodes nodes; postorder[n_nodes] lists every node, children before parents (the last
  *   entry is the root); parent[v] (-1 for the root); length[v] = length of the edge above v.

@@ -623,3 +623,52 @@ def test_failing_rank_keeps_its_place_in_every_collective(monkeypatch):
         del calls[:]
         bank.loss_grad(Q, np.full(S, 1.0 / S))
         assert calls == [1, S * S]
+
+
+def test_non_symmetric_mask_above_32_states_trains_through_the_general_path():
+    """SURVEY row +g2: a non-symmetric mask makes Q non-reversible; above 32 states that is the batched
+    scaling-and-squaring path (general_large.hip.h).  Six epochs of `train_quantization` (torch keeps theta -> Q
+    and Adam, HIP does loss + dL/dQ) against the oracle's float64 run of the reference algorithm; and one
+    400-state evaluation (the co-evolution size) against torch.matrix_exp + autograd."""
+    from cherryml_amd import CherryBank, RateMatrix, train_quantization
+    from torch.utils.data import TensorDataset
+    from oracle import ratelearn_oracle as orc
+    rng = np.random.default_rng(3)
+    S, B, E = 48, 5, 6
+    t = np.sort(rng.uniform(0.02, 3.0, size=B))
+    C = rng.poisson(2.0, size=(B, S, S)).astype(np.float64)
+    mask = (rng.random((S, S)) < 0.7).astype(np.float64)
+    np.fill_diagonal(mask, 0.0)
+    assert not np.array_equal(mask, mask.T)
+    u0 = rng.normal(0.0, 0.3, size=S * (S - 1) // 2)
+    p0 = rng.normal(0.0, 0.2, size=S)
+    ref = orc.train(t, C, mask, upper_diag=u0, log_pi=p0, num_epochs=E)
+    mod = RateMatrix(num_states=S, mode="pande_reversible", mask=torch.tensor(mask),
+                     pi=torch.ones(S, dtype=torch.float64) / S, pi_requires_grad=True)
+    with torch.no_grad():
+        mod.upper_diag.copy_(torch.tensor(u0))
+        mod._pi.copy_(torch.tensor(p0))
+    mod = mod.to("cuda")
+    assert not mod.is_reversible()
+    opt = torch.optim.Adam([mod._pi, mod.upper_diag], lr=0.1)
+    df, Qd = train_quantization(mod, TensorDataset(torch.tensor(t), torch.tensor(C)), num_epochs=E, optimizer=opt)
+    assert np.allclose(df.loss.to_numpy(), ref["loss"], rtol=1e-9, atol=0)
+    assert relerr(Qd["Q_best"], ref["Q_best"]) < 1e-6 and relerr(Qd["Q_last"], ref["Q_last"]) < 1e-6
+    # 400 states, general path, single evaluation
+    S = 400
+    Q = rng.uniform(0.0, 1.0, size=(S, S)) * (rng.random((S, S)) < 0.3) * (4.0 / S)
+    np.fill_diagonal(Q, 0.0)
+    Q -= np.diag(Q.sum(1))
+    # (branch lengths at which no entry of P is tiny: both this path and torch.matrix_exp are accurate in the absolute
+    # sense only, and counts sitting on 1e-10-sized entries of P would compare their rounding, not their algebra)
+    t = np.array([0.5, 1.5, 6.0])
+    C = rng.poisson(0.3, size=(3, S, S)).astype(np.float64)
+    Qt = torch.tensor(Q, requires_grad=True)
+    want = orc.bank_loss(Qt, torch.tensor(t), torch.tensor(C))
+    want.backward()
+    with CherryBank(t, C) as bank:
+        loss, dQ = bank.loss_grad_general(Q)
+        P = bank.expm_bank(Q, None)[0]
+    assert abs(loss[0] - want.item()) < 1e-12 * abs(want.item())
+    assert relerr(dQ[0], Qt.grad.numpy()) < 1e-10
+    assert np.abs(P - orc.expm_bank(Q, t)).max() < 1e-13

@@ -162,9 +162,10 @@ def _random_rate_matrix(rng, S):
     return Q
 
 
-@pytest.mark.parametrize("S,B", [(3, 4), (20, 9), (21, 5), (32, 3)])
+@pytest.mark.parametrize("S,B", [(3, 4), (20, 9), (21, 5), (32, 3), (33, 3), (48, 9), (100, 5), (161, 3)])
 def test_general_path_non_reversible(S, B):
-    """cb_loss_grad_general / cb_expm_bank(pi=NULL): arbitrary (non-reversible) Q."""
+    """cb_loss_grad_general / cb_expm_bank(pi=NULL): arbitrary (non-reversible) Q.  S <= 32: one workgroup per
+    site (general_small.hip.h); S > 32: batched 80 x 80-tile GEMMs over the buckets (general_large.hip.h)."""
     rng = np.random.default_rng(S)
     Q = _random_rate_matrix(rng, S)
     t = np.array([float("%.8f" % (0.03 * 1.1 ** i)) for i in np.linspace(-64, 64, B).astype(int)])
