@@ -305,6 +305,17 @@ __global__ void pack_counts_quad(int S, int B, int Bl, int nq, int TS, const int
   }
 }
 
+// flag[0] |= 1 when some matrix of C [nmat][S][S] is not symmetric (small path)
+__global__ void small_sym_check(int S, const double *C, int *flag) {
+  const double *M = C + (size_t)blockIdx.x * S * S;
+  bool bad = false;
+  for (int e = threadIdx.x; e < S * S; e += blockDim.x) {
+    const int i = e / S, j = e - i * S;
+    if (j < i && M[e] != M[(size_t)j * S + i]) bad = true;
+  }
+  if (bad) atomicOr(flag, 1);
+}
+
 // small path: Ct[l,k][j][i] = C[l,src[l,k]][i][j]  for the live slots k < nlive[l]
 __global__ void transpose_small(int S, int B, int Bl, const int *nlive, const int *src, const double *C,
                                 double *Ct) {
@@ -476,6 +487,15 @@ extern "C" int cb_create(int device, int S, int L, int B, int dtype, const doubl
       }
       hipLaunchKernelGGL(pack_counts_quad, dim3((unsigned)((size_t)L * h->nq)), dim3(256), 0, h->stream, S, B, Bl,
                          h->nq, TS, h->nlive, src_idx, Cdev, h->Cq);
+      // symmetric counts (cherry counting, SiteRM assembly with reverse transitions): sp_bank's symmetric form
+      int *flag = h->status;
+      (void)hipMemsetAsync(flag, 0, sizeof(int), h->stream);
+      hipLaunchKernelGGL(small_sym_check, dim3((unsigned)nmat), dim3(256), 0, h->stream, S, Cdev, flag);
+      int hf = 1;
+      if (hipMemcpyAsync(&hf, flag, sizeof hf, hipMemcpyDeviceToHost, h->stream) == hipSuccess &&
+          hipStreamSynchronize(h->stream) == hipSuccess)
+        h->sym_counts = hf == 0 && !getenv("CB_NO_SYM");
+      (void)hipMemsetAsync(flag, 0, sizeof(int), h->stream);
     }
   } else {
     const size_t LL = (size_t)h->LD * h->LD;
@@ -1308,6 +1328,7 @@ static int run_fused_training(cb_bank *h, int kind, double *pi_param, double *up
     a.m_up = d_mom + 2 * (size_t)L * S; a.v_up = a.m_up + L * nup;
     a.mask = d_mask; a.lr = lr; a.beta1 = 0.9; a.beta2 = 0.999; a.eps = 1e-8;
     a.loss_curve = d_loss; a.Q_best = d_Qb; a.Q_last = d_Ql; a.Q_pow2 = d_Qp;
+    a.sym = (S <= 24 && h->sym_counts) ? 1 : 0;
     for (bool &b : h->ev_rec) b = false;
     mark(h, EV_START);
     const char *env_split = getenv("CB_LG_SPLIT");
@@ -1344,7 +1365,8 @@ static int run_fused_training(cb_bank *h, int kind, double *pi_param, double *up
           const double bc1 = 1.0 - pow_b1, bc2s = std::sqrt(1.0 - pow_b2);
 #define SPK(T)                                                                                         \
   do {                                                                                                 \
-    hipLaunchKernelGGL((sp_bank<T>), gb, dim3(256), lds_b, h->stream, a, g);                            \
+    if (a.sym) hipLaunchKernelGGL((sp_bank<T, true>), gb, dim3(256), lds_b, h->stream, a, g);           \
+    else hipLaunchKernelGGL((sp_bank<T, false>), gb, dim3(256), lds_b, h->stream, a, g);                \
     hipLaunchKernelGGL((sp_finish<T>), dim3(L), dim3(256), lds_f, h->stream, a, g, e, bc1, bc2s);       \
   } while (0)
           switch (TS) {

@@ -36,6 +36,7 @@ struct TrainArgs {
   double *loss_curve;               // [E][L]
   double *Q_best, *Q_last;          // [L][S][S]
   double *Q_pow2;                   // [n_pow2][S][S] (site 0) or null
+  int sym;                          // all count matrices symmetric: sp_bank's symmetric form, sp_finish mirrors M
 };
 
 __device__ __forceinline__ double softplus_t(double x) {  // torch: beta 1, threshold 20
@@ -449,7 +450,7 @@ __global__ __launch_bounds__(64) void sp_prepare(TrainArgs a, SpSplit g, int epo
 #define SPB_LOSS (SPB_MW + 4 * 1600)   // TS <= 5: [tile][64] per wave (1600); TS = 6: [tile][16] (576)
 #define SPB_TOTAL (SPB_LOSS + 8)
 
-template <int TS>
+template <int TS, bool SYM = false>   // SYM: all count matrices symmetric (small_quad's symmetric form)
 __global__ __launch_bounds__(256, 2) void sp_bank(TrainArgs a, SpSplit g) {
   extern __shared__ double lds[];
   double *sA = lds + SPB_A, *sV = lds + SPB_V, *sLam = lds + SPB_LAM;
@@ -478,7 +479,7 @@ __global__ __launch_bounds__(256, 2) void sp_bank(TrainArgs a, SpSplit g) {
   for (int qd = q0 + wave; qd < q1; qd += 4) {
     const int bucket = 4 * qd + blk;
     const double tb = bucket < Bn ? t_l[bucket] : 0.0;
-    small_quad<TS, LANEM>(S, tb, Cq_l + (size_t)qd * (TS * TS * 64), inv_n, sA, sV, lds + SPB_TAB + wave * 384, sLam,
+    small_quad<TS, LANEM, SYM>(S, tb, Cq_l + (size_t)qd * (TS * TS * 64), inv_n, sA, sV, lds + SPB_TAB + wave * 384, sLam,
                          rho, Mw, lossacc);
   }
   lossacc = wave_sum(lossacc);
@@ -536,6 +537,13 @@ __global__ __launch_bounds__(256) void sp_finish(TrainArgs a, SpSplit g, int epo
     for (int c = 0; c < g.nchunk; ++c) tot += Mp[(size_t)c * 576 + e];
     const int tile = e >> 4, At = tile / TS, Ct = tile - At * TS;
     sG[(4 * At + ((e >> 2) & 3)) * CB_LS + 4 * Ct + (e & 3)] = tot;
+  }
+  if (a.sym) {   // sp_bank<TS, true> accumulated the tiles on or above the diagonal only: M is symmetric
+    __syncthreads();
+    for (int e = tid; e < 16 * TS * TS; e += 256) {
+      const int tile = e >> 4, At = tile / TS, Ct = tile - At * TS, i = (e >> 2) & 3, j = e & 3;
+      if (At > Ct) sG[(4 * At + i) * CB_LS + 4 * Ct + j] = sG[(4 * Ct + j) * CB_LS + 4 * At + i];
+    }
   }
   if (tid == 0) {
     double tot = 0.0;

@@ -672,3 +672,42 @@ def test_non_symmetric_mask_above_32_states_trains_through_the_general_path():
     assert abs(loss[0] - want.item()) < 1e-12 * abs(want.item())
     assert relerr(dQ[0], Qt.grad.numpy()) < 1e-10
     assert np.abs(P - orc.expm_bank(Q, t)).max() < 1e-13
+
+
+@pytest.mark.parametrize("N", [4, 12, 20, 21, 24])
+def test_symmetric_counts_take_the_symmetric_quad_form(N, monkeypatch):
+    """Symmetric count matrices (cherry counting and the SiteRM assembly with reverse transitions produce them) make
+    Pt, G and W symmetric: `sp_bank<TS, true>` computes the tiles on or above the diagonal only and `sp_finish`
+    mirrors M.  Same losses and matrices as the full form (CB_NO_SYM=1 at cb_create) and as the oracle, for both
+    parameterisations (SiteRM and the per-site pande_reversible)."""
+    from cherryml_amd import CherryBank
+    from cherryml_amd._siterm._vectorized import _invert
+    from oracle import ratelearn_oracle as orc
+    rng = np.random.default_rng(100 + N)
+    L, B, E = 5, 7, 6
+    times = np.sort(rng.uniform(0.05, 2.0, size=(L, B)), axis=1)
+    C = rng.poisson(3.0, size=(L, B, N, N)).astype(np.float64)
+    C = C + C.transpose(0, 1, 3, 2)
+    C[1, 2] = 0.0                                    # an empty bucket
+    Q0 = rng.uniform(0.2, 1.0, size=(L, N, N))
+    pi = rng.dirichlet(np.full(N, 5.0), size=L)
+    Q0 = 0.5 * (Q0 + Q0.transpose(0, 2, 1)) * pi[:, None, :]     # reversible initial matrices
+    for l in range(L):
+        np.fill_diagonal(Q0[l], 0.0)
+        Q0[l] -= np.diag(Q0[l].sum(1))
+    th0, Th0 = _invert(Q0)
+    runs = {}
+    for name, env in (("sym", None), ("full", "1")):
+        if env is None:
+            monkeypatch.delenv("CB_NO_SYM", raising=False)
+        else:
+            monkeypatch.setenv("CB_NO_SYM", env)
+        with CherryBank(times, C) as bank:
+            runs[name] = bank.train_siterm(th0, Th0, E, lr=0.1)
+    a, b = runs["sym"], runs["full"]
+    assert np.allclose(a["loss_per_epoch_per_site"], b["loss_per_epoch_per_site"], rtol=1e-12, atol=0)
+    assert relerr(a["res"], b["res"]) < 1e-11
+    ref = orc.siterm_train(C, times, E, initialization=Q0)
+    assert np.allclose(a["loss_per_epoch_per_site"], ref["loss_per_epoch_per_site"], rtol=1e-8, atol=0)
+    for l in range(L):
+        assert relerr(a["res"][l], ref["res"][l]) < 1e-6, l
