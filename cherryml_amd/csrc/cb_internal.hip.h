@@ -29,6 +29,11 @@ int cb_fail(int code, const char *fmt, ...);
                   #expr, hipGetErrorString(e_), __FILE__, __LINE__);                    \
   } while (0)
 
+// cb_expm_bank flag (internal): the matrix is the one of the previous call on this handle -- skip the eigensolve
+#define CB_REUSE_EIGH 256
+// new branch lengths for a counts-free (CB_EXPM_ONLY) single-bank handle, B <= its creation B (cherrybank.hip)
+int cb_internal_set_times(cb_handle h, const double *t_host, int B);
+
 // device buffers of one call of the per-family entry points (uploaded on the default stream, freed on return)
 struct CbDevBufs {
   std::vector<void *> ptrs;

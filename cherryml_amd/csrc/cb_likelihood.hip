@@ -4,27 +4,26 @@
 #include "likelihood.hip.h"
 
 // ---------------------------------------------------------------- held-out likelihood
-extern "C" int cb_tree_likelihood(int device, int S, int S1, const double *Q, const double *pi_rev,
-                                  const double *pi_root, int n_nodes, const int *postorder, const int *parent,
-                                  const double *length, int n_cats, const double *cat_rate, int n_units,
-                                  const int *unit_cat, const int8_t *code_a, const int8_t *code_b, double *ll,
-                                  double *kernel_ms) {
-  if (!Q || !pi_root || !postorder || !parent || !length || !cat_rate || !unit_cat || !code_a || !ll)
-    return fail(CB_EINVAL, "cb_tree_likelihood: NULL argument");
-  if (S < 2 || S > 16 * TL_NW * TL_MAXT || n_nodes < 1 || n_cats < 1 || n_units < 1)
-    return fail(CB_EINVAL, "cb_tree_likelihood: bad sizes (S = %d, nodes = %d, categories = %d, units = %d)", S,
-                n_nodes, n_cats, n_units);
-  if (S1 < 0 || (S1 > 0 && (S1 * S1 != S || !code_b)))
-    return fail(CB_EINVAL, "cb_tree_likelihood: pair model needs S = S1 * S1 and code_b");
+namespace {
+// host-side view of one family: validated tree, levels (nodes of equal height), children in post-order
+struct TlFamily {
+  int n_nodes = 0, n_units = 0, n_cats = 0, root = 0, n_levels = 0;
+  std::vector<int> level_ptr, level_nodes, child_ptr, child_idx, nchild;
+};
+
+int tl_prepare(int S, int S1, int n_nodes, const int *postorder, const int *parent, const double *length, int n_cats,
+               const double *cat_rate, int n_units, const int *unit_cat, const int8_t *code_a, const int8_t *code_b,
+               TlFamily &f) {
+  if (n_nodes < 1 || n_cats < 1 || n_units < 1)
+    return fail(CB_EINVAL, "cb_tree_likelihood: bad sizes (nodes = %d, categories = %d, units = %d)", n_nodes, n_cats, n_units);
   if (S > 64 && n_cats != 1)
     return fail(CB_EUNSUPPORTED, "cb_tree_likelihood: S > 64 takes one rate category (the reference evaluates pairs "
                 "of sites at rate 1, _likelihood.py:214-230)");
-  const int ndev = cb_device_count();
-  if (ndev <= 0) return fail(CB_EHIP, "cb_tree_likelihood: no HIP device (this path has no CPU fallback)");
-  if (device < 0 || device >= ndev) return fail(CB_EINVAL, "cb_tree_likelihood: device %d of %d", device, ndev);
+  f.n_nodes = n_nodes; f.n_units = n_units; f.n_cats = n_cats;
   // ---- tree: heights, levels, children in post-order (= the reference's child order, _tree.py traversal)
   const int root = postorder[n_nodes - 1];
-  std::vector<int> height(n_nodes, 0), nchild(n_nodes, 0), seen(n_nodes, 0);
+  std::vector<int> height(n_nodes, 0), seen(n_nodes, 0);
+  f.nchild.assign(n_nodes, 0);
   for (int i = 0; i < n_nodes; ++i) {
     const int v = postorder[i];
     if (v < 0 || v >= n_nodes || seen[v]) return fail(CB_EINVAL, "cb_tree_likelihood: postorder is not a permutation");
@@ -37,21 +36,25 @@ extern "C" int cb_tree_likelihood(int device, int S, int S1, const double *Q, co
     if (p < 0 || p >= n_nodes || seen[p]) return fail(CB_EINVAL, "cb_tree_likelihood: node %d precedes its child %d", p, v);
     if (!(length[v] >= 0.0) || !std::isfinite(length[v])) return fail(CB_EINVAL, "cb_tree_likelihood: length[%d] = %g", v, length[v]);
     height[p] = std::max(height[p], height[v] + 1);
-    nchild[p]++;
+    f.nchild[p]++;
   }
-  std::vector<int> child_ptr(n_nodes + 1, 0), child_idx(std::max(n_nodes - 1, 1)), fill(n_nodes, 0);
-  for (int v = 0; v < n_nodes; ++v) child_ptr[v + 1] = child_ptr[v] + nchild[v];
+  f.root = root;
+  f.child_ptr.assign(n_nodes + 1, 0);
+  f.child_idx.assign(std::max(n_nodes - 1, 1), 0);
+  std::vector<int> fill(n_nodes, 0);
+  for (int v = 0; v < n_nodes; ++v) f.child_ptr[v + 1] = f.child_ptr[v] + f.nchild[v];
   for (int i = 0; i + 1 < n_nodes; ++i) {
     const int v = postorder[i], p = parent[v];
-    child_idx[child_ptr[p] + fill[p]++] = v;
+    f.child_idx[f.child_ptr[p] + fill[p]++] = v;
   }
-  const int n_levels = height[root] + 1;
-  std::vector<int> level_ptr(n_levels + 1, 0), level_nodes(n_nodes);
-  for (int v = 0; v < n_nodes; ++v) level_ptr[height[v] + 1]++;
-  for (int l = 0; l < n_levels; ++l) level_ptr[l + 1] += level_ptr[l];
+  f.n_levels = height[root] + 1;
+  f.level_ptr.assign(f.n_levels + 1, 0);
+  f.level_nodes.assign(n_nodes, 0);
+  for (int v = 0; v < n_nodes; ++v) f.level_ptr[height[v] + 1]++;
+  for (int l = 0; l < f.n_levels; ++l) f.level_ptr[l + 1] += f.level_ptr[l];
   {
-    std::vector<int> at(level_ptr.begin(), level_ptr.end() - 1);
-    for (int i = 0; i < n_nodes; ++i) level_nodes[at[height[postorder[i]]]++] = postorder[i];
+    std::vector<int> at(f.level_ptr.begin(), f.level_ptr.end() - 1);
+    for (int i = 0; i < n_nodes; ++i) f.level_nodes[at[height[postorder[i]]]++] = postorder[i];
   }
   for (int u = 0; u < n_units; ++u)
     if (unit_cat[u] < 0 || unit_cat[u] >= n_cats) return fail(CB_EINVAL, "cb_tree_likelihood: unit_cat[%d] = %d", u, unit_cat[u]);
@@ -59,99 +62,205 @@ extern "C" int cb_tree_likelihood(int device, int S, int S1, const double *Q, co
     if (!(cat_rate[c] >= 0.0) || !std::isfinite(cat_rate[c])) return fail(CB_EINVAL, "cb_tree_likelihood: cat_rate[%d] = %g", c, cat_rate[c]);
   const int alpha = S1 > 0 ? S1 : S;
   for (int v = 0; v < n_nodes; ++v)
-    if (!nchild[v])
+    if (!f.nchild[v])
       for (int u = 0; u < n_units; ++u) {
         const size_t i = (size_t)v * n_units + u;
         if (code_a[i] >= alpha || (S1 > 0 && code_b[i] >= alpha)) return fail(CB_EINVAL, "cb_tree_likelihood: state code out of range at node %d unit %d", v, u);
       }
-  // ---- transition bank expm(rate_c * length_v * Q), [cat][node][S][S], by the bank's own expm kernels
-  const bool large = S > 32;
-  const int L = large ? 1 : n_cats, B = large ? n_cats * n_nodes : n_nodes;
-  std::vector<double> t((size_t)n_cats * n_nodes);
-  for (int c = 0; c < n_cats; ++c)
-    for (int v = 0; v < n_nodes; ++v) t[(size_t)c * n_nodes + v] = v == root ? 0.0 : cat_rate[c] * length[v];
-  cb_handle h = nullptr;
-  int rc = cb_create(device, S, L, B, CB_F64, t.data(), nullptr, CB_EXPM_ONLY, &h);
-  if (rc != CB_OK) return rc;
-  struct Guard {
-    cb_handle h;
-    ~Guard() { cb_destroy(h); }
-  } guard{h};
-  if ((rc = cb_set_stream(h, nullptr, 0)) != CB_OK) return rc;
-  const size_t SS = (size_t)S * S;
-  std::vector<double> Qrep((size_t)L * SS), pirep;
-  for (int l = 0; l < L; ++l) std::copy(Q, Q + SS, Qrep.begin() + (size_t)l * SS);
-  if (pi_rev) {
-    pirep.resize((size_t)L * S);
-    for (int l = 0; l < L; ++l) std::copy(pi_rev, pi_rev + S, pirep.begin() + (size_t)l * S);
+  return CB_OK;
+}
+
+// the pruning of one family: one launch per height over (nodes of that height) x (blocks of units), stream 0
+int tl_prune(int S, int S1, const TlFamily &f, const double *dP, int cat_stride_nodes, const double *dproot, const int *duc,
+             const int8_t *dca, const int8_t *dcb, const int *dlev, const int *dcp, const int *dci, double *dmsg, double *dll,
+             int NU) {
+  TlArgs a{};
+  a.S = S; a.S1 = S1; a.n_nodes = cat_stride_nodes; a.n_units = f.n_units; a.NU = NU; a.root = f.root;
+  a.child_ptr = dcp; a.child_idx = dci; a.P = dP; a.unit_cat = duc;
+  a.code_a = reinterpret_cast<const signed char *>(dca);
+  a.code_b = reinterpret_cast<const signed char *>(dcb);
+  a.pi_root = dproot; a.msg = dmsg; a.ll = dll;
+  const int nt = (S + 15) / 16, Sp = nt * 16;
+  const size_t lds = ((size_t)(Sp + Sp / 4) * 16 + TL_NW * 16) * sizeof(double);
+  if (S > 64 && hipFuncSetAttribute(reinterpret_cast<const void *>(tl_mfma_kernel),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+    return fail(CB_EHIP, "cb_tree_likelihood: cannot reserve %zu bytes of LDS", lds);
+  for (int l = 0; l < f.n_levels; ++l) {
+    const int nl = f.level_ptr[l + 1] - f.level_ptr[l];
+    a.n_blocks = S > 64 ? NU / 16 : (f.n_units + 64 / S - 1) / (64 / S);
+    const int per_launch = std::max(1, (1 << 30) / a.n_blocks);   // keep the 1-D grid below 2^30 workgroups
+    for (int y0 = 0; y0 < nl; y0 += per_launch) {
+      TlArgs b = a;
+      b.level_nodes = dlev + f.level_ptr[l] + y0;
+      b.n_level = std::min(per_launch, nl - y0);
+      const dim3 grid((unsigned)b.n_level * (unsigned)a.n_blocks);
+      if (S > 64)
+        hipLaunchKernelGGL(tl_mfma_kernel, grid, dim3(TL_NW * 64), lds, 0, b);
+      else
+        hipLaunchKernelGGL(tl_group_kernel, grid, dim3(64), 0, 0, b);
+    }
   }
+  return CB_OK;
+}
+}  // namespace
+
+// MANY families under ONE model in one call (the reference maps families over a process pool,
+// evaluation/_likelihood.py:474-600 / utils.py:59-67).  Family f: n_nodes[f] nodes, n_units[f] units, n_cats[f]
+// rate categories; postorder / parent / length (node indices local to the family), cat_rate, unit_cat, code_a /
+// code_b ([n_nodes[f]][n_units[f]]) and ll are the families' arrays concatenated in order.  What the batch shares:
+// the model's eigendecomposition -- for S > 32 (the 400-state pair model: 3 ms cold per family) ONE counts-free
+// bank handle serves all families (new branch lengths per family, eigensolve once) -- the uploads of Q / pi, and
+// the message buffer; nothing synchronises with the host between families.  Results equal cb_tree_likelihood's.
+extern "C" int cb_tree_likelihood_batch(int device, int S, int S1, const double *Q, const double *pi_rev,
+                                        const double *pi_root, int n_fam, const int *n_nodes, const int *postorder,
+                                        const int *parent, const double *length, const int *n_cats,
+                                        const double *cat_rate, const int *n_units, const int *unit_cat,
+                                        const int8_t *code_a, const int8_t *code_b, double *ll, double *kernel_ms) {
+  if (!Q || !pi_root || !n_nodes || !postorder || !parent || !length || !n_cats || !cat_rate || !n_units || !unit_cat ||
+      !code_a || !ll)
+    return fail(CB_EINVAL, "cb_tree_likelihood: NULL argument");
+  if (S < 2 || S > 16 * TL_NW * TL_MAXT || n_fam < 1)
+    return fail(CB_EINVAL, "cb_tree_likelihood: bad sizes (S = %d, families = %d)", S, n_fam);
+  if (S1 < 0 || (S1 > 0 && (S1 * S1 != S || !code_b)))
+    return fail(CB_EINVAL, "cb_tree_likelihood: pair model needs S = S1 * S1 and code_b");
+  const int ndev = cb_device_count();
+  if (ndev <= 0) return fail(CB_EHIP, "cb_tree_likelihood: no HIP device (this path has no CPU fallback)");
+  if (device < 0 || device >= ndev) return fail(CB_EINVAL, "cb_tree_likelihood: device %d of %d", device, ndev);
+  std::vector<TlFamily> fam(n_fam);
+  std::vector<size_t> off_n(n_fam + 1, 0), off_u(n_fam + 1, 0), off_c(n_fam + 1, 0), off_k(n_fam + 1, 0);
+  int rc = CB_OK, max_nodes = 0;
+  size_t max_msg = 0, max_bank = 0;
+  for (int f = 0; f < n_fam; ++f) {
+    if (n_nodes[f] < 1 || n_units[f] < 1 || n_cats[f] < 1) return fail(CB_EINVAL, "cb_tree_likelihood: family %d has bad sizes", f);
+    rc = tl_prepare(S, S1, n_nodes[f], postorder + off_n[f], parent + off_n[f], length + off_n[f], n_cats[f],
+                    cat_rate + off_k[f], n_units[f], unit_cat + off_u[f], code_a + off_c[f],
+                    code_b ? code_b + off_c[f] : nullptr, fam[f]);
+    if (rc != CB_OK) return rc;
+    off_n[f + 1] = off_n[f] + n_nodes[f];
+    off_u[f + 1] = off_u[f] + n_units[f];
+    off_c[f + 1] = off_c[f] + (size_t)n_nodes[f] * n_units[f];
+    off_k[f + 1] = off_k[f] + n_cats[f];
+    const int NU = S > 64 ? (n_units[f] + 15) / 16 * 16 : n_units[f];
+    max_nodes = std::max(max_nodes, n_nodes[f]);
+    max_msg = std::max(max_msg, (size_t)n_nodes[f] * S * NU);
+    max_bank = std::max(max_bank, (size_t)n_cats[f] * n_nodes[f]);
+  }
+  const bool large = S > 32;
+  const size_t SS = (size_t)S * S;
+  HIP_TRY(hipSetDevice(device));
   CbDevBufs d;
+  // shared by all families
+  int max_cats = 1;
+  for (int f = 0; f < n_fam; ++f) max_cats = std::max(max_cats, n_cats[f]);
+  const int Lrep = large ? 1 : max_cats;
+  std::vector<double> Qrep((size_t)Lrep * SS), pirep;
+  for (int l = 0; l < Lrep; ++l) std::copy(Q, Q + SS, Qrep.begin() + (size_t)l * SS);
+  if (pi_rev) {
+    pirep.resize((size_t)Lrep * S);
+    for (int l = 0; l < Lrep; ++l) std::copy(pi_rev, pi_rev + S, pirep.begin() + (size_t)l * S);
+  }
   const double *dQ = d.up(Qrep.data(), Qrep.size(), rc);
   const double *dpi = pi_rev ? d.up(pirep.data(), pirep.size(), rc) : nullptr;
-  double *dP = d.up<double>(nullptr, (size_t)n_cats * n_nodes * SS, rc);
-  const int NU = S > 64 ? (n_units + 15) / 16 * 16 : n_units;
-  const size_t msg_count = (size_t)n_nodes * S * NU;
-  double *dmsg = d.up<double>(nullptr, msg_count, rc);
-  double *dll = d.up<double>(nullptr, n_units, rc);
   const double *dproot = d.up(pi_root, S, rc);
-  const int *dlev = d.up(level_nodes.data(), n_nodes, rc), *dcp = d.up(child_ptr.data(), n_nodes + 1, rc);
-  const int *dci = d.up(child_idx.data(), child_idx.size(), rc), *duc = d.up(unit_cat, n_units, rc);
-  const int8_t *dca = d.up(code_a, (size_t)n_nodes * n_units, rc);
-  const int8_t *dcb = S1 > 0 ? d.up(code_b, (size_t)n_nodes * n_units, rc) : nullptr;
+  double *dP = d.up<double>(nullptr, max_bank * SS, rc);
+  double *dmsg = d.up<double>(nullptr, max_msg, rc);
+  double *dll = d.up<double>(nullptr, off_u[n_fam], rc);
+  const int *duc = d.up(unit_cat, off_u[n_fam], rc);
+  const int8_t *dca = d.up(code_a, off_c[n_fam], rc);
+  const int8_t *dcb = S1 > 0 ? d.up(code_b, off_c[n_fam], rc) : nullptr;
+  // per-family tree arrays, concatenated
+  std::vector<int> lev_all(off_n[n_fam]), cp_all(off_n[n_fam] + n_fam), ci_all(off_n[n_fam]);
+  for (int f = 0; f < n_fam; ++f) {
+    std::copy(fam[f].level_nodes.begin(), fam[f].level_nodes.end(), lev_all.begin() + off_n[f]);
+    std::copy(fam[f].child_ptr.begin(), fam[f].child_ptr.end(), cp_all.begin() + off_n[f] + f);
+    std::copy(fam[f].child_idx.begin(), fam[f].child_idx.begin() + std::max(n_nodes[f] - 1, 0), ci_all.begin() + off_n[f]);
+  }
+  const int *dlev = d.up(lev_all.data(), lev_all.size(), rc), *dcp = d.up(cp_all.data(), cp_all.size(), rc);
+  const int *dci = d.up(ci_all.data(), ci_all.size(), rc);
   if (rc != CB_OK) return rc;
-  hipEvent_t ev0 = nullptr, ev1 = nullptr, evm = nullptr;
+  // S > 32: one counts-free handle for all families (capacity = the largest family), eigensolve once
+  cb_handle hl = nullptr;
+  struct Guard {
+    cb_handle *h;
+    ~Guard() { if (*h) cb_destroy(*h); }
+  } guard{&hl};
+  if (large) {
+    std::vector<double> t0(max_nodes, 0.0);
+    if ((rc = cb_create(device, S, 1, max_nodes, CB_F64, t0.data(), nullptr, CB_EXPM_ONLY, &hl)) != CB_OK) return rc;
+    if ((rc = cb_set_stream(hl, nullptr, 0)) != CB_OK) return rc;
+  }
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  double ms_total = 0.0, ms_prune = 0.0;
+  std::vector<hipEvent_t> evm;   // one "bank done" marker per family when timing
   if (kernel_ms) {
     HIP_TRY(hipEventCreate(&ev0));
     HIP_TRY(hipEventCreate(&ev1));
-    HIP_TRY(hipEventCreate(&evm));
     HIP_TRY(hipStreamSynchronize(0));   // the timed region starts with resident inputs
     HIP_TRY(hipEventRecord(ev0, 0));
   }
-  rc = cb_expm_bank(h, dQ, dpi, CB_PTR_DEVICE | CB_NO_SYNC, dP);
-  if (kernel_ms) (void)hipEventRecord(evm, 0);
-  if (rc == CB_OK) {
-    TlArgs a{};
-    a.S = S; a.S1 = S1; a.n_nodes = n_nodes; a.n_units = n_units; a.NU = NU; a.root = root;
-    a.child_ptr = dcp; a.child_idx = dci; a.P = dP; a.unit_cat = duc;
-    a.code_a = reinterpret_cast<const signed char *>(dca);
-    a.code_b = reinterpret_cast<const signed char *>(dcb);
-    a.pi_root = dproot; a.msg = dmsg; a.ll = dll;
-    const int nt = (S + 15) / 16, Sp = nt * 16;
-    const size_t lds = ((size_t)(Sp + Sp / 4) * 16 + TL_NW * 16) * sizeof(double);
-    if (S > 64 && hipFuncSetAttribute(reinterpret_cast<const void *>(tl_mfma_kernel),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-      rc = fail(CB_EHIP, "cb_tree_likelihood: cannot reserve %zu bytes of LDS", lds);
-    for (int l = 0; l < n_levels && rc == CB_OK; ++l) {
-      const int nl = level_ptr[l + 1] - level_ptr[l];
-      a.n_blocks = S > 64 ? NU / 16 : (n_units + 64 / S - 1) / (64 / S);
-      const int per_launch = std::max(1, (1 << 30) / a.n_blocks);   // keep the 1-D grid below 2^30 workgroups
-      for (int y0 = 0; y0 < nl; y0 += per_launch) {
-        TlArgs b = a;
-        b.level_nodes = dlev + level_ptr[l] + y0;
-        b.n_level = std::min(per_launch, nl - y0);
-        const dim3 grid((unsigned)b.n_level * (unsigned)a.n_blocks);
-        if (S > 64)
-          hipLaunchKernelGGL(tl_mfma_kernel, grid, dim3(TL_NW * 64), lds, 0, b);
-        else
-          hipLaunchKernelGGL(tl_group_kernel, grid, dim3(64), 0, 0, b);
+  for (int f = 0; f < n_fam && rc == CB_OK; ++f) {
+    const TlFamily &F = fam[f];
+    const double *len = length + off_n[f], *cr = cat_rate + off_k[f];
+    std::vector<double> t((size_t)F.n_cats * F.n_nodes);
+    for (int c = 0; c < F.n_cats; ++c)
+      for (int v = 0; v < F.n_nodes; ++v) t[(size_t)c * F.n_nodes + v] = v == F.root ? 0.0 : cr[c] * len[v];
+    // ---- transition bank expm(rate_c * length_v * Q), [cat][node][S][S], by the bank's own expm kernels
+    if (large) {
+      if ((rc = cb_internal_set_times(hl, t.data(), F.n_nodes)) != CB_OK) break;
+      rc = cb_expm_bank(hl, dQ, dpi, CB_PTR_DEVICE | CB_NO_SYNC | (f > 0 && dpi ? CB_REUSE_EIGH : 0), dP);
+    } else {
+      cb_handle h = nullptr;
+      if ((rc = cb_create(device, S, F.n_cats, F.n_nodes, CB_F64, t.data(), nullptr, CB_EXPM_ONLY, &h)) != CB_OK) break;
+      rc = cb_set_stream(h, nullptr, 0);
+      if (rc == CB_OK) rc = cb_expm_bank(h, dQ, dpi, CB_PTR_DEVICE | CB_NO_SYNC, dP);
+      if (rc == CB_OK && hipStreamSynchronize(0) != hipSuccess) rc = fail(CB_EHIP, "cb_tree_likelihood: bank failed");
+      cb_destroy(h);
+    }
+    if (rc != CB_OK) break;
+    hipEvent_t em = nullptr;
+    if (kernel_ms && hipEventCreate(&em) == hipSuccess) {
+      (void)hipEventRecord(em, 0);
+      evm.push_back(em);
+    }
+    const int NU = S > 64 ? (F.n_units + 15) / 16 * 16 : F.n_units;
+    rc = tl_prune(S, S1, F, dP, F.n_nodes, dproot, duc + off_u[f], dca + off_c[f], dcb ? dcb + off_c[f] : nullptr,
+                  dlev + off_n[f], dcp + off_n[f] + f, dci + off_n[f], dmsg, dll + off_u[f], NU);
+    if (kernel_ms && rc == CB_OK) {   // pruning time of this family: bank marker -> now (needs a marker pair per family)
+      hipEvent_t ep = nullptr;
+      if (hipEventCreate(&ep) == hipSuccess) {
+        (void)hipEventRecord(ep, 0);
+        evm.push_back(ep);
       }
     }
   }
   if (kernel_ms) {
-    float ms = 0.f, ms_prune = 0.f;
+    float ms = 0.f;
     hipError_t e = hipEventRecord(ev1, 0);
     if (e == hipSuccess) e = hipEventSynchronize(ev1);
     if (e == hipSuccess) e = hipEventElapsedTime(&ms, ev0, ev1);
-    if (e == hipSuccess) e = hipEventElapsedTime(&ms_prune, evm, ev1);
-    kernel_ms[0] = ms;
+    ms_total = ms;
+    for (size_t i = 0; i + 1 < evm.size(); i += 2) {
+      float mp = 0.f;
+      if (hipEventElapsedTime(&mp, evm[i], evm[i + 1]) == hipSuccess) ms_prune += mp;
+    }
+    for (hipEvent_t ev : evm) (void)hipEventDestroy(ev);
+    kernel_ms[0] = ms_total;
     kernel_ms[1] = ms_prune;
     (void)hipEventDestroy(ev0);
     (void)hipEventDestroy(ev1);
-    (void)hipEventDestroy(evm);
     if (e != hipSuccess && rc == CB_OK) rc = fail(CB_EHIP, "cb_tree_likelihood: %s", hipGetErrorString(e));
   }
   if (rc != CB_OK) return rc;
   HIP_TRY(hipGetLastError());
-  HIP_TRY(hipMemcpy(ll, dll, n_units * sizeof(double), hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(ll, dll, off_u[n_fam] * sizeof(double), hipMemcpyDeviceToHost));
   return CB_OK;
+}
+
+extern "C" int cb_tree_likelihood(int device, int S, int S1, const double *Q, const double *pi_rev,
+                                  const double *pi_root, int n_nodes, const int *postorder, const int *parent,
+                                  const double *length, int n_cats, const double *cat_rate, int n_units,
+                                  const int *unit_cat, const int8_t *code_a, const int8_t *code_b, double *ll,
+                                  double *kernel_ms) {
+  return cb_tree_likelihood_batch(device, S, S1, Q, pi_rev, pi_root, 1, &n_nodes, postorder, parent, length, &n_cats,
+                                  cat_rate, &n_units, unit_cat, code_a, code_b, ll, kernel_ms);
 }

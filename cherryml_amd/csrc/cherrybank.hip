@@ -29,6 +29,7 @@ int cb_fail(int code, const char *fmt, ...) {
 // ------------------------------------------------------------------ handle
 struct cb_bank {
   int dev = 0, S = 0, L = 0, B = 0;
+  int B_cap = 0;        // B at creation (cb_internal_set_times may lower B)
   int dtype = CB_F64;   // element type of the bank products (large path): CB_F64 or CB_F32
   int LD = 0;           // large path: padded leading dimension
   bool large = false;
@@ -353,6 +354,7 @@ extern "C" int cb_create(int device, int S, int L, int B, int dtype, const doubl
   h->S = S;
   h->L = L;
   h->B = B;
+  h->B_cap = B;
   h->large = S > 32;
   h->dtype = expm_only ? CB_F64 : dtype;   // a counts-free handle has no bank products to narrow
   h->expm_only = expm_only;
@@ -682,13 +684,15 @@ static int launch_small(cb_bank *h, const SmallArgs &a) {
 
 // h->A (padded, symmetric) and h->dsq are filled.  Output: dQ (S x S, dQ = D^1/2 dA D^-1/2) when
 // `dA_padded` is false, else dL/dA itself as a padded LD x LD matrix.
-static int large_eval(cb_bank *h, bool normalize, double *lossd, double *out, bool dA_padded, double *Pd) {
+static int large_eval(cb_bank *h, bool normalize, double *lossd, double *out, bool dA_padded, double *Pd,
+                      bool reuse_eigh = false) {
   const int S = h->S, LD = h->LD;
   const int B = Pd ? h->B : h->Bl;                 // the loss visits live buckets only
   const double *tb = Pd ? h->t : h->t_live;
   const size_t LL = (size_t)LD * LD;
   double *dQd = out;
-  int rc = large_eigh(h, true);
+  int rc = CB_OK;
+  if (!(reuse_eigh && h->have_prev)) rc = large_eigh(h, true);   // reuse: same matrix as the previous call (CB_REUSE_EIGH)
   if (rc != CB_OK) return rc;
   mark(h, EV_EIGH);
   hipLaunchKernelGGL(lg_tables, dim3((unsigned)(((size_t)B * LD + 255) / 256)), dim3(256), 0,
@@ -755,11 +759,12 @@ static int large_eval(cb_bank *h, bool normalize, double *lossd, double *out, bo
 }
 
 static int large_loss_grad(cb_bank *h, const double *Qd, const double *pid, bool normalize,
-                           double *lossd, double *dQd, double *Pd) {
+                           double *lossd, double *dQd, double *Pd, bool reuse_eigh = false) {
   const size_t LL = (size_t)h->LD * h->LD;
-  hipLaunchKernelGGL(lg_build_A, dim3((unsigned)((LL + 255) / 256)), dim3(256), 0, h->stream, h->S, h->LD,
-                     Qd, pid, h->A, h->dsq);
-  return large_eval(h, normalize, lossd, dQd, false, Pd);
+  if (!(reuse_eigh && h->have_prev))
+    hipLaunchKernelGGL(lg_build_A, dim3((unsigned)((LL + 255) / 256)), dim3(256), 0, h->stream, h->S, h->LD,
+                       Qd, pid, h->A, h->dsq);
+  return large_eval(h, normalize, lossd, dQd, false, Pd, reuse_eigh);
 }
 
 // ---------------------------------------------------------------- entry points
@@ -859,7 +864,7 @@ extern "C" int cb_expm_bank(cb_handle h, const double *Q, const double *pi, int 
   if (!pi) {
     rc = general_run(h, Qd, 0, h->loss, nullptr, Pd);
   } else if (h->large) {
-    rc = large_loss_grad(h, Qd, pid, false, h->loss, nullptr, Pd);
+    rc = large_loss_grad(h, Qd, pid, false, h->loss, nullptr, Pd, (flags & CB_REUSE_EIGH) != 0);
   } else {
     SmallArgs a{};
     a.S = h->S;
@@ -887,6 +892,20 @@ extern "C" int cb_expm_bank(cb_handle h, const double *Q, const double *pi, int 
   }
   if (rc != CB_OK) return rc;
   return finish_call(h, flags);
+}
+
+// internal (cb_internal.hip.h): new branch lengths for a counts-free handle, B <= the B it was created with --
+// lets cb_tree_likelihood_batch push family after family through ONE handle (one eigendecomposition)
+int cb_internal_set_times(cb_handle h, const double *t_host, int B) {
+  if (!h || !t_host) return fail(CB_EINVAL, "cb_internal_set_times: NULL argument");
+  if (!h->expm_only || h->L != 1) return fail(CB_EINVAL, "cb_internal_set_times: counts-free single-bank handles only");
+  if (B < 1 || B > h->B_cap) return fail(CB_EINVAL, "cb_internal_set_times: B = %d exceeds the handle's capacity %d", B, h->B_cap);
+  HIP_TRY(hipSetDevice(h->dev));
+  HIP_TRY(hipStreamSynchronize(h->stream));     // the previous bank is done with h->t
+  HIP_TRY(hipMemcpy(h->t, t_host, B * sizeof(double), hipMemcpyHostToDevice));
+  h->B = B;
+  h->t_host.assign(t_host, t_host + B);
+  return CB_OK;
 }
 
 extern "C" int cb_eigh(cb_handle h, const double *A, int flags, double *lam, double *U) {
@@ -953,7 +972,11 @@ static int general_large_run(cb_bank *h, const double *Qd, int flags, double *lo
   if (h->L != 1) return fail(CB_EUNSUPPORTED, "general path, S > 32: L == 1 banks only");
   if (!Pd && h->dtype == CB_F32)
     return fail(CB_EUNSUPPORTED, "general (non-reversible) path: CB_F64 / CB_MIXED handles only (the counts of a CB_F32 handle are float32)");
-  const int S = h->S, LD = h->LD, B = Pd ? h->B : h->Bl, Bcap = h->B;
+  const int S = h->S, LD = h->LD, B = Pd ? h->B : h->Bl, Bcap = h->B_cap;
+  // counts-free handles never run the adjoint: the Horner iterates and the squarings ping-pong between two
+  // slots instead of keeping all 17 + s_max of them (a 2047-node family at 400 states: 10 GB instead of 100)
+  const bool lean = h->expm_only;
+  const int n_horner = lean ? 2 : GL_DEG - 1;
   const std::vector<double> &th = Pd ? h->t_host : h->t_live_host;
   const size_t LL = (size_t)LD * LD, BL = (size_t)B * LL, capBL = (size_t)Bcap * LL;
   const int nt32 = (LD + 31) / 32;
@@ -961,9 +984,9 @@ static int general_large_run(cb_bank *h, const double *Qd, int flags, double *lo
   if (!w.Qn) {
     bool ok = dev_alloc(h, &w.Qn, LL) == CB_OK && dev_alloc(h, &w.QT, LL) == CB_OK && dev_alloc(h, &w.colsum, LD) == CB_OK &&
               dev_alloc(h, &w.alpha, Bcap) == CB_OK && dev_alloc(h, &w.nsq, Bcap) == CB_OK &&
-              dev_alloc(h, &w.R, (GL_DEG - 1) * capBL) == CB_OK && dev_alloc(h, &w.RT, (GL_DEG - 1) * capBL) == CB_OK &&
-              dev_alloc(h, &w.G, 2 * capBL) == CB_OK && dev_alloc(h, &w.GT, 2 * capBL) == CB_OK &&
-              dev_alloc(h, &w.Xbar, capBL) == CB_OK && dev_alloc(h, &w.lpart, (size_t)Bcap * nt32 * nt32) == CB_OK;
+              dev_alloc(h, &w.R, n_horner * capBL) == CB_OK && dev_alloc(h, &w.RT, n_horner * capBL) == CB_OK &&
+              (lean || (dev_alloc(h, &w.G, 2 * capBL) == CB_OK && dev_alloc(h, &w.GT, 2 * capBL) == CB_OK &&
+                        dev_alloc(h, &w.Xbar, capBL) == CB_OK && dev_alloc(h, &w.lpart, (size_t)Bcap * nt32 * nt32) == CB_OK));
     if (!ok) return CB_ENOMEM;
   }
   hipLaunchKernelGGL(gl_prep, dim3(LD), dim3(256), 0, h->stream, S, LD, Qd, w.Qn, w.QT, w.colsum);
@@ -985,11 +1008,12 @@ static int general_large_run(cb_bank *h, const double *Qd, int flags, double *lo
     alpha[b] = std::ldexp(th[b], -sq);
     smax = std::max(smax, sq);
   }
-  if (w.cap_slots < smax + 1) {   // (an outgrown stack stays allocated until cb_destroy)
+  const int need_slots = lean ? std::min(smax + 1, 2) : smax + 1;
+  if (w.cap_slots < need_slots) {   // (an outgrown stack stays allocated until cb_destroy)
     w.E = w.ET = nullptr;
-    if (dev_alloc(h, &w.E, (size_t)(smax + 1) * capBL) != CB_OK || dev_alloc(h, &w.ET, (size_t)(smax + 1) * capBL) != CB_OK)
+    if (dev_alloc(h, &w.E, (size_t)need_slots * capBL) != CB_OK || dev_alloc(h, &w.ET, (size_t)need_slots * capBL) != CB_OK)
       return CB_ENOMEM;
-    w.cap_slots = smax + 1;
+    w.cap_slots = need_slots;
   }
   HIP_TRY(hipMemcpyAsync(w.alpha, alpha.data(), B * sizeof(double), hipMemcpyHostToDevice, h->stream));
   HIP_TRY(hipMemcpyAsync(w.nsq, nsq.data(), B * sizeof(int), hipMemcpyHostToDevice, h->stream));
@@ -997,10 +1021,10 @@ static int general_large_run(cb_bank *h, const double *Qd, int flags, double *lo
   const int tn = (LD + LG_TN - 1) / LG_TN;
   const dim3 grid((unsigned)(tn * tn * B)), blk(LG4_THREADS);
   const unsigned nel = (unsigned)((BL + 255) / 256);
-  auto Rn = [&](int k) { return w.R + (size_t)(k - 2) * BL; };    // R_k, k = 2..18
-  auto Rt = [&](int k) { return w.RT + (size_t)(k - 2) * BL; };
-  auto En = [&](int i) { return w.E + (size_t)i * BL; };
-  auto Et = [&](int i) { return w.ET + (size_t)i * BL; };
+  auto Rn = [&](int k) { return w.R + (size_t)(lean ? k & 1 : k - 2) * BL; };    // R_k, k = 2..18
+  auto Rt = [&](int k) { return w.RT + (size_t)(lean ? k & 1 : k - 2) * BL; };
+  auto En = [&](int i) { return w.E + (size_t)(lean ? i & 1 : i) * BL; };
+  auto Et = [&](int i) { return w.ET + (size_t)(lean ? i & 1 : i) * BL; };
   auto gemm = [&](BgArgs a) {
     a.LD = LD;
     a.B = B;
@@ -1022,7 +1046,7 @@ static int general_large_run(cb_bank *h, const double *Qd, int flags, double *lo
     gemm(a);
   }
   const double inv_n = (flags & CB_NORMALIZE) ? 1.0 / (h->comm ? h->n_global[0] : h->n_host[0]) : 1.0;
-  GlLoss gl{S, LD, B, w.E, w.ET, w.nsq, h->Ct, inv_n, w.G, w.GT, BL, w.lpart, Pd};
+  GlLoss gl{S, LD, B, w.E, w.ET, w.nsq, lean ? 1 : ~0, h->Ct, inv_n, w.G, w.GT, BL, w.lpart, Pd};
   hipLaunchKernelGGL(gl_loss, dim3(nt32, nt32, B), dim3(32, 8), 0, h->stream, gl);
   if (Pd) {
     HIP_TRY(hipGetLastError());

@@ -105,6 +105,7 @@ struct GlLoss {
   int S, LD, B;
   const double *E, *ET;    // squaring stacks [slot][B][LD][LD]
   const int *nsq;
+  int slot_and;            // ~0: bucket b's result sits in slot nsq[b]; 1: two ping-pong slots (counts-free handles)
   const double *Ct;        // [B][LD][LD] transposed counts (padded)
   double inv_n;
   double *G, *GT;          // Pbar buffers (two halves each)
@@ -116,7 +117,7 @@ __global__ void gl_loss(GlLoss a) {
   __shared__ double tile[32][33];
   __shared__ double red[32];
   const int b = blockIdx.z, LD = a.LD;
-  const size_t LL = (size_t)LD * LD, slot = ((size_t)a.nsq[b] * a.B + b) * LL;
+  const size_t LL = (size_t)LD * LD, slot = ((size_t)(a.nsq[b] & a.slot_and) * a.B + b) * LL;
   const int i0 = blockIdx.y * 32, j0 = blockIdx.x * 32;
   if (a.P) {
     for (int r = threadIdx.y; r < 32; r += blockDim.y) {

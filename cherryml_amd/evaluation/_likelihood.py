@@ -44,36 +44,120 @@ def _tree_arrays(tree: Tree):
     return index, np.array([index[v] for v in order], dtype=np.int32), parent, length
 
 
+def tree_likelihood_batch(trees: List[Tree], codes_a: List[np.ndarray], codes_b: Optional[List[np.ndarray]], Q, pi_root,
+                          unit_rates: List, reversible: bool = True, alphabet_size: Optional[int] = None,
+                          device: int = 0, profile: Optional[dict] = None) -> List[np.ndarray]:
+    """Log-likelihood of every unit of MANY families under one model, one call of cb_tree_likelihood_batch:
+    family f has tree `trees[f]`, `codes_a[f]` [n_nodes, n_units] (rows in `tree.nodes()` order, -1 =
+    unobserved; `codes_b[f]` for pairs) and `unit_rates[f]` [n_units] scaling Q per unit.  The model's
+    eigendecomposition is shared by the families (400-state pair model: one eigensolve for the batch)."""
+    Q, pi_root = _f64(Q), _f64(pi_root).reshape(-1)
+    S = Q.shape[0]
+    pairs = codes_b is not None
+    n_nodes, n_units, n_cats = [], [], []
+    cat_order, cat_parent, cat_length, cat_rates, cat_ucat, cat_a, cat_b = [], [], [], [], [], [], []
+    for f, tree in enumerate(trees):
+        _, order, parent, length = _tree_arrays(tree)
+        rates = _f64(unit_rates[f]).reshape(-1)
+        cr, uc = np.unique(rates, return_inverse=True)
+        a = np.ascontiguousarray(codes_a[f], dtype=np.int8)
+        if a.ndim != 2 or a.shape[0] != parent.size or rates.size != a.shape[1]:
+            raise ValueError("codes must be [n_nodes, n_units] and unit_rates [n_units]")
+        if pairs:
+            b = np.ascontiguousarray(codes_b[f], dtype=np.int8)
+            if b.shape != a.shape:
+                raise ValueError("codes must be [n_nodes, n_units] and unit_rates [n_units]")
+            cat_b.append(b.reshape(-1))
+        n_nodes.append(parent.size), n_units.append(a.shape[1]), n_cats.append(cr.size)
+        cat_order.append(order), cat_parent.append(parent), cat_length.append(length)
+        cat_rates.append(cr), cat_ucat.append(uc.astype(np.int32)), cat_a.append(a.reshape(-1))
+    i32 = lambda x: np.ascontiguousarray(x, dtype=np.int32)   # noqa: E731
+    n_nodes, n_units, n_cats = i32(n_nodes), i32(n_units), i32(n_cats)
+    order, parent, length = i32(np.concatenate(cat_order)), i32(np.concatenate(cat_parent)), _f64(np.concatenate(cat_length))
+    cat_rate, unit_cat = _f64(np.concatenate(cat_rates)), i32(np.concatenate(cat_ucat))
+    a = np.ascontiguousarray(np.concatenate(cat_a), dtype=np.int8)
+    b = np.ascontiguousarray(np.concatenate(cat_b), dtype=np.int8) if pairs else None
+    pi_rev = _f64(_stationary_distribution(Q)) if reversible else None
+    ll, ms = np.empty(int(n_units.sum())), np.zeros(2)
+    S1 = 0 if not pairs else int(alphabet_size if alphabet_size is not None else round(S ** 0.5))
+    rc = _lib.load().cb_tree_likelihood_batch(
+        device, S, S1, Q.ctypes.data, None if pi_rev is None else pi_rev.ctypes.data, pi_root.ctypes.data,
+        len(trees), n_nodes.ctypes.data, order.ctypes.data, parent.ctypes.data, length.ctypes.data,
+        n_cats.ctypes.data, cat_rate.ctypes.data, n_units.ctypes.data, unit_cat.ctypes.data, a.ctypes.data,
+        None if b is None else b.ctypes.data, ll.ctypes.data, ms.ctypes.data)
+    _lib.check(rc, "cb_tree_likelihood_batch")
+    if profile is not None:
+        profile["kernel_ms"] = profile.get("kernel_ms", 0.0) + float(ms[0])
+        key = "prune_ms_pairs" if pairs else "prune_ms_sites"
+        profile[key] = profile.get(key, 0.0) + float(ms[1])
+    return np.split(ll, np.cumsum(n_units)[:-1])
+
+
 def tree_likelihood(tree: Tree, codes_a: np.ndarray, codes_b: Optional[np.ndarray], Q, pi_root, unit_rates,
                     reversible: bool = True, alphabet_size: Optional[int] = None, device: int = 0,
                     profile: Optional[dict] = None) -> np.ndarray:
     """Log-likelihood of every unit (column of `codes_a` [n_nodes, n_units], rows in `tree.nodes()`
     order, -1 = unobserved; `codes_b` for pairs).  `unit_rates[u]` scales Q for unit u."""
-    Q, pi_root = _f64(Q), _f64(pi_root).reshape(-1)
-    S = Q.shape[0]
-    _, order, parent, length = _tree_arrays(tree)
-    rates = _f64(unit_rates).reshape(-1)
-    cat_rate, unit_cat = np.unique(rates, return_inverse=True)
-    unit_cat = np.ascontiguousarray(unit_cat, dtype=np.int32)
-    a = np.ascontiguousarray(codes_a, dtype=np.int8)
-    b = None if codes_b is None else np.ascontiguousarray(codes_b, dtype=np.int8)
-    n_units = a.shape[1]
-    if a.shape[0] != parent.size or rates.size != n_units or (b is not None and b.shape != a.shape):
-        raise ValueError("codes must be [n_nodes, n_units] and unit_rates [n_units]")
-    pi_rev = _f64(_stationary_distribution(Q)) if reversible else None
-    ll, ms = np.empty(n_units), np.zeros(2)
-    S1 = 0 if b is None else int(alphabet_size if alphabet_size is not None else round(S ** 0.5))
-    rc = _lib.load().cb_tree_likelihood(
-        device, S, S1, Q.ctypes.data, None if pi_rev is None else pi_rev.ctypes.data, pi_root.ctypes.data,
-        parent.size, order.ctypes.data, parent.ctypes.data, length.ctypes.data, cat_rate.size,
-        cat_rate.ctypes.data, n_units, unit_cat.ctypes.data, a.ctypes.data, None if b is None else b.ctypes.data,
-        ll.ctypes.data, ms.ctypes.data)
-    _lib.check(rc, "cb_tree_likelihood")
-    if profile is not None:
-        profile["kernel_ms"] = profile.get("kernel_ms", 0.0) + float(ms[0])
-        key = "prune_ms_pairs" if b is not None else "prune_ms_sites"
-        profile[key] = profile.get(key, 0.0) + float(ms[1])
-    return ll
+    return tree_likelihood_batch([tree], [codes_a], None if codes_b is None else [codes_b], Q, pi_root, [unit_rates],
+                                 reversible=reversible, alphabet_size=alphabet_size, device=device, profile=profile)[0]
+
+
+def _family_units(tree: Tree, msa: Dict[str, str], contact_map: Optional[np.ndarray], num_sites: int,
+                  amino_acids: List[str], with_pairs: bool):
+    """(independent sites, contacting pairs, leaf state codes [n_nodes, num_sites]) of one family (:88-126)"""
+    if contact_map is not None and with_pairs:
+        pairs = [(int(i), int(j)) for i, j in zip(*np.where(np.asarray(contact_map) == 1)) if i < j]
+    else:
+        pairs = []
+    flat = [s for p in pairs for s in p]
+    if len(set(flat)) != len(flat):   # :88-95
+        raise Exception(f"Each site can only be in contact with one other site. The contacting sites were: {pairs}")
+    in_pair = set(flat)
+    indep = [i for i in range(num_sites) if i not in in_pair]
+    nodes = tree.nodes()
+    lut = np.full(256, -1, dtype=np.int8)
+    for i, aa in enumerate(amino_acids):
+        if len(aa) == 1 and ord(aa) < 256:
+            lut[ord(aa)] = i
+    codes = np.full((len(nodes), num_sites), -1, dtype=np.int8)
+    for r, v in enumerate(nodes):
+        if tree.is_leaf(v) and v in msa:
+            codes[r] = lut[np.frombuffer(msa[v].encode("latin-1"), dtype=np.uint8)]
+    return indep, pairs, codes
+
+
+def dp_likelihood_computation_batch(trees: List[Tree], msas: List[Dict[str, str]], contact_maps: List[Optional[np.ndarray]],
+                                    site_rates: List[List[float]], amino_acids: List[str], pi_1: np.ndarray,
+                                    Q_1: np.ndarray, reversible_1: bool = True, pi_2: Optional[np.ndarray] = None,
+                                    Q_2: Optional[np.ndarray] = None, reversible_2: Optional[bool] = True,
+                                    device: int = 0, profile: Optional[dict] = None) -> List[Tuple[float, List[float]]]:
+    """`dp_likelihood_computation` for many families under the same models: two GPU calls for the whole batch
+    (independent sites; contacting pairs), the reference's per-family results."""
+    profile = {} if profile is None else profile
+    units = [_family_units(t, m, c, len(r), amino_acids, Q_2 is not None)
+             for t, m, c, r in zip(trees, msas, contact_maps, site_rates)]
+    lls = [[0.0] * len(r) for r in site_rates]
+    with_sites = [f for f, (indep, _, _) in enumerate(units) if indep]
+    if with_sites:
+        out = tree_likelihood_batch([trees[f] for f in with_sites], [units[f][2][:, units[f][0]] for f in with_sites], None,
+                                    Q_1, pi_1, [[site_rates[f][i] for i in units[f][0]] for f in with_sites],
+                                    reversible=bool(reversible_1), device=device, profile=profile)
+        for f, ll1 in zip(with_sites, out):
+            for i, x in zip(units[f][0], ll1):
+                lls[f][i] = float(x)
+    with_pairs = [f for f, (_, pairs, _) in enumerate(units) if pairs]
+    if with_pairs:
+        ia = {f: [p[0] for p in units[f][1]] for f in with_pairs}
+        ib = {f: [p[1] for p in units[f][1]] for f in with_pairs}
+        out = tree_likelihood_batch([trees[f] for f in with_pairs], [units[f][2][:, ia[f]] for f in with_pairs],
+                                    [units[f][2][:, ib[f]] for f in with_pairs], Q_2, pi_2,
+                                    [np.ones(len(ia[f])) for f in with_pairs], reversible=bool(reversible_2),
+                                    alphabet_size=len(amino_acids), device=device, profile=profile)
+        for f, ll2 in zip(with_pairs, out):
+            for (i, j), x in zip(units[f][1], ll2):
+                lls[f][i] = float(x) / 2.0
+                lls[f][j] = float(x) / 2.0
+    return [(sum(l), l) for l in lls]
 
 
 def dp_likelihood_computation(tree: Tree, msa: Dict[str, str], contact_map: Optional[np.ndarray],
@@ -86,46 +170,14 @@ def dp_likelihood_computation(tree: Tree, msa: Dict[str, str], contact_map: Opti
     """`dp_likelihood_computation` (_likelihood.py:47-327).  `fact_*` / `device_*` are accepted for
     call compatibility and ignored: the spectral factorisation happens on the GPU."""
     st_all = time.time()
-    num_sites = len(site_rates)
-    if contact_map is not None and Q_2 is not None:
-        pairs = [(int(i), int(j)) for i, j in zip(*np.where(np.asarray(contact_map) == 1)) if i < j]
-    else:
-        pairs = []
-    flat = [s for p in pairs for s in p]
-    if len(set(flat)) != len(flat):   # :88-95
-        raise Exception(f"Each site can only be in contact with one other site. The contacting sites were: {pairs}")
-    in_pair = set(flat)
-    indep = [i for i in range(num_sites) if i not in in_pair]
-    nodes = tree.nodes()
-    code = {aa: i for i, aa in enumerate(amino_acids)}
-    lut = np.full(256, -1, dtype=np.int8)
-    for aa, i in code.items():
-        if len(aa) == 1 and ord(aa) < 256:
-            lut[ord(aa)] = i
-    codes = np.full((len(nodes), num_sites), -1, dtype=np.int8)
-    for r, v in enumerate(nodes):
-        if tree.is_leaf(v) and v in msa:
-            codes[r] = lut[np.frombuffer(msa[v].encode("latin-1"), dtype=np.uint8)]
-    lls = [0.0] * num_sites
     profile = {} if profile is None else profile
-    if indep:
-        ll1 = tree_likelihood(tree, codes[:, indep], None, Q_1, pi_1, [site_rates[i] for i in indep],
-                              reversible=bool(reversible_1), device=device, profile=profile)
-        for i, x in zip(indep, ll1):
-            lls[i] = float(x)
-    if pairs:
-        ia, ib = [p[0] for p in pairs], [p[1] for p in pairs]
-        ll2 = tree_likelihood(tree, codes[:, ia], codes[:, ib], Q_2, pi_2, np.ones(len(pairs)),
-                              reversible=bool(reversible_2), alphabet_size=len(amino_acids), device=device,
-                              profile=profile)
-        for (i, j), x in zip(pairs, ll2):
-            lls[i] = float(x) / 2.0
-            lls[j] = float(x) / 2.0
+    res = dp_likelihood_computation_batch([tree], [msa], [contact_map], [list(site_rates)], amino_acids, pi_1, Q_1,
+                                          reversible_1, pi_2, Q_2, reversible_2, device=device, profile=profile)[0]
     if output_profiling_path is not None:
         with open(output_profiling_path, "w") as f:
             f.write(f"GPU time (expm bank + pruning): {profile.get('kernel_ms', 0.0) / 1e3}\n"
                     f"Total time: {time.time() - st_all}\n")
-    return sum(lls), lls
+    return res
 
 
 def write_log_likelihood(log_likelihood: Tuple[float, Optional[List[float]]], path: str) -> None:
@@ -145,8 +197,8 @@ def compute_log_likelihoods(tree_dir: str, msa_dir: str, site_rates_dir: str, co
                             Q_2_path: Optional[str], reversible_2: Optional[bool], device_2: Optional[str],
                             output_likelihood_dir: str, num_processes: int = 1, device: int = 0, **_ignored) -> None:
     """The stage `compute_log_likelihoods` (_likelihood.py:474-600): `<family>.txt` (total, then the
-    per-site values) and `<family>.profiling` in `output_likelihood_dir`.  Families run one after
-    another on one GPU; `num_processes`, `device_1/2` and the CPU threading knobs are accepted and
+    per-site values) and `<family>.profiling` in `output_likelihood_dir`.  Families run in batches
+    on one GPU (cb_tree_likelihood_batch: shared eigendecompositions, no host synchronisation per family); `num_processes`, `device_1/2` and the CPU threading knobs are accepted and
     ignored."""
     st = time.time()
     os.makedirs(output_likelihood_dir, exist_ok=True)
@@ -163,18 +215,25 @@ def compute_log_likelihoods(tree_dir: str, msa_dir: str, site_rates_dir: str, co
         raise Exception(f"Q_1 states are:\n{list(Q_1_df.index)}\n\nbut expected amino acids:\n{amino_acids}")
     if Q_2_df is not None and (list(Q_2_df.index) != pairs_of_amino_acids or list(Q_2_df.columns) != pairs_of_amino_acids):
         raise Exception(f"Q_2 states are:\n{list(Q_2_df.index)}\n\nbut expected pairs of amino acids:\n{pairs_of_amino_acids}")
-    for family in families:
-        tree = read_tree(os.path.join(tree_dir, family + ".txt"))
-        msa = read_msa(os.path.join(msa_dir, family + ".txt"))
-        site_rates = list(read_site_rates(os.path.join(site_rates_dir, family + ".txt")))
-        contact_map = (read_contact_map(os.path.join(contact_map_dir, family + ".txt"))
-                       if contact_map_dir is not None else None)
-        res = dp_likelihood_computation(
-            tree=tree, msa=msa, contact_map=contact_map, site_rates=site_rates, amino_acids=amino_acids,
-            pi_1=pi_1_df.to_numpy(), Q_1=Q_1_df.to_numpy(), reversible_1=reversible_1,
-            pi_2=pi_2_df.to_numpy() if pi_2_df is not None else None,
-            Q_2=Q_2_df.to_numpy() if Q_2_df is not None else None, reversible_2=reversible_2,
-            output_profiling_path=os.path.join(output_likelihood_dir, family + ".profiling"), device=device)
-        write_log_likelihood(res, os.path.join(output_likelihood_dir, family + ".txt"))
+    # families in chunks (bounded host memory); each chunk is two GPU calls sharing the models' eigendecompositions
+    chunk = 64
+    for c0 in range(0, len(families), chunk):
+        fams = families[c0:c0 + chunk]
+        st_c = time.time()
+        trees = [read_tree(os.path.join(tree_dir, f + ".txt")) for f in fams]
+        msas = [read_msa(os.path.join(msa_dir, f + ".txt")) for f in fams]
+        rates = [list(read_site_rates(os.path.join(site_rates_dir, f + ".txt"))) for f in fams]
+        cmaps = [read_contact_map(os.path.join(contact_map_dir, f + ".txt")) if contact_map_dir is not None else None
+                 for f in fams]
+        profile = {}
+        results = dp_likelihood_computation_batch(
+            trees, msas, cmaps, rates, amino_acids, pi_1_df.to_numpy(), Q_1_df.to_numpy(), reversible_1,
+            pi_2_df.to_numpy() if pi_2_df is not None else None, Q_2_df.to_numpy() if Q_2_df is not None else None,
+            reversible_2, device=device, profile=profile)
+        for family, res in zip(fams, results):
+            write_log_likelihood(res, os.path.join(output_likelihood_dir, family + ".txt"))
+            with open(os.path.join(output_likelihood_dir, family + ".profiling"), "w") as f:   # per family: its share
+                f.write(f"GPU time (expm bank + pruning): {profile.get('kernel_ms', 0.0) / 1e3 / len(fams)}\n"
+                        f"Total time: {(time.time() - st_c) / len(fams)}\n")
     with open(os.path.join(output_likelihood_dir, "profiling_0.txt"), "w") as f:
         f.write(f"Total time: {time.time() - st}\n")

@@ -339,6 +339,19 @@ int cb_tree_likelihood(int device, int S, int S1, const double *Q, const double 
                        const double *length, int n_cats, const double *cat_rate, int n_units,
                        const int *unit_cat, const int8_t *code_a, const int8_t *code_b, double *ll,
                        double *kernel_ms);
+/* MANY families under one model in one call (the reference maps families over a process pool,
+ * _likelihood.py:474-600 with utils.py:59-67).  Family f has n_nodes[f] nodes, n_units[f] units and
+ * n_cats[f] rate categories; postorder / parent / length (node indices local to the family), cat_rate,
+ * unit_cat, code_a / code_b ([n_nodes[f]][n_units[f]]) and ll are the families' arrays concatenated in
+ * order.  The batch shares the model: for S > 32 one counts-free bank handle serves every family and the
+ * eigendecomposition of Q is computed ONCE (3 ms cold at 400 states, formerly per family); Q / pi uploads,
+ * the message buffer and the stream are shared, and pruning never waits for the host between families.
+ * Results equal cb_tree_likelihood's family by family; kernel_ms as there, summed over the batch. */
+int cb_tree_likelihood_batch(int device, int S, int S1, const double *Q, const double *pi_rev,
+                             const double *pi_root, int n_fam, const int *n_nodes, const int *postorder,
+                             const int *parent, const double *length, const int *n_cats,
+                             const double *cat_rate, const int *n_units, const int *unit_cat,
+                             const int8_t *code_a, const int8_t *code_b, double *ll, double *kernel_ms);
 
 /* ---- count-matrix text format, host only ---------------------------------------
  * Replaces the tokenising loops of cherryml/io/_count_matrices.py:8-62 (read_count_matrices): `text` is the

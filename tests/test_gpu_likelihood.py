@@ -118,6 +118,55 @@ def test_likelihood_pairs_match_oracle(n_leaves, n_pairs, extra):
     assert abs(ll - ll_o) <= RTOL * abs(ll_o)
 
 
+def _random_pair_model(rng):
+    pi2 = rng.dirichlet(np.full(400, 5.0))
+    sym = rng.uniform(0.0, 1.0, (400, 400)) * (rng.uniform(size=(400, 400)) < 0.3)
+    sym = np.triu(sym, 1) + np.triu(sym, 1).T
+    Q2 = sym * pi2[None, :]
+    Q2[np.diag_indices(400)] = -Q2.sum(1)
+    Q2 /= -(pi2 * np.diag(Q2)).sum()
+    return pi2, Q2
+
+
+@pytest.mark.parametrize("reversible_2", [True, False])
+def test_likelihood_batch_of_families_equals_family_by_family(reversible_2):
+    """cb_tree_likelihood_batch: ragged families (2 .. 60 leaves, 0 .. 23 pairs, one family without pairs,
+    one without independent sites) in two GPU calls; every per-site value equals the single-family call's
+    bit for bit (same kernels, shared eigendecomposition) and the oracle's to 1e-9."""
+    from cherryml_amd.evaluation import dp_likelihood_computation, dp_likelihood_computation_batch
+    from oracle import likelihood_oracle as lo
+    z = load_golden("likelihood.npz")
+    aa = [str(a) for a in z["amino_acids"]]
+    rng = np.random.default_rng(2024)
+    pi2, Q2 = _random_pair_model(rng)
+    trees, msas, cms, rates = [], [], [], []
+    for n_leaves, n_pairs, extra in [(9, 5, 3), (2, 0, 7), (60, 23, 1), (17, 4, 0), (33, 16, 20)]:
+        tree, names = _random_tree(rng, n_leaves)
+        L = 2 * n_pairs + extra
+        cm = np.zeros((L, L), dtype=int)
+        perm = rng.permutation(L)
+        for k in range(n_pairs):
+            i, j = perm[2 * k], perm[2 * k + 1]
+            cm[i, j] = cm[j, i] = 1
+        trees.append(tree), msas.append(_random_msa(rng, names, L, aa, gap=0.15)), cms.append(cm)
+        rates.append(list(rng.choice(np.round(rng.uniform(0.1, 3.0, 4), 3), size=L)))
+    profile = {}
+    got = dp_likelihood_computation_batch(trees, msas, cms, rates, aa, z["pi_wag"], z["wag"], True, pi2, Q2, reversible_2,
+                                          profile=profile)
+    assert len(got) == 5 and profile["kernel_ms"] > 0
+    for f in range(5):
+        one = dp_likelihood_computation(trees[f], msas[f], cms[f], rates[f], aa, z["pi_wag"], z["wag"], pi_2=pi2, Q_2=Q2,
+                                        reversible_2=reversible_2)
+        assert np.array_equal(np.array(got[f][1]), np.array(one[1]), equal_nan=True), f
+        if f in (0, 3):
+            # family 3 has two leaves at distance 0 from their parent in different states: probability 0, and the
+            # reference's log-space pruning turns that into NaN (-inf - -inf, _likelihood.py:238-296) -- so do we
+            ll_o, lls_o = lo.log_likelihood(trees[f], msas[f], cms[f], rates[f], aa, z["pi_wag"], z["wag"], pi2, Q2)
+            assert np.isnan(lls_o).all() == (f == 3)
+            assert np.allclose(got[f][1], lls_o, rtol=RTOL, atol=1e-12, equal_nan=True)
+            assert np.isnan(ll_o) if f == 3 else abs(got[f][0] - ll_o) <= RTOL * abs(ll_o)
+
+
 def test_likelihood_small_alphabet_pairs_and_general_S():
     """S1 = 4 (16 pair states, lane-group kernel with pair observations) and S1 = 9 (81 states, MFMA kernel,
     S not a multiple of 4 or 16)."""
