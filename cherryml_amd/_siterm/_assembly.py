@@ -94,33 +94,51 @@ def get_count_prior_probability_matrices(rate_matrix: np.ndarray, quantization_p
     return out
 
 
-def _assemble(pairs, codes, grid, site_rates, prior, lam, reverse, S, device: int, to_torch: bool, profile=None):
-    L, B = codes.shape[1], len(grid)
-    codes = np.ascontiguousarray(codes)
+def _assemble_batch(pairs_list, codes_list, grid, site_rates_list, prior, lam, reverse, S, device: int, to_torch: bool,
+                    profile=None):
+    """cb_siterm_assemble_batch: the mixed count tensor [sum L_f, B, S, S] of many families (sites concatenated)."""
+    n_sites = np.ascontiguousarray([c.shape[1] for c in codes_list], dtype=np.int32)
+    n_pairs = np.ascontiguousarray([len(p) for p in pairs_list], dtype=np.int64)
+    B, Ltot = len(grid), int(n_sites.sum())
+    flat = [np.ascontiguousarray(c, dtype=np.int8).reshape(-1) for c in codes_list]
+    base = np.concatenate([[0], np.cumsum([f.size for f in flat])])
+    shifted = []
+    for f, p in enumerate(pairs_list):
+        q = np.array(p, dtype=PAIR_DTYPE, copy=True)
+        q["seq_a"] += base[f]
+        q["seq_b"] += base[f]
+        shifted.append(q)
+    pairs = np.ascontiguousarray(np.concatenate(shifted)) if shifted else np.zeros(0, dtype=PAIR_DTYPE)
+    codes = np.ascontiguousarray(np.concatenate(flat))
     grid = np.ascontiguousarray(grid, dtype=np.float64)
-    rates = np.ascontiguousarray(site_rates, dtype=np.float64)
+    for c, r in zip(codes_list, site_rates_list):
+        if np.size(r) != c.shape[1]:
+            raise ValueError(f"site_rates has {np.size(r)} entries, the MSA has {c.shape[1]} sites")
+    rates = np.ascontiguousarray(np.concatenate([np.asarray(r, dtype=np.float64).reshape(-1) for r in site_rates_list]))
     prior = np.ascontiguousarray(prior, dtype=np.float64)
-    if rates.size != L:
-        raise ValueError(f"site_rates has {rates.size} entries, the MSA has {L} sites")
     lib = _lib.load()
     if to_torch:
         import torch
-        out = torch.empty((L, B, S, S), dtype=torch.float64, device=torch.device("cuda", device))
+        out = torch.empty((Ltot, B, S, S), dtype=torch.float64, device=torch.device("cuda", device))
         torch.cuda.synchronize(out.device)
         ptr, flags = out.data_ptr(), CB_PTR_DEVICE
     else:
-        out = np.empty((L, B, S, S))
+        out = np.empty((Ltot, B, S, S))
         ptr, flags = out.ctypes.data, 0
     import ctypes
     ms = ctypes.c_double(0.0)
-    rc = lib.cb_siterm_assemble(device, S, B, L, grid.ctypes.data, codes.ctypes.data, codes.size,
-                                pairs.ctypes.data, len(pairs), rates.ctypes.data, prior.ctypes.data,
-                                float(lam), int(bool(reverse)), flags, ptr,
-                                ctypes.addressof(ms) if profile is not None else None)
-    _lib.check(rc, "cb_siterm_assemble")
+    rc = lib.cb_siterm_assemble_batch(device, S, B, len(codes_list), n_sites.ctypes.data, grid.ctypes.data, codes.ctypes.data,
+                                      codes.size, pairs.ctypes.data, n_pairs.ctypes.data, rates.ctypes.data,
+                                      prior.ctypes.data, float(lam), int(bool(reverse)), flags, ptr,
+                                      ctypes.addressof(ms) if profile is not None else None)
+    _lib.check(rc, "cb_siterm_assemble_batch")
     if profile is not None:
         profile["kernel_ms"] = ms.value
     return out
+
+
+def _assemble(pairs, codes, grid, site_rates, prior, lam, reverse, S, device: int, to_torch: bool, profile=None):
+    return _assemble_batch([pairs], [codes], grid, [site_rates], prior, lam, reverse, S, device, to_torch, profile)
 
 
 def get_raw_count_matrices(transitions: List[Tuple[str, str, float]], quantization_points_sorted,
@@ -139,22 +157,18 @@ def get_raw_count_matrices(transitions: List[Tuple[str, str, float]], quantizati
                      include_reverse_transitions, S, device, False)
 
 
-def estimate_site_specific_rate_matrices_given_tree_and_site_rates(
-    tree, site_rates: List[float], msa: Dict[str, str], alphabet: List[str],
+def estimate_site_specific_rate_matrices_given_trees_and_site_rates(
+    trees: List, site_rates: List[List[float]], msas: List[Dict[str, str]], alphabet: List[str],
     regularization_strength: float, regularization_rate_matrix: np.ndarray,
     quantization_points: List[float], optimization_num_epochs: int,
     transitions_strategy: str = "cherry++", include_reverse_transitions: bool = True,
-    rate_matrix_parameterization: str = "pande_reversible", log_dir: Optional[str] = None,
-    plot_site_specific_rate_matrices: int = 0, use_vectorized_cherryml_implementation: bool = True,
+    rate_matrix_parameterization: str = "pande_reversible", use_vectorized_cherryml_implementation: bool = True,
     vectorized_cherryml_implementation_device: str = "cpu",
-    vectorized_cherryml_implementation_num_cores: int = 1,
-) -> Dict:
-    """:442-731 (`_estimate_site_specific_rate_matrices_given_tree_and_site_rates`), vectorised path:
-    {"res": [L,S,S] site-specific rate matrices, "time_*": seconds per sub-step}.  Sites without
-    any count (e.g. all gaps) get the prior `Q0 * rate_l`, like the reference's per-site path
-    (:655-658).  `use_vectorized_cherryml_implementation=False` selects the reference's per-site
-    semantics (the pande_reversible parameterisation of `_quantized_transitions_mle`, :43-84) -- batched
-    over the sites on the device all the same."""
+) -> List[Dict]:
+    """MANY families under the same prior / grid / epochs in one go (the reference runs this estimator family by
+    family, over a process pool): one `cb_siterm_assemble_batch`, one bank over all families' sites, one device
+    optimisation loop.  Sites are independent, so every family's "res" equals what the single-family function
+    returns for it; the "time_*" entries are the batch's, repeated in every family's dictionary."""
     from .._device import resolve_device
     resolve_device(vectorized_cherryml_implementation_device, "estimate_site_specific_rate_matrices_given_tree_and_site_rates")
     if rate_matrix_parameterization != "pande_reversible":
@@ -167,20 +181,20 @@ def estimate_site_specific_rate_matrices_given_tree_and_site_rates(
     grid = sorted(quantization_points)
     Q0 = np.asarray(regularization_rate_matrix, dtype=np.float64)
     S = len(alphabet)
-    pairs, codes = _pairs_and_codes(tree, msa, alphabet, transitions_strategy)
-    L = codes.shape[1]
+    pc = [_pairs_and_codes(tree, msa, alphabet, transitions_strategy) for tree, msa in zip(trees, msas)]
+    n_sites = [c.shape[1] for _, c in pc]
     prof["time_get_transitions"] = time.time() - st
     st = time.time()
     prior = get_count_prior_probability_matrices(Q0, grid)
     prof["time_get_count_prior_probability_matrices"] = time.time() - st
     st = time.time()
     dev = torch.cuda.current_device()
-    counts = _assemble(pairs, codes, grid, site_rates, prior, regularization_strength,
-                       include_reverse_transitions, S, dev, True)
+    counts = _assemble_batch([p for p, _ in pc], [c for _, c in pc], grid, site_rates, prior, regularization_strength,
+                             include_reverse_transitions, S, dev, True)
     totals = counts.sum(dim=(1, 2, 3)).cpu().numpy()
     prof["time_get_count_matrices"] = time.time() - st
     st = time.time()
-    rates = np.asarray(site_rates, dtype=np.float64)
+    rates = np.concatenate([np.asarray(r, dtype=np.float64).reshape(-1) for r in site_rates])
     init = Q0[None, :, :] * rates[:, None, None]
     res = init.copy()
     has = totals > 0
@@ -214,4 +228,29 @@ def estimate_site_specific_rate_matrices_given_tree_and_site_rates(
                                                 do_adam=True, normalize=True)
             res[idx] = r["Q_best"].reshape(len(idx), S, S) if int(optimization_num_epochs) > 0 else init[idx]
     prof["time_optimization"] = time.time() - st
-    return {"res": res, **prof}
+    cuts = np.cumsum(n_sites)[:-1]
+    return [{"res": part, **prof} for part in np.split(res, cuts)]
+
+
+def estimate_site_specific_rate_matrices_given_tree_and_site_rates(
+    tree, site_rates: List[float], msa: Dict[str, str], alphabet: List[str],
+    regularization_strength: float, regularization_rate_matrix: np.ndarray,
+    quantization_points: List[float], optimization_num_epochs: int,
+    transitions_strategy: str = "cherry++", include_reverse_transitions: bool = True,
+    rate_matrix_parameterization: str = "pande_reversible", log_dir: Optional[str] = None,
+    plot_site_specific_rate_matrices: int = 0, use_vectorized_cherryml_implementation: bool = True,
+    vectorized_cherryml_implementation_device: str = "cpu",
+    vectorized_cherryml_implementation_num_cores: int = 1,
+) -> Dict:
+    """:442-731 (`_estimate_site_specific_rate_matrices_given_tree_and_site_rates`), vectorised path:
+    {"res": [L,S,S] site-specific rate matrices, "time_*": seconds per sub-step}.  Sites without
+    any count (e.g. all gaps) get the prior `Q0 * rate_l`, like the reference's per-site path
+    (:655-658).  `use_vectorized_cherryml_implementation=False` selects the reference's per-site
+    semantics (the pande_reversible parameterisation of `_quantized_transitions_mle`, :43-84) -- batched
+    over the sites on the device all the same."""
+    return estimate_site_specific_rate_matrices_given_trees_and_site_rates(
+        [tree], [site_rates], [msa], alphabet, regularization_strength, regularization_rate_matrix, quantization_points,
+        optimization_num_epochs, transitions_strategy=transitions_strategy,
+        include_reverse_transitions=include_reverse_transitions, rate_matrix_parameterization=rate_matrix_parameterization,
+        use_vectorized_cherryml_implementation=use_vectorized_cherryml_implementation,
+        vectorized_cherryml_implementation_device=vectorized_cherryml_implementation_device)[0]

@@ -178,26 +178,51 @@ extern "C" int cb_count_co_transitions(int device, int S, int B, const double *g
                       flags, counts, true);
 }
 
-extern "C" int cb_siterm_assemble(int device, int S, int B, int n_sites, const double *grid, const int8_t *seqs,
-                                  int64_t seqs_bytes, const cb_count_pair *pairs, int64_t n_pairs,
-                                  const double *site_rates, const double *prior, double lambda,
-                                  int include_reverse, int flags, double *counts, double *kernel_ms) {
-  if (!grid || !seqs || !pairs || !site_rates || !prior || !counts)
+// MANY families in one call: the site axis is the families' sites concatenated (family f owns rows
+// [sum_{g<f} n_sites[g], +n_sites[f]) of site_rates and counts), pairs are the families' transitions
+// concatenated (n_pairs[f] each, offsets into the one seqs buffer).  Sites are independent, so the
+// result is cb_siterm_assemble's family by family -- and the tensor feeds ONE cb_create / cb_train_siterm
+// over all families' sites.
+extern "C" int cb_siterm_assemble_batch(int device, int S, int B, int n_fam, const int *n_sites, const double *grid,
+                                        const int8_t *seqs, int64_t seqs_bytes, const cb_count_pair *pairs,
+                                        const int64_t *n_pairs, const double *site_rates, const double *prior,
+                                        double lambda, int include_reverse, int flags, double *counts,
+                                        double *kernel_ms) {
+  if (!grid || !seqs || !pairs || !site_rates || !prior || !counts || !n_sites || !n_pairs)
     return fail(CB_EINVAL, "cb_siterm_assemble: NULL argument");
-  if (S < 2 || S > 64 || B < 1 || n_sites < 1 || n_pairs < 0 || seqs_bytes < 0)
-    return fail(CB_EINVAL, "cb_siterm_assemble: bad sizes (S=%d, B=%d, n_sites=%d)", S, B, n_sites);
+  if (S < 2 || S > 64 || B < 1 || n_fam < 1 || seqs_bytes < 0)
+    return fail(CB_EINVAL, "cb_siterm_assemble: bad sizes (S=%d, B=%d, families=%d)", S, B, n_fam);
   if (!(lambda >= 0.0 && lambda <= 1.0)) return fail(CB_EINVAL, "cb_siterm_assemble: lambda must be in [0, 1]");
   for (int b = 1; b < B; ++b)
     if (!(grid[b] > grid[b - 1])) return fail(CB_EINVAL, "cb_siterm_assemble: grid must be strictly increasing");
-  for (int64_t p = 0; p < n_pairs; ++p)
-    if (pairs[p].seq_a < 0 || pairs[p].seq_b < 0 || pairs[p].seq_a + n_sites > seqs_bytes ||
-        pairs[p].seq_b + n_sites > seqs_bytes)
-      return fail(CB_EINVAL, "cb_siterm_assemble: pair %lld points outside seqs", (long long)p);
+  int64_t tot_sites = 0, tot_pairs = 0;
+  for (int f = 0; f < n_fam; ++f) {
+    if (n_sites[f] < 1 || n_pairs[f] < 0)
+      return fail(CB_EINVAL, "cb_siterm_assemble: family %d has n_sites = %d, n_pairs = %lld", f, n_sites[f], (long long)n_pairs[f]);
+    tot_sites += n_sites[f];
+    tot_pairs += n_pairs[f];
+  }
+  if (tot_sites > INT32_MAX) return fail(CB_EINVAL, "cb_siterm_assemble: %lld sites in one call", (long long)tot_sites);
+  // the kernel's view of a transition: its family's first site (aux) and site count (n)
+  std::vector<cb_count_pair> own(pairs, pairs + tot_pairs);
+  {
+    int64_t p = 0, site0 = 0;
+    for (int f = 0; f < n_fam; ++f) {
+      for (int64_t k = 0; k < n_pairs[f]; ++k, ++p) {
+        if (own[p].seq_a < 0 || own[p].seq_b < 0 || own[p].seq_a + n_sites[f] > seqs_bytes || own[p].seq_b + n_sites[f] > seqs_bytes)
+          return fail(CB_EINVAL, "cb_siterm_assemble: pair %lld points outside seqs", (long long)p);
+        own[p].aux = (int32_t)site0;
+        own[p].n = n_sites[f];
+      }
+      site0 += n_sites[f];
+    }
+  }
+  const int64_t n_pairs_all = tot_pairs;
   const int ndev = cb_device_count();
   if (ndev <= 0) return fail(CB_EHIP, "cb_siterm_assemble: no HIP device visible");
   if (device < 0 || device >= ndev) return fail(CB_EINVAL, "cb_siterm_assemble: device %d out of range", device);
   HIP_TRY(hipSetDevice(device));
-  const size_t SS = (size_t)S * S, nmat = (size_t)n_sites * B, ncounts = nmat * SS;
+  const size_t SS = (size_t)S * S, nmat = (size_t)tot_sites * B, ncounts = nmat * SS;
   void *d_grid = nullptr, *d_seqs = nullptr, *d_pairs = nullptr, *d_rates = nullptr, *d_prior = nullptr,
        *d_live = nullptr, *d_counts_own = nullptr;
   int rc = CB_OK;
@@ -205,8 +230,8 @@ extern "C" int cb_siterm_assemble(int device, int S, int B, int n_sites, const d
   if (rc == CB_OK && (expr) != hipSuccess) rc = fail(CB_EHIP, "cb_siterm_assemble: %s failed", #expr)
   TRYA(hipMalloc(&d_grid, B * sizeof(double)));
   TRYA(hipMalloc(&d_seqs, seqs_bytes > 0 ? seqs_bytes : 1));
-  TRYA(hipMalloc(&d_pairs, (n_pairs > 0 ? n_pairs : 1) * sizeof(cb_count_pair)));
-  TRYA(hipMalloc(&d_rates, n_sites * sizeof(double)));
+  TRYA(hipMalloc(&d_pairs, (n_pairs_all > 0 ? n_pairs_all : 1) * sizeof(cb_count_pair)));
+  TRYA(hipMalloc(&d_rates, tot_sites * sizeof(double)));
   TRYA(hipMalloc(&d_prior, (size_t)B * SS * sizeof(double)));
   TRYA(hipMalloc(&d_live, nmat * sizeof(int)));
   double *d_counts = counts;
@@ -216,8 +241,8 @@ extern "C" int cb_siterm_assemble(int device, int S, int B, int n_sites, const d
   }
   TRYA(hipMemcpyAsync(d_grid, grid, B * sizeof(double), hipMemcpyHostToDevice, 0));
   TRYA(hipMemcpyAsync(d_seqs, seqs, seqs_bytes, hipMemcpyHostToDevice, 0));
-  TRYA(hipMemcpyAsync(d_pairs, pairs, n_pairs * sizeof(cb_count_pair), hipMemcpyHostToDevice, 0));
-  TRYA(hipMemcpyAsync(d_rates, site_rates, n_sites * sizeof(double), hipMemcpyHostToDevice, 0));
+  TRYA(hipMemcpyAsync(d_pairs, own.data(), n_pairs_all * sizeof(cb_count_pair), hipMemcpyHostToDevice, 0));
+  TRYA(hipMemcpyAsync(d_rates, site_rates, tot_sites * sizeof(double), hipMemcpyHostToDevice, 0));
   TRYA(hipMemcpyAsync(d_prior, prior, (size_t)B * SS * sizeof(double), hipMemcpyHostToDevice, 0));
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   if (kernel_ms && rc == CB_OK) {
@@ -229,10 +254,10 @@ extern "C" int cb_siterm_assemble(int device, int S, int B, int n_sites, const d
   TRYA(hipMemsetAsync(d_live, 0, nmat * sizeof(int), 0));
   TRYA(hipMemsetAsync(d_counts, 0, ncounts * sizeof(double), 0));
   if (rc == CB_OK) {
-    if (n_pairs > 0)
-      hipLaunchKernelGGL(siterm_raw_counts_kernel, dim3((unsigned)((n_pairs + 3) / 4)), dim3(256), 0, 0, S, B, n_sites,
+    if (n_pairs_all > 0)
+      hipLaunchKernelGGL(siterm_raw_counts_kernel, dim3((unsigned)((n_pairs_all + 3) / 4)), dim3(256), 0, 0, S, B,
                          (const double *)d_grid, (const int8_t *)d_seqs, (const cb_count_pair *)d_pairs,
-                         (long long)n_pairs, d_counts, (int *)d_live);
+                         (long long)n_pairs_all, d_counts, (int *)d_live);
     hipLaunchKernelGGL(siterm_mix_kernel, dim3((unsigned)nmat), dim3(64), 0, 0, S, B, (const double *)d_grid,
                        (const double *)d_rates, (const double *)d_prior, lambda, include_reverse,
                        (const int *)d_live, d_counts);
@@ -253,4 +278,13 @@ extern "C" int cb_siterm_assemble(int device, int S, int B, int n_sites, const d
   for (void *q : {d_grid, d_seqs, d_pairs, d_rates, d_prior, d_live, d_counts_own})
     if (q) (void)hipFree(q);
   return rc;
+}
+
+extern "C" int cb_siterm_assemble(int device, int S, int B, int n_sites, const double *grid, const int8_t *seqs,
+                                  int64_t seqs_bytes, const cb_count_pair *pairs, int64_t n_pairs,
+                                  const double *site_rates, const double *prior, double lambda,
+                                  int include_reverse, int flags, double *counts, double *kernel_ms) {
+  if (n_sites < 1 || n_pairs < 0) return fail(CB_EINVAL, "cb_siterm_assemble: bad sizes (S=%d, B=%d, n_sites=%d)", S, B, n_sites);
+  return cb_siterm_assemble_batch(device, S, B, 1, &n_sites, grid, seqs, seqs_bytes, pairs, &n_pairs, site_rates, prior,
+                                  lambda, include_reverse, flags, counts, kernel_ms);
 }

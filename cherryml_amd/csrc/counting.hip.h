@@ -263,8 +263,10 @@ __global__ __launch_bounds__(256) void count_co_transitions_kernel(
 // two sequences carry states (x, y) at site l (:226-256).  One wavefront per transition, lanes
 // over the sites; the increments are small integers, so double atomics are exact and order
 // independent.  live[l * B + b] marks the (site, bucket) matrices that received anything.
+// A transition spans pr.n sites and its family's first site is row pr.aux of the site axis (many
+// families in one call, cb_siterm_assemble_batch; one family: aux = 0, n = n_sites).
 __global__ __launch_bounds__(256) void siterm_raw_counts_kernel(
-    int S, int B, int n_sites, const double *__restrict__ grid, const int8_t *__restrict__ seqs,
+    int S, int B, const double *__restrict__ grid, const int8_t *__restrict__ seqs,
     const cb_count_pair *__restrict__ pairs, long long n_pairs, double *__restrict__ raw,
     int *__restrict__ live) {
   const long long p = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -273,11 +275,12 @@ __global__ __launch_bounds__(256) void siterm_raw_counts_kernel(
   const int b = cnt_quantize(pr.len_a + pr.len_b, grid, B);
   if (b < 0) return;  // outside the grid: dropped (:240-247)
   const int8_t *sa = seqs + pr.seq_a, *sb = seqs + pr.seq_b;
-  for (int l = threadIdx.x & 63; l < n_sites; l += 64) {
-    const int x = sa[l], y = sb[l];
+  for (int k = threadIdx.x & 63; k < pr.n; k += 64) {
+    const int x = sa[k], y = sb[k];
     if (x < 0 || y < 0) continue;
-    atomicAdd(&raw[(((size_t)l * B + b) * S + x) * S + y], 1.0);
-    live[(size_t)l * B + b] = 1;
+    const size_t l = (size_t)pr.aux + k;
+    atomicAdd(&raw[((l * B + b) * S + x) * S + y], 1.0);
+    live[l * B + b] = 1;
   }
 }
 

@@ -274,6 +274,17 @@ int cb_siterm_assemble(int device, int S, int B, int n_sites, const double *grid
                        const double *site_rates, const double *prior, double lambda,
                        int include_reverse, int flags, double *counts, double *kernel_ms);
 /* kernel_ms (may be NULL): GPU time of the clear + count + mix kernels, inputs resident, by HIP events. */
+/* MANY families in one call (the reference runs SiteRM family by family over a process pool, utils.py:59-67):
+ * the site axis of site_rates and counts is the families' sites concatenated (n_sites[f] each), pairs are
+ * the families' transitions concatenated (n_pairs[f] each, byte offsets into the one seqs buffer; a pair of
+ * family f spans n_sites[f] codes).  Sites are independent: the result equals cb_siterm_assemble's family
+ * by family, one upload and one synchronisation for all of them, and the tensor feeds ONE cb_create /
+ * cb_train_siterm over all families' sites (a single family rarely fills 256 compute units). */
+int cb_siterm_assemble_batch(int device, int S, int B, int n_fam, const int *n_sites, const double *grid,
+                             const int8_t *seqs, int64_t seqs_bytes, const cb_count_pair *pairs,
+                             const int64_t *n_pairs, const double *site_rates, const double *prior,
+                             double lambda, int include_reverse, int flags, double *counts,
+                             double *kernel_ms);
 
 /* ---- FastCherries branch lengths / site rates of ONE family -----------------------
  * Replaces cherryml/phylogeny_estimation/FastCherries/branch_length_estimation.cpp

@@ -121,3 +121,49 @@ def test_per_site_dispatch_matches_reference(case):
              optimization_num_epochs=a["epochs"], transitions_strategy=a["strategy"],
              include_reverse_transitions=a["reverse"], use_vectorized_cherryml_implementation=True)
     assert rv["res"].shape == r["res"].shape
+
+
+def test_batch_of_families_equals_family_by_family():
+    """cb_siterm_assemble_batch + one bank over all families' sites: the count tensor is bit-identical to the
+    families' own tensors stacked, and every family's rate matrices equal the single-family estimator's
+    (sites are independent; the families here have different trees, site counts and gap patterns)."""
+    from cherryml_amd._siterm import estimate_site_specific_rate_matrices_given_tree_and_site_rates as est
+    from cherryml_amd._siterm import estimate_site_specific_rate_matrices_given_trees_and_site_rates as est_batch
+    from cherryml_amd._siterm._assembly import _assemble, _assemble_batch, _pairs_and_codes
+    z = load_golden("siterm_assembly.npz")
+    cases = [c for c in ASSEMBLY_CASES if str(z[c + "_strategy"]) == "cherry++"]
+    a0 = _inputs(z, cases[0])
+    same = [c for c in cases if [str(x) for x in z[c + "_alphabet"]] == a0["alphabet"]
+            and sorted(z[c + "_grid"].tolist()) == a0["grid"] and np.array_equal(z[c + "_Q0"], a0["Q0"])]
+    assert len(same) >= 2, same
+    fams = [_inputs(z, c) for c in same]
+    _run_batch_vs_single(z, same[0], fams)
+    # a 20-state family, the same family without its last three sites, and with its sites reversed
+    r = _inputs(z, "rand_cherry")
+    cut = dict(r, msa={k: v[:-3] for k, v in r["msa"].items()}, rates=r["rates"][:-3])
+    rev = dict(r, msa={k: v[::-1] for k, v in r["msa"].items()}, rates=r["rates"][::-1].copy())
+    _run_batch_vs_single(z, "rand_cherry", [r, cut, rev])
+
+
+def _run_batch_vs_single(z, case0, fams):
+    from cherryml_amd._siterm import estimate_site_specific_rate_matrices_given_tree_and_site_rates as est
+    from cherryml_amd._siterm import estimate_site_specific_rate_matrices_given_trees_and_site_rates as est_batch
+    from cherryml_amd._siterm._assembly import _assemble, _assemble_batch, _pairs_and_codes
+    a0 = fams[0]
+    same = [case0]
+    S = len(a0["alphabet"])
+    pc = [_pairs_and_codes(f["tree"], f["msa"], a0["alphabet"], "cherry++") for f in fams]
+    prior = z[same[0] + "_prior"]
+    stacked = np.concatenate([_assemble(p, c, a0["grid"], f["rates"], prior, a0["lam"], True, S, 0, False)
+                              for (p, c), f in zip(pc, fams)])
+    batch = _assemble_batch([p for p, _ in pc], [c for _, c in pc], a0["grid"], [f["rates"] for f in fams], prior,
+                            a0["lam"], True, S, 0, False)
+    assert np.array_equal(batch, stacked)
+    kw = dict(alphabet=a0["alphabet"], regularization_strength=a0["lam"], regularization_rate_matrix=a0["Q0"],
+              quantization_points=a0["grid"], optimization_num_epochs=a0["epochs"])
+    got = est_batch([f["tree"] for f in fams], [list(f["rates"]) for f in fams], [f["msa"] for f in fams], **kw)
+    for f, g in zip(fams, got):
+        one = est(tree=f["tree"], site_rates=list(f["rates"]), msa=f["msa"], **kw)
+        assert g["res"].shape == one["res"].shape
+        # (not bit for bit: how a site's buckets are split over workgroups depends on the number of sites in the bank)
+        assert max(relerr(g["res"][l], one["res"][l]) for l in range(len(one["res"]))) < 1e-8
