@@ -831,10 +831,12 @@ def run_likelihood(steps, warmup, world, rank, local_rank, fence, with_cpu):
                    "prune_ms_pairs": prune_pairs, "prune_ms_sites": float(np.mean(sms)),
                    "bank_ms": kernel_ms - prune_pairs - float(np.mean(sms)),
                    "host_ms_per_call_including_uploads": dt / steps * 1e3},
-        "roofline": {"bound": "mfma", "kernel": "tl_mfma_kernel (all heights of the tree)", "achieved": ach,
+        "roofline": {"bound": "mfma", "kernel": "tl_leaf_kernel + tl_mfma_kernel (all heights of the tree)", "achieved": ach,
                      "peak": F64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / F64_PEAK_TFLOPS, "traffic": None,
                      "flops_per_step": flops,
-                     "note": "2 S^2 flops per (node, pair); every P_v (1.28 MB) is read once per 16-pair block"},
+                     "note": "ALGORITHMIC 2 S^2 flops per (non-root node, pair) / time of all pruning launches of the pair "
+                             "model; the leaves (half of the nodes) are gathered from P_v's columns instead of multiplied "
+                             "(tl_leaf_kernel), internal nodes read P_v (1.28 MB) once per 32-pair block (tl_mfma_kernel)"},
     }
     if with_cpu:
         from oracle import likelihood_oracle as lo

@@ -81,21 +81,41 @@ int tl_prune(int S, int S1, const TlFamily &f, const double *dP, int cat_stride_
   a.code_b = reinterpret_cast<const signed char *>(dcb);
   a.pi_root = dproot; a.msg = dmsg; a.ll = dll;
   const int nt = (S + 15) / 16, Sp = nt * 16;
-  const size_t lds = ((size_t)(Sp + Sp / 4) * 16 + TL_NW * 16) * sizeof(double);
-  if (S > 64 && hipFuncSetAttribute(reinterpret_cast<const void *>(tl_mfma_kernel),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+  const int NB = f.n_units > 16 ? 2 : 1;   // unit blocks of 16 per workgroup
+  const size_t lds = ((size_t)(Sp * NB + Sp / 4 + NB) * 16 + (size_t)TL_NW * NB * 16) * sizeof(double);
+  const size_t lds_leaf = ((size_t)TL_LR * (S + 1) + TL_LR + (size_t)TL_LR * 2 * S1) * sizeof(double) + 2 * (size_t)f.n_units;
+  if (S > 64 && lds_leaf > 160 * 1024)
+    return fail(CB_EUNSUPPORTED, "cb_tree_likelihood: %d units per family at S > 64 (at most 50 000)", f.n_units);
+  const void *mfma_fn = NB == 2 ? reinterpret_cast<const void *>(tl_mfma_kernel<2>)
+                                : reinterpret_cast<const void *>(tl_mfma_kernel<1>);
+  if (S > 64 && (hipFuncSetAttribute(mfma_fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
+                 hipFuncSetAttribute(reinterpret_cast<const void *>(tl_leaf_kernel),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_leaf) != hipSuccess))
     return fail(CB_EHIP, "cb_tree_likelihood: cannot reserve %zu bytes of LDS", lds);
+  static const int rs_force = getenv("CB_TL_RS") ? atoi(getenv("CB_TL_RS")) : 0;
   for (int l = 0; l < f.n_levels; ++l) {
     const int nl = f.level_ptr[l + 1] - f.level_ptr[l];
-    a.n_blocks = S > 64 ? NU / 16 : (f.n_units + 64 / S - 1) / (64 / S);
-    const int per_launch = std::max(1, (1 << 30) / a.n_blocks);   // keep the 1-D grid below 2^30 workgroups
+    // height 0 = the leaves (never the root when the tree has an edge): gathered, not multiplied
+    const bool leaves = S > 64 && l == 0 && f.n_levels > 1;
+    a.n_blocks = leaves ? 1 : S > 64 ? (f.n_units + 16 * NB - 1) / (16 * NB) : (f.n_units + 64 / S - 1) / (64 / S);
+    a.RS = 1;
+    if (S > 64 && !leaves) {   // small levels: split the rows of a node over 2 or 4 workgroups (one per CU)
+      const long wgs = (long)nl * a.n_blocks;
+      a.RS = rs_force > 0 ? rs_force : wgs * 4 <= 256 ? 4 : wgs * 2 <= 256 ? 2 : 1;
+    }
+    const int per_node = a.n_blocks * a.RS;
+    const int per_launch = std::max(1, (1 << 30) / per_node);   // keep the 1-D grid below 2^30 workgroups
     for (int y0 = 0; y0 < nl; y0 += per_launch) {
       TlArgs b = a;
       b.level_nodes = dlev + f.level_ptr[l] + y0;
       b.n_level = std::min(per_launch, nl - y0);
-      const dim3 grid((unsigned)b.n_level * (unsigned)a.n_blocks);
-      if (S > 64)
-        hipLaunchKernelGGL(tl_mfma_kernel, grid, dim3(TL_NW * 64), lds, 0, b);
+      const dim3 grid((unsigned)b.n_level * (unsigned)per_node);
+      if (leaves)
+        hipLaunchKernelGGL(tl_leaf_kernel, grid, dim3(TL_LT), lds_leaf, 0, b);
+      else if (S > 64 && NB == 2)
+        hipLaunchKernelGGL(tl_mfma_kernel<2>, grid, dim3(TL_NW * 64), lds, 0, b);
+      else if (S > 64)
+        hipLaunchKernelGGL(tl_mfma_kernel<1>, grid, dim3(TL_NW * 64), lds, 0, b);
       else
         hipLaunchKernelGGL(tl_group_kernel, grid, dim3(64), 0, 0, b);
     }
@@ -140,7 +160,7 @@ extern "C" int cb_tree_likelihood_batch(int device, int S, int S1, const double 
     off_u[f + 1] = off_u[f] + n_units[f];
     off_c[f + 1] = off_c[f] + (size_t)n_nodes[f] * n_units[f];
     off_k[f + 1] = off_k[f] + n_cats[f];
-    const int NU = S > 64 ? (n_units[f] + 15) / 16 * 16 : n_units[f];
+    const int NU = S > 64 ? (n_units[f] + 31) / 32 * 32 : n_units[f];   // (tl_mfma_kernel: 16 or 32 unit columns per workgroup)
     max_nodes = std::max(max_nodes, n_nodes[f]);
     max_msg = std::max(max_msg, (size_t)n_nodes[f] * S * NU);
     max_bank = std::max(max_bank, (size_t)n_cats[f] * n_nodes[f]);
@@ -222,7 +242,7 @@ extern "C" int cb_tree_likelihood_batch(int device, int S, int S1, const double 
       (void)hipEventRecord(em, 0);
       evm.push_back(em);
     }
-    const int NU = S > 64 ? (F.n_units + 15) / 16 * 16 : F.n_units;
+    const int NU = S > 64 ? (F.n_units + 31) / 32 * 32 : F.n_units;
     rc = tl_prune(S, S1, F, dP, F.n_nodes, dproot, duc + off_u[f], dca + off_c[f], dcb ? dcb + off_c[f] : nullptr,
                   dlev + off_n[f], dcp + off_n[f] + f, dci + off_n[f], dmsg, dll + off_u[f], NU);
     if (kernel_ms && rc == CB_OK) {   // pruning time of this family: bank marker -> now (needs a marker pair per family)
