@@ -227,23 +227,30 @@ static int large_eigh(cb_bank *h, bool warm) {
       if (rowsum <= 2e-3) {
         hipLaunchKernelGGL(lgx_combine, dim3(nel), dim3(256), 0, h->stream, LD, Xu, P2, P3, P4, R);
       } else {
+        // scale until the 8th-order polynomial is exact to rounding (|Y| <= 0.075: |Y|^9 / 9! < 1e-15).  A masked
+        // sweep (far pairs only, the state still far from converged) does not need THAT rotation to 1e-16 -- any
+        // orthogonal matrix close to it serves -- so it stops at |Y| <= masked_lim (0.5: error 5e-9) and lets the
+        // Newton-Schulz step restore orthogonality (error^2): two or three squarings fewer per such sweep.
+        static const double masked_lim = getenv("CB_POLY_LIM_MASKED") ? atof(getenv("CB_POLY_LIM_MASKED")) : 0.5;
+        const double poly_lim = masked ? masked_lim : 0.075;
         int sq = 0;
         double sc = 1.0;
-        while (rowsum * sc > 0.075) {
+        while (rowsum * sc > poly_lim) {
           sc *= 0.5;
           ++sq;
         }
+        const bool need_ns = sq > ns_from || (masked && masked_lim > 0.076);
         hipLaunchKernelGGL(lgx_poly8, dim3(nel), dim3(256), 0, h->stream, LD, sc, Xu, P2, P3, P4, lo, hiT);
         const double sc2 = sc * sc;
         // (every product also writes its transpose: the next step needs R^T as the k-major operand)
-        launch_sg(h, K4Args{h->S, LD, hiT, P4, R, nullptr, lo, nullptr, sq > 0 ? Rt : nullptr}, 2, sc2 * sc2, 1.0);  // R = lo + hi Y^4
+        launch_sg(h, K4Args{h->S, LD, hiT, P4, R, nullptr, lo, nullptr, (sq > 0 || need_ns) ? Rt : nullptr}, 2, sc2 * sc2, 1.0);  // R = lo + hi Y^4
         double *cur = R, *nxt = R2, *curT = Rt, *nxtT = Rt2;
         for (int q = 0; q < sq; ++q) {                                        // R <- R R
           launch_sg(h, K4Args{h->S, LD, curT, cur, nxt, nullptr, nullptr, nullptr, nxtT}, 0);
           std::swap(cur, nxt);
           std::swap(curT, nxtT);
         }
-        if (sq > ns_from) {                                                   // R <- R (3 I - R^T R) / 2
+        if (need_ns) {                                                        // R <- R (3 I - R^T R) / 2
           double *N = lo;                                                     // free by now
           launch_sg(h, K4Args{h->S, LD, cur, cur, N, nullptr, nullptr, nullptr}, 0);
           launch_sg(h, K4Args{h->S, LD, curT, N, nxt, nullptr, cur, nullptr}, 2, -0.5, 1.5);
