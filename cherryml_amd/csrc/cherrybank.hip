@@ -665,8 +665,12 @@ static int launch_small_nw(cb_bank *h, const SmallArgs &a) {
   else if (S <= 8) LAUNCH(1, 2);
   else if (S <= 16) LAUNCH(1, 4);
   else if (S <= 20) LAUNCH(2, 5);
-  else if (S <= 24) LAUNCH(2, 6);
-  else LAUNCH(2, 8);
+  else if constexpr (NW == 4) {   // more than 20 states: the four-wave form only (see the kernels' launch bounds)
+    if (S <= 24) LAUNCH(2, 6);
+    else LAUNCH(2, 8);
+  } else {
+    return fail(CB_EINVAL, "internal: %d states dispatched to the eight-wave small kernels", S);
+  }
 #undef LAUNCH
   HIP_TRY(hipGetLastError());
   return CB_OK;
@@ -674,8 +678,9 @@ static int launch_small_nw(cb_bank *h, const SmallArgs &a) {
 
 template <int MODE>
 static int launch_small(cb_bank *h, const SmallArgs &a) {
-  // few sites: more waves per site; many sites: 4 waves (2 workgroups per CU)
-  if (h->L < 512) return launch_small_nw<MODE, 8>(h, a);
+  // few sites: more waves per site; many sites: 4 waves (2 workgroups per CU); more than 20 states: 4 waves always
+  // (one per SIMD with the whole register file, small_bank_kernel's launch bounds)
+  if (h->L < 512 && h->S <= 20) return launch_small_nw<MODE, 8>(h, a);
   return launch_small_nw<MODE, 4>(h, a);
 }
 
@@ -1151,8 +1156,12 @@ static int launch_train_nw(cb_bank *h, const TrainArgs &a) {
   else if (S <= 8) LAUNCH(1, 2);
   else if (S <= 16) LAUNCH(1, 4);
   else if (S <= 20) LAUNCH(2, 5);
-  else if (S <= 24) LAUNCH(2, 6);
-  else LAUNCH(2, 8);
+  else if constexpr (NW == 4) {   // more than 20 states: the four-wave form only (see the kernels' launch bounds)
+    if (S <= 24) LAUNCH(2, 6);
+    else LAUNCH(2, 8);
+  } else {
+    return fail(CB_EINVAL, "internal: %d states dispatched to the eight-wave small kernels", S);
+  }
 #undef LAUNCH
   HIP_TRY(hipGetLastError());
   return CB_OK;
@@ -1447,7 +1456,7 @@ static int run_fused_training(cb_bank *h, int kind, double *pi_param, double *up
         (void)hipMemset(stamps, 0, 16 * sizeof(unsigned long long));
         (void)hipMemcpyToSymbol(HIP_SYMBOL(g_small_stamps), &stamps, sizeof stamps);
       }
-      rc = (L < 512) ? launch_train_nw<8>(h, a) : launch_train_nw<4>(h, a);
+      rc = (L < 512 && S <= 20) ? launch_train_nw<8>(h, a) : launch_train_nw<4>(h, a);
       if (stamps) {
         unsigned long long st[16];
         (void)hipStreamSynchronize(h->stream);

@@ -612,8 +612,10 @@ __device__ __forceinline__ void small_site_eval(double *lds, int S, int B,
   SM_STAMP(5);
 }
 
+// (21 .. 32 states: the tile sets of the two larger forms need more than 256 registers; their dispatch takes the
+// four-wave workgroup -- one wave per SIMD, all 512 registers -- instead of spilling)
 template <int NT, int KS, int NW, int MODE>
-__global__ __launch_bounds__(NW * 64, CB_SMALL_MIN_WGS) void small_bank_kernel(SmallArgs a) {
+__global__ __launch_bounds__(NW * 64, (KS >= 6 && NW == 4) ? 1 : CB_SMALL_MIN_WGS) void small_bank_kernel(SmallArgs a) {
   extern __shared__ double lds[];
   using LD = SmallLds<NW>;
   double *sA = lds + LD::A, *sG = lds + LD::G, *sV = lds + LD::V, *sLam = lds + LD::LAM,

@@ -204,7 +204,7 @@ __device__ __attribute__((noinline)) void small_site_eval_call(double *lds, int 
 }
 
 template <int NT, int KS, int NW>
-__global__ __launch_bounds__(NW * 64, CB_SMALL_MIN_WGS) void small_train_kernel(TrainArgs a) {
+__global__ __launch_bounds__(NW * 64, (KS >= 6 && NW == 4) ? 1 : CB_SMALL_MIN_WGS) void small_train_kernel(TrainArgs a) {
   extern __shared__ double lds[];
   using LD = SmallLds<NW>;
   double *sA = lds + LD::A, *sG = lds + LD::G, *sD = lds + LD::D;

@@ -33,7 +33,7 @@ out = {"bytes_per_launch": {}, "detail": {}, "calibration": {},
 NAMES = ["k1_pt_loss_gt", "k2_t_eq_g_u", "k3_w_phi", "lgj_round", "lg_transpose_pad", "small_train_kernel", "small_bank_kernel",
          "lg_prepare", "lg_bank", "lg_finish", "count_transitions_lds_kernel", "count_reduce_slabs", "k3_reduce", "sp_prepare",
          "sp_bank", "sp_finish", "sg_gemm", "lgx_build", "ble_branch_lengths_kernel", "ble_site_rates_kernel",
-         "siterm_raw_counts_kernel", "siterm_mix_kernel", "tl_mfma_kernel", "tl_group_kernel", "lg_cast_f32"]
+         "siterm_raw_counts_kernel", "siterm_mix_kernel", "tl_mfma_kernel", "tl_leaf_kernel", "tl_group_kernel", "lg_cast_f32"]
 WORKLOADS = ["coevo400", "coevo400_mixed", "coevo400_f32", "coevo400_demo", "lg20", "siterm", "counting", "ble", "assembly", "likelihood"]
 
 
