@@ -237,20 +237,20 @@ extern "C" int cb_tree_likelihood_batch(int device, int S, int S1, const double 
       cb_destroy(h);
     }
     if (rc != CB_OK) break;
-    hipEvent_t em = nullptr;
-    if (kernel_ms && hipEventCreate(&em) == hipSuccess) {
-      (void)hipEventRecord(em, 0);
-      evm.push_back(em);
-    }
+    // pruning time of this family: a marker pair around its launches (both or neither)
+    hipEvent_t em = nullptr, ep = nullptr;
+    const bool timed = kernel_ms && hipEventCreate(&em) == hipSuccess && hipEventCreate(&ep) == hipSuccess;
+    if (timed) (void)hipEventRecord(em, 0);
     const int NU = S > 64 ? (F.n_units + 31) / 32 * 32 : F.n_units;
     rc = tl_prune(S, S1, F, dP, F.n_nodes, dproot, duc + off_u[f], dca + off_c[f], dcb ? dcb + off_c[f] : nullptr,
                   dlev + off_n[f], dcp + off_n[f] + f, dci + off_n[f], dmsg, dll + off_u[f], NU);
-    if (kernel_ms && rc == CB_OK) {   // pruning time of this family: bank marker -> now (needs a marker pair per family)
-      hipEvent_t ep = nullptr;
-      if (hipEventCreate(&ep) == hipSuccess) {
-        (void)hipEventRecord(ep, 0);
-        evm.push_back(ep);
-      }
+    if (timed) {
+      (void)hipEventRecord(ep, 0);
+      evm.push_back(em);
+      evm.push_back(ep);
+    } else {
+      if (em) (void)hipEventDestroy(em);
+      if (ep) (void)hipEventDestroy(ep);
     }
   }
   if (kernel_ms) {

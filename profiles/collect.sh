@@ -13,8 +13,11 @@ python3 $R/bench.py --steps 20 --warmup 5 > $R/gpurun_out/${TAG}_bench_driver.lo
 python3 $R/bench.py > $R/gpurun_out/${TAG}_bench_default.log 2>&1
 for v in "coevo400 f64" "coevo400 mixed" "coevo400 f32" "coevo400_demo f64" "lg20 f64" "siterm f64" "counting f64" "ble f64" "assembly f64" "likelihood f64"; do
   set -- $v; w=$1; dt=$2; name=$w; [ "$dt" != "f64" ] && name=${w}_$dt
+  # the bench line of this workload UNPROFILED (kernel tracing adds a few percent to launch-bound epochs) ...
+  python3 $R/bench.py --workload $w --dtype $dt --no-cpu-baseline --no-secondary > $R/gpurun_out/${TAG}_bench_$name.log 2>&1
+  # ... and the same command under the kernel trace for the per-kernel statistics
   rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${TAG}_trace_$name -- \
-    python3 $R/bench.py --workload $w --dtype $dt --no-cpu-baseline --no-secondary > $R/gpurun_out/${TAG}_bench_$name.log 2>&1
+    python3 $R/bench.py --workload $w --dtype $dt --no-cpu-baseline --no-secondary > $R/gpurun_out/${TAG}_benchprof_$name.log 2>&1
   for c in FETCH_SIZE WRITE_SIZE; do
     rocprofv3 --pmc $c --output-format csv -d $R/gpurun_out/${TAG}_pmc_${name}_$c -- \
       python3 $R/bench.py --workload $w --dtype $dt --steps 3 --warmup 1 --no-cpu-baseline --no-secondary > /dev/null 2>&1
