@@ -261,6 +261,7 @@ def main():
         wl = make_workload(workload, args.sites, rng)
         S = wl["S"]
         bank_dtype = args.dtype if S > 32 else "f64"   # the small-state kernels are float64
+        resumed = False   # the timed epochs continue the warm-up's optimisation (C-driven 400-state loop)
         if wl["kind"] == "single" and S > 32 and (world > 1 or args.force_sharded):
             # ---- co-evolution on N > 1 GPUs: torch keeps theta -> Q and Adam (the collective is
             #      torch.distributed's), HIP does loss + dL/dQ; buckets sharded over the ranks,
@@ -296,13 +297,16 @@ def main():
                         "in-library ncclAllReduce, Adam in HIP)")
                 u0 = module.upper_diag.detach().cpu().numpy().copy()
                 p0 = module._pi.detach().cpu().numpy().copy()
-                call = lambda E: sharded.train_pande_reversible(u0, p0, mask=wl["mask"], num_epochs=E, lr=0.1)  # noqa: E731
+                # the K timed epochs CONTINUE the optimisation of the W warm-up epochs (CB_TRAIN_RESUME): epochs W .. W+K-1
+                call = lambda E, resume=False: sharded.train_pande_reversible(  # noqa: E731
+                    u0, p0, mask=wl["mask"], num_epochs=E, lr=0.1, resume=resume)
                 if warmup > 0:
                     call(warmup)
                 bank.profile(True)
                 fence()
                 t0 = time.perf_counter()
-                r = call(steps)
+                r = call(steps, warmup > 0)
+                resumed = warmup > 0
                 fence()
                 dt = time.perf_counter() - t0
                 tm = bank.timing_means()
@@ -353,18 +357,23 @@ def main():
                 u0 = mod.upper_diag.detach().numpy().copy()
                 p0 = mod._pi.detach().numpy().copy()
                 sharding = f"replicas only x{world}"
-                call = lambda E: bank.train_pande_reversible(u0, p0, mask=wl["mask"], num_epochs=E, lr=0.1)  # noqa: E731
+                # S > 32: the K timed epochs CONTINUE the optimisation of the W warm-up epochs (CB_TRAIN_RESUME), i.e. they
+                # are epochs W .. W+K-1 of one training; the small-state trainers restart (their epoch cost does not
+                # depend on the iterate)
+                call = lambda E, resume=False: bank.train_pande_reversible(  # noqa: E731
+                    u0, p0, mask=wl["mask"], num_epochs=E, lr=0.1, resume=resume and S > 32)
             else:
                 from cherryml_amd._siterm._vectorized import _invert
                 th0, Th0 = _invert(wl["init"])
                 sharding = f"sites x{world} (no collective)"
-                call = lambda E: bank.train_siterm(th0, Th0, E, lr=0.1)  # noqa: E731
+                call = lambda E, resume=False: bank.train_siterm(th0, Th0, E, lr=0.1)  # noqa: E731
             if warmup > 0:
                 call(warmup)
             bank.profile(True)
             fence()
             t0 = time.perf_counter()
-            r = call(steps)
+            r = call(steps, warmup > 0)
+            resumed = warmup > 0 and S > 32 and wl["kind"] == "single"
             fence()
             dt = time.perf_counter() - t0
             if S > 32:
@@ -430,6 +439,8 @@ def main():
             "config": {"workload": wl["desc"], "states": S, "buckets": 129,
                        **({"non_empty_buckets": wl["live"]} if "live" in wl else {}), "sharding": sharding,
                        "epoch": glue,
+                       **({"timed_epochs": f"{warmup} .. {warmup + steps - 1} of one optimisation from the JTT-IPW start "
+                                           "(the warm-up epochs are its first ones; CB_TRAIN_RESUME)"} if resumed else {}),
                        **({"arithmetic": "float32 operands + float32 MFMA accumulation in P_b, G_b U, (T_b^T U) o Phi_b; "
                                          "eigensolver, loss sums, divided differences, bucket sum, Adam in float64"}
                           if bank_dtype == "f32" else {})},

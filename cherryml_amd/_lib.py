@@ -7,6 +7,7 @@ from ._build import LIB
 
 CB_PTR_DEVICE = 1
 CB_NORMALIZE = 2
+CB_TRAIN_RESUME = 16
 CB_NO_SYNC = 4
 CB_F64, CB_F32, CB_MIXED = 0, 1, 2
 

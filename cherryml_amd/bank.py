@@ -5,7 +5,7 @@ from typing import Optional, Tuple
 import numpy as np
 
 from . import _lib
-from ._lib import CB_NO_SYNC, CB_NORMALIZE, CB_PTR_DEVICE
+from ._lib import CB_NO_SYNC, CB_NORMALIZE, CB_PTR_DEVICE, CB_TRAIN_RESUME
 
 
 def _as_f64(a, shape=None) -> np.ndarray:
@@ -197,24 +197,27 @@ class CherryBank:
 
     # -- fused device-side optimisers (pande_reversible: any S; SiteRM: S <= 32) -----
     def train_pande_reversible(self, upper_diag, log_pi, mask=None, num_epochs=2000, lr=0.1,
-                               do_adam=True, normalize=True):
+                               do_adam=True, normalize=True, resume=False):
         """All epochs of the reference loop (trainer.py:156-218) on the device.
         L == 1: returns dict(loss[E], Q_best, Q_last, Q_pow2 {epoch: Q}, upper_diag, log_pi).
         L > 1 (S <= 32): L independent problems in one batched launch sequence -- upper_diag [L, S(S-1)/2],
-        log_pi [L, S] -> loss [E, L], Q_best / Q_last [L, S, S] (no power-of-two snapshots)."""
+        log_pi [L, S] -> loss [E, L], Q_best / Q_last [L, S, S] (no power-of-two snapshots).
+        resume=True (S > 32): continue the optimisation the previous call on this bank ended (CB_TRAIN_RESUME:
+        parameters, Adam state and best iterate stay on the device; `upper_diag` / `log_pi` are ignored on the way
+        in; E epochs + E' resumed epochs = E + E' epochs of one call, bit for bit; no power-of-two snapshots)."""
         S, E, L = self.S, int(num_epochs), self.L
         nup = S * (S - 1) // 2
         up = _as_f64(upper_diag, (nup,) if L == 1 else (L, nup)).copy()
         lp = _as_f64(log_pi, (S,) if L == 1 else (L, S)).copy()
         mk = None if mask is None else _as_f64(mask, (S, S))
-        n_pow2 = (max(E, 1).bit_length() if E > 0 else 0) if L == 1 else 0
+        n_pow2 = (max(E, 1).bit_length() if E > 0 else 0) if (L == 1 and not resume) else 0
         loss = np.zeros(E) if L == 1 else np.zeros((E, L))
         Qb, Ql = (np.zeros((S, S)), np.zeros((S, S))) if L == 1 else (np.zeros((L, S, S)), np.zeros((L, S, S)))
         Qp = np.zeros((max(n_pow2, 1), S, S))
         rc = _lib.load().cb_train_pande_reversible(
             self._h, up.ctypes.data, lp.ctypes.data, None if mk is None else mk.ctypes.data, E,
-            float(lr), int(bool(do_adam)), CB_NORMALIZE if normalize else 0, loss.ctypes.data,
-            Qb.ctypes.data, Ql.ctypes.data, Qp.ctypes.data if n_pow2 else None, n_pow2)
+            float(lr), int(bool(do_adam)), (CB_NORMALIZE if normalize else 0) | (CB_TRAIN_RESUME if resume else 0),
+            loss.ctypes.data, Qb.ctypes.data, Ql.ctypes.data, Qp.ctypes.data if n_pow2 else None, n_pow2)
         _lib.check(rc, "cb_train_pande_reversible")
         snaps = {1 << i: Qp[i] for i in range(n_pow2) if (1 << i) <= E}
         return dict(loss=loss, Q_best=Qb, Q_last=Ql, Q_pow2=snaps, upper_diag=up, log_pi=lp)

@@ -30,6 +30,10 @@ int cb_fail(int code, const char *fmt, ...) {
 struct cb_bank {
   int dev = 0, S = 0, L = 0, B = 0;
   int B_cap = 0;        // B at creation (cb_internal_set_times may lower B)
+  // the optimisation a later CB_TRAIN_RESUME call continues (large fused trainer): epochs done, Adam's beta powers,
+  // and what the call looked like (mask, moments) -- a resumed call must look the same
+  int tr_epochs = 0, tr_sig = 0;
+  double tr_pow_b1 = 1.0, tr_pow_b2 = 1.0;
   int dtype = CB_F64;   // element type of the bank products (large path): CB_F64 or CB_F32
   int LD = 0;           // large path: padded leading dimension
   bool large = false;
@@ -1177,15 +1181,26 @@ static int run_fused_training_large(cb_bank *h, double *pi_param, double *up_par
   const double t_enter = now();
   const int S = h->S, LD = h->LD;
   const size_t SS = (size_t)S * S, nup = (size_t)S * (S - 1) / 2;
+  // CB_TRAIN_RESUME: parameters, moments, best iterate and the bookkeeping words stay where the previous call left
+  // them (workspace slots of unchanged size are never moved; the loss-curve slot may be, it carries no state)
+  const bool resume = (flags & CB_TRAIN_RESUME) != 0;
+  const int sig = 1 + (mask ? 2 : 0) + (do_adam ? 4 : 0);
+  if (resume && (h->tr_epochs <= 0 || h->tr_sig != sig))
+    return fail(CB_EINVAL, "CB_TRAIN_RESUME: no finished training call with the same mask / optimiser on this handle");
+  if (resume && Q_pow2) return fail(CB_EINVAL, "CB_TRAIN_RESUME: Q_pow2 must be NULL");
+  const int e0 = resume ? h->tr_epochs : 0;
   int slot = 0;
   auto alloc = [&](double **p, size_t n) -> bool { return ws_get(h, slot++, n, p); };
   auto release = [&]() { (void)hipStreamSynchronize(h->stream); };
   double *d_pi = nullptr, *d_up = nullptr, *d_mom = nullptr, *d_mask = nullptr, *d_loss = nullptr, *d_Qb = nullptr,
          *d_Ql = nullptr, *d_Qp = nullptr, *d_vec = nullptr;
   const size_t nmom = 2 * (S + nup);
-  bool ok = alloc(&d_pi, S) && alloc(&d_up, nup) && alloc(&d_mom, nmom) && alloc(&d_loss, E) && alloc(&d_Qb, SS) &&
-            alloc(&d_Ql, SS) && (!mask || alloc(&d_mask, SS)) && (!(Q_pow2 && n_pow2 > 0) || alloc(&d_Qp, std::max<size_t>(n_pow2, 16) * SS)) &&
-            alloc(&d_vec, (size_t)LD + S + 8);
+  // fixed slots (an optional buffer keeps its number): a resumed call finds the state where the first call put it
+  auto at = [&](int s, double **p, size_t n) -> bool { return ws_get(h, s, n, p); };
+  bool ok = at(0, &d_pi, S) && at(1, &d_up, nup) && at(2, &d_mom, nmom) && at(3, &d_loss, E) && at(4, &d_Qb, SS) &&
+            at(5, &d_Ql, SS) && (!mask || at(6, &d_mask, SS)) &&
+            (!(Q_pow2 && n_pow2 > 0) || at(7, &d_Qp, std::max<size_t>(n_pow2, 16) * SS)) && at(8, &d_vec, (size_t)LD + S + 8);
+  (void)alloc;
   if (!ok) {
     release();
     return fail(CB_ENOMEM, "fused training: device allocation failed");
@@ -1202,15 +1217,18 @@ static int run_fused_training_large(cb_bank *h, double *pi_param, double *up_par
       return fail(CB_ENOMEM, "fused training: pinned staging allocation failed");
     }
   }
-  TRYH(h2d_staged(h, d_pi, pi_param, S * sizeof(double)));
-  TRYH(h2d_staged(h, d_up, up_param, nup * sizeof(double)));
-  TRYH(hipMemsetAsync(d_mom, 0, nmom * sizeof(double), h->stream));
-  TRYH(hipMemsetAsync(d_Qb, 0, SS * sizeof(double), h->stream));
-  TRYH(hipMemsetAsync(d_Ql, 0, SS * sizeof(double), h->stream));
+  if (!resume) {
+    TRYH(h2d_staged(h, d_pi, pi_param, S * sizeof(double)));
+    TRYH(h2d_staged(h, d_up, up_param, nup * sizeof(double)));
+    TRYH(hipMemsetAsync(d_mom, 0, nmom * sizeof(double), h->stream));
+    TRYH(hipMemsetAsync(d_Qb, 0, SS * sizeof(double), h->stream));
+    TRYH(hipMemsetAsync(d_Ql, 0, SS * sizeof(double), h->stream));
+  }
   if (mask) TRYH(h2d_staged(h, d_mask, mask, SS * sizeof(double)));
   const double init_state[2] = {INFINITY, 0.0};
   LargeTrain a{};
   a.S = S; a.LD = LD; a.do_adam = do_adam; a.n_pow2 = d_Qp ? n_pow2 : 0;
+  a.epoch0 = e0;
   a.p_pi = d_pi; a.p_up = d_up;
   a.m_pi = d_mom; a.v_pi = d_mom + S; a.m_up = d_mom + 2 * (size_t)S; a.v_up = a.m_up + nup;
   a.mask = d_mask; a.lr = lr; a.beta1 = 0.9; a.beta2 = 0.999; a.eps = 1e-8;
@@ -1222,12 +1240,13 @@ static int run_fused_training_large(cb_bank *h, double *pi_param, double *up_par
   a.inv_n = (flags & CB_NORMALIZE) ? 1.0 / (h->comm ? h->n_global[0] : h->n_host[0]) : 1.0;
   a.loss_curve = d_loss; a.Q_last = d_Ql; a.Q_best = d_Qb; a.Q_pow2 = d_Qp;
   if (dbg) fprintf(stderr, "[cherrybank] large trainer: copies enqueued after %.2f ms\n", now() - t_enter);
-  TRYH(h2d_staged(h, a.state, init_state, sizeof init_state));
+  if (!resume) TRYH(h2d_staged(h, a.state, init_state, sizeof init_state));
   TRYH(hipStreamSynchronize(h->stream));  // init_state is on this stack frame
   if (dbg) fprintf(stderr, "[cherrybank] large trainer: synced after %.2f ms\n", now() - t_enter);
   if (h->profile) fold_pending(h);
   if (dbg) fprintf(stderr, "[cherrybank] large trainer: parameters uploaded after %.2f ms\n", now() - t_enter);
-  double pow_b1 = 1.0, pow_b2 = 1.0;
+  double pow_b1 = resume ? h->tr_pow_b1 : 1.0, pow_b2 = resume ? h->tr_pow_b2 : 1.0;
+  h->tr_epochs = 0;   // (set again when this call succeeds)
   // fault injection for the tests of the collective failure protocol: this rank's evaluation "fails" at that epoch
   const int fault_epoch = getenv("CB_FAULT_INJECT") ? atoi(getenv("CB_FAULT_INJECT")) : -1000;
   for (int e = 0; e < E && rc == CB_OK; ++e) {
@@ -1237,7 +1256,7 @@ static int run_fused_training_large(cb_bank *h, double *pi_param, double *up_par
     }
     for (bool &b : h->ev_rec) b = false;
     hipLaunchKernelGGL(lt_pi, dim3(1), dim3(256), 0, h->stream, a);
-    hipLaunchKernelGGL(lt_build, dim3(LD), dim3(256), 0, h->stream, a, e);
+    hipLaunchKernelGGL(lt_build, dim3(LD), dim3(256), 0, h->stream, a, e0 + e);
     mark(h, EV_START);
     rc = large_eval(h, flags & CB_NORMALIZE, h->loss, h->Mt, true, nullptr);
     if (rc == CB_OK && fault_epoch == e) rc = fail(CB_ENUMERIC, "injected fault at epoch %d (CB_FAULT_INJECT)", e);
@@ -1271,7 +1290,7 @@ static int run_fused_training_large(cb_bank *h, double *pi_param, double *up_par
     pow_b1 *= a.beta1;
     pow_b2 *= a.beta2;
     hipLaunchKernelGGL(lt_gd, dim3((S + 3) / 4), dim3(256), 0, h->stream, a);
-    hipLaunchKernelGGL(lt_step_pi, dim3(1), dim3(256), 0, h->stream, a, e, 1.0 - pow_b1, std::sqrt(1.0 - pow_b2));
+    hipLaunchKernelGGL(lt_step_pi, dim3(1), dim3(256), 0, h->stream, a, e0 + e, 1.0 - pow_b1, std::sqrt(1.0 - pow_b2));
     hipLaunchKernelGGL(lt_step_up, dim3(S), dim3(256), 0, h->stream, a, 1.0 - pow_b1, std::sqrt(1.0 - pow_b2));
     if (hipGetLastError() != hipSuccess) rc = fail(CB_EHIP, "fused training launch failed");
   }
@@ -1300,6 +1319,12 @@ static int run_fused_training_large(cb_bank *h, double *pi_param, double *up_par
   }
 #undef TRYH
   release();
+  if (rc == CB_OK) {   // what a CB_TRAIN_RESUME call continues
+    h->tr_epochs = e0 + E;
+    h->tr_sig = sig;
+    h->tr_pow_b1 = pow_b1;
+    h->tr_pow_b2 = pow_b2;
+  }
   if (dbg) fprintf(stderr, "[cherrybank] large trainer: %d epochs done after %.2f ms\n", E, now() - t_enter);
   return rc;
 }
@@ -1316,6 +1341,8 @@ static int run_fused_training(cb_bank *h, int kind, double *pi_param, double *up
     return run_fused_training_large(h, pi_param, up_param, mask, E, lr, do_adam, flags, loss_curve, Q_best, Q_last,
                                     Q_pow2, n_pow2);
   }
+  if (flags & CB_TRAIN_RESUME)
+    return fail(CB_EUNSUPPORTED, "CB_TRAIN_RESUME: S > 32 only (the small-state trainers run their epochs inside one launch)");
   if (h->comm)
     return fail(CB_EUNSUPPORTED, "fused training with cb_allreduce_setup: S > 32 only (a small bank does not shard; "
                                  "sites are independent)");

@@ -20,6 +20,7 @@
 
 struct LargeTrain {
   int S, LD, do_adam, n_pow2;
+  int epoch0;                           // epochs done by earlier calls of this optimisation (CB_TRAIN_RESUME)
   double *p_pi, *p_up;                  // [S], [S(S-1)/2]
   double *m_pi, *v_pi, *m_up, *v_up;    // Adam moments
   const double *mask;                   // [S][S] or null
@@ -127,7 +128,7 @@ __global__ __launch_bounds__(256) void lt_step_pi(LargeTrain a, int epoch, doubl
   const int S = a.S;
   if (threadIdx.x == 0) {
     const double loss = *a.loss;
-    a.loss_curve[epoch] = loss;
+    a.loss_curve[epoch - a.epoch0] = loss;   // (the curve of THIS call)
     const bool better = epoch == 0 || loss < a.state[0];  // strict <, first iterate always taken (trainer.py:179)
     a.state[1] = better ? 1.0 : 0.0;
     if (better) a.state[0] = loss;

@@ -238,13 +238,13 @@ class ShardedBank:
         return self
 
     def train_pande_reversible(self, upper_diag, log_pi, mask=None, num_epochs=2000, lr=0.1, do_adam=True,
-                               normalize=True):
+                               normalize=True, resume=False):
         """The reference loop (trainer.py:156-218) over the sharded bank, driven from C on every rank
         (needs `enable_in_library_allreduce()`); every rank returns the same result."""
         if getattr(self, "rccl", None) is None:
             raise RuntimeError("ShardedBank.train_pande_reversible: call enable_in_library_allreduce() first")
         return self.bank.train_pande_reversible(upper_diag, log_pi, mask=mask, num_epochs=num_epochs, lr=lr,
-                                                do_adam=do_adam, normalize=normalize)
+                                                do_adam=do_adam, normalize=normalize, resume=resume)
 
     def close(self):
         if hasattr(self.bank, "close"):

@@ -49,7 +49,9 @@ enum {
   CB_NORMALIZE = 2,  /* divide each site's loss (and gradient) by its total count
                         (trainer.py:176-177 `loss_normalization`)     */
   CB_NO_SYNC = 4,    /* with CB_PTR_DEVICE: enqueue only, do not wait  */
-  CB_EXPM_ONLY = 8   /* cb_create: no counts (C may be NULL); the handle serves cb_expm_bank / cb_eigh only */
+  CB_EXPM_ONLY = 8,  /* cb_create: no counts (C may be NULL); the handle serves cb_expm_bank / cb_eigh only */
+  CB_TRAIN_RESUME = 16 /* cb_train_pande_reversible, S > 32: continue the optimisation the previous call on this
+                        * handle ended (see there) */
 };
 
 /* ABI version of the loaded library (bumped on incompatible change). */
@@ -175,6 +177,12 @@ int cb_last_sweeps(cb_handle h);
  *   Q_best[L*S*S], Q_last[L*S*S]     as trainer.py:179-181,237-242
  *   Q_pow2[n_pow2*S*S]               Q at epochs 1,2,4,... (trainer.py:183-184); may be NULL; L == 1 only
  * All pointers are host pointers.
+ * flags & CB_TRAIN_RESUME (S > 32): the call CONTINUES the optimisation the previous successful call on this
+ * handle ended -- parameters, Adam moments and step count, best loss and Q_best are the handle's (the
+ * upper_diag / log_pi inputs are ignored, mask / do_adam / lr must be the same), the eigensolver stays warm;
+ * loss_curve holds this call's num_epochs losses, Q_pow2 must be NULL.  E epochs then E' resumed epochs equal
+ * E + E' epochs of one call bit for bit.  (The reference has no such entry: its loop runs to the end in one
+ * call; this is what lets a caller put a barrier or a checkpoint between epochs of the device-driven loop.)
  */
 int cb_train_pande_reversible(cb_handle h, double *upper_diag, double *log_pi,
                               const double *mask, int num_epochs, double lr,

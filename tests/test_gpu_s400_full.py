@@ -189,3 +189,34 @@ def test_f32_dtype_is_refused_for_small_state_spaces():
         CherryBank(g["t"], g["C"], dtype="f32")
     with pytest.raises(ValueError):
         CherryBank(g["t"], g["C"], dtype="bf16")
+
+
+def test_resumed_training_equals_one_call(dense):
+    """CB_TRAIN_RESUME: 6 epochs, then 9 resumed epochs (twice: 5 + 4) = 15 epochs of one call, bit for bit -- loss
+    curve, parameters, Q_last, Q_best; a resume without a finished call, with another mask, or on a small bank is
+    refused.  (bench.py times its K epochs as the continuation of its W warm-up epochs through this.)"""
+    from cherryml_amd import CherryBank
+    z = load_golden("coevo_dense_traj.npz")
+    sel, mask = z["sel"], dense["mask"]
+    t, C = dense["t"][sel], dense["C"][sel]
+    u0, p0 = z["upper_diag0"], z["log_pi0"]
+    with CherryBank(t, C) as bank:
+        whole = bank.train_pande_reversible(u0, p0, mask=mask, num_epochs=15, lr=0.1)
+    with CherryBank(t, C) as bank:   # (a fresh handle: the same cold first eigensolve as `whole`)
+        with pytest.raises(ValueError):
+            bank.train_pande_reversible(u0, p0, mask=mask, num_epochs=3, lr=0.1, resume=True)
+        a = bank.train_pande_reversible(u0, p0, mask=mask, num_epochs=6, lr=0.1)
+        with pytest.raises(ValueError):
+            bank.train_pande_reversible(u0, p0, mask=None, num_epochs=3, lr=0.1, resume=True)
+        b = bank.train_pande_reversible(u0 * 0, p0 * 0, mask=mask, num_epochs=5, lr=0.1, resume=True)   # (inputs ignored)
+        c = bank.train_pande_reversible(u0, p0, mask=mask, num_epochs=4, lr=0.1, resume=True)
+    assert np.array_equal(np.concatenate([a["loss"], b["loss"], c["loss"]]), whole["loss"])
+    for key in ("Q_last", "Q_best", "upper_diag", "log_pi"):
+        assert np.array_equal(c[key], whole[key]), key
+    assert c["Q_pow2"] == {}
+    g = load_golden("eval_s20_symmask.npz")
+    with CherryBank(g["t"], g["C"]) as small:
+        nup = 20 * 19 // 2
+        small.train_pande_reversible(np.zeros(nup), np.zeros(20), num_epochs=2)
+        with pytest.raises(NotImplementedError):
+            small.train_pande_reversible(np.zeros(nup), np.zeros(20), num_epochs=2, resume=True)
