@@ -274,8 +274,11 @@ __global__ __launch_bounds__(LG4_THREADS, 4) void k1_pt_loss_gt(K1Args<T, TG> a)
   // LDS (the panel buffers are free after the K loop; no workgroup barrier, the four waves stay independent)
   // and handles the mirrored entries with the lanes running along THEIR rows: 128-byte runs, like the
   // direct entries.  (Staging whole 80 x 48 parts through LDS with barriers in between gave the same
-  // traffic, 400 MB, but serialised the waves: 0.245 -> 0.262 ms.)
-  T *sW = sAB + wave * (16 * 17);
+  // traffic, 400 MB, but serialised the waves: 0.245 -> 0.262 ms.  Issuing tile j + 1's count loads before tile j's
+  // arithmetic -- a software pipeline over the 7 tiles of a wave -- costs 4 .. 56 spilled registers at the 128 the
+  // four-workgroup occupancy allows and measured 0.240 against 0.236 ms without it: the other three workgroups of
+  // the CU already cover those latencies.)
+  T *sW = sAB + wave * (2 * 16 * 17);   // two patches per wave: log Pt, 1 / Pt
   auto tile_epilogue = [&](int rbase, int cbase, const acc_t &v) {   // wave-uniform tile origin
     if (rbase >= a.LD || cbase >= a.LD) return;
     const int col = cbase + lo;
@@ -322,29 +325,39 @@ __global__ __launch_bounds__(LG4_THREADS, 4) void k1_pt_loss_gt(K1Args<T, TG> a)
       }
       return;
     }
+    // log and reciprocal ONCE per Pt value: the mirrored entry (same value, other lane) takes them through the patches
+    T lg[4], rc[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      lg[r] = k1_log(pt[r]);
+      rc[r] = k1_rcp(pt[r]);
+    }
     TG g1[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const bool nz = c1[r] != T(0);
-      lossacc = fma(-(double)c1[r], (double)k1_log(nz ? pt[r] : T(1)), lossacc);
-      g1[r] = (TG)(nz ? -c1[r] * inv_nT * k1_rcp(pt[r]) : T(0));
+      lossacc = fma(-(double)c1[r], (double)(nz ? lg[r] : T(0)), lossacc);   // (Pt <= 0 only where C = 0: rounding of a tiny entry)
+      g1[r] = (TG)(nz ? -c1[r] * inv_nT * rc[r] : T(0));
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) Gt[idx[r]] = g1[r];
     if (mirror) {
-      // Pt(row = rbase + rl[r], col = cbase + lo) -> patch[lo][rl[r]]; read back patch[rl[r]][lo] =
-      // Pt(row = rbase + lo, col = cbase + rl[r]), the value of the mirrored entry this lane now owns
-      lg_wave_lds_fence();   // the previous tile's reads of the patch are done
+      // value(row = rbase + rl[r], col = cbase + lo) -> patch[lo][rl[r]]; read back patch[rl[r]][lo] =
+      // value(row = rbase + lo, col = cbase + rl[r]), that of the mirrored entry this lane now owns
+      lg_wave_lds_fence();   // the previous tile's reads of the patches are done
 #pragma unroll
-      for (int r = 0; r < 4; ++r) sW[lo * 17 + rl[r]] = pt[r];
+      for (int r = 0; r < 4; ++r) {
+        sW[lo * 17 + rl[r]] = lg[r];
+        sW[16 * 17 + lo * 17 + rl[r]] = rc[r];
+      }
       lg_wave_lds_fence();
       TG g2[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const T pm = sW[rl[r] * 17 + lo];
+        const T lm = sW[rl[r] * 17 + lo], rm = sW[16 * 17 + rl[r] * 17 + lo];
         const bool nz = c2[r] != T(0);
-        lossacc = fma(-(double)c2[r], (double)k1_log(nz ? pm : T(1)), lossacc);
-        g2[r] = (TG)(nz ? -c2[r] * inv_nT * k1_rcp(pm) : T(0));
+        lossacc = fma(-(double)c2[r], (double)(nz ? lm : T(0)), lossacc);
+        g2[r] = (TG)(nz ? -c2[r] * inv_nT * rm : T(0));
       }
 #pragma unroll
       for (int r = 0; r < 4; ++r) Gt[idm[r]] = g2[r];
