@@ -197,6 +197,32 @@ def test_likelihood_small_alphabet_pairs_and_general_S():
         assert np.allclose(lls, lls_o, rtol=RTOL, atol=1e-12), S1
 
 
+def test_likelihood_single_site_model_with_100_states():
+    """S > 64 WITHOUT pairs (S1 = 0): a 100-letter alphabet, one rate category -- the leaf gather's single-site form
+    (observed: one column of P_v; gap: the row sum) and the MFMA kernel with 20 units (ragged 32-block)."""
+    from cherryml_amd.evaluation import dp_likelihood_computation
+    from oracle import likelihood_oracle as lo
+    rng = np.random.default_rng(77)
+    S = 100
+    aa = [chr(48 + i) for i in range(S)]
+    assert "-" not in aa
+    tree, names = _random_tree(rng, 21)
+    L = 20
+    msa = _random_msa(rng, names, L, aa, gap=0.2)
+    pi = rng.dirichlet(np.full(S, 4.0))
+    sym = rng.uniform(0.1, 1.0, (S, S))
+    sym = np.triu(sym, 1) + np.triu(sym, 1).T
+    Q = sym * pi[None, :]
+    Q[np.diag_indices(S)] = -Q.sum(1)
+    Q /= -(pi * np.diag(Q)).sum()
+    rates = [1.0] * L
+    ll_o, lls_o = lo.log_likelihood(tree, msa, None, rates, aa, pi, Q)
+    ll, lls = dp_likelihood_computation(tree, msa, None, rates, aa, pi, Q)
+    assert np.allclose(lls, lls_o, rtol=RTOL, atol=1e-12)
+    with pytest.raises(NotImplementedError):   # more than one rate category at S > 64
+        dp_likelihood_computation(tree, msa, None, [1.0] * (L - 1) + [2.0], aa, pi, Q)
+
+
 def test_likelihood_errors():
     from cherryml_amd.evaluation import dp_likelihood_computation, tree_likelihood
     z = load_golden("likelihood.npz")
