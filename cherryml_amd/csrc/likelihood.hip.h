@@ -315,7 +315,7 @@ __global__ __launch_bounds__(TL_NW * 64, 2) void tl_mfma_kernel(TlArgs a) {
 #pragma unroll
   for (int j = 0; j < TL_MAXT; ++j)
     if ((wave + TL_NW * j) * RS + rs < nt) g_tiles = j + 1;
-  TlProd<NB> pr{Pv, sW, a.msg + (size_t)v * S * a.NU, S, Sp, a.NU, (wave * RS + rs) * 16, TL_NW * RS * 16, lo, hi};
+  TlProd<NB> pr{Pv, sW, a.msg + (size_t)v * S * a.NU, S, Sp, a.NU, (wave * RS + rs) * 16, TL_NW * RS * 16, lo, hi, {}, {}, {}};
 #pragma unroll
   for (int nb = 0; nb < NB; ++nb) {
     pr.u[nb] = u[nb];
