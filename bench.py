@@ -468,7 +468,7 @@ def main():
             sys.stdout.write(json.dumps(out) + "\n")
             sys.stdout.flush()
 
-    defaults = {"coevo400": (200, 5), "coevo400_demo": (200, 5), "lg20": (500, 50), "siterm": (20, 2), "counting": (20, 3), "ble": (5, 1), "assembly": (5, 1),
+    defaults = {"coevo400": (200, 5), "coevo400_demo": (200, 5), "lg20": (500, 50), "siterm": (100, 2), "counting": (20, 3), "ble": (5, 1), "assembly": (5, 1),
                 "likelihood": (5, 1)}
     steps = args.steps if args.steps is not None else defaults[args.workload][0]
     warmup = args.warmup if args.warmup is not None else defaults[args.workload][1]
