@@ -51,6 +51,8 @@ def tree_likelihood_batch(trees: List[Tree], codes_a: List[np.ndarray], codes_b:
     family f has tree `trees[f]`, `codes_a[f]` [n_nodes, n_units] (rows in `tree.nodes()` order, -1 =
     unobserved; `codes_b[f]` for pairs) and `unit_rates[f]` [n_units] scaling Q per unit.  The model's
     eigendecomposition is shared by the families (400-state pair model: one eigensolve for the batch)."""
+    if len(trees) == 0:
+        return []
     Q, pi_root = _f64(Q), _f64(pi_root).reshape(-1)
     S = Q.shape[0]
     pairs = codes_b is not None
