@@ -156,7 +156,7 @@ static int large_eigh(cb_bank *h, bool warm) {
     bool got = false;
     if (h->poll) {
       // spin on the pinned words (a few microseconds after the kernel's last workgroup); give up
-      // after 20 ms and take the ordinary route
+      // after 2 ms (a sweep is a few hundred microseconds of GPU work) and take the ordinary route
       volatile unsigned long long *pl = h->poll;
       const auto t_spin = std::chrono::steady_clock::now();
       for (unsigned it = 0;; ++it) {
@@ -170,7 +170,7 @@ static int large_eigh(cb_bank *h, bool warm) {
           break;
         }
         if ((it & 1023u) == 1023u &&
-            std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_spin).count() > 20.0)
+            std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_spin).count() > 2.0)
           break;
       }
     }
