@@ -32,6 +32,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
         return LIB
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wextra"]
+    flags += os.environ.get("CB_EXTRA_HIPCC_FLAGS", "").split()   # (experiments: e.g. -DCB_SETPRIO)
     objdir = os.path.join(PKG_DIR, "build")
     os.makedirs(objdir, exist_ok=True)
     # compile the translation units side by side, then link
