@@ -32,6 +32,8 @@ struct cb_bank {
   int B_cap = 0;        // B at creation (cb_internal_set_times may lower B)
   // the optimisation a later CB_TRAIN_RESUME call continues (large fused trainer): epochs done, Adam's beta powers,
   // and what the call looked like (mask, moments) -- a resumed call must look the same
+  hipStream_t xstream[3] = {};     // CB_BANK_STREAMS: extra queues, each with its share of the buckets
+  hipEvent_t ev_fork = nullptr, ev_join[3] = {};
   int tr_epochs = 0, tr_sig = 0;
   double tr_pow_b1 = 1.0, tr_pow_b2 = 1.0;
   int dtype = CB_F64;   // element type of the bank products (large path): CB_F64 or CB_F32
@@ -585,6 +587,14 @@ extern "C" void cb_destroy(cb_handle h) {
     if (p) (void)hipFree(p);
   if (h->pin) (void)hipHostFree(h->pin);
   if (h->poll) (void)hipHostFree(h->poll);
+  for (hipStream_t x : h->xstream)
+    if (x) {
+      (void)hipStreamSynchronize(x);
+      (void)hipStreamDestroy(x);
+    }
+  if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
+  for (hipEvent_t e : h->ev_join)
+    if (e) (void)hipEventDestroy(e);
   if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
   delete h;
 }
@@ -715,6 +725,7 @@ static int large_eval(cb_bank *h, bool normalize, double *lossd, double *out, bo
   // CB_MIXED: P_b, the loss and G_b in float64 (the O(t^2) entries of P_b keep their relative accuracy),
   // G_b rounded to float32 once, the two contractions on the float32 MFMA
   const bool f32 = h->dtype == CB_F32 && !Pd, mixed = h->dtype == CB_MIXED && !Pd;
+  static const int n_parts = getenv("CB_BANK_STREAMS") ? std::min(4, std::max(1, atoi(getenv("CB_BANK_STREAMS")))) : 1;
   if (f32 || mixed)
     hipLaunchKernelGGL(lg_cast_f32, dim3((unsigned)((std::max(LL, (size_t)B * LD) + 255) / 256)), dim3(256), 0, h->stream, LL,
                        (size_t)B * LD, h->U, h->Vc, h->A, h->F, h->Uf, h->Utf, h->Af, h->Ff);
@@ -725,6 +736,59 @@ static int large_eval(cb_bank *h, bool normalize, double *lossd, double *out, bo
   } else if (mixed) {
     K1Args<double, float> k1{S, LD, B, h->Vc, h->A, tb, h->F, h->sigma, h->Ct, h->Gt32, h->loss_part, inv_n, h->dsq, nullptr};
     hipLaunchKernelGGL((k1_pt_loss_gt<double, float>), dim3(tiles_k1 * B), dim3(LG4_THREADS), 0, h->stream, k1);
+  } else if (n_parts > 1 && !Pd && dQd && B >= 4 * n_parts && !h->comm && !h->profile) {
+    // OPT-IN (CB_BANK_STREAMS=n, float64 bank, no profile markers): the buckets in n equal parts on n queues,
+    // K1 -> K2 -> K3 each, so that the drain of one part's kernel overlaps the other parts' kernels; same results bit
+    // for bit (disjoint buckets, the bucket sum is taken after the join).  n = 2: 1.110 -> 1.072 ms per epoch on the
+    // bench bank; 3 and 4 are slower again.  Not the default: with kernels of two queues sharing the chip the
+    // per-kernel durations the bench reports (HIP events on one stream, rocprof averages) stop meaning anything.
+    if (!h->ev_fork) HIP_TRY(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
+    for (int p = 1; p < n_parts; ++p)
+      if (!h->xstream[p - 1]) {
+        HIP_TRY(hipStreamCreateWithFlags(&h->xstream[p - 1], hipStreamNonBlocking));
+        HIP_TRY(hipEventCreateWithFlags(&h->ev_join[p - 1], hipEventDisableTiming));
+      }
+    HIP_TRY(hipEventRecord(h->ev_fork, h->stream));
+    for (int p = 1; p < n_parts; ++p) HIP_TRY(hipStreamWaitEvent(h->xstream[p - 1], h->ev_fork, 0));
+    auto part_of = [&](int p, int &b0, int &Bs, hipStream_t &st) {
+      b0 = (int)((long)B * p / n_parts);
+      Bs = (int)((long)B * (p + 1) / n_parts) - b0;
+      st = p ? h->xstream[p - 1] : h->stream;
+    };
+    for (int p = 0; p < n_parts; ++p) {
+      int b0, Bs; hipStream_t st;
+      part_of(p, b0, Bs, st);
+      K1Args<double> k1{S, LD, Bs, h->Vc, h->A, tb + b0, h->F + (size_t)b0 * LD, h->sigma, h->Ct + b0 * LL, h->Gt + b0 * LL,
+                        h->loss_part + (size_t)b0 * tiles_k1, inv_n, h->dsq, nullptr};
+      hipLaunchKernelGGL((k1_pt_loss_gt<double, double, false>), dim3(tiles_k1 * Bs), dim3(LG4_THREADS), 0, st, k1);
+    }
+    for (int p = 0; p < n_parts; ++p) {
+      int b0, Bs; hipStream_t st;
+      part_of(p, b0, Bs, st);
+      K2Args<double> k2{LD, h->Gt + b0 * LL, h->U, h->T + b0 * LL};
+      hipLaunchKernelGGL(k2_t_eq_g_u<double>, dim3(tiles * Bs), dim3(LG4_THREADS), 0, st, k2);
+    }
+    for (int p = 0; p < n_parts; ++p) {
+      int b0, Bs; hipStream_t st;
+      part_of(p, b0, Bs, st);
+      K3Args<double> k3{LD, Bs, h->T + b0 * LL, h->U, tb + b0, h->lam, h->E + (size_t)b0 * LD, h->H + (size_t)b0 * LD,
+                        h->Gt + b0 * LL, h->sym_counts ? 1 : 0};
+      hipLaunchKernelGGL(k3_w_phi<double>, dim3(tiles_k3 * Bs), dim3(LG4_THREADS), 0, st, k3);
+    }
+    for (int p = 1; p < n_parts; ++p) {
+      HIP_TRY(hipEventRecord(h->ev_join[p - 1], h->xstream[p - 1]));
+      HIP_TRY(hipStreamWaitEvent(h->stream, h->ev_join[p - 1], 0));
+    }
+    hipLaunchKernelGGL(lg_finish_loss, dim3(1), dim3(256), 0, h->stream, h->loss_part, B * tiles_k1, S,
+                       h->dsq, h->dirsum, inv_n, lossd);
+    hipLaunchKernelGGL(k3_reduce<double>, dim3((unsigned)((LL + 255) / 256)), dim3(256), 0, h->stream,
+                       h->Gt, B, LL, h->Mt, h->sym_counts ? LD : 0);
+    K4Args k4a{S, LD, h->Mt, h->Vc, h->X, nullptr, nullptr, nullptr};
+    launch_sg(h, k4a, 0);
+    K4Args k4b{S, LD, h->Vc, h->X, dQd, dA_padded ? nullptr : h->dsq, nullptr, nullptr};
+    launch_sg(h, k4b, 0);
+    HIP_TRY(hipGetLastError());
+    return CB_OK;
   } else {
     K1Args<double> k1{S, LD, B, h->Vc, h->A, tb, h->F, h->sigma, h->Ct, h->Gt, h->loss_part, inv_n, h->dsq, Pd};
     if (Pd) hipLaunchKernelGGL((k1_pt_loss_gt<double, double, true>), dim3(tiles_k1 * B), dim3(LG4_THREADS), 0, h->stream, k1);

@@ -220,3 +220,25 @@ def test_resumed_training_equals_one_call(dense):
         small.train_pande_reversible(np.zeros(nup), np.zeros(20), num_epochs=2)
         with pytest.raises(NotImplementedError):
             small.train_pande_reversible(np.zeros(nup), np.zeros(20), num_epochs=2, resume=True)
+
+
+def test_two_queue_bank_option_gives_the_same_bits(dense, tmp_path):
+    """CB_BANK_STREAMS=2 (read once per process, hence the subprocess): the buckets' K1 -> K2 -> K3 chains on two
+    queues -- the trajectory is bit-identical to the single-queue one."""
+    import os
+    import subprocess
+    import sys
+    z = load_golden("coevo_dense_traj.npz")
+    sel, mask = z["sel"], dense["mask"]
+    np.savez(tmp_path / "in.npz", t=dense["t"][sel], C=dense["C"][sel], mask=mask, u0=z["upper_diag0"], p0=z["log_pi0"])
+    code = ("import sys, numpy as np; from cherryml_amd import CherryBank; z = np.load(sys.argv[1]);\n"
+            "b = CherryBank(z['t'], z['C']); r = b.train_pande_reversible(z['u0'], z['p0'], mask=z['mask'], num_epochs=12, lr=0.1);\n"
+            "np.savez(sys.argv[2], loss=r['loss'], Q=r['Q_last']); b.close()")
+    outs = []
+    for n in ("1", "2"):
+        env = dict(os.environ, CB_BANK_STREAMS=n, PYTHONPATH=os.getcwd() + os.pathsep + os.environ.get("PYTHONPATH", ""))
+        out = tmp_path / f"out{n}.npz"
+        subprocess.run([sys.executable, "-c", code, str(tmp_path / "in.npz"), str(out)], check=True, env=env, timeout=600)
+        outs.append(np.load(out))
+    assert np.array_equal(outs[0]["loss"], outs[1]["loss"]) and np.array_equal(outs[0]["Q"], outs[1]["Q"])
+    assert np.allclose(outs[0]["loss"], z["loss_f64"][:12], rtol=1e-9, atol=0)
