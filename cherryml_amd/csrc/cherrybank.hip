@@ -1478,7 +1478,7 @@ static int run_fused_training(cb_bank *h, int kind, double *pi_param, double *up
         g.Mpart = buf + (size_t)L * LGS_TOTAL;
         g.lpart = g.Mpart + (size_t)L * g.nchunk * 576;
         g.best = g.lpart + (size_t)L * g.nchunk;
-        const size_t lds_p = SPP_TOTAL * sizeof(double), lds_b = SPB_TOTAL * sizeof(double), lds_f = SPF_TOTAL * sizeof(double);
+        const size_t lds_p = SPP_TOTAL * sizeof(double), lds_f = SPF_TOTAL * sizeof(double);
         const int TS = quad_ts(S);
         double pow_b1 = 1.0, pow_b2 = 1.0;
         for (int e = 0; e < E && rc == CB_OK; ++e) {
@@ -1486,11 +1486,14 @@ static int run_fused_training(cb_bank *h, int kind, double *pi_param, double *up
           pow_b2 *= a.beta2;
           hipLaunchKernelGGL(sp_prepare, dim3(L), dim3(64), lds_p, h->stream, a, g, e);
           const dim3 gb((unsigned)((size_t)L * g.nchunk));
+          const bool w3 = (size_t)L * g.nchunk > 512;   // more workgroups than two per CU can hold at once: the three-per-CU form
           const double bc1 = 1.0 - pow_b1, bc2s = std::sqrt(1.0 - pow_b2);
 #define SPK(T)                                                                                         \
   do {                                                                                                 \
-    if (a.sym) hipLaunchKernelGGL((sp_bank<T, true>), gb, dim3(256), lds_b, h->stream, a, g);           \
-    else hipLaunchKernelGGL((sp_bank<T, false>), gb, dim3(256), lds_b, h->stream, a, g);                \
+    if (a.sym && w3) hipLaunchKernelGGL((sp_bank<T, true, true>), gb, dim3(256), spb_total(T, true, true) * sizeof(double), h->stream, a, g);      \
+    else if (a.sym) hipLaunchKernelGGL((sp_bank<T, true, false>), gb, dim3(256), spb_total(T, true, false) * sizeof(double), h->stream, a, g);  \
+    else if (w3) hipLaunchKernelGGL((sp_bank<T, false, true>), gb, dim3(256), spb_total(T, false, true) * sizeof(double), h->stream, a, g);     \
+    else hipLaunchKernelGGL((sp_bank<T, false, false>), gb, dim3(256), spb_total(T, false, false) * sizeof(double), h->stream, a, g);           \
     hipLaunchKernelGGL((sp_finish<T>), dim3(L), dim3(256), lds_f, h->stream, a, g, e, bc1, bc2s);       \
   } while (0)
           switch (TS) {

@@ -283,7 +283,10 @@ __device__ __forceinline__ void quad_load_counts(double (&cv)[TS][TS], const dou
 // 25 at 20 states: 275 instead of 375 MFMAs and ~28 % fewer vector instructions per quad), only their counts are
 // loaded, the lower G~ tiles are the upper ones transposed (a 4 x 4 transposition inside the MFMA block = one lane
 // permutation), and M is accumulated on its upper tiles only (the caller mirrors the sum).
-template <int TS, bool LANEM, bool SYM = false>
+// ULDS: the B-layout tiles of U are re-read from LDS where they are used (25 ds_read_b64 per tile row of the T and
+// W phases) instead of living in 2 TS^2 registers across both phases -- the register peak drops by ~50, which is what
+// lets three workgroups share a CU (sp_bank).
+template <int TS, bool LANEM, bool SYM = false, bool ULDS = false>
 __device__ __forceinline__ void small_quad(int S, double tb, const double *__restrict__ Cq, double inv_n,
                                            const double *sA, const double *sV, double *tabw,
                                            const double *sLam, double rho, double *Mw, double &lossacc) {
@@ -372,19 +375,24 @@ __device__ __forceinline__ void small_quad(int S, double tb, const double *__res
       for (int J = I + 1; J < TS; ++J) g[J][I] = __shfl(g[I][J], src, 64);
   }
   asm volatile("" ::: "memory");
-  double UB[TS][TS];  // B layout of U(I,K): U[4 I + q][4 K + r]  (= A layout of U^T(K,I))
+  double UB[ULDS ? 1 : TS][ULDS ? 1 : TS];  // B layout of U(I,K): U[4 I + q][4 K + r]  (= A layout of U^T(K,I))
+  if (!ULDS) {
 #pragma unroll
-  for (int I = 0; I < TS; ++I)
+    for (int I = 0; I < TS; ++I)
 #pragma unroll
-    for (int K = 0; K < TS; ++K) UB[I][K] = sV[(4 * K + r) * CB_LS + 4 * I + q];
+      for (int K = 0; K < TS; ++K) UB[ULDS ? 0 : I][ULDS ? 0 : K] = sV[(4 * K + r) * CB_LS + 4 * I + q];
+  }
+  const double *ub0 = sV + r * CB_LS + q;   // UB(I, K) = ub0[4 K CB_LS + 4 I]
+#define Q_UB(I, K) (ULDS ? ub0[4 * (K) * CB_LS + 4 * (I)] : UB[ULDS ? 0 : (I)][ULDS ? 0 : (K)])
   // ---- T(It,Mt) = sum_Jt G~(It,Jt) U(Jt,Mt), stored over g[Mt][It] ---------------------------
 #pragma unroll
   for (int It = 0; It < TS; ++It) {
+    if (ULDS) asm volatile("" ::: "memory");   // (keeps the compiler from hoisting the U reads out of the row loop)
     double acc[TS];
 #pragma unroll
     for (int Jt = 0; Jt < TS; ++Jt)
 #pragma unroll
-      for (int Mt = 0; Mt < TS; ++Mt) acc[Mt] = mfma4_f64(g[Jt][It], UB[Jt][Mt], Jt == 0 ? 0.0 : acc[Mt]);
+      for (int Mt = 0; Mt < TS; ++Mt) acc[Mt] = mfma4_f64(g[Jt][It], Q_UB(Jt, Mt), Jt == 0 ? 0.0 : acc[Mt]);
 #pragma unroll
     for (int Mt = 0; Mt < TS; ++Mt) g[Mt][It] = acc[Mt];
     __builtin_amdgcn_sched_barrier(0);
@@ -395,12 +403,13 @@ __device__ __forceinline__ void small_quad(int S, double tb, const double *__res
   for (int Ct = 0; Ct < TS; ++Ct) {
     const int c = min(4 * Ct + r, 31);
     const double EC = tab[32 + c], HC = tab[64 + c], LC = sLam[c];
+    if (ULDS) asm volatile("" ::: "memory");
     double acc[TS];
 #pragma unroll
     for (int It = 0; It < TS; ++It)
 #pragma unroll
       for (int At = 0; At < TS; ++At)
-        if (!SYM || At <= Ct) acc[At] = mfma4_f64(UB[It][At], g[Ct][It], It == 0 ? 0.0 : acc[At]);
+        if (!SYM || At <= Ct) acc[At] = mfma4_f64(Q_UB(It, At), g[Ct][It], It == 0 ? 0.0 : acc[At]);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int At = 0; At < TS; ++At) {
@@ -429,6 +438,7 @@ __device__ __forceinline__ void small_quad(int S, double tb, const double *__res
   Q_STAMP(12);
   if (g_small_stamps && blockIdx.x == 0 && threadIdx.x == 0 && g_small_stamps[15] == 1) g_small_stamps[15] = 2;
 #undef Q_STAMP
+#undef Q_UB
 }
 
 // ---- A = sym(D^1/2 Q D^-1/2) into LDS -----------------------------------------

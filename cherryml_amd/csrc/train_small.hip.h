@@ -447,11 +447,23 @@ __global__ __launch_bounds__(64) void sp_prepare(TrainArgs a, SpSplit g, int epo
 #define SPB_LAM (2 * SPB_ROWS * CB_LS)
 #define SPB_TAB (SPB_LAM + 32)
 #define SPB_MW (SPB_TAB + 4 * 384)
-#define SPB_LOSS (SPB_MW + 4 * 1600)   // TS <= 5: [tile][64] per wave (1600); TS = 6: [tile][16] (576)
-#define SPB_TOTAL (SPB_LOSS + 8)
 
-template <int TS, bool SYM = false>   // SYM: all count matrices symmetric (small_quad's symmetric form)
-__global__ __launch_bounds__(256, 2) void sp_bank(TrainArgs a, SpSplit g) {
+// Workgroups per CU: THREE where the quad fits 168 registers once the B-layout tiles of U are re-read from LDS
+// (small_quad's ULDS form) and M is accumulated in 16 slots per tile (44 KB of LDS per workgroup) -- up to 16
+// states, and 20 states with symmetric counts (the SiteRM case); two elsewhere (the other forms spill 40 .. 83
+// registers at 168).  CB_SPB_WGS=2 at build time restores two everywhere.
+#ifndef CB_SPB_WGS
+#define CB_SPB_WGS 3
+#endif
+__host__ __device__ constexpr bool spb_w3_ok(int TS, bool SYM) { return CB_SPB_WGS >= 3 && (TS <= 4 || (TS == 5 && SYM)); }
+__host__ __device__ constexpr int spb_wgs(int TS, bool SYM, bool W3) { return (W3 && spb_w3_ok(TS, SYM)) ? 3 : 2; }
+__host__ __device__ constexpr int spb_mws(int TS, bool SYM, bool W3) { return (TS <= 5 && spb_wgs(TS, SYM, W3) < 3) ? 1600 : 576; }   // M doubles per wave
+// after Mw: 8 doubles of loss partials; Mw = 4 waves x spb_mws doubles ([tile][64] per wave: 1600, or [tile][16]: 576)
+__host__ __device__ constexpr int spb_total(int TS, bool SYM, bool W3) { return SPB_MW + 4 * spb_mws(TS, SYM, W3) + 8; }
+// W3: the three-workgroup form (many sites); the two-workgroup form keeps U's tiles in registers and is the faster one
+// per quad, which is what counts when the grid does not fill the chip (one LG-sized bank)
+template <int TS, bool SYM = false, bool W3 = false>   // SYM: all count matrices symmetric (small_quad's symmetric form)
+__global__ __launch_bounds__(256, spb_wgs(TS, SYM, W3)) void sp_bank(TrainArgs a, SpSplit g) {
   extern __shared__ double lds[];
   double *sA = lds + SPB_A, *sV = lds + SPB_V, *sLam = lds + SPB_LAM;
   const int S = a.S, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, blk = (lane >> 2) & 3;
@@ -462,8 +474,9 @@ __global__ __launch_bounds__(256, 2) void sp_bank(TrainArgs a, SpSplit g) {
     sV[e] = fr[LGS_V + e];
   }
   if (tid < 32) sLam[tid] = fr[LGS_LAM + tid];
-  constexpr bool LANEM = TS <= 5;               // per-lane M slots while they fit LDS (2 workgroups per CU)
-  constexpr int MWS = LANEM ? 1600 : 576;       // doubles per wave
+  constexpr bool LANEM = spb_mws(TS, SYM, W3) == 1600;   // per-lane M slots while they fit LDS (2 workgroups per CU)
+  constexpr int MWS = spb_mws(TS, SYM, W3);             // doubles per wave
+  constexpr int SPB_LOSS = SPB_MW + 4 * MWS;
   double *Mw = lds + SPB_MW + wave * MWS;
   for (int e = lane; e < (LANEM ? 64 : 16) * TS * TS; e += 64) Mw[e] = 0.0;
   __syncthreads();
@@ -479,7 +492,7 @@ __global__ __launch_bounds__(256, 2) void sp_bank(TrainArgs a, SpSplit g) {
   for (int qd = q0 + wave; qd < q1; qd += 4) {
     const int bucket = 4 * qd + blk;
     const double tb = bucket < Bn ? t_l[bucket] : 0.0;
-    small_quad<TS, LANEM, SYM>(S, tb, Cq_l + (size_t)qd * (TS * TS * 64), inv_n, sA, sV, lds + SPB_TAB + wave * 384, sLam,
+    small_quad<TS, LANEM, SYM, (spb_wgs(TS, SYM, W3) >= 3)>(S, tb, Cq_l + (size_t)qd * (TS * TS * 64), inv_n, sA, sV, lds + SPB_TAB + wave * 384, sLam,
                          rho, Mw, lossacc);
   }
   lossacc = wave_sum(lossacc);
