@@ -111,24 +111,14 @@ def cached_computation(output_dirs: List[str], exclude_args: Optional[List[str]]
             rank, world = _dist_state()
             if _agree(all(os.path.exists(tk) for tk in tokens)):
                 return chosen
-            if rank == 0:
+            def prepare():
                 for d in chosen.values():
                     os.makedirs(d, exist_ok=True)
                     tk = os.path.join(d, "result.success")
                     if os.path.exists(tk):
                         os.remove(tk)
-            if world > 1:
-                _agree(None)   # the directories exist / stale tokens are gone before any rank starts
-                error = None
-                if collective or rank == 0:
-                    try:
-                        func(**full)
-                    except Exception as exc:  # exchanged below: all ranks raise together
-                        error = f"{type(exc).__name__}: {exc}"
-                _raise_together(error, func.__name__)
-            else:
-                func(**full)
-            if rank == 0:
+
+            def write_tokens():
                 for d in chosen.values():
                     if write_extra_log_files:
                         with open(os.path.join(d, "_function_binding.log"), "w") as f:
@@ -136,8 +126,26 @@ def cached_computation(output_dirs: List[str], exclude_args: Optional[List[str]]
                                     "\n".join(f"{k}={v!r}" for k, v in key_items) + "\n")
                     with open(os.path.join(d, "result.success"), "w") as f:
                         f.write("SUCCESS\n")
-            if world > 1:
-                _agree(None)   # tokens are on disk before any rank moves on to read the outputs
+
+            if world == 1:
+                prepare()
+                func(**full)
+                write_tokens()
+                return chosen
+            # world > 1: every step that can fail on one rank alone (rank 0's filesystem work, the stage body) ends in
+            # an exchange of the error, so that no rank is left waiting in a collective its peer never enters
+            def guarded(step, runs_here):
+                error = None
+                if runs_here:
+                    try:
+                        step()
+                    except Exception as exc:
+                        error = f"{type(exc).__name__}: {exc}"
+                _raise_together(error, func.__name__)
+
+            guarded(prepare, rank == 0)          # the directories exist / stale tokens are gone before any rank starts
+            guarded(lambda: func(**full), collective or rank == 0)
+            guarded(write_tokens, rank == 0)     # tokens are on disk before any rank moves on to read the outputs
             return chosen
 
         return wrapper

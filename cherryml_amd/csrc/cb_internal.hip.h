@@ -29,10 +29,13 @@ int cb_fail(int code, const char *fmt, ...);
                   #expr, hipGetErrorString(e_), __FILE__, __LINE__);                    \
   } while (0)
 
-// cb_expm_bank flag (internal): the matrix is the one of the previous call on this handle -- skip the eigensolve
+// cb_internal_expm_bank flag: the matrix is the one of the previous call on this handle -- skip the eigensolve
+// (the public cb_expm_bank masks it out)
 #define CB_REUSE_EIGH 256
-// new branch lengths for a counts-free (CB_EXPM_ONLY) single-bank handle, B <= its creation B (cherrybank.hip)
-int cb_internal_set_times(cb_handle h, const double *t_host, int B);
+int cb_internal_expm_bank(cb_handle h, const double *Q, const double *pi, int flags, double *P);
+// new branch lengths for a counts-free (CB_EXPM_ONLY) single-bank handle, B <= its creation B (cherrybank.hip);
+// t_dev != NULL: the same values already on the device -- copied on the handle's stream, no host wait
+int cb_internal_set_times(cb_handle h, const double *t_host, int B, const double *t_dev);
 
 // device buffers of one call of the per-family entry points (uploaded on the default stream, freed on return)
 struct CbDevBufs {

@@ -130,7 +130,10 @@ int tl_prune(int S, int S1, const TlFamily &f, const double *dP, int cat_stride_
 // code_b ([n_nodes[f]][n_units[f]]) and ll are the families' arrays concatenated in order.  What the batch shares:
 // the model's eigendecomposition -- for S > 32 (the 400-state pair model: 3 ms cold per family) ONE counts-free
 // bank handle serves all families (new branch lengths per family, eigensolve once) -- the uploads of Q / pi, and
-// the message buffer; nothing synchronises with the host between families.  Results equal cb_tree_likelihood's.
+// the message buffer.  S > 32 with a reversible Q: all branch lengths are uploaded once and a family's bank is
+// enqueued behind the previous family's pruning without a host wait; the general (non-reversible) bank reads one
+// norm back per family, and for S <= 32 a handle is made (and waited for) per family.  Results equal
+// cb_tree_likelihood's.
 extern "C" int cb_tree_likelihood_batch(int device, int S, int S1, const double *Q, const double *pi_rev,
                                         const double *pi_root, int n_fam, const int *n_nodes, const int *postorder,
                                         const int *parent, const double *length, const int *n_cats,
@@ -205,8 +208,9 @@ extern "C" int cb_tree_likelihood_batch(int device, int S, int S1, const double 
     ~Guard() { if (*h) cb_destroy(*h); }
   } guard{&hl};
   if (large) {
-    std::vector<double> t0(max_nodes, 0.0);
-    if ((rc = cb_create(device, S, 1, max_nodes, CB_F64, t0.data(), nullptr, CB_EXPM_ONLY, &hl)) != CB_OK) return rc;
+    // capacity = the largest [category][node] bank of the batch (33 <= S <= 64 has several rate categories)
+    std::vector<double> t0(max_bank, 0.0);
+    if ((rc = cb_create(device, S, 1, (int)max_bank, CB_F64, t0.data(), nullptr, CB_EXPM_ONLY, &hl)) != CB_OK) return rc;
     if ((rc = cb_set_stream(hl, nullptr, 0)) != CB_OK) return rc;
   }
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -218,19 +222,29 @@ extern "C" int cb_tree_likelihood_batch(int device, int S, int S1, const double 
     HIP_TRY(hipStreamSynchronize(0));   // the timed region starts with resident inputs
     HIP_TRY(hipEventRecord(ev0, 0));
   }
-  for (int f = 0; f < n_fam && rc == CB_OK; ++f) {
+  // branch lengths x category rates of ALL families, uploaded once (S > 32: a family's bank then starts behind the
+  // previous family's pruning on the stream without the host waiting for it)
+  std::vector<size_t> off_t(n_fam + 1, 0);
+  for (int f = 0; f < n_fam; ++f) off_t[f + 1] = off_t[f] + (size_t)n_cats[f] * n_nodes[f];
+  std::vector<double> t_all(off_t[n_fam]);
+  for (int f = 0; f < n_fam; ++f) {
     const TlFamily &F = fam[f];
     const double *len = length + off_n[f], *cr = cat_rate + off_k[f];
-    std::vector<double> t((size_t)F.n_cats * F.n_nodes);
     for (int c = 0; c < F.n_cats; ++c)
-      for (int v = 0; v < F.n_nodes; ++v) t[(size_t)c * F.n_nodes + v] = v == F.root ? 0.0 : cr[c] * len[v];
+      for (int v = 0; v < F.n_nodes; ++v) t_all[off_t[f] + (size_t)c * F.n_nodes + v] = v == F.root ? 0.0 : cr[c] * len[v];
+  }
+  const double *dt_all = large ? d.up(t_all.data(), t_all.size(), rc) : nullptr;
+  if (rc != CB_OK) return rc;
+  for (int f = 0; f < n_fam && rc == CB_OK; ++f) {
+    const TlFamily &F = fam[f];
+    const double *t = t_all.data() + off_t[f];
     // ---- transition bank expm(rate_c * length_v * Q), [cat][node][S][S], by the bank's own expm kernels
     if (large) {
-      if ((rc = cb_internal_set_times(hl, t.data(), F.n_nodes)) != CB_OK) break;
-      rc = cb_expm_bank(hl, dQ, dpi, CB_PTR_DEVICE | CB_NO_SYNC | (f > 0 && dpi ? CB_REUSE_EIGH : 0), dP);
+      if ((rc = cb_internal_set_times(hl, t, F.n_cats * F.n_nodes, dt_all + off_t[f])) != CB_OK) break;
+      rc = cb_internal_expm_bank(hl, dQ, dpi, CB_PTR_DEVICE | CB_NO_SYNC | (f > 0 && dpi ? CB_REUSE_EIGH : 0), dP);
     } else {
       cb_handle h = nullptr;
-      if ((rc = cb_create(device, S, F.n_cats, F.n_nodes, CB_F64, t.data(), nullptr, CB_EXPM_ONLY, &h)) != CB_OK) break;
+      if ((rc = cb_create(device, S, F.n_cats, F.n_nodes, CB_F64, t, nullptr, CB_EXPM_ONLY, &h)) != CB_OK) break;
       rc = cb_set_stream(h, nullptr, 0);
       if (rc == CB_OK) rc = cb_expm_bank(h, dQ, dpi, CB_PTR_DEVICE | CB_NO_SYNC, dP);
       if (rc == CB_OK && hipStreamSynchronize(0) != hipSuccess) rc = fail(CB_EHIP, "cb_tree_likelihood: bank failed");

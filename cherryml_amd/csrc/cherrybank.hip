@@ -34,7 +34,8 @@ struct cb_bank {
   // and what the call looked like (mask, moments) -- a resumed call must look the same
   hipStream_t xstream[3] = {};     // CB_BANK_STREAMS: extra queues, each with its share of the buckets
   hipEvent_t ev_fork = nullptr, ev_join[3] = {};
-  int tr_epochs = 0, tr_sig = 0;
+  int tr_epochs = 0;
+  uint64_t tr_sig = 0;
   double tr_pow_b1 = 1.0, tr_pow_b2 = 1.0;
   int dtype = CB_F64;   // element type of the bank products (large path): CB_F64 or CB_F32
   int LD = 0;           // large path: padded leading dimension
@@ -915,7 +916,13 @@ extern "C" int cb_loss_grad(cb_handle h, const double *Q, const double *pi, int 
   return finish_call(h, flags);
 }
 
+// the public entry honours documented flag bits only: CB_REUSE_EIGH is internal (a caller passing that bit with a
+// different Q would silently get the previous matrix's bank)
 extern "C" int cb_expm_bank(cb_handle h, const double *Q, const double *pi, int flags, double *P) {
+  return cb_internal_expm_bank(h, Q, pi, flags & ~CB_REUSE_EIGH, P);
+}
+
+int cb_internal_expm_bank(cb_handle h, const double *Q, const double *pi, int flags, double *P) {
   if (!h || !Q || !P) return fail(CB_EINVAL, "cb_expm_bank: NULL argument");
   HIP_TRY(hipSetDevice(h->dev));
   const size_t SS = (size_t)h->S * h->S, nP = (size_t)h->L * h->B * SS;
@@ -969,13 +976,17 @@ extern "C" int cb_expm_bank(cb_handle h, const double *Q, const double *pi, int 
 
 // internal (cb_internal.hip.h): new branch lengths for a counts-free handle, B <= the B it was created with --
 // lets cb_tree_likelihood_batch push family after family through ONE handle (one eigendecomposition)
-int cb_internal_set_times(cb_handle h, const double *t_host, int B) {
+int cb_internal_set_times(cb_handle h, const double *t_host, int B, const double *t_dev) {
   if (!h || !t_host) return fail(CB_EINVAL, "cb_internal_set_times: NULL argument");
   if (!h->expm_only || h->L != 1) return fail(CB_EINVAL, "cb_internal_set_times: counts-free single-bank handles only");
   if (B < 1 || B > h->B_cap) return fail(CB_EINVAL, "cb_internal_set_times: B = %d exceeds the handle's capacity %d", B, h->B_cap);
   HIP_TRY(hipSetDevice(h->dev));
-  HIP_TRY(hipStreamSynchronize(h->stream));     // the previous bank is done with h->t
-  HIP_TRY(hipMemcpy(h->t, t_host, B * sizeof(double), hipMemcpyHostToDevice));
+  if (t_dev) {   // already resident: ordered behind the previous bank on the handle's stream, the host does not wait
+    HIP_TRY(hipMemcpyAsync(h->t, t_dev, B * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+  } else {
+    HIP_TRY(hipStreamSynchronize(h->stream));     // the previous bank is done with h->t
+    HIP_TRY(hipMemcpy(h->t, t_host, B * sizeof(double), hipMemcpyHostToDevice));
+  }
   h->B = B;
   h->t_host.assign(t_host, t_host + B);
   return CB_OK;
@@ -1248,9 +1259,23 @@ static int run_fused_training_large(cb_bank *h, double *pi_param, double *up_par
   // CB_TRAIN_RESUME: parameters, moments, best iterate and the bookkeeping words stay where the previous call left
   // them (workspace slots of unchanged size are never moved; the loss-curve slot may be, it carries no state)
   const bool resume = (flags & CB_TRAIN_RESUME) != 0;
-  const int sig = 1 + (mask ? 2 : 0) + (do_adam ? 4 : 0);
+  // what a resumed call must repeat exactly (else the best-loss word would compare losses of two different problems):
+  // optimiser, learning rate, normalisation, and the CONTENTS of the mask (FNV-1a over its bytes)
+  uint64_t sig = 1469598103934665603ull;
+  auto mix = [&](const void *p, size_t n) {
+    const unsigned char *c = static_cast<const unsigned char *>(p);
+    for (size_t i = 0; i < n; ++i) sig = (sig ^ c[i]) * 1099511628211ull;
+  };
+  {
+    const int head[3] = {mask ? 1 : 0, do_adam ? 1 : 0, (flags & CB_NORMALIZE) ? 1 : 0};
+    mix(head, sizeof head);
+    mix(&lr, sizeof lr);
+    if (mask) mix(mask, SS * sizeof(double));
+    if (sig == 0) sig = 1;
+  }
   if (resume && (h->tr_epochs <= 0 || h->tr_sig != sig))
-    return fail(CB_EINVAL, "CB_TRAIN_RESUME: no finished training call with the same mask / optimiser on this handle");
+    return fail(CB_EINVAL, "CB_TRAIN_RESUME: no finished training call with the same mask / optimiser / learning rate / "
+                           "normalisation on this handle");
   if (resume && Q_pow2) return fail(CB_EINVAL, "CB_TRAIN_RESUME: Q_pow2 must be NULL");
   const int e0 = resume ? h->tr_epochs : 0;
   int slot = 0;

@@ -200,7 +200,7 @@ def compute_log_likelihoods(tree_dir: str, msa_dir: str, site_rates_dir: str, co
                             output_likelihood_dir: str, num_processes: int = 1, device: int = 0, **_ignored) -> None:
     """The stage `compute_log_likelihoods` (_likelihood.py:474-600): `<family>.txt` (total, then the
     per-site values) and `<family>.profiling` in `output_likelihood_dir`.  Families run in batches
-    on one GPU (cb_tree_likelihood_batch: shared eigendecompositions, no host synchronisation per family); `num_processes`, `device_1/2` and the CPU threading knobs are accepted and
+    on one GPU (cb_tree_likelihood_batch: shared eigendecompositions and uploads); `num_processes`, `device_1/2` and the CPU threading knobs are accepted and
     ignored."""
     st = time.time()
     os.makedirs(output_likelihood_dir, exist_ok=True)

@@ -179,7 +179,8 @@ int cb_last_sweeps(cb_handle h);
  * All pointers are host pointers.
  * flags & CB_TRAIN_RESUME (S > 32): the call CONTINUES the optimisation the previous successful call on this
  * handle ended -- parameters, Adam moments and step count, best loss and Q_best are the handle's (the
- * upper_diag / log_pi inputs are ignored, mask / do_adam / lr must be the same), the eigensolver stays warm;
+ * upper_diag / log_pi inputs are ignored; the mask's contents, do_adam, lr and CB_NORMALIZE must be the same, else
+ * CB_EINVAL), the eigensolver stays warm;
  * loss_curve holds this call's num_epochs losses, Q_pow2 must be NULL.  E epochs then E' resumed epochs equal
  * E + E' epochs of one call bit for bit.  (The reference has no such entry: its loop runs to the end in one
  * call; this is what lets a caller put a barrier or a checkpoint between epochs of the device-driven loop.)
@@ -364,7 +365,8 @@ int cb_tree_likelihood(int device, int S, int S1, const double *Q, const double 
  * unit_cat, code_a / code_b ([n_nodes[f]][n_units[f]]) and ll are the families' arrays concatenated in
  * order.  The batch shares the model: for S > 32 one counts-free bank handle serves every family and the
  * eigendecomposition of Q is computed ONCE (3 ms cold at 400 states, formerly per family); Q / pi uploads,
- * the message buffer and the stream are shared, and pruning never waits for the host between families.
+ * the message buffer and the stream are shared; with S > 32 and a reversible Q the host does not wait
+ * between families (all branch lengths are uploaded once), otherwise once per family.
  * Results equal cb_tree_likelihood's family by family; kernel_ms as there, summed over the batch. */
 int cb_tree_likelihood_batch(int device, int S, int S1, const double *Q, const double *pi_rev,
                              const double *pi_root, int n_fam, const int *n_nodes, const int *postorder,

@@ -281,3 +281,49 @@ def test_too_few_live_buckets_raises_on_every_rank():
         ShardedBank(np.arange(1.0, 5.0), C, make_bank=lambda tt, CC: OracleBank(tt, CC))
     with pytest.raises(ValueError, match="no counts"):
         ShardedBank.from_rank_counts(np.arange(1.0, 5.0), C, make_bank=lambda tt, CC: OracleBank(tt, CC))
+
+
+def _cache_worker(rank, world, port, out, cache_dir, mode):
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, here)
+    sys.path.insert(0, os.path.dirname(here))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from cherryml_amd import caching
+    caching.set_cache_dir(cache_dir)
+
+    @caching.cached_computation(output_dirs=["output_dir"])
+    def stage(x: int, output_dir=None):
+        if mode == "body":
+            raise ValueError("body broke")
+        with open(os.path.join(output_dir, "result.txt"), "w") as f:
+            f.write(str(x))
+
+    res = {}
+    try:
+        res["dirs"] = stage(x=3)
+    except Exception as exc:
+        res["error"] = f"{type(exc).__name__}: {exc}"
+    torch.save(res, os.path.join(out, f"c{rank}.pt"))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("mode", ["ok", "prepare", "body"])
+def test_cached_stage_failures_on_rank_0_raise_on_every_rank(tmp_path, mode):
+    """Rank 0's filesystem work of the cache decorator (directory creation, tokens) sits inside the failure
+    exchange: when it raises (here: the cache root is a FILE), rank 1 raises too instead of waiting in the next
+    broadcast for ever."""
+    out = tmp_path / "out"
+    out.mkdir()
+    cache = tmp_path / "cache"
+    if mode == "prepare":
+        cache.write_text("not a directory")
+    mp.spawn(_cache_worker, args=(2, _free_port(), str(out), str(cache), mode), nprocs=2, join=True)
+    for r in range(2):
+        res = torch.load(out / f"c{r}.pt")
+        if mode == "ok":
+            assert os.path.exists(os.path.join(res["dirs"]["output_dir"], "result.success"))
+        else:
+            assert "error" in res and "rank 0" in res["error"], res

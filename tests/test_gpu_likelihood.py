@@ -223,6 +223,37 @@ def test_likelihood_single_site_model_with_100_states():
         dp_likelihood_computation(tree, msa, None, [1.0] * (L - 1) + [2.0], aa, pi, Q)
 
 
+@pytest.mark.parametrize("S", [40, 64])
+def test_likelihood_33_to_64_states_with_several_rate_categories(S):
+    """33 <= S <= 64 keeps several rate categories AND takes the shared counts-free bank handle of the large path: the
+    handle's capacity and the uploaded branch lengths are [category][node] (they were [node], so every
+    category but the first read an unwritten bank).  Single family and a ragged batch, against the oracle."""
+    from cherryml_amd.evaluation import dp_likelihood_computation, dp_likelihood_computation_batch
+    from oracle import likelihood_oracle as lo
+    rng = np.random.default_rng(4000 + S)
+    aa = [chr(48 + i) for i in range(S)]
+    assert "-" not in aa
+    pi = rng.dirichlet(np.full(S, 4.0))
+    sym = rng.uniform(0.1, 1.0, (S, S))
+    sym = np.triu(sym, 1) + np.triu(sym, 1).T
+    Q = sym * pi[None, :]
+    Q[np.diag_indices(S)] = -Q.sum(1)
+    Q /= -(pi * np.diag(Q)).sum()
+    trees, msas, rates = [], [], []
+    for n_leaves, L, n_rates in [(13, 11, 5), (4, 7, 1), (31, 23, 3)]:
+        tree, names = _random_tree(rng, n_leaves)
+        trees.append(tree), msas.append(_random_msa(rng, names, L, aa, gap=0.15))
+        rates.append(list(rng.choice(np.round(rng.uniform(0.1, 3.5, n_rates), 3), size=L)))
+    want = [lo.log_likelihood(trees[f], msas[f], None, rates[f], aa, pi, Q) for f in range(3)]
+    for reversible in (True, False):
+        got = dp_likelihood_computation_batch(trees, msas, [None] * 3, rates, aa, pi, Q, reversible)
+        for f in range(3):
+            assert np.allclose(got[f][1], want[f][1], rtol=RTOL, atol=1e-12), (reversible, f)
+            assert abs(got[f][0] - want[f][0]) <= RTOL * abs(want[f][0])
+            one = dp_likelihood_computation(trees[f], msas[f], None, rates[f], aa, pi, Q, reversible_1=reversible)
+            assert np.array_equal(np.array(one[1]), np.array(got[f][1])), (reversible, f)
+
+
 def test_likelihood_errors():
     from cherryml_amd.evaluation import dp_likelihood_computation, tree_likelihood
     z = load_golden("likelihood.npz")

@@ -208,6 +208,14 @@ def test_resumed_training_equals_one_call(dense):
         a = bank.train_pande_reversible(u0, p0, mask=mask, num_epochs=6, lr=0.1)
         with pytest.raises(ValueError):
             bank.train_pande_reversible(u0, p0, mask=None, num_epochs=3, lr=0.1, resume=True)
+        with pytest.raises(ValueError):   # another learning rate, other mask CONTENTS, another normalisation
+            bank.train_pande_reversible(u0, p0, mask=mask, num_epochs=3, lr=0.05, resume=True)
+        other = mask.copy()
+        other[0, 1] = other[1, 0] = 1.0 - other[0, 1]
+        with pytest.raises(ValueError):
+            bank.train_pande_reversible(u0, p0, mask=other, num_epochs=3, lr=0.1, resume=True)
+        with pytest.raises(ValueError):
+            bank.train_pande_reversible(u0, p0, mask=mask, num_epochs=3, lr=0.1, resume=True, normalize=False)
         b = bank.train_pande_reversible(u0 * 0, p0 * 0, mask=mask, num_epochs=5, lr=0.1, resume=True)   # (inputs ignored)
         c = bank.train_pande_reversible(u0, p0, mask=mask, num_epochs=4, lr=0.1, resume=True)
     assert np.array_equal(np.concatenate([a["loss"], b["loss"], c["loss"]]), whole["loss"])
