@@ -20,10 +20,17 @@ Workloads (BASELINE.json configs):
   counting  the stage that PRODUCES the LG bank: 1000 families x 64 cherries
             x 200 sites, step = one histogram pass over all cherries, inputs resident in HBM
 
-N > 1 (one process per GPU, torch.distributed/RCCL): coevo400 shards the buckets of ONE bank
-over the ranks and all-reduces (loss, dL/dA) each epoch -- strong scaling, `value` = the bank's
-pairs / epoch time; lg20 does not shard (replicas only); siterm shards the sites (no
-collective) -- weak scaling.
+  co_counting  the stage that PRODUCES the co-evolution bank (BASELINE config 5): 10,000 families x 64
+            cherries x ~65 contacting site pairs per GPU into the [129][400][400] histogram
+
+N > 1: `python bench.py --gpus N` started bare launches its own N rank processes (one per GPU,
+torch.distributed / RCCL; under torch.distributed.run it is one of the ranks); `n_gpus` is the process
+group's rank count and a mismatch with --gpus is an error.  coevo400 shards the buckets of ONE bank over
+the ranks and all-reduces (loss, dL/dA) each epoch -- STRONG scaling, `value` = the bank's pairs / epoch
+time, capped by the replicated eigensolver (the line's `amdahl` object); lg20 does not shard (replicas
+only).  The workloads that shard without a replicated term ride along as `secondary_siterm` (sites x N,
+no collective) and `secondary_co_counting` (families x N + the all-reduce of the integer counts): WEAK
+scaling, each with its own `value`, `scaling`, `roofline`.
 """
 import argparse
 import json
@@ -211,6 +218,64 @@ def cpu_baseline(wl, name):
                 sample=sample, seconds_per_epoch=dt)
 
 
+# -------------------------------------------------------------------- launcher
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def launch_ranks(n, argv, child=None, grace=15.0, poll=0.05):
+    """`python bench.py --gpus N` started bare (no WORLD_SIZE in the environment): THIS process touches no GPU (it
+    imports numpy only), starts N fresh rank processes of this script -- one per GPU, RANK / LOCAL_RANK / WORLD_SIZE /
+    MASTER_ADDR / MASTER_PORT in their environment, as `torch.distributed.run` would set them (the reference starts its
+    own ranks from inside the stage the same way: counting/_count_transitions.py:295-316, `mpirun -np N`) --, relays
+    rank 0's standard output (whose last line is the JSON line) and returns non-zero when any rank does.  A rank that
+    fails takes the others down after `grace` seconds (they may be waiting for it in a collective).  Never an exec:
+    the children are ordinary child processes.  `child` replaces the command (tests use a stub)."""
+    import subprocess
+    cmd = list(child) if child else [sys.executable, os.path.abspath(__file__)]
+    port = _free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), CB_BENCH_LAUNCHER="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC only on these hosts (RCCL across processes)
+        # rank 0's stdout is the result; the other ranks' stdout joins the launcher's stderr
+        procs.append(subprocess.Popen(cmd + list(argv), env=env, stdout=subprocess.PIPE if r == 0 else sys.stderr))
+    import threading
+    chunks = []
+    reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    codes = [None] * n
+    failed_at, first_bad = None, None
+    while any(c is None for c in codes):
+        for r, pr in enumerate(procs):
+            if codes[r] is None:
+                codes[r] = pr.poll()
+                if codes[r] not in (None, 0) and failed_at is None:
+                    failed_at, first_bad = time.time(), codes[r]
+                    print(f"bench launcher: rank {r} exited with code {codes[r]}", file=sys.stderr)
+        if failed_at is not None and time.time() - failed_at > grace:
+            for r, pr in enumerate(procs):   # exactly the processes started above
+                if codes[r] is None:
+                    pr.kill()
+                    codes[r] = pr.wait()
+                    print(f"bench launcher: rank {r} killed after rank failure", file=sys.stderr)
+        time.sleep(poll)
+    reader.join(timeout=5.0)
+    out = (chunks[0] if chunks else b"").decode(errors="replace")
+    if first_bad is not None:
+        sys.stderr.write(out)   # no result line on stdout from a failed job
+        return first_bad if 0 < first_bad < 256 else 1
+    sys.stdout.write(out)
+    sys.stdout.flush()
+    return 0
+
+
 # ------------------------------------------------------------------------ main
 def main():
     ap = argparse.ArgumentParser()
@@ -218,7 +283,8 @@ def main():
     ap.add_argument("--steps", type=int, default=None)
     ap.add_argument("--warmup", type=int, default=None)
     ap.add_argument("--workload", default="coevo400",
-                    choices=["coevo400", "coevo400_demo", "lg20", "siterm", "counting", "ble", "assembly", "likelihood"])
+                    choices=["coevo400", "coevo400_demo", "lg20", "siterm", "counting", "co_counting", "ble", "assembly",
+                             "likelihood"])
     ap.add_argument("--sites", type=int, default=5000)
     ap.add_argument("--dtype", default="f64", choices=["f64", "f32", "mixed"],
                     help="element type of the bank products (coevo400 only): f32 = float32 MFMA (cb_create dtype CB_F32)")
@@ -231,18 +297,36 @@ def main():
                          "torch.distributed instead of the C-driven loop with the in-library ncclAllReduce")
     args = ap.parse_args()
 
-    import torch
-    import torch.distributed as dist
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
+        # started bare: be the launcher (no torch import, no GPU touched in this process)
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
+
+    def refuse(found, what):
+        # a line that says n_gpus = N must have run on N ranks: refuse (on every rank) instead of warning
+        print(f"bench.py: --gpus {args.gpus} but {what} has {found} rank(s); start it bare (`python bench.py --gpus N` "
+              "launches its own ranks) or under torch.distributed.run with --nproc-per-node equal to --gpus", file=sys.stderr)
+        sys.exit(2)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        refuse(world, "the environment (WORLD_SIZE)")
+
+    import torch
+    import torch.distributed as dist
+
     if world > 1 or args.force_sharded:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world)
-    if args.gpus != world and rank == 0 and world > 1:
-        print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
+        if dist.get_world_size() != args.gpus:   # n_gpus in the line = the communicator's rank count
+            n_found = dist.get_world_size()
+            dist.destroy_process_group()
+            refuse(n_found, "the process group")
+        world = dist.get_world_size()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
@@ -449,6 +533,20 @@ def main():
             "phase_ms": {k: round(v, 4) for k, v in tm.items()},
             "final_loss": final_loss,
         }
+        if S > 32:
+            # the Amdahl arithmetic of sharding ONE bank over ranks: the eigensolver and K4 run on the
+            # whole matrix on every rank, K1-K3 on the rank's buckets only; `other` = theta -> A, parameter kernels,
+            # the all-reduce (N > 1) and launch gaps
+            rep, shd = tm["eigh"] + tm["k4"], tm["k1"] + tm["k2"] + tm["k3"]
+            other = max(dt / steps * 1e3 - tm["total"], 0.0)
+            out["amdahl"] = {
+                "replicated_ms": round(rep, 4), "sharded_ms": round(shd, 4), "other_ms": round(other, 4),
+                "measured_on_ranks": world,
+                "note": "per epoch on rank 0: replicated = eigensolver + K4 (every rank, whole matrix), sharded = K1 + K2 + K3 "
+                        "(this rank's buckets), other = theta->A, parameter kernels, all-reduce, gaps",
+                **({"projected_speedup_at_8": round((rep + shd + other) / (rep + shd / 8.0 + other), 2),
+                    "projection": "(replicated + sharded + other) / (replicated + sharded / 8 + other), all-reduce not "
+                                  "included: an upper bound for one bank on 8 GPUs"} if world == 1 else {})}
         if with_cpu:
             out["cpu_baseline"] = cpu_baseline(wl, workload)
         bank.close()
@@ -468,7 +566,7 @@ def main():
             sys.stdout.write(json.dumps(out) + "\n")
             sys.stdout.flush()
 
-    defaults = {"coevo400": (200, 5), "coevo400_demo": (200, 5), "lg20": (500, 50), "siterm": (100, 2), "counting": (20, 3), "ble": (5, 1), "assembly": (5, 1),
+    defaults = {"co_counting": (10, 2), "coevo400": (200, 5), "coevo400_demo": (200, 5), "lg20": (500, 50), "siterm": (100, 2), "counting": (20, 3), "ble": (5, 1), "assembly": (5, 1),
                 "likelihood": (5, 1)}
     steps = args.steps if args.steps is not None else defaults[args.workload][0]
     warmup = args.warmup if args.warmup is not None else defaults[args.workload][1]
@@ -481,18 +579,32 @@ def main():
     if args.workload == "ble":
         finish(run_ble(steps, warmup, world, rank, local_rank, fence, world == 1 and not args.no_cpu_baseline))
         return
+    if args.workload == "co_counting":
+        finish(run_co_counting(steps, warmup, world, rank, local_rank, fence, world == 1 and not args.no_cpu_baseline))
+        return
     if args.workload == "counting":
         out = run_counting(steps, warmup, world, rank, local_rank, fence,
                            world == 1 and not args.no_cpu_baseline)
         finish(out)
         return
     out = run(args.workload, steps, warmup, world == 1 and not args.no_cpu_baseline)
-    if rank == 0 and world == 1 and args.workload == "coevo400" and not args.no_secondary:
-        # BASELINE.json's metric names both sizes: the line always carries the 20x20 LG configuration
-        # too (its own epoch counts: an LG epoch takes 0.09 ms)
-        sec = run("lg20", *defaults["lg20"], not args.no_cpu_baseline)
-        out["secondary"] = {k: sec[k] for k in ("value", "unit", "ms_per_step", "steps", "config",
-                                                "roofline", "cpu_baseline") if k in sec}
+    keep = ("value", "unit", "n_gpus", "scaling", "ms_per_step", "steps", "warmup", "dtype", "config", "roofline",
+            "cpu_baseline", "phase_ms")
+    if args.workload == "coevo400" and not args.no_secondary:
+        # every rank takes part (the multi-rank runs end in collectives); rank 0 attaches the lines
+        extra = {}
+        if world == 1:
+            # BASELINE.json's metric names both sizes: the line always carries the 20x20 LG configuration
+            # too (its own epoch counts: an LG epoch takes < 0.1 ms)
+            extra["secondary"] = run("lg20", *defaults["lg20"], not args.no_cpu_baseline)
+        # BASELINE.json configs 4 and 5 -- the workloads that shard WITHOUT a replicated term (weak scaling):
+        # SiteRM (sites x N, no collective) and co-transition counting (families x N + one integer all-reduce)
+        extra["secondary_siterm"] = run("siterm", *defaults["siterm"], world == 1 and not args.no_cpu_baseline)
+        extra["secondary_co_counting"] = run_co_counting(*defaults["co_counting"], world, rank, local_rank, fence,
+                                                         world == 1 and not args.no_cpu_baseline)
+        if rank == 0:
+            for name, sec in extra.items():
+                out[name] = {k: sec[k] for k in keep if k in sec}
     finish(out)
 
 
@@ -599,6 +711,140 @@ def run_counting(steps, warmup, world, rank, local_rank, fence, with_cpu):
         out["cpu_baseline"] = {"value": float(C.sum()) / cdt, "unit": "cherry-pairs/s", "cores": 1,
                                "kind": "port", "sample": f"{npairs} of {len(pairs)} cherries x {L} sites, "
                                "the oracle's per-site loop (the reference's Python counter)"}
+    return out
+
+
+def make_co_counting_input(rng, F, NCH=64, L=200):
+    """A config-5-shaped synthetic input (BASELINE.json: co-evolution, 10k families, family-sharded): F families of NCH
+    cherries (2 NCH leaves) x L sites, 20 letters, per family a set of disjoint contacting site pairs >= 7 apart (what
+    the reference's maximal matching of a contact map leaves: _maximal_matching.py:70-93), cherry lengths ~ 2 Exp(0.2)."""
+    from cherryml_amd.counting._stage import PAIR_DTYPE
+    S = 20
+    seqs = rng.integers(0, S, size=(F, 2 * NCH, L), dtype=np.int8)
+    same = rng.integers(0, 10, size=(F, NCH, L), dtype=np.int8) < 7     # the leaves of a cherry mostly agree (70 %)
+    np.copyto(seqs[:, 1::2], seqs[:, 0::2], where=same)
+    del same
+    np.copyto(seqs, np.int8(-1), where=rng.integers(0, 20, size=seqs.shape, dtype=np.int8) < 1)   # 5 % gaps
+    perm = np.argsort(rng.random((F, L)), axis=1).astype(np.int32).reshape(F, L // 2, 2)
+    perm.sort(axis=2)
+    ok = perm[:, :, 1] - perm[:, :, 0] >= 7
+    want = rng.integers(40, 90, size=F)
+    ok &= np.cumsum(ok, axis=1) <= want[:, None]
+    n_c = ok.sum(axis=1)
+    contacts = perm[ok].reshape(-1)                           # family-major, [sum n_c][2]
+    c_off = np.concatenate([[0], np.cumsum(n_c)[:-1]])
+    pairs = np.zeros(F * NCH, dtype=PAIR_DTYPE)
+    fam = np.repeat(np.arange(F), NCH)
+    ch = np.tile(np.arange(NCH), F)
+    pairs["seq_a"] = (fam * 2 * NCH + 2 * ch) * L
+    pairs["seq_b"] = (fam * 2 * NCH + 2 * ch + 1) * L
+    pairs["aux"] = c_off[fam]
+    pairs["n"] = n_c[fam]
+    pairs["len_a"] = rng.exponential(0.2, size=F * NCH)
+    pairs["len_b"] = rng.exponential(0.2, size=F * NCH)
+    return S, seqs.reshape(-1), contacts.astype(np.int32), pairs, int(n_c.max())
+
+
+def run_co_counting(steps, warmup, world, rank, local_rank, fence, with_cpu, families=10000):
+    """cb_count_co_transitions on a config-5-shaped synthetic input: `families` families x 64 cherries x ~65 contacting
+    site pairs PER RANK (families shard over the ranks exactly as the reference's MPI ranks take them,
+    _count_co_transitions.cpp:626-628), a step = one pass over this rank's families into the resident
+    [129][400][400] 8-byte histogram (165 MB) and, at N > 1, the all-reduce of those integer counts (what one EM
+    iteration exchanges: the summed sufficient statistics).  Weak scaling."""
+    import torch
+    import torch.distributed as dist
+    from cherryml_amd import _lib
+
+    rng = np.random.default_rng(11 + rank)
+    grid = quantization_grid()
+    B = grid.size
+    S, seqs, contacts, pairs, max_n = make_co_counting_input(rng, families)
+    S2 = S * S
+    dev = torch.device("cuda", local_rank)
+    d_seqs = torch.from_numpy(seqs).to(dev)
+    d_contacts = torch.from_numpy(contacts).to(dev)
+    d_grid = torch.from_numpy(grid).to(dev)
+    d_pairs = torch.from_numpy(pairs.view(np.uint8)).to(dev)
+    d_counts = torch.zeros(B * S2 * S2, dtype=torch.int64, device=dev)
+    lib = _lib.load()
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+
+    def step(timed=False):
+        d_counts.zero_()
+        if timed:
+            ev[0].record()
+        rc = lib.cb_count_co_transitions(local_rank, S, B, d_grid.data_ptr(), d_seqs.data_ptr(), d_seqs.numel(),
+                                         d_contacts.data_ptr(), d_contacts.numel() // 2, d_pairs.data_ptr(), len(pairs), 1,
+                                         _lib.CB_PTR_DEVICE | (max_n << 8), d_counts.data_ptr())
+        _lib.check(rc, "cb_count_co_transitions")
+        if timed:
+            ev[1].record()
+        if world > 1:
+            dist.all_reduce(d_counts, op=dist.ReduceOp.SUM)
+        if timed:
+            ev[2].record()
+
+    for _ in range(warmup):
+        step()
+    fence()
+    kms, ams = [], []
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step(True)
+        torch.cuda.synchronize()
+        kms.append(ev[0].elapsed_time(ev[1]))
+        ams.append(ev[1].elapsed_time(ev[2]))
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tdt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tdt, op=dist.ReduceOp.MAX)
+        dt = float(tdt.item())
+    if rank != 0:
+        return None
+    counted = float(d_counts.sum().item()) * 0.25            # all ranks' (cherry, contact) events after the all-reduce
+    kernel_ms = float(np.mean(kms))
+    n_events = int(pairs["n"].sum())
+    # algorithmic bytes of one pass (this rank): every leaf sequence once, the pair records, the contact lists, and the
+    # count tensor cleared and written once (the reference's C++ keeps the same dense [B][400][400] tensor per rank)
+    nbytes = float(seqs.nbytes + pairs.nbytes + contacts.nbytes + 2 * B * S2 * S2 * 8)
+    achieved = nbytes / (kernel_ms * 1e-3) / 1e9
+    out = {
+        "metric": "cherry-pairs/sec (whole node): cherry x contacting-site-pair events counted per pass",
+        "value": counted / (dt / steps), "unit": "cherry-pairs/s", "n_gpus": world, "steps": steps, "warmup": warmup,
+        "ms_per_step": dt / steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "i8/u64", "data": "synthetic",
+        "config": {"workload": f"co-transition counting: {families} families x 64 cherries x {n_events / len(pairs):.0f} "
+                               "contacting site pairs per GPU, 20 letters (400 pair states), B=129, cherry mode",
+                   "states": S2, "buckets": B,
+                   "sharding": f"families x{world}" + (", all-reduce of the 165 MB integer count tensor per pass" if world > 1
+                                                       else " (no collective)")},
+        "roofline": {"bound": "hbm", "kernel": "co_bucket + co_plan + co_expand + co_count_lds (one pass)", "achieved": achieved,
+                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "ms_per_launch": kernel_ms, "bytes_per_launch": nbytes,
+                     "note": "events binned by bucket, 100-row x 400-column LDS histograms per (bucket, row block, event "
+                             "chunk), non-zero bins added to the 8-byte global bins once; time excludes the clear"},
+        "phase_ms": {"count": kernel_ms, "allreduce": float(np.mean(ams))},
+        "counted_events": counted,
+    }
+    if with_cpu:
+        from oracle import counting_oracle as co
+        npairs = 40
+        codes = seqs.astype(np.int64)
+        t0 = time.perf_counter()
+        C = np.zeros((B, S2, S2))
+        for p in pairs[:npairs]:
+            q = co.quantization_idx(float(p["len_a"] + p["len_b"]), grid)
+            if q is None:
+                continue
+            L = 200
+            ij = contacts[2 * p["aux"]: 2 * (p["aux"] + p["n"])].reshape(-1, 2).tolist()
+            co.co_count_pair(C[q], codes[p["seq_a"]: p["seq_a"] + L].tolist(), codes[p["seq_b"]: p["seq_b"] + L].tolist(),
+                             ij, S, True)
+        cdt = time.perf_counter() - t0
+        out["cpu_baseline"] = {"value": float(C.sum()) / cdt, "unit": "cherry-pairs/s", "cores": 1, "kind": "port",
+                               "sample": f"{npairs} of {len(pairs)} cherries, the oracle's per-contact loop (the reference's "
+                                         "Python counter, _count_co_transitions.py:108-140)"}
     return out
 
 

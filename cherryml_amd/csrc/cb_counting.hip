@@ -61,6 +61,92 @@ static int launch_count_transitions(int device, int S, int B, const double *grid
   return CB_OK;
 }
 
+// device-pointer launch of the co-transition counter: adds into counts[B * S^2 * S^2] (see counting.hip.h).
+// total_events = sum of pair.n when the caller knows it, else max_n (largest pair.n) bounds it; with neither the
+// event total is read back from the device after the first kernel (one synchronisation).
+static int launch_count_co_transitions(int device, int S, int B, const double *grid, const int8_t *seqs,
+                                       const int32_t *contacts, const cb_count_pair *pairs, int64_t n_pairs,
+                                       int symmetric, int64_t total_events, int max_n,
+                                       unsigned long long *counts) {
+  const int S2 = S * S;
+  const int R = std::min(S2, CO_LDS_WORDS / S2);
+  if (R < 1 || (size_t)2 * B * 8 + CO_THREADS * 8 > 150 * 1024) {   // S > 200 or an enormous grid: the plain atomic form
+    const unsigned blocks = (unsigned)((n_pairs + 3) / 4);
+    hipLaunchKernelGGL(count_co_transitions_kernel, dim3(blocks), dim3(256), 0, 0, S, B, grid, seqs, contacts, pairs,
+                       (long long)n_pairs, symmetric, counts);
+    HIP_TRY(hipGetLastError());
+    return CB_OK;
+  }
+  if (reinterpret_cast<uintptr_t>(contacts) & 7) return fail(CB_EINVAL, "cb_count_co_transitions: the contact list must be 8-byte aligned");
+  const int nrb = (S2 + R - 1) / R;
+  const int target = 2048;
+  const int max_work = target + (B + 8) * nrb;
+  const unsigned pair_blocks = (unsigned)((n_pairs + CO_THREADS - 1) / CO_THREADS);
+  // scratch layout (8-byte words): bucket_ev[B] cursor[B] | bucket_off[B+1] n_work[1] work[4 * max_work] qbuf events
+  const size_t head = (size_t)2 * B, fixed = head + (B + 1) + 1 + (size_t)4 * max_work + ((size_t)n_pairs + 1) / 2;
+  unsigned long long *scr = nullptr;
+  int rc = count_scratch(device, fixed, &scr);
+  if (rc != CB_OK) return rc;
+  HIP_TRY(hipMemsetAsync(scr, 0, head * sizeof(unsigned long long), 0));
+  auto carve = [&](unsigned long long *base) {
+    struct { unsigned long long *bucket_ev, *cursor, *bucket_off; int *n_work; CoWork *work; int *qbuf; unsigned *events; } w;
+    w.bucket_ev = base;
+    w.cursor = base + B;
+    w.bucket_off = base + head;
+    w.n_work = reinterpret_cast<int *>(base + head + B + 1);
+    w.work = reinterpret_cast<CoWork *>(base + head + B + 2);
+    w.qbuf = reinterpret_cast<int *>(base + head + B + 2 + (size_t)4 * max_work);
+    w.events = reinterpret_cast<unsigned *>(base + fixed);
+    return w;
+  };
+  auto w = carve(scr);
+  hipLaunchKernelGGL(co_bucket_kernel, dim3(pair_blocks), dim3(CO_THREADS), (size_t)B * 8, 0, B, grid, pairs,
+                     (long long)n_pairs, w.qbuf, w.bucket_ev);
+  hipLaunchKernelGGL(co_plan_kernel, dim3(1), dim3(256), (size_t)2 * B * 8, 0, B, nrb, target, max_work, w.bucket_ev,
+                     w.bucket_off, w.work, w.n_work);
+  HIP_TRY(hipGetLastError());
+  if (total_events < 0) {
+    if (max_n > 0) total_events = n_pairs * (int64_t)max_n;
+    else {
+      unsigned long long tot = 0;
+      HIP_TRY(hipMemcpy(&tot, w.bucket_off + B, sizeof tot, hipMemcpyDeviceToHost));
+      total_events = (int64_t)tot;
+    }
+  }
+  if (total_events == 0) return CB_OK;
+  // the event array behind the fixed part: growing the scratch would move (and lose) the part already filled, so the
+  // scratch is grown FIRST when it is too small and the two kernels above are simply run again
+  const size_t need = fixed + ((size_t)total_events + 1) / 2 + 1;
+  unsigned long long *scr2 = nullptr;
+  rc = count_scratch(device, need, &scr2);
+  if (rc != CB_OK) return rc;
+  if (scr2 != scr) {
+    scr = scr2;
+    w = carve(scr);
+    HIP_TRY(hipMemsetAsync(scr, 0, head * sizeof(unsigned long long), 0));
+    hipLaunchKernelGGL(co_bucket_kernel, dim3(pair_blocks), dim3(CO_THREADS), (size_t)B * 8, 0, B, grid, pairs,
+                       (long long)n_pairs, w.qbuf, w.bucket_ev);
+    hipLaunchKernelGGL(co_plan_kernel, dim3(1), dim3(256), (size_t)2 * B * 8, 0, B, nrb, target, max_work, w.bucket_ev,
+                       w.bucket_off, w.work, w.n_work);
+  }
+  hipLaunchKernelGGL(co_expand_kernel, dim3(pair_blocks), dim3(CO_THREADS), (size_t)(B + CO_THREADS) * 8, 0, B, seqs,
+                     contacts, pairs, (long long)n_pairs, w.qbuf, w.bucket_off, w.cursor, w.events);
+  const size_t lds = (size_t)R * S2 * sizeof(unsigned);
+  if (symmetric) {
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(co_count_lds_kernel<true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(co_count_lds_kernel<true>, dim3(max_work), dim3(CO_THREADS), lds, 0, S, R, w.events, w.work,
+                       w.n_work, counts);
+  } else {
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(co_count_lds_kernel<false>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(co_count_lds_kernel<false>, dim3(max_work), dim3(CO_THREADS), lds, 0, S, R, w.events, w.work,
+                       w.n_work, counts);
+  }
+  HIP_TRY(hipGetLastError());
+  return CB_OK;
+}
+
 static int count_common(int device, int S, int B, const double *grid, const int8_t *seqs,
                         int64_t seqs_bytes, const void *aux, size_t aux_bytes,
                         const cb_count_pair *pairs, int64_t n_pairs, int symmetric, int flags,
@@ -71,10 +157,13 @@ static int count_common(int device, int S, int B, const double *grid, const int8
     HIP_TRY(hipSetDevice(device));
     if (n_pairs > 0) {
       const unsigned blocks = (unsigned)((n_pairs + 3) / 4);
-      if (co)
-        hipLaunchKernelGGL(count_co_transitions_kernel, dim3(blocks), dim3(256), 0, 0, S, B, grid, seqs,
-                           (const int32_t *)aux, pairs, (long long)n_pairs, symmetric, counts);
-      else {
+      (void)blocks;
+      if (co) {
+        // resident form: the caller states the largest pair.n in flags bits 8..23 (0 = unknown: one read-back)
+        int rc = launch_count_co_transitions(device, S, B, grid, seqs, (const int32_t *)aux, pairs, n_pairs, symmetric,
+                                             -1, (flags >> 8) & 0xFFFF, counts);
+        if (rc != CB_OK) return rc;
+      } else {
         // resident form: the caller states the largest pair.n in flags bits 8..23 (0 = unknown)
         int rc = launch_count_transitions(device, S, B, grid, seqs, (const double *)aux, pairs, n_pairs,
                                           symmetric, (flags >> 8) & 0xFFFF, counts);
@@ -127,11 +216,12 @@ static int count_common(int device, int S, int B, const double *grid, const int8
   if (n_pairs > 0) TRYC(hipMemcpy(d_pairs, pairs, n_pairs * sizeof(cb_count_pair), hipMemcpyHostToDevice));
   TRYC(hipMemset(d_counts, 0, nbins * sizeof(unsigned long long)));
   if (rc == CB_OK && n_pairs > 0) {
-    const unsigned blocks = (unsigned)((n_pairs + 3) / 4);
-    if (co)
-      hipLaunchKernelGGL(count_co_transitions_kernel, dim3(blocks), dim3(256), 0, 0, S, B, d_grid, d_seqs,
-                         (const int32_t *)d_aux, d_pairs, (long long)n_pairs, symmetric, d_counts);
-    else {
+    if (co) {
+      int64_t total_events = 0;
+      for (int64_t p = 0; p < n_pairs; ++p) total_events += pairs[p].n > 0 ? pairs[p].n : 0;
+      rc = launch_count_co_transitions(device, S, B, d_grid, d_seqs, (const int32_t *)d_aux, d_pairs, n_pairs, symmetric,
+                                       total_events, 0, d_counts);
+    } else {
       int max_sites = 0;
       for (int64_t p = 0; p < n_pairs; ++p) max_sites = pairs[p].n > max_sites ? pairs[p].n : max_sites;
       if (rc == CB_OK)

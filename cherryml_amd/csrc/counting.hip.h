@@ -258,6 +258,237 @@ __global__ __launch_bounds__(256) void count_co_transitions_kernel(
   }
 }
 
+// ---- co-transitions, binned by bucket and privatised in LDS (reference _count_co_transitions.cpp:359-381) ------
+// The histogram is [B][S^2][S^2] (165 MB of 8-byte bins at 20 letters, 129 buckets): far beyond LDS, and scattered
+// 8-byte global atomics run in the guide's "64 lanes -> 64 rows" regime (0.08 TB/s).  The quantised length is a property
+// of the PAIR, so the pass is organised by bucket:
+//   co_bucket_kernel   q(pair) and the number of (pair, contact) events per bucket
+//   co_plan_kernel     bucket offsets into ONE flat event array and the work list: (bucket, row block, event range)
+//   co_expand_kernel   every event as 4 state codes in one 32-bit word (a_i, a_j, b_i, b_j; 0xFFFFFFFF = a gap), written
+//                      to its bucket's range -- the only kernel that chases pair -> contacts -> sequence bytes
+//   co_count_lds_kernel one workgroup per work item: R rows x S^2 columns of 32-bit bins in LDS (100 x 400 at 20 letters
+//                      = 160,000 B), streams its event range (4 bytes per event, coalesced), adds the increments that
+//                      fall into its rows, and adds its non-zero bins to the 8-byte global bins once (contiguous
+//                      lanes -> contiguous addresses).  Integers throughout: bit-exact, order-independent.
+#define CO_THREADS 1024
+#define CO_LDS_WORDS 40000           // 160,000 B of the 163,840 a workgroup may declare
+#define CO_EVENT_GAP 0xFFFFFFFFu
+
+struct CoWork {
+  int q, rb;               // bucket, row block (q < 0: an empty slot)
+  int single, pad;         // the only chunk of its bucket: plain adds instead of atomics on the flush
+  unsigned long long e0, e1;   // event range
+};
+
+__global__ __launch_bounds__(CO_THREADS) void co_bucket_kernel(int B, const double *__restrict__ grid,
+                                                               const cb_count_pair *__restrict__ pairs, long long n_pairs,
+                                                               int *__restrict__ qbuf,
+                                                               unsigned long long *__restrict__ bucket_ev) {
+  extern __shared__ unsigned long long co_ev[];   // [B]
+  for (int b = threadIdx.x; b < B; b += CO_THREADS) co_ev[b] = 0ull;
+  __syncthreads();
+  const long long p = (long long)blockIdx.x * CO_THREADS + threadIdx.x;
+  if (p < n_pairs) {
+    const cb_count_pair pr = pairs[p];
+    int q = cnt_quantize(pr.len_a + pr.len_b, grid, B);
+    if (pr.n <= 0) q = -1;
+    qbuf[p] = q;
+    if (q >= 0) atomicAdd(&co_ev[q], (unsigned long long)pr.n);
+  }
+  __syncthreads();
+  for (int b = threadIdx.x; b < B; b += CO_THREADS)
+    if (co_ev[b]) atomicAdd(&bucket_ev[b], co_ev[b]);
+}
+
+// one workgroup.  Chunks of a bucket's event range are sized so that the whole pass has about `target` work items;
+// the row blocks of one chunk are `stride` slots apart inside a group of stride * nrb slots (stride = 8 = number of
+// XCDs: consecutive workgroup ids go round the XCDs, so the nrb readers of one event range share an L2).
+__global__ __launch_bounds__(256) void co_plan_kernel(int B, int nrb, int target, int max_work,
+                                                      const unsigned long long *__restrict__ bucket_ev,
+                                                      unsigned long long *__restrict__ bucket_off,
+                                                      CoWork *__restrict__ work, int *__restrict__ n_work) {
+  extern __shared__ unsigned long long co_plan[];   // [B] event offsets, then [B] first chunk id (as u64)
+  unsigned long long *ev_off = co_plan, *first = co_plan + B;
+  __shared__ unsigned long long chunk_s;
+  __shared__ int total_chunks;
+  if (threadIdx.x == 0) {
+    unsigned long long off = 0;
+    for (int b = 0; b < B; ++b) {
+      ev_off[b] = off;
+      bucket_off[b] = off;
+      off += bucket_ev[b];
+    }
+    bucket_off[B] = off;
+    unsigned long long chunk = (off * (unsigned long long)nrb + target - 1) / (unsigned long long)target;
+    if (chunk < 16384ull) chunk = 16384ull;
+    chunk_s = chunk;
+    int k = 0;
+    for (int b = 0; b < B; ++b) {
+      first[b] = (unsigned long long)k;
+      k += (int)((bucket_ev[b] + chunk - 1) / chunk);
+    }
+    total_chunks = k;
+    const int groups = (k + 7) / 8;
+    n_work[0] = groups * 8 * nrb <= max_work ? groups * 8 * nrb : 0;   // (cannot exceed: max_work is the bound below)
+  }
+  __syncthreads();
+  const unsigned long long chunk = chunk_s;
+  const int slots = (total_chunks + 7) / 8 * 8 * nrb;
+  if (slots > max_work) return;
+  for (int i = threadIdx.x; i < slots; i += 256) work[i].q = -1;   // holes of the last group
+  __syncthreads();
+  for (int b = threadIdx.x; b < B; b += 256) {
+    const unsigned long long n = bucket_ev[b];
+    if (!n) continue;
+    const int nch = (int)((n + chunk - 1) / chunk);
+    const unsigned long long per = (n + nch - 1) / nch;
+    for (int c = 0; c < nch; ++c) {
+      const int cid = (int)first[b] + c;
+      const unsigned long long e0 = ev_off[b] + (unsigned long long)c * per;
+      unsigned long long e1 = e0 + per;
+      if (e1 > ev_off[b] + n) e1 = ev_off[b] + n;
+      for (int rb = 0; rb < nrb; ++rb) {
+        CoWork w;
+        w.q = b; w.rb = rb; w.single = nch == 1; w.pad = 0; w.e0 = e0; w.e1 = e1;
+        work[(cid / 8) * 8 * nrb + rb * 8 + (cid & 7)] = w;
+      }
+    }
+  }
+}
+
+// thread = pair for the offsets (two-level: LDS counters per bucket inside the workgroup, one returning global add per
+// (workgroup, non-empty bucket)), then wave = pair for the events, four pairs in flight per wave.
+__global__ __launch_bounds__(CO_THREADS) void co_expand_kernel(
+    int B, const int8_t *__restrict__ seqs, const int32_t *__restrict__ contacts,
+    const cb_count_pair *__restrict__ pairs, long long n_pairs, const int *__restrict__ qbuf,
+    const unsigned long long *__restrict__ bucket_off, unsigned long long *__restrict__ cursor,
+    unsigned *__restrict__ events) {
+  extern __shared__ unsigned long long co_x[];   // [B] counters / bases, then [CO_THREADS] event offset of each pair
+  unsigned long long *cnt = co_x, *off_l = co_x + B;
+  for (int b = threadIdx.x; b < B; b += CO_THREADS) cnt[b] = 0ull;
+  __syncthreads();
+  const long long pb = (long long)blockIdx.x * CO_THREADS;
+  const long long p = pb + threadIdx.x;
+  int q = -1;
+  unsigned long long local = 0;
+  if (p < n_pairs) {
+    q = qbuf[p];
+    if (q >= 0) local = atomicAdd(&cnt[q], (unsigned long long)pairs[p].n);
+  }
+  __syncthreads();
+  for (int b = threadIdx.x; b < B; b += CO_THREADS) {
+    const unsigned long long c = cnt[b];
+    if (c) cnt[b] = bucket_off[b] + atomicAdd(&cursor[b], c);
+  }
+  __syncthreads();
+  off_l[threadIdx.x] = q >= 0 ? cnt[q] + local : ~0ull;
+  __syncthreads();
+  const int lane = threadIdx.x & 63, w0 = (threadIdx.x >> 6) * 64;
+  auto emit = [&](const cb_count_pair &pr, unsigned long long base, int c) {
+    const int2 ij = *reinterpret_cast<const int2 *>(contacts + 2 * ((size_t)pr.aux + c));
+    const int8_t *sa = seqs + pr.seq_a, *sb = seqs + pr.seq_b;
+    const int ai = sa[ij.x], aj = sa[ij.y], bi = sb[ij.x], bj = sb[ij.y];
+    const bool gap = (ai | aj | bi | bj) < 0;
+    events[base + c] = gap ? CO_EVENT_GAP : ((unsigned)ai | (unsigned)aj << 8 | (unsigned)bi << 16 | (unsigned)bj << 24);
+  };
+  for (int k0 = 0; k0 < 64; k0 += 4) {
+    cb_count_pair pr[4];
+    unsigned long long base[4];
+    bool on[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const long long pp = pb + w0 + k0 + u;
+      base[u] = off_l[w0 + k0 + u];
+      on[u] = pp < n_pairs && base[u] != ~0ull;
+      pr[u] = pairs[on[u] ? pp : 0];
+    }
+    // the first 64 contacts of the four pairs together (independent load chains), the rest pair by pair
+    int2 ij[4];
+    int code[4][4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int c = on[u] && lane < pr[u].n ? lane : 0;
+      ij[u] = on[u] && pr[u].n > 0 ? *reinterpret_cast<const int2 *>(contacts + 2 * ((size_t)pr[u].aux + c)) : make_int2(0, 0);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int8_t *sa = seqs + (on[u] ? pr[u].seq_a : 0), *sb = seqs + (on[u] ? pr[u].seq_b : 0);
+      code[u][0] = sa[ij[u].x];
+      code[u][1] = sa[ij[u].y];
+      code[u][2] = sb[ij[u].x];
+      code[u][3] = sb[ij[u].y];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      if (on[u] && lane < pr[u].n) {
+        const bool gap = (code[u][0] | code[u][1] | code[u][2] | code[u][3]) < 0;
+        events[base[u] + lane] = gap ? CO_EVENT_GAP
+                                     : ((unsigned)code[u][0] | (unsigned)code[u][1] << 8 | (unsigned)code[u][2] << 16 |
+                                        (unsigned)code[u][3] << 24);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (on[u])
+        for (int c = 64 + lane; c < pr[u].n; c += 64) emit(pr[u], base[u], c);
+  }
+}
+
+template <bool SYM>
+__global__ __launch_bounds__(CO_THREADS) void co_count_lds_kernel(int S, int R, const unsigned *__restrict__ events,
+                                                                  const CoWork *__restrict__ work,
+                                                                  const int *__restrict__ n_work,
+                                                                  unsigned long long *__restrict__ counts) {
+  extern __shared__ unsigned co_hist[];   // [rows][S^2]
+  if ((int)blockIdx.x >= n_work[0]) return;
+  const CoWork w = work[blockIdx.x];
+  if (w.q < 0) return;
+  const int S2 = S * S;
+  const int r0 = w.rb * R;
+  const int rows = R < S2 - r0 ? R : S2 - r0;
+  const int nb = rows * S2;
+  for (int i = threadIdx.x; i < nb; i += CO_THREADS) co_hist[i] = 0u;
+  __syncthreads();
+  const unsigned urows = (unsigned)rows;
+  auto add = [&](int row, int col) {
+    const unsigned rr = (unsigned)(row - r0);
+    if (rr < urows) atomicAdd(&co_hist[rr * S2 + col], 1u);
+  };
+  for (unsigned long long e = w.e0 + threadIdx.x; e < w.e1; e += 4ull * CO_THREADS) {
+    unsigned ev[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const unsigned long long eu = e + (unsigned long long)u * CO_THREADS;
+      ev[u] = eu < w.e1 ? events[eu] : CO_EVENT_GAP;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      if (ev[u] == CO_EVENT_GAP) continue;
+      const int ai = ev[u] & 0xFF, aj = (ev[u] >> 8) & 0xFF, bi = (ev[u] >> 16) & 0xFF, bj = ev[u] >> 24;
+      const int s1 = ai * S + aj, s1r = aj * S + ai, s2 = bi * S + bj, s2r = bj * S + bi;
+      add(s1, s2);
+      add(s1r, s2r);
+      if (SYM) {
+        add(s2, s1);
+        add(s2r, s1r);
+      }
+    }
+  }
+  __syncthreads();
+  unsigned long long *dst = counts + ((size_t)w.q * S2 + r0) * S2;
+  if (w.single) {
+    for (int i = threadIdx.x; i < nb; i += CO_THREADS) {
+      const unsigned v = co_hist[i];
+      if (v) dst[i] += v;
+    }
+  } else {
+    for (int i = threadIdx.x; i < nb; i += CO_THREADS) {
+      const unsigned v = co_hist[i];
+      if (v) atomicAdd(&dst[i], (unsigned long long)v);
+    }
+  }
+}
+
 // ---- SiteRM count / pseudocount assembly (reference _siterm/_site_specific_rate_matrix.py) ------
 // raw[l][b][x][y] += 1 for every transition whose total length quantises to bucket b and whose
 // two sequences carry states (x, y) at site l (:226-256).  One wavefront per transition, lanes

@@ -91,6 +91,14 @@ class RcclCommunicator:
         self.comm = comm.value
         self.allreduce_fn = C.cast(rccl.ncclAllReduce, C.c_void_p).value
         self.rank, self.world = rank, world
+        # the communicator's own rank count (what a bench line may call n_gpus), checked against the group's
+        n = C.c_int(-1)
+        rccl.ncclCommCount.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
+        rc = rccl.ncclCommCount(C.c_void_p(self.comm), C.byref(n))
+        if rc != 0 or n.value != world:
+            self.destroy()
+            raise RuntimeError(f"ncclCommCount says {n.value} rank(s) (code {rc}), the process group has {world}")
+        self.count = n.value
 
     def destroy(self):
         if getattr(self, "comm", None):

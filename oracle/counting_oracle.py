@@ -134,6 +134,24 @@ def count_transitions(tree_dir, msa_dir, site_rates_dir, families, amino_acids,
     return C
 
 
+def co_count_pair(Cq, code_a, code_b, contacts, S, symmetric) -> None:
+    """The per-pair inner loop of the reference's Python co-transition counter (_count_co_transitions.py:108-140;
+    C++ :359-381) on integer state codes (-1 = not in the alphabet): for every contact (i, j) of a pair whose four
+    residues are known, states s = a_i S + a_j, e = b_i S + b_j and their site-swapped versions s', e' get
+    0.5 at (s, e), (s', e') for an edge, 0.25 at (s, e), (s', e'), (e, s), (e', s') for a cherry."""
+    for i, j in contacts:
+        ai, aj, bi, bj = code_a[i], code_a[j], code_b[i], code_b[j]
+        if ai < 0 or aj < 0 or bi < 0 or bj < 0:
+            continue
+        s1, s1r, s2, s2r = ai * S + aj, aj * S + ai, bi * S + bj, bj * S + bi
+        if not symmetric:
+            Cq[s1, s2] += 0.5
+            Cq[s1r, s2r] += 0.5
+        else:
+            for s, e in ((s1, s2), (s1r, s2r), (s2, s1), (s2r, s1r)):
+                Cq[s, e] += 0.25
+
+
 def count_co_transitions(tree_dir, msa_dir, contact_map_dir, families, amino_acids,
                          quantization_points, edge_or_cherry,
                          minimum_distance_for_nontrivial_contact) -> np.ndarray:
@@ -150,22 +168,10 @@ def count_co_transitions(tree_dir, msa_dir, contact_map_dir, families, amino_aci
         contacts = [(i, j) for i, j in zip(*np.where(cm == 1))
                     if abs(i - j) >= minimum_distance_for_nontrivial_contact and i < j]
         for a, b, la, lb in transition_pairs(nodes, children, root, edge_or_cherry):
-            sa, sb = msa[a], msa[b]
             total = la if edge_or_cherry == "edge" else la + lb
             q = quantization_idx(total, grid)
             if q is None:
                 continue
-            for i, j in contacts:
-                if not all(c in idx for c in (sa[i], sa[j], sb[i], sb[j])):
-                    continue
-                s1 = idx[sa[i]] * S + idx[sa[j]]
-                s1r = idx[sa[j]] * S + idx[sa[i]]
-                s2 = idx[sb[i]] * S + idx[sb[j]]
-                s2r = idx[sb[j]] * S + idx[sb[i]]
-                if edge_or_cherry == "edge":
-                    C[q, s1, s2] += 0.5
-                    C[q, s1r, s2r] += 0.5
-                else:
-                    for s, e in ((s1, s2), (s1r, s2r), (s2, s1), (s2r, s1r)):
-                        C[q, s, e] += 0.25
+            co_count_pair(C[q], [idx.get(c, -1) for c in msa[a]], [idx.get(c, -1) for c in msa[b]], contacts, S,
+                          edge_or_cherry != "edge")
     return C

@@ -25,9 +25,13 @@ int ncclCommInitRank(void **comm, int nranks, ncclUniqueId id, int rank) {
   fwrite(&rank, sizeof rank, 1, f);
   fwrite(id.internal, 1, 128, f);
   fclose(f);
-  *comm = malloc(16);
+  int *c = malloc(16);
+  c[0] = nranks;
+  *comm = c;
   return 0;
 }
+
+int ncclCommCount(void *comm, int *count) { *count = ((int *)comm)[0]; return 0; }
 
 int ncclAllReduce(const void *s, void *r, size_t n, int dt, int op, void *comm, void *stream) { return 0; }
 int ncclCommDestroy(void *comm) { free(comm); return 0; }

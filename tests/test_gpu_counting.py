@@ -96,3 +96,82 @@ def test_quantisation_ties_and_range_on_device(tmp_path):
                                 ["f"], ["A", "C"], grid, "edge")
     assert np.array_equal(C, want)
     assert C.sum() == 2 * sum(1 for x in lengths if grid[0] <= x <= grid[-1])
+
+
+def _co_counts_numpy(S, grid, seqs, contacts, pairs, symmetric):
+    """[B, S^2, S^2] uint64 by the oracle's per-pair quantiser and np.add.at (reference
+    _count_co_transitions.py:108-140: a pair's quantised length, then +1 at (s1, s2), (s1', s2') [and reversed])."""
+    B, S2 = len(grid), S * S
+    want = np.zeros((B, S2, S2), dtype=np.uint64)
+    for p in pairs:
+        q = co.quantization_idx(float(p["len_a"] + p["len_b"]), grid)
+        if q is None or p["n"] <= 0:
+            continue
+        ij = contacts[2 * p["aux"]: 2 * (p["aux"] + p["n"])].reshape(-1, 2)
+        a = seqs[p["seq_a"] + ij].astype(np.int64)
+        b = seqs[p["seq_b"] + ij].astype(np.int64)
+        ok = (a >= 0).all(1) & (b >= 0).all(1)
+        a, b = a[ok], b[ok]
+        s1, s1r = a[:, 0] * S + a[:, 1], a[:, 1] * S + a[:, 0]
+        s2, s2r = b[:, 0] * S + b[:, 1], b[:, 1] * S + b[:, 0]
+        np.add.at(want[q], (s1, s2), 1)
+        np.add.at(want[q], (s1r, s2r), 1)
+        if symmetric:
+            np.add.at(want[q], (s2, s1), 1)
+            np.add.at(want[q], (s2r, s1r), 1)
+    return want
+
+
+@pytest.mark.parametrize("S,n_fam,symmetric", [(20, 40, 1), (20, 7, 0), (4, 5, 1), (25, 6, 1), (1, 2, 1)])
+def test_co_counting_bucket_binned_lds_kernel_random(S, n_fam, symmetric):
+    """cb_count_co_transitions (bucket-binned events + LDS row-block histograms, counting.hip.h) on random ragged
+    families -- 0 to 150 contacts per family (more than one wavefront's 64), gaps, pairs outside the grid, pairs without
+    contacts, a heavy bucket that is split into several chunks, alphabets whose S^2 rows need 1, 4 or 10 row blocks --
+    bit-exact against numpy, through host pointers and through device pointers (resident form, adds into counts,
+    with and without the caller's bound on pair.n)."""
+    import torch
+    from cherryml_amd import _lib
+    from cherryml_amd.counting._stage import PAIR_DTYPE
+    rng = np.random.default_rng(1000 * S + n_fam)
+    grid = np.array([float("%.8f" % (0.03 * 1.1 ** i)) for i in range(-64, 65)])
+    B = len(grid)
+    seq_chunks, contact_chunks, rows, seq_off, c_off = [], [], [], 0, 0
+    for f in range(n_fam):
+        L = int(rng.integers(8, 260))
+        leaves = int(rng.integers(2, 40)) * 2
+        codes = rng.integers(0, S, size=(leaves, L)).astype(np.int8)
+        codes[1::2] = np.where(rng.random((leaves // 2, L)) < 0.6, codes[0::2], codes[1::2])
+        codes[rng.random(codes.shape) < 0.07] = -1
+        n_c = int(rng.choice([0, 1, 63, 64, 65, 150, int(rng.integers(2, 100))]))
+        ij = np.sort(rng.integers(0, L, size=(n_c, 2)), axis=1).astype(np.int32)
+        for k in range(leaves // 2):
+            heavy = rng.random() < 0.5          # half of all pairs land in ONE bucket (it is split into chunks)
+            la = 0.05 if heavy else float(rng.choice([1e-6, 40.0, rng.exponential(0.3)]))
+            rows.append((seq_off + 2 * k * L, seq_off + (2 * k + 1) * L, c_off, n_c, 0, la, float(rng.exponential(0.05)) if not heavy else 0.05))
+        seq_chunks.append(codes.reshape(-1))
+        contact_chunks.append(ij.reshape(-1))
+        seq_off += codes.size
+        c_off += n_c
+    seqs = np.concatenate(seq_chunks)
+    contacts = np.concatenate(contact_chunks + [np.zeros(2, np.int32)]).astype(np.int32)
+    pairs = np.array(rows, dtype=PAIR_DTYPE)
+    want = _co_counts_numpy(S, grid, seqs, contacts, pairs, symmetric)
+    assert want.sum() > 0 or S == 1
+    lib = _lib.load()
+    got = np.zeros_like(want)
+    rc = lib.cb_count_co_transitions(0, S, B, grid.ctypes.data, seqs.ctypes.data, seqs.size, contacts.ctypes.data,
+                                     contacts.size // 2, pairs.ctypes.data, len(pairs), symmetric, 0, got.ctypes.data)
+    _lib.check(rc, "cb_count_co_transitions")
+    assert np.array_equal(got, want)
+    # resident form: device pointers, ADDS into counts; flags bits 8.. = the caller's bound on pair.n (0: read back)
+    dev = torch.device("cuda", 0)
+    d = [torch.from_numpy(x).to(dev) for x in (grid, seqs, contacts, pairs.view(np.uint8))]
+    for bound in (0, int(pairs["n"].max())):
+        d_counts = torch.ones(want.size, dtype=torch.int64, device=dev)
+        for _ in range(2):
+            rc = lib.cb_count_co_transitions(0, S, B, d[0].data_ptr(), d[1].data_ptr(), seqs.size, d[2].data_ptr(),
+                                             contacts.size // 2, d[3].data_ptr(), len(pairs), symmetric,
+                                             _lib.CB_PTR_DEVICE | (bound << 8), d_counts.data_ptr())
+            _lib.check(rc, "cb_count_co_transitions")
+        torch.cuda.synchronize()
+        assert np.array_equal(d_counts.cpu().numpy().astype(np.uint64).reshape(want.shape), 2 * want + 1), bound
