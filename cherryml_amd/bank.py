@@ -147,6 +147,10 @@ class CherryBank:
     def last_sweeps(self) -> int:
         return int(_lib.load().cb_last_sweeps(self._h))
 
+    def last_kernel_form(self) -> int:
+        """which trainer kernels the last train_* call launched (cb_last_kernel_form: 1000 + 100 TS + 10 sym + w3, ...)"""
+        return int(_lib.load().cb_last_kernel_form(self._h))
+
     # -- host-pointer API (numpy) -----------------------------------------
     def _shape_Q(self, Q, pi):
         Q = _as_f64(Q).reshape(self.L, self.S, self.S)

@@ -70,7 +70,12 @@ static int launch_count_co_transitions(int device, int S, int B, const double *g
                                        unsigned long long *counts) {
   const int S2 = S * S;
   const int R = std::min(S2, CO_LDS_WORDS / S2);
-  if (R < 1 || (size_t)2 * B * 8 + CO_THREADS * 8 > 150 * 1024) {   // S > 200 or an enormous grid: the plain atomic form
+#ifdef CB_CO_PLAIN   // (build-time experiment: time the scattered-global-atomic form this path replaced)
+  const bool plain = true;
+#else
+  const bool plain = false;
+#endif
+  if (plain || R < 1 || (size_t)2 * B * 8 > 64 * 1024) {   // S > 200 or an enormous grid: the plain atomic form
     const unsigned blocks = (unsigned)((n_pairs + 3) / 4);
     hipLaunchKernelGGL(count_co_transitions_kernel, dim3(blocks), dim3(256), 0, 0, S, B, grid, seqs, contacts, pairs,
                        (long long)n_pairs, symmetric, counts);
@@ -129,8 +134,8 @@ static int launch_count_co_transitions(int device, int S, int B, const double *g
     hipLaunchKernelGGL(co_plan_kernel, dim3(1), dim3(256), (size_t)2 * B * 8, 0, B, nrb, target, max_work, w.bucket_ev,
                        w.bucket_off, w.work, w.n_work);
   }
-  hipLaunchKernelGGL(co_expand_kernel, dim3(pair_blocks), dim3(CO_THREADS), (size_t)(B + CO_THREADS) * 8, 0, B, seqs,
-                     contacts, pairs, (long long)n_pairs, w.qbuf, w.bucket_off, w.cursor, w.events);
+  hipLaunchKernelGGL(co_expand_kernel, dim3((unsigned)((n_pairs + CO_XP - 1) / CO_XP)), dim3(CO_XP), (size_t)B * 8, 0, B,
+                     seqs, contacts, pairs, (long long)n_pairs, w.qbuf, w.bucket_off, w.cursor, w.events);
   const size_t lds = (size_t)R * S2 * sizeof(unsigned);
   if (symmetric) {
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(co_count_lds_kernel<true>),

@@ -36,6 +36,7 @@ struct cb_bank {
   hipEvent_t ev_fork = nullptr, ev_join[3] = {};
   int tr_epochs = 0;
   uint64_t tr_sig = 0;
+  int last_form = 0;    // which trainer kernels the last training call launched (cb_last_kernel_form)
   double tr_pow_b1 = 1.0, tr_pow_b2 = 1.0;
   int dtype = CB_F64;   // element type of the bank products (large path): CB_F64 or CB_F32
   int LD = 0;           // large path: padded leading dimension
@@ -1335,6 +1336,7 @@ static int run_fused_training_large(cb_bank *h, double *pi_param, double *up_par
   if (h->profile) fold_pending(h);
   if (dbg) fprintf(stderr, "[cherrybank] large trainer: parameters uploaded after %.2f ms\n", now() - t_enter);
   double pow_b1 = resume ? h->tr_pow_b1 : 1.0, pow_b2 = resume ? h->tr_pow_b2 : 1.0;
+  h->last_form = 4000;
   h->tr_epochs = 0;   // (set again when this call succeeds)
   // fault injection for the tests of the collective failure protocol: this rank's evaluation "fails" at that epoch
   const int fault_epoch = getenv("CB_FAULT_INJECT") ? atoi(getenv("CB_FAULT_INJECT")) : -1000;
@@ -1509,10 +1511,12 @@ static int run_fused_training(cb_bank *h, int kind, double *pi_param, double *up
         for (int e = 0; e < E && rc == CB_OK; ++e) {
           pow_b1 *= a.beta1;
           pow_b2 *= a.beta2;
-          hipLaunchKernelGGL(sp_prepare, dim3(L), dim3(64), lds_p, h->stream, a, g, e);
+          if (L < 64) hipLaunchKernelGGL(sp_prepare<256>, dim3(L), dim3(256), lds_p, h->stream, a, g, e);
+          else hipLaunchKernelGGL(sp_prepare<64>, dim3(L), dim3(64), lds_p, h->stream, a, g, e);
           const dim3 gb((unsigned)((size_t)L * g.nchunk));
           const bool w3 = (size_t)L * g.nchunk > 512;   // more workgroups than two per CU can hold at once: the three-per-CU form
           const double bc1 = 1.0 - pow_b1, bc2s = std::sqrt(1.0 - pow_b2);
+          h->last_form = 1000 + 100 * TS + (a.sym ? 10 : 0) + (w3 ? 1 : 0);
 #define SPK(T)                                                                                         \
   do {                                                                                                 \
     if (a.sym && w3) hipLaunchKernelGGL((sp_bank<T, true, true>), gb, dim3(256), spb_total(T, true, true) * sizeof(double), h->stream, a, g);      \
@@ -1534,6 +1538,7 @@ static int run_fused_training(cb_bank *h, int kind, double *pi_param, double *up
       }
     } else if (E > 0 && split) {
       // one LG-sized bank: the epoch spread over the chip, three small launches per epoch
+      h->last_form = 2000;
       LgSplit g{};
       double *buf = nullptr;
       const size_t nbuf = LGS_TOTAL + (size_t)h->Bl * 1025 + 8;  // L == 1: nlive[0] == Bl
@@ -1569,6 +1574,7 @@ static int run_fused_training(cb_bank *h, int kind, double *pi_param, double *up
         }
       }
     } else if (E > 0) {
+      h->last_form = 3000;
       unsigned long long *stamps = nullptr;
       if (getenv("CB_DEBUG_STAMPS")) {
         (void)hipMalloc((void **)&stamps, 16 * sizeof(unsigned long long));
@@ -1680,6 +1686,7 @@ extern "C" int cb_timing_sums(cb_handle h, double *ms_sum, int n, int *calls) {
 }
 
 extern "C" int cb_last_sweeps(cb_handle h) { return h ? h->last_sweeps : 0; }
+extern "C" int cb_last_kernel_form(cb_handle h) { return h ? h->last_form : 0; }
 
 extern "C" int cb_last_timings(cb_handle h, double *ms, int n) {
   if (!h || !ms) return fail(CB_EINVAL, "cb_last_timings: NULL argument");

@@ -311,108 +311,136 @@ __global__ __launch_bounds__(256) void co_plan_kernel(int B, int nrb, int target
   unsigned long long *ev_off = co_plan, *first = co_plan + B;
   __shared__ unsigned long long chunk_s;
   __shared__ int total_chunks;
+  // (B is ~129: the counts go to LDS with all threads, one thread does the two short prefix sums there)
+  for (int b = threadIdx.x; b < B; b += 256) first[b] = bucket_ev[b];
+  __syncthreads();
   if (threadIdx.x == 0) {
     unsigned long long off = 0;
     for (int b = 0; b < B; ++b) {
       ev_off[b] = off;
-      bucket_off[b] = off;
-      off += bucket_ev[b];
+      off += first[b];
     }
-    bucket_off[B] = off;
     unsigned long long chunk = (off * (unsigned long long)nrb + target - 1) / (unsigned long long)target;
     if (chunk < 16384ull) chunk = 16384ull;
     chunk_s = chunk;
     int k = 0;
     for (int b = 0; b < B; ++b) {
+      const unsigned long long n = first[b];
       first[b] = (unsigned long long)k;
-      k += (int)((bucket_ev[b] + chunk - 1) / chunk);
+      k += (int)((n + chunk - 1) / chunk);
     }
     total_chunks = k;
     const int groups = (k + 7) / 8;
     n_work[0] = groups * 8 * nrb <= max_work ? groups * 8 * nrb : 0;   // (cannot exceed: max_work is the bound below)
+    bucket_off[B] = off;
   }
+  __syncthreads();
+  for (int b = threadIdx.x; b < B; b += 256) bucket_off[b] = ev_off[b];
   __syncthreads();
   const unsigned long long chunk = chunk_s;
   const int slots = (total_chunks + 7) / 8 * 8 * nrb;
   if (slots > max_work) return;
-  for (int i = threadIdx.x; i < slots; i += 256) work[i].q = -1;   // holes of the last group
-  __syncthreads();
-  for (int b = threadIdx.x; b < B; b += 256) {
-    const unsigned long long n = bucket_ev[b];
-    if (!n) continue;
-    const int nch = (int)((n + chunk - 1) / chunk);
-    const unsigned long long per = (n + nch - 1) / nch;
-    for (int c = 0; c < nch; ++c) {
-      const int cid = (int)first[b] + c;
-      const unsigned long long e0 = ev_off[b] + (unsigned long long)c * per;
-      unsigned long long e1 = e0 + per;
-      if (e1 > ev_off[b] + n) e1 = ev_off[b] + n;
-      for (int rb = 0; rb < nrb; ++rb) {
-        CoWork w;
-        w.q = b; w.rb = rb; w.single = nch == 1; w.pad = 0; w.e0 = e0; w.e1 = e1;
-        work[(cid / 8) * 8 * nrb + rb * 8 + (cid & 7)] = w;
+  // one thread per SLOT (a hot bucket has dozens of chunks: a thread per bucket would write them one after another)
+  const int nchunks = total_chunks;
+  for (int i = threadIdx.x; i < slots; i += 256) {
+    const int group = i / (8 * nrb), in = i - group * 8 * nrb;
+    const int rb = in >> 3, cid = group * 8 + (in & 7);
+    CoWork w;
+    w.q = -1; w.rb = rb; w.single = 0; w.pad = 0; w.e0 = 0; w.e1 = 0;
+    if (cid < nchunks) {
+      int lo = 0, hi = B - 1;   // the last bucket whose first chunk id is <= cid (empty buckets share their successor's)
+      while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if ((int)first[mid] <= cid) lo = mid;
+        else hi = mid - 1;
       }
+      const int b = lo, c = cid - (int)first[b];
+      const unsigned long long n = bucket_ev[b];
+      const int nch = (int)((n + chunk - 1) / chunk);
+      const unsigned long long per = (n + nch - 1) / nch;
+      w.q = b;
+      w.single = nch == 1;
+      w.e0 = ev_off[b] + (unsigned long long)c * per;
+      w.e1 = w.e0 + per < ev_off[b] + n ? w.e0 + per : ev_off[b] + n;
     }
+    work[i] = w;
   }
 }
 
-// thread = pair for the offsets (two-level: LDS counters per bucket inside the workgroup, one returning global add per
-// (workgroup, non-empty bucket)), then wave = pair for the events, four pairs in flight per wave.
-__global__ __launch_bounds__(CO_THREADS) void co_expand_kernel(
+// 256 pairs per workgroup.  Phase A, thread = pair: the pair's offset inside its bucket's event range (two-level: LDS
+// counters per bucket inside the workgroup, one returning global add per (workgroup, non-empty bucket)); its record
+// goes to LDS.  Phase B, wave = 64 of those pairs with their events FLATTENED: lane = event, 64 consecutive events per
+// step whatever the pairs' contact counts are (a pair with 65 contacts would otherwise cost a second, almost empty,
+// pass), four steps in flight -- every load of a step is independent of the previous step.
+#define CO_XP 256
+__global__ __launch_bounds__(CO_XP) void co_expand_kernel(
     int B, const int8_t *__restrict__ seqs, const int32_t *__restrict__ contacts,
     const cb_count_pair *__restrict__ pairs, long long n_pairs, const int *__restrict__ qbuf,
     const unsigned long long *__restrict__ bucket_off, unsigned long long *__restrict__ cursor,
     unsigned *__restrict__ events) {
-  extern __shared__ unsigned long long co_x[];   // [B] counters / bases, then [CO_THREADS] event offset of each pair
-  unsigned long long *cnt = co_x, *off_l = co_x + B;
-  for (int b = threadIdx.x; b < B; b += CO_THREADS) cnt[b] = 0ull;
+  extern __shared__ unsigned long long co_x[];   // [B] counters / bases
+  __shared__ unsigned long long p_base[CO_XP];   // first event of the pair in the global event array
+  __shared__ long long p_sa[CO_XP], p_sb[CO_XP], p_aux[CO_XP];
+  __shared__ int p_woff[CO_XP + 4];              // per wave: exclusive prefix of the pairs' event counts, [64] + total
+  unsigned long long *cnt = co_x;
+  for (int b = threadIdx.x; b < B; b += CO_XP) cnt[b] = 0ull;
   __syncthreads();
-  const long long pb = (long long)blockIdx.x * CO_THREADS;
-  const long long p = pb + threadIdx.x;
-  int q = -1;
+  const long long p = (long long)blockIdx.x * CO_XP + threadIdx.x;
+  int q = -1, n = 0;
   unsigned long long local = 0;
   if (p < n_pairs) {
     q = qbuf[p];
-    if (q >= 0) local = atomicAdd(&cnt[q], (unsigned long long)pairs[p].n);
+    if (q >= 0) {
+      const cb_count_pair pr = pairs[p];
+      n = pr.n;
+      p_sa[threadIdx.x] = pr.seq_a;
+      p_sb[threadIdx.x] = pr.seq_b;
+      p_aux[threadIdx.x] = pr.aux;
+      local = atomicAdd(&cnt[q], (unsigned long long)n);
+    }
   }
   __syncthreads();
-  for (int b = threadIdx.x; b < B; b += CO_THREADS) {
+  for (int b = threadIdx.x; b < B; b += CO_XP) {
     const unsigned long long c = cnt[b];
     if (c) cnt[b] = bucket_off[b] + atomicAdd(&cursor[b], c);
   }
   __syncthreads();
-  off_l[threadIdx.x] = q >= 0 ? cnt[q] + local : ~0ull;
+  p_base[threadIdx.x] = q >= 0 ? cnt[q] + local : 0ull;
+  // wave-level exclusive scan of n (a pair outside the grid has none)
+  const int lane = threadIdx.x & 63, w0 = threadIdx.x & ~63, wv = threadIdx.x >> 6;
+  int incl = n;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const int up = __shfl_up(incl, d, 64);
+    if (lane >= d) incl += up;
+  }
+  int *woff = p_woff + wv * 65;   // 4 waves x 65 ints
+  woff[lane] = incl - n;
+  if (lane == 63) woff[64] = incl;
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+  __builtin_amdgcn_wave_barrier();
   __syncthreads();
-  const int lane = threadIdx.x & 63, w0 = (threadIdx.x >> 6) * 64;
-  auto emit = [&](const cb_count_pair &pr, unsigned long long base, int c) {
-    const int2 ij = *reinterpret_cast<const int2 *>(contacts + 2 * ((size_t)pr.aux + c));
-    const int8_t *sa = seqs + pr.seq_a, *sb = seqs + pr.seq_b;
-    const int ai = sa[ij.x], aj = sa[ij.y], bi = sb[ij.x], bj = sb[ij.y];
-    const bool gap = (ai | aj | bi | bj) < 0;
-    events[base + c] = gap ? CO_EVENT_GAP : ((unsigned)ai | (unsigned)aj << 8 | (unsigned)bi << 16 | (unsigned)bj << 24);
-  };
-  for (int k0 = 0; k0 < 64; k0 += 4) {
-    cb_count_pair pr[4];
-    unsigned long long base[4];
+  const int total = woff[64];
+  int pl = 0;   // this lane's pair inside the wave (monotone over the steps)
+  for (int e0 = 0; e0 < total; e0 += 4 * 64) {
+    int pi[4], ci[4];
     bool on[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-      const long long pp = pb + w0 + k0 + u;
-      base[u] = off_l[w0 + k0 + u];
-      on[u] = pp < n_pairs && base[u] != ~0ull;
-      pr[u] = pairs[on[u] ? pp : 0];
+      const int e = e0 + 64 * u + lane;
+      on[u] = e < total;
+      const int ec = on[u] ? e : total - 1;
+      while (pl < 63 && woff[pl + 1] <= ec) ++pl;
+      pi[u] = w0 + pl;
+      ci[u] = ec - woff[pl];
     }
-    // the first 64 contacts of the four pairs together (independent load chains), the rest pair by pair
     int2 ij[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) ij[u] = *reinterpret_cast<const int2 *>(contacts + 2 * ((size_t)p_aux[pi[u]] + ci[u]));
     int code[4][4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-      const int c = on[u] && lane < pr[u].n ? lane : 0;
-      ij[u] = on[u] && pr[u].n > 0 ? *reinterpret_cast<const int2 *>(contacts + 2 * ((size_t)pr[u].aux + c)) : make_int2(0, 0);
-    }
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int8_t *sa = seqs + (on[u] ? pr[u].seq_a : 0), *sb = seqs + (on[u] ? pr[u].seq_b : 0);
+      const int8_t *sa = seqs + p_sa[pi[u]], *sb = seqs + p_sb[pi[u]];
       code[u][0] = sa[ij[u].x];
       code[u][1] = sa[ij[u].y];
       code[u][2] = sb[ij[u].x];
@@ -420,17 +448,13 @@ __global__ __launch_bounds__(CO_THREADS) void co_expand_kernel(
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-      if (on[u] && lane < pr[u].n) {
+      if (on[u]) {
         const bool gap = (code[u][0] | code[u][1] | code[u][2] | code[u][3]) < 0;
-        events[base[u] + lane] = gap ? CO_EVENT_GAP
-                                     : ((unsigned)code[u][0] | (unsigned)code[u][1] << 8 | (unsigned)code[u][2] << 16 |
-                                        (unsigned)code[u][3] << 24);
+        events[p_base[pi[u]] + ci[u]] = gap ? CO_EVENT_GAP
+                                            : ((unsigned)code[u][0] | (unsigned)code[u][1] << 8 |
+                                               (unsigned)code[u][2] << 16 | (unsigned)code[u][3] << 24);
       }
     }
-#pragma unroll
-    for (int u = 0; u < 4; ++u)
-      if (on[u])
-        for (int c = 64 + lane; c < pr[u].n; c += 64) emit(pr[u], base[u], c);
   }
 }
 

@@ -326,3 +326,227 @@ __device__ double wave_rotation_cross16_regs(const double *Gam, double *Rc, int 
   return wave_max(off2);
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// Warm-started FIRST-ORDER sweeps on the matrix cores (one wavefront, n <= 32).  An optimiser step perturbs A a little,
+// so the columns of G = A' U_prev are already nearly orthogonal; a whole Jacobi sweep then spends n - 1 dependent
+// rounds (LDS round trip, three reductions, two rsqrt each: ~30k cycles at n = 20) on rotations whose angles are all
+// small.  Small angles commute to first order, so ALL pairs are rotated at once:
+//     Gamma = G^T G,     X_ij = Gamma_ij / (Gamma_jj - Gamma_ii)   (the small-angle limit of every pair's rotation;
+//     G <- G exp(X)       antisymmetric),  exp(X) applied to G term by term: T_0 = G, T_k = T_{k-1} X / k
+// with as many terms as the bound ||X|| <= max_j sum_i |X_ij| needs for a remainder below 1e-17 -- so the implicit
+// V <- V exp(X) stays orthogonal to rounding.  Each term is ONE n x n product = NT^2 KS v_mfma_f64_16x16x4 from LDS
+// (~1k cycles).  An iteration squares the cosines (like a Jacobi sweep); the one that STARTED below CB_JAC_STOP is the
+// last.  Pairs that are nearly degenerate make X large (||X|| > 0.5: the first epochs of an optimisation, equal-rate
+// models): that iteration is an exact Jacobi sweep instead.  Layouts: Gc / Tc column-major (column k at k * LS), X
+// row-major; every operand outside n x n is fed as zero.
+template <int NT, int KS>
+__device__ __forceinline__ void wave_mm(int n, const double *Af, int ams, int aks, const double *Bf, int bks, int bns,
+                                        d4 (&acc)[NT][NT]) {
+  const int lane = threadIdx.x & 63, lo = lane & 15, hi = lane >> 4;
+  double a[NT][KS], b[NT][KS];
+#pragma unroll
+  for (int x = 0; x < NT; ++x)
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      const int m = 16 * x + lo, k = 4 * s + hi;
+      const bool ok = m < n && k < n;
+      const int mc = min(m, n - 1), kc = min(k, n - 1);
+      const double av = Af[mc * ams + kc * aks], bv = Bf[kc * bks + mc * bns];
+      a[x][s] = ok ? av : 0.0;
+      b[x][s] = ok ? bv : 0.0;
+    }
+#pragma unroll
+  for (int mt = 0; mt < NT; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      d4 c = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int s = 0; s < KS; ++s) c = mfma_f64(a[mt][s], b[nt][s], c);
+      acc[mt][nt] = c;
+    }
+}
+
+// smallest Taylor degree m with x^(m+1) / (m+1)! < 1e-17
+__device__ __forceinline__ int fo_taylor_degree(double x) {
+  const double lim[15] = {4.5e-9, 3.9e-6, 1.24e-4, 1.04e-3, 4.4e-3, 1.26e-2, 2.82e-2, 5.34e-2,
+                          9.03e-2, 0.14, 0.2025, 0.279, 0.369, 0.4725, 0.588};
+  int m = 1;
+#pragma unroll
+  for (int i = 0; i < 15; ++i) m += x > lim[i] ? 1 : 0;
+  return m;
+}
+
+#define CB_FO_MAX_NORM 0.5
+#define CB_FO_MAX_ITERS 48
+
+// Gc = A' Uc on entry is formed here (Uc = the previous eigenvectors); on return the columns of Gc are orthogonal.
+// Uc is used as the Taylor-term scratch after that; X: one more n x LS frame; dg: n doubles.  Returns the iterations.
+template <int NT, int KS>
+__device__ int wave_orthogonalise_first_order(int n, const double *A, double sigma, double *Gc, double *Uc, double *X,
+                                              double *dg, int LS) {
+  const int lane = threadIdx.x & 63, lo = lane & 15, hi = lane >> 4;
+  d4 acc[NT][NT];
+  // ---- G0 = A' U = A U - sigma U
+  wave_mm<NT, KS>(n, A, LS, 1, Uc, 1, LS, acc);
+#pragma unroll
+  for (int mt = 0; mt < NT; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = 16 * mt + hi + 4 * r, col = 16 * nt + lo;
+        if (row < n && col < n) Gc[col * LS + row] = fma(-sigma, Uc[col * LS + row], acc[mt][nt][r]);
+      }
+  wave_lds_fence();
+  int it = 0;
+  for (; it < CB_FO_MAX_ITERS; ++it) {
+    // ---- Gamma = G^T G, its diagonal through LDS
+    d4 gam[NT][NT];
+    wave_mm<NT, KS>(n, Gc, LS, 1, Gc, 1, LS, gam);
+#pragma unroll
+    for (int mt = 0; mt < NT; ++mt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = 16 * mt + hi + 4 * r;
+        if (row < n && hi + 4 * r == lo) dg[row] = gam[mt][mt][r];
+      }
+    wave_lds_fence();
+    // ---- X, the largest squared cosine, the column sums of |X|
+    double cos2 = 0.0, colsum[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const int col = 16 * nt + lo;
+      const double dj = dg[min(col, n - 1)];
+      double cs = 0.0;
+#pragma unroll
+      for (int mt = 0; mt < NT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = 16 * mt + hi + 4 * r;
+          const double di = dg[min(row, n - 1)];
+          const bool live = row < n && col < n && row != col;
+          const double g = gam[mt][nt][r];
+          const double den = dj - di;
+          // (a vanishing denominator gives inf / NaN: the norm test below then sends the iteration to Jacobi)
+          // (a pair that is orthogonal to rounding is left alone, as in the Jacobi sweeps: exactly degenerate
+          //  eigenvalues would otherwise divide rounding noise by rounding noise)
+          const double g2 = g * g, dd = di * dj;
+          const double x = (live && g2 > dd * (CB_JAC_SKIP * CB_JAC_SKIP)) ? g * fast_rcp(den) : 0.0;
+          if (live) cos2 = fmax(cos2, g2 * fast_rcp(dd));
+          cs += fabs(x);
+          if (row < n && col < n) X[row * LS + col] = x;
+        }
+      cs += __shfl_xor(cs, 16, 64);
+      cs += __shfl_xor(cs, 32, 64);
+      colsum[nt] = cs;
+    }
+    // NaN-safe maximum (fmax drops NaNs): a NaN or inf anywhere must end up in the result
+    double nrm = 0.0;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) nrm = (colsum[nt] == colsum[nt]) ? fmax(nrm, colsum[nt]) : INFINITY;
+    nrm = wave_max(nrm);
+    cos2 = wave_max(cos2);
+    wave_lds_fence();
+    const bool last = cos2 < CB_JAC_STOP * CB_JAC_STOP;
+    if (!(nrm <= CB_FO_MAX_NORM)) {   // near-degenerate pairs: exact rotations for this iteration
+      if (n <= 4) wave_jacobi_columns<1, false>(n, Gc, nullptr, LS, 1);
+      else if (n <= 8) wave_jacobi_columns<2, false>(n, Gc, nullptr, LS, 1);
+      else if (n <= 16) wave_jacobi_columns<4, false>(n, Gc, nullptr, LS, 1);
+      else if (n <= 20) wave_jacobi_columns<5, false>(n, Gc, nullptr, LS, 1);
+      else if (n <= 24) wave_jacobi_columns<6, false>(n, Gc, nullptr, LS, 1);
+      else wave_jacobi_columns<8, false>(n, Gc, nullptr, LS, 1);
+      if (last) {
+        ++it;
+        break;
+      }
+      continue;
+    }
+    // ---- G <- G exp(X), term by term
+    const int deg = fo_taylor_degree(nrm);
+#pragma unroll
+    for (int mt = 0; mt < NT; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = 16 * mt + hi + 4 * r, col = 16 * nt + lo;
+          acc[mt][nt][r] = Gc[min(col, n - 1) * LS + min(row, n - 1)];
+        }
+    const double *Tsrc = Gc;
+    for (int k = 1; k <= deg; ++k) {
+      d4 t[NT][NT];
+      wave_mm<NT, KS>(n, Tsrc, 1, LS, X, LS, 1, t);
+      const double ik = 1.0 / (double)k;
+      wave_lds_fence();   // every lane has read the previous term before it is overwritten
+#pragma unroll
+      for (int mt = 0; mt < NT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int row = 16 * mt + hi + 4 * r, col = 16 * nt + lo;
+            const double v = t[mt][nt][r] * ik;
+            acc[mt][nt][r] += v;
+            if (k < deg && row < n && col < n) Uc[col * LS + row] = v;
+          }
+      wave_lds_fence();
+      Tsrc = Uc;
+    }
+#pragma unroll
+    for (int mt = 0; mt < NT; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = 16 * mt + hi + 4 * r, col = 16 * nt + lo;
+          if (row < n && col < n) Gc[col * LS + row] = acc[mt][nt][r];
+        }
+    wave_lds_fence();
+    if (last) {
+      ++it;
+      break;
+    }
+  }
+  return it;
+}
+
+// wave_eigh_rate with the first-order sweeps: Uc must hold the previous eigenvectors (warm start only).
+// MAXN bounds the sizes the caller can bring (the S <= 24 trainers do not instantiate the 28 / 32-row forms).
+template <int MAXN = 32>
+__device__ int wave_eigh_rate_warm_mfma(int n, const double *A, double *Gc, double *Uc, double *X, double *dg, double *lam,
+                                        int LS) {
+  const int lane = threadIdx.x & 63;
+  double mx = 0.0;
+  for (int i = lane; i < n; i += 64) mx = fmax(mx, fabs(A[i * LS + i]));
+  double sigma = wave_max(mx);
+  if (!(sigma > 0.0)) sigma = 1.0;
+  int its;
+  if (n <= 4) its = wave_orthogonalise_first_order<1, 1>(n, A, sigma, Gc, Uc, X, dg, LS);
+  else if (n <= 8) its = wave_orthogonalise_first_order<1, 2>(n, A, sigma, Gc, Uc, X, dg, LS);
+  else if (n <= 12) its = wave_orthogonalise_first_order<1, 3>(n, A, sigma, Gc, Uc, X, dg, LS);
+  else if (n <= 16) its = wave_orthogonalise_first_order<1, 4>(n, A, sigma, Gc, Uc, X, dg, LS);
+  else if (n <= 20) its = wave_orthogonalise_first_order<2, 5>(n, A, sigma, Gc, Uc, X, dg, LS);
+  else if (n <= 24 || MAXN <= 24) its = wave_orthogonalise_first_order<2, 6>(n, A, sigma, Gc, Uc, X, dg, LS);
+  else if constexpr (MAXN > 24) {
+    if (n <= 28) its = wave_orthogonalise_first_order<2, 7>(n, A, sigma, Gc, Uc, X, dg, LS);
+    else its = wave_orthogonalise_first_order<2, 8>(n, A, sigma, Gc, Uc, X, dg, LS);
+  }
+  // normalise: 4 lanes per column (as wave_eigh_rate)
+  for (int k0 = 0; k0 < n; k0 += 16) {
+    const int k = k0 + (lane >> 2), sub = lane & 3;
+    double nn = 0.0;
+    if (k < n)
+      for (int r = sub; r < n; r += 4) nn = fma(Gc[k * LS + r], Gc[k * LS + r], nn);
+    nn += __shfl_xor(nn, 1, 64);
+    nn += __shfl_xor(nn, 2, 64);
+    if (k < n) {
+      const double nrm = sqrt(nn);
+      const double inv = -1.0 / nrm;
+      for (int r = sub; r < n; r += 4) Uc[k * LS + r] = Gc[k * LS + r] * inv;
+      if (sub == 0) lam[k] = sigma - nrm;
+    }
+  }
+  wave_lds_fence();
+  return its;
+}

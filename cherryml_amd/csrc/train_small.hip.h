@@ -406,30 +406,40 @@ struct SpSplit {
 #define SPP_LAM (3 * SP_ROWS * CB_LS)
 #define SPP_D (SPP_LAM + 32)
 #define SPP_PI (SPP_D + 32)
-#define SPP_TOTAL (SPP_PI + 32)
+#define SPP_X (SPP_PI + 32)                     // first-order sweeps: X frame, then the diagonal of Gamma
+#define SPP_DG (SPP_X + SP_ROWS * CB_LS)
+#define SPP_TOTAL (SPP_DG + 32)
 
 // one wavefront per workgroup: only the eigensolver's wave has work for most of the kernel, and
-// 19 KB of LDS lets eight sites overlap per CU
-__global__ __launch_bounds__(64) void sp_prepare(TrainArgs a, SpSplit g, int epoch) {
+// 26 KB of LDS lets six sites overlap per CU.  Every epoch after the first is warm-started from the previous
+// eigenvectors and solved by first-order sweeps on the matrix cores (jacobi_wave.hip.h: a solve late in an
+// optimisation is ~8 20 x 20 products instead of two or three 19-round Jacobi sweeps)
+// NTH = 64 for many sites (above); a few sites (one LG-sized bank) take 256 threads: theta -> A, the frame copies and
+// the Q_last write are then spread over four waves (the single wave spent more time there than in the eigensolver)
+template <int NTH>
+__global__ __launch_bounds__(NTH, 2) void sp_prepare(TrainArgs a, SpSplit g, int epoch) {
   extern __shared__ double lds[];
   double *sA = lds + SPP_A, *sG = lds + SPP_G, *sV = lds + SPP_V, *sLam = lds + SPP_LAM, *sD = lds + SPP_D,
          *sPi = lds + SPP_PI;
   const int S = a.S, tid = threadIdx.x, l = blockIdx.x;
   double *fr = g.frames + (size_t)l * LGS_TOTAL;
   if (epoch == 0 && tid == 0) g.best[l] = INFINITY;
+  if (epoch > 0)  // previous eigenvectors: warm start (issued first: the loads fly while theta -> A is computed)
+    for (int e = tid; e < SP_ROWS * CB_LS; e += NTH) sV[e] = fr[LGS_V + e];
   tr_build(a, l, epoch, sA, sD, sPi);
-  if (epoch > 0)  // previous eigenvectors: warm start
-    for (int e = tid; e < SP_ROWS * CB_LS; e += 64) sV[e] = fr[LGS_V + e];
   __syncthreads();
-  if (tid < 64) wave_eigh_rate(S, sA, sG, sV, sLam, CB_LS, epoch > 0);
+  if (NTH == 64 || tid < 64) {
+    if (epoch > 0) wave_eigh_rate_warm_mfma<24>(S, sA, sG, sV, lds + SPP_X, lds + SPP_DG, sLam, CB_LS);
+    else wave_eigh_rate(S, sA, sG, sV, sLam, CB_LS, false);
+  }
   __syncthreads();
-  for (int e = tid; e < SP_ROWS * 32; e += 64) {
+  for (int e = tid; e < SP_ROWS * 32; e += NTH) {
     const int k = e >> 5, i = e & 31;
     if (k >= S || i >= S) sV[k * CB_LS + i] = 0.0;
   }
-  for (int k = S + tid; k < 32; k += 64) sLam[k] = 0.0;
+  for (int k = S + tid; k < 32; k += NTH) sLam[k] = 0.0;
   __syncthreads();
-  for (int e = tid; e < SP_ROWS * CB_LS; e += 64) {
+  for (int e = tid; e < SP_ROWS * CB_LS; e += NTH) {
     fr[LGS_A + e] = sA[e];
     fr[LGS_V + e] = sV[e];
   }
@@ -547,6 +557,7 @@ __global__ __launch_bounds__(256) void sp_finish(TrainArgs a, SpSplit g, int epo
   const double *Mp = g.Mpart + (size_t)l * g.nchunk * 576;
   for (int e = tid; e < 16 * TS * TS; e += 256) {
     double tot = 0.0;
+#pragma unroll 4
     for (int c = 0; c < g.nchunk; ++c) tot += Mp[(size_t)c * 576 + e];
     const int tile = e >> 4, At = tile / TS, Ct = tile - At * TS;
     sG[(4 * At + ((e >> 2) & 3)) * CB_LS + 4 * Ct + (e & 3)] = tot;
@@ -558,12 +569,13 @@ __global__ __launch_bounds__(256) void sp_finish(TrainArgs a, SpSplit g, int epo
       if (At > Ct) sG[(4 * At + i) * CB_LS + 4 * Ct + j] = sG[(4 * Ct + j) * CB_LS + 4 * At + i];
     }
   }
-  if (tid == 0) {
-    double tot = 0.0;
-    for (int c = 0; c < g.nchunk; ++c) tot += g.lpart[(size_t)l * g.nchunk + c];
-    double dir = 0.0;
-    for (int k = 0; k < S; ++k) dir = fma(log(sD[k]), a.dirsum[(size_t)l * S + k], dir);
-    sFlag[2] = (tot - dir) * a.inv_n[l];
+  if (tid < 64) {   // the direct pi term on S lanes (fixed-order tree sum) instead of S logarithms in a row on one thread
+    const double dir = wave_sum(tid < S ? log(sD[tid]) * a.dirsum[(size_t)l * S + tid] : 0.0);
+    if (tid == 0) {
+      double tot = 0.0;
+      for (int c = 0; c < g.nchunk; ++c) tot += g.lpart[(size_t)l * g.nchunk + c];
+      sFlag[2] = (tot - dir) * a.inv_n[l];
+    }
   }
   __syncthreads();
   small_dA_from_M(S, sG, sV, sRed);

@@ -159,6 +159,11 @@ int cb_timing_sums(cb_handle h, double *ms_sum, int n, int *calls);
 /* sweeps used by the last large-path eigendecomposition: tournament (Jacobi) sweeps of the cold path
  * + hybrid / first-order sweeps of a warm-started solve */
 int cb_last_sweeps(cb_handle h);
+/* Which kernels the last cb_train_* call on this handle launched (tests pin the form they compare): 1000 + 100 TS +
+ * 10 sym + w3 = the site-parallel split sp_prepare / sp_bank<TS, sym, w3> / sp_finish (TS = ceil(S / 4) tiles, sym =
+ * symmetric-count form, w3 = three workgroups per CU); 2000 = lg_prepare / lg_bank / lg_finish (one bank, 24 < S <= 32);
+ * 3000 = the one-kernel trainer; 4000 = the C-driven S > 32 loop; 0 = none yet. */
+int cb_last_kernel_form(cb_handle h);
 
 /*
  * Fused optimiser for the reference's `pande_reversible` parameterisation

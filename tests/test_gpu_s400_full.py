@@ -132,6 +132,17 @@ def test_dense_bank_60_epoch_trajectories_vs_reference(dense):
     # Q_last follows the trajectory itself (Q_best also depends on which epoch wins a flat argmin)
     assert relerr(r32["Q_last"], _from_support(z["Q_last_support_f64"], mask)) < 1e-3
     assert relerr(r32["Q_last"], _from_support(z["Q_last_support_f32"], mask)) < 1e-3
+    # CB_MIXED (P_b, loss, G_b in float64; the two gradient products on the float32 MFMA) anchored to the REFERENCE's runs
+    # too, not only to our own f64 bank: it must sit closer to the float64 reference than the reference's own
+    # float32 arithmetic does
+    rmx = _train(t, C, mask, z["upper_diag0"], z["log_pi0"], E, dtype="mixed")
+    assert np.allclose(rmx["loss"], z["loss_f64"], rtol=1e-7, atol=0)
+    for key in ("Q_best", "Q_last"):
+        e64 = relerr(rmx[key], _from_support(z[f"{key}_support_f64"], mask))
+        e32 = relerr(rmx[key], _from_support(z[f"{key}_support_f32"], mask))
+        print(f"dense sub-bank mixed bank: {key} to the f64 reference {e64:.2e}, to the reference's own float32 run {e32:.2e}")
+    emx = relerr(rmx["Q_last"], _from_support(z["Q_last_support_f64"], mask))
+    assert emx < 1e-4 and emx < 10 * d_ref + 1e-6
 
 
 def test_dense_bank_full_60_epoch_trajectory_vs_reference(dense):

@@ -277,3 +277,21 @@ def test_likelihood_oracle_against_reference(case, model, pair):
     if case + "_published" in z:   # the value typed into the reference's tests (FastTree-verified, 4 decimals)
         pub = z[case + "_published"]
         assert np.allclose(ll if pub.ndim == 0 else lls, pub, atol=1e-4)
+
+
+def test_oracle_siterm_matches_reference_on_cfg4_sites():
+    """The oracle's SiteRM loop on 3 of the bench-tensor sites (B = 129, N = 20) and 2 of the 21-state non-symmetric
+    sites the reference was run on (tests/golden/make_golden_siterm_cfg4.py): first 8 epochs of the loss curves."""
+    import os
+    import sys
+    from oracle import ratelearn_oracle as orc
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    from make_golden_siterm_cfg4 import nonsymmetric_21_state_problem
+    z = load_golden("siterm_cfg4.npz")
+    k = np.array([0, 1, 17])
+    sel = z["sites20"][k]
+    r = orc.siterm_train(z["banks20"][sel % 2], z["times20"][k], 8, initialization=z["init20"][k])
+    assert np.allclose(r["loss_per_epoch_per_site"], z["lpeps20"][:8, k], rtol=1e-9, atol=0)
+    T, C, Q0 = nonsymmetric_21_state_problem(L=24)
+    r = orc.siterm_train(C[:2], T[:2], 8, initialization=Q0[:2])
+    assert np.allclose(r["loss_per_epoch_per_site"], z["lpeps21"][:8, :2], rtol=1e-9, atol=0)
