@@ -199,23 +199,34 @@ def cpu_baseline(wl, name):
         t, C = wl["t"][sel], wl["C"][sel]
         init = jtt_ipw_from_arrays(wl["t"], wl["C"], wl["mask"])
         u, p = orc.invert_pande_reversible(init, wl["mask"])
-        reps = 1 if wl["S"] == 400 else 200
+        # >= 3 timed evaluations each way; the MEDIAN is the baseline and the spread is reported (a single evaluation of
+        # the 400-state sample varied by 70 % between two runs of the same command in round 2)
+        reps, inner = (3, 1) if wl["S"] == 400 else (5, 40)
         orc.evaluate(u, p, wl["mask"], t[:1], C[:1], torch.float32)  # warm up
-        t0 = time.time()
+        samples = []
         for _ in range(reps):
-            orc.evaluate(u, p, wl["mask"], t, C, torch.float32)
-        dt = (time.time() - t0) / reps * (B / nb)
-        sample = f"{nb} of {B} buckets x {reps} evaluation(s), float32 expm as the reference, scaled to {B}"
+            t0 = time.time()
+            for _ in range(inner):
+                orc.evaluate(u, p, wl["mask"], t, C, torch.float32)
+            samples.append((time.time() - t0) / inner * (B / nb))
+        dt = float(np.median(samples))
+        spread = dict(evaluations=reps * inner, seconds_per_epoch_min=min(samples), seconds_per_epoch_max=max(samples))
+        sample = (f"{nb} of {B} buckets x {reps} timed evaluation(s)" + (f" of {inner} each" if inner > 1 else "") +
+                  f", float32 expm as the reference, scaled to {B}; value = median")
     else:
         L = min(16, wl["C"].shape[0])
-        Q = torch.tensor(wl["init"][:L], requires_grad=True)
-        t0 = time.time()
-        _, tot = orc.siterm_loss(Q, torch.tensor(wl["C"][:L]), torch.tensor(wl["t"][:L]))
-        tot.backward()
-        dt = (time.time() - t0) * (wl["C"].shape[0] / L)
-        sample = f"{L} of {wl['C'].shape[0]} sites, float64 as the reference's SiteRM path, scaled"
+        samples = []
+        for _ in range(3):
+            Q = torch.tensor(wl["init"][:L], requires_grad=True)
+            t0 = time.time()
+            _, tot = orc.siterm_loss(Q, torch.tensor(wl["C"][:L]), torch.tensor(wl["t"][:L]))
+            tot.backward()
+            samples.append((time.time() - t0) * (wl["C"].shape[0] / L))
+        dt = float(np.median(samples))
+        spread = dict(evaluations=3, seconds_per_epoch_min=min(samples), seconds_per_epoch_max=max(samples))
+        sample = f"{L} of {wl['C'].shape[0]} sites x 3 timed evaluations, float64 as the reference's SiteRM path, scaled; value = median"
     return dict(value=wl["n_pairs"] / dt, unit="cherry-pairs/s", cores=int(cores), kind="port",
-                sample=sample, seconds_per_epoch=dt)
+                sample=sample, seconds_per_epoch=dt, **spread)
 
 
 # -------------------------------------------------------------------- launcher
@@ -492,17 +503,27 @@ def main():
             # (mixed: the dominant kernel is then K1 in float64; K2 / K3 run on the f32 MFMA)
             dom_f32 = bank_dtype == "f32" or (bank_dtype == "mixed" and dom != "k1")
             peak = F32_PEAK_TFLOPS if dom_f32 else F64_PEAK_TFLOPS
+            peak_of = lambda k: (F32_PEAK_TFLOPS if (bank_dtype == "f32" or (bank_dtype == "mixed" and k != "k1"))  # noqa: E731
+                                 else F64_PEAK_TFLOPS)
+            util, util_src = _mfma_util(bank_dtype)
             roofline = dict(bound="mfma", kernel=names[dom] + ("<float>" if dom_f32 else "<double>"),
                             achieved=achieved, peak=peak, unit="TFLOP/s", frac=achieved / peak,
                             epoch_frac=epoch_tflops / (peak * world), epoch_tflops=epoch_tflops,
                             epoch_flops=epoch_flops,
                             traffic=traffic.get(names[dom] + ("_f32" if dom_f32 else "_mixed" if bank_dtype == "mixed" else ""))
                             if world == 1 else None,
+                            traffic_source=_traffic_source() if world == 1 else None,
                             ms_per_launch=tm[dom], flops_per_launch=flops,
                             note="achieved = algorithmic 2 S^3 B flops (SURVEY 8d) / launch time; k1 (Pt symmetric) "
                                  f"and k3 (symmetric counts) multiply only the upper-triangular tiles, {tri:.2f} of "
                                  "those flops; k2 multiplies all of them",
-                            per_kernel_tflops={k: round(flops / (tm[k] * 1e-3) / 1e12, 2) for k in names if tm[k] > 0})
+                            per_kernel_tflops={k: round(flops / (tm[k] * 1e-3) / 1e12, 2) for k in names if tm[k] > 0},
+                            # what the matrix pipe really executes: k1 / k3 run `tri` of the algorithmic flops
+                            per_kernel_executed_tflops={k: round((flops if k == "k2" else flops * tri) / (tm[k] * 1e-3) / 1e12, 2)
+                                                        for k in names if tm[k] > 0},
+                            per_kernel_executed_frac={k: round((flops if k == "k2" else flops * tri) / (tm[k] * 1e-3) / 1e12 / peak_of(k), 3)
+                                                      for k in names if tm[k] > 0},
+                            per_kernel_mfma_util=util, mfma_util_source=util_src)
         else:
             Lb = wl["C"].shape[0] if wl["kind"] == "sites" else 1
             nbytes = float(Lb) * B_local * S * S * 8  # C streamed once per epoch
@@ -511,6 +532,7 @@ def main():
             roofline = dict(bound="hbm", kernel=kname, achieved=achieved,
                             peak=HBM_PEAK_GBS, unit="GB/s", frac=achieved / HBM_PEAK_GBS,
                             traffic=traffic.get("epoch:" + workload) if world == 1 else None,
+                            traffic_source=_traffic_source() if world == 1 else None,
                             ms_per_epoch_in_kernel=tm["small"], bytes_per_epoch=nbytes,
                             note="figures are per epoch; the kernels are VALU / MFMA bound (log, reciprocal, divided "
                                  "differences on every count entry), HBM only streams the counts once")
@@ -820,7 +842,9 @@ def run_co_counting(steps, warmup, world, rank, local_rank, fence, with_cpu, fam
                    "sharding": f"families x{world}" + (", all-reduce of the 165 MB integer count tensor per pass" if world > 1
                                                        else " (no collective)")},
         "roofline": {"bound": "hbm", "kernel": "co_bucket + co_plan + co_expand + co_count_lds (one pass)", "achieved": achieved,
-                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                     "traffic": _pmc_traffic().get("pass:co_counting") if world == 1 else None,
+                     "traffic_source": _traffic_source() if world == 1 else None,
                      "ms_per_launch": kernel_ms, "bytes_per_launch": nbytes,
                      "note": "events binned by bucket, 100-row x 400-column LDS histograms per (bucket, row block, event "
                              "chunk), non-zero bins added to the 8-byte global bins once; time excludes the clear"},
@@ -1004,6 +1028,33 @@ def _pmc_traffic():
         return {}
     with open(path) as f:
         return json.load(f).get("bytes_per_launch", {})
+
+
+def _traffic_source():
+    """`roofline.traffic` is NOT measured by the run that prints the line (a counter pass cannot share a run with the
+    timing): it is read from the committed PMC summary; this says which one."""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if not os.path.exists(path):
+        return None
+    with open(path) as f:
+        d = json.load(f)
+    return (f"profiles/pmc_traffic.json ({d.get('round', 'r02')}, collected {d.get('collected', '2026-10-03')}; "
+            "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes), not measured in this run")
+
+
+def _mfma_util(dtype):
+    """measured MFMA-pipe utilisation of K1 / K2 / K3 (SQ_VALU_MFMA_BUSY_CYCLES, profiles/mfma_util.json) per kernel"""
+    path = os.path.join(ROOT, "profiles", "mfma_util.json")
+    if not os.path.exists(path):
+        return {}, None
+    with open(path) as f:
+        d = json.load(f)
+    out = {}
+    for key, v in d.get("kernels", {}).items():
+        name, dt = key.split(":")
+        if dt == dtype:
+            out[name.split("_")[0]] = round(v["mfma_util"], 3)
+    return out, f"profiles/mfma_util.json ({d.get('round', 'r02')}, collected {d.get('collected', '2026-10-03')})"
 
 
 def _bench_tree(rng, n_leaves):

@@ -92,7 +92,6 @@ int tl_prune(int S, int S1, const TlFamily &f, const double *dP, int cat_stride_
                  hipFuncSetAttribute(reinterpret_cast<const void *>(tl_leaf_kernel),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_leaf) != hipSuccess))
     return fail(CB_EHIP, "cb_tree_likelihood: cannot reserve %zu bytes of LDS", lds);
-  static const int rs_force = getenv("CB_TL_RS") ? atoi(getenv("CB_TL_RS")) : 0;
   for (int l = 0; l < f.n_levels; ++l) {
     const int nl = f.level_ptr[l + 1] - f.level_ptr[l];
     // height 0 = the leaves (never the root when the tree has an edge): gathered, not multiplied
@@ -101,7 +100,7 @@ int tl_prune(int S, int S1, const TlFamily &f, const double *dP, int cat_stride_
     a.RS = 1;
     if (S > 64 && !leaves) {   // small levels: split the rows of a node over 2 or 4 workgroups (one per CU)
       const long wgs = (long)nl * a.n_blocks;
-      a.RS = rs_force > 0 ? rs_force : wgs * 4 <= 256 ? 4 : wgs * 2 <= 256 ? 2 : 1;
+      a.RS = wgs * 4 <= 256 ? 4 : wgs * 2 <= 256 ? 2 : 1;
     }
     const int per_node = a.n_blocks * a.RS;
     const int per_launch = std::max(1, (1 << 30) / per_node);   // keep the 1-D grid below 2^30 workgroups

@@ -1221,28 +1221,16 @@ extern "C" int cb_loss_grad_general(cb_handle h, const double *Q, int flags, dou
 }
 
 // ------------------------------------------------------------- fused trainers
+// The one-kernel trainer (one workgroup per site for all epochs): what is left to it after the three-launch splits took
+// S <= 24 (any L) and the single 25 .. 32-state bank -- SEVERAL sites, or the SiteRM parameterisation, at 25 .. 32 states.
 template <int NW>
 static int launch_train_nw(cb_bank *h, const TrainArgs &a) {
+  static_assert(NW == 4, "25 .. 32 states: the four-wave form only (see the kernels' launch bounds)");
   const size_t lds = (SmallLds<NW>::TOTAL + 72) * sizeof(double);
-  const int S = h->S;
-#define LAUNCH(NT, KS)                                                                          \
-  do {                                                                                          \
-    auto kern = small_train_kernel<NT, KS, NW>;                                                 \
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),                           \
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));         \
-    hipLaunchKernelGGL(kern, dim3(h->L), dim3(NW * 64), lds, h->stream, a);                     \
-  } while (0)
-  if (S <= 4) LAUNCH(1, 1);
-  else if (S <= 8) LAUNCH(1, 2);
-  else if (S <= 16) LAUNCH(1, 4);
-  else if (S <= 20) LAUNCH(2, 5);
-  else if constexpr (NW == 4) {   // more than 20 states: the four-wave form only (see the kernels' launch bounds)
-    if (S <= 24) LAUNCH(2, 6);
-    else LAUNCH(2, 8);
-  } else {
-    return fail(CB_EINVAL, "internal: %d states dispatched to the eight-wave small kernels", S);
-  }
-#undef LAUNCH
+  if (h->S <= 24) return fail(CB_EINVAL, "internal: %d states dispatched to the one-kernel trainer", h->S);
+  auto kern = small_train_kernel<2, 8, NW>;
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(kern, dim3(h->L), dim3(NW * 64), lds, h->stream, a);
   HIP_TRY(hipGetLastError());
   return CB_OK;
 }
@@ -1482,10 +1470,10 @@ static int run_fused_training(cb_bank *h, int kind, double *pi_param, double *up
     a.sym = (S <= 24 && h->sym_counts) ? 1 : 0;
     for (bool &b : h->ev_rec) b = false;
     mark(h, EV_START);
-    const char *env_split = getenv("CB_LG_SPLIT");
-    const char *env_sp = getenv("CB_SITE_SPLIT");
-    const bool site_split = S <= 24 && !(env_sp && atoi(env_sp) == 0) && !(L == 1 && env_split && atoi(env_split) == 0);
-    const bool split = !site_split && kind == 0 && L == 1 && !(env_split && atoi(env_split) == 0);
+    // which kernels (cb_last_kernel_form): S <= 24 -- the site-parallel split, any L, both parameterisations;
+    // 24 < S <= 32 -- one pande_reversible bank: the LG split; several sites or SiteRM: the one-kernel trainer
+    const bool site_split = S <= 24;
+    const bool split = !site_split && kind == 0 && L == 1;
     if (E > 0 && site_split) {
       // three launches per epoch over all sites (train_small.hip.h: sp_prepare / sp_bank / sp_finish)
       SpSplit g{};
@@ -1575,27 +1563,7 @@ static int run_fused_training(cb_bank *h, int kind, double *pi_param, double *up
       }
     } else if (E > 0) {
       h->last_form = 3000;
-      unsigned long long *stamps = nullptr;
-      if (getenv("CB_DEBUG_STAMPS")) {
-        (void)hipMalloc((void **)&stamps, 16 * sizeof(unsigned long long));
-        (void)hipMemset(stamps, 0, 16 * sizeof(unsigned long long));
-        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_small_stamps), &stamps, sizeof stamps);
-      }
-      rc = (L < 512 && S <= 20) ? launch_train_nw<8>(h, a) : launch_train_nw<4>(h, a);
-      if (stamps) {
-        unsigned long long st[16];
-        (void)hipStreamSynchronize(h->stream);
-        (void)hipMemcpy(st, stamps, sizeof st, hipMemcpyDeviceToHost);
-        const char *names[] = {"theta->A (tr_build)", "eigh (wave 0)", "bucket loop", "loss + M reduction", "dA = U M U^T", "gradients + Adam"};
-        for (int i = 0; i < 6; ++i)
-          fprintf(stderr, "[cherrybank] small trainer, workgroup 0, epoch 1: %-22s %8llu ticks\n", names[i], st[i + 1] - st[i]);
-        const char *qn[] = {"quad: tables (exp, phi2)", "quad: Pt + epilogue", "quad: counts + T", "quad: W + Phi + M"};
-        for (int i = 0; i < 4; ++i)
-          fprintf(stderr, "[cherrybank] small trainer, first 4x4-tile quad of wave 0:  %-26s %8llu ticks\n", qn[i], st[9 + i] - st[8 + i]);
-        unsigned long long *null_p = nullptr;
-        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_small_stamps), &null_p, sizeof null_p);
-        (void)hipFree(stamps);
-      }
+      rc = launch_train_nw<4>(h, a);
     }
     mark(h, EV_SMALL);  // cb_last_timings(): CB_T_SMALL = all E epochs
   }

@@ -9,41 +9,21 @@
 // `second`: an independent product of the same kind (ns, alpha, beta) enqueued in the same launch (grid.y = 2)
 static void launch_sg(cb_bank *h, const K4Args &g, int ns, double alpha = 0.0, double beta = 0.0,
                       const K4Args *second = nullptr) {
-  // Shapes measured in situ (200 epochs of the bench bank, eigh ms per epoch): 16 x 80 strips, 8 waves x 4 k-steps in
-  // flight (variant 1) 0.343; 16 x 48 strips (3) 0.320; 16 x 32, 7 in flight (7) 0.332; ONE 16 x 16 tile per workgroup,
-  // K split over its 8 waves, 7 k-steps in flight (4, the default) 0.300; the same with 16 waves (5) 0.324, with 4 (6)
-  // 0.310.  These launches are latency chains (launch floor 2.6 us + load -> MFMA -> LDS reduce), not bandwidth: the
-  // 16 x 16 shape reads 64 MB from L2 per product against 38 MB for the strips and is still the fastest.
-  static const int variant = getenv("CB_SG_VARIANT") ? atoi(getenv("CB_SG_VARIANT")) : 4;
-  const dim3 nwg((unsigned)((h->LD / 16) * ((h->LD + 79) / 80)), second ? 2 : 1);
+  // ONE 16 x 16 tile per workgroup, K split over its 8 waves, 7 k-steps in flight.  Shapes measured in situ in round 2
+  // (200 epochs of the bench bank, eigh ms per epoch): 16 x 80 strips with 8 waves x 4 k-steps 0.343; 16 x 48 strips
+  // 0.320; 16 x 32 0.332; this one 0.300; the same with 16 waves 0.324, with 4 waves 0.310.  These launches are latency
+  // chains (launch floor 2.6 us + load -> MFMA -> LDS reduce), not bandwidth: the 16 x 16 shape reads 64 MB from L2 per
+  // product against 38 MB for the strips and is still the fastest.  (The other shapes were removed with their switch.)
+  const dim3 n1((unsigned)((h->LD / 16) * ((h->LD + 15) / 16)), second ? 2 : 1);
   const K4Args &g2 = second ? *second : g;
-  if (variant == 3) {
-    const dim3 n3((unsigned)((h->LD / 16) * ((h->LD + 47) / 48)), second ? 2 : 1);
-    hipLaunchKernelGGL((sg_gemm<8, 4, 3>), n3, dim3(512), 0, h->stream, g, g2, ns, alpha, beta);
-    return;
-  }
-  if (variant >= 4 && variant <= 6) {
-    const dim3 n1((unsigned)((h->LD / 16) * ((h->LD + 15) / 16)), second ? 2 : 1);
-    if (variant == 4) hipLaunchKernelGGL((sg_gemm<8, 7, 1>), n1, dim3(512), 0, h->stream, g, g2, ns, alpha, beta);
-    else if (variant == 5) hipLaunchKernelGGL((sg_gemm<16, 7, 1>), n1, dim3(1024), 0, h->stream, g, g2, ns, alpha, beta);
-    else hipLaunchKernelGGL((sg_gemm<4, 7, 1>), n1, dim3(256), 0, h->stream, g, g2, ns, alpha, beta);
-    return;
-  }
-  if (variant == 7) {
-    const dim3 n2((unsigned)((h->LD / 16) * ((h->LD + 31) / 32)), second ? 2 : 1);
-    hipLaunchKernelGGL((sg_gemm<8, 7, 2>), n2, dim3(512), 0, h->stream, g, g2, ns, alpha, beta);
-    return;
-  }
-  if (variant == 0) hipLaunchKernelGGL((sg_gemm<4, 4>), nwg, dim3(256), 0, h->stream, g, g2, ns, alpha, beta);
-  else if (variant == 1) hipLaunchKernelGGL((sg_gemm<8, 4>), nwg, dim3(512), 0, h->stream, g, g2, ns, alpha, beta);
-  else hipLaunchKernelGGL((sg_gemm<8, 7>), nwg, dim3(512), 0, h->stream, g, g2, ns, alpha, beta);
+  hipLaunchKernelGGL((sg_gemm<8, 7, 1>), n1, dim3(512), 0, h->stream, g, g2, ns, alpha, beta);
 }
 
 static int large_eigh(cb_bank *h, bool warm) {
   const int LD = h->LD;
   const size_t LL = (size_t)LD * LD;
   hipLaunchKernelGGL(lgj_sigma, dim3(1), dim3(256), 0, h->stream, LD, h->A, h->sigma, h->off_bits);
-  const bool warm_started = warm && h->have_prev && !getenv("CB_NO_WARM");
+  const bool warm_started = warm && h->have_prev;
   bool gr_valid = false;   // the row-major copy of G (first-order sweeps) is current
   if (warm_started) {
     // Warm start: Jacobi from the previous epoch's orthonormal basis V0 = U_prev,
@@ -66,14 +46,8 @@ static int large_eigh(cb_bank *h, bool warm) {
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(lgj_round),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   const int max_sweeps = 40;
-  const char *env_inner = getenv("CB_INNER_SWEEPS");
-  const int inner_sweeps = env_inner ? atoi(env_inner) : 0;  // 0 = each pair once per sweep
-  const char *env_within = getenv("CB_WITHIN_SWEEPS");
-  const char *env_passes = getenv("CB_WITHIN_PASSES");
-  const int within = env_within ? atoi(env_within) : 6;
-  const int passes = env_passes ? atoi(env_passes) : 2;
-  unsigned long long *dbg_stamps = nullptr;
-  if (getenv("CB_DEBUG_STAMPS")) HIP_TRY(hipMalloc((void **)&dbg_stamps, 8 * sizeof(unsigned long long)));
+  const int inner_sweeps = 0;        // each pair once per sweep
+  const int within = 6, passes = 2;  // within passes per sweep and their inner sweeps
   // (h->off_bits[0..63] were zeroed by lgj_sigma, the first kernel of the solve)
   double prev_cos = 1.0;     // largest cosine seen by the previous first-order sweep of this solve
   auto enqueue_sweep = [&](int sweep) {
@@ -83,13 +57,11 @@ static int large_eigh(cb_bank *h, bool warm) {
       // the group alignment alternates so that the groups overlap by one block
       for (int w = 0; w < passes; ++w)
         hipLaunchKernelGGL(lgj_round, dim3(nb / 2), dim3(JB_THREADS), lds, h->stream, LD,
-                           ((sweep + w) & 1) && nb > 2 ? -2 : -1, within, h->Gc, h->off_bits,
-                           (unsigned long long *)nullptr);
+                           ((sweep + w) & 1) && nb > 2 ? -2 : -1, within, h->Gc, h->off_bits);
     }
     for (int r = 0; r < nb - 1; ++r)
       hipLaunchKernelGGL(lgj_round, dim3(nb / 2), dim3(JB_THREADS), lds, h->stream, LD, r,
-                         inner_sweeps, h->Gc, h->off_bits,
-                         (dbg_stamps && sweep == 2 && r == 5) ? dbg_stamps : nullptr);
+                         inner_sweeps, h->Gc, h->off_bits);
     // a sweep that STARTS below 1e-8 ends at rounding level (quadratic convergence)
     hipLaunchKernelGGL(lgj_check, dim3(1), dim3(64), 0, h->stream, h->off_bits, 1e-8);
   };
@@ -100,8 +72,8 @@ static int large_eigh(cb_bank *h, bool warm) {
   // (nothing changed), < 0 on error.
   //   exp(X): |X| <= 1e-5 second order, <= 2e-3 fourth order, else 8th order (Paterson-Stockmeyer,
   //   4 products) on X / 2^s + s squarings + one Newton-Schulz step (the squarings amplify rounding).
-  const int band = getenv("CB_HYBRID_BAND") ? atoi(getenv("CB_HYBRID_BAND")) : 3;
-  const int ns_from = getenv("CB_HYBRID_NS_FROM") ? atoi(getenv("CB_HYBRID_NS_FROM")) : 2;  // squarings without a polish
+  const int band = 3;      // blocks: pairs further apart are rotated to first order, nearer ones exactly
+  const int ns_from = 2;   // squarings allowed without a Newton-Schulz polish
   const bool dbg_e = getenv("CB_DEBUG") != nullptr;
   auto light_sweep = [&](bool hybrid_ok, double trigger) -> int {
     double *Gr = h->gx, *Gam = h->gx + LL, *X = h->gx + 2 * LL, *Xf = h->gx + 3 * LL, *P4 = h->gx + 4 * LL,
@@ -120,7 +92,7 @@ static int large_eigh(cb_bank *h, bool warm) {
     }
     gr_valid = false;
     launch_sg(h, K4Args{h->S, LD, Gr, Gr, Gam, nullptr, nullptr, nullptr, nullptr, dg}, 0);
-    if (!h->poll && !getenv("CB_NO_POLL")) {
+    if (!h->poll) {
       void *q = nullptr;
       if (hipHostMalloc(&q, 8 * sizeof(unsigned long long), hipHostMallocCoherent | hipHostMallocMapped) == hipSuccess) {
         h->poll = (unsigned long long *)q;
@@ -138,7 +110,7 @@ static int large_eigh(cb_bank *h, bool warm) {
     // enqueued now and run while the statistics travel to the host (that round trip was a 14-19 us
     // hole in every sweep).  X^3 and X^4 only when the sweep is expected to need them.
     double *P2 = Gr, *P3 = Gam;                                            // both free once lgx_build has run
-    const bool spec = h->poll != nullptr && !getenv("CB_NO_SPECULATE");
+    const bool spec = h->poll != nullptr;
     const bool spec_deep = spec && !(prev_cos <= 1e-4);
     bool have_p2 = false, have_p34 = false;
     if (spec) {
@@ -231,7 +203,7 @@ static int large_eigh(cb_bank *h, bool warm) {
         // sweep (far pairs only, the state still far from converged) does not need THAT rotation to 1e-16 -- any
         // orthogonal matrix close to it serves -- so it stops at |Y| <= masked_lim (0.5: error 5e-9) and lets the
         // Newton-Schulz step restore orthogonality (error^2): two or three squarings fewer per such sweep.
-        static const double masked_lim = getenv("CB_POLY_LIM_MASKED") ? atof(getenv("CB_POLY_LIM_MASKED")) : 0.5;
+        const double masked_lim = 0.5;
         const double poly_lim = masked ? masked_lim : 0.075;
         int sq = 0;
         double sc = 1.0;
@@ -269,27 +241,25 @@ static int large_eigh(cb_bank *h, bool warm) {
   // Banded Jacobi pass of the hybrid sweep: every column pair at most `band` blocks apart is rotated
   // exactly -- distance <= 1 by the two within passes (16-column groups, both alignments, to
   // convergence), distance k = 2..band by two rounds of disjoint block pairs (i, i + k).
-  const int hybrid_within = getenv("CB_HYBRID_WITHIN") ? atoi(getenv("CB_HYBRID_WITHIN")) : 2;
+  const int hybrid_within = 2;
   auto band_pass = [&](int shift) {
     gr_valid = false;
     for (int w = 0; w < 2; ++w)
       hipLaunchKernelGGL(lgj_round, dim3(nb / 2), dim3(JB_THREADS), lds, h->stream, LD,
-                         ((shift + w) & 1) && nb > 2 ? -2 : -1, hybrid_within, h->Gc, h->off_bits,
-                         (unsigned long long *)nullptr);
+                         ((shift + w) & 1) && nb > 2 ? -2 : -1, hybrid_within, h->Gc, h->off_bits);
     for (int k = 2; k <= band && k < nb; ++k)
       for (int par = 0; par < 2; ++par)
         hipLaunchKernelGGL(lgj_round, dim3((unsigned)(((nb + 2 * k - 1) / (2 * k)) * k)), dim3(JB_THREADS), lds,
-                           h->stream, LD, -(10 + 2 * (k - 2) + par), 0, h->Gc, h->off_bits,
-                           (unsigned long long *)nullptr);
+                           h->stream, LD, -(10 + 2 * (k - 2) + par), 0, h->Gc, h->off_bits);
   };
   // Sweeps are enqueued without waiting for the host: as many as the previous (warm) solve needed,
   // then one at a time.  Launches after convergence return immediately.  Once a sweep started
   // below 2e-5 the state is expected below 1e-8 and the first-order sweep is tried.
   int sweep = 0, enq = 0;
   unsigned long long st[64] = {};
-  const bool use_light = !getenv("CB_NO_LIGHT");
-  const double light_trigger = getenv("CB_LIGHT_TRIGGER") ? atof(getenv("CB_LIGHT_TRIGGER")) : 3e-4;
-  const bool speculate = warm && h->last_sweeps > 1 && !getenv("CB_NO_SPECULATE");
+  const bool use_light = true;
+  const double light_trigger = 3e-4;
+  const bool speculate = warm && h->last_sweeps > 1;
   int batch = speculate ? std::max(1, h->spec_sweeps) : 1;
   bool converged = false;
   int light_done = 0;
@@ -298,7 +268,7 @@ static int large_eigh(cb_bank *h, bool warm) {
   // So a sweep = ONE first-order rotation of all far pairs (GEMMs) + `reps` banded Jacobi passes
   // over the near pairs (2 * band launches each) instead of LD/8 + 1 tournament rounds; it
   // converges like a full Jacobi sweep.  Falls through to the Jacobi loop below when it refuses.
-  const int hybrid_reps = getenv("CB_HYBRID_REPS") ? atoi(getenv("CB_HYBRID_REPS")) : 1;
+  const int hybrid_reps = 1;
   int hybrid_iters = 0;
   auto run_hybrid = [&]() -> int {   // 1: converged; 0: gave up, G is valid, carry on with tournament sweeps; < 0: error
     prev_cos = 1.0;
@@ -325,8 +295,8 @@ static int large_eigh(cb_bank *h, bool warm) {
   }
   // A COLD solve takes tournament sweeps until one of them started below `cold_switch`, then sorts its
   // columns by norm (the eigenvalue order the hybrid sweep relies on) and finishes with hybrid sweeps.
-  bool cold_hybrid_pending = !warm_started && hybrid_on && !getenv("CB_NO_COLD_HYBRID");
-  const double cold_switch = getenv("CB_COLD_SWITCH") ? atof(getenv("CB_COLD_SWITCH")) : 3e-2;
+  bool cold_hybrid_pending = !warm_started && hybrid_on;
+  const double cold_switch = 3e-2;
   for (; !converged;) {
     for (int i = 0; i < batch && enq < max_sweeps; ++i) enqueue_sweep(enq++);
     HIP_TRY(hipMemcpyAsync(st, h->off_bits, sizeof st, hipMemcpyDeviceToHost, h->stream));
@@ -390,15 +360,6 @@ static int large_eigh(cb_bank *h, bool warm) {
     h->spec_sweeps = need;
   }
   h->last_sweeps = sweep + hybrid_iters;
-  if (dbg_stamps) {
-    unsigned long long st[8];
-    HIP_TRY(hipMemcpy(st, dbg_stamps, sizeof st, hipMemcpyDeviceToHost));
-    (void)hipFree(dbg_stamps);
-    const char *names[] = {"stage", "gram", "reduce+sync", "offmeasure", "inner", "NS+sync", "apply"};
-    for (int i = 0; i < 6; ++i)
-      fprintf(stderr, "[cherrybank] lgj_round %-12s %6llu ticks (100 MHz)\n", names[i == 2 ? 3 : (i > 2 ? i + 1 : i)],
-              st[i + 1] - st[i]);
-  }
   if (!converged) return fail(CB_ENUMERIC, "block Jacobi did not converge in %d sweeps", max_sweeps);
   hipLaunchKernelGGL(lgj_norms, dim3((LD + 3) / 4), dim3(256), 0, h->stream, LD, h->Gc, h->X);
   hipLaunchKernelGGL(lgj_finish, dim3((LD + 3) / 4), dim3(256), 0, h->stream, LD, h->Gc, h->X, h->sigma,

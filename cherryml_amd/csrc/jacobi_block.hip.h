@@ -54,16 +54,11 @@ __device__ __forceinline__ int jb_rowstride(int LD) { return LD + ((2 - LD % 32 
 //             parity = code & 1: block pairs (i, i + k) with (i / k) % 2 == parity, cross pairs once
 //             (the eigen-columns are kept sorted, so near-degenerate columns are a few blocks apart).
 __global__ __launch_bounds__(JB_THREADS) void lgj_round(int LD, int round, int inner_sweeps,
-                                                        double *Gc, unsigned long long *off_bits,
-                                                        unsigned long long *stamps,
-                                                        unsigned long long *dist_bits = nullptr) {
+                                                        double *Gc, unsigned long long *off_bits) {
   // off_bits[0]: running max cosine of this sweep; off_bits[1]: solve finished (set by lgj_check):
   // sweeps are enqueued speculatively, the surplus launches return at once
   if (off_bits[1] != 0ull) return;
   extern __shared__ double lds[];
-#define JB_STAMP(i)                                                              \
-  if (stamps && blockIdx.x == 0 && threadIdx.x == 0) stamps[i] = __builtin_amdgcn_s_memtime();
-  JB_STAMP(0)
   const int RS = jb_rowstride(LD);
   double *sG = lds;                 // [16][RS]
   double *sGam = sG + 16 * RS;      // [16][17]  Gram -> orthogonalised columns
@@ -106,7 +101,6 @@ __global__ __launch_bounds__(JB_THREADS) void lgj_round(int LD, int round, int i
     }
   }
   __syncthreads();
-  JB_STAMP(1)
   // 2. Gram via MFMA: lane (lo, hi) feeds G[r = 4 s + hi][c = lo] as A and as B.
   //    Four independent accumulators: a dependent f64 MFMA chain costs ~300 cycles a link.
   d4 acc = {0.0, 0.0, 0.0, 0.0};
@@ -145,7 +139,6 @@ __global__ __launch_bounds__(JB_THREADS) void lgj_round(int LD, int round, int i
     sGam[(e >> 4) * 17 + (e & 15)] = v;
   }
   __syncthreads();
-  JB_STAMP(2)
   // 3. 16x16 rotation (wave 0); the convergence measure comes out of the rotation loop
   if (wave == 0) {
     double off;
@@ -159,7 +152,6 @@ __global__ __launch_bounds__(JB_THREADS) void lgj_round(int LD, int round, int i
         }
       }
       off = wave_max(off);
-      JB_STAMP(3)
       if (inner_sweeps >= 100) {
         wave_rotation_spd16(sGam, sR, 17, inner_sweeps - 100);   // (the 4-lanes-per-pair cyclic solver, for comparison)
       } else {
@@ -176,20 +168,16 @@ __global__ __launch_bounds__(JB_THREADS) void lgj_round(int LD, int round, int i
     } else {
       double off2;
       if (round >= 0 || round <= -10) {
-        JB_STAMP(3)
         off2 = wave_rotation_cross16_regs(sGam, sR, 17);
       } else {
         for (int e = lane; e < 256; e += 64) sR[(e >> 4) * 17 + (e & 15)] = ((e >> 4) == (e & 15)) ? 1.0 : 0.0;
         wave_lds_fence();
-        JB_STAMP(3)
         off2 = wave_rotation_spd16_blockpairs(sGam, sR, 17, false);
       }
       off = off2 > 0.0 ? off2 * fast_rsqrt(off2) : 0.0;
     }
-    JB_STAMP(4)
     if (lane == 0) {
       atomicMax(off_bits, dbl_bits(off));
-      if (dist_bits && round >= 0) atomicMax(dist_bits + (bi > bj ? bi - bj : bj - bi), dbl_bits(off));
     }
   }
   __syncthreads();
@@ -212,7 +200,6 @@ __global__ __launch_bounds__(JB_THREADS) void lgj_round(int LD, int round, int i
     sN[q * 17 + c] = 1.5 * sR[q * 17 + c] - 0.5 * d;  // column q of R'
   }
   __syncthreads();
-  JB_STAMP(5)
   // 4. apply R:  new^T[c'][r] = sum_c R[c][c'] old^T[c][r]
   double Rf[4];
 #pragma unroll
@@ -242,8 +229,6 @@ __global__ __launch_bounds__(JB_THREADS) void lgj_round(int LD, int round, int i
 #pragma unroll
     for (int r = 0; r < 4; ++r) Gc[(size_t)gcol(hi + 4 * r) * LD + r0 + lo] = o[r];
   }
-  JB_STAMP(6)
-#undef JB_STAMP
 }
 
 // End of a sweep: state[0] = largest cosine met before its rotation during the sweep.  Quadratic

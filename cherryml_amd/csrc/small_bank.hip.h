@@ -24,9 +24,6 @@
 #define CB_SMALL_MIN_WGS 2
 #endif
 
-// in-kernel phase stamps of workgroup 0 (debug: CB_DEBUG_STAMPS), see cb_train_* host code
-__device__ unsigned long long *g_small_stamps = nullptr;
-#define SM_STAMP(i) do { if (g_small_stamps && blockIdx.x == 0 && threadIdx.x == 0) g_small_stamps[i] = __builtin_amdgcn_s_memtime(); } while (0)
 
 struct SmallArgs {
   int S, L, B;        // B = bucket stride of t / Ct / P
@@ -304,8 +301,6 @@ __device__ __forceinline__ void small_quad(int S, double tb, const double *__res
   }
   double *tab = tabw + blk * 96;  // this block's F[32], E[32], H[32]
   const bool split = tb * rho <= 1.0;
-#define Q_STAMP(i) do { if (g_small_stamps && blockIdx.x == 0 && threadIdx.x == 0 && g_small_stamps[15] == 1) g_small_stamps[i] = __builtin_amdgcn_s_memtime(); } while (0)
-  Q_STAMP(8);
   // spectral tables of the four buckets: 16 lanes per block, lanes (q, r) cover k = 4 q + r and + 16
   {
     const int k0 = 4 * q + r;
@@ -321,7 +316,6 @@ __device__ __forceinline__ void small_quad(int S, double tb, const double *__res
     }
   }
   wave_lds_fence();
-  Q_STAMP(9);
   // Register budget (2 waves per SIMD = 256 VGPRs): g 2 TS^2 + counts 2 TS^2 + ONE operand form of U
   // 2 TS^2 at a time.  The two forms are re-read from LDS at the start of their phase (the memory
   // clobbers keep the compiler from hoisting both out of the bucket loop) and the scheduler is
@@ -397,7 +391,6 @@ __device__ __forceinline__ void small_quad(int S, double tb, const double *__res
     for (int Mt = 0; Mt < TS; ++Mt) g[Mt][It] = acc[Mt];
     __builtin_amdgcn_sched_barrier(0);
   }
-  Q_STAMP(11);
   // ---- W(At,Ct) = sum_It U^T(At,It) T(It,Ct);  M += W o Phi -----------------------------------
 #pragma unroll
   for (int Ct = 0; Ct < TS; ++Ct) {
@@ -435,9 +428,6 @@ __device__ __forceinline__ void small_quad(int S, double tb, const double *__res
     __builtin_amdgcn_sched_barrier(0);
   }
   wave_lds_fence();  // the tables are rewritten by the next quad
-  Q_STAMP(12);
-  if (g_small_stamps && blockIdx.x == 0 && threadIdx.x == 0 && g_small_stamps[15] == 1) g_small_stamps[15] = 2;
-#undef Q_STAMP
 #undef Q_UB
 }
 
@@ -495,13 +485,11 @@ __device__ __forceinline__ void small_site_eval(double *lds, int S, int B,
          *sD = lds + LD::D;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int lo = lane & 15, hi = lane >> 4;
-  SM_STAMP(1);
   if (wave == 0) {
     const int sweeps = wave_eigh_rate(S, sA, sG, sV, sLam, CB_LS, warm);
     if (lane == 0 && sweeps_out) *sweeps_out = sweeps;
   }
   __syncthreads();
-  SM_STAMP(2);
   // zero padding of the 32 x 32 eigenvector frame and of lam (operands are read unguarded)
   for (int e = threadIdx.x; e < 32 * 32; e += blockDim.x) {
     const int k = e >> 5, i = e & 31;
@@ -529,7 +517,6 @@ __device__ __forceinline__ void small_site_eval(double *lds, int S, int B,
       const double tb = bucket < B ? t_l[bucket] : 0.0;   // a missing bucket: t = 0, no counts -> contributes nothing
       small_quad<TS, false>(S, tb, Cq_l + (size_t)qd * (TS * TS * 64), inv_n, sA, sV, tab, sLam, rho, Mw, lossacc);
     }
-    SM_STAMP(3);
     lossacc = wave_sum(lossacc);
     if (lane == 0) lds[LD::LOSS + wave] = lossacc;
     if (want_grad) {
@@ -617,9 +604,7 @@ __device__ __forceinline__ void small_site_eval(double *lds, int S, int B,
     __syncthreads();
     return;
   }
-  SM_STAMP(4);
   small_dA_from_M(S, sG, sV, lds + LD::RED);
-  SM_STAMP(5);
 }
 
 // (21 .. 32 states: the tile sets of the two larger forms need more than 256 registers; their dispatch takes the

@@ -216,8 +216,6 @@ __global__ __launch_bounds__(NW * 64, (KS >= 6 && NW == 4) ? 1 : CB_SMALL_MIN_WG
   if (threadIdx.x == 0) sFlag[1] = INFINITY;
   double pow_b1 = 1.0, pow_b2 = 1.0;
   for (int epoch = 0; epoch < a.E; ++epoch) {
-    if (epoch == 1) SM_STAMP(0);
-    if (epoch == 1 && g_small_stamps && blockIdx.x == 0 && threadIdx.x == 0) g_small_stamps[15] = 1;  // arm the per-quad stamps
     tr_build(a, l, epoch, sA, sD, sPi);
     // sV still holds the previous epoch's eigenvectors (zero padded): warm start
     small_site_eval_call<NT, KS, NW>(lds, S, a.nlive[l], a.t + lb, a.Ct + lb * S * S, a.inv_n[l],
@@ -228,8 +226,6 @@ __global__ __launch_bounds__(NW * 64, (KS >= 6 && NW == 4) ? 1 : CB_SMALL_MIN_WG
     pow_b2 *= a.beta2;
     tr_update(a, l, epoch, lds[LD::LOSSTOT], 1.0 - pow_b1, sqrt(1.0 - pow_b2), sA, sG, sD, sPi, sGd,
               sFlag, lds + LD::RED, sFlag + 1);
-    if (epoch == 1) SM_STAMP(6);
-    if (epoch == 1 && g_small_stamps && blockIdx.x == 0 && threadIdx.x == 0) g_small_stamps = nullptr;  // one epoch only
   }
 }
 

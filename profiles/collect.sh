@@ -8,10 +8,11 @@ set -u
 R=${GRAFT_REPO_ROOT:-$PWD}
 cd /tmp && export TMPDIR=/tmp
 TAG=${1:-final}
+export HSA_ENABLE_IPC_MODE_LEGACY=${HSA_ENABLE_IPC_MODE_LEGACY:-0}
 # plain (unprofiled) lines first, on the fresh box, as the driver runs them
 python3 $R/bench.py --steps 20 --warmup 5 > $R/gpurun_out/${TAG}_bench_driver.log 2>&1
 python3 $R/bench.py > $R/gpurun_out/${TAG}_bench_default.log 2>&1
-for v in "coevo400 f64" "coevo400 mixed" "coevo400 f32" "coevo400_demo f64" "lg20 f64" "siterm f64" "counting f64" "ble f64" "assembly f64" "likelihood f64"; do
+for v in "coevo400 f64" "coevo400 mixed" "coevo400 f32" "coevo400_demo f64" "lg20 f64" "siterm f64" "counting f64" "co_counting f64" "ble f64" "assembly f64" "likelihood f64"; do
   set -- $v; w=$1; dt=$2; name=$w; [ "$dt" != "f64" ] && name=${w}_$dt
   # the bench line of this workload UNPROFILED (kernel tracing adds a few percent to launch-bound epochs) ...
   python3 $R/bench.py --workload $w --dtype $dt --no-cpu-baseline --no-secondary > $R/gpurun_out/${TAG}_bench_$name.log 2>&1

@@ -28,13 +28,16 @@ tag = sys.argv[1] if len(sys.argv) > 1 else "final"
 rnd = sys.argv[2] if len(sys.argv) > 2 else "r02"
 here = os.path.dirname(os.path.abspath(__file__))
 root = os.path.dirname(here)
-out = {"bytes_per_launch": {}, "detail": {}, "calibration": {},
+import datetime
+STAMP = {"round": rnd, "collected": datetime.datetime.now(datetime.timezone.utc).strftime("%Y-%m-%d")}
+out = {**STAMP, "bytes_per_launch": {}, "detail": {}, "calibration": {},
        "source": f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), gpurun_out/{tag}_pmc_*"}
 NAMES = ["k1_pt_loss_gt", "k2_t_eq_g_u", "k3_w_phi", "lgj_round", "lg_transpose_pad", "small_train_kernel", "small_bank_kernel",
          "lg_prepare", "lg_bank", "lg_finish", "count_transitions_lds_kernel", "count_reduce_slabs", "k3_reduce", "sp_prepare",
-         "sp_bank", "sp_finish", "sg_gemm", "lgx_build", "ble_branch_lengths_kernel", "ble_site_rates_kernel",
+         "sp_bank", "sp_finish", "sg_gemm", "co_bucket_kernel", "co_plan_kernel", "co_expand_kernel", "co_count_lds_kernel", "lgx_build", "ble_branch_lengths_kernel", "ble_site_rates_kernel",
          "siterm_raw_counts_kernel", "siterm_mix_kernel", "tl_mfma_kernel", "tl_leaf_kernel", "tl_group_kernel", "lg_cast_f32"]
-WORKLOADS = ["coevo400", "coevo400_mixed", "coevo400_f32", "coevo400_demo", "lg20", "siterm", "counting", "ble", "assembly", "likelihood"]
+WORKLOADS = ["coevo400", "coevo400_mixed", "coevo400_f32", "coevo400_demo", "lg20", "siterm", "counting", "co_counting", "ble", "assembly",
+             "likelihood"]
 
 
 def kshort(full):
@@ -89,6 +92,9 @@ for w in ("siterm", "lg20"):   # S <= 20: three launches per epoch (sp_prepare /
         bpl[f"epoch:{w}"] = sum(bpl[f"{k}:{w}"] for k in ("sp_prepare", "sp_bank", "sp_finish"))
 if all(f"{k}:counting" in bpl for k in ("count_transitions_lds_kernel", "count_reduce_slabs")):
     bpl["pass:counting"] = bpl["count_transitions_lds_kernel:counting"] + bpl["count_reduce_slabs:counting"]
+co = ("co_bucket_kernel", "co_plan_kernel", "co_expand_kernel", "co_count_lds_kernel")
+if all(f"{k}:co_counting" in bpl for k in co):
+    bpl["pass:co_counting"] = sum(bpl[f"{k}:co_counting"] for k in co)
 json.dump(out, open(f"{here}/pmc_traffic.json", "w"), indent=1)
 for name in ("bench_default", "bench_driver"):
     d = f"{root}/gpurun_out/{tag}_{name}.log"
@@ -98,7 +104,7 @@ for name in ("bench_default", "bench_driver"):
             open(f"{here}/{rnd}_{tag}_{name}.json", "w").write(line[-1])
 
 # ---- MFMA utilisation (north_star: "rocprof HBM GB/s and MFMA utilisation vs gfx950 peak")
-util = {"source": f"rocprofv3 --pmc SQ_* (one pass of 8 counters), gpurun_out/{tag}_pmc_sq_*; durations from the "
+util = {**STAMP, "source": f"rocprofv3 --pmc SQ_* (one pass of 8 counters), gpurun_out/{tag}_pmc_sq_*; durations from the "
                   "--kernel-trace --stats summaries of the same workloads", "simds": 1024, "clock_GHz": 2.4, "kernels": {}}
 for dt, w in (("f64", "coevo400"), ("mixed", "coevo400_mixed"), ("f32", "coevo400_f32")):
     fs = newest(f"{root}/gpurun_out/{tag}_pmc_sq_{dt}/*/*counter_collection.csv")

@@ -364,25 +364,59 @@ def test_coevolution_end_to_end_pipeline_small_alphabet(tmp_path):
     assert np.abs(Q.to_numpy().sum(1)).max() < 1e-12
 
 
-def test_split_and_single_kernel_lg_trainers_agree():
-    """L = 1 banks use three small launches per epoch (bank spread over the chip); the
-    single-workgroup kernel (CB_LG_SPLIT=0) must give the same trajectory."""
+def _random_reversible_init(rng, N):
+    pi = rng.dirichlet(np.full(N, 8.0))
+    R = rng.gamma(2.0, 0.3, size=(N, N))
+    R = np.triu(R, 1)
+    R = R + R.T
+    d = np.sqrt(pi)
+    Q = R * d[None, :] / d[:, None]
+    return Q - np.diag(Q.sum(1))
+
+
+def test_every_trainer_form_matches_the_oracle():
+    """Which kernels a training call launches is decided by (S, L, parameterisation) alone -- the CB_LG_SPLIT / CB_SITE_SPLIT
+    switches of rounds 1-2 are gone -- and cb_last_kernel_form says which: the site-parallel split (S <= 24), the LG split
+    (one 25 .. 32-state bank), the one-kernel trainer (several sites or SiteRM at 25 .. 32 states), each against the oracle."""
     from cherryml_amd import CherryBank
+    from cherryml_amd._siterm._vectorized import _invert
     from oracle import ratelearn_oracle as orc
     g = load_golden("traj_lgbank.npz")
     u0, p0 = orc.invert_pande_reversible(g["init"], np.ones((20, 20)))
-    outs = []
-    for env in ("1", "0"):
-        os.environ["CB_LG_SPLIT"] = env
-        try:
-            with CherryBank(g["t"], g["C"]) as bank:
-                outs.append(bank.train_pande_reversible(u0, p0, num_epochs=30, lr=0.1))
-        finally:
-            del os.environ["CB_LG_SPLIT"]
-    assert np.allclose(outs[0]["loss"], outs[1]["loss"], rtol=1e-12, atol=0)
-    assert relerr(outs[0]["Q_best"], outs[1]["Q_best"]) < 1e-9
-    assert relerr(outs[0]["Q_last"], outs[1]["Q_last"]) < 1e-9
-    assert np.allclose(outs[0]["loss"], g["loss_f64"][:30], rtol=1e-9, atol=0)
+    with CherryBank(g["t"], g["C"]) as bank:
+        r = bank.train_pande_reversible(u0, p0, num_epochs=30, lr=0.1)
+        assert bank.last_kernel_form() == 1510          # sp_bank<5, symmetric, two workgroups per CU>
+    assert np.allclose(r["loss"], g["loss_f64"][:30], rtol=1e-9, atol=0)
+    rng = np.random.default_rng(28)
+    N, B, E = 28, 6, 12
+    t = np.sort(rng.uniform(0.02, 2.0, size=B))
+    for L in (1, 3):
+        C = rng.poisson(3.0, size=(L, B, N, N)).astype(np.float64)
+        C = C + C.transpose(0, 1, 3, 2) + 5.0 * np.eye(N)
+        inits = [_random_reversible_init(rng, N) for _ in range(L)]
+        ups = [orc.invert_pande_reversible(q, np.ones((N, N))) for q in inits]
+        with CherryBank(np.tile(t, (L, 1)) if L > 1 else t, C if L > 1 else C[0]) as bank:
+            got = bank.train_pande_reversible(np.array([u for u, _ in ups]) if L > 1 else ups[0][0],
+                                              np.array([p for _, p in ups]) if L > 1 else ups[0][1], num_epochs=E, lr=0.1)
+            assert bank.last_kernel_form() == (2000 if L == 1 else 3000)
+        for l in range(L):
+            ref = orc.train(t, C[l], np.ones((N, N)), upper_diag=ups[l][0], log_pi=ups[l][1], num_epochs=E, dtype=torch.float64)
+            loss = got["loss"] if L == 1 else got["loss"][:, l]
+            assert np.allclose(loss, ref["loss"], rtol=1e-9, atol=0), (L, l)
+            assert relerr(got["Q_last"] if L == 1 else got["Q_last"][l], ref["Q_last"]) < 1e-6
+    # SiteRM parameterisation at 28 states: the one-kernel trainer
+    L = 4
+    C = rng.poisson(3.0, size=(L, B, N, N)).astype(np.float64)
+    C = C + C.transpose(0, 1, 3, 2) + 5.0 * np.eye(N)
+    T = np.sort(rng.uniform(0.02, 2.0, size=(L, B)), axis=1)
+    init = np.array([_random_reversible_init(rng, N) for _ in range(L)])
+    ref = orc.siterm_train(C, T, E, initialization=init)
+    th0, Th0 = _invert(init)
+    with CherryBank(T, C) as bank:
+        got = bank.train_siterm(th0, Th0, E, lr=0.1)
+        assert bank.last_kernel_form() == 3000
+    assert np.allclose(got["loss_per_epoch_per_site"], ref["loss_per_epoch_per_site"], rtol=1e-8, atol=0)
+    assert max(relerr(got["res"][l], ref["res"][l]) for l in range(L)) < 1e-6
 
 
 def test_fused_trainers_with_empty_buckets():
