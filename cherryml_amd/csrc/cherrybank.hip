@@ -344,14 +344,19 @@ extern "C" int cb_create(int device, int S, int L, int B, int dtype, const doubl
   *out = nullptr;
   if (dtype != CB_F64 && dtype != CB_F32 && dtype != CB_MIXED)
     return fail(CB_EINVAL, "cb_create: dtype must be CB_F64, CB_F32 or CB_MIXED (got %d)", dtype);
-  if (dtype != CB_F64 && S <= 32)
-    return fail(CB_EUNSUPPORTED, "cb_create: CB_F32 / CB_MIXED are built for the MFMA-bound large path only (S > 32; got S=%d): "
-                                 "the small-state kernels are float64", S);
+  // CB_F32 / CB_MIXED live in the tile kernels of the large path (K1-K3 templated on the element type).  A single bank
+  // of ANY size can take that path (LD = 32 at 20 states: the reference's own float32 LG arithmetic, opt-in, slower
+  // than the float64 small-state kernels -- an arithmetic mode, not a fast path); batches of sites (L > 1) are float64.
+  const bool narrow = dtype != CB_F64 && !(flags & CB_EXPM_ONLY);
+  if (narrow && S <= 32 && L != 1)
+    return fail(CB_EUNSUPPORTED, "cb_create: CB_F32 / CB_MIXED with S <= 32 are built for single banks only (L == 1; got L=%d): "
+                                 "the site-batched small-state kernels are float64", L);
   if (S < 2 || L < 1 || B < 1) return fail(CB_EINVAL, "cb_create: need S>=2, L>=1, B>=1 (got %d,%d,%d)", S, L, B);
   const bool expm_only = (flags & CB_EXPM_ONLY) != 0;
   if (!t || (!C && !expm_only)) return fail(CB_EINVAL, "cb_create: t and C must not be NULL");
   if (S > 32 && L != 1)
     return fail(CB_EUNSUPPORTED, "cb_create: S > 32 is supported for L == 1 only (got L=%d)", L);
+  if (narrow && S < 4) return fail(CB_EUNSUPPORTED, "cb_create: CB_F32 / CB_MIXED need S >= 4 (got %d)", S);
   if (S > 1024) return fail(CB_EUNSUPPORTED, "cb_create: S > 1024 not supported");
   int ndev = cb_device_count();
   if (ndev <= 0) return fail(CB_EHIP, "cb_create: no HIP device visible");
@@ -363,7 +368,7 @@ extern "C" int cb_create(int device, int S, int L, int B, int dtype, const doubl
   h->L = L;
   h->B = B;
   h->B_cap = B;
-  h->large = S > 32;
+  h->large = S > 32 || narrow;
   h->dtype = expm_only ? CB_F64 : dtype;   // a counts-free handle has no bank products to narrow
   h->expm_only = expm_only;
   h->LD = (S + 15) / 16 * 16;

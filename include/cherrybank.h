@@ -77,7 +77,9 @@ int cb_device_count(void);
  * the sum over buckets and every vector / matrix crossing this ABI stay float64.  CB_MIXED keeps P_b, the
  * loss and G_b = -C_b / P_b in float64 too (the O(t^2) entries of P_b, which divide counts, keep their
  * relative accuracy), rounds G_b to float32 once and runs the two contractions G_b U and (T_b^T U) o Phi_b
- * on the float32 MFMA.  S <= 32: CB_F64 only.
+ * on the float32 MFMA.  S <= 32: a SINGLE bank (L == 1, S >= 4) takes CB_F32 / CB_MIXED through the same tile kernels
+ * (padded to 32 columns; an arithmetic mode -- the reference's own LG arithmetic --, slower than the float64 small-state
+ * kernels); batches of sites (L > 1) are CB_F64 only (CB_EUNSUPPORTED otherwise).
  */
 int cb_create(int device, int S, int L, int B, int dtype, const double *t, const double *C,
               int flags, cb_handle *out);

@@ -193,11 +193,38 @@ def test_cfg5_fp64_vs_fp32_sweep():
         assert relerr(b["Q_last"], a["Q_last"]) < tol_q and relerr(b["Q_best"], a["Q_best"]) < tol_q
 
 
-def test_f32_dtype_is_refused_for_small_state_spaces():
+def test_float32_modes_of_a_single_small_bank_vs_both_reference_runs():
+    """cb_create's dtype at S <= 32 (VERDICT r2 "missing 3"): float32 is the reference's OWN arithmetic for the LG bank
+    (ratelearner.py:98,107).  A single bank of any size takes CB_F32 / CB_MIXED through the tile kernels of the 400-state
+    path (LD = 32 at 20 states); batches of sites stay float64 and refuse.  Reported and asserted here: one evaluation and
+    the 100-epoch LG trajectory of the reference (tests/golden/traj_lgbank.npz, B = 129) in the three modes, against the
+    reference run in float64 AND as is (float32)."""
     from cherryml_amd import CherryBank
+    from oracle import ratelearn_oracle as orc
     g = load_golden("eval_s20_symmask.npz")
-    with pytest.raises(NotImplementedError):
-        CherryBank(g["t"], g["C"], dtype="f32")
+    p = np.exp(g["log_pi"] - g["log_pi"].max())
+    pi = p / p.sum()
+    for dtype, tol_loss, tol_grad in (("f64", 1e-12, 1e-10), ("mixed", 1e-12, 2e-5), ("f32", 2e-6, 2e-3)):
+        with CherryBank(g["t"], g["C"], dtype=dtype) as bank:
+            loss, dQ = bank.loss_grad(g["Q_f64"], pi, normalize=True)
+        assert abs(loss[0] - g["loss_f64"]) < tol_loss * abs(g["loss_f64"]), dtype
+        assert relerr(dQ[0], g["dQ_f64"]) < tol_grad, (dtype, relerr(dQ[0], g["dQ_f64"]))
+    z = load_golden("traj_lgbank.npz")
+    E = 100
+    u0, p0 = z["upper_diag0_f64"], z["log_pi0_f64"]
+    d_ref = relerr(z["Q_last_f32"], z["Q_last_f64"])
+    for dtype, tol_loss, tol_q in (("mixed", 1e-6, 1e-4), ("f32", 1e-5, 2e-3)):
+        with CherryBank(z["t"], z["C"], dtype=dtype) as bank:
+            r = bank.train_pande_reversible(u0, p0, num_epochs=E, lr=0.1)
+            assert bank.last_kernel_form() == 4000      # the C-driven tile-kernel loop, not the float64 small-state split
+        dl = np.abs(r["loss"] / z["loss_f64"][:E] - 1).max()
+        e64, e32 = relerr(r["Q_last"], z["Q_last_f64"]), relerr(r["Q_last"], z["Q_last_f32"])
+        print(f"LG bank, {dtype}: loss curve within {dl:.1e} of the f64 reference; Q_last to the f64 reference {e64:.2e}, to the reference's own float32 run {e32:.2e} "
+              f"(reference f32 vs f64: {d_ref:.2e})")
+        assert dl < tol_loss and e64 < tol_q and e32 < tol_q + 2 * d_ref
+    s = load_golden("siterm_aa.npz")
+    with pytest.raises(NotImplementedError):   # batches of sites: float64 only
+        CherryBank(np.asarray(s["times"]), s["counts"], dtype="f32")
     with pytest.raises(ValueError):
         CherryBank(g["t"], g["C"], dtype="bf16")
 
