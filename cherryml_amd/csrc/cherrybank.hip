@@ -1491,7 +1491,7 @@ static int run_fused_training(cb_bank *h, int kind, double *pi_param, double *up
       g.nchunk = (nquads + g.quads_per_chunk - 1) / g.quads_per_chunk;
       g.quads_per_chunk = (nquads + g.nchunk - 1) / g.nchunk;  // even split
       double *buf = nullptr;
-      const size_t nbuf = (size_t)L * LGS_TOTAL + (size_t)L * g.nchunk * 577 + L + 8;
+      const size_t nbuf = (size_t)L * LGS_TOTAL + (size_t)L * g.nchunk * 577 + L + 24;
       if (!alloc(&buf, nbuf)) rc = fail(CB_ENOMEM, "fused training: device allocation failed");
       if (rc == CB_OK) {
         g.frames = buf;
@@ -1500,24 +1500,28 @@ static int run_fused_training(cb_bank *h, int kind, double *pi_param, double *up
         g.best = g.lpart + (size_t)L * g.nchunk;
         const size_t lds_p = SPP_TOTAL * sizeof(double), lds_f = SPF_TOTAL * sizeof(double);
         const int TS = quad_ts(S);
-        double pow_b1 = 1.0, pow_b2 = 1.0;
-        for (int e = 0; e < E && rc == CB_OK; ++e) {
-          pow_b1 *= a.beta1;
-          pow_b2 *= a.beta2;
-          if (L < 64) hipLaunchKernelGGL(sp_prepare<256>, dim3(L), dim3(256), lds_p, h->stream, a, g, e);
-          else hipLaunchKernelGGL(sp_prepare<64>, dim3(L), dim3(64), lds_p, h->stream, a, g, e);
-          const dim3 gb((unsigned)((size_t)L * g.nchunk));
-          const bool w3 = (size_t)L * g.nchunk > 512;   // more workgroups than two per CU can hold at once: the three-per-CU form
-          const double bc1 = 1.0 - pow_b1, bc2s = std::sqrt(1.0 - pow_b2);
-          h->last_form = 1000 + 100 * TS + (a.sym ? 10 : 0) + (w3 ? 1 : 0);
+        const size_t lds_s = std::max(lds_p, lds_f);
+        // few sites (one LG-sized bank): finish(e - 1) and prepare(e) are ONE launch (sp_step), two launches per epoch
+        const bool fuse = L < 64;
+        double pow_b1 = 1.0, pow_b2 = 1.0, bc1_prev = 0.0, bc2s_prev = 0.0;
+        const dim3 gb((unsigned)((size_t)L * g.nchunk));
+        const bool w3 = (size_t)L * g.nchunk > 512;   // more workgroups than two per CU can hold at once: the three-per-CU form
+        h->last_form = 1000 + 100 * TS + (a.sym ? 10 : 0) + (w3 ? 1 : 0);
 #define SPK(T)                                                                                         \
   do {                                                                                                 \
+    if (fuse && e > 0) hipLaunchKernelGGL((sp_step<T>), dim3(L), dim3(256), lds_s, h->stream, a, g, e, bc1_prev, bc2s_prev);                      \
+    else if (fuse) hipLaunchKernelGGL(sp_prepare<256>, dim3(L), dim3(256), lds_p, h->stream, a, g, e);                                           \
+    else hipLaunchKernelGGL(sp_prepare<64>, dim3(L), dim3(64), lds_p, h->stream, a, g, e);                                                       \
     if (a.sym && w3) hipLaunchKernelGGL((sp_bank<T, true, true>), gb, dim3(256), spb_total(T, true, true) * sizeof(double), h->stream, a, g);      \
     else if (a.sym) hipLaunchKernelGGL((sp_bank<T, true, false>), gb, dim3(256), spb_total(T, true, false) * sizeof(double), h->stream, a, g);  \
     else if (w3) hipLaunchKernelGGL((sp_bank<T, false, true>), gb, dim3(256), spb_total(T, false, true) * sizeof(double), h->stream, a, g);     \
     else hipLaunchKernelGGL((sp_bank<T, false, false>), gb, dim3(256), spb_total(T, false, false) * sizeof(double), h->stream, a, g);           \
-    hipLaunchKernelGGL((sp_finish<T>), dim3(L), dim3(256), lds_f, h->stream, a, g, e, bc1, bc2s);       \
+    if (!fuse || e == E - 1) hipLaunchKernelGGL((sp_finish<T>), dim3(L), dim3(256), lds_f, h->stream, a, g, e, bc1, bc2s);                       \
   } while (0)
+        for (int e = 0; e < E && rc == CB_OK; ++e) {
+          pow_b1 *= a.beta1;
+          pow_b2 *= a.beta2;
+          const double bc1 = 1.0 - pow_b1, bc2s = std::sqrt(1.0 - pow_b2);
           switch (TS) {
             case 1: SPK(1); break;
             case 2: SPK(2); break;
@@ -1525,9 +1529,23 @@ static int run_fused_training(cb_bank *h, int kind, double *pi_param, double *up
             case 5: SPK(5); break;
             default: SPK(6); break;
           }
-#undef SPK
+          bc1_prev = bc1;
+          bc2s_prev = bc2s;
           if ((e & 63) == 63 && hipGetLastError() != hipSuccess) rc = fail(CB_EHIP, "fused training launch failed");
         }
+#undef SPK
+#ifdef CB_SP_STAMPS
+        if (fuse && E > 301) {
+          unsigned long long st[10];
+          (void)hipStreamSynchronize(h->stream);
+          (void)hipMemcpy(st, g.best, sizeof st, hipMemcpyDeviceToHost);
+          // (stamps 0-4: finish(300), inside the launch of epoch 301; stamps 5-8: prepare(300), inside the launch of epoch 300)
+          const char *nm[] = {"finish: frames in", "finish: M sum + loss", "finish: dA = U M U^T", "finish: tr_update", "-",
+                              "prepare: tr_build", "prepare: eigensolver", "prepare: pad + frames out"};
+          for (int i = 0; i < 8; ++i)
+            if (i != 4) fprintf(stderr, "[cherrybank] sp_step epoch 300: %-30s %7.2f us\n", nm[i], (double)(st[2 + i] - st[1 + i]) * 0.01);
+        }
+#endif
       }
     } else if (E > 0 && split) {
       // one LG-sized bank: the epoch spread over the chip, three small launches per epoch

@@ -412,18 +412,24 @@ struct SpSplit {
 // optimisation is ~8 20 x 20 products instead of two or three 19-round Jacobi sweeps)
 // NTH = 64 for many sites (above); a few sites (one LG-sized bank) take 256 threads: theta -> A, the frame copies and
 // the Q_last write are then spread over four waves (the single wave spent more time there than in the eigensolver)
+#ifdef CB_SP_STAMPS   // build-time experiment: phase stamps of site 0 at epoch 300 into g.best[1 + i] (100 MHz ticks)
+#define SP_STAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0 && epoch == 300) ((unsigned long long *)g.best)[1 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define SP_STAMP(i) do { } while (0)
+#endif
 template <int NTH>
-__global__ __launch_bounds__(NTH, 2) void sp_prepare(TrainArgs a, SpSplit g, int epoch) {
-  extern __shared__ double lds[];
+__device__ __forceinline__ void sp_prepare_body(const TrainArgs &a, const SpSplit &g, int epoch, double *lds, bool v_resident) {
   double *sA = lds + SPP_A, *sG = lds + SPP_G, *sV = lds + SPP_V, *sLam = lds + SPP_LAM, *sD = lds + SPP_D,
          *sPi = lds + SPP_PI;
   const int S = a.S, tid = threadIdx.x, l = blockIdx.x;
   double *fr = g.frames + (size_t)l * LGS_TOTAL;
+  SP_STAMP(5);
   if (epoch == 0 && tid == 0) g.best[l] = INFINITY;
-  if (epoch > 0)  // previous eigenvectors: warm start (issued first: the loads fly while theta -> A is computed)
+  if (epoch > 0 && !v_resident)  // previous eigenvectors: warm start (issued first: the loads fly while theta -> A is computed)
     for (int e = tid; e < SP_ROWS * CB_LS; e += NTH) sV[e] = fr[LGS_V + e];
   tr_build(a, l, epoch, sA, sD, sPi);
   __syncthreads();
+  SP_STAMP(6);
   if (NTH == 64 || tid < 64) {
     if (epoch > 0) wave_eigh_rate_warm_mfma<24>(S, sA, sG, sV, lds + SPP_X, lds + SPP_DG, sLam, CB_LS);
     else wave_eigh_rate(S, sA, sG, sV, sLam, CB_LS, false);
@@ -435,6 +441,7 @@ __global__ __launch_bounds__(NTH, 2) void sp_prepare(TrainArgs a, SpSplit g, int
   }
   for (int k = S + tid; k < 32; k += NTH) sLam[k] = 0.0;
   __syncthreads();
+  SP_STAMP(7);
   for (int e = tid; e < SP_ROWS * CB_LS; e += NTH) {
     fr[LGS_A + e] = sA[e];
     fr[LGS_V + e] = sV[e];
@@ -444,6 +451,13 @@ __global__ __launch_bounds__(NTH, 2) void sp_prepare(TrainArgs a, SpSplit g, int
     fr[LGS_D + tid] = sD[tid];
     fr[LGS_PI + tid] = sPi[tid];
   }
+  SP_STAMP(8);
+}
+
+template <int NTH>
+__global__ __launch_bounds__(NTH, 2) void sp_prepare(TrainArgs a, SpSplit g, int epoch) {
+  extern __shared__ double lds[];
+  sp_prepare_body<NTH>(a, g, epoch, lds, false);
 }
 
 // bank LDS: only the first 24 rows of the A / V frames are touched for S <= 20; Mw = [wave][tile][lane]
@@ -533,12 +547,12 @@ __global__ __launch_bounds__(256, spb_wgs(TS, SYM, W3)) void sp_bank(TrainArgs a
 #define SPF_TOTAL (SPF_RED + 1056)
 
 template <int TS>
-__global__ __launch_bounds__(256) void sp_finish(TrainArgs a, SpSplit g, int epoch, double bc1, double bc2s) {
-  extern __shared__ double lds[];
+__device__ __forceinline__ void sp_finish_body(const TrainArgs &a, const SpSplit &g, int epoch, double bc1, double bc2s, double *lds) {
   double *sA = lds + SPF_A, *sG = lds + SPF_G, *sV = lds + SPF_V, *sD = lds + SPF_D, *sPi = lds + SPF_PI,
          *sGd = lds + SPF_GD, *sFlag = lds + SPF_FLAG, *sRed = lds + SPF_RED;
   const int S = a.S, tid = threadIdx.x, l = blockIdx.x;
   const double *fr = g.frames + (size_t)l * LGS_TOTAL;
+  SP_STAMP(0);
   for (int e = tid; e < SP_ROWS * CB_LS; e += 256) {
     sA[e] = fr[LGS_A + e];
     sV[e] = fr[LGS_V + e];
@@ -549,6 +563,7 @@ __global__ __launch_bounds__(256) void sp_finish(TrainArgs a, SpSplit g, int epo
     sPi[tid] = fr[LGS_PI + tid];
   }
   __syncthreads();
+  SP_STAMP(1);
   // M = sum over the chunks in a fixed order; entry e = tile * 16 + 4 i + j
   const double *Mp = g.Mpart + (size_t)l * g.nchunk * 576;
   for (int e = tid; e < 16 * TS * TS; e += 256) {
@@ -574,6 +589,26 @@ __global__ __launch_bounds__(256) void sp_finish(TrainArgs a, SpSplit g, int epo
     }
   }
   __syncthreads();
+  SP_STAMP(2);
   small_dA_from_M(S, sG, sV, sRed);
+  SP_STAMP(3);
   tr_update(a, l, epoch, sFlag[2], bc1, bc2s, sA, sG, sD, sPi, sGd, sFlag, sRed, g.best + l);
+  SP_STAMP(4);
+}
+
+template <int TS>
+__global__ __launch_bounds__(256) void sp_finish(TrainArgs a, SpSplit g, int epoch, double bc1, double bc2s) {
+  extern __shared__ double lds[];
+  sp_finish_body<TS>(a, g, epoch, bc1, bc2s, lds);
+}
+
+// Few sites (one LG-sized bank): sp_finish of epoch e - 1 and sp_prepare of epoch e in ONE launch -- the eigenvectors
+// the finish just used are the warm start of the next solve and are already in LDS (the two frame layouts agree on A, G
+// and V), a launch boundary (~3 us) and a frame read go away.  An epoch is then two launches: sp_step, sp_bank.
+template <int TS>
+__global__ __launch_bounds__(256, 2) void sp_step(TrainArgs a, SpSplit g, int epoch, double bc1_prev, double bc2s_prev) {
+  extern __shared__ double lds[];
+  static_assert(SPF_A == SPP_A && SPF_G == SPP_G && SPF_V == SPP_V, "finish and prepare share the A / G / V frames");
+  sp_finish_body<TS>(a, g, epoch - 1, bc1_prev, bc2s_prev, lds);   // (ends with a barrier; parameters are updated)
+  sp_prepare_body<256>(a, g, epoch, lds, true);
 }
