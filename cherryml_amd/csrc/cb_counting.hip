@@ -84,7 +84,10 @@ static int launch_count_co_transitions(int device, int S, int B, const double *g
   }
   if (reinterpret_cast<uintptr_t>(contacts) & 7) return fail(CB_EINVAL, "cb_count_co_transitions: the contact list must be 8-byte aligned");
   const int nrb = (S2 + R - 1) / R;
-  const int target = 2048;
+#ifndef CO_TARGET
+#define CO_TARGET 1024   // measured on the 10,000-family bench input: 512 -> 0.684, 1024 -> 0.659, 2048 -> 0.760, 4096 -> 0.990 ms
+#endif
+  const int target = CO_TARGET;   // work items of the whole pass (about; see co_plan_kernel)
   const int max_work = target + (B + 8) * nrb;
   const unsigned pair_blocks = (unsigned)((n_pairs + CO_THREADS - 1) / CO_THREADS);
   // scratch layout (8-byte words): bucket_ev[B] cursor[B] | bucket_off[B+1] n_work[1] work[4 * max_work] qbuf events

@@ -85,6 +85,33 @@ def test_coevolution_pipeline_on_demo_data(tmp_path):
     assert d32 < 1e-3
 
 
+def test_coevolution_resident_chain_equals_the_file_passing_pipeline(tmp_path):
+    """count -> JTT-IPW -> optimise as ONE resident chain (estimation_end_to_end/_resident.py: device-resident counts, the
+    initialiser from two reduced S x S sums, no 84 MB count file between the stages) against the same reference golden
+    as the pipeline above: initialiser 1e-11, learned Q 1e-6 (stated tolerance), and the reference's float32 result."""
+    import cherryml_amd
+    from cherryml_amd import caching
+    from cherryml_amd.estimation_end_to_end import coevolution_fit_resident, create_maximal_matching_contact_map
+    z = load_golden("demo_e2e.npz")
+    dirs, fams = _materialise(tmp_path, z)
+    mask = np.unpackbits(z["co_mask_packed"])[:160000].reshape(400, 400).astype(np.float64)
+    caching.set_cache_dir(str(tmp_path / "cache"))
+    try:
+        cm_dir = create_maximal_matching_contact_map(
+            i_contact_map_dir=dirs["contact_map"], families=fams, minimum_distance_for_nontrivial_contact=7,
+            num_processes=1)["o_contact_map_dir"]
+    finally:
+        caching.set_cache_dir(None)
+    grid = [float(q) for q in z["quantization_points"]]
+    r = coevolution_fit_resident(tree_dir=dirs["tree"], msa_dir=dirs["msa"], contact_map_dir=cm_dir, families=fams,
+                                 amino_acids=AA, quantization_points=grid, edge_or_cherry="cherry++",
+                                 minimum_distance_for_nontrivial_contact=7, mask=mask, num_epochs=int(z["co_epochs"]))
+    assert r["n_pairs"] == float(z["co_counts_val"].sum())
+    assert np.allclose(r["initialization"], z["co_init"], rtol=1e-11, atol=1e-15)
+    assert relerr(r["Q_best"], z["co_Q_best_f64"]) < 1e-6
+    assert relerr(r["Q_best"], z["co_learned_f32"]) < 1e-3
+
+
 def test_public_api_lg_with_given_trees_and_with_fast_cherries(tmp_path):
     """`cherryml_public_api` (what `python -m cherryml` calls).  With the demo trees handed over it is the
     LG pipeline above (same golden, same tolerance).  With `tree_estimator_name="FastCherries"` and two

@@ -295,3 +295,23 @@ def test_native_formatter_writes_the_bytes_of_repr(tmp_path):
     q, C, st = F.read_count_matrices_arrays(str(tmp_path / "c.txt"))
     assert st == states and list(q) == [0.03, 6.729e-05]
     assert np.array_equal(C[0], cm[0][1].to_numpy()) and np.array_equal(C[1], cm[1][1].to_numpy())
+
+
+def test_jtt_ipw_from_two_reduced_sums_equals_the_tensor_form():
+    """The resident chain (estimation_end_to_end/_resident.py) initialises from sum_b sym(C_b) and sum_b sym(C_b) / t_b
+    -- what the ranks all-reduce instead of the 165 MB tensor --: the same matrix as jtt_ipw_from_arrays on the tensor."""
+    from cherryml_amd.estimation import jtt_ipw_from_arrays
+    from cherryml_amd.estimation_end_to_end import jtt_ipw_from_reduced_statistics
+    rng = np.random.default_rng(3)
+    B, S = 17, 12
+    t = np.sort(rng.uniform(0.01, 3.0, B))
+    C = rng.poisson(2.0, size=(B, S, S)).astype(np.float64)
+    C[::4] = 0.0
+    mask = (rng.random((S, S)) < 0.6).astype(np.float64)
+    mask = np.maximum(mask, mask.T)
+    np.fill_diagonal(mask, 1.0)
+    Cs = 0.5 * (C + C.transpose(0, 2, 1))
+    for m in (None, mask):
+        want = jtt_ipw_from_arrays(t, C, m)
+        got = jtt_ipw_from_reduced_statistics(Cs.sum(0), (Cs / t[:, None, None]).sum(0), t, m)
+        assert np.allclose(got, want, rtol=1e-12, atol=1e-14)
