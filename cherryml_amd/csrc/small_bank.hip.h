@@ -283,10 +283,12 @@ __device__ __forceinline__ void quad_load_counts(double (&cv)[TS][TS], const dou
 // ULDS: the B-layout tiles of U are re-read from LDS where they are used (25 ds_read_b64 per tile row of the T and
 // W phases) instead of living in 2 TS^2 registers across both phases -- the register peak drops by ~50, which is what
 // lets three workgroups share a CU (sp_bank).
-template <int TS, bool LANEM, bool SYM = false, bool ULDS = false>
+// LOGT: the logarithms of the loss by table (fast_log_table; `ltab` = 256 doubles of LDS filled by fast_log_table_fill)
+template <int TS, bool LANEM, bool SYM = false, bool ULDS = false, bool LOGT = false>
 __device__ __forceinline__ void small_quad(int S, double tb, const double *__restrict__ Cq, double inv_n,
                                            const double *sA, const double *sV, double *tabw,
-                                           const double *sLam, double rho, double *Mw, double &lossacc) {
+                                           const double *sLam, double rho, double *Mw, double &lossacc,
+                                           const double *ltab = nullptr) {
   const int lane = threadIdx.x & 63, q = lane >> 4, blk = (lane >> 2) & 3, r = lane & 3;
   // counts of this quad: issued first (coalesced, 64 consecutive doubles per load), consumed by the
   // epilogue after the table computation and the first MFMA row -- no registers held across quads
@@ -351,7 +353,7 @@ __device__ __forceinline__ void small_quad(int S, double tb, const double *__res
         const double c = cv[I][J];
         const bool nz = c != 0.0;
         // (SYM: an off-diagonal tile stands for its mirror image too)
-        lossacc = fma((SYM && J > I) ? -2.0 * c : -c, fast_log(nz ? pt : 1.0), lossacc);
+        lossacc = fma((SYM && J > I) ? -2.0 * c : -c, LOGT ? fast_log_table(nz ? pt : 1.0, ltab) : fast_log(nz ? pt : 1.0), lossacc);
         g[I][J] = nz ? -c * inv_n * fast_rcp(pt) : 0.0;
       }
       // pin the loss here: otherwise the compiler sinks all TS^2 logarithms (they feed nothing but

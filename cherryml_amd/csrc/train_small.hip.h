@@ -479,7 +479,7 @@ __host__ __device__ constexpr bool spb_w3_ok(int TS, bool SYM) { return CB_SPB_W
 __host__ __device__ constexpr int spb_wgs(int TS, bool SYM, bool W3) { return (W3 && spb_w3_ok(TS, SYM)) ? 3 : 2; }
 __host__ __device__ constexpr int spb_mws(int TS, bool SYM, bool W3) { return (TS <= 5 && spb_wgs(TS, SYM, W3) < 3) ? 1600 : 576; }   // M doubles per wave
 // after Mw: 8 doubles of loss partials; Mw = 4 waves x spb_mws doubles ([tile][64] per wave: 1600, or [tile][16]: 576)
-__host__ __device__ constexpr int spb_total(int TS, bool SYM, bool W3) { return SPB_MW + 4 * spb_mws(TS, SYM, W3) + 8; }
+__host__ __device__ constexpr int spb_total(int TS, bool SYM, bool W3) { return SPB_MW + 4 * spb_mws(TS, SYM, W3) + 8 + 256; }   // + the log table
 // W3: the three-workgroup form (many sites); the two-workgroup form keeps U's tiles in registers and is the faster one
 // per quad, which is what counts when the grid does not fill the chip (one LG-sized bank)
 template <int TS, bool SYM = false, bool W3 = false>   // SYM: all count matrices symmetric (small_quad's symmetric form)
@@ -497,6 +497,8 @@ __global__ __launch_bounds__(256, spb_wgs(TS, SYM, W3)) void sp_bank(TrainArgs a
   constexpr bool LANEM = spb_mws(TS, SYM, W3) == 1600;   // per-lane M slots while they fit LDS (2 workgroups per CU)
   constexpr int MWS = spb_mws(TS, SYM, W3);             // doubles per wave
   constexpr int SPB_LOSS = SPB_MW + 4 * MWS;
+  const double *ltab = lds + SPB_LOSS + 8;   // (16-byte aligned: every offset before it is even)
+  fast_log_table_fill(lds + SPB_LOSS + 8, tid, 256);
   double *Mw = lds + SPB_MW + wave * MWS;
   for (int e = lane; e < (LANEM ? 64 : 16) * TS * TS; e += 64) Mw[e] = 0.0;
   __syncthreads();
@@ -512,8 +514,8 @@ __global__ __launch_bounds__(256, spb_wgs(TS, SYM, W3)) void sp_bank(TrainArgs a
   for (int qd = q0 + wave; qd < q1; qd += 4) {
     const int bucket = 4 * qd + blk;
     const double tb = bucket < Bn ? t_l[bucket] : 0.0;
-    small_quad<TS, LANEM, SYM, (spb_wgs(TS, SYM, W3) >= 3)>(S, tb, Cq_l + (size_t)qd * (TS * TS * 64), inv_n, sA, sV, lds + SPB_TAB + wave * 384, sLam,
-                         rho, Mw, lossacc);
+    small_quad<TS, LANEM, SYM, (spb_wgs(TS, SYM, W3) >= 3), true>(S, tb, Cq_l + (size_t)qd * (TS * TS * 64), inv_n, sA, sV,
+                                                                   lds + SPB_TAB + wave * 384, sLam, rho, Mw, lossacc, ltab);
   }
   lossacc = wave_sum(lossacc);
   if (lane == 0) lds[SPB_LOSS + wave] = lossacc;
