@@ -1,0 +1,183 @@
+// The handle (`struct cb_bank`) and its host-side helpers: event sets of the phase timer, device / workspace /
+// pinned-staging allocation.  Included by cherrybank.hip (one translation unit; see eigh_large_host.hip.h).
+#pragma once
+// ------------------------------------------------------------------ handle
+struct cb_bank {
+  int dev = 0, S = 0, L = 0, B = 0;
+  int B_cap = 0;        // B at creation (cb_internal_set_times may lower B)
+  // the optimisation a later CB_TRAIN_RESUME call continues (large fused trainer): epochs done, Adam's beta powers,
+  // and what the call looked like (mask, moments) -- a resumed call must look the same
+  hipStream_t xstream[3] = {};     // CB_BANK_STREAMS: extra queues, each with its share of the buckets
+  hipEvent_t ev_fork = nullptr, ev_join[3] = {};
+  int tr_epochs = 0;
+  uint64_t tr_sig = 0;
+  int last_form = 0;    // which trainer kernels the last training call launched (cb_last_kernel_form)
+  double tr_pow_b1 = 1.0, tr_pow_b2 = 1.0;
+  int dtype = CB_F64;   // element type of the bank products (large path): CB_F64 or CB_F32
+  int LD = 0;           // large path: padded leading dimension
+  bool large = false;
+  hipStream_t own_stream = nullptr, stream = nullptr;
+  std::vector<void *> allocs;
+  std::vector<double> n_host;  // [L]
+  // resident bank
+  double *t = nullptr;       // [L,B]
+  double *Ct = nullptr;      // small: [L,B,S,S]; large: [B,LD,LD]
+  double *n_dev = nullptr;   // [L]
+  double *inv_n = nullptr;   // [L]  1/n
+  double *ones = nullptr;    // [L]  1.0
+  double *Cq = nullptr;      // S <= 24: counts in quad order [L][nq][TS*TS][64]
+  int nq = 0;
+  double *dirsum = nullptr;  // [L,S] colsum - rowsum of sum_b C
+  double *dirsum_g = nullptr;  // the same summed over the ranks (cb_allreduce_setup; the trainers' direct pi term)
+  // live buckets (C_b != 0), stored first per site; Bl = max over sites = stride of Ct / t_live
+  int Bl = 0;
+  double *t_live = nullptr;  // [L,Bl]
+  int *nlive = nullptr;      // [L] device
+  std::vector<int> nlive_host;
+  // staging for host-pointer calls
+  double *Q = nullptr, *pi = nullptr, *loss = nullptr, *dQ = nullptr;
+  int *status = nullptr;
+  // large-path workspaces
+  double *Gc2 = nullptr, *gx = nullptr;  // second column buffer and 12 LD^2 + LD scratch of the first-order / hybrid sweeps
+  int last_light = 0;
+  // in-library all-reduce (cb_allreduce_setup)
+  void *comm = nullptr;
+  int (*allreduce)(const void *, void *, size_t, int, int, void *, hipStream_t) = nullptr;
+  double *inv_n_global = nullptr;  // [L] 1 / n_total
+  std::vector<double> n_global;
+  bool expm_only = false;   // created with CB_EXPM_ONLY: no counts, no loss / training entry points
+  bool sym_counts = false;  // every live bucket has C_b == C_b^T (cherry counts are, by construction)
+  int spec_sweeps = 0;  // Jacobi sweeps to enqueue before the first host check (learned from the previous solve)
+  double *A = nullptr, *dsq = nullptr, *Gc = nullptr, *Vc = nullptr, *U = nullptr, *lam = nullptr,
+         *sigma = nullptr, *F = nullptr, *E = nullptr, *H = nullptr, *Gt = nullptr, *T = nullptr,
+         *Mt_part = nullptr, *Mt = nullptr, *X = nullptr, *loss_part = nullptr;
+  // CB_F32 (large path): counts, Gt / W, T and the per-epoch operand copies in float32
+  float *Ct32 = nullptr, *Gt32 = nullptr, *T32 = nullptr, *Uf = nullptr, *Utf = nullptr, *Af = nullptr, *Ff = nullptr;
+  unsigned long long *off_bits = nullptr;
+  unsigned long long *poll = nullptr;      // 8 words of coherent pinned host memory the first-order sweep publishes to
+  unsigned long long poll_seq = 0;
+  int k3_chunk = 0, k3_nchunks = 0;
+  int last_sweeps = 0;
+  double *gn_scratch = nullptr, *gn_partial = nullptr;  // general path, allocated on first use
+  int gn_nw = 0;
+  // general path, S > 32 (general_large.hip.h), allocated on first use / grown with the number of squarings
+  struct {
+    double *Qn = nullptr, *QT = nullptr, *colsum = nullptr, *alpha = nullptr, *R = nullptr, *RT = nullptr, *E = nullptr,
+           *ET = nullptr, *G = nullptr, *GT = nullptr, *Xbar = nullptr, *lpart = nullptr;
+    int *nsq = nullptr;
+    int cap_slots = 0;   // squaring slots E / ET can hold
+  } gl;
+  std::vector<double> t_host, t_live_host;   // branch lengths on the host (all buckets / live buckets first), L == 1
+  bool have_prev = false;  // h->U / h->Vc hold the eigenvectors of the previous solve
+  // trainer workspaces, kept between calls (hipMalloc / hipFree cost milliseconds each)
+  double *ws_ptr[16] = {};
+  size_t ws_cap[16] = {};
+  // pinned staging for the trainers' parameter / result transfers: hipMemcpyAsync straight from
+  // fresh pageable user arrays re-pins pages and was measured at ~20 ms per call
+  char *pin = nullptr;
+  size_t pin_cap = 0, pin_off = 0;
+  // profiling
+  bool profile = false;
+  hipEvent_t ev[CB_T_COUNT + 1] = {};
+  bool ev_rec[CB_T_COUNT + 1] = {};
+  double t_sum[CB_T_COUNT] = {};
+  int t_calls = 0;
+  bool t_pending = false;  // last profiled call not yet folded into t_sum
+  // second event set: the C-driven trainer alternates between the two, so that folding an epoch's
+  // phase times never waits for the epoch just enqueued (that wait starved the queue: ~30 us of
+  // launch gaps at the start of every profiled epoch)
+  hipEvent_t ev2[CB_T_COUNT + 1] = {};
+  bool ev_rec2[CB_T_COUNT + 1] = {};
+  bool t_pending2 = false;
+};
+
+static void swap_event_sets(cb_bank *h) {
+  for (int i = 0; i <= CB_T_COUNT; ++i) {
+    std::swap(h->ev[i], h->ev2[i]);
+    std::swap(h->ev_rec[i], h->ev_rec2[i]);
+  }
+  std::swap(h->t_pending, h->t_pending2);
+}
+
+static void fold_pending(cb_bank *h);
+// event i marks the END of phase i-1 .. see mark()
+enum { EV_START = 0, EV_EIGH, EV_K1, EV_K2, EV_K3, EV_K4, EV_SMALL, EV_END };
+static void mark(cb_bank *h, int which) {
+  if (!h->profile) return;
+  if (!h->ev[which]) (void)hipEventCreate(&h->ev[which]);
+  (void)hipEventRecord(h->ev[which], h->stream);
+  h->ev_rec[which] = true;
+}
+
+template <typename T>
+static int dev_alloc(cb_bank *h, T **p, size_t count) {
+  void *q = nullptr;
+  hipError_t e = hipMalloc(&q, count * sizeof(T) + 64);
+  if (e != hipSuccess)
+    return fail(CB_ENOMEM, "hipMalloc of %zu bytes failed: %s", count * sizeof(T),
+                hipGetErrorString(e));
+  h->allocs.push_back(q);
+  *p = static_cast<T *>(q);
+  return CB_OK;
+}
+#define ALLOC(ptr, count)                         \
+  do {                                            \
+    int rc_ = dev_alloc(h, &(ptr), (count));      \
+    if (rc_ != CB_OK) return rc_;                 \
+  } while (0)
+
+// workspace slot `slot` with room for `n` doubles (grown on demand -- generously, because a
+// hipFree + hipMalloc pair stalls the next call by ~13 ms -- and freed with the handle)
+static bool ws_get(cb_bank *h, int slot, size_t n, double **out) {
+  if (n == 0) n = 1;
+  if (h->ws_cap[slot] < n) {
+    size_t want = 4096;
+    while (want < n) want *= 2;
+    if (want * sizeof(double) <= (size_t)256 << 20) n = want;
+    if (h->ws_ptr[slot]) {
+      (void)hipStreamSynchronize(h->stream);
+      (void)hipFree(h->ws_ptr[slot]);
+      h->ws_ptr[slot] = nullptr;
+      h->ws_cap[slot] = 0;
+    }
+    void *q = nullptr;
+    if (hipMalloc(&q, n * sizeof(double) + 64) != hipSuccess) return false;
+    h->ws_ptr[slot] = static_cast<double *>(q);
+    h->ws_cap[slot] = n;
+  }
+  *out = h->ws_ptr[slot];
+  return true;
+}
+
+static bool pin_reserve(cb_bank *h, size_t bytes) {
+  h->pin_off = 0;
+  if (h->pin_cap >= bytes) return true;
+  if (h->pin) {
+    (void)hipStreamSynchronize(h->stream);
+    (void)hipHostFree(h->pin);
+    h->pin = nullptr;
+    h->pin_cap = 0;
+  }
+  size_t want = (size_t)1 << 20;
+  while (want < bytes) want *= 2;
+  void *q = nullptr;
+  if (hipHostMalloc(&q, want, hipHostMallocDefault) != hipSuccess) return false;
+  h->pin = static_cast<char *>(q);
+  h->pin_cap = want;
+  return true;
+}
+// host -> device through the staging buffer (asynchronous; the slice stays reserved until the
+// next pin_reserve)
+static hipError_t h2d_staged(cb_bank *h, void *dst, const void *src, size_t bytes) {
+  char *slice = h->pin + h->pin_off;
+  h->pin_off += (bytes + 63) & ~(size_t)63;
+  memcpy(slice, src, bytes);
+  return hipMemcpyAsync(dst, slice, bytes, hipMemcpyHostToDevice, h->stream);
+}
+// device -> staging slice (asynchronous); *slice_out is valid after the stream is synchronised
+static hipError_t d2h_staged(cb_bank *h, const void *src, size_t bytes, char **slice_out) {
+  char *slice = h->pin + h->pin_off;
+  h->pin_off += (bytes + 63) & ~(size_t)63;
+  *slice_out = slice;
+  return hipMemcpyAsync(slice, src, bytes, hipMemcpyDeviceToHost, h->stream);
+}
