@@ -328,44 +328,17 @@ __device__ double wave_rotation_cross16_regs(const double *Gam, double *Rc, int 
 
 
 // ---------------------------------------------------------------------------------------------------------------
-// Warm-started FIRST-ORDER sweeps on the matrix cores (one wavefront, n <= 32).  An optimiser step perturbs A a little,
+// Warm-started FIRST-ORDER sweeps on the matrix cores (one wavefront, n <= 24).  An optimiser step perturbs A a little,
 // so the columns of G = A' U_prev are already nearly orthogonal; a whole Jacobi sweep then spends n - 1 dependent
 // rounds (LDS round trip, three reductions, two rsqrt each: ~30k cycles at n = 20) on rotations whose angles are all
 // small.  Small angles commute to first order, so ALL pairs are rotated at once:
 //     Gamma = G^T G,     X_ij = Gamma_ij / (Gamma_jj - Gamma_ii)   (the small-angle limit of every pair's rotation;
 //     G <- G exp(X)       antisymmetric),  exp(X) applied to G term by term: T_0 = G, T_k = T_{k-1} X / k
-// with as many terms as the bound ||X|| <= max_j sum_i |X_ij| needs for a remainder below 1e-17 -- so the implicit
-// V <- V exp(X) stays orthogonal to rounding.  Each term is ONE n x n product = NT^2 KS v_mfma_f64_16x16x4 from LDS
-// (~1k cycles).  An iteration squares the cosines (like a Jacobi sweep); the one that STARTED below CB_JAC_STOP is the
-// last.  Pairs that are nearly degenerate make X large (||X|| > 0.5: the first epochs of an optimisation, equal-rate
-// models): that iteration is an exact Jacobi sweep instead.  Layouts: Gc / Tc column-major (column k at k * LS), X
-// row-major; every operand outside n x n is fed as zero.
-template <int NT, int KS>
-__device__ __forceinline__ void wave_mm(int n, const double *Af, int ams, int aks, const double *Bf, int bks, int bns,
-                                        d4 (&acc)[NT][NT]) {
-  const int lane = threadIdx.x & 63, lo = lane & 15, hi = lane >> 4;
-  double a[NT][KS], b[NT][KS];
-#pragma unroll
-  for (int x = 0; x < NT; ++x)
-#pragma unroll
-    for (int s = 0; s < KS; ++s) {
-      const int m = 16 * x + lo, k = 4 * s + hi;
-      const bool ok = m < n && k < n;
-      const int mc = min(m, n - 1), kc = min(k, n - 1);
-      const double av = Af[mc * ams + kc * aks], bv = Bf[kc * bks + mc * bns];
-      a[x][s] = ok ? av : 0.0;
-      b[x][s] = ok ? bv : 0.0;
-    }
-#pragma unroll
-  for (int mt = 0; mt < NT; ++mt)
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-      d4 c = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-      for (int s = 0; s < KS; ++s) c = mfma_f64(a[mt][s], b[nt][s], c);
-      acc[mt][nt] = c;
-    }
-}
+// with as many terms as the bound ||X||_2 <= ||X||_F needs for a remainder below 1e-17 -- so the implicit
+// V <- V exp(X) stays orthogonal to rounding.  Each term is ONE n x n product on the matrix cores from LDS.  An
+// iteration squares the cosines (like a Jacobi sweep); the one that STARTED below CB_JAC_STOP is the last.  Pairs that
+// are nearly degenerate make X large (||X|| > 0.5: the first epochs of an optimisation, equal-rate models): that
+// iteration is an exact Jacobi sweep instead.  Layouts: Gc / Tc column-major (column k at k * LS), X row-major.
 
 // smallest Taylor degree m with x^(m+1) / (m+1)! < 1e-17
 __device__ __forceinline__ int fo_taylor_degree(double x) {
@@ -380,72 +353,86 @@ __device__ __forceinline__ int fo_taylor_degree(double x) {
 #define CB_FO_MAX_NORM 0.5
 #define CB_FO_MAX_ITERS 48
 
-// Gc = A' Uc on entry is formed here (Uc = the previous eigenvectors); on return the columns of Gc are orthogonal.
-// Uc is used as the Taylor-term scratch after that; X: one more n x LS frame; dg: n doubles.  Returns the iterations.
-template <int NT, int KS>
-__device__ int wave_orthogonalise_first_order(int n, const double *A, double sigma, double *Gc, double *Uc, double *X,
-                                              double *dg, int LS) {
-  const int lane = threadIdx.x & 63, lo = lane & 15, hi = lane >> 4;
-  d4 acc[NT][NT];
+// The products run on v_mfma_f64_4x4x4 (FOUR independent 4 x 4 x 4 products per instruction, 16 cycles): 5 x 5 tiles
+// of 4 x 4 at 20 states = 125 tile products = 35 instructions (7 output slots x 5 k-steps, slot s / block b = tile
+// 4 s + b) = 560 cycles of matrix pipe per product.  (The first version multiplied a frame padded to 32 x 32 with
+// v_mfma_f64_16x16x4: 24 instructions of 64 cycles = 1536 cycles, a third of them useful -- 12.0 us of eigensolver per
+// LG epoch late in an optimisation; this form: LG epoch 50.0 -> 45.9 us, SiteRM 1.41 -> 1.36 ms.)
+// Lane = 16 q + 4 b + r holds A_b[i = r][k = q], B_b[k = q][j = r], D_b[i = q][j = r] (common.hip.h).
+// REQUIRES: every frame (A, Gc, Uc, X) zero outside n x n up to 4 TS rows / columns (no bounds tests on operands).
+template <int TS>
+struct Mm4 {
+  static constexpr int NT = TS * TS, NS = (NT + 3) / 4;
+};
+
+template <int TS>
+__device__ __forceinline__ void wave_mm4(const double *Af, int ams, int aks, const double *Bf, int bks, int bns,
+                                         const int (&ti)[Mm4<TS>::NS], const int (&tj)[Mm4<TS>::NS],
+                                         double (&acc)[Mm4<TS>::NS]) {
+  constexpr int NS = Mm4<TS>::NS;
+  const int lane = threadIdx.x & 63, q = lane >> 4, r = lane & 3;
+  double a[NS][TS], b[NS][TS];
+#pragma unroll
+  for (int s = 0; s < NS; ++s)
+#pragma unroll
+    for (int K = 0; K < TS; ++K) {
+      a[s][K] = Af[(4 * ti[s] + r) * ams + (4 * K + q) * aks];
+      b[s][K] = Bf[(4 * K + q) * bks + (4 * tj[s] + r) * bns];
+    }
+#pragma unroll
+  for (int s = 0; s < NS; ++s) {
+    double c = 0.0;
+#pragma unroll
+    for (int K = 0; K < TS; ++K) c = mfma4_f64(a[s][K], b[s][K], c);
+    acc[s] = c;
+  }
+}
+
+template <int TS>
+__device__ int wave_orthogonalise_first_order4(int n, const double *A, double sigma, double *Gc, double *Uc, double *X,
+                                               double *dg, int LS) {
+  constexpr int NS = Mm4<TS>::NS, NT = Mm4<TS>::NT;
+  const int lane = threadIdx.x & 63, q = lane >> 4, blk = (lane >> 2) & 3, r = lane & 3;
+  int ti[NS], tj[NS], row[NS], col[NS];
+  bool live[NS];
+#pragma unroll
+  for (int s = 0; s < NS; ++s) {
+    const int t = 4 * s + blk;
+    live[s] = t < NT;
+    const int tc = live[s] ? t : NT - 1;   // a dead block repeats the last tile (its result is ignored)
+    ti[s] = tc / TS;
+    tj[s] = tc - ti[s] * TS;
+    row[s] = 4 * ti[s] + q;
+    col[s] = 4 * tj[s] + r;
+  }
+  double acc[NS];
   // ---- G0 = A' U = A U - sigma U
-  wave_mm<NT, KS>(n, A, LS, 1, Uc, 1, LS, acc);
+  wave_mm4<TS>(A, LS, 1, Uc, 1, LS, ti, tj, acc);
 #pragma unroll
-  for (int mt = 0; mt < NT; ++mt)
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int row = 16 * mt + hi + 4 * r, col = 16 * nt + lo;
-        if (row < n && col < n) Gc[col * LS + row] = fma(-sigma, Uc[col * LS + row], acc[mt][nt][r]);
-      }
+  for (int s = 0; s < NS; ++s)
+    if (live[s]) Gc[col[s] * LS + row[s]] = fma(-sigma, Uc[col[s] * LS + row[s]], acc[s]);
   wave_lds_fence();
   int it = 0;
   for (; it < CB_FO_MAX_ITERS; ++it) {
-    // ---- Gamma = G^T G, its diagonal through LDS
-    d4 gam[NT][NT];
-    wave_mm<NT, KS>(n, Gc, LS, 1, Gc, 1, LS, gam);
+    double gam[NS];
+    wave_mm4<TS>(Gc, LS, 1, Gc, 1, LS, ti, tj, gam);
 #pragma unroll
-    for (int mt = 0; mt < NT; ++mt)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int row = 16 * mt + hi + 4 * r;
-        if (row < n && hi + 4 * r == lo) dg[row] = gam[mt][mt][r];
-      }
+    for (int s = 0; s < NS; ++s)
+      if (live[s] && row[s] == col[s]) dg[row[s]] = gam[s];
     wave_lds_fence();
-    // ---- X, the largest squared cosine, the column sums of |X|
-    double cos2 = 0.0, colsum[NT];
+    double cos2 = 0.0, fro2 = 0.0;
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-      const int col = 16 * nt + lo;
-      const double dj = dg[min(col, n - 1)];
-      double cs = 0.0;
-#pragma unroll
-      for (int mt = 0; mt < NT; ++mt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int row = 16 * mt + hi + 4 * r;
-          const double di = dg[min(row, n - 1)];
-          const bool live = row < n && col < n && row != col;
-          const double g = gam[mt][nt][r];
-          const double den = dj - di;
-          // (a vanishing denominator gives inf / NaN: the norm test below then sends the iteration to Jacobi)
-          // (a pair that is orthogonal to rounding is left alone, as in the Jacobi sweeps: exactly degenerate
-          //  eigenvalues would otherwise divide rounding noise by rounding noise)
-          const double g2 = g * g, dd = di * dj;
-          const double x = (live && g2 > dd * (CB_JAC_SKIP * CB_JAC_SKIP)) ? g * fast_rcp(den) : 0.0;
-          if (live) cos2 = fmax(cos2, g2 * fast_rcp(dd));
-          cs += fabs(x);
-          if (row < n && col < n) X[row * LS + col] = x;
-        }
-      cs += __shfl_xor(cs, 16, 64);
-      cs += __shfl_xor(cs, 32, 64);
-      colsum[nt] = cs;
+    for (int s = 0; s < NS; ++s) {
+      const double di = dg[row[s]], dj = dg[col[s]];
+      const bool on = live[s] && row[s] < n && col[s] < n && row[s] != col[s];
+      const double g = gam[s], g2 = g * g, dd = di * dj;
+      const double x = (on && g2 > dd * (CB_JAC_SKIP * CB_JAC_SKIP)) ? g * fast_rcp(dj - di) : 0.0;
+      if (on) cos2 = fmax(cos2, g2 * fast_rcp(dd));
+      fro2 = fma(x, x, fro2);
+      if (live[s]) X[row[s] * LS + col[s]] = x;
     }
-    // NaN-safe maximum (fmax drops NaNs): a NaN or inf anywhere must end up in the result
-    double nrm = 0.0;
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) nrm = (colsum[nt] == colsum[nt]) ? fmax(nrm, colsum[nt]) : INFINITY;
-    nrm = wave_max(nrm);
+    fro2 = wave_sum(fro2);                        // ||X||_2 <= ||X||_F (NaN / inf propagate: the test below fails)
+    const double nrm = sqrt(fro2);
     cos2 = wave_max(cos2);
     wave_lds_fence();
     const bool last = cos2 < CB_JAC_STOP * CB_JAC_STOP;
@@ -454,54 +441,34 @@ __device__ int wave_orthogonalise_first_order(int n, const double *A, double sig
       else if (n <= 8) wave_jacobi_columns<2, false>(n, Gc, nullptr, LS, 1);
       else if (n <= 16) wave_jacobi_columns<4, false>(n, Gc, nullptr, LS, 1);
       else if (n <= 20) wave_jacobi_columns<5, false>(n, Gc, nullptr, LS, 1);
-      else if (n <= 24) wave_jacobi_columns<6, false>(n, Gc, nullptr, LS, 1);
-      else wave_jacobi_columns<8, false>(n, Gc, nullptr, LS, 1);
+      else wave_jacobi_columns<6, false>(n, Gc, nullptr, LS, 1);
       if (last) {
         ++it;
         break;
       }
       continue;
     }
-    // ---- G <- G exp(X), term by term
     const int deg = fo_taylor_degree(nrm);
 #pragma unroll
-    for (int mt = 0; mt < NT; ++mt)
-#pragma unroll
-      for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int row = 16 * mt + hi + 4 * r, col = 16 * nt + lo;
-          acc[mt][nt][r] = Gc[min(col, n - 1) * LS + min(row, n - 1)];
-        }
+    for (int s = 0; s < NS; ++s) acc[s] = Gc[col[s] * LS + row[s]];
     const double *Tsrc = Gc;
     for (int k = 1; k <= deg; ++k) {
-      d4 t[NT][NT];
-      wave_mm<NT, KS>(n, Tsrc, 1, LS, X, LS, 1, t);
+      double t[NS];
+      wave_mm4<TS>(Tsrc, 1, LS, X, LS, 1, ti, tj, t);
       const double ik = 1.0 / (double)k;
       wave_lds_fence();   // every lane has read the previous term before it is overwritten
 #pragma unroll
-      for (int mt = 0; mt < NT; ++mt)
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int row = 16 * mt + hi + 4 * r, col = 16 * nt + lo;
-            const double v = t[mt][nt][r] * ik;
-            acc[mt][nt][r] += v;
-            if (k < deg && row < n && col < n) Uc[col * LS + row] = v;
-          }
+      for (int s = 0; s < NS; ++s) {
+        const double v = t[s] * ik;
+        acc[s] += v;
+        if (k < deg && live[s]) Uc[col[s] * LS + row[s]] = v;
+      }
       wave_lds_fence();
       Tsrc = Uc;
     }
 #pragma unroll
-    for (int mt = 0; mt < NT; ++mt)
-#pragma unroll
-      for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int row = 16 * mt + hi + 4 * r, col = 16 * nt + lo;
-          if (row < n && col < n) Gc[col * LS + row] = acc[mt][nt][r];
-        }
+    for (int s = 0; s < NS; ++s)
+      if (live[s]) Gc[col[s] * LS + row[s]] = acc[s];
     wave_lds_fence();
     if (last) {
       ++it;
@@ -511,29 +478,22 @@ __device__ int wave_orthogonalise_first_order(int n, const double *A, double sig
   return it;
 }
 
-// wave_eigh_rate with the first-order sweeps: Uc must hold the previous eigenvectors (warm start only).
-// MAXN bounds the sizes the caller can bring (the S <= 24 trainers do not instantiate the 28 / 32-row forms).
-template <int MAXN = 32>
-__device__ int wave_eigh_rate_warm_mfma(int n, const double *A, double *Gc, double *Uc, double *X, double *dg, double *lam,
-                                        int LS) {
+// n <= 24, frames of at least 4 ceil(n / 4) rows, ZERO outside n x n (the caller pads: see sp_prepare_body).
+__device__ int wave_eigh_rate_warm_mfma4(int n, const double *A, double *Gc, double *Uc, double *X, double *dg, double *lam,
+                                         int LS) {
   const int lane = threadIdx.x & 63;
   double mx = 0.0;
   for (int i = lane; i < n; i += 64) mx = fmax(mx, fabs(A[i * LS + i]));
   double sigma = wave_max(mx);
   if (!(sigma > 0.0)) sigma = 1.0;
   int its;
-  if (n <= 4) its = wave_orthogonalise_first_order<1, 1>(n, A, sigma, Gc, Uc, X, dg, LS);
-  else if (n <= 8) its = wave_orthogonalise_first_order<1, 2>(n, A, sigma, Gc, Uc, X, dg, LS);
-  else if (n <= 12) its = wave_orthogonalise_first_order<1, 3>(n, A, sigma, Gc, Uc, X, dg, LS);
-  else if (n <= 16) its = wave_orthogonalise_first_order<1, 4>(n, A, sigma, Gc, Uc, X, dg, LS);
-  else if (n <= 20) its = wave_orthogonalise_first_order<2, 5>(n, A, sigma, Gc, Uc, X, dg, LS);
-  else if (n <= 24 || MAXN <= 24) its = wave_orthogonalise_first_order<2, 6>(n, A, sigma, Gc, Uc, X, dg, LS);
-  else if constexpr (MAXN > 24) {
-    if (n <= 28) its = wave_orthogonalise_first_order<2, 7>(n, A, sigma, Gc, Uc, X, dg, LS);
-    else its = wave_orthogonalise_first_order<2, 8>(n, A, sigma, Gc, Uc, X, dg, LS);
-  }
-  // normalise: 4 lanes per column (as wave_eigh_rate)
-  for (int k0 = 0; k0 < n; k0 += 16) {
+  if (n <= 4) its = wave_orthogonalise_first_order4<1>(n, A, sigma, Gc, Uc, X, dg, LS);
+  else if (n <= 8) its = wave_orthogonalise_first_order4<2>(n, A, sigma, Gc, Uc, X, dg, LS);
+  else if (n <= 12) its = wave_orthogonalise_first_order4<3>(n, A, sigma, Gc, Uc, X, dg, LS);
+  else if (n <= 16) its = wave_orthogonalise_first_order4<4>(n, A, sigma, Gc, Uc, X, dg, LS);
+  else if (n <= 20) its = wave_orthogonalise_first_order4<5>(n, A, sigma, Gc, Uc, X, dg, LS);
+  else its = wave_orthogonalise_first_order4<6>(n, A, sigma, Gc, Uc, X, dg, LS);
+  for (int k0 = 0; k0 < n; k0 += 16) {   // normalise: 4 lanes per column (as wave_eigh_rate)
     const int k = k0 + (lane >> 2), sub = lane & 3;
     double nn = 0.0;
     if (k < n)

@@ -428,10 +428,15 @@ __device__ __forceinline__ void sp_prepare_body(const TrainArgs &a, const SpSpli
   if (epoch > 0 && !v_resident)  // previous eigenvectors: warm start (issued first: the loads fly while theta -> A is computed)
     for (int e = tid; e < SP_ROWS * CB_LS; e += NTH) sV[e] = fr[LGS_V + e];
   tr_build(a, l, epoch, sA, sD, sPi);
+  // the 4 x 4-tile products of the warm solve read whole tiles: A is zero outside S x S (V already is)
+  for (int e = tid; e < SP_ROWS * SP_ROWS; e += NTH) {
+    const int i = e / SP_ROWS, j = e - i * SP_ROWS;
+    if (i >= S || j >= S) sA[i * CB_LS + j] = 0.0;
+  }
   __syncthreads();
   SP_STAMP(6);
   if (NTH == 64 || tid < 64) {
-    if (epoch > 0) wave_eigh_rate_warm_mfma<24>(S, sA, sG, sV, lds + SPP_X, lds + SPP_DG, sLam, CB_LS);
+    if (epoch > 0) wave_eigh_rate_warm_mfma4(S, sA, sG, sV, lds + SPP_X, lds + SPP_DG, sLam, CB_LS);
     else wave_eigh_rate(S, sA, sG, sV, sLam, CB_LS, false);
   }
   __syncthreads();

@@ -175,3 +175,38 @@ def test_co_counting_bucket_binned_lds_kernel_random(S, n_fam, symmetric):
             _lib.check(rc, "cb_count_co_transitions")
         torch.cuda.synchronize()
         assert np.array_equal(d_counts.cpu().numpy().astype(np.uint64).reshape(want.shape), 2 * want + 1), bound
+
+
+def test_co_counting_edge_cases():
+    """No pairs at all, pairs that all fall outside the grid, pairs without contacts, a grid of ONE point, and an alphabet
+    whose S^2 = 900 rows need 21 LDS row blocks: the histogram is what numpy says (mostly: zero)."""
+    from cherryml_amd import _lib
+    from cherryml_amd.counting._stage import PAIR_DTYPE
+    lib = _lib.load()
+    rng = np.random.default_rng(9)
+
+    def run(S, grid, seqs, contacts, pairs, symmetric=1):
+        grid = np.asarray(grid, dtype=np.float64)
+        contacts = np.concatenate([np.asarray(contacts, dtype=np.int32).reshape(-1), np.zeros(2, np.int32)])
+        got = np.zeros((len(grid), S * S, S * S), dtype=np.uint64)
+        rc = lib.cb_count_co_transitions(0, S, len(grid), grid.ctypes.data, seqs.ctypes.data, seqs.size, contacts.ctypes.data,
+                                         contacts.size // 2, pairs.ctypes.data if len(pairs) else None, len(pairs), symmetric, 0,
+                                         got.ctypes.data)
+        _lib.check(rc, "cb_count_co_transitions")
+        assert np.array_equal(got, _co_counts_numpy(S, grid, seqs, contacts, pairs, symmetric))
+        return got
+
+    seqs = rng.integers(0, 4, size=40).astype(np.int8)
+    ij = np.array([[0, 9], [1, 8], [2, 7]], dtype=np.int32)
+    none = np.zeros(0, dtype=PAIR_DTYPE)
+    assert run(4, [0.1, 0.2, 0.4], seqs, ij, none).sum() == 0
+    far = np.array([(0, 10, 0, 3, 0, 5.0, 5.0), (20, 30, 0, 3, 0, 1e-9, 1e-9)], dtype=PAIR_DTYPE)
+    assert run(4, [0.1, 0.2, 0.4], seqs, ij, far).sum() == 0
+    empty = np.array([(0, 10, 0, 0, 0, 0.1, 0.1), (20, 30, 3, 0, 0, 0.05, 0.05)], dtype=PAIR_DTYPE)
+    assert run(4, [0.1, 0.2, 0.4], seqs, ij, empty).sum() == 0
+    one = np.array([(0, 10, 0, 3, 0, 0.1, 0.1), (20, 30, 1, 2, 0, 0.15, 0.05)], dtype=PAIR_DTYPE)
+    assert run(4, [0.2], seqs, ij, one).sum() == 4 * 5 and run(4, [0.2], seqs, ij, one, symmetric=0).sum() == 2 * 5
+    big = rng.integers(0, 30, size=4000).astype(np.int8)
+    cij = np.sort(rng.integers(0, 100, size=(70, 2)), axis=1).astype(np.int32)
+    many = np.array([(100 * k, 100 * k + 2000, 0, 70, 0, 0.01 * (k + 1), 0.02) for k in range(20)], dtype=PAIR_DTYPE)
+    assert run(30, [0.03, 0.06, 0.12, 0.24], big, cij, many).sum() > 0
