@@ -6,10 +6,11 @@
 // ------------------------------------------------------------------------ counting
 // Replica scratch of the resident (device-pointer) form, kept per device for the life of the
 // process (the only process-wide state of the library; never holds results between calls).
-static int count_scratch(int device, size_t elems, unsigned long long **out) {
+static int count_scratch(int device, size_t elems, unsigned long long **out, bool *moved = nullptr) {
   static unsigned long long *buf[64] = {};
   static size_t cap[64] = {};
   if (device < 0 || device >= 64) return fail(CB_EINVAL, "counting: device %d out of range", device);
+  if (moved) *moved = cap[device] < elems;   // a re-allocation loses the contents -- and may return the SAME address
   if (cap[device] < elems) {
     if (buf[device]) (void)hipFree(buf[device]);
     buf[device] = nullptr;
@@ -126,9 +127,10 @@ static int launch_count_co_transitions(int device, int S, int B, const double *g
   // scratch is grown FIRST when it is too small and the two kernels above are simply run again
   const size_t need = fixed + ((size_t)total_events + 1) / 2 + 1;
   unsigned long long *scr2 = nullptr;
-  rc = count_scratch(device, need, &scr2);
+  bool moved = false;   // (comparing the pointers is not enough: freeing and re-allocating a block can hand the address back)
+  rc = count_scratch(device, need, &scr2, &moved);
   if (rc != CB_OK) return rc;
-  if (scr2 != scr) {
+  if (moved) {
     scr = scr2;
     w = carve(scr);
     HIP_TRY(hipMemsetAsync(scr, 0, head * sizeof(unsigned long long), 0));

@@ -210,3 +210,28 @@ def test_co_counting_edge_cases():
     cij = np.sort(rng.integers(0, 100, size=(70, 2)), axis=1).astype(np.int32)
     many = np.array([(100 * k, 100 * k + 2000, 0, 70, 0, 0.01 * (k + 1), 0.02) for k in range(20)], dtype=PAIR_DTYPE)
     assert run(30, [0.03, 0.06, 0.12, 0.24], big, cij, many).sum() > 0
+
+
+def test_co_counting_scratch_regrowth_between_calls():
+    """The per-device scratch of the co-transition pass grows between calls of one process; a re-allocation loses its
+    contents (and may hand the same address back), so the first two kernels are run again after it -- a sequence of calls
+    with growing inputs, each checked against numpy."""
+    from cherryml_amd import _lib
+    from cherryml_amd.counting._stage import PAIR_DTYPE
+    lib = _lib.load()
+    rng = np.random.default_rng(77)
+    grid = np.array([float("%.8f" % (0.03 * 1.1 ** i)) for i in range(-64, 65)])
+    S, L = 6, 120
+    for n_pairs, n_c in ((3, 5), (400, 40), (5, 3), (3000, 90), (9000, 110)):
+        codes = rng.integers(0, S, size=(2 * n_pairs, L)).astype(np.int8)
+        ij = np.sort(rng.integers(0, L, size=(n_c, 2)), axis=1).astype(np.int32)
+        pairs = np.array([(2 * k * L, (2 * k + 1) * L, 0, n_c, 0, float(rng.exponential(0.2)), float(rng.exponential(0.2)))
+                          for k in range(n_pairs)], dtype=PAIR_DTYPE)
+        seqs = codes.reshape(-1)
+        contacts = np.concatenate([ij.reshape(-1), np.zeros(2, np.int32)]).astype(np.int32)
+        want = _co_counts_numpy(S, grid, seqs, contacts, pairs, 1)
+        got = np.zeros_like(want)
+        rc = lib.cb_count_co_transitions(0, S, len(grid), grid.ctypes.data, seqs.ctypes.data, seqs.size, contacts.ctypes.data,
+                                         contacts.size // 2, pairs.ctypes.data, len(pairs), 1, 0, got.ctypes.data)
+        _lib.check(rc, "cb_count_co_transitions")
+        assert np.array_equal(got, want), (n_pairs, n_c)
