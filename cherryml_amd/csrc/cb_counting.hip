@@ -63,8 +63,8 @@ static int launch_count_transitions(int device, int S, int B, const double *grid
 }
 
 // device-pointer launch of the co-transition counter: adds into counts[B * S^2 * S^2] (see counting.hip.h).
-// total_events = sum of pair.n when the caller knows it, else max_n (largest pair.n) bounds it; with neither the
-// event total is read back from the device after the first kernel (one synchronisation).
+// total_events = sum of pair.n when the caller knows it (host form); the resident form reads it back from the device
+// after the first two kernels (one synchronisation).
 static int launch_count_co_transitions(int device, int S, int B, const double *grid, const int8_t *seqs,
                                        const int32_t *contacts, const cb_count_pair *pairs, int64_t n_pairs,
                                        int symmetric, int64_t total_events, int max_n,
@@ -115,12 +115,14 @@ static int launch_count_co_transitions(int device, int S, int B, const double *g
                      w.bucket_off, w.work, w.n_work);
   HIP_TRY(hipGetLastError());
   if (total_events < 0) {
-    if (max_n > 0) total_events = n_pairs * (int64_t)max_n;
-    else {
-      unsigned long long tot = 0;
-      HIP_TRY(hipMemcpy(&tot, w.bucket_off + B, sizeof tot, hipMemcpyDeviceToHost));
-      total_events = (int64_t)tot;
-    }
+    // resident form: the pairs live on the device, so the event total is read back after the first two kernels (one
+    // 8-byte copy, ~15 us).  The caller's bound on pair.n (`max_n`, flags bits 8..23) is only a plausibility check: sizing
+    // the event array from it would turn a wrong bound into out-of-bounds stores.
+    unsigned long long tot = 0;
+    HIP_TRY(hipMemcpy(&tot, w.bucket_off + B, sizeof tot, hipMemcpyDeviceToHost));
+    if (max_n > 0 && tot > (unsigned long long)n_pairs * (unsigned long long)max_n)
+      return fail(CB_EINVAL, "cb_count_co_transitions: %llu events exceed n_pairs x the stated largest pair.n (%d)", tot, max_n);
+    total_events = (int64_t)tot;
   }
   if (total_events == 0) return CB_OK;
   // the event array behind the fixed part: growing the scratch would move (and lose) the part already filled, so the

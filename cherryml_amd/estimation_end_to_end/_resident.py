@@ -90,7 +90,7 @@ def coevolution_fit_resident(
             rc = _lib.load().cb_count_co_transitions(
                 device, S1, B, d_grid.data_ptr(), d_seqs.data_ptr(), int(seqs.size), d_contacts.data_ptr(),
                 contacts.size // 2, d_pairs.data_ptr(), len(pairs), int(mode != "edge"),
-                _lib.CB_PTR_DEVICE | (min(int(pairs["n"].max()), 0xFFFF) << 8), d_counts.data_ptr())
+                _lib.CB_PTR_DEVICE, d_counts.data_ptr())
             _lib.check(rc, "cb_count_co_transitions")
             torch.cuda.synchronize(dev)
         box["counts"] = d_counts

@@ -226,7 +226,10 @@ int cb_train_siterm(cb_handle h, double *theta, double *Theta, int num_epochs,
  * stream and ADDS into `counts` (the caller zeroes it, validates its offsets, and
  * synchronises): the form a resident pipeline and bench.py use.  In that form bits 8..23
  * of `flags` may carry the largest pair.n (sites per pair); when given and the [B][S][S]
- * histogram fits LDS, cb_count_transitions uses the LDS-privatised kernel.
+ * histogram fits LDS, cb_count_transitions uses the LDS-privatised kernel.  cb_count_co_transitions bins its
+ * (pair, contact) events by bucket and needs their total to size the event array: the host form sums pair.n, the resident
+ * form reads the total back after its first two kernels (one 8-byte copy: this form synchronises the default stream
+ * once per call); bits 8..23, when given, are only checked against it (CB_EINVAL when exceeded).
  */
 typedef struct {
   int64_t seq_a, seq_b; /* byte offsets of the two encoded sequences in `seqs`        */

@@ -163,7 +163,7 @@ def test_co_counting_bucket_binned_lds_kernel_random(S, n_fam, symmetric):
                                      contacts.size // 2, pairs.ctypes.data, len(pairs), symmetric, 0, got.ctypes.data)
     _lib.check(rc, "cb_count_co_transitions")
     assert np.array_equal(got, want)
-    # resident form: device pointers, ADDS into counts; flags bits 8.. = the caller's bound on pair.n (0: read back)
+    # resident form: device pointers, ADDS into counts; flags bits 8.. = the caller's bound on pair.n (checked only)
     dev = torch.device("cuda", 0)
     d = [torch.from_numpy(x).to(dev) for x in (grid, seqs, contacts, pairs.view(np.uint8))]
     for bound in (0, int(pairs["n"].max())):
@@ -175,6 +175,11 @@ def test_co_counting_bucket_binned_lds_kernel_random(S, n_fam, symmetric):
             _lib.check(rc, "cb_count_co_transitions")
         torch.cuda.synchronize()
         assert np.array_equal(d_counts.cpu().numpy().astype(np.uint64).reshape(want.shape), 2 * want + 1), bound
+    if pairs["n"].max() > 1:   # a stated bound that the pairs exceed is refused, not trusted
+        rc = lib.cb_count_co_transitions(0, S, B, d[0].data_ptr(), d[1].data_ptr(), seqs.size, d[2].data_ptr(),
+                                         contacts.size // 2, d[3].data_ptr(), len(pairs), symmetric,
+                                         _lib.CB_PTR_DEVICE | (1 << 8), d_counts.data_ptr())
+        assert rc != 0 and "exceed" in lib.cb_last_error().decode()
 
 
 def test_co_counting_edge_cases():
