@@ -56,6 +56,9 @@ def coevolution_fit_resident(
     from ..distributed import ShardedBank
     from ..estimation._ratelearn._rate_matrix import RateMatrix
 
+    if _lib.load().cb_device_count() <= 0:   # (a missing library raises CherryBankError inside load())
+        raise _lib.CherryBankError("coevolution_fit_resident: no HIP device visible; cherryml_amd computes this path on the "
+                                   "MI355X only and has no CPU fallback")
     mode = _normalise_mode(edge_or_cherry)
     grid = np.array(sorted(float(q) for q in quantization_points), dtype=np.float64)
     S1, B = len(amino_acids), len(grid)

@@ -59,6 +59,11 @@ def test_no_gpu_fails_loudly_whatever_the_device_argument_says(tmp_path):
     with pytest.raises(ValueError):
         cherryml_amd.quantized_transitions_mle_vectorized_over_sites(
             np.ones((1, 1, 4, 4)), np.ones((1, 1)), 1, device="tpu")
+    from cherryml_amd.estimation_end_to_end import coevolution_fit_resident
+    with pytest.raises(_lib.CherryBankError, match="no CPU fallback"):   # the resident chain too
+        coevolution_fit_resident(tree_dir=str(tmp_path), msa_dir=str(tmp_path), contact_map_dir=str(tmp_path), families=[],
+                                 amino_acids=list("AC"), quantization_points=[0.1, 0.2], edge_or_cherry="cherry",
+                                 minimum_distance_for_nontrivial_contact=3, num_epochs=1)
 
 
 def test_positional_arguments_refused():
