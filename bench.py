@@ -332,12 +332,18 @@ def main():
     if world > 1 or args.force_sharded:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        # CB_BENCH_BACKEND=gloo is a TEST HOOK (never a measurement): with it several ranks may share one GPU (RCCL refuses
+        # that), which is how the N > 1 control flow -- launcher, sharding, collectives on device tensors, the fall-back
+        # when no raw RCCL communicator can be made, the JSON relay -- runs on a one-GPU box; the line says so in `data`
+        backend = os.environ.get("CB_BENCH_BACKEND", "nccl")
+        dist.init_process_group(backend, rank=rank, world_size=world)
         if dist.get_world_size() != args.gpus:   # n_gpus in the line = the communicator's rank count
             n_found = dist.get_world_size()
             dist.destroy_process_group()
             refuse(n_found, "the process group")
         world = dist.get_world_size()
+    if os.environ.get("CB_BENCH_BACKEND", "nccl") != "nccl":
+        local_rank = local_rank % max(torch.cuda.device_count(), 1)   # (test hook: ranks may share a device)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
@@ -541,7 +547,8 @@ def main():
             "value": n_pairs_total / (dt / steps), "unit": "cherry-pairs/s", "n_gpus": world,
             "steps": steps, "warmup": warmup, "ms_per_step": dt / steps * 1e3,
             "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": bank_dtype,
-            "data": "synthetic",
+            "data": "synthetic" if os.environ.get("CB_BENCH_BACKEND", "nccl") == "nccl" else
+                    "synthetic; TEST HOOK CB_BENCH_BACKEND (ranks may share one GPU): control-flow check, not a measurement",
             "config": {"workload": wl["desc"], "states": S, "buckets": 129,
                        **({"non_empty_buckets": wl["live"]} if "live" in wl else {}), "sharding": sharding,
                        "epoch": glue,
