@@ -42,6 +42,30 @@ def jtt_ipw_from_reduced_statistics(F_sym: np.ndarray, R_sym: np.ndarray, grid: 
     return res
 
 
+def _train_with_torch_glue(sharded, module, num_epochs: int, lr: float, do_adam: bool) -> Dict:
+    """The reference's loop (trainer.py:156-218: loss, best iterate = Q BEFORE the step with strict <, snapshots at epochs
+    1, 2, 4, ...) with the sharded bank's differentiable loss; every rank takes the same steps (the all-reduced loss and
+    gradient are identical everywhere)."""
+    import torch
+    opt = (torch.optim.Adam if do_adam else torch.optim.SGD)(module.parameters(), lr=lr)
+    losses, best, Q_best, Q, snaps = [], None, None, None, {}
+    for epoch in range(num_epochs):
+        opt.zero_grad()
+        Q = module()
+        loss = sharded.loss(Q, module.stationary(), normalize=True)[0]
+        value = float(loss.item())
+        if best is None or value < best:
+            best, Q_best = value, Q.detach().cpu().numpy().copy()
+        if (epoch & (epoch + 1)) == 0:
+            snaps[epoch + 1] = Q.detach().cpu().numpy().copy()
+        loss.backward()
+        opt.step()
+        losses.append(value)
+    return dict(loss=np.array(losses), Q_best=Q_best, Q_last=None if Q is None else Q.detach().cpu().numpy().copy(),
+                Q_pow2=snaps, upper_diag=module.upper_diag.detach().cpu().numpy().copy(),
+                log_pi=module._pi.detach().cpu().numpy().copy())
+
+
 def coevolution_fit_resident(
     tree_dir: str, msa_dir: str, contact_map_dir: str, families: List[str], amino_acids: List[str],
     quantization_points: List[Union[str, float]], edge_or_cherry: str, minimum_distance_for_nontrivial_contact: int,
@@ -121,8 +145,18 @@ def coevolution_fit_resident(
         sharded = ShardedBank.from_rank_counts(grid, C, dtype=bank_dtype)
         del C
         try:
-            sharded.enable_in_library_allreduce()
-            r = sharded.train_pande_reversible(u0, p0, mask=mask, num_epochs=num_epochs, lr=learning_rate, do_adam=do_adam)
+            try:   # raises on EVERY rank when any rank cannot make its raw RCCL communicator
+                sharded.enable_in_library_allreduce()
+                in_library = True
+            except RuntimeError as exc:
+                import warnings
+                warnings.warn(f"coevolution_fit_resident: in-library all-reduce unavailable ({exc}); theta -> Q and the "
+                              "optimiser step stay in torch, the collective is torch.distributed's")
+                in_library = False
+            if in_library:
+                r = sharded.train_pande_reversible(u0, p0, mask=mask, num_epochs=num_epochs, lr=learning_rate, do_adam=do_adam)
+            else:
+                r = _train_with_torch_glue(sharded, mod.to(dev), num_epochs, learning_rate, do_adam)
         finally:
             sharded.close()
     else:

@@ -33,3 +33,65 @@ def test_two_ranks_share_the_gpu_through_the_gloo_hook():
     # weak scaling: both ranks' events are in the counted total (10,000 families x 64 cherries x ~65 contacts each)
     assert cc["value"] * cc["ms_per_step"] * 1e-3 > 6.0e7
     assert "secondary" not in d      # the LG replica line belongs to N = 1
+
+
+_RESIDENT_WORKER = r'''
+import os, sys, numpy as np
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], "tests"))
+import torch, torch.distributed as dist
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+if world > 1:
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+torch.cuda.set_device(0)
+from cherryml_amd.estimation_end_to_end import coevolution_fit_resident
+z = np.load(sys.argv[2], allow_pickle=True)
+r = coevolution_fit_resident(tree_dir=str(z["tree"]), msa_dir=str(z["msa"]), contact_map_dir=str(z["cm"]),
+                             families=[str(f) for f in z["families"]], amino_acids=list("ARNDCQEGHILKMFPSTWYV"),
+                             quantization_points=[float(q) for q in z["grid"]], edge_or_cherry="cherry++",
+                             minimum_distance_for_nontrivial_contact=7, mask=z["mask"], num_epochs=int(z["epochs"]))
+np.savez(sys.argv[3] + f".{rank}.npz", Q_best=r["Q_best"], loss=r["loss"], init=r["initialization"], n_pairs=r["n_pairs"])
+if world > 1:
+    dist.destroy_process_group()
+'''
+
+
+def test_resident_chain_two_ranks_equal_one_rank(tmp_path):
+    """`coevolution_fit_resident` with the demo families dealt over TWO ranks (gloo on the one GPU: each rank counts its
+    families, the JTT-IPW start comes from the all-reduced S x S sums, the counts meet in the collective over the non-empty
+    buckets, no raw RCCL communicator -> torch's collective) gives the one-rank result: same pair total and initialiser,
+    loss curves and learned Q to rounding."""
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from conftest import load_golden, relerr
+    from test_gpu_demo_e2e import _materialise
+    from cherryml_amd import caching
+    from cherryml_amd.estimation_end_to_end import create_maximal_matching_contact_map
+    z = load_golden("demo_e2e.npz")
+    dirs, fams = _materialise(tmp_path, z)
+    caching.set_cache_dir(str(tmp_path / "cache"))
+    try:
+        cm_dir = create_maximal_matching_contact_map(i_contact_map_dir=dirs["contact_map"], families=fams,
+                                                     minimum_distance_for_nontrivial_contact=7, num_processes=1)["o_contact_map_dir"]
+    finally:
+        caching.set_cache_dir(None)
+    mask = np.unpackbits(z["co_mask_packed"])[:160000].reshape(400, 400).astype(np.float64)
+    spec = tmp_path / "spec.npz"
+    np.savez(spec, tree=dirs["tree"], msa=dirs["msa"], cm=cm_dir, families=np.array(fams), grid=z["quantization_points"].astype(float),
+             mask=mask, epochs=int(z["co_epochs"]))
+    script = tmp_path / "worker.py"
+    script.write_text(_RESIDENT_WORKER)
+    base = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    base.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29577")
+    subprocess.run([sys.executable, str(script), ROOT, str(spec), str(tmp_path / "one")], env=dict(base, RANK="0", WORLD_SIZE="1"),
+                   check=True, timeout=600)
+    procs = [subprocess.Popen([sys.executable, str(script), ROOT, str(spec), str(tmp_path / "two")],
+                              env=dict(base, RANK=str(r), WORLD_SIZE="2")) for r in range(2)]
+    assert [p.wait(timeout=600) for p in procs] == [0, 0]
+    one = np.load(str(tmp_path / "one") + ".0.npz")
+    for r in range(2):
+        two = np.load(str(tmp_path / "two") + f".{r}.npz")
+        assert float(two["n_pairs"]) == float(one["n_pairs"]) == float(z["co_counts_val"].sum())
+        assert np.allclose(two["init"], one["init"], rtol=1e-12, atol=1e-300)
+        assert np.allclose(two["loss"], one["loss"], rtol=1e-10, atol=0)
+        assert relerr(two["Q_best"], one["Q_best"]) < 1e-8
+    assert relerr(one["Q_best"], z["co_Q_best_f64"]) < 1e-6
