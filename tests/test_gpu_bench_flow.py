@@ -95,3 +95,82 @@ def test_resident_chain_two_ranks_equal_one_rank(tmp_path):
         assert np.allclose(two["loss"], one["loss"], rtol=1e-10, atol=0)
         assert relerr(two["Q_best"], one["Q_best"]) < 1e-8
     assert relerr(one["Q_best"], z["co_Q_best_f64"]) < 1e-6
+
+
+_INLIB_WORKER = r'''
+import ctypes as C, glob, os, sys, numpy as np
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], "tests"))
+import torch, torch.distributed as dist
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+torch.cuda.set_device(0)
+from cherryml_amd import CherryBank
+from cherryml_amd.distributed import ShardedBank
+z = np.load(sys.argv[2])
+hip = C.CDLL(glob.glob(os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so*"))[0])
+calls = []
+
+@C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_void_p)
+def allreduce(send, recv, count, dtype, op, comm, stream):
+    """ncclAllReduce's signature; the transport is gloo through the host (two ranks share the GPU: RCCL cannot)."""
+    assert dtype == 8 and op == 0, (dtype, op)          # ncclFloat64, ncclSum
+    buf = np.empty(count)
+    assert hip.hipStreamSynchronize(C.c_void_p(stream)) == 0
+    assert hip.hipMemcpy(C.c_void_p(buf.ctypes.data), C.c_void_p(send), C.c_size_t(count * 8), 2) == 0
+    t = torch.from_numpy(buf)
+    dist.all_reduce(t)
+    assert hip.hipMemcpy(C.c_void_p(recv), C.c_void_p(buf.ctypes.data), C.c_size_t(count * 8), 1) == 0
+    calls.append(int(count))
+    return 0
+
+C_rank = torch.tensor(z["C"] * (0.3 if rank == 0 else 0.7), device="cuda")   # this rank's share of every family count
+sb = ShardedBank.from_rank_counts(z["t"], C_rank)
+class _NoComm:                       # stands for the RcclCommunicator the bank would own
+    def destroy(self): pass
+sb.rccl = _NoComm()
+sb.bank.allreduce_setup(1, C.cast(allreduce, C.c_void_p).value, [sb.total_count])
+E = int(z["E"])
+r = sb.train_pande_reversible(z["u0"], z["p0"], mask=z["mask"], num_epochs=E, lr=0.1)
+np.savez(sys.argv[3] + f".{rank}.npz", loss=r["loss"], Q_last=r["Q_last"], Q_best=r["Q_best"], calls=np.array(calls),
+         local=np.array(sb.local_buckets))
+sb.close()
+dist.destroy_process_group()
+'''
+
+
+def test_c_driven_sharded_loop_with_two_real_ranks(tmp_path):
+    """`cb_allreduce_setup` + `cb_train_pande_reversible` (S > 32): the WHOLE sharded epoch loop from C on two ranks that
+    really hold different shares of the counts and different buckets (gloo processes on the one GPU; the function handed
+    over in place of `ncclAllReduce` has its signature and moves the bytes through gloo).  Both ranks reproduce the
+    single-process trajectory of the full bank; every epoch made exactly two collective calls (1 and LD^2 doubles) after
+    the set-up's two."""
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from conftest import load_golden, relerr
+    from cherryml_amd import CherryBank
+    import bench
+    z = load_golden("coevo_dense_traj.npz")
+    rng = np.random.default_rng(0)
+    wl = bench.make_workload("coevo400", 0, rng)
+    sel = z["sel"]
+    t, Cm, mask = wl["t"][sel], wl["C"][sel], wl["mask"]
+    E = 8
+    with CherryBank(t, Cm) as bank:
+        one = bank.train_pande_reversible(z["upper_diag0"], z["log_pi0"], mask=mask, num_epochs=E, lr=0.1)
+    spec = tmp_path / "spec.npz"
+    np.savez(spec, t=t, C=Cm, mask=mask, u0=z["upper_diag0"], p0=z["log_pi0"], E=E)
+    script = tmp_path / "worker.py"
+    script.write_text(_INLIB_WORKER)
+    base = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    base.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29578")
+    procs = [subprocess.Popen([sys.executable, str(script), ROOT, str(spec), str(tmp_path / "two")],
+                              env=dict(base, RANK=str(r), WORLD_SIZE="2")) for r in range(2)]
+    assert [p.wait(timeout=600) for p in procs] == [0, 0]
+    got = [np.load(str(tmp_path / "two") + f".{r}.npz") for r in range(2)]
+    assert set(got[0]["local"]).isdisjoint(got[1]["local"]) and len(got[0]["local"]) + len(got[1]["local"]) == len(sel)
+    for g in got:
+        assert np.allclose(g["loss"], one["loss"], rtol=1e-11, atol=0)
+        assert relerr(g["Q_last"], one["Q_last"]) < 1e-9 and relerr(g["Q_best"], one["Q_best"]) < 1e-9
+        calls = list(g["calls"])
+        assert calls[-2 * E:] == [1, 400 * 400] * E, calls
+    assert np.array_equal(got[0]["Q_last"], got[1]["Q_last"])      # identical steps on both ranks
