@@ -130,9 +130,14 @@ class _NoComm:                       # stands for the RcclCommunicator the bank 
 sb.rccl = _NoComm()
 sb.bank.allreduce_setup(1, C.cast(allreduce, C.c_void_p).value, [sb.total_count])
 E = int(z["E"])
-r = sb.train_pande_reversible(z["u0"], z["p0"], mask=z["mask"], num_epochs=E, lr=0.1)
-np.savez(sys.argv[3] + f".{rank}.npz", loss=r["loss"], Q_last=r["Q_last"], Q_best=r["Q_best"], calls=np.array(calls),
-         local=np.array(sb.local_buckets))
+if os.environ.get("FAULT_RANK") == str(rank):
+    os.environ["CB_FAULT_INJECT"] = "3"      # this rank's evaluation "fails" at epoch 3 (read by the library at the call)
+try:
+    r = sb.train_pande_reversible(z["u0"], z["p0"], mask=z["mask"], num_epochs=E, lr=0.1)
+    np.savez(sys.argv[3] + f".{rank}.npz", loss=r["loss"], Q_last=r["Q_last"], Q_best=r["Q_best"], calls=np.array(calls),
+             local=np.array(sb.local_buckets))
+except Exception as exc:
+    np.savez(sys.argv[3] + f".{rank}.npz", error=str(exc), calls=np.array(calls))
 sb.close()
 dist.destroy_process_group()
 '''
@@ -174,3 +179,31 @@ def test_c_driven_sharded_loop_with_two_real_ranks(tmp_path):
         calls = list(g["calls"])
         assert calls[-2 * E:] == [1, 400 * 400] * E, calls
     assert np.array_equal(got[0]["Q_last"], got[1]["Q_last"])      # identical steps on both ranks
+
+
+def test_a_failing_rank_takes_its_peer_down_after_the_same_collectives(tmp_path):
+    """The failure protocol of the C-driven loop with two real ranks: rank 1's evaluation fails at epoch 3
+    (CB_FAULT_INJECT); it keeps its place in every remaining all-reduce with NaN payloads, so rank 0's parameters turn
+    NaN, its own eigensolver refuses them, and BOTH ranks return an error -- after the same number of collective calls,
+    nobody left waiting."""
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from conftest import load_golden
+    import bench
+    z = load_golden("coevo_dense_traj.npz")
+    wl = bench.make_workload("coevo400", 0, np.random.default_rng(0))
+    sel = z["sel"]
+    E = 8
+    spec = tmp_path / "spec.npz"
+    np.savez(spec, t=wl["t"][sel], C=wl["C"][sel], mask=wl["mask"], u0=z["upper_diag0"], p0=z["log_pi0"], E=E)
+    script = tmp_path / "worker.py"
+    script.write_text(_INLIB_WORKER)
+    base = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "CB_FAULT_INJECT")}
+    base.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29579", FAULT_RANK="1")
+    procs = [subprocess.Popen([sys.executable, str(script), ROOT, str(spec), str(tmp_path / "f")],
+                              env=dict(base, RANK=str(r), WORLD_SIZE="2")) for r in range(2)]
+    assert [p.wait(timeout=600) for p in procs] == [0, 0]
+    got = [np.load(str(tmp_path / "f") + f".{r}.npz") for r in range(2)]
+    assert "error" in got[0].files and "error" in got[1].files, [g.files for g in got]
+    assert "injected fault" in str(got[1]["error"]) and "NaN" in str(got[1]["error"])
+    assert len(got[0]["calls"]) == len(got[1]["calls"])          # same number of collectives on both ranks
