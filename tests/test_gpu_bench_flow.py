@@ -207,3 +207,62 @@ def test_a_failing_rank_takes_its_peer_down_after_the_same_collectives(tmp_path)
     assert "error" in got[0].files and "error" in got[1].files, [g.files for g in got]
     assert "injected fault" in str(got[1]["error"]) and "NaN" in str(got[1]["error"])
     assert len(got[0]["calls"]) == len(got[1]["calls"])          # same number of collectives on both ranks
+
+
+_COUNT_WORKER = r'''
+import os, sys, numpy as np
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], "tests"))
+import torch, torch.distributed as dist
+dist.init_process_group("gloo", rank=int(os.environ["RANK"]), world_size=int(os.environ["WORLD_SIZE"]))
+torch.cuda.set_device(0)
+import cherryml_amd
+z = np.load(sys.argv[2], allow_pickle=True)
+fams = [str(f) for f in z["families"]]
+AA = list("ARNDCQEGHILKMFPSTWYV")
+cherryml_amd.count_transitions(tree_dir=str(z["tree"]), msa_dir=str(z["msa"]), site_rates_dir=str(z["rates"]), families=fams,
+                               amino_acids=AA, quantization_points=[str(q) for q in z["grid"]], edge_or_cherry="cherry++",
+                               output_count_matrices_dir=sys.argv[3] + "/single")
+cherryml_amd.count_co_transitions(tree_dir=str(z["tree"]), msa_dir=str(z["msa"]), contact_map_dir=str(z["cm"]), families=fams,
+                                  amino_acids=AA, quantization_points=[str(q) for q in z["grid"]], edge_or_cherry="cherry++",
+                                  minimum_distance_for_nontrivial_contact=7, output_count_matrices_dir=sys.argv[3] + "/co")
+dist.destroy_process_group()
+'''
+
+
+def test_counting_stages_with_families_dealt_over_two_ranks(tmp_path):
+    """`count_transitions` / `count_co_transitions` under torch.distributed: families dealt round-robin to two ranks (the
+    reference's MPI scheme, _count_transitions.cpp:626-628), each rank counts its own on the GPU, the integer counts are
+    all-reduced, rank 0 writes -- the files equal the reference's counts of the demo families bit for bit."""
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from conftest import load_golden
+    from test_gpu_demo_e2e import _materialise
+    from cherryml_amd import caching
+    from cherryml_amd.estimation_end_to_end import create_maximal_matching_contact_map
+    from cherryml_amd.io import read_count_matrices_arrays
+    z = load_golden("demo_e2e.npz")
+    dirs, fams = _materialise(tmp_path, z)
+    caching.set_cache_dir(str(tmp_path / "cache"))
+    try:
+        cm_dir = create_maximal_matching_contact_map(i_contact_map_dir=dirs["contact_map"], families=fams,
+                                                     minimum_distance_for_nontrivial_contact=7, num_processes=1)["o_contact_map_dir"]
+    finally:
+        caching.set_cache_dir(None)
+    spec = tmp_path / "spec.npz"
+    np.savez(spec, tree=dirs["tree"], msa=dirs["msa"], rates=dirs["site_rates"], cm=cm_dir, families=np.array(fams),
+             grid=np.array([str(q) for q in z["quantization_points"]]))
+    script = tmp_path / "worker.py"
+    script.write_text(_COUNT_WORKER)
+    out = tmp_path / "out"
+    out.mkdir()
+    base = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    base.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29580")
+    procs = [subprocess.Popen([sys.executable, str(script), ROOT, str(spec), str(out)], env=dict(base, RANK=str(r), WORLD_SIZE="2"))
+             for r in range(2)]
+    assert [p.wait(timeout=600) for p in procs] == [0, 0]
+    q, C, _ = read_count_matrices_arrays(str(out / "single" / "result.txt"))
+    assert np.array_equal(q, z["lg_t"]) and np.array_equal(C, z["lg_counts"])
+    q, C, _ = read_count_matrices_arrays(str(out / "co" / "result.txt"))
+    ref = np.zeros_like(C)
+    ref[tuple(z["co_counts_nz"].T)] = z["co_counts_val"]
+    assert np.array_equal(q, z["co_t"]) and np.array_equal(C, ref)
