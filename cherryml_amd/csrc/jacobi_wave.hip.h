@@ -436,6 +436,7 @@ __device__ int wave_orthogonalise_first_order4(int n, const double *A, double si
     cos2 = wave_max(cos2);
     wave_lds_fence();
     const bool last = cos2 < CB_JAC_STOP * CB_JAC_STOP;
+    if (!(cos2 == cos2)) break;       // a non-finite matrix: nothing to converge to (the loss of this epoch is NaN)
     if (!(nrm <= CB_FO_MAX_NORM)) {   // near-degenerate pairs: exact rotations for this iteration
       if (n <= 4) wave_jacobi_columns<1, false>(n, Gc, nullptr, LS, 1);
       else if (n <= 8) wave_jacobi_columns<2, false>(n, Gc, nullptr, LS, 1);
@@ -475,6 +476,9 @@ __device__ int wave_orthogonalise_first_order4(int n, const double *A, double si
       break;
     }
   }
+  // insurance: the iteration count ran out without a sweep that started below CB_JAC_STOP (never observed) -- finish with
+  // the plain Jacobi sweeps, which stop by the same rule
+  if (it >= CB_FO_MAX_ITERS) it += wave_jacobi_columns_n(n, Gc, LS, CB_JAC_MAX_SWEEPS);
   return it;
 }
 
