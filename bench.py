@@ -534,7 +534,8 @@ def main():
             Lb = wl["C"].shape[0] if wl["kind"] == "sites" else 1
             nbytes = float(Lb) * B_local * S * S * 8  # C streamed once per epoch
             achieved = nbytes / (tm["small"] * 1e-3) / 1e9 if tm["small"] > 0 else 0.0
-            kname = "sp_prepare + sp_bank + sp_finish (3 launches per epoch)"
+            kname = ("sp_prepare + sp_bank + sp_finish (3 launches per epoch)" if Lb >= 64 else
+                     "sp_step (= sp_finish + sp_prepare) + sp_bank (2 launches per epoch)")
             roofline = dict(bound="hbm", kernel=kname, achieved=achieved,
                             peak=HBM_PEAK_GBS, unit="GB/s", frac=achieved / HBM_PEAK_GBS,
                             traffic=traffic.get("epoch:" + workload) if world == 1 else None,
