@@ -34,7 +34,7 @@ out = {**STAMP, "bytes_per_launch": {}, "detail": {}, "calibration": {},
        "source": f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), gpurun_out/{tag}_pmc_*"}
 NAMES = ["k1_pt_loss_gt", "k2_t_eq_g_u", "k3_w_phi", "lgj_round", "lg_transpose_pad", "small_train_kernel", "small_bank_kernel",
          "lg_prepare", "lg_bank", "lg_finish", "count_transitions_lds_kernel", "count_reduce_slabs", "k3_reduce", "sp_prepare",
-         "sp_bank", "sp_finish", "sg_gemm", "co_bucket_kernel", "co_plan_kernel", "co_expand_kernel", "co_count_lds_kernel", "lgx_build", "ble_branch_lengths_kernel", "ble_site_rates_kernel",
+         "sp_bank", "sp_finish", "sp_step", "sg_gemm", "co_bucket_kernel", "co_plan_kernel", "co_expand_kernel", "co_count_lds_kernel", "lgx_build", "ble_branch_lengths_kernel", "ble_site_rates_kernel",
          "siterm_raw_counts_kernel", "siterm_mix_kernel", "tl_mfma_kernel", "tl_leaf_kernel", "tl_group_kernel", "lg_cast_f32"]
 WORKLOADS = ["coevo400", "coevo400_mixed", "coevo400_f32", "coevo400_demo", "lg20", "siterm", "counting", "co_counting", "ble", "assembly",
              "likelihood"]
@@ -87,8 +87,10 @@ if "lg_transpose_pad" in out["detail"]:
     out["calibration"] = {"kernel": "lg_transpose_pad", "true_read_bytes": 129 * 400 * 400 * 8,
                           "FETCH_SIZE_x1024": d["fetch_KB_raw"] * 1024, "ratio": 129 * 400 * 400 * 8 / (d["fetch_KB_raw"] * 1024)}
 bpl = out["bytes_per_launch"]
-for w in ("siterm", "lg20"):   # S <= 20: three launches per epoch (sp_prepare / sp_bank / sp_finish)
-    if all(f"{k}:{w}" in bpl for k in ("sp_prepare", "sp_bank", "sp_finish")):
+for w in ("siterm", "lg20"):   # S <= 20: three launches per epoch (sp_prepare / sp_bank / sp_finish), or two for a few sites
+    if all(f"{k}:{w}" in bpl for k in ("sp_step", "sp_bank")):
+        bpl[f"epoch:{w}"] = bpl[f"sp_step:{w}"] + bpl[f"sp_bank:{w}"]
+    elif all(f"{k}:{w}" in bpl for k in ("sp_prepare", "sp_bank", "sp_finish")):
         bpl[f"epoch:{w}"] = sum(bpl[f"{k}:{w}"] for k in ("sp_prepare", "sp_bank", "sp_finish"))
 if all(f"{k}:counting" in bpl for k in ("count_transitions_lds_kernel", "count_reduce_slabs")):
     bpl["pass:counting"] = bpl["count_transitions_lds_kernel:counting"] + bpl["count_reduce_slabs:counting"]
