@@ -467,10 +467,12 @@ def test_sharded_bank_from_rank_counts_on_device_tensor():
     sb.close()
 
 
-@pytest.mark.parametrize("N,B", [(21, 7), (24, 5), (12, 9), (7, 3)])
+@pytest.mark.parametrize("N,B", [(21, 7), (24, 5), (12, 9), (7, 3), (17, 4), (16, 4), (9, 3), (3, 5)])
 def test_siterm_trainer_other_state_counts(N, B):
-    """The 4x4-tile path instantiates 1, 2, 4, 5 and 6 tiles per side (S <= 4, 8, 16, 20, 24): fused SiteRM
-    trainer (site-parallel split) against the oracle for alphabets other than 4 and 20 (21 = amino acids + gap)."""
+    """The 4x4-tile path instantiates 1, 2, 4, 5 and 6 tiles per side (S <= 4, 8, 16, 20, 24) and the warm eigensolver's
+    4x4x4 products 1 .. 6 tiles per side (S <= 4, 8, 12, 16, 20, 24; 17 and 9 states sit just above a tile boundary, i.e.
+    on zero-padded frames): fused SiteRM trainer (site-parallel split) against the oracle for alphabets other than 4 and
+    20 (21 = amino acids + gap)."""
     from cherryml_amd import quantized_transitions_mle_vectorized_over_sites as qvec
     from oracle import ratelearn_oracle as orc
     rng = np.random.default_rng(N * 10 + B)
