@@ -38,6 +38,7 @@ SIGNATURES = {
     "cb_last_timings": (C.c_int, [_vp, _vp, C.c_int]),
     "cb_timing_sums": (C.c_int, [_vp, _vp, C.c_int, C.POINTER(C.c_int)]),
     "cb_last_sweeps": (C.c_int, [_vp]),
+    "cb_eigh_counters": (C.c_int, [_vp, _vp, C.c_int]),
     "cb_last_kernel_form": (C.c_int, [_vp]),
     "cb_train_pande_reversible": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, C.c_double, C.c_int,
                                             C.c_int, _vp, _vp, _vp, _vp, C.c_int]),

@@ -147,6 +147,13 @@ class CherryBank:
     def last_sweeps(self) -> int:
         return int(_lib.load().cb_last_sweeps(self._h))
 
+    def eigh_counters(self) -> dict:
+        """planned (device-controlled) warm eigensolves of the S > 32 trainer: how many, how many had to be continued,
+        sweeps of the last one (cb_eigh_counters)."""
+        v = np.zeros(3, dtype=np.int32)
+        _lib.check(_lib.load().cb_eigh_counters(self._h, v.ctypes.data, 3), "cb_eigh_counters")
+        return {"planned_solves": int(v[0]), "stalls": int(v[1]), "last_sweeps": int(v[2])}
+
     def last_kernel_form(self) -> int:
         """which trainer kernels the last train_* call launched (cb_last_kernel_form: 1000 + 100 TS + 10 sym + w3, ...)"""
         return int(_lib.load().cb_last_kernel_form(self._h))

@@ -10,6 +10,7 @@
 #include "train_large.hip.h"
 #include "general_small.hip.h"
 #include "general_large.hip.h"
+#include "eigh_planned.hip.h"
 
 #define CB_ABI_VERSION 2
 
@@ -142,18 +143,25 @@ static int launch_small(cb_bank *h, const SmallArgs &a) {
 
 // --------------------------------------------------------------- large path
 #include "eigh_large_host.hip.h"   // launch_sg, large_eigh
+#include "eigh_planned_host.hip.h" // EighPlan, enqueue_planned_solve, eigh_planned_record
 
 // h->A (padded, symmetric) and h->dsq are filled.  Output: dQ (S x S, dQ = D^1/2 dA D^-1/2) when
 // `dA_padded` is false, else dL/dA itself as a padded LD x LD matrix.
+// `plan`: a warm solve enqueued as a device-controlled plan (eigh_planned_host.hip.h) instead of the host-driven loop; the
+// caller reads the record of solve `h->eseq` afterwards and repeats the evaluation without a plan if the solve stalled.
 static int large_eval(cb_bank *h, bool normalize, double *lossd, double *out, bool dA_padded, double *Pd,
-                      bool reuse_eigh = false) {
+                      bool reuse_eigh = false, const EighPlan *plan = nullptr, int plan_first_slot = 0) {
   const int S = h->S, LD = h->LD;
   const int B = Pd ? h->B : h->Bl;                 // the loss visits live buckets only
   const double *tb = Pd ? h->t : h->t_live;
   const size_t LL = (size_t)LD * LD;
   double *dQd = out;
   int rc = CB_OK;
-  if (!(reuse_eigh && h->have_prev)) rc = large_eigh(h, true);   // reuse: same matrix as the previous call (CB_REUSE_EIGH)
+  const bool planned_now = plan && h->have_prev;
+  // (the three bank kernels return at once when the planned solve in front of them stalled: EC_STALL)
+  const unsigned long long *skipw = planned_now ? h->ectl + EC_STALL : nullptr;
+  if (planned_now) rc = enqueue_planned_solve(h, *plan, ++h->eseq, plan_first_slot);
+  else if (!(reuse_eigh && h->have_prev)) rc = large_eigh(h, true);   // reuse: same matrix as the previous call (CB_REUSE_EIGH)
   if (rc != CB_OK) return rc;
   mark(h, EV_EIGH);
   hipLaunchKernelGGL(lg_tables, dim3((unsigned)(((size_t)B * LD + 255) / 256)), dim3(256), 0,
@@ -232,7 +240,7 @@ static int large_eval(cb_bank *h, bool normalize, double *lossd, double *out, bo
     HIP_TRY(hipGetLastError());
     return CB_OK;
   } else {
-    K1Args<double> k1{S, LD, B, h->Vc, h->A, tb, h->F, h->sigma, h->Ct, h->Gt, h->loss_part, inv_n, h->dsq, Pd};
+    K1Args<double> k1{S, LD, B, h->Vc, h->A, tb, h->F, h->sigma, h->Ct, h->Gt, h->loss_part, inv_n, h->dsq, Pd, skipw};
     if (Pd) hipLaunchKernelGGL((k1_pt_loss_gt<double, double, true>), dim3(tiles_k1 * B), dim3(LG4_THREADS), 0, h->stream, k1);
     else hipLaunchKernelGGL((k1_pt_loss_gt<double, double, false>), dim3(tiles_k1 * B), dim3(LG4_THREADS), 0, h->stream, k1);
   }
@@ -254,10 +262,10 @@ static int large_eval(cb_bank *h, bool normalize, double *lossd, double *out, bo
       hipLaunchKernelGGL(k3_reduce<float>, dim3((unsigned)((LL + 255) / 256)), dim3(256), 0, h->stream,
                          h->Gt32, B, LL, h->Mt, h->sym_counts ? LD : 0);
     } else {
-      K2Args<double> k2{LD, h->Gt, h->U, h->T};
+      K2Args<double> k2{LD, h->Gt, h->U, h->T, skipw};
       hipLaunchKernelGGL(k2_t_eq_g_u<double>, dim3(tiles * B), dim3(LG4_THREADS), 0, h->stream, k2);
       mark(h, EV_K2);
-      K3Args<double> k3{LD, B, h->T, h->U, tb, h->lam, h->E, h->H, h->Gt, h->sym_counts ? 1 : 0};
+      K3Args<double> k3{LD, B, h->T, h->U, tb, h->lam, h->E, h->H, h->Gt, h->sym_counts ? 1 : 0, skipw};
       hipLaunchKernelGGL(k3_w_phi<double>, dim3(tiles_k3 * B), dim3(LG4_THREADS), 0, h->stream, k3);
       mark(h, EV_K3);
       hipLaunchKernelGGL(k3_reduce<double>, dim3((unsigned)((LL + 255) / 256)), dim3(256), 0, h->stream,
@@ -528,6 +536,12 @@ extern "C" int cb_timing_sums(cb_handle h, double *ms_sum, int n, int *calls) {
 }
 
 extern "C" int cb_last_sweeps(cb_handle h) { return h ? h->last_sweeps : 0; }
+extern "C" int cb_eigh_counters(cb_handle h, int *counts, int n) {
+  if (!h || !counts || n < 0) return fail(CB_EINVAL, "cb_eigh_counters: NULL argument");
+  const int v[3] = {h->planned_solves, h->planned_stalls, h->last_sweeps};
+  for (int i = 0; i < n && i < 3; ++i) counts[i] = v[i];
+  return CB_OK;
+}
 extern "C" int cb_last_kernel_form(cb_handle h) { return h ? h->last_form : 0; }
 
 extern "C" int cb_last_timings(cb_handle h, double *ms, int n) {

@@ -377,6 +377,7 @@ extern "C" void cb_destroy(cb_handle h) {
     if (p) (void)hipFree(p);
   if (h->pin) (void)hipHostFree(h->pin);
   if (h->poll) (void)hipHostFree(h->poll);
+  if (h->epin) (void)hipHostFree(h->epin);
   for (hipStream_t x : h->xstream)
     if (x) {
       (void)hipStreamSynchronize(x);

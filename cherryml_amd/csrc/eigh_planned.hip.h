@@ -1,0 +1,507 @@
+// Warm solves of the large-path eigensolver WITHOUT the host in the loop (round 4).
+//
+// eigh_large_host.hip.h asks the host for a decision after every sweep (which rotation, how many squarings): a pinned-memory
+// round trip per sweep, and a solve whose duration depends on how fast the host answers.  Here every decision is taken ON THE
+// DEVICE and left in a control block (`ctl`); the host only enqueues a PLAN -- a fixed sequence of launches, predicted from the
+// previous epoch's solve -- in which every kernel reads the control block and does what the state needs:
+//
+//   slot s  (a "rotation sweep"):  lge_gram   Gamma = G^T G straight from the column-major G (both operands k-contiguous, 32-byte
+//                                             loads), X / Xf, the sweep statistics, and -- its last workgroup -- the DECISION:
+//                                             all pairs or far pairs only, polynomial order, scaling, squarings, "this is the
+//                                             final sweep"
+//                                  lge_gemm   the powers of X, the Paterson-Stockmeyer steps, the squarings and G <- G R, each
+//                                             predicated on the decision (a launch that is not needed returns at once)
+//                                  lge_poly   the polynomial coefficients B0, B1, B2 (elementwise)
+//   band pass after slot s:        lgj_round  banded Jacobi rounds (jacobi_block.hip.h), run when the sweep was a masked one
+//   lge_norms / lge_finish:        norms, sorting, U / lambda -- or, when the plan ran out before convergence, the STALL word:
+//                                  the host then repeats this solve with the host-driven loop (the only host intervention, rare)
+//
+// A plan that under-provides is never wrong, only slower: a slot that cannot evaluate the polynomial order / squarings the state
+// asks for applies exp(alpha X) with alpha < 1 (an exactly orthogonal partial rotation; "damped") and the next slot continues.
+// Schedule: band pass, far-pair rotation, band pass, then plain first-order sweeps ("B F B L L L"): on the recorded Adam trajectory
+// of the bench bank (profiles/tools/eigh_proto.py) the large-angle rotations of near-degenerate neighbours BEFORE the far-pair
+// rotation leave the state at 2e-5 .. 2.5e-4 after one far rotation instead of 2e-3 (the exact rotations of near pairs otherwise
+// mix their large cosines into the far pairs again), and the second masked sweep of the old schedule (9 products) disappears.
+// exp(Y) is evaluated to 12th order on |Y| <= 0.5 (remainder 0.5^13 / 13! = 2e-14, typically 1e-16) -- one product more than the
+// 8th-order form, two fewer than 8th order + Newton-Schulz polish.
+#pragma once
+#include "jacobi_block.hip.h"
+#include "large_bank.hip.h"
+
+// control block (unsigned long long words)
+enum {
+  EC_STALL = 0,    // sticky: the plan ended without convergence (or met a non-finite matrix); lge_finish leaves U alone
+  EC_FINAL = 1,    // index of the final sweep slot (EC_NONE while unknown): slots above it return at once
+  EC_NSWEEP = 2,   // sweeps run so far
+  EC_MODE = 3,     // decision of the current sweep: order | masked << 8 | damped << 9 | active << 16
+  EC_SQ = 4,       // squarings of the current sweep
+  EC_ERR = 5,      // 2: non-finite input
+  EC_ARRIVE = 6,   // lge_gram's arrival counter (left at zero)
+  EC_MASKED = 7,   // the last sweep rotated far pairs only (the band pass behind it runs)
+  EC_SC = 8,       // bits of the scale s: Y = s X
+  EC_BANDS = 9,    // band passes run so far
+  EC_REC = 16,     // 4 words per sweep: cosine, row sum (all pairs), row sum (far pairs), EC_MODE | sq << 24
+  EC_MAXREC = 12,
+  EC_JSTATE = 64,  // two words of lgj_round's own (running maximum; "finished", which stays zero here)
+  EC_WORDS = 80
+};
+#define EC_NONE 0xFFFFFFFFull
+
+struct GramArgs {
+  int LD, band, slot;
+  int cap;       // highest polynomial order this slot's launches evaluate: 2, 4 or 12
+  int nsq;       // squaring launches this slot has
+  const double *G;   // [LD][LD] column-major: G[c][r]
+  double *X, *Xf;
+  double *part;      // [2][LD/16][LD] row-sum partials, then [(LD/16)^2] cosine partials
+  unsigned long long *ctl;
+  double trigger;
+};
+
+__device__ __forceinline__ double lge_lim(int order) {
+  return order == 2 ? 1e-5 : order == 4 ? 2e-3 : order == 8 ? 0.06 : 0.5;
+}
+
+// One 16 x 16 tile of Gamma per workgroup, K split over its 8 waves; operands straight from L2 as 32-byte pieces of the
+// columns (chunk j of a column = its rows 16 j .. 16 j + 15; lane (lo, hi) holds rows 16 j + 4 hi .. + 3 of column lo, so
+// one double4 feeds four MFMA k-steps and a wave instruction reads 16 runs of 128 bytes).  The diagonal entries the tile
+// needs (Gamma_mm of its 16 rows, Gamma_nn of its 16 columns) are summed from the same registers in a fixed order, the same
+// order in the tile (n, m) -- X stays exactly antisymmetric.
+__global__ __launch_bounds__(512, 6) void lge_gram(GramArgs a) {   // 6 waves per SIMD = 3 workgroups per CU: 768 slots
+  __shared__ double sRed[8][256];
+  __shared__ double sDg[2][32][16];
+  __shared__ double sD[2][16];
+  __shared__ double sStat[1][8];
+  const unsigned long long *ctl = a.ctl;
+  if (ctl[EC_STALL] != 0ull || (unsigned long long)a.slot > ctl[EC_FINAL]) return;
+  const int LD = a.LD, nt = LD / 16;
+  const int tm = blockIdx.x / nt, tn = blockIdx.x - tm * nt;
+  const int m0 = tm * 16, n0 = tn * 16;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, lo = lane & 15, hi = lane >> 4;
+  const double *rowA = a.G + (size_t)(m0 + lo) * LD + 4 * hi, *rowB = a.G + (size_t)(n0 + lo) * LD + 4 * hi;
+  // (two accumulators, not four: 96 registers would leave two workgroups per CU = 512 slots for the 625 tiles, i.e. two rounds)
+  d4 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = acc0;
+  double da = 0.0, db = 0.0;
+  const int nchunks = LD / 16;
+  for (int j0 = wave; j0 < nchunks; j0 += 32) {   // four chunks of this wave in flight
+    d4 av[4], bv[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int j = min(j0 + 8 * u, nchunks - 1);
+      av[u] = *reinterpret_cast<const d4 *>(rowA + 16 * j);
+      bv[u] = *reinterpret_cast<const d4 *>(rowB + 16 * j);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      if (j0 + 8 * u < nchunks) {
+        acc0 = mfma_f64(av[u][0], bv[u][0], acc0);
+        acc1 = mfma_f64(av[u][1], bv[u][1], acc1);
+        acc0 = mfma_f64(av[u][2], bv[u][2], acc0);
+        acc1 = mfma_f64(av[u][3], bv[u][3], acc1);
+        da += (av[u][0] * av[u][0] + av[u][1] * av[u][1]) + (av[u][2] * av[u][2] + av[u][3] * av[u][3]);
+        db += (bv[u][0] * bv[u][0] + bv[u][1] * bv[u][1]) + (bv[u][2] * bv[u][2] + bv[u][3] * bv[u][3]);
+      }
+    }
+  }
+  const d4 acc = acc0 + acc1;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) sRed[wave][r * 64 + lane] = acc[r];
+  sDg[0][wave * 4 + hi][lo] = da;
+  sDg[1][wave * 4 + hi][lo] = db;
+  __syncthreads();
+  if (threadIdx.x < 32) {
+    const int w = threadIdx.x >> 4, c = threadIdx.x & 15;
+    double s = 0.0;
+#pragma unroll
+    for (int p = 0; p < 32; ++p) s += sDg[w][p][c];
+    sD[w][c] = s;
+  }
+  __syncthreads();
+  double mc2 = 0.0, rs = 0.0, rsf = 0.0;
+  if (threadIdx.x < 256) {
+    const int t = threadIdx.x, r = t >> 6, l = t & 63;
+    const int ri = (l >> 4) + 4 * r, ci = l & 15;
+    const int row = m0 + ri, col = n0 + ci;
+    double g = 0.0;
+#pragma unroll
+    for (int w = 0; w < 8; ++w) g += sRed[w][t];
+    const double gii = sD[0][ri], gjj = sD[1][ci];
+    double x = 0.0;
+    const double g2 = g * g, ab = gii * gjj;
+    if (!(g2 == g2) || !(ab == ab)) mc2 = INFINITY;   // NaN in G: reported as an infinite cosine (fmax drops NaNs)
+    if (row != col && g2 > ab * (CB_JAC_SKIP * CB_JAC_SKIP)) {
+      mc2 = fmax(mc2, g2 * fast_rcp(ab));
+      const double d = gjj - gii;
+      // (fast_rcp is odd in its argument, so X stays exactly antisymmetric)
+      x = d != 0.0 ? g * fast_rcp(d) : (g > 0.0 ? 1.0 : -1.0);   // exactly degenerate and coupled: a huge row sum
+      rs = fabs(x);
+    }
+    const int bd = row / JB_W - col / JB_W;
+    const bool far = bd > a.band || -bd > a.band;
+    a.X[(size_t)row * LD + col] = x;
+    a.Xf[(size_t)row * LD + col] = far ? x : 0.0;
+    rsf = far ? rs : 0.0;
+    // row sums over this tile's 16 columns (lanes with equal l >> 4)
+#pragma unroll
+    for (int m = 1; m < 16; m <<= 1) {
+      rs += __shfl_xor(rs, m);
+      rsf += __shfl_xor(rsf, m);
+    }
+    if (ci == 0) {
+      a.part[(size_t)tn * LD + row] = rs;
+      a.part[(size_t)(nt + tn) * LD + row] = rsf;
+    }
+    mc2 = wave_max(mc2);
+    if (l == 0) sStat[0][r] = mc2;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0)
+    a.part[(size_t)2 * nt * LD + blockIdx.x] = fmax(fmax(sStat[0][0], sStat[0][1]), fmax(sStat[0][2], sStat[0][3]));
+}
+
+// The statistics of the sweep from lge_gram's partials (fixed order) and the DECISION, one workgroup.  A launch of its own:
+// as the last-arriving workgroup of lge_gram it needed 625 arrivals on one device-scope counter and a release fence in every
+// workgroup -- 34 us for the pair against 10 + 5 for two launches.
+__global__ __launch_bounds__(512) void lge_decide(GramArgs a) {
+  __shared__ double sStat[3][8];
+  unsigned long long *ctl = a.ctl;
+  if (ctl[EC_STALL] != 0ull || (unsigned long long)a.slot > ctl[EC_FINAL]) return;
+  const int LD = a.LD, nt = LD / 16;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const double *pp = a.part;
+  double m0s = 0.0, m1s = 0.0, m2s = 0.0;
+  for (int i = threadIdx.x; i < LD; i += 512) {
+    double s1 = 0.0, s2 = 0.0;
+    int t = 0;
+    for (; t + 5 <= nt; t += 5) {
+      double u[5], v[5];
+#pragma unroll
+      for (int q = 0; q < 5; ++q) {
+        u[q] = pp[(size_t)(t + q) * LD + i];
+        v[q] = pp[(size_t)(nt + t + q) * LD + i];
+      }
+#pragma unroll
+      for (int q = 0; q < 5; ++q) {
+        s1 += u[q];
+        s2 += v[q];
+      }
+    }
+    for (; t < nt; ++t) {
+      s1 += pp[(size_t)t * LD + i];
+      s2 += pp[(size_t)(nt + t) * LD + i];
+    }
+    m1s = fmax(m1s, s1);
+    m2s = fmax(m2s, s2);
+    if (!(s1 == s1)) m0s = INFINITY;
+  }
+  for (int i = threadIdx.x; i < nt * nt; i += 512) m0s = fmax(m0s, pp[(size_t)2 * nt * LD + i]);
+  m0s = wave_max(m0s);
+  m1s = wave_max(m1s);
+  m2s = wave_max(m2s);
+  if (lane == 0) {
+    sStat[0][wave] = m0s;
+    sStat[1][wave] = m1s;
+    sStat[2][wave] = m2s;
+  }
+  __syncthreads();
+  if (threadIdx.x != 0) return;
+  double c2 = 0.0, rowsum = 0.0, rowsum_far = 0.0;
+  for (int w = 0; w < 8; ++w) {
+    c2 = fmax(c2, sStat[0][w]);
+    rowsum = fmax(rowsum, sStat[1][w]);
+    rowsum_far = fmax(rowsum_far, sStat[2][w]);
+  }
+  const double cosmax = sqrt(c2);
+  const unsigned long long k = ctl[EC_NSWEEP];
+  ctl[EC_NSWEEP] = k + 1;
+  unsigned long long mode = 0ull, sq = 0ull;
+  double sc = 1.0;
+  if (!(cosmax == cosmax) || !(rowsum == rowsum) || cosmax > 1e300 || rowsum > 1e300) {
+    ctl[EC_ERR] = 2ull;
+    ctl[EC_STALL] = 1ull;
+    ctl[EC_MASKED] = 0ull;
+  } else {
+    // all pairs at once only when the state is close enough for the small-angle limit to hold for the near-degenerate
+    // neighbours too (the rule of eigh_large_host.hip.h)
+    const bool masked = cosmax > a.trigger || rowsum > 0.5;
+    const double rsu = masked ? rowsum_far : rowsum;
+    if (!masked && cosmax <= 1e-8) ctl[EC_FINAL] = (unsigned long long)a.slot;   // starts below 1e-8: ends at rounding level
+    int order = rsu <= lge_lim(2) ? 2 : rsu <= lge_lim(4) ? 4 : rsu <= lge_lim(8) ? 8 : 12;
+    if (order > a.cap) order = a.cap;
+    const double lim = lge_lim(order);
+    while (rsu * sc > lim) {
+      sc *= 0.5;
+      ++sq;
+    }
+    unsigned long long damped = 0ull;
+    if (sq > (unsigned long long)a.nsq) {   // the slot cannot square that often: a partial (still orthogonal) rotation
+      sq = (unsigned long long)a.nsq;
+      sc = lim / rsu;
+      damped = 1ull;
+    }
+    mode = (unsigned long long)order | (masked ? 256ull : 0ull) | (damped << 9) | (1ull << 16);
+    ctl[EC_MASKED] = masked ? 1ull : 0ull;
+  }
+  ctl[EC_MODE] = mode;
+  ctl[EC_SQ] = sq;
+  ctl[EC_SC] = dbl_bits(sc);
+  if (k < EC_MAXREC) {
+    ctl[EC_REC + 4 * k + 0] = dbl_bits(cosmax);
+    ctl[EC_REC + 4 * k + 1] = dbl_bits(rowsum);
+    ctl[EC_REC + 4 * k + 2] = dbl_bits(rowsum_far);
+    ctl[EC_REC + 4 * k + 3] = mode | (sq << 24) | ((unsigned long long)a.slot << 32);
+  }
+}
+
+// what a launch of lge_gemm is (the control block decides whether it runs and on which operands)
+enum { EG_P2 = 0, EG_P34, EG_T1, EG_RP, EG_SQ, EG_GR, EG_R4 };
+
+struct EgArgs {
+  int LD, slot, kind, q;             // q: index of an EG_SQ launch
+  const unsigned long long *ctl;
+  const double *X, *Xf;              // EG_P2 / EG_P34: the generator (all pairs / far pairs)
+  double *P2, *P3, *P4;
+  const double *B0, *B1, *B2;        // lge_poly's outputs
+  double *T;                         // EG_T1's output (8th order: lge_poly writes it)
+  double *R[2], *Rt[2];              // R_q lives in R[q & 1], its transpose in Rt[q & 1]
+  const double *Gin;                 // EG_GR
+  double *Gout;
+};
+
+// out[m][n] = sum_k Aop[k][m] Bop[k][n]: sg_gemm<8, 7, 1>'s tile (one 16 x 16 tile per workgroup, K over 8 waves, seven
+// k-steps in flight) with the operands, the epilogue and the decision to run at all taken from the control block.
+// gridDim.y == 2 (EG_P34): blockIdx.y == 0 forms X^3, 1 forms X^4.
+__global__ __launch_bounds__(512) void lge_gemm(EgArgs a) {
+  __shared__ double sRed[4][256];
+  const unsigned long long *ctl = a.ctl;
+  if (ctl[EC_STALL] != 0ull || (unsigned long long)a.slot > ctl[EC_FINAL]) return;
+  const unsigned long long mode = ctl[EC_MODE];
+  if (!(mode >> 16)) return;
+  const int order = (int)(mode & 255ull);
+  const bool masked = (mode & 256ull) != 0ull;
+  const int sq = (int)ctl[EC_SQ];
+  double sc;
+  {
+    const unsigned long long b = ctl[EC_SC];
+    memcpy(&sc, &b, 8);
+  }
+  const int LD = a.LD;
+  const double *Ap, *Bp, *Bp2 = nullptr, *sub = nullptr, *sub2 = nullptr;
+  double *out, *outT = nullptr;
+  double alpha = 1.0, beta = 0.0, beta2 = 0.0, eye = 0.0, c1 = 1.0, c2 = 0.0;
+  const double *Xu = masked ? a.Xf : a.X;
+  switch (a.kind) {
+    case EG_P2:   // X^T X = -X^2; second order: R = I + X - X^T X / 2 at once
+      Ap = Xu; Bp = Xu;
+      if (order == 2) { out = a.R[0]; sub = Xu; alpha = -0.5; beta = 1.0; eye = 1.0; }
+      else out = a.P2;
+      break;
+    case EG_R4:   // fourth order in one product (slots without the polynomial launches):
+      // R = I + Y + Y^2/2 + Y^2 (Y/6 + Y^2/24),  Y = s X,  Y^2 = -s^2 P2:  acc = P2 (s X / 6 - s^2 P2 / 24)
+      if (order != 4) return;
+      Ap = a.P2; Bp = Xu; Bp2 = a.P2; c1 = sc * (1.0 / 6.0); c2 = -(sc * sc) * (1.0 / 24.0);
+      out = a.R[0]; alpha = -(sc * sc); sub = Xu; beta = sc; sub2 = a.P2; beta2 = -0.5 * (sc * sc); eye = 1.0;
+      break;
+    case EG_P34:
+      if (order < 4) return;
+      if (blockIdx.y == 0) { Ap = Xu; Bp = a.P2; out = a.P3; }     // X^T P2 = X^3
+      else { Ap = a.P2; Bp = a.P2; out = a.P4; }                   // P2^T P2 = X^4
+      break;
+    case EG_T1:   // T = B1 + Y^4 B2   (Y^4 = s^4 P4, symmetric)
+      if (order != 12) return;
+      Ap = a.P4; Bp = a.B2; out = a.T; sub = a.B1; alpha = (sc * sc) * (sc * sc); beta = 1.0;
+      break;
+    case EG_RP:   // R_0 = B0 + Y^4 T
+      if (order < 8) return;
+      Ap = a.P4; Bp = a.T; out = a.R[0]; outT = a.Rt[0]; sub = a.B0; alpha = (sc * sc) * (sc * sc); beta = 1.0;
+      break;
+    case EG_SQ:   // R_{q+1} = R_q R_q
+      if (a.q >= sq) return;
+      Ap = a.Rt[a.q & 1]; Bp = a.R[a.q & 1]; out = a.R[(a.q + 1) & 1]; outT = a.Rt[(a.q + 1) & 1];
+      break;
+    default:      // EG_GR: Gout[c'][r] = sum_c R[c][c'] Gin[c][r]
+      Ap = a.R[sq & 1]; Bp = a.Gin; out = a.Gout;
+      break;
+  }
+  const int nt = LD / 16;
+  const int tm = blockIdx.x / nt, tn = blockIdx.x - tm * nt;
+  const int m0 = tm * 16, n0 = tn * 16;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, lo = lane & 15, hi = lane >> 4;
+  d4 acc = {0.0, 0.0, 0.0, 0.0};
+  const int nsteps = LD / 4;
+  Ap += m0 + lo;
+  Bp += n0 + lo;
+  if (Bp2) Bp2 += n0 + lo;
+  for (int s0 = wave; s0 < nsteps; s0 += 7 * 8) {   // seven k-steps of this wave in flight
+    double av[7], bv[7];
+#pragma unroll
+    for (int u = 0; u < 7; ++u) {
+      const int s = min(s0 + 8 * u, nsteps - 1);
+      const size_t krow = (size_t)(4 * s + hi) * LD;
+      av[u] = Ap[krow];
+      bv[u] = Bp[krow];
+    }
+    if (Bp2) {   // (workgroup-uniform) second B operand: B = c1 Bp + c2 Bp2
+#pragma unroll
+      for (int u = 0; u < 7; ++u) {
+        const int s = min(s0 + 8 * u, nsteps - 1);
+        bv[u] = fma(c2, Bp2[(size_t)(4 * s + hi) * LD], c1 * bv[u]);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 7; ++u)
+      if (s0 + 8 * u < nsteps) acc = mfma_f64(av[u], bv[u], acc);
+  }
+  // K was split over the 8 waves: fold the upper four into the lower four, then sum those
+  if (wave >= 4) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) sRed[wave - 4][r * 64 + lane] = acc[r];
+  }
+  __syncthreads();
+  if (wave < 4) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc[r] += sRed[wave][r * 64 + lane];
+  }
+  __syncthreads();
+  if (wave < 4) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) sRed[wave][r * 64 + lane] = acc[r];
+  }
+  __syncthreads();
+  if (threadIdx.x >= 256) return;
+  const int t = threadIdx.x, r = t >> 6, l = t & 63;
+  const int row = m0 + (l >> 4) + 4 * r, col = n0 + (l & 15);
+  const double v = (sRed[0][t] + sRed[1][t]) + (sRed[2][t] + sRed[3][t]);
+  const size_t idx = (size_t)row * LD + col;
+  double o = alpha * v;
+  if (sub) o = fma(beta, sub[idx], o);
+  if (sub2) o = fma(beta2, sub2[idx], o);
+  if (eye != 0.0 && row == col) o += eye;
+  out[idx] = o;
+  if (outT) outT[(size_t)col * LD + row] = o;
+}
+
+// The polynomial coefficients of exp(Y), Y = s X, from X, P2 = -X^2, P3 = X^3, P4 = X^4 (elementwise):
+//   order 4:  R_0 = I + Y + Y^2/2 + Y^3/6 + Y^4/24
+//   order 8:  B0 = I + Y + Y^2/2 + Y^3/6,  T = I/4! + Y/5! + Y^2/6! + Y^3/7! + Y^4/8!          (R_0 = B0 + Y^4 T)
+//   order 12: B0, B1 = I/4! + .. + Y^3/7!, B2 = I/8! + Y/9! + Y^2/10! + Y^3/11! + Y^4/12!      (R_0 = B0 + Y^4 (B1 + Y^4 B2))
+struct PolyArgs {
+  int LD, slot;
+  const unsigned long long *ctl;
+  const double *X, *Xf, *P2, *P3, *P4;
+  double *B0, *B1, *B2, *T, *R0;
+};
+
+__global__ __launch_bounds__(256) void lge_poly(PolyArgs a) {
+  const unsigned long long *ctl = a.ctl;
+  if (ctl[EC_STALL] != 0ull || (unsigned long long)a.slot > ctl[EC_FINAL]) return;
+  const unsigned long long mode = ctl[EC_MODE];
+  const int order = (int)(mode & 255ull);
+  if (!(mode >> 16) || order < 4) return;
+  double sc;
+  {
+    const unsigned long long b = ctl[EC_SC];
+    memcpy(&sc, &b, 8);
+  }
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (size_t)a.LD * a.LD) return;
+  const int i = idx / a.LD, j = idx - (size_t)i * a.LD;
+  const double dl = i == j ? 1.0 : 0.0;
+  const double *Xu = (mode & 256ull) ? a.Xf : a.X;
+  const double s2 = sc * sc;
+  const double y1 = sc * Xu[idx], y2 = -s2 * a.P2[idx], y3 = s2 * sc * a.P3[idx], y4 = s2 * s2 * a.P4[idx];
+  const double b0 = dl + y1 + 0.5 * y2 + y3 * (1.0 / 6.0);
+  if (order == 4) {
+    a.R0[idx] = b0 + y4 * (1.0 / 24.0);
+    return;
+  }
+  a.B0[idx] = b0;
+  const double b1 = dl * (1.0 / 24.0) + y1 * (1.0 / 120.0) + y2 * (1.0 / 720.0) + y3 * (1.0 / 5040.0);
+  if (order == 8) {
+    a.T[idx] = b1 + y4 * (1.0 / 40320.0);
+    return;
+  }
+  a.B1[idx] = b1;
+  a.B2[idx] = dl * (1.0 / 40320.0) + y1 * (1.0 / 362880.0) + y2 * (1.0 / 3628800.0) + y3 * (1.0 / 39916800.0) +
+              y4 * (1.0 / 479001600.0);
+}
+
+// Solve prologue: sigma = max |A_ii| and a clean control block (one launch, first kernel of the solve).
+__global__ void lge_begin(int LD, const double *A, double *sigma, unsigned long long *ctl) {
+  __shared__ double s[256];
+  if (threadIdx.x < EC_WORDS) ctl[threadIdx.x] = threadIdx.x == EC_FINAL ? EC_NONE : 0ull;
+  double m = 0.0;
+  for (int i = threadIdx.x; i < LD; i += 256) m = fmax(m, fabs(A[(size_t)i * LD + i]));
+  s[threadIdx.x] = m;
+  __syncthreads();
+  for (int st = 128; st >= 1; st >>= 1) {
+    if ((int)threadIdx.x < st) s[threadIdx.x] = fmax(s[threadIdx.x], s[threadIdx.x + st]);
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *sigma = s[0] > 0.0 ? s[0] : 1.0;
+}
+
+// A stalled solve continues (more slots on the same G): the stall word cleared, everything else kept.
+__global__ void lge_resume(unsigned long long *ctl) {
+  if (threadIdx.x == 0 && ctl[EC_ERR] == 0ull) ctl[EC_STALL] = 0ull;
+}
+
+// |g_k| per column of the buffer the final sweep wrote; workgroup 0 also settles the solve's outcome (STALL when the plan
+// ended before a sweep started below 1e-8) and publishes the record of the solve to pinned host memory, where the host
+// looks BEHIND the kernels it has already enqueued (one epoch of the bank is queued at that point).
+__global__ void lge_norms(int LD, const double *G0, const double *G1, double *nrm, unsigned long long *ctl,
+                          volatile unsigned long long *pin, unsigned long long seq) {
+  const unsigned long long fin = ctl[EC_FINAL];
+  const bool stall = ctl[EC_STALL] != 0ull || fin == EC_NONE;
+  if (blockIdx.x == 0) {   // (blockDim.x == 256)
+    if (pin && threadIdx.x < EC_WORDS) {
+      const int i = threadIdx.x;
+      pin[i] = i == EC_STALL ? (stall ? 1ull : 0ull) : ctl[i];
+      __threadfence_system();
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      if (stall) ctl[EC_STALL] = 1ull;
+      if (pin) {
+        pin[EC_WORDS] = seq;   // the word the host watches, written last
+        __threadfence_system();
+      }
+    }
+  }
+  if (stall) return;
+  const double *Gc = ((fin + 1) & 1ull) ? G1 : G0;
+  const int k = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (k >= LD) return;
+  double nn = 0.0;
+  for (int r = lane; r < LD; r += 64) {
+    const double v = Gc[(size_t)k * LD + r];
+    nn = fma(v, v, nn);
+  }
+  nn = wave_sum(nn);
+  if (lane == 0) nrm[k] = sqrt(nn);
+}
+
+// lgj_finish on the buffer of the final sweep; leaves U / lambda alone after a stall
+__global__ void lge_finish(int LD, const double *G0, const double *G1, const double *nrm, const double *sigma, double *lam,
+                           double *U, double *Ut, const unsigned long long *ctl) {
+  if (ctl[EC_STALL] != 0ull) return;
+  const double *Gc = ((ctl[EC_FINAL] + 1) & 1ull) ? G1 : G0;
+  const int k = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (k >= LD) return;
+  const double mine = nrm[k];
+  int before = 0;
+  for (int j = lane; j < LD; j += 64) {
+    const double o = nrm[j];
+    before += (o > mine || (o == mine && j < k)) ? 1 : 0;
+  }
+  const int pos = (int)wave_sum((double)before);
+  const double inv = -1.0 / mine;
+  for (int r = lane; r < LD; r += 64) {
+    const double v = Gc[(size_t)k * LD + r] * inv;
+    Ut[(size_t)pos * LD + r] = v;
+    U[(size_t)r * LD + pos] = v;
+  }
+  if (lane == 0) lam[pos] = *sigma - mine;
+}

@@ -1,0 +1,215 @@
+// Host side of the planned (device-controlled) warm solves of eigh_planned.hip.h: the plan, its launches, the record a
+// finished solve leaves in pinned memory and the next plan derived from it.  Nothing here waits for the GPU: the only
+// reader of the record is the trainer loop (train_host.hip.h), which looks at it while an epoch of bank kernels is queued.
+// Included by cherrybank.hip after eigh_large_host.hip.h (launch_sg).
+#pragma once
+
+// (EighSlot / EighPlan: handle_host.hip.h -- the handle keeps the plan between CB_TRAIN_RESUME calls)
+struct EighRecord {
+  bool stall = false;
+  int err = 0, nsweep = 0, final_slot = -1;
+  struct {
+    double c, rs, rsf;
+    int order, sq, slot;
+    bool masked, damped;
+  } sweep[EC_MAXREC];
+};
+
+static const int kPlannedBand = 2;   // blocks: pairs nearer than this are rotated exactly by the band passes
+
+static void eigh_plan_default(EighPlan &p, int extra = 0) {
+  p = EighPlan{};
+  p.lead_band = 1;
+  p.nslots = std::min<int>(EC_MAXREC, 6 + extra);
+  for (int i = 0; i < p.nslots; ++i) {
+    p.slot[i].cap = i < 3 + extra ? 12 : 4;
+    p.slot[i].nsq = i == 0 ? 2 : (i < 3 + extra ? 1 : 0);
+    p.slot[i].band_after = i < 2 + extra ? 1 : 0;
+  }
+}
+
+// The next solve is planned like the last one went, with margins: one spare sweep, the twelfth-order launches wherever the
+// last generator was within 4x of the fourth-order limit, one more squaring where the last one was close to needing it.
+static void eigh_plan_from_record(const EighRecord &r, const EighPlan &prev, EighPlan &p) {
+  (void)prev;
+  if (r.stall || r.nsweep <= 0) {
+    eigh_plan_default(p, 2);
+    return;
+  }
+  p = EighPlan{};
+  const int n = std::min<int>(r.nsweep, EC_MAXREC - 1);
+  p.nslots = n + 1;
+  for (int i = 0; i < n; ++i) {
+    const auto &s = r.sweep[i];
+    const double rsu = s.masked ? s.rsf : s.rs;
+    EighSlot &q = p.slot[i];
+    // (the generator's norm moves by an order of magnitude from one epoch to the next: 20x below the fourth-order limit)
+    q.cap = (s.order >= 8 || rsu > 1e-4 || s.damped) ? 12 : (rsu > 1e-7 ? 4 : 2);
+    if (q.cap == 12) {
+      int need = s.sq + (s.damped ? 1 : 0);
+      if (rsu * std::ldexp(1.0, -s.sq) > 0.3) ++need;
+      q.nsq = std::min(2, need);
+    }
+    // a band pass behind the sweep when it is expected to be a masked one (near the rule's thresholds counts)
+    q.band_after = (s.masked || s.c > 2e-4 || s.rs > 0.3) ? 1 : 0;
+  }
+  p.slot[n] = EighSlot{4, 0, 0};   // the spare
+  // the band pass in front pays while near-degenerate neighbours are far from separated (profiles/tools/eigh_proto.py)
+  p.lead_band = (r.sweep[0].masked && r.sweep[0].c > 1e-3) ? 1 : 0;
+}
+
+// More slots for a solve whose plan ended before convergence (it continues from its current state).
+static void eigh_plan_continue(const EighRecord &r, EighPlan &p) {
+  eigh_plan_default(p, 0);
+  const bool masked = r.nsweep > 0 && r.sweep[std::min(r.nsweep, (int)EC_MAXREC) - 1].masked;
+  p.lead_band = masked ? 1 : 0;
+}
+
+static bool eigh_planned_setup(cb_bank *h) {
+  if (h->ectl) return true;
+  const int LD = h->LD, nt = LD / 16;
+  void *q = nullptr;
+  if (hipMalloc(&q, EC_WORDS * sizeof(unsigned long long)) != hipSuccess) return false;
+  h->allocs.push_back(q);
+  unsigned long long *ctl = static_cast<unsigned long long *>(q);
+  if (hipMalloc(&q, ((size_t)2 * nt * LD + (size_t)nt * nt + 8) * sizeof(double)) != hipSuccess) return false;
+  h->allocs.push_back(q);
+  h->epart = static_cast<double *>(q);
+  if (hipHostMalloc(&q, 2 * (EC_WORDS + 16) * sizeof(unsigned long long), hipHostMallocCoherent | hipHostMallocMapped) != hipSuccess) {
+    (void)hipGetLastError();
+    return false;
+  }
+  memset(q, 0, 2 * (EC_WORDS + 16) * sizeof(unsigned long long));
+  h->epin = static_cast<unsigned long long *>(q);
+  const int RS = LD + ((2 - LD % 32 + 32) % 32);
+  const size_t lds = (size_t)(16 * RS + 3 * 16 * 17 + JB_WAVES * 256) * sizeof(double);
+  if (hipFuncSetAttribute(reinterpret_cast<const void *>(lgj_round), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+    return false;
+  if (hipMemsetAsync(ctl, 0, EC_WORDS * sizeof(unsigned long long), h->stream) != hipSuccess) return false;
+  h->ectl = ctl;
+  return true;
+}
+
+// Enqueue one warm solve (h->U / h->Vc hold the previous eigenvectors, h->A the new matrix).  `seq` is what lge_norms
+// leaves in the record's sequence word.  first_slot > 0: the CONTINUATION of a stalled solve -- its G buffers hold a valid,
+// partly converged state (every rotation applied so far was orthogonal), so the new slots simply carry on from it.
+static int enqueue_planned_solve(cb_bank *h, const EighPlan &p, unsigned long long seq, int first_slot = 0) {
+  const int LD = h->LD, nt = LD / 16, nb = LD / JB_W;
+  const size_t LL = (size_t)LD * LD;
+  unsigned long long *ctl = h->ectl;
+  double *Gb[2] = {h->Gc, h->Gc2};
+  double *X = h->gx, *Xf = h->gx + LL, *P2 = h->gx + 2 * LL, *P3 = h->gx + 3 * LL, *P4 = h->gx + 4 * LL, *B0 = h->gx + 5 * LL,
+         *B1 = h->gx + 6 * LL, *B2 = h->gx + 7 * LL, *T = h->gx + 8 * LL, *R0 = h->gx + 9 * LL, *R0t = h->gx + 10 * LL,
+         *R1 = h->gx + 11 * LL, *R1t = h->gx + 6 * LL;   // (B1 is dead once R_0 exists; so is B2, but one spare is enough)
+  const int RS = LD + ((2 - LD % 32 + 32) % 32);
+  const size_t lds = (size_t)(16 * RS + 3 * 16 * 17 + JB_WAVES * 256) * sizeof(double);
+  if (first_slot > 0) {
+    hipLaunchKernelGGL(lge_resume, dim3(1), dim3(64), 0, h->stream, ctl);
+  } else {
+    hipLaunchKernelGGL(lge_begin, dim3(1), dim3(256), 0, h->stream, LD, h->A, h->sigma, ctl);
+    // warm start G = A' U_prev:  Gc[k][r] = sum_j U_prev[j][k] A[j][r] - sigma Ut_prev[k][r]
+    K4Args g0{h->S, LD, h->U, h->A, Gb[0], nullptr, h->Vc, h->sigma};
+    launch_sg(h, g0, 0);
+  }
+  unsigned long long *jstate = ctl + EC_JSTATE;   // lgj_round's own two words (zeroed by lge_begin)
+  int shift = 0;
+  auto band_pass = [&](double *G, const unsigned long long *must_nonzero) {
+    for (int w = 0; w < 2; ++w)
+      hipLaunchKernelGGL(lgj_round, dim3(nb / 2), dim3(JB_THREADS), lds, h->stream, LD, ((shift + w) & 1) && nb > 2 ? -2 : -1, 2, G,
+                         jstate, ctl + EC_STALL, must_nonzero);
+    for (int k = 2; k <= kPlannedBand && k < nb; ++k)
+      for (int par = 0; par < 2; ++par)
+        hipLaunchKernelGGL(lgj_round, dim3((unsigned)(((nb + 2 * k - 1) / (2 * k)) * k)), dim3(JB_THREADS), lds, h->stream, LD,
+                           -(10 + 2 * (k - 2) + par), 0, G, jstate, ctl + EC_STALL, must_nonzero);
+    ++shift;
+  };
+  if (p.lead_band) band_pass(Gb[first_slot & 1], nullptr);
+  const dim3 tiles((unsigned)(nt * nt));
+  const unsigned nel = (unsigned)((LL + 255) / 256);
+  for (int i = 0; i < p.nslots; ++i) {
+    const EighSlot &q = p.slot[i];
+    const int s = first_slot + i;
+    double *Gin = Gb[s & 1], *Gout = Gb[(s + 1) & 1];
+    GramArgs ga{LD, kPlannedBand, s, q.cap, q.cap == 12 ? q.nsq : 0, Gin, X, Xf, h->epart, ctl, 3e-4};
+    hipLaunchKernelGGL(lge_gram, tiles, dim3(512), 0, h->stream, ga);
+    hipLaunchKernelGGL(lge_decide, dim3(1), dim3(512), 0, h->stream, ga);
+    EgArgs e{};
+    e.LD = LD; e.slot = s; e.ctl = ctl; e.X = X; e.Xf = Xf; e.P2 = P2; e.P3 = P3; e.P4 = P4; e.B0 = B0; e.B1 = B1; e.B2 = B2; e.T = T;
+    e.R[0] = R0; e.R[1] = R1; e.Rt[0] = R0t; e.Rt[1] = R1t; e.Gin = Gin; e.Gout = Gout;
+    auto gemm = [&](int kind, int qq = 0, unsigned ny = 1) {
+      EgArgs c = e;
+      c.kind = kind;
+      c.q = qq;
+      hipLaunchKernelGGL(lge_gemm, dim3(tiles.x, ny), dim3(512), 0, h->stream, c);
+    };
+    gemm(EG_P2);
+    if (q.cap == 12) {
+      gemm(EG_P34, 0, 2);
+      PolyArgs pa{LD, s, ctl, X, Xf, P2, P3, P4, B0, B1, B2, T, R0};
+      hipLaunchKernelGGL(lge_poly, dim3(nel), dim3(256), 0, h->stream, pa);
+      gemm(EG_T1);
+      gemm(EG_RP);
+      for (int k = 0; k < q.nsq; ++k) gemm(EG_SQ, k);
+    } else if (q.cap == 4) {
+      gemm(EG_R4);   // (second order: EG_P2 has written R already and this launch returns)
+    }
+    gemm(EG_GR);
+    if (q.band_after) band_pass(Gout, ctl + EC_MASKED);
+  }
+  volatile unsigned long long *pin = h->epin + (size_t)(seq & 1ull) * (EC_WORDS + 16);
+  hipLaunchKernelGGL(lge_norms, dim3((LD + 3) / 4), dim3(256), 0, h->stream, LD, Gb[0], Gb[1], h->X, ctl, pin, seq);
+  hipLaunchKernelGGL(lge_finish, dim3((LD + 3) / 4), dim3(256), 0, h->stream, LD, Gb[0], Gb[1], h->X, h->sigma, h->lam, h->U, h->Vc,
+                     ctl);
+  HIP_TRY(hipGetLastError());
+  return CB_OK;
+}
+
+// The record of solve `seq`, once lge_norms has published it.  The caller has an epoch of bank kernels queued behind the
+// solve, so looking here is not on the GPU's critical path; after 200 ms without the word the stream is synchronised.
+static int eigh_planned_record(cb_bank *h, unsigned long long seq, EighRecord &r) {
+  volatile unsigned long long *pin = h->epin + (size_t)(seq & 1ull) * (EC_WORDS + 16);
+  const auto t0 = std::chrono::steady_clock::now();
+  bool got = false;
+  for (unsigned it = 0;; ++it) {
+    if (pin[EC_WORDS] == seq) {
+      got = true;
+      break;
+    }
+#if defined(__x86_64__)
+    __builtin_ia32_pause();
+#endif
+    if ((it & 4095u) == 4095u && std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() > 200.0) break;
+  }
+  if (!got) {
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    if (pin[EC_WORDS] != seq) return fail(CB_EHIP, "eigensolver: the record of the planned solve never reached the host");
+  }
+  std::atomic_thread_fence(std::memory_order_acquire);
+  r = EighRecord{};
+  r.stall = pin[EC_STALL] != 0ull;
+  r.err = (int)pin[EC_ERR];
+  {
+    const unsigned long long ns = pin[EC_NSWEEP];
+    r.nsweep = (int)(ns < (unsigned long long)EC_MAXREC ? ns : (unsigned long long)EC_MAXREC);
+  }
+  r.final_slot = pin[EC_FINAL] == EC_NONE ? -1 : (int)pin[EC_FINAL];
+  for (int k = 0; k < r.nsweep; ++k) {
+    unsigned long long w[4] = {pin[EC_REC + 4 * k], pin[EC_REC + 4 * k + 1], pin[EC_REC + 4 * k + 2], pin[EC_REC + 4 * k + 3]};
+    memcpy(&r.sweep[k].c, &w[0], 8);
+    memcpy(&r.sweep[k].rs, &w[1], 8);
+    memcpy(&r.sweep[k].rsf, &w[2], 8);
+    r.sweep[k].order = (int)(w[3] & 255ull);
+    r.sweep[k].masked = (w[3] & 256ull) != 0ull;
+    r.sweep[k].damped = (w[3] & 512ull) != 0ull;
+    r.sweep[k].sq = (int)((w[3] >> 24) & 255ull);
+    r.sweep[k].slot = (int)(w[3] >> 32);
+  }
+  if (getenv("CB_DEBUG")) {
+    fprintf(stderr, "[cherrybank] planned eigh %llu:%s", seq, r.stall ? " STALL" : "");
+    for (int k = 0; k < r.nsweep; ++k)
+      fprintf(stderr, " %s%d%s/%d c=%.1e |X|<=%.1e(%.1e)", r.sweep[k].masked ? "M" : "L", r.sweep[k].order, r.sweep[k].damped ? "d" : "",
+              r.sweep[k].sq, r.sweep[k].c, r.sweep[k].rs, r.sweep[k].rsf);
+    fprintf(stderr, "\n");
+  }
+  return CB_OK;
+}

@@ -2,6 +2,17 @@
 // pinned-staging allocation.  Included by cherrybank.hip (one translation unit; see eigh_large_host.hip.h).
 #pragma once
 // ------------------------------------------------------------------ handle
+// plan of a device-controlled warm eigensolve (eigh_planned_host.hip.h)
+struct EighSlot {
+  int cap = 12;         // polynomial order the slot's launches can evaluate: 2 (one product), 4 (two) or 12 (powers, polynomial, two more)
+  int nsq = 0;          // squaring launches
+  int band_after = 0;   // a banded Jacobi pass behind the sweep (runs when the sweep was a masked one)
+};
+struct EighPlan {
+  int lead_band = 1;    // a banded Jacobi pass before the first sweep
+  int nslots = 0;
+  EighSlot slot[EC_MAXREC];
+};
 struct cb_bank {
   int dev = 0, S = 0, L = 0, B = 0;
   int B_cap = 0;        // B at creation (cb_internal_set_times may lower B)
@@ -56,6 +67,13 @@ struct cb_bank {
   unsigned long long *off_bits = nullptr;
   unsigned long long *poll = nullptr;      // 8 words of coherent pinned host memory the first-order sweep publishes to
   unsigned long long poll_seq = 0;
+  // planned (device-controlled) warm solves, eigh_planned_host.hip.h: control block, statistics partials, pinned records
+  unsigned long long *ectl = nullptr, *epin = nullptr;
+  double *epart = nullptr;
+  unsigned long long eseq = 0;
+  int planned_solves = 0, planned_stalls = 0;   // counters (cb_eigh_counters)
+  EighPlan eplan;            // the next solve's plan: part of the optimisation's state (a resumed call continues with it,
+                             // so W + K epochs in two calls equal one call bit for bit)
   int k3_chunk = 0, k3_nchunks = 0;
   int last_sweeps = 0;
   double *gn_scratch = nullptr, *gn_partial = nullptr;  // general path, allocated on first use

@@ -53,11 +53,16 @@ __device__ __forceinline__ int jb_rowstride(int LD) { return LD + ((2 - LD % 32 
 // round <= -10: banded round of the hybrid sweep (large_eigh): code = -round - 10, k = code / 2 + 2,
 //             parity = code & 1: block pairs (i, i + k) with (i / k) % 2 == parity, cross pairs once
 //             (the eigen-columns are kept sorted, so near-degenerate columns are a few blocks apart).
+// must_zero / must_nonzero (planned solves, eigh_planned.hip.h): words of the device-side control block that decide whether
+// this launch runs (the stall word; "the last sweep rotated far pairs only").
 __global__ __launch_bounds__(JB_THREADS) void lgj_round(int LD, int round, int inner_sweeps,
-                                                        double *Gc, unsigned long long *off_bits) {
+                                                        double *Gc, unsigned long long *off_bits,
+                                                        const unsigned long long *must_zero = nullptr,
+                                                        const unsigned long long *must_nonzero = nullptr) {
   // off_bits[0]: running max cosine of this sweep; off_bits[1]: solve finished (set by lgj_check):
   // sweeps are enqueued speculatively, the surplus launches return at once
   if (off_bits[1] != 0ull) return;
+  if ((must_zero && *must_zero != 0ull) || (must_nonzero && *must_nonzero == 0ull)) return;
   extern __shared__ double lds[];
   const int RS = jb_rowstride(LD);
   double *sG = lds;                 // [16][RS]

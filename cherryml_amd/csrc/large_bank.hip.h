@@ -229,6 +229,8 @@ struct K1Args {
   double inv_n;
   const double *dsq;     // [LD] sqrt(pi) (expm mode)
   double *P;             // [B][S][S] (expm mode, T = double only) or null
+  const unsigned long long *skip = nullptr;   // device word: non-zero => return at once (the planned eigensolve stalled; the
+                                              // host repeats the evaluation, train_host.hip.h)
 };
 
 // Pt_b is symmetric: only the tilesN (tilesN + 1) / 2 tiles with tm <= tn run the main loop; an
@@ -236,6 +238,7 @@ struct K1Args {
 // count and its own Gt^T entry).  40 % fewer MFMAs than the full grid at LD = 400.
 template <typename T, typename TG = T, bool EXPM = false>   // EXPM: write P_b (cb_expm_bank) instead of loss / Gt
 __global__ __launch_bounds__(LG4_THREADS, 4) void k1_pt_loss_gt(K1Args<T, TG> a) {  // four workgroups per CU
+  if (a.skip && *a.skip != 0ull) return;
   __shared__ T sAB[4 * LG_KT * LG_TM];   // A panels | B panels (two K-steps each); after the K loop: the transposition buffer
   T *sA = sAB, *sB = sAB + 2 * LG_KT * LG_TM;
   typedef typename Mfma<T>::acc_t acc_t;
@@ -384,10 +387,12 @@ struct K2Args {
   const T *Gt;  // [B][LD][LD]
   const T *U;   // [LD][LD]
   T *Tm;        // [B][LD][LD]
+  const unsigned long long *skip = nullptr;   // as K1Args::skip
 };
 
 template <typename T>
 __global__ __launch_bounds__(LG4_THREADS, 4) void k2_t_eq_g_u(K2Args<T> a) {
+  if (a.skip && *a.skip != 0ull) return;
   __shared__ T sA[2 * LG_KT * LG_TM];
   __shared__ T sB[2 * LG_KT * LG_TN];
   typedef typename Mfma<T>::acc_t acc_t;
@@ -422,10 +427,12 @@ struct K3Args {
   const double *H;       // [B][LD] exp(t lam / 2)
   T *W;                  // [B][LD][LD] out (aliases the Gt buffer)
   int sym;               // counts symmetric => Gt_b, hence W_b, symmetric: upper-triangular tiles only
+  const unsigned long long *skip = nullptr;   // as K1Args::skip
 };
 
 template <typename T>
 __global__ __launch_bounds__(LG4_THREADS, 4) void k3_w_phi(K3Args<T> a) {
+  if (a.skip && *a.skip != 0ull) return;
   __shared__ T sA[2 * LG_KT * LG_TM];
   __shared__ T sB[2 * LG_KT * LG_TN];
   typedef typename Mfma<T>::acc_t acc_t;

@@ -109,6 +109,14 @@ static int run_fused_training_large(cb_bank *h, double *pi_param, double *up_par
   h->tr_epochs = 0;   // (set again when this call succeeds)
   // fault injection for the tests of the collective failure protocol: this rank's evaluation "fails" at that epoch
   const int fault_epoch = getenv("CB_FAULT_INJECT") ? atoi(getenv("CB_FAULT_INJECT")) : -1000;
+  // planned solves: float64 work on LD x LD matrices with LD a multiple of 16 and at least 8 column blocks (the hybrid
+  // scheme's own condition); CB_EIGH_HOST=1 keeps the host-driven loop of rounds 1-3
+  const bool planned = !getenv("CB_EIGH_HOST") && !getenv("CB_NO_HYBRID") && LD % 16 == 0 && LD / JB_W >= 8 && eigh_planned_setup(h);
+  EighPlan &plan = h->eplan;
+  if (!resume) eigh_plan_default(plan);
+  // test hook: every plan cut down to one sweep, so that every solve stalls and is continued (tests/test_gpu_s400_full.py)
+  const bool short_plans = getenv("CB_EIGH_SHORT_PLAN") != nullptr;
+  if (short_plans) plan.nslots = 1;
   for (int e = 0; e < E && rc == CB_OK; ++e) {
     if (h->profile) {  // fold the epoch before the previous one (its events are long complete), then re-record that set
       swap_event_sets(h);
@@ -118,7 +126,43 @@ static int run_fused_training_large(cb_bank *h, double *pi_param, double *up_par
     hipLaunchKernelGGL(lt_pi, dim3(1), dim3(256), 0, h->stream, a);
     hipLaunchKernelGGL(lt_build, dim3(LD), dim3(256), 0, h->stream, a, e0 + e);
     mark(h, EV_START);
-    rc = large_eval(h, flags & CB_NORMALIZE, h->loss, h->Mt, true, nullptr);
+    // Every solve after the first is a PLAN (eigh_planned_host.hip.h): the device takes the sweep decisions, the host enqueues
+    // the whole epoch and only then looks at the solve's record -- with K1 .. K4 queued behind it, so the GPU never waits.
+    const bool use_plan = planned && h->have_prev;
+    rc = large_eval(h, flags & CB_NORMALIZE, h->loss, h->Mt, true, nullptr, false, use_plan ? &plan : nullptr);
+    if (rc == CB_OK && use_plan) {
+      EighRecord rec;
+      rc = eigh_planned_record(h, h->eseq, rec);
+      ++h->planned_solves;
+      if (rc == CB_OK && rec.err == 2) rc = fail(CB_ENUMERIC, "eigensolver: non-finite input");
+      int slots_done = plan.nslots;
+      for (int attempt = 0; rc == CB_OK && rec.stall && attempt < 3; ++attempt) {
+        // the plan ended before the solve converged: U, lambda untouched, the queued K1 .. K3 returned at once (EC_STALL).
+        // The solve CONTINUES from its current state with more slots, and the epoch's kernels are enqueued again.
+        ++h->planned_stalls;
+        EighPlan more;
+        eigh_plan_continue(rec, more);
+        for (bool &b : h->ev_rec) b = false;
+        mark(h, EV_START);
+        rc = large_eval(h, flags & CB_NORMALIZE, h->loss, h->Mt, true, nullptr, false, &more, slots_done);
+        slots_done += more.nslots;
+        if (rc == CB_OK) rc = eigh_planned_record(h, h->eseq, rec);
+        if (rc == CB_OK && rec.err == 2) rc = fail(CB_ENUMERIC, "eigensolver: non-finite input");
+      }
+      if (rc == CB_OK && rec.stall) {   // still not converged: the host-driven solver, from the previous eigenvectors
+        HIP_TRY(hipStreamSynchronize(h->stream));
+        HIP_TRY(hipMemsetAsync(h->ectl, 0, sizeof(unsigned long long), h->stream));
+        for (bool &b : h->ev_rec) b = false;
+        mark(h, EV_START);
+        rc = large_eval(h, flags & CB_NORMALIZE, h->loss, h->Mt, true, nullptr);
+      }
+      if (rc == CB_OK) {
+        const EighPlan prev = plan;
+        eigh_plan_from_record(rec, prev, plan);
+        if (short_plans) plan.nslots = 1;
+        h->last_sweeps = rec.nsweep;
+      }
+    }
     if (rc == CB_OK && fault_epoch == e) rc = fail(CB_ENUMERIC, "injected fault at epoch %d (CB_FAULT_INJECT)", e);
     if (rc != CB_OK && h->comm) {
       // A rank that fails alone (its eigensolver met a non-finite matrix, say) must not leave its peers

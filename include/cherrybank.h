@@ -161,6 +161,12 @@ int cb_timing_sums(cb_handle h, double *ms_sum, int n, int *calls);
 /* sweeps used by the last large-path eigendecomposition: tournament (Jacobi) sweeps of the cold path
  * + hybrid / first-order sweeps of a warm-started solve */
 int cb_last_sweeps(cb_handle h);
+/* Warm solves of the large-path eigensolver run as device-controlled PLANS inside cb_train_pande_reversible (S > 32):
+ * the sweep decisions are taken on the device and the host only looks at a solve's record while the epoch's bank kernels
+ * are queued (csrc/eigh_planned.hip.h).  counts[0] = planned solves so far on this handle, counts[1] = how many of them
+ * ran out of plan before converging and were continued with more slots ("stalls"; rare), counts[2] = sweeps of the last
+ * planned solve.  CB_EIGH_HOST=1 in the environment keeps the host-driven solver of rounds 1-3 (counts stay 0). */
+int cb_eigh_counters(cb_handle h, int *counts, int n);
 /* Which kernels the last cb_train_* call on this handle launched (tests pin the form they compare): 1000 + 100 TS +
  * 10 sym + w3 = the site-parallel split sp_prepare / sp_bank<TS, sym, w3> / sp_finish (TS = ceil(S / 4) tiles, sym =
  * symmetric-count form, w3 = three workgroups per CU); 2000 = lg_prepare / lg_bank / lg_finish (one bank, 24 < S <= 32);

@@ -268,6 +268,40 @@ def test_resumed_training_equals_one_call(dense):
             small.train_pande_reversible(np.zeros(nup), np.zeros(20), num_epochs=2, resume=True)
 
 
+def test_planned_eigensolves_match_the_host_driven_solver_and_survive_short_plans(dense, monkeypatch):
+    """Round 4: every warm eigensolve of the C-driven trainer is a device-controlled PLAN (csrc/eigh_planned.hip.h: the sweep
+    decisions are taken on the device, the host only reads a record while the epoch's bank kernels are queued).  The same 25
+    epochs (a) planned, (b) with the host-driven solver of rounds 1-3 (CB_EIGH_HOST=1), (c) planned with every plan cut down
+    to ONE sweep (CB_EIGH_SHORT_PLAN=1: every solve runs out of plan, is continued from its current state, and the epoch's
+    kernels are enqueued again): same loss curves to 1e-11, same matrices to 1e-9; the counters say which path ran."""
+    from cherryml_amd import CherryBank
+    z = load_golden("coevo_dense_traj.npz")
+    sel, mask = z["sel"], dense["mask"]
+    t, C = dense["t"][sel], dense["C"][sel]
+    u0, p0 = z["upper_diag0"], z["log_pi0"]
+    E = 25
+    runs = {}
+    for name, env in (("planned", {}), ("host", {"CB_EIGH_HOST": "1"}), ("short", {"CB_EIGH_SHORT_PLAN": "1"})):
+        for k in ("CB_EIGH_HOST", "CB_EIGH_SHORT_PLAN"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        with CherryBank(t, C) as bank:
+            r = bank.train_pande_reversible(u0, p0, mask=mask, num_epochs=E, lr=0.1)
+            r["counters"] = bank.eigh_counters()
+        runs[name] = r
+    a, b, c = runs["planned"], runs["host"], runs["short"]
+    assert a["counters"]["planned_solves"] == E - 1       # every solve but the cold first one
+    assert a["counters"]["stalls"] <= 6                   # (the first warm solves of a training start far from converged)
+    assert b["counters"]["planned_solves"] == 0
+    assert c["counters"]["planned_solves"] == E - 1 and c["counters"]["stalls"] >= E - 1
+    for other in (b, c):
+        assert np.all(np.isfinite(other["loss"]))
+        assert np.allclose(a["loss"], other["loss"], rtol=1e-11, atol=0)
+        for key in ("Q_last", "Q_best"):
+            assert relerr(a[key], other[key]) < 1e-9, key
+
+
 def test_two_queue_bank_option_gives_the_same_bits(dense, tmp_path):
     """CB_BANK_STREAMS=2 (read once per process, hence the subprocess): the buckets' K1 -> K2 -> K3 chains on two
     queues -- the trajectory is bit-identical to the single-queue one."""
