@@ -9,6 +9,7 @@ CB_PTR_DEVICE = 1
 CB_NORMALIZE = 2
 CB_TRAIN_RESUME = 16
 CB_NO_SYNC = 4
+CB_EXPM_ONLY = 8
 CB_F64, CB_F32, CB_MIXED = 0, 1, 2
 
 CB_EINVAL, CB_EHIP, CB_ENOMEM, CB_ENUMERIC, CB_EUNSUPPORTED = -1, -2, -3, -4, -5
@@ -45,6 +46,7 @@ SIGNATURES = {
     "cb_train_siterm": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_double, C.c_int, _vp, _vp]),
     "cb_count_transitions": (C.c_int, [C.c_int, C.c_int, C.c_int, _vp, _vp, C.c_int64, _vp, C.c_int64,
                                        _vp, C.c_int64, C.c_int, C.c_int, _vp]),
+    "cb_jtt_ipw_stats": (C.c_int, [C.c_int, C.c_int, C.c_int, _vp, C.c_int, _vp, C.c_double, C.c_int, C.c_int, _vp, _vp]),
     "cb_count_co_transitions": (C.c_int, [C.c_int, C.c_int, C.c_int, _vp, _vp, C.c_int64, _vp, C.c_int64,
                                           _vp, C.c_int64, C.c_int, C.c_int, _vp]),
     "cb_ble_log_bank": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp]),

@@ -77,20 +77,21 @@ def _pairs_and_codes(tree, msa, alphabet, transitions_strategy):
 
 
 def get_count_prior_probability_matrices(rate_matrix: np.ndarray, quantization_points_sorted) -> np.ndarray:
-    """:325-355: prior[b] = diag(pi0) expm(t_b Q0) through the reversible factorisation
-    (markov_chain/_markov_chain.py:56-155); ValueError when a matrix does not sum to 1."""
+    """:325-355: prior[b] = diag(pi0) expm(t_b Q0); ValueError when a matrix does not sum to 1.  The reference goes
+    through the reversible factorisation on the host (markov_chain/_markov_chain.py:56-155); here the bank expm(t_b Q0)
+    is the hot path's own spectral expm kernel (`cb_expm_bank`: symmetrised eigendecomposition + the phi_2 split on the
+    device), only the stationary vector of the 20 x 20 model is host arithmetic."""
+    from ..bank import CherryBank
     Q0 = np.asarray(rate_matrix, dtype=np.float64)
+    grid = np.asarray(quantization_points_sorted, dtype=np.float64)
     w, v = np.linalg.eig(Q0.transpose())
     pi = v[:, int(np.argmin(np.abs(w.real)))].real
     pi = pi / pi.sum()
-    P1, P2 = np.diag(np.sqrt(pi)), np.diag(np.sqrt(1.0 / pi))
-    D, U = np.linalg.eigh(P1 @ Q0 @ P2)
-    left, right = P2 @ U, U.T @ P1
-    out = np.zeros((len(quantization_points_sorted),) + Q0.shape)
-    for b, t in enumerate(quantization_points_sorted):
-        out[b] = pi[:, None] * (left @ (np.diag(np.exp(t * D)) @ right))
-        if abs(float(out[b].sum()) - 1.0) > 1e-6:
-            raise ValueError("count_prior_probability_matrices[b, :, :] does not add up to 1!")
+    with CherryBank.expm_only(grid, Q0.shape[0]) as bank:
+        out = pi[None, :, None] * bank.expm_bank(Q0, pi)[0]
+    bad = np.abs(out.sum(axis=(1, 2)) - 1.0) > 1e-6
+    if np.any(bad) or not np.all(np.isfinite(out)):
+        raise ValueError("count_prior_probability_matrices[b, :, :] does not add up to 1!")
     return out
 
 

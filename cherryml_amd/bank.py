@@ -98,6 +98,25 @@ class CherryBank:
                                                   n.ctypes.data), "cb_allreduce_setup")
 
     # -- lifetime ---------------------------------------------------------
+    @classmethod
+    def expm_only(cls, t, num_states: int, device: int = 0) -> "CherryBank":
+        """A counts-free bank (cb_create with CB_EXPM_ONLY): branch lengths only, serves `expm_bank` / `eigh`; the loss and
+        training entry points refuse it."""
+        import ctypes as Ct
+        lib = _lib.load()
+        if lib.cb_device_count() <= 0:
+            raise _lib.CherryBankError("no HIP device visible; cherryml_amd has no CPU fallback")
+        self = cls.__new__(cls)
+        self._h = None
+        self.dtype = "f64"
+        tn = _as_f64(t).reshape(-1)
+        self.L, self.B, self.S, self.device = 1, int(tn.size), int(num_states), int(device)
+        h = Ct.c_void_p()
+        _lib.check(lib.cb_create(self.device, self.S, 1, self.B, _lib.CB_F64, tn.ctypes.data, None, _lib.CB_EXPM_ONLY,
+                                 Ct.byref(h)), "cb_create")
+        self._h = h
+        return self
+
     def close(self):
         if getattr(self, "_h", None) is not None:
             _lib.load().cb_destroy(self._h)

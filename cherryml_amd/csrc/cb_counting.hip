@@ -390,3 +390,63 @@ extern "C" int cb_siterm_assemble(int device, int S, int B, int n_sites, const d
   return cb_siterm_assemble_batch(device, S, B, 1, &n_sites, grid, seqs, seqs_bytes, pairs, &n_pairs, site_rates, prior,
                                   lambda, include_reverse, flags, counts, kernel_ms);
 }
+
+// ------------------------------------------------------------------------ JTT-IPW statistics
+extern "C" int cb_jtt_ipw_stats(int device, int S, int B, const void *counts, int counts_f64, const double *grid, double unit,
+                                int symmetrize, int flags, double *F, double *R) {
+  if (S <= 0 || B <= 0 || !counts || !grid || !F || !R) return fail(CB_EINVAL, "cb_jtt_ipw_stats: bad argument");
+  HIP_TRY(hipSetDevice(device));
+  const size_t SS = (size_t)S * S, nC = (size_t)B * SS;
+  const bool devp = (flags & CB_PTR_DEVICE) != 0;
+  const void *dC = counts;
+  const double *dgrid = grid;
+  double *dF = F, *dR = R;
+  void *tmp[3] = {nullptr, nullptr, nullptr};
+  auto cleanup = [&]() {
+    for (void *p : tmp)
+      if (p) (void)hipFree(p);
+  };
+  if (!devp) {
+    if (hipMalloc(&tmp[0], nC * 8) != hipSuccess || hipMalloc(&tmp[1], (size_t)B * 8) != hipSuccess ||
+        hipMalloc(&tmp[2], 2 * SS * 8) != hipSuccess) {
+      cleanup();
+      return fail(CB_ENOMEM, "cb_jtt_ipw_stats: device allocation failed");
+    }
+    if (hipMemcpy(tmp[0], counts, nC * 8, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(tmp[1], grid, (size_t)B * 8, hipMemcpyHostToDevice) != hipSuccess) {
+      cleanup();
+      return fail(CB_EHIP, "cb_jtt_ipw_stats: upload failed");
+    }
+    dC = tmp[0];
+    dgrid = static_cast<const double *>(tmp[1]);
+    dF = static_cast<double *>(tmp[2]);
+    dR = dF + SS;
+  }
+  const int nt = (S + 15) / 16, npairs = nt * (nt + 1) / 2, nchunks = (B + JT_BC - 1) / JT_BC;
+  unsigned long long *scratch = nullptr;
+  int rc = count_scratch(device, (size_t)nchunks * 2 * SS, &scratch);
+  if (rc != CB_OK) {
+    cleanup();
+    return rc;
+  }
+  double *part = reinterpret_cast<double *>(scratch);
+  // (the padded rows / columns of edge tiles are never written; jtt_stats_reduce only reads entries inside S x S)
+  const dim3 g((unsigned)npairs, (unsigned)nchunks);
+  if (counts_f64)
+    hipLaunchKernelGGL(jtt_stats_partial<double>, g, dim3(256), 0, 0, S, B, static_cast<const double *>(dC), dgrid, unit,
+                       symmetrize, part);
+  else
+    hipLaunchKernelGGL(jtt_stats_partial<unsigned long long>, g, dim3(256), 0, 0, S, B,
+                       static_cast<const unsigned long long *>(dC), dgrid, unit, symmetrize, part);
+  hipLaunchKernelGGL(jtt_stats_reduce, dim3((unsigned)((2 * SS + 255) / 256)), dim3(256), 0, 0, 2 * SS, nchunks, part, dF, dR);
+  if (hipGetLastError() != hipSuccess) {
+    cleanup();
+    return fail(CB_EHIP, "cb_jtt_ipw_stats: launch failed");
+  }
+  if (!devp) {
+    const hipError_t e1 = hipMemcpy(F, dF, SS * 8, hipMemcpyDeviceToHost), e2 = hipMemcpy(R, dR, SS * 8, hipMemcpyDeviceToHost);
+    cleanup();
+    if (e1 != hipSuccess || e2 != hipSuccess) return fail(CB_EHIP, "cb_jtt_ipw_stats: download failed");
+  }
+  return CB_OK;
+}

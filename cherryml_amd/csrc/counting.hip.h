@@ -622,3 +622,83 @@ __global__ __launch_bounds__(64) void siterm_mix_kernel(int S, int B, const doub
     if (x != y) M[y * S + x] = __dadd_rn(__dmul_rn(ryx, one_m), __dmul_rn(__dmul_rn(l1, P[y * S + x]), lambda));
   }
 }
+
+// ------------------------------------------------------------------------ JTT-IPW statistics
+// The two S x S sums the closed-form initialiser is made of (reference: cherryml/estimation/_jtt_ipw.py:66-110):
+//   F[i][j] = sum_b sym(C_b)[i][j],   R[i][j] = sum_b sym(C_b)[i][j] / t_b,   sym(C) = (C + C^T) / 2  (or C itself)
+// from the resident count tensor (u64 integers in units of `unit`, as the counting kernels leave them, or doubles).
+// One streaming pass: workgroup = (upper-triangular 16 x 16 tile pair, chunk of JT_BC buckets); thread (r, c) sums its
+// entry of the tile AND of the mirror tile (both read along rows: 128-byte runs), the mirror sums are transposed once
+// through LDS at the end (sums are linear), so every count is read exactly once.  Partials per chunk, summed in a fixed
+// order by jtt_stats_reduce: the result does not depend on the launch geometry or on timing.
+#define JT_BC 16
+template <typename T>
+__global__ __launch_bounds__(256) void jtt_stats_partial(int S, int B, const T *__restrict__ C, const double *__restrict__ grid,
+                                                         double unit, int symmetrize, double *__restrict__ part) {
+  __shared__ double sF[16][17], sR[16][17];
+  const int nt = (S + 15) / 16;
+  // tile pair index -> (ti <= tj)
+  int ti = 0, rem = blockIdx.x;
+  while (rem >= nt - ti) {
+    rem -= nt - ti;
+    ++ti;
+  }
+  const int tj = ti + rem;
+  const int r = threadIdx.x >> 4, c = threadIdx.x & 15;
+  const int i = ti * 16 + r, j = tj * 16 + c;     // my entry of tile (ti, tj)
+  const int i2 = tj * 16 + r, j2 = ti * 16 + c;   // my entry of the mirror tile (tj, ti)
+  const bool ok = i < S && j < S, ok2 = i2 < S && j2 < S;
+  const int b0 = blockIdx.y * JT_BC, b1 = min(B, b0 + JT_BC);
+  double aF = 0.0, aR = 0.0, mF = 0.0, mR = 0.0;
+  const size_t SS = (size_t)S * S;
+  for (int b = b0; b < b1; ++b) {
+    const double t = grid[b];
+    const double v = ok ? (double)C[b * SS + (size_t)i * S + j] : 0.0;
+    const double w = ok2 ? (double)C[b * SS + (size_t)i2 * S + j2] : 0.0;
+    aF += v;
+    aR += v / t;
+    mF += w;
+    mR += w / t;
+  }
+  double *pF = part + (size_t)blockIdx.y * 2 * SS, *pR = pF + SS;
+  if (!symmetrize) {   // F = sum_b C_b: both tiles as they are
+    if (ok) {
+      pF[(size_t)i * S + j] = aF * unit;
+      pR[(size_t)i * S + j] = aR * unit;
+    }
+    if (ok2 && ti != tj) {
+      pF[(size_t)i2 * S + j2] = mF * unit;
+      pR[(size_t)i2 * S + j2] = mR * unit;
+    }
+    return;
+  }
+  sF[r][c] = mF;
+  sR[r][c] = mR;
+  __syncthreads();
+  const double symF = 0.5 * (aF + sF[c][r]) * unit, symR = 0.5 * (aR + sR[c][r]) * unit;
+  __syncthreads();
+  if (ok) {
+    pF[(size_t)i * S + j] = symF;
+    pR[(size_t)i * S + j] = symR;
+  }
+  if (ti != tj) {   // the mirror tile is the transpose: through LDS, so that the stores run along rows too
+    sF[r][c] = symF;
+    sR[r][c] = symR;
+    __syncthreads();
+    if (ok2) {
+      pF[(size_t)i2 * S + j2] = sF[c][r];
+      pR[(size_t)i2 * S + j2] = sR[c][r];
+    }
+  }
+}
+
+__global__ void jtt_stats_reduce(size_t n2, int nchunks, const double *__restrict__ part, double *__restrict__ F,
+                                 double *__restrict__ R) {
+  const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n2) return;
+  const size_t SS = n2 / 2;
+  double s = 0.0;
+  for (int k = 0; k < nchunks; ++k) s += part[(size_t)k * n2 + e];
+  if (e < SS) F[e] = s;
+  else R[e - SS] = s;
+}

@@ -27,19 +27,9 @@ from ..counting._stage import _device_index, _gather, _my_families, _normalise_m
 def jtt_ipw_from_reduced_statistics(F_sym: np.ndarray, R_sym: np.ndarray, grid: np.ndarray, mask: Optional[np.ndarray],
                                     pseudocounts: float = 1e-8) -> np.ndarray:
     """`jtt_ipw_from_arrays(use_ipw=True, symmetrize=True)` from F_sym = sum_b sym(C_b) and R_sym = sum_b sym(C_b) / t_b
-    (sym(C) = (C + C^T) / 2): the pseudocount enters every bucket once, the mask multiplies entrywise."""
-    B = len(grid)
-    S = F_sym.shape[0]
-    m = np.ones((S, S)) if mask is None else np.asarray(mask, dtype=np.float64)
-    hollow = 1.0 - np.eye(S)
-    F = (F_sym + B * pseudocounts) * m
-    R = (R_sym + pseudocounts * np.sum(1.0 / np.asarray(grid, dtype=np.float64))) * m
-    F_off = F * hollow
-    ctp = F_off / F_off.sum(axis=1)[:, None]
-    mut = (R * hollow).sum(axis=1) / F.sum(axis=1)
-    res = mut[:, None] * ctp
-    np.fill_diagonal(res, -mut)
-    return res
+    (what the ranks all-reduce instead of the tensor): estimation/_jtt_ipw.py::jtt_ipw_from_statistics."""
+    from ..estimation import jtt_ipw_from_statistics
+    return jtt_ipw_from_statistics(F_sym, R_sym, grid, mask, True, pseudocounts)
 
 
 def _train_with_torch_glue(sharded, module, num_epochs: int, lr: float, do_adam: bool) -> Dict:
@@ -124,12 +114,13 @@ def coevolution_fit_resident(
 
     _run_local_then_agree(local, "coevolution_fit_resident")
     unit = 0.5 if mode == "edge" else 0.25
-    C = (box.pop("counts").to(torch.float64) * unit).reshape(B, S, S)       # this rank's sufficient statistics, resident
-    # JTT-IPW from two S x S sums (all-reduced), not from the tensor
-    Csym = 0.5 * (C + C.transpose(1, 2))
-    tg = torch.from_numpy(grid).to(dev)
-    stats = torch.stack([Csym.sum(dim=0), (Csym / tg[:, None, None]).sum(dim=0)])
-    del Csym
+    counts_u64 = box.pop("counts")                                       # this rank's histogram (units of `unit`), resident
+    # JTT-IPW from two S x S sums (all-reduced), not from the tensor: one streaming pass of cb_jtt_ipw_stats over the integers
+    from ..estimation import jtt_ipw_statistics
+    F_r, R_r = jtt_ipw_statistics(grid, counts_u64.reshape(B, S, S), unit, True)
+    stats = torch.from_numpy(np.stack([F_r, R_r])).to(dev)
+    C = (counts_u64.to(torch.float64) * unit).reshape(B, S, S)           # the sufficient statistics the bank is built from
+    del counts_u64
     n_pairs = C.sum().reshape(1)
     if on:
         dist.all_reduce(stats, op=dist.ReduceOp.SUM)

@@ -261,6 +261,16 @@ int cb_count_co_transitions(int device, int S, int B, const double *grid, const 
                             const cb_count_pair *pairs, int64_t n_pairs, int symmetric, int flags,
                             unsigned long long *counts);
 
+/* JTT-IPW sufficient statistics (cherryml/estimation/_jtt_ipw.py:66-110 reduced to what is linear in the
+ * counts): F[S][S] = sum_b sym(C_b), R[S][S] = sum_b sym(C_b) / grid[b], sym(C) = (C + C^T) / 2 when `symmetrize`, else C.
+ * `counts` [B][S][S]: 8-byte unsigned integers in units of `unit` (what cb_count_transitions / cb_count_co_transitions
+ * leave on the device; counts_f64 == 0) or doubles (counts_f64 != 0; multiplied by `unit` too).  One streaming pass over
+ * the tensor, sums in a fixed order.  The closed form itself (pseudocounts, mask, rates) is O(S^2) host arithmetic:
+ * cherryml_amd/estimation/_jtt_ipw.py.  flags = 0: host pointers, synchronous; CB_PTR_DEVICE: device pointers, enqueued on
+ * HIP's default stream like the counting kernels (the caller synchronises). */
+int cb_jtt_ipw_stats(int device, int S, int B, const void *counts, int counts_f64, const double *grid, double unit,
+                     int symmetrize, int flags, double *F, double *R);
+
 /* ---- multi-GPU inside the library (SURVEY 8b / 8e option 1) ------------------------------------------
  * After this call cb_loss_grad and cb_loss_grad_general return the sums over all ranks of the
  * communicator: every rank holds a shard of the buckets (its own cb_create), evaluates its partial

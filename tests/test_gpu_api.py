@@ -747,3 +747,60 @@ def test_symmetric_counts_take_the_symmetric_quad_form(N, monkeypatch):
     assert np.allclose(a["loss_per_epoch_per_site"], ref["loss_per_epoch_per_site"], rtol=1e-8, atol=0)
     for l in range(L):
         assert relerr(a["res"][l], ref["res"][l]) < 1e-6, l
+
+
+def test_jtt_ipw_statistics_kernel_and_stage_on_the_reference_goldens(tmp_path):
+    """SURVEY 8f #2 on the device (round 4): `cb_jtt_ipw_stats` -- F = sum_b sym(C_b), R = sum_b sym(C_b) / t_b in one
+    streaming pass -- against numpy on ragged sizes (1 .. 400 states: edge tiles, diagonal tiles, bucket chunks), float64
+    and integer counts (host and device pointers), symmetrised or not; then the stage function `jtt_ipw` itself on the
+    reference's own goldens (tests/estimation_tests/jtt_ipw_test.py:12-74) and its `max_time`; the closed form on top is
+    checked against the oracle's tensor form (1e-12)."""
+    import cherryml_amd
+    from cherryml_amd.estimation import jtt_ipw_from_arrays, jtt_ipw_statistics
+    from cherryml_amd.io import read_rate_matrix, write_count_matrices
+    from oracle import ratelearn_oracle as orc
+    rng = np.random.default_rng(11)
+    for S, B in ((1, 1), (3, 2), (16, 16), (17, 33), (20, 129), (37, 5), (400, 9)):
+        t = np.sort(rng.uniform(1e-3, 4.0, B))
+        Ci = rng.poisson(1.5, size=(B, S, S)).astype(np.uint64)
+        Ci[::3] = 0
+        unit = 0.25
+        Cf = Ci.astype(np.float64) * unit
+        for sym in (True, False):
+            X = 0.5 * (Cf + Cf.transpose(0, 2, 1)) if sym else Cf
+            wantF, wantR = X.sum(0), (X / t[:, None, None]).sum(0)
+            F, R = jtt_ipw_statistics(t, Cf, 1.0, sym)                         # float64 counts, host pointers
+            assert np.allclose(F, wantF, rtol=1e-13, atol=0) and np.allclose(R, wantR, rtol=1e-12, atol=0)
+            F2, R2 = jtt_ipw_statistics(t, Ci, unit, sym)                      # integer histogram, host pointers
+            assert np.array_equal(F2, F) and np.allclose(R2, R, rtol=1e-13, atol=0)
+            d = torch.from_numpy(Ci.astype(np.int64)).cuda()                   # the resident histogram
+            F3, R3 = jtt_ipw_statistics(t, d, unit, sym)
+            assert np.array_equal(F3, F2) and np.array_equal(R3, R2)
+            F4, R4 = jtt_ipw_statistics(t, torch.from_numpy(Cf).cuda(), 1.0, sym)
+            assert np.array_equal(F4, F) and np.array_equal(R4, R)
+        if S > 1:
+            mask = (rng.random((S, S)) < 0.7).astype(np.float64)
+            mask = np.maximum(mask, mask.T)
+            np.fill_diagonal(mask, 1.0)
+            for m in (None, mask):
+                for ipw in (True, False):
+                    got = jtt_ipw_from_arrays(t, Cf + 1.0, m, use_ipw=ipw)
+                    assert np.allclose(got, orc.jtt_ipw(t, Cf + 1.0, m, use_ipw=ipw), rtol=1e-12, atol=1e-15)
+            cut = float(t[B // 2])
+            got = jtt_ipw_from_arrays(t, Cf + 1.0, None, max_time=cut)
+            assert np.allclose(got, orc.jtt_ipw(t[t <= cut], (Cf + 1.0)[t <= cut]), rtol=1e-12, atol=1e-15)
+    g = load_golden("jtt_ipw_toy.npz")
+    states = list("ABC")
+    cpath = str(tmp_path / "c.txt")
+    write_count_matrices([(float(t), pd.DataFrame(C, index=states, columns=states)) for t, C in zip(g["t"], g["C"])], cpath)
+    mpath = str(tmp_path / "m.txt")
+    pd.DataFrame(g["mask"], index=states, columns=states).to_csv(mpath, sep=" ")
+    for key, mp, ipw in [("Q1_JTT_IPW_on_toy_matrix", None, True), ("Q1_JTT_IPW_on_toy_matrix_mask", mpath, True),
+                         ("Q1_JTT_on_toy_matrix", None, False), ("Q1_JTT_on_toy_matrix_mask", mpath, False)]:
+        out = str(tmp_path / key)
+        os.makedirs(out)
+        cherryml_amd.jtt_ipw(count_matrices_path=cpath, mask_path=mp, use_ipw=ipw, output_rate_matrix_dir=out)
+        got = read_rate_matrix(os.path.join(out, "result.txt")).to_numpy()
+        np.testing.assert_almost_equal(got, g[key], decimal=7)
+        np.testing.assert_almost_equal(got, orc.jtt_ipw(g["t"], g["C"], g["mask"].astype(float) if mp else None, use_ipw=ipw),
+                                       decimal=12)

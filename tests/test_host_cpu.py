@@ -180,26 +180,29 @@ def test_other_modes_have_zero_row_sums():
 
 
 def test_jtt_ipw_reference_goldens(tmp_path):
-    """reference tests/estimation_tests/jtt_ipw_test.py:12-74 (exact goldens)."""
+    """reference tests/estimation_tests/jtt_ipw_test.py:12-74 (exact goldens): the closed form on top of the two S x S
+    sums (host logic; the sums themselves are the GPU pass cb_jtt_ipw_stats, checked on the same goldens through the stage
+    function in tests/test_gpu_api.py) and the oracle; without a GPU the stage fails loudly."""
+    from cherryml_amd.estimation import jtt_ipw_from_statistics
     g = load_golden("jtt_ipw_toy.npz")
-    states = list("ABC")
-    cpath = str(tmp_path / "c.txt")
-    write_count_matrices([(float(t), pd.DataFrame(C, index=states, columns=states))
-                          for t, C in zip(g["t"], g["C"])], cpath)
-    mpath = str(tmp_path / "m.txt")
-    pd.DataFrame(g["mask"], index=states, columns=states).to_csv(mpath, sep=" ")
-    for key, mp, ipw in [("Q1_JTT_IPW_on_toy_matrix", None, True),
-                         ("Q1_JTT_IPW_on_toy_matrix_mask", mpath, True),
-                         ("Q1_JTT_on_toy_matrix", None, False),
-                         ("Q1_JTT_on_toy_matrix_mask", mpath, False)]:
-        out = str(tmp_path / key)
-        os.makedirs(out)
-        cherryml_amd.jtt_ipw(count_matrices_path=cpath, mask_path=mp, use_ipw=ipw,
-                             output_rate_matrix_dir=out)
-        got = read_rate_matrix(os.path.join(out, "result.txt")).to_numpy()
+    t, C = g["t"], g["C"].astype(np.float64)
+    Cs = 0.5 * (C + C.transpose(0, 2, 1))
+    F, R = Cs.sum(0), (Cs / t[:, None, None]).sum(0)
+    for key, m, ipw in [("Q1_JTT_IPW_on_toy_matrix", None, True),
+                        ("Q1_JTT_IPW_on_toy_matrix_mask", g["mask"].astype(float), True),
+                        ("Q1_JTT_on_toy_matrix", None, False),
+                        ("Q1_JTT_on_toy_matrix_mask", g["mask"].astype(float), False)]:
+        got = jtt_ipw_from_statistics(F, R, t, m, use_ipw=ipw)
         np.testing.assert_almost_equal(got, g[key], decimal=7)
-        np.testing.assert_almost_equal(got, orc.jtt_ipw(
-            g["t"], g["C"], g["mask"].astype(float) if mp else None, use_ipw=ipw), decimal=12)
+        np.testing.assert_almost_equal(got, orc.jtt_ipw(t, C, m, use_ipw=ipw), decimal=12)
+    if _lib.load().cb_device_count() <= 0:
+        states = list("ABC")
+        cpath = str(tmp_path / "c.txt")
+        write_count_matrices([(float(tt), pd.DataFrame(Cb, index=states, columns=states)) for tt, Cb in zip(t, C)], cpath)
+        os.makedirs(str(tmp_path / "o"))
+        with pytest.raises(_lib.CherryBankError):
+            cherryml_amd.jtt_ipw(count_matrices_path=cpath, mask_path=None, use_ipw=True,
+                                 output_rate_matrix_dir=str(tmp_path / "o"))
 
 
 def test_newick_conversion_and_standard_site_rate_grid():
@@ -303,9 +306,10 @@ def test_native_formatter_writes_the_bytes_of_repr(tmp_path):
 
 
 def test_jtt_ipw_from_two_reduced_sums_equals_the_tensor_form():
-    """The resident chain (estimation_end_to_end/_resident.py) initialises from sum_b sym(C_b) and sum_b sym(C_b) / t_b
-    -- what the ranks all-reduce instead of the 165 MB tensor --: the same matrix as jtt_ipw_from_arrays on the tensor."""
-    from cherryml_amd.estimation import jtt_ipw_from_arrays
+    """The estimator is computed from sum_b sym(C_b) and sum_b sym(C_b) / t_b (the GPU pass; also what the ranks of the
+    resident chain all-reduce instead of the 165 MB tensor): the same matrix as the reference's tensor form (the oracle),
+    with and without a mask, symmetrised or not, both rate estimators."""
+    from cherryml_amd.estimation import jtt_ipw_from_statistics
     from cherryml_amd.estimation_end_to_end import jtt_ipw_from_reduced_statistics
     rng = np.random.default_rng(3)
     B, S = 17, 12
@@ -317,6 +321,11 @@ def test_jtt_ipw_from_two_reduced_sums_equals_the_tensor_form():
     np.fill_diagonal(mask, 1.0)
     Cs = 0.5 * (C + C.transpose(0, 2, 1))
     for m in (None, mask):
-        want = jtt_ipw_from_arrays(t, C, m)
+        want = orc.jtt_ipw(t, C, m)
         got = jtt_ipw_from_reduced_statistics(Cs.sum(0), (Cs / t[:, None, None]).sum(0), t, m)
         assert np.allclose(got, want, rtol=1e-12, atol=1e-14)
+        for ipw in (True, False):
+            for sym in (True, False):
+                X = Cs if sym else C
+                got = jtt_ipw_from_statistics(X.sum(0), (X / t[:, None, None]).sum(0), t, m, use_ipw=ipw)
+                assert np.allclose(got, orc.jtt_ipw(t, C, m, use_ipw=ipw, symmetrize=sym), rtol=1e-12, atol=1e-14)
