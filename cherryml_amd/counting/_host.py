@@ -12,8 +12,27 @@ import numpy as np
 
 
 # ------------------------------------------------------------------------ formats
-def read_tree_arrays(path: str):
-    """-> (names[n], children[n] = list of (child index, length) in file order, root index)"""
+_strtof = None
+
+
+def parse_float32(text: str) -> float:
+    """The decimal string rounded to float32 ONCE, as `std::stof` does (libc `strtof`), widened to float: what the
+    reference's C++ counters keep of a branch length (counting/_count_transitions.cpp:247, _count_co_transitions.cpp:245).
+    (`np.float32(float(text))` would round twice -- to double, then to float.)"""
+    global _strtof
+    if _strtof is None:
+        import ctypes
+        fn = ctypes.CDLL(None).strtof
+        fn.restype = ctypes.c_float
+        fn.argtypes = [ctypes.c_char_p, ctypes.c_void_p]
+        _strtof = fn
+    float(text)   # the same ValueError as the double path for a malformed field
+    return float(_strtof(text.encode("ascii"), None))
+
+
+def read_tree_arrays(path: str, length_float32: bool = False):
+    """-> (names[n], children[n] = list of (child index, length) in file order, root index)
+    length_float32: branch lengths through float32 (`cpp_compat` of the counting stages)."""
     with open(path, "r") as f:
         lines = f.read().strip().split("\n")
     try:
@@ -42,7 +61,7 @@ def read_tree_arrays(path: str):
     for i in range(n + 2, n + 2 + m):
         try:
             u, v, length = lines[i].split(" ")
-            length = float(length)
+            length = parse_float32(length) if length_float32 else float(length)
         except Exception:
             raise Exception(f"Tree file: {path} should have line '[u] [v] [length]' at position "
                             f"{i}, but it had line: '{lines[i]}'")

@@ -72,13 +72,13 @@ def _normalise_mode(edge_or_cherry: str) -> str:
     return edge_or_cherry
 
 
-def _gather(tree_dir, msa_dir, families, amino_acids, mode, aux_dir, aux_reader):
+def _gather(tree_dir, msa_dir, families, amino_acids, mode, aux_dir, aux_reader, length_float32: bool = False):
     """Concatenate the families: encoded sequences, per-family aux arrays, pair records."""
     seq_chunks, aux_chunks, pair_rows = [], [], []
     seq_off = 0
     aux_off = 0
     for fam in families:
-        names, children, root = _host.read_tree_arrays(os.path.join(tree_dir, fam + ".txt"))
+        names, children, root = _host.read_tree_arrays(os.path.join(tree_dir, fam + ".txt"), length_float32)
         msa = _host.read_msa(os.path.join(msa_dir, fam + ".txt"))
         pairs = _host.build_pairs(children, root, mode)
         used = sorted({p[0] for p in pairs} | {p[1] for p in pairs})
@@ -124,14 +124,31 @@ def _run_local_then_agree(local, name):
     _raise_together(error, name)
 
 
-def _write(output_dir, grid, counts, unit, states, start, num_processes):
+def _write_cpp_layout(path, grid, C, states):
+    """The count-matrix file as the reference's C++ counters write it (counting/_count_transitions.cpp:524-548: an ofstream
+    at its default precision -- six significant digits, `%g` -- for the quantisation points AND the counts, a tab in front
+    of and behind the header row).  Lossy above 999 999.5 counts per bin; the reference's reader takes it as it is."""
+    with open(path, "w") as f:
+        f.write(f"{len(grid)} matrices\n{len(states)} states\n")
+        head = "\t" + "".join(s + "\t" for s in states) + "\n"
+        for b, q in enumerate(grid):
+            f.write("%g\n" % q)
+            f.write(head)
+            for i, st in enumerate(states):
+                f.write(st + "\t" + "\t".join("%g" % v for v in C[b, i]) + "\n")
+
+
+def _write(output_dir, grid, counts, unit, states, start, num_processes, cpp_compat: bool = False):
     """Rank 0 only (every rank holds the same all-reduced counts); files appear atomically."""
     if _rank() != 0:
         return
     C = counts.astype(np.float64) * unit
     tmp = os.path.join(output_dir, "result.txt.tmp")
-    write_count_matrices([(float(q), pd.DataFrame(C[b], index=states, columns=states))
-                          for b, q in enumerate(grid)], tmp)
+    if cpp_compat:
+        _write_cpp_layout(tmp, grid, C, states)
+    else:
+        write_count_matrices([(float(q), pd.DataFrame(C[b], index=states, columns=states))
+                              for b, q in enumerate(grid)], tmp)
     os.replace(tmp, os.path.join(output_dir, "result.txt"))
     tmp = os.path.join(output_dir, "profiling.txt.tmp")
     with open(tmp, "w") as f:
@@ -156,7 +173,13 @@ def count_transitions(
     use_cpp_implementation: bool = True,
     cpp_command_line_prefix: str = "",
     cpp_command_line_suffix: str = "",
+    cpp_compat: bool = False,
 ) -> None:
+    """`use_cpp_implementation` is accepted and ignored: there is one implementation (the GPU), and by default it follows
+    the reference's PYTHON counter (float64 branch lengths, `repr` digits in the file).  `cpp_compat=True` reproduces what
+    the reference's default, the C++ binary, does differently: branch lengths rounded to float32 when the tree is read
+    (_count_transitions.cpp:247, `std::stof`) -- a length near a bucket boundary can land in the neighbouring bucket --
+    and the result file in the C++ writer's layout with six significant digits (:524-548)."""
     start = time.time()
     logging.getLogger(__name__).info(f"Starting on {len(families)} families")
     mode = _normalise_mode(edge_or_cherry)
@@ -175,7 +198,7 @@ def count_transitions(
 
     def local():   # this rank's families; no collective inside
         seqs, aux_chunks, pairs = _gather(tree_dir, msa_dir, _my_families(families), amino_acids, mode,
-                                          site_rates_dir, rates_reader)
+                                          site_rates_dir, rates_reader, cpp_compat)
         rates = np.ascontiguousarray(np.concatenate(aux_chunks)) if aux_chunks else np.zeros(0)
         rc = _lib.load().cb_count_transitions(
             _device_index(), S, B, grid.ctypes.data, seqs.ctypes.data, seqs.size, rates.ctypes.data,
@@ -185,7 +208,7 @@ def count_transitions(
     _run_local_then_agree(local, "count_transitions")
     counts = _all_reduce_counts(counts)
     _write(output_count_matrices_dir, grid, counts, 1.0 if mode == "edge" else 0.5,
-           list(amino_acids), start, num_processes)
+           list(amino_acids), start, num_processes, cpp_compat)
 
 
 @caching.cached_computation(
@@ -206,7 +229,10 @@ def count_co_transitions(
     use_cpp_implementation: bool = True,
     cpp_command_line_prefix: str = "",
     cpp_command_line_suffix: str = "",
+    cpp_compat: bool = False,
 ) -> None:
+    """As `count_transitions`: `cpp_compat=True` = float32 branch lengths (_count_co_transitions.cpp:245) and the C++
+    writer's six-digit file; the default follows the reference's Python counter."""
     start = time.time()
     logging.getLogger(__name__).info(f"Starting on {len(families)} families")
     mode = _normalise_mode(edge_or_cherry)
@@ -229,7 +255,7 @@ def count_co_transitions(
 
     def local():   # this rank's families; no collective inside
         seqs, aux_chunks, pairs = _gather(tree_dir, msa_dir, _my_families(families), amino_acids, mode,
-                                          contact_map_dir, contacts_reader)
+                                          contact_map_dir, contacts_reader, cpp_compat)
         contacts = np.ascontiguousarray(np.concatenate(aux_chunks)) if aux_chunks else np.zeros(0, dtype=np.int32)
         contacts = contacts.astype(np.int32)
         rc = _lib.load().cb_count_co_transitions(
@@ -241,4 +267,4 @@ def count_co_transitions(
     counts = _all_reduce_counts(counts)
     states = [a + b for a in amino_acids for b in amino_acids]
     _write(output_count_matrices_dir, grid, counts, 0.5 if mode == "edge" else 0.25, states, start,
-           num_processes)
+           num_processes, cpp_compat)

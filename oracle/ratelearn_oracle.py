@@ -38,6 +38,9 @@ __all__ = [
     "bank_loss",
     "evaluate",
     "train",
+    "rate_matrix_Q",
+    "evaluate_mode",
+    "train_mode",
     "siterm_Q",
     "siterm_invert",
     "siterm_train",
@@ -181,6 +184,82 @@ def train(t: np.ndarray, C: np.ndarray, mask: Optional[np.ndarray] = None,
     out["upper_diag"] = u.detach().numpy().astype(np.float64)
     out["log_pi"] = p.detach().numpy().astype(np.float64)
     return out
+
+
+# ------------------------------------------------- the other parameterisations
+def rate_matrix_Q(mode: str, upper_diag: torch.Tensor, lower_diag: Optional[torch.Tensor], log_pi: torch.Tensor,
+                  mask: torch.Tensor) -> torch.Tensor:
+    """theta -> Q for every mode of the reference's RateMatrix.forward (rate.py:104-218):
+      "default"                off-diagonals softplus(upper | lower) * mask, diagonal = -row sums          (:106-128)
+      "stationary[_reversible]" R = softplus(upper) (+ its transpose | + softplus(lower)) * mask,
+                               diag_i = -(R pi)_i / pi_i,  Q = (R + diag) diag(pi)                          (:130-161)
+      "pande"                  as "pande_reversible" with an independent lower triangle                    (:190-217)
+    """
+    S = log_pi.shape[0]
+    if mode == "pande_reversible":
+        return pande_reversible_Q(upper_diag, log_pi, mask)
+    iu = torch.triu_indices(S, S, offset=1)
+    il = torch.tril_indices(S, S, offset=-1)
+    R = torch.zeros(S, S, dtype=upper_diag.dtype)
+    R[iu[0], iu[1]] = torch.nn.functional.softplus(upper_diag)
+    if mode == "stationary_reversible":
+        R = R + R.T
+    else:
+        R[il[0], il[1]] = torch.nn.functional.softplus(lower_diag)
+    R = R * mask
+    if mode == "default":
+        return R - torch.diag(R.sum(1))
+    pi = torch.softmax(log_pi, dim=-1)
+    if mode in ("stationary", "stationary_reversible"):
+        return (R + torch.diag(-(R @ pi) / pi)) @ torch.diag(pi)
+    if mode == "pande":
+        root = pi.sqrt()
+        Q = (torch.diag(root ** (-1)) @ R) @ torch.diag(root)
+        return Q - torch.diag(Q.sum(1))
+    raise ValueError(f"Unknown rate matrix parameterization: {mode}")
+
+
+def evaluate_mode(mode: str, upper_diag, lower_diag, log_pi, mask, t, C, normalize: bool = True) -> Dict[str, np.ndarray]:
+    """One epoch body (trainer.py:156-186) in float64 for any parameterisation: Q, loss, dL/dQ and the parameter gradients
+    (a parameter the mode does not use has gradient zero)."""
+    dt = torch.float64
+    u = torch.tensor(np.asarray(upper_diag), dtype=dt, requires_grad=True)
+    lo = torch.tensor(np.asarray(lower_diag), dtype=dt, requires_grad=True) if lower_diag is not None else None
+    p = torch.tensor(np.asarray(log_pi), dtype=dt, requires_grad=True)
+    Q = rate_matrix_Q(mode, u, lo, p, torch.tensor(np.asarray(mask), dtype=dt))
+    Q.retain_grad()
+    loss = bank_loss(Q, torch.tensor(t, dtype=dt), torch.tensor(C, dtype=dt), normalize)
+    loss.backward()
+    g = lambda x: np.zeros(tuple(x.shape)) if x.grad is None else x.grad.numpy().copy()
+    out = dict(Q=Q.detach().numpy().copy(), loss=float(loss.item()), dQ=Q.grad.numpy().copy(), d_upper=g(u), d_log_pi=g(p))
+    if lo is not None:
+        out["d_lower"] = g(lo)
+    return out
+
+
+def train_mode(mode: str, upper_diag, lower_diag, log_pi, mask, t, C, num_epochs: int, lr: float,
+               do_adam: bool = True) -> Dict[str, np.ndarray]:
+    """trainer.py:118-243 for any parameterisation, float64; parameters in the reference module's registration order
+    (_pi, upper_diag, lower_diag: rate.py:44-57)."""
+    dt = torch.float64
+    u = torch.tensor(np.asarray(upper_diag), dtype=dt, requires_grad=True)
+    lo = torch.tensor(np.asarray(lower_diag), dtype=dt, requires_grad=True) if lower_diag is not None else None
+    p = torch.tensor(np.asarray(log_pi), dtype=dt, requires_grad=True)
+    m = torch.tensor(np.asarray(mask), dtype=dt)
+    tt, CC = torch.tensor(t, dtype=dt), torch.tensor(C, dtype=dt)
+    params = [p, u] + ([lo] if lo is not None else [])
+    opt = torch.optim.Adam(params, lr=lr) if do_adam else torch.optim.SGD(params, lr=lr)
+    losses, best, Q_best, Q = [], None, None, None
+    for _ in range(num_epochs):
+        opt.zero_grad()
+        Q = rate_matrix_Q(mode, u, lo, p, m)
+        loss = bank_loss(Q, tt, CC, True)
+        if best is None or loss < best:
+            best, Q_best = loss.detach().clone(), Q.detach().numpy().copy()
+        loss.backward()
+        opt.step()
+        losses.append(float(loss.item()))
+    return dict(loss=np.array(losses), Q_best=Q_best, Q_last=Q.detach().numpy().copy())
 
 
 # -------------------------------------------------------- SiteRM (vectorised)

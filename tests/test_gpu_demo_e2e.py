@@ -85,6 +85,60 @@ def test_coevolution_pipeline_on_demo_data(tmp_path):
     assert d32 < 1e-3
 
 
+def test_all_32_demo_families_are_counted_exactly_like_the_reference(tmp_path):
+    """BASELINE.json config 3 as it really is (parity margin c): ALL 32 demo_data families (the reference's own
+    files, tests/golden/demo32_co_inputs.npz) through this package's maximal matching + `cb_count_co_transitions` against
+    the counts the REFERENCE's pipeline produced from them (coevo_demo_full.npz: Python `count_co_transitions`): every one
+    of the 730 864 non-zero bins and sum C = 1 057 194 bit for bit; the masked JTT-IPW initialiser (now from the device
+    statistics pass) to 1e-11 on its support; and the resident chain counts the same pairs."""
+    import cherryml_amd
+    from cherryml_amd import caching
+    from cherryml_amd.estimation_end_to_end import coevolution_fit_resident, create_maximal_matching_contact_map
+    from cherryml_amd.io import read_count_matrices_arrays, read_rate_matrix
+    zin = load_golden("demo32_co_inputs.npz")
+    z = dict(np.load(os.path.join(os.path.dirname(__file__), "golden", "coevo_demo_full.npz")))
+    fams = [str(f) for f in zin["families"]]
+    assert fams == [str(f) for f in z["families"]] and len(fams) == 32
+    dirs = {}
+    for kind in ("msa", "tree", "contact_map"):
+        d = tmp_path / kind
+        d.mkdir()
+        off, blob = zin[f"{kind}_offsets"], zin[f"{kind}_bytes"].tobytes()
+        for k, fam in enumerate(fams):
+            (d / f"{fam}.txt").write_bytes(blob[off[k]:off[k + 1]])
+        dirs[kind] = str(d)
+    pairs = [a + b for a in AA for b in AA]
+    mask = np.unpackbits(z["mask_packed"])[:160000].reshape(400, 400)
+    mpath = str(tmp_path / "mask.txt")
+    pd.DataFrame(mask, index=pairs, columns=pairs).to_csv(mpath, sep=" ")
+    caching.set_cache_dir(str(tmp_path / "cache"))
+    try:
+        res = cherryml_amd.coevolution_end_to_end_with_cherryml_optimizer(
+            msa_dir=dirs["msa"], contact_map_dir=dirs["contact_map"], minimum_distance_for_nontrivial_contact=7,
+            coevolution_mask_path=mpath, families=fams, tree_estimator=None,
+            initial_tree_estimator_rate_matrix_path=None, num_epochs=1, tree_dir=dirs["tree"])
+        cm_dir = create_maximal_matching_contact_map(
+            i_contact_map_dir=dirs["contact_map"], families=fams, minimum_distance_for_nontrivial_contact=7,
+            num_processes=1)["o_contact_map_dir"]
+    finally:
+        caching.set_cache_dir(None)
+    q, C, states = read_count_matrices_arrays(os.path.join(res["count_matrices_dir_0"], "result.txt"))
+    assert states == pairs and np.array_equal(q, z["t"])
+    ref = np.zeros(tuple(z["C_shape"]))
+    ref[z["C_b"].astype(np.int64), z["C_i"].astype(np.int64), z["C_j"].astype(np.int64)] = z["C_quarters"] * 0.25
+    assert C.sum() == 1057194.0 and np.count_nonzero(C) == 730864
+    assert np.array_equal(C, ref)                                                     # bit-exact, all 129 x 400 x 400 bins
+    init = read_rate_matrix(os.path.join(res["jtt_ipw_dir_0"], "result.txt")).to_numpy()
+    sup = mask.astype(bool) | np.eye(400, dtype=bool)   # (the golden keeps masked matrices on the mask's support + diagonal)
+    assert np.all(init[~sup] == 0.0) and np.allclose(init[sup], z["init_support"], rtol=1e-11, atol=1e-15)
+    r = coevolution_fit_resident(tree_dir=dirs["tree"], msa_dir=dirs["msa"], contact_map_dir=cm_dir, families=fams,
+                                 amino_acids=AA, quantization_points=[float(x) for x in res["quantization_points"]],
+                                 edge_or_cherry="cherry++", minimum_distance_for_nontrivial_contact=7,
+                                 mask=mask.astype(np.float64), num_epochs=1)
+    assert r["n_pairs"] == 1057194.0
+    assert np.allclose(r["initialization"][sup], z["init_support"], rtol=1e-11, atol=1e-15)
+
+
 def test_coevolution_resident_chain_equals_the_file_passing_pipeline(tmp_path):
     """count -> JTT-IPW -> optimise as ONE resident chain (estimation_end_to_end/_resident.py: device-resident counts, the
     initialiser from two reduced S x S sums, no 84 MB count file between the stages) against the same reference golden

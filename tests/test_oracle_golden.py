@@ -295,3 +295,26 @@ def test_oracle_siterm_matches_reference_on_cfg4_sites():
     T, C, Q0 = nonsymmetric_21_state_problem(L=24)
     r = orc.siterm_train(C[:2], T[:2], 8, initialization=Q0[:2])
     assert np.allclose(r["loss_per_epoch_per_site"], z["lpeps21"][:8, :2], rtol=1e-9, atol=0)
+
+
+@pytest.mark.parametrize("case", ["toy3", "s20"])
+@pytest.mark.parametrize("mode", ["default", "pande", "stationary", "stationary_reversible"])
+def test_oracle_other_parameterisations_against_reference(mode, case):
+    """rate.py:98-128, 190-218 ("default", "pande", "stationary", "stationary_reversible"): the oracle's restatement against the
+    reference itself (tests/golden/make_golden_modes.py: float64 module, one evaluation + 30 epochs of train_quantization;
+    the 20-state case carries the reference's own non-symmetric random mask)."""
+    z = load_golden("modes.npz")
+    k = f"{mode}_{case}"
+    t, C, mask = z[f"{case}_t"], z[f"{case}_C"], z[f"{case}_mask"]
+    lower = z[f"{k}_lower"] if f"{k}_lower" in z else None
+    ev = orc.evaluate_mode(mode, z[f"{k}_upper"], lower, z[f"{k}_log_pi"], mask, t, C)
+    assert abs(ev["loss"] - float(z[f"{k}_loss"])) <= 1e-13 * abs(float(z[f"{k}_loss"]))
+    assert relerr(ev["Q"], z[f"{k}_Q"]) < 1e-14 and relerr(ev["dQ"], z[f"{k}_dQ"]) < 1e-12
+    assert relerr(ev["d_upper"], z[f"{k}_d_upper"]) < 1e-12
+    if lower is not None:
+        assert relerr(ev["d_lower"], z[f"{k}_d_lower"]) < 1e-12
+    if mode != "default":
+        assert relerr(ev["d_log_pi"], z[f"{k}_d_log_pi"]) < 1e-11
+    tr = orc.train_mode(mode, z[f"{k}_upper"], lower, z[f"{k}_log_pi"], mask, t, C, 30, 0.05)
+    assert np.allclose(tr["loss"], z[f"{k}_traj_loss"], rtol=1e-10, atol=0)
+    assert relerr(tr["Q_best"], z[f"{k}_Q_best"]) < 1e-9 and relerr(tr["Q_last"], z[f"{k}_Q_last"]) < 1e-9
