@@ -171,7 +171,8 @@ __device__ __forceinline__ double fast_log(double x) {
 // - (j >= 64 ? ln 2 : 0) (the upper half of [1, 2) is treated as m / 2 with k + 1, so that x just below 1 is not
 // assembled from -ln 2 + ln 1.99..);  log x = (k + [j >= 64]) ln 2 + ltab[2 j + 1] + log1p(r),  r = m ltab[2 j] - 1,
 // |r| <= 2^-8: a degree-6 polynomial leaves < 1e-17 ABSOLUTE error (+ rounding) -- what a sum of c log P needs -- for 14 cheap
-// instructions instead of the ~32 (one reciprocal + Newton among them) of fast_log.  x > 0, normal range.
+// instructions instead of the ~32 (one reciprocal + Newton among them) of fast_log.  x > 0, normal range; anything else
+// returns what log returns (NaN, +-Inf).
 __device__ __forceinline__ void fast_log_table_fill(double *ltab, int tid, int nthreads) {
   for (int j = tid; j < 128; j += nthreads) {
     const double c = 1.0 / (1.0 + (j + 0.5) * (1.0 / 128.0));
@@ -191,7 +192,10 @@ __device__ __forceinline__ double fast_log_table(double x, const double *ltab) {
   p = fma(p, r, 1.0 / 3.0);
   p = fma(p, r, -0.5);
   p = fma(p * r, r, r);
-  return fma((double)k, 6.93147180559945286227e-01, ct.y + p);
+  const double v = fma((double)k, 6.93147180559945286227e-01, ct.y + p);
+  // only the exponent and mantissa bits were read: NaN / Inf / 0 / negative arguments must not come out finite (a loss that
+  // turned non-finite has to stay non-finite, or the best-iterate comparison would record it -- ADVICE r3)
+  return (x > 0.0 && x < INFINITY) ? v : (x == 0.0 ? -INFINITY : (x > 0.0 ? INFINITY : NAN));
 }
 
 // XCD-aware block id: hardware deals consecutive workgroup ids round-robin over the 8

@@ -436,7 +436,9 @@ __device__ int wave_orthogonalise_first_order4(int n, const double *A, double si
     cos2 = wave_max(cos2);
     wave_lds_fence();
     const bool last = cos2 < CB_JAC_STOP * CB_JAC_STOP;
-    if (!(cos2 == cos2)) break;       // a non-finite matrix: nothing to converge to (the loss of this epoch is NaN)
+    // (a NaN norm -- an exactly degenerate pair divides by zero above, or the matrix itself is non-finite -- takes the exact
+    // branch below: it is what degenerate pairs need, and on a non-finite matrix the iteration count bounds the loop and the
+    // loss of the epoch comes out NaN through fast_log_table's argument check)
     if (!(nrm <= CB_FO_MAX_NORM)) {   // near-degenerate pairs: exact rotations for this iteration
       if (n <= 4) wave_jacobi_columns<1, false>(n, Gc, nullptr, LS, 1);
       else if (n <= 8) wave_jacobi_columns<2, false>(n, Gc, nullptr, LS, 1);
@@ -483,7 +485,9 @@ __device__ int wave_orthogonalise_first_order4(int n, const double *A, double si
 }
 
 // n <= 24, frames of at least 4 ceil(n / 4) rows, ZERO outside n x n (the caller pads: see sp_prepare_body).
-__device__ int wave_eigh_rate_warm_mfma4(int n, const double *A, double *Gc, double *Uc, double *X, double *dg, double *lam,
+// (inlined: as a call it saved and restored 103 callee-saved registers through scratch memory, 416 bytes per lane, on the
+// one path of the LG epoch that is pure latency)
+__device__ __forceinline__ int wave_eigh_rate_warm_mfma4(int n, const double *A, double *Gc, double *Uc, double *X, double *dg, double *lam,
                                          int LS) {
   const int lane = threadIdx.x & 63;
   double mx = 0.0;

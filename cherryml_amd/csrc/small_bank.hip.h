@@ -284,7 +284,13 @@ __device__ __forceinline__ void quad_load_counts(double (&cv)[TS][TS], const dou
 // W phases) instead of living in 2 TS^2 registers across both phases -- the register peak drops by ~50, which is what
 // lets three workgroups share a CU (sp_bank).
 // LOGT: the logarithms of the loss by table (fast_log_table; `ltab` = 256 doubles of LDS filled by fast_log_table_fill)
-template <int TS, bool LANEM, bool SYM = false, bool ULDS = false, bool LOGT = false>
+// QLS / TABS: LDS row stride of the A / V frames and distance of the four blocks' spectral tables (doubles).  With the 33 / 96 of
+// the 32 x 32 frames a `ds_read_b64` of a quad is a 2-way bank conflict in both tile layouts (rows q and q + 1, 33 doubles
+// apart, overlap in 3 of their 4 words) and a 4-way one on the tables (96 doubles = 3 bank rows: the four blocks on the same
+// banks): 2.06 conflict cycles per LDS instruction in sp_bank<5, true, true> (profiles/r03_sp_bank_sq_counters.json), in a
+// kernel whose four SIMDs share one LDS.  36 / 100 (both = 4 mod 32) make every read of the quad conflict-free: the lanes of a
+// 32-lane group address q * 36 + r, r * 36 + q or blk * 100 + {q, r} -- disjoint words.
+template <int TS, bool LANEM, bool SYM = false, bool ULDS = false, bool LOGT = false, int QLS = CB_LS, int TABS = 96>
 __device__ __forceinline__ void small_quad(int S, double tb, const double *__restrict__ Cq, double inv_n,
                                            const double *sA, const double *sV, double *tabw,
                                            const double *sLam, double rho, double *Mw, double &lossacc,
@@ -301,7 +307,7 @@ __device__ __forceinline__ void small_quad(int S, double tb, const double *__res
   } else {
     quad_load_counts<TS>(cv, Cq);
   }
-  double *tab = tabw + blk * 96;  // this block's F[32], E[32], H[32]
+  double *tab = tabw + blk * TABS;  // this block's F[32], E[32], H[32]
   const bool split = tb * rho <= 1.0;
   // spectral tables of the four buckets: 16 lanes per block, lanes (q, r) cover k = 4 q + r and + 16
   {
@@ -337,18 +343,18 @@ __device__ __forceinline__ void small_quad(int S, double tb, const double *__res
       asm volatile("" ::: "memory");
       double uf[TS];
 #pragma unroll
-      for (int K = 0; K < TS; ++K) uf[K] = sV[(4 * K + q) * CB_LS + 4 * I + r] * Fk[K];
+      for (int K = 0; K < TS; ++K) uf[K] = sV[(4 * K + q) * QLS + 4 * I + r] * Fk[K];
 #pragma unroll
       for (int K = 0; K < TS; ++K)       // K outer: TS independent accumulator chains in flight
 #pragma unroll
         for (int J = SYM ? I : 0; J < TS; ++J)
-          g[I][J] = mfma4_f64(uf[K], sV[(4 * K + q) * CB_LS + 4 * J + r], K == 0 ? 0.0 : g[I][J]);
+          g[I][J] = mfma4_f64(uf[K], sV[(4 * K + q) * QLS + 4 * J + r], K == 0 ? 0.0 : g[I][J]);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int J = SYM ? I : 0; J < TS; ++J) {
         const int row = 4 * I + q, col = 4 * J + r;
         const bool valid = (row < S) && (col < S);
-        double pt = g[I][J] + tsplit * sA[min(row, 31) * CB_LS + min(col, 31)] + (row == col ? isplit : 0.0);
+        double pt = g[I][J] + tsplit * sA[min(row, 31) * QLS + min(col, 31)] + (row == col ? isplit : 0.0);
         pt = valid ? pt : 1.0;
         const double c = cv[I][J];
         const bool nz = c != 0.0;
@@ -376,10 +382,10 @@ __device__ __forceinline__ void small_quad(int S, double tb, const double *__res
 #pragma unroll
     for (int I = 0; I < TS; ++I)
 #pragma unroll
-      for (int K = 0; K < TS; ++K) UB[ULDS ? 0 : I][ULDS ? 0 : K] = sV[(4 * K + r) * CB_LS + 4 * I + q];
+      for (int K = 0; K < TS; ++K) UB[ULDS ? 0 : I][ULDS ? 0 : K] = sV[(4 * K + r) * QLS + 4 * I + q];
   }
-  const double *ub0 = sV + r * CB_LS + q;   // UB(I, K) = ub0[4 K CB_LS + 4 I]
-#define Q_UB(I, K) (ULDS ? ub0[4 * (K) * CB_LS + 4 * (I)] : UB[ULDS ? 0 : (I)][ULDS ? 0 : (K)])
+  const double *ub0 = sV + r * QLS + q;   // UB(I, K) = ub0[4 K QLS + 4 I]
+#define Q_UB(I, K) (ULDS ? ub0[4 * (K) * QLS + 4 * (I)] : UB[ULDS ? 0 : (I)][ULDS ? 0 : (K)])
   // ---- T(It,Mt) = sum_Jt G~(It,Jt) U(Jt,Mt), stored over g[Mt][It] ---------------------------
 #pragma unroll
   for (int It = 0; It < TS; ++It) {

@@ -467,11 +467,17 @@ __global__ __launch_bounds__(NTH, 2) void sp_prepare(TrainArgs a, SpSplit g, int
 
 // bank LDS: only the first 24 rows of the A / V frames are touched for S <= 20; Mw = [wave][tile][lane]
 #define SPB_ROWS 24
+#ifndef SPB_LS
+#define SPB_LS 36      // row stride of sp_bank's OWN copy of the frames, SPB_TABS: distance of a wave's four spectral tables
+#endif
+#ifndef SPB_TABS
+#define SPB_TABS 100   // (small_quad: both = 4 mod 32 -> conflict-free ds_read_b64 in every layout of the quad)
+#endif
 #define SPB_A 0
-#define SPB_V (SPB_ROWS * CB_LS)
-#define SPB_LAM (2 * SPB_ROWS * CB_LS)
+#define SPB_V (SPB_ROWS * SPB_LS)
+#define SPB_LAM (2 * SPB_ROWS * SPB_LS)
 #define SPB_TAB (SPB_LAM + 32)
-#define SPB_MW (SPB_TAB + 4 * 384)
+#define SPB_MW (SPB_TAB + 4 * 4 * SPB_TABS)
 
 // Workgroups per CU: THREE where the quad fits 168 registers once the B-layout tiles of U are re-read from LDS
 // (small_quad's ULDS form) and M is accumulated in 16 slots per tile (44 KB of LDS per workgroup) -- up to 16
@@ -494,9 +500,10 @@ __global__ __launch_bounds__(256, spb_wgs(TS, SYM, W3)) void sp_bank(TrainArgs a
   const int S = a.S, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, blk = (lane >> 2) & 3;
   const int l = blockIdx.x / g.nchunk, chunk = blockIdx.x - l * g.nchunk;
   const double *fr = g.frames + (size_t)l * LGS_TOTAL;
-  for (int e = tid; e < SPB_ROWS * CB_LS; e += 256) {
-    sA[e] = fr[LGS_A + e];
-    sV[e] = fr[LGS_V + e];
+  for (int e = tid; e < SPB_ROWS * 32; e += 256) {   // the frames (row stride CB_LS in memory) re-strided
+    const int k = e >> 5, i = e & 31;
+    sA[k * SPB_LS + i] = fr[LGS_A + k * CB_LS + i];
+    sV[k * SPB_LS + i] = fr[LGS_V + k * CB_LS + i];
   }
   if (tid < 32) sLam[tid] = fr[LGS_LAM + tid];
   constexpr bool LANEM = spb_mws(TS, SYM, W3) == 1600;   // per-lane M slots while they fit LDS (2 workgroups per CU)
@@ -512,15 +519,15 @@ __global__ __launch_bounds__(256, spb_wgs(TS, SYM, W3)) void sp_bank(TrainArgs a
   const double *t_l = a.t + lb, *Cq_l = a.Cq + (size_t)l * a.nq * (TS * TS * 64);
   const double inv_n = a.inv_n[l];
   double rho = 0.0;
-  for (int i = lane; i < S; i += 64) rho = fmax(rho, fabs(sA[i * CB_LS + i]));
+  for (int i = lane; i < S; i += 64) rho = fmax(rho, fabs(sA[i * SPB_LS + i]));
   rho = 2.0 * wave_max(rho);
   const int q0 = chunk * g.quads_per_chunk, q1 = min(nquads, q0 + g.quads_per_chunk);
   double lossacc = 0.0;
   for (int qd = q0 + wave; qd < q1; qd += 4) {
     const int bucket = 4 * qd + blk;
     const double tb = bucket < Bn ? t_l[bucket] : 0.0;
-    small_quad<TS, LANEM, SYM, (spb_wgs(TS, SYM, W3) >= 3), true>(S, tb, Cq_l + (size_t)qd * (TS * TS * 64), inv_n, sA, sV,
-                                                                   lds + SPB_TAB + wave * 384, sLam, rho, Mw, lossacc, ltab);
+    small_quad<TS, LANEM, SYM, (spb_wgs(TS, SYM, W3) >= 3), true, SPB_LS, SPB_TABS>(
+        S, tb, Cq_l + (size_t)qd * (TS * TS * 64), inv_n, sA, sV, lds + SPB_TAB + wave * (4 * SPB_TABS), sLam, rho, Mw, lossacc, ltab);
   }
   lossacc = wave_sum(lossacc);
   if (lane == 0) lds[SPB_LOSS + wave] = lossacc;
