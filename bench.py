@@ -46,6 +46,9 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8.0 TB/s spec
 F64_PEAK_TFLOPS = 78.6     # 256 CU x 4 SIMD x 32 flop/clk x 2.4 GHz (f64 MFMA = f64 vector rate)
 F32_PEAK_TFLOPS = 157.3    # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 / 32x32x2, 64 flop/clk/SIMD (exact f32)
+LDS_ATOMIC_PEAK_G = 9830.4  # G lane-atomics/s: 16 lanes per clock per CU (LDS table: a 4-byte LDS write / atomic = 4 cycles per
+                            # wave-instruction) x 256 CUs x 2.4 GHz, conflict-free
+L2_GATHER_PEAK_GBS = 16800.0  # MI355X_MICROARCH.md, "Indexed rows": rows gathered from a table shared in the XCD's L2, chip-wide
 
 
 # --------------------------------------------------------------------- inputs
@@ -486,10 +489,18 @@ def main():
             bank.profile(False)
             final_loss = float(np.sum(r["loss"][-1]) if "loss" in r
                                else np.sum(r["loss_per_epoch_per_site"][-1]))
+        tm_max, rccl_ranks = None, None
+        if world > 1 or args.force_sharded:
+            rccl_ranks = getattr(getattr(bank, "rccl", None), "count", None)   # ncclCommCount of the raw communicator
         if world > 1:
             tdt = torch.tensor([dt], dtype=torch.float64, device=dev)
             dist.all_reduce(tdt, op=dist.ReduceOp.MAX)
             dt = float(tdt.item())
+            # the slowest rank sets the pace: per-phase maxima over the ranks beside rank 0's own phase times
+            keys = [k for k in ("eigh", "k1", "k2", "k3", "k4", "allreduce", "small") if k in tm]
+            tv = torch.tensor([float(tm[k]) for k in keys], dtype=torch.float64, device=dev)
+            dist.all_reduce(tv, op=dist.ReduceOp.MAX)
+            tm_max = {k: round(float(v), 4) for k, v in zip(keys, tv.tolist())}
         if rank != 0:
             bank.close()   # every rank releases its handle (and its RCCL communicator)
             return None
@@ -563,6 +574,20 @@ def main():
             "phase_ms": {k: round(v, 4) for k, v in tm.items()},
             "final_loss": final_loss,
         }
+        if tm_max is not None:
+            out["phase_ms_max_over_ranks"] = tm_max
+        if world > 1 or args.force_sharded:
+            # which transport carried the per-epoch all-reduce: the raw RCCL communicator's own rank count (None: torch's)
+            out["rccl_ranks"] = rccl_ranks
+        if S <= 32 and wl["kind"] == "single":
+            # one 20-state bank is not a roofline case: an epoch is two dependent launches whose serial sections
+            # (theta -> A, the warm eigensolve, partial sums, parameter step: one workgroup) are pure latency
+            out["latency_budget"] = {
+                "us_per_epoch": round(tm["small"] * 1e3, 2), "target_us": 35.0, "launches_per_epoch": 2,
+                "launch_floor_us": 2.9, "algorithmic_bytes_per_epoch": float(B_local * S * S * 8),
+                "note": "sp_step (finish of epoch e-1 + prepare of epoch e, ONE workgroup: ~30 us of dependent latency) + "
+                        "sp_bank (one quad per wave over the chip: ~13 us); launch floor = a dependent empty kernel on this "
+                        "box (profiles/tools/launch_probe2)"}
         if S > 32:
             # the Amdahl arithmetic of sharding ONE bank over ranks: the eigensolver and K4 run on the
             # whole matrix on every rank, K1-K3 on the rank's buckets only; `other` = theta -> A, parameter kernels,
@@ -632,9 +657,17 @@ def main():
         extra["secondary_siterm"] = run("siterm", *defaults["siterm"], world == 1 and not args.no_cpu_baseline)
         extra["secondary_co_counting"] = run_co_counting(*defaults["co_counting"], world, rank, local_rank, fence,
                                                          world == 1 and not args.no_cpu_baseline)
+        # the other widened rows of SURVEY 8f (each a few tens of milliseconds of GPU time; per family, so they shard like
+        # SiteRM): LG counting, FastCherries branch lengths, SiteRM assembly, held-out likelihood
+        cpu = world == 1 and not args.no_cpu_baseline
+        extra["secondary_counting"] = run_counting(*defaults["counting"], world, rank, local_rank, fence, cpu)
+        extra["secondary_ble"] = run_ble(*defaults["ble"], world, rank, local_rank, fence, cpu)
+        extra["secondary_assembly"] = run_assembly(*defaults["assembly"], world, rank, local_rank, fence, cpu)
+        extra["secondary_likelihood"] = run_likelihood(*defaults["likelihood"], world, rank, local_rank, fence, cpu)
         if rank == 0:
             for name, sec in extra.items():
-                out[name] = {k: sec[k] for k in keep if k in sec}
+                if sec is not None:
+                    out[name] = {k: sec[k] for k in keep + ("latency_budget", "phase_ms_max_over_ranks") if k in sec}
     finish(out)
 
 
@@ -715,10 +748,18 @@ def run_counting(steps, warmup, world, rank, local_rank, fence, with_cpu):
         "config": {"workload": f"counting: {F} families x {NCH} cherries x {L} sites per GPU, "
                                "B=129 grid, cherry (symmetric) mode", "states": S, "buckets": B,
                    "sharding": f"families x{world}, all-reduce of integer counts"},
-        "roofline": {"bound": "hbm", "kernel": "count_transitions_lds_kernel", "achieved": achieved,
-                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+        # The pass is bound by LDS atomics, not by HBM (30.7 MB of algorithmic bytes in 85 us = 4.6 % of the HBM peak says
+        # nothing): every valid (cherry, site) is two ds_add_u32 into the workgroup's histogram.  Peak: an LDS atomic is a
+        # 4-byte LDS write cycle-wise (MI355X_MICROARCH.md, LDS table: ds_write_b32 = 4 cycles per wave-instruction,
+        # i.e. 16 lanes per clock per CU) x 256 CUs x 2.4 GHz = 9.83e12 lane-atomics / s when conflict-free.
+        "roofline": {"bound": "lds_atomic", "kernel": "count_transitions_lds_kernel",
+                     "achieved": 2.0 * counted / world / (kernel_ms * 1e-3) / 1e9, "peak": LDS_ATOMIC_PEAK_G,
+                     "unit": "G lane-atomics/s", "frac": 2.0 * counted / world / (kernel_ms * 1e-3) / 1e9 / LDS_ATOMIC_PEAK_G,
+                     "hbm_achieved_GBs": achieved, "hbm_frac": achieved / HBM_PEAK_GBS,
                      "traffic": _pmc_traffic().get("pass:counting"), "ms_per_launch": kernel_ms, "bytes_per_launch": nbytes,
-                     "note": "per-workgroup LDS histogram (packed 16-bit bins) + slab reduction"},
+                     "note": "per-workgroup LDS histogram (packed 16-bit bins) + slab reduction; achieved = 2 LDS atomics per "
+                             "counted pair-site; what keeps it far from the LDS peak is the branch-free grid search in front "
+                             "of every atomic (~25 % of the pass) and the slab write + reduction"},
         "counted_pairs": counted,
     }
     if with_cpu:
@@ -933,6 +974,7 @@ def run_ble(steps, warmup, world, rank, local_rank, fence, with_cpu):
     # bytes a pass must at least touch: both code bytes of every cherry x site, per bisection step
     steps_bl, steps_sr = int(np.ceil(np.log2(len(grid)))), int(np.ceil(np.log2(R)))
     nbytes = 2.0 * n * L * (steps_bl * (1 + int(np.mean(iters))) + steps_sr * int(np.mean(iters)))
+    gather_bytes = 16.0 * n * L * (steps_bl * (1 + int(np.mean(iters))) + steps_sr * int(np.mean(iters)))
     out = {
         "metric": "cherry-pairs/sec (whole node): cherry x site pairs fitted per coordinate ascent",
         "value": valid * world / (kernel_ms * 1e-3), "unit": "cherry-pairs/s", "n_gpus": world, "steps": steps,
@@ -942,12 +984,18 @@ def run_ble(steps, warmup, world, rank, local_rank, fence, with_cpu):
                                f"129 grid points x {R} rate categories, LG", "iterations": int(np.mean(iters)),
                    "sharding": f"families x{world} (no collective)",
                    "host_ms_per_call_including_uploads": dt / steps * 1e3},
-        "roofline": {"bound": "hbm", "kernel": "ble_branch_lengths_kernel + ble_site_rates_kernel", "achieved":
-                     nbytes / (kernel_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": nbytes / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
-                     "bytes_per_step": nbytes, "passes": passes,
-                     "note": "gathers from the L2-resident 8 MB log-transition bank; algorithmic bytes = the "
-                             "sequence codes re-read at every bisection step"},
+        # Bound: 8-byte gathers from the L2-resident 8 MB log-transition bank -- two per (cherry, site, bisection step) --
+        # not HBM.  Peak: rows gathered from a table every workgroup shares in the XCD's L2, 16.8 TB/s chip-wide
+        # (MI355X_MICROARCH.md, "Indexed rows"); an 8-byte word costs a 64-byte sector there, which `sector_frac` prices.
+        "roofline": {"bound": "l2_gather", "kernel": "ble_branch_lengths_kernel + ble_site_rates_kernel",
+                     "achieved": gather_bytes / (kernel_ms * 1e-3) / 1e9, "peak": L2_GATHER_PEAK_GBS, "unit": "GB/s",
+                     "frac": gather_bytes / (kernel_ms * 1e-3) / 1e9 / L2_GATHER_PEAK_GBS,
+                     "sector_frac": 8.0 * gather_bytes / (kernel_ms * 1e-3) / 1e9 / L2_GATHER_PEAK_GBS,
+                     "hbm_frac": nbytes / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                     "bytes_per_step": gather_bytes, "code_bytes_per_step": nbytes, "passes": passes,
+                     "note": "achieved = 16 gathered bytes per (cherry, site, bisection step) over the whole coordinate ascent, "
+                             "including its one-off bank kernels; wave-uniform bisection with a wavefront reduction per step: "
+                             "the dependent gather -> reduce -> compare chain, not bandwidth, sets the time"},
     }
     if with_cpu:
         from oracle import ble_oracle as bo

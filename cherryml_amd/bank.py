@@ -140,7 +140,7 @@ class CherryBank:
         _lib.check(_lib.load().cb_set_stream(self._h, hip_stream or None, int(own)), "cb_set_stream")
 
     # -- profiling ----------------------------------------------------------
-    TIMING_NAMES = ("total", "eigh", "k1", "k2", "k3", "k4", "small")
+    TIMING_NAMES = ("total", "eigh", "k1", "k2", "k3", "k4", "small", "allreduce")
 
     def profile(self, enable: bool = True):
         _lib.check(_lib.load().cb_profile(self._h, int(enable)), "cb_profile")

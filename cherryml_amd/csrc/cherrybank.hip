@@ -560,7 +560,8 @@ static int read_phase_times(cb_bank *h, double (&v)[CB_T_COUNT]) {
   {
     int last = EV_START;
     for (int i = 0; i <= CB_T_COUNT; ++i)
-      if (h->ev_rec[i] && i != EV_END) last = i;
+      if (h->ev_rec[i] && i != EV_END && i != EV_AR) last = i;
+    if (h->ev_rec[EV_AR]) last = EV_AR;
     HIP_TRY(hipEventSynchronize(h->ev[last]));
   }
   auto span = [&](int a, int b) -> double {
@@ -575,6 +576,7 @@ static int read_phase_times(cb_bank *h, double (&v)[CB_T_COUNT]) {
     v[CB_T_K2] = span(EV_K1, EV_K2);
     v[CB_T_K3] = span(EV_K2, EV_K3);
     v[CB_T_K4] = span(EV_K3, EV_K4);
+    v[CB_T_ALLREDUCE] = span(EV_K4, EV_AR);
     v[CB_T_TOTAL] = span(EV_START, h->ev_rec[EV_K4] ? EV_K4 : EV_K1);
   } else {
     v[CB_T_SMALL] = span(EV_START, EV_SMALL);

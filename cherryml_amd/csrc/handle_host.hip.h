@@ -119,7 +119,7 @@ static void swap_event_sets(cb_bank *h) {
 
 static void fold_pending(cb_bank *h);
 // event i marks the END of phase i-1 .. see mark()
-enum { EV_START = 0, EV_EIGH, EV_K1, EV_K2, EV_K3, EV_K4, EV_SMALL, EV_END };
+enum { EV_START = 0, EV_EIGH, EV_K1, EV_K2, EV_K3, EV_K4, EV_SMALL, EV_END, EV_AR };   // (EV_AR = CB_T_COUNT: the last slot)
 static void mark(cb_bank *h, int which) {
   if (!h->profile) return;
   if (!h->ev[which]) (void)hipEventCreate(&h->ev[which]);

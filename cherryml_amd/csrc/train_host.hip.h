@@ -189,6 +189,7 @@ static int run_fused_training_large(cb_bank *h, double *pi_param, double *up_par
         rc = fail(CB_EHIP, "ncclAllReduce failed with code %d", ar);
         break;
       }
+      mark(h, EV_AR);   // CB_T_ALLREDUCE = the span from the end of K4 to here
     }
     if (h->profile) h->t_pending = true;
     pow_b1 *= a.beta1;

@@ -151,7 +151,8 @@ enum {
   CB_T_K3 = 4,      /* large path: Mt accumulation (one launch)     */
   CB_T_K4 = 5,      /* large path: reduce + back-rotation           */
   CB_T_SMALL = 6,   /* small path: the fused per-site kernel (one launch) */
-  CB_T_COUNT = 7
+  CB_T_ALLREDUCE = 7, /* sharded C-driven loop (cb_allreduce_setup): the two ncclAllReduce calls of an epoch */
+  CB_T_COUNT = 8
 };
 int cb_profile(cb_handle h, int enable);
 int cb_last_timings(cb_handle h, double *ms, int n);

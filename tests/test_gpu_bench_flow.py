@@ -33,6 +33,14 @@ def test_two_ranks_share_the_gpu_through_the_gloo_hook():
     # weak scaling: both ranks' events are in the counted total (10,000 families x 64 cherries x ~65 contacts each)
     assert cc["value"] * cc["ms_per_step"] * 1e-3 > 6.0e7
     assert "secondary" not in d      # the LG replica line belongs to N = 1
+    # round 4: the N > 1 line is self-diagnosing -- which transport carried the per-epoch all-reduce (None: torch's, because
+    # the raw RCCL communicator could not be made here), per-phase maxima over the ranks, and every widened row of SURVEY 8f
+    assert "rccl_ranks" in d and d["rccl_ranks"] is None
+    mx = d["phase_ms_max_over_ranks"]
+    assert all(mx[k] >= d["phase_ms"][k] - 1e-9 for k in ("eigh", "k1", "k2", "k3")) and "allreduce" in mx
+    for name in ("secondary_counting", "secondary_ble", "secondary_assembly", "secondary_likelihood"):
+        assert d[name]["n_gpus"] == 2 and d[name]["value"] > 0 and d[name]["roofline"]["bound"] in ("hbm", "mfma", "lds_atomic", "l2_gather"), name
+    assert d["secondary_counting"]["roofline"]["bound"] == "lds_atomic" and d["secondary_ble"]["roofline"]["bound"] == "l2_gather"
 
 
 _RESIDENT_WORKER = r'''
