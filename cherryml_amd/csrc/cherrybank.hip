@@ -179,7 +179,8 @@ static int large_eval(cb_bank *h, bool normalize, double *lossd, double *out, bo
   if (f32 || mixed)
     hipLaunchKernelGGL(lg_cast_f32, dim3((unsigned)((std::max(LL, (size_t)B * LD) + 255) / 256)), dim3(256), 0, h->stream, LL,
                        (size_t)B * LD, h->U, h->Vc, h->A, h->F, h->Uf, h->Utf, h->Af, h->Ff);
-  mark(h, EV_END);  // (re-used as "before K1" marker)
+  // (no event between the spectral tables and K1: a hipEventRecord costs ~6 us of idle GPU between two kernels; CB_T_K1
+  // is the span from the end of the eigensolver to the end of K1 = lg_tables (4 us) [+ the float32 casts] + K1)
   if (f32) {
     K1Args<float> k1{S, LD, B, h->Utf, h->Af, tb, h->Ff, h->sigma, h->Ct32, h->Gt32, h->loss_part, inv_n, h->dsq, nullptr};
     hipLaunchKernelGGL(k1_pt_loss_gt<float>, dim3(tiles_k1 * B), dim3(LG4_THREADS), 0, h->stream, k1);
@@ -572,7 +573,7 @@ static int read_phase_times(cb_bank *h, double (&v)[CB_T_COUNT]) {
   };
   if (h->large) {
     v[CB_T_EIGH] = span(EV_START, EV_EIGH);
-    v[CB_T_K1] = span(EV_END, EV_K1);
+    v[CB_T_K1] = span(EV_EIGH, EV_K1);
     v[CB_T_K2] = span(EV_K1, EV_K2);
     v[CB_T_K3] = span(EV_K2, EV_K3);
     v[CB_T_K4] = span(EV_K3, EV_K4);

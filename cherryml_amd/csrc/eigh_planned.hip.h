@@ -33,7 +33,7 @@ enum {
   EC_STALL = 0,    // sticky: the plan ended without convergence (or met a non-finite matrix); lge_finish leaves U alone
   EC_FINAL = 1,    // index of the final sweep slot (EC_NONE while unknown): slots above it return at once
   EC_NSWEEP = 2,   // sweeps run so far
-  EC_MODE = 3,     // decision of the current sweep: order | masked << 8 | damped << 9 | active << 16
+  EC_MODE = 3,     // decision of the current sweep: order | masked << 8 | damped << 9 | second order << 10 | active << 16
   EC_SQ = 4,       // squarings of the current sweep
   EC_ERR = 5,      // 2: non-finite input
   EC_ARRIVE = 6,   // lge_gram's arrival counter (left at zero)
@@ -53,6 +53,8 @@ struct GramArgs {
   int nsq;       // squaring launches this slot has
   const double *G;   // [LD][LD] column-major: G[c][r]
   double *X, *Xf;
+  double *Gm, *dg;   // slots with the second-order launch: Gamma itself and its diagonal (as X was built from it)
+  int so;            // the slot has the second-order launch (lge_so)
   double *part;      // [2][LD/16][LD] row-sum partials, then [(LD/16)^2] cosine partials
   unsigned long long *ctl;
   double trigger;
@@ -140,6 +142,10 @@ __global__ __launch_bounds__(512, 6) void lge_gram(GramArgs a) {   // 6 waves pe
     const bool far = bd > a.band || -bd > a.band;
     a.X[(size_t)row * LD + col] = x;
     a.Xf[(size_t)row * LD + col] = far ? x : 0.0;
+    if (a.so) {
+      a.Gm[(size_t)row * LD + col] = g;
+      if (row == col) a.dg[row] = gii;
+    }
     rsf = far ? rs : 0.0;
     // row sums over this tile's 16 columns (lanes with equal l >> 4)
 #pragma unroll
@@ -225,7 +231,11 @@ __global__ __launch_bounds__(512) void lge_decide(GramArgs a) {
     // neighbours too (the rule of eigh_large_host.hip.h)
     const bool masked = cosmax > a.trigger || rowsum > 0.5;
     const double rsu = masked ? rowsum_far : rowsum;
-    if (!masked && cosmax <= 1e-8) ctl[EC_FINAL] = (unsigned long long)a.slot;   // starts below 1e-8: ends at rounding level
+    // second-order generator (lge_so): the sweep then converges cubically -- it ends at ~ c |X|^2 instead of ~ c |X| --,
+    // so it is the last one already when c |X|^2 <= 2e-14 (what a first-order sweep from 1e-8 leaves at worst)
+    const bool so = a.so != 0 && !masked && cosmax > 1e-8;
+    if (!masked && (cosmax <= 1e-8 || (so && cosmax * rowsum * rowsum <= 2e-14)))
+      ctl[EC_FINAL] = (unsigned long long)a.slot;   // starts below 1e-8: ends at rounding level
     int order = rsu <= lge_lim(2) ? 2 : rsu <= lge_lim(4) ? 4 : rsu <= lge_lim(8) ? 8 : 12;
     if (order > a.cap) order = a.cap;
     const double lim = lge_lim(order);
@@ -239,7 +249,7 @@ __global__ __launch_bounds__(512) void lge_decide(GramArgs a) {
       sc = lim / rsu;
       damped = 1ull;
     }
-    mode = (unsigned long long)order | (masked ? 256ull : 0ull) | (damped << 9) | (1ull << 16);
+    mode = (unsigned long long)order | (masked ? 256ull : 0ull) | (damped << 9) | (so ? 1024ull : 0ull) | (1ull << 16);
     ctl[EC_MASKED] = masked ? 1ull : 0ull;
   }
   ctl[EC_MODE] = mode;
@@ -278,7 +288,7 @@ __global__ __launch_bounds__(512) void lge_gemm(EgArgs a) {
   const unsigned long long mode = ctl[EC_MODE];
   if (!(mode >> 16)) return;
   const int order = (int)(mode & 255ull);
-  const bool masked = (mode & 256ull) != 0ull;
+  const bool masked = (mode & (256ull | 1024ull)) != 0ull;   // far pairs only, OR the second-order generator: both live in Xf
   const int sq = (int)ctl[EC_SQ];
   double sc;
   {
@@ -291,9 +301,9 @@ __global__ __launch_bounds__(512) void lge_gemm(EgArgs a) {
   double alpha = 1.0, beta = 0.0, beta2 = 0.0, eye = 0.0, c1 = 1.0, c2 = 0.0;
   const double *Xu = masked ? a.Xf : a.X;
   switch (a.kind) {
-    case EG_P2:   // X^T X = -X^2; second order: R = I + X - X^T X / 2 at once
+    case EG_P2:   // X^T X = -X^2; second order: R = I + Y + Y^2 / 2 = I + s X - s^2 X^T X / 2 at once (s < 1: a damped sweep)
       Ap = Xu; Bp = Xu;
-      if (order == 2) { out = a.R[0]; sub = Xu; alpha = -0.5; beta = 1.0; eye = 1.0; }
+      if (order == 2) { out = a.R[0]; sub = Xu; alpha = -0.5 * (sc * sc); beta = sc; eye = 1.0; }
       else out = a.P2;
       break;
     case EG_R4:   // fourth order in one product (slots without the polynomial launches):
@@ -381,6 +391,81 @@ __global__ __launch_bounds__(512) void lge_gemm(EgArgs a) {
   if (outT) outT[(size_t)col * LD + row] = o;
 }
 
+// Second-order generator of an all-pairs sweep.  With Gamma = D + E (E off-diagonal) the rotation exp(X) that diagonalises
+// it satisfies, order by order (e^-X Gamma e^X = Gamma + [Gamma, X] + [[Gamma, X], X] / 2 + ..):
+//     X1_mn = E_mn / (D_n - D_m)                              (lge_gram: the small-angle limit of every pair's rotation)
+//     X2_mn = [E, X1]_mn / (2 (D_n - D_m)),   [E, X1] = E X1 - X1 E = (E X1) + (E X1)^T
+// A first-order sweep leaves cosines ~ c |X|; with X = X1 + X2 it leaves ~ c |X|^2: on the recorded bench trajectory
+// (profiles/tools/eigh_proto.py) 1.9 all-pairs sweeps per solve instead of 2.8, for ONE more launch per sweep: both products
+// of the commutator on the same 16 x 16 tile (out[m][n] = sum_k E[k][m] X[k][n] + X[k][m] E[k][n], E symmetric, X
+// antisymmetric), the division in the epilogue.  The corrected generator goes to Xf, which an all-pairs sweep does not
+// use, and the products that follow take it from there (EC_MODE bit 10).
+struct SoArgs {
+  int LD, slot;
+  const unsigned long long *ctl;
+  const double *Gm, *dg, *X;
+  double *Xs;   // = Xf
+};
+
+__global__ __launch_bounds__(512) void lge_so(SoArgs a) {
+  __shared__ double sRed[4][256];
+  const unsigned long long *ctl = a.ctl;
+  if (ctl[EC_STALL] != 0ull || (unsigned long long)a.slot > ctl[EC_FINAL]) return;
+  if (!(ctl[EC_MODE] & 1024ull)) return;
+  const int LD = a.LD, nt = LD / 16;
+  const int tm = blockIdx.x / nt, tn = blockIdx.x - tm * nt;
+  const int m0 = tm * 16, n0 = tn * 16;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, lo = lane & 15, hi = lane >> 4;
+  d4 accA = {0.0, 0.0, 0.0, 0.0}, accB = accA;
+  const int nsteps = LD / 4;
+  const double *Em = a.Gm + m0 + lo, *En = a.Gm + n0 + lo, *Xm = a.X + m0 + lo, *Xn = a.X + n0 + lo;
+  for (int s0 = wave; s0 < nsteps; s0 += 7 * 8) {   // seven k-steps of this wave in flight
+    double e1[7], x1[7], x2[7], e2[7];
+#pragma unroll
+    for (int u = 0; u < 7; ++u) {
+      const int s = min(s0 + 8 * u, nsteps - 1);
+      const int k = 4 * s + hi;
+      const size_t krow = (size_t)k * LD;
+      e1[u] = k == m0 + lo ? 0.0 : Em[krow];   // E = Gamma without its diagonal
+      x1[u] = Xn[krow];
+      x2[u] = Xm[krow];
+      e2[u] = k == n0 + lo ? 0.0 : En[krow];
+    }
+#pragma unroll
+    for (int u = 0; u < 7; ++u)
+      if (s0 + 8 * u < nsteps) {
+        accA = mfma_f64(e1[u], x1[u], accA);
+        accB = mfma_f64(x2[u], e2[u], accB);
+      }
+  }
+  d4 acc = accA + accB;   // (the tile (n, m) holds the same two sums with their roles exchanged: [E, X] stays exactly symmetric)
+  if (wave >= 4) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) sRed[wave - 4][r * 64 + lane] = acc[r];
+  }
+  __syncthreads();
+  if (wave < 4) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc[r] += sRed[wave][r * 64 + lane];
+  }
+  __syncthreads();
+  if (wave < 4) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) sRed[wave][r * 64 + lane] = acc[r];
+  }
+  __syncthreads();
+  if (threadIdx.x >= 256) return;
+  const int t = threadIdx.x, r = t >> 6, l = t & 63;
+  const int row = m0 + (l >> 4) + 4 * r, col = n0 + (l & 15);
+  const double v = (sRed[0][t] + sRed[1][t]) + (sRed[2][t] + sRed[3][t]);
+  const size_t idx = (size_t)row * LD + col;
+  const double x1v = a.X[idx];
+  const double d = a.dg[col] - a.dg[row];
+  // (pairs lge_gram left alone -- orthogonal to rounding, or exactly degenerate -- stay as they are)
+  const double x2v = (row != col && x1v != 0.0 && d != 0.0) ? 0.5 * v * fast_rcp(d) : 0.0;
+  a.Xs[idx] = x1v + x2v;
+}
+
 // The polynomial coefficients of exp(Y), Y = s X, from X, P2 = -X^2, P3 = X^3, P4 = X^4 (elementwise):
 //   order 4:  R_0 = I + Y + Y^2/2 + Y^3/6 + Y^4/24
 //   order 8:  B0 = I + Y + Y^2/2 + Y^3/6,  T = I/4! + Y/5! + Y^2/6! + Y^3/7! + Y^4/8!          (R_0 = B0 + Y^4 T)
@@ -407,7 +492,7 @@ __global__ __launch_bounds__(256) void lge_poly(PolyArgs a) {
   if (idx >= (size_t)a.LD * a.LD) return;
   const int i = idx / a.LD, j = idx - (size_t)i * a.LD;
   const double dl = i == j ? 1.0 : 0.0;
-  const double *Xu = (mode & 256ull) ? a.Xf : a.X;
+  const double *Xu = (mode & (256ull | 1024ull)) ? a.Xf : a.X;
   const double s2 = sc * sc;
   const double y1 = sc * Xu[idx], y2 = -s2 * a.P2[idx], y3 = s2 * sc * a.P3[idx], y4 = s2 * s2 * a.P4[idx];
   const double b0 = dl + y1 + 0.5 * y2 + y3 * (1.0 / 6.0);

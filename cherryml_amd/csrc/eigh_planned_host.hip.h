@@ -25,6 +25,7 @@ static void eigh_plan_default(EighPlan &p, int extra = 0) {
     p.slot[i].cap = i < 3 + extra ? 12 : 4;
     p.slot[i].nsq = i == 0 ? 2 : (i < 3 + extra ? 1 : 0);
     p.slot[i].band_after = i < 2 + extra ? 1 : 0;
+    p.slot[i].so = i >= 1 ? 1 : 0;
   }
 }
 
@@ -44,7 +45,8 @@ static void eigh_plan_from_record(const EighRecord &r, const EighPlan &prev, Eig
     const double rsu = s.masked ? s.rsf : s.rs;
     EighSlot &q = p.slot[i];
     // (the generator's norm moves by an order of magnitude from one epoch to the next: 20x below the fourth-order limit)
-    q.cap = (s.order >= 8 || rsu > 1e-4 || s.damped) ? 12 : (rsu > 1e-7 ? 4 : 2);
+    q.cap = (s.order >= 8 || rsu > 1e-4 || s.damped) ? 12 : 4;   // (never 2 from a record: the last sweep's |X| moves over
+                                                                  // two orders of magnitude from epoch to epoch, a damped sweep is a lost one)
     if (q.cap == 12) {
       int need = s.sq + (s.damped ? 1 : 0);
       if (rsu * std::ldexp(1.0, -s.sq) > 0.3) ++need;
@@ -52,8 +54,12 @@ static void eigh_plan_from_record(const EighRecord &r, const EighPlan &prev, Eig
     }
     // a band pass behind the sweep when it is expected to be a masked one (near the rule's thresholds counts)
     q.band_after = (s.masked || s.c > 2e-4 || s.rs > 0.3) ? 1 : 0;
+    q.so = s.masked ? 0 : 1;
   }
-  p.slot[n] = EighSlot{4, 0, 0};   // the spare
+  // the spare: with second-order sweeps in front of it, a sweep MORE than last time starts at |X| ~ 1e-7 -- the second-order
+  // polynomial (gram, decide, one product, G R: four launches when it is not needed) is enough; should it not be, the sweep is a
+  // damped one, the solve stalls and is continued
+  p.slot[n] = EighSlot{2, 0, 0, 0};
   // the band pass in front pays while near-degenerate neighbours are far from separated (profiles/tools/eigh_proto.py)
   p.lead_band = (r.sweep[0].masked && r.sweep[0].c > 1e-3) ? 1 : 0;
 }
@@ -72,7 +78,7 @@ static bool eigh_planned_setup(cb_bank *h) {
   if (hipMalloc(&q, EC_WORDS * sizeof(unsigned long long)) != hipSuccess) return false;
   h->allocs.push_back(q);
   unsigned long long *ctl = static_cast<unsigned long long *>(q);
-  if (hipMalloc(&q, ((size_t)2 * nt * LD + (size_t)nt * nt + 8) * sizeof(double)) != hipSuccess) return false;
+  if (hipMalloc(&q, ((size_t)2 * nt * LD + (size_t)nt * nt + 8 + LD) * sizeof(double)) != hipSuccess) return false;
   h->allocs.push_back(q);
   h->epart = static_cast<double *>(q);
   if (hipHostMalloc(&q, 2 * (EC_WORDS + 16) * sizeof(unsigned long long), hipHostMallocCoherent | hipHostMallocMapped) != hipSuccess) {
@@ -115,7 +121,8 @@ static int enqueue_planned_solve(cb_bank *h, const EighPlan &p, unsigned long lo
   int shift = 0;
   auto band_pass = [&](double *G, const unsigned long long *must_nonzero) {
     for (int w = 0; w < 2; ++w)
-      hipLaunchKernelGGL(lgj_round, dim3(nb / 2), dim3(JB_THREADS), lds, h->stream, LD, ((shift + w) & 1) && nb > 2 ? -2 : -1, 2, G,
+      hipLaunchKernelGGL(lgj_round, dim3(nb / 2), dim3(JB_THREADS), lds, h->stream, LD, ((shift + w) & 1) && nb > 2 ? -2 : -1,
+                         must_nonzero ? 1 : 2, G,   // (inner sweeps: two in front of the first sweep, one behind a masked one)
                          jstate, ctl + EC_STALL, must_nonzero);
     for (int k = 2; k <= kPlannedBand && k < nb; ++k)
       for (int par = 0; par < 2; ++par)
@@ -130,9 +137,15 @@ static int enqueue_planned_solve(cb_bank *h, const EighPlan &p, unsigned long lo
     const EighSlot &q = p.slot[i];
     const int s = first_slot + i;
     double *Gin = Gb[s & 1], *Gout = Gb[(s + 1) & 1];
-    GramArgs ga{LD, kPlannedBand, s, q.cap, q.cap == 12 ? q.nsq : 0, Gin, X, Xf, h->epart, ctl, 3e-4};
+    // (Gamma goes to P3's buffer -- dead until the powers are formed --, its diagonal behind the statistics partials)
+    GramArgs ga{LD, kPlannedBand, s, q.cap, q.cap == 12 ? q.nsq : 0, Gin, X, Xf, P3, h->epart + (size_t)2 * nt * LD + (size_t)nt * nt + 8,
+                q.so, h->epart, ctl, 3e-4};
     hipLaunchKernelGGL(lge_gram, tiles, dim3(512), 0, h->stream, ga);
     hipLaunchKernelGGL(lge_decide, dim3(1), dim3(512), 0, h->stream, ga);
+    if (q.so) {
+      SoArgs so{LD, s, ctl, ga.Gm, ga.dg, X, Xf};
+      hipLaunchKernelGGL(lge_so, tiles, dim3(512), 0, h->stream, so);
+    }
     EgArgs e{};
     e.LD = LD; e.slot = s; e.ctl = ctl; e.X = X; e.Xf = Xf; e.P2 = P2; e.P3 = P3; e.P4 = P4; e.B0 = B0; e.B1 = B1; e.B2 = B2; e.T = T;
     e.R[0] = R0; e.R[1] = R1; e.Rt[0] = R0t; e.Rt[1] = R1t; e.Gin = Gin; e.Gout = Gout;

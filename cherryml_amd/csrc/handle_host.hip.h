@@ -7,6 +7,7 @@ struct EighSlot {
   int cap = 12;         // polynomial order the slot's launches can evaluate: 2 (one product), 4 (two) or 12 (powers, polynomial, two more)
   int nsq = 0;          // squaring launches
   int band_after = 0;   // a banded Jacobi pass behind the sweep (runs when the sweep was a masked one)
+  int so = 0;           // the second-order launch (lge_so; runs when the sweep is an all-pairs one above 1e-8)
 };
 struct EighPlan {
   int lead_band = 1;    // a banded Jacobi pass before the first sweep

@@ -115,8 +115,14 @@ static int run_fused_training_large(cb_bank *h, double *pi_param, double *up_par
   EighPlan &plan = h->eplan;
   if (!resume) eigh_plan_default(plan);
   // test hook: every plan cut down to one sweep, so that every solve stalls and is continued (tests/test_gpu_s400_full.py)
-  const bool short_plans = getenv("CB_EIGH_SHORT_PLAN") != nullptr;
-  if (short_plans) plan.nslots = 1;
+  // (= 2: that one sweep with the second-order polynomial only, so that it is also a DAMPED one -- exp(alpha X), alpha << 1)
+  const int short_plans = getenv("CB_EIGH_SHORT_PLAN") ? std::max(1, atoi(getenv("CB_EIGH_SHORT_PLAN"))) : 0;
+  auto shorten = [&]() {
+    if (!short_plans) return;
+    plan.nslots = 1;
+    if (short_plans >= 2) plan.slot[0] = EighSlot{2, 0, plan.slot[0].band_after, 0};
+  };
+  shorten();
   for (int e = 0; e < E && rc == CB_OK; ++e) {
     if (h->profile) {  // fold the epoch before the previous one (its events are long complete), then re-record that set
       swap_event_sets(h);
@@ -159,7 +165,7 @@ static int run_fused_training_large(cb_bank *h, double *pi_param, double *up_par
       if (rc == CB_OK) {
         const EighPlan prev = plan;
         eigh_plan_from_record(rec, prev, plan);
-        if (short_plans) plan.nslots = 1;
+        shorten();
         h->last_sweeps = rec.nsweep;
       }
     }

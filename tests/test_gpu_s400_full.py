@@ -273,7 +273,7 @@ def test_planned_eigensolves_match_the_host_driven_solver_and_survive_short_plan
     decisions are taken on the device, the host only reads a record while the epoch's bank kernels are queued).  The same 25
     epochs (a) planned, (b) with the host-driven solver of rounds 1-3 (CB_EIGH_HOST=1), (c) planned with every plan cut down
     to ONE sweep (CB_EIGH_SHORT_PLAN=1: every solve runs out of plan, is continued from its current state, and the epoch's
-    kernels are enqueued again): same loss curves to 1e-11, same matrices to 1e-9; the counters say which path ran."""
+    kernels are enqueued again), (d) the same with that sweep limited to the second-order polynomial (= 2: a damped rotation): same loss curves to 1e-11, same matrices to 1e-9; the counters say which path ran."""
     from cherryml_amd import CherryBank
     z = load_golden("coevo_dense_traj.npz")
     sel, mask = z["sel"], dense["mask"]
@@ -281,7 +281,8 @@ def test_planned_eigensolves_match_the_host_driven_solver_and_survive_short_plan
     u0, p0 = z["upper_diag0"], z["log_pi0"]
     E = 25
     runs = {}
-    for name, env in (("planned", {}), ("host", {"CB_EIGH_HOST": "1"}), ("short", {"CB_EIGH_SHORT_PLAN": "1"})):
+    for name, env in (("planned", {}), ("host", {"CB_EIGH_HOST": "1"}), ("short", {"CB_EIGH_SHORT_PLAN": "1"}),
+                      ("damped", {"CB_EIGH_SHORT_PLAN": "2"})):
         for k in ("CB_EIGH_HOST", "CB_EIGH_SHORT_PLAN"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
@@ -290,12 +291,15 @@ def test_planned_eigensolves_match_the_host_driven_solver_and_survive_short_plan
             r = bank.train_pande_reversible(u0, p0, mask=mask, num_epochs=E, lr=0.1)
             r["counters"] = bank.eigh_counters()
         runs[name] = r
-    a, b, c = runs["planned"], runs["host"], runs["short"]
+    a, b, c, d = runs["planned"], runs["host"], runs["short"], runs["damped"]
     assert a["counters"]["planned_solves"] == E - 1       # every solve but the cold first one
     assert a["counters"]["stalls"] <= 6                   # (the first warm solves of a training start far from converged)
     assert b["counters"]["planned_solves"] == 0
     assert c["counters"]["planned_solves"] == E - 1 and c["counters"]["stalls"] >= E - 1
-    for other in (b, c):
+    # (d) the one sweep of every plan can only evaluate the second-order polynomial: it applies exp(alpha X) with alpha << 1 --
+    # a DAMPED, still exactly orthogonal rotation (a slot that under-provides is never wrong, only slower) -- and stalls
+    assert d["counters"]["stalls"] >= E - 1
+    for other in (b, c, d):
         assert np.all(np.isfinite(other["loss"]))
         assert np.allclose(a["loss"], other["loss"], rtol=1e-11, atol=0)
         for key in ("Q_last", "Q_best"):
