@@ -242,7 +242,7 @@ def _free_port():
     return port
 
 
-def launch_ranks(n, argv, child=None, grace=15.0, poll=0.05):
+def launch_ranks(n, argv, child=None, grace=15.0, poll=0.05, _attempt=0):
     """`python bench.py --gpus N` started bare (no WORLD_SIZE in the environment): THIS process touches no GPU (it
     imports numpy only), starts N fresh rank processes of this script -- one per GPU, RANK / LOCAL_RANK / WORLD_SIZE /
     MASTER_ADDR / MASTER_PORT in their environment, as `torch.distributed.run` would set them (the reference starts its
@@ -252,6 +252,9 @@ def launch_ranks(n, argv, child=None, grace=15.0, poll=0.05):
     the children are ordinary child processes.  `child` replaces the command (tests use a stub)."""
     import subprocess
     cmd = list(child) if child else [sys.executable, os.path.abspath(__file__)]
+    # (the port is free NOW; another process can still take it before rank 0 binds it -- a job that dies within seconds of its
+    # start is therefore started once more on another port: `_attempt`)
+    t_start = time.time()
     port = _free_port()
     procs = []
     for r in range(n):
@@ -283,6 +286,9 @@ def launch_ranks(n, argv, child=None, grace=15.0, poll=0.05):
     reader.join(timeout=5.0)
     out = (chunks[0] if chunks else b"").decode(errors="replace")
     if first_bad is not None:
+        if _attempt == 0 and child is None and failed_at - t_start < 8.0:   # died at the rendezvous: once more, new port
+            print("bench launcher: the job failed within seconds of its start; retrying once on another port", file=sys.stderr)
+            return launch_ranks(n, argv, child, grace, poll, _attempt=1)
         sys.stderr.write(out)   # no result line on stdout from a failed job
         return first_bad if 0 < first_bad < 256 else 1
     sys.stdout.write(out)
@@ -293,7 +299,8 @@ def launch_ranks(n, argv, child=None, grace=15.0, poll=0.05):
 # ------------------------------------------------------------------------ main
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--gpus", type=int, default=None,
+                    help="ranks of ONE node (default: WORLD_SIZE when started under torch.distributed.run, else 1)")
     ap.add_argument("--steps", type=int, default=None)
     ap.add_argument("--warmup", type=int, default=None)
     ap.add_argument("--workload", default="coevo400",
@@ -311,6 +318,8 @@ def main():
                          "torch.distributed instead of the C-driven loop with the in-library ncclAllReduce")
     args = ap.parse_args()
 
+    if args.gpus is None:   # left at its default: adopt the launcher's rank count (an EXPLICIT mismatch is still refused below)
+        args.gpus = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:

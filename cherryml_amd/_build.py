@@ -19,8 +19,28 @@ def _sources():
     return out
 
 
+FLAGS_FILE = LIB + ".flags"   # the CB_EXTRA_HIPCC_FLAGS the library was built with (git-ignored like the library)
+
+
+def _extra_flags() -> str:
+    return " ".join(os.environ.get("CB_EXTRA_HIPCC_FLAGS", "").split())
+
+
+def built_flags() -> str:
+    try:
+        with open(FLAGS_FILE) as f:
+            return f.read().strip()
+    except OSError:
+        return ""
+
+
 def needs_build() -> bool:
+    """Stale when a source is newer than the library -- or when the library was built with OTHER experiment flags than
+    the ones asked for now (a profiling script that rebuilt with -DCB_CO_PLAIN must not leave that library behind for the
+    next bench or test run: ADVICE r3)."""
     if not os.path.exists(LIB):
+        return True
+    if built_flags() != _extra_flags():
         return True
     mt = os.path.getmtime(LIB)
     return any(os.path.getmtime(s) > mt for s in _sources())
@@ -51,6 +71,8 @@ def build(force: bool = False, verbose: bool = False) -> str:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
     os.replace(LIB + ".tmp", LIB)
+    with open(FLAGS_FILE, "w") as f:
+        f.write(_extra_flags() + "\n")
     return LIB
 
 

@@ -84,6 +84,15 @@ def load():
             f"{LIB} is missing: the HIP extension has not been built. Run "
             "`python -c 'import __graft_entry__ as g; g.build()'` (needs hipcc). "
             "cherryml_amd has no CPU fallback.")
+    try:   # a library left behind by a profiling script that built with experiment macros must not pass unnoticed
+        with open(LIB + ".flags") as f:
+            built = f.read().strip()
+    except OSError:
+        built = ""
+    if built and built != " ".join(os.environ.get("CB_EXTRA_HIPCC_FLAGS", "").split()):
+        import warnings
+        warnings.warn(f"{LIB} was built with CB_EXTRA_HIPCC_FLAGS={built!r} (an experiment build); rebuild with "
+                      "`python -m cherryml_amd._build` for the shipped kernels", RuntimeWarning)
     lib = C.CDLL(LIB)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported

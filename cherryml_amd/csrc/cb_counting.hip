@@ -6,9 +6,14 @@
 // ------------------------------------------------------------------------ counting
 // Replica scratch of the resident (device-pointer) form, kept per device for the life of the
 // process (the only process-wide state of the library; never holds results between calls).
+#include <mutex>
+// (one lock for the whole table: the counting entry points are not meant to run concurrently on one device -- their kernels
+// share this scratch on the default stream -- but two host threads growing it at once must not corrupt the table)
+static std::mutex g_scratch_mutex;
 static int count_scratch(int device, size_t elems, unsigned long long **out, bool *moved = nullptr) {
   static unsigned long long *buf[64] = {};
   static size_t cap[64] = {};
+  std::lock_guard<std::mutex> lock(g_scratch_mutex);
   if (device < 0 || device >= 64) return fail(CB_EINVAL, "counting: device %d out of range", device);
   if (moved) *moved = cap[device] < elems;   // a re-allocation loses the contents -- and may return the SAME address
   if (cap[device] < elems) {
@@ -76,14 +81,16 @@ static int launch_count_co_transitions(int device, int S, int B, const double *g
 #else
   const bool plain = false;
 #endif
-  if (plain || R < 1 || (size_t)2 * B * 8 > 64 * 1024) {   // S > 200 or an enormous grid: the plain atomic form
+  // (co_expand loads the contacts as int2: a list that is not 8-byte aligned -- an offset view of a device buffer -- takes the
+  // plain form too, which reads them as 4-byte words; same counts)
+  const bool misaligned = (reinterpret_cast<uintptr_t>(contacts) & 7) != 0;
+  if (plain || misaligned || R < 1 || (size_t)2 * B * 8 > 64 * 1024) {   // S > 200 or an enormous grid: the plain atomic form
     const unsigned blocks = (unsigned)((n_pairs + 3) / 4);
     hipLaunchKernelGGL(count_co_transitions_kernel, dim3(blocks), dim3(256), 0, 0, S, B, grid, seqs, contacts, pairs,
                        (long long)n_pairs, symmetric, counts);
     HIP_TRY(hipGetLastError());
     return CB_OK;
   }
-  if (reinterpret_cast<uintptr_t>(contacts) & 7) return fail(CB_EINVAL, "cb_count_co_transitions: the contact list must be 8-byte aligned");
   const int nrb = (S2 + R - 1) / R;
 #ifndef CO_TARGET
 #define CO_TARGET 1024   // measured on the 10,000-family bench input: 512 -> 0.684, 1024 -> 0.659, 2048 -> 0.760, 4096 -> 0.990 ms
@@ -94,7 +101,9 @@ static int launch_count_co_transitions(int device, int S, int B, const double *g
   // scratch layout (8-byte words): bucket_ev[B] cursor[B] | bucket_off[B+1] n_work[1] work[4 * max_work] qbuf events
   const size_t head = (size_t)2 * B, fixed = head + (B + 1) + 1 + (size_t)4 * max_work + ((size_t)n_pairs + 1) / 2;
   unsigned long long *scr = nullptr;
-  int rc = count_scratch(device, fixed, &scr);
+  // host form: the event total is known, so the scratch gets its final size NOW (the two-step growth below -- and its
+  // repeated launches -- is for the resident form only, which learns the total from the device)
+  int rc = count_scratch(device, total_events >= 0 ? fixed + ((size_t)total_events + 1) / 2 + 1 : fixed, &scr);
   if (rc != CB_OK) return rc;
   HIP_TRY(hipMemsetAsync(scr, 0, head * sizeof(unsigned long long), 0));
   auto carve = [&](unsigned long long *base) {

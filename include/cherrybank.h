@@ -236,7 +236,9 @@ int cb_train_siterm(cb_handle h, double *theta, double *Theta, int num_epochs,
  * histogram fits LDS, cb_count_transitions uses the LDS-privatised kernel.  cb_count_co_transitions bins its
  * (pair, contact) events by bucket and needs their total to size the event array: the host form sums pair.n, the resident
  * form reads the total back after its first two kernels (one 8-byte copy: this form synchronises the default stream
- * once per call); bits 8..23, when given, are only checked against it (CB_EINVAL when exceeded).
+ * once per call); bits 8..23, when given, are only checked against it (CB_EINVAL when exceeded).  A resident contact list that
+ * is not 8-byte aligned is counted by the slower scattered-atomic kernel (same counts).  The entry points share one scratch
+ * buffer per device on HIP's default stream: do not run them concurrently on one device.
  */
 typedef struct {
   int64_t seq_a, seq_b; /* byte offsets of the two encoded sequences in `seqs`        */

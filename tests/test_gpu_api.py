@@ -853,3 +853,18 @@ def test_other_parameterisations_match_the_reference(mode, case):
     df, Qd = train_quantization(mod, TensorDataset(torch.tensor(t), torch.tensor(C)), num_epochs=30, optimizer=opt)
     assert np.allclose(df.loss.to_numpy(), z[f"{k}_traj_loss"], rtol=1e-8, atol=0)
     assert relerr(Qd["Q_best"], z[f"{k}_Q_best"]) < 1e-6 and relerr(Qd["Q_last"], z[f"{k}_Q_last"]) < 1e-6
+
+
+def test_non_finite_iterate_gives_nan_loss_and_never_becomes_the_best(tmp_path):
+    """the table logarithm of the small-state trainers read only exponent and mantissa bits, so a non-finite P came
+    out as a large FINITE loss, which the best-iterate comparison (`loss < best`) could record.  A plain gradient step with an
+    absurd learning rate throws the parameters to +-inf after the first epoch: every later loss must be NaN (as
+    torch.matrix_exp's would be), and Q_best must stay the first iterate."""
+    from cherryml_amd import CherryBank
+    g = load_golden("eval_s20_symmask.npz")
+    with CherryBank(g["t"], g["C"]) as bank:
+        ok = bank.train_pande_reversible(g["upper_diag"], g["log_pi"], mask=g["mask"], num_epochs=1, lr=0.1)
+        r = bank.train_pande_reversible(g["upper_diag"], g["log_pi"], mask=g["mask"], num_epochs=6, lr=1e300, do_adam=False)
+    assert np.isfinite(r["loss"][0]) and r["loss"][0] == ok["loss"][0]
+    assert np.all(np.isnan(r["loss"][1:])), r["loss"]
+    assert np.array_equal(r["Q_best"], ok["Q_best"])      # the iterate of epoch 0, not a later non-finite one

@@ -175,6 +175,17 @@ def test_co_counting_bucket_binned_lds_kernel_random(S, n_fam, symmetric):
             _lib.check(rc, "cb_count_co_transitions")
         torch.cuda.synchronize()
         assert np.array_equal(d_counts.cpu().numpy().astype(np.uint64).reshape(want.shape), 2 * want + 1), bound
+    # a resident contact list that is NOT 8-byte aligned (an offset view of a device buffer): counted all the same
+    shifted = torch.empty(contacts.size + 1, dtype=torch.int32, device=dev)
+    shifted[1:] = d[2]
+    assert shifted[1:].data_ptr() % 8 == 4
+    d_counts = torch.zeros(want.size, dtype=torch.int64, device=dev)
+    rc = lib.cb_count_co_transitions(0, S, B, d[0].data_ptr(), d[1].data_ptr(), seqs.size, shifted[1:].data_ptr(),
+                                     contacts.size // 2, d[3].data_ptr(), len(pairs), symmetric, _lib.CB_PTR_DEVICE,
+                                     d_counts.data_ptr())
+    _lib.check(rc, "cb_count_co_transitions")
+    torch.cuda.synchronize()
+    assert np.array_equal(d_counts.cpu().numpy().astype(np.uint64).reshape(want.shape), want)
     if pairs["n"].max() > 1:   # a stated bound that the pairs exceed is refused, not trusted
         rc = lib.cb_count_co_transitions(0, S, B, d[0].data_ptr(), d[1].data_ptr(), seqs.size, d[2].data_ptr(),
                                          contacts.size // 2, d[3].data_ptr(), len(pairs), symmetric,
