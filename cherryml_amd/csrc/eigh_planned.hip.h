@@ -134,8 +134,12 @@ __global__ __launch_bounds__(512, 6) void lge_gram(GramArgs a) {   // 6 waves pe
     if (row != col && g2 > ab * (CB_JAC_SKIP * CB_JAC_SKIP)) {
       mc2 = fmax(mc2, g2 * fast_rcp(ab));
       const double d = gjj - gii;
-      // (fast_rcp is odd in its argument, so X stays exactly antisymmetric)
-      x = d != 0.0 ? g * fast_rcp(d) : (g > 0.0 ? 1.0 : -1.0);   // exactly degenerate and coupled: a huge row sum
+      // The pair's Jacobi angle theta = atan(2 g / d) / 2, of which g / d is the small-angle limit: identical for the far
+      // pairs (|g / d| ~ 1e-3: they differ by (g / d)^2 / 3), but BOUNDED by pi / 4 for a near-degenerate pair -- an isolated
+      // one (d -> 0 at a cosine of 1e-4: g / d = 2.8 on the recorded trajectory) then no longer pushes the row sum over the
+      // all-pairs limit and into a masked sweep that has no band pass planned behind it (a stalled solve), and exp(X) rotates
+      // it by exactly its Jacobi angle.  (atan and fast_rcp are odd: X stays exactly antisymmetric.)
+      x = d != 0.0 ? 0.5 * atan(2.0 * g * fast_rcp(d)) : (g > 0.0 ? 0.78539816339744831 : -0.78539816339744831);
       rs = fabs(x);
     }
     const int bd = row / JB_W - col / JB_W;
@@ -229,7 +233,9 @@ __global__ __launch_bounds__(512) void lge_decide(GramArgs a) {
   } else {
     // all pairs at once only when the state is close enough for the small-angle limit to hold for the near-degenerate
     // neighbours too (the rule of eigh_large_host.hip.h)
-    const bool masked = cosmax > a.trigger || rowsum > 0.5;
+    // (row sums of Jacobi ANGLES: one near-degenerate pair contributes at most pi / 4, so the all-pairs limit is 1 -- a row
+    // with two large angles, i.e. a cluster, is still sent to the band passes)
+    const bool masked = cosmax > a.trigger || rowsum > 1.0;
     const double rsu = masked ? rowsum_far : rowsum;
     // second-order generator (lge_so): the sweep then converges cubically -- it ends at ~ c |X|^2 instead of ~ c |X| --,
     // so it is the last one already when c |X|^2 <= 2e-14 (what a first-order sweep from 1e-8 leaves at worst)
