@@ -20,17 +20,17 @@ static const int kPlannedBand = 2;   // blocks: pairs nearer than this are rotat
 static void eigh_plan_default(EighPlan &p, int extra = 0) {
   p = EighPlan{};
   p.lead_band = 1;
-  p.nslots = std::min<int>(EC_MAXREC, 6 + extra);
+  p.nslots = std::min<int>(EC_MAXREC, 7 + extra);
   for (int i = 0; i < p.nslots; ++i) {
-    p.slot[i].cap = i < 3 + extra ? 12 : 4;
-    p.slot[i].nsq = i == 0 ? 2 : (i < 3 + extra ? 1 : 0);
-    p.slot[i].band_after = i < 2 + extra ? 1 : 0;
+    p.slot[i].cap = i < 5 + extra ? 12 : 4;
+    p.slot[i].nsq = i == 0 ? 2 : (i < 5 + extra ? 1 : 0);
+    p.slot[i].band_after = i < 3 + extra ? 1 : 0;   // (a masked sweep without a band pass behind it gets nowhere)
     p.slot[i].so = i >= 1 ? 1 : 0;
   }
 }
 
-// The next solve is planned like the last one went, with margins: one spare sweep, the twelfth-order launches wherever the
-// last generator was within 4x of the fourth-order limit, one more squaring where the last one was close to needing it.
+// The next solve is planned like the last one went, with margins: one spare sweep, the twelfth-order launches in every slot but
+// the last, at least one squaring launch in each of them, a band pass behind every sweep that was masked or close to it.
 static void eigh_plan_from_record(const EighRecord &r, const EighPlan &prev, EighPlan &p) {
   (void)prev;
   if (r.stall || r.nsweep <= 0) {
@@ -44,22 +44,25 @@ static void eigh_plan_from_record(const EighRecord &r, const EighPlan &prev, Eig
     const auto &s = r.sweep[i];
     const double rsu = s.masked ? s.rsf : s.rs;
     EighSlot &q = p.slot[i];
-    // (the generator's norm moves by an order of magnitude from one epoch to the next: 20x below the fourth-order limit)
-    q.cap = (s.order >= 8 || rsu > 1e-4 || s.damped) ? 12 : 4;   // (never 2 from a record: the last sweep's |X| moves over
-                                                                  // two orders of magnitude from epoch to epoch, a damped sweep is a lost one)
+    // (the generator's norm at a given position moves by orders of magnitude from one epoch to the next -- a solve that needs a
+    // sweep more, an isolated near-degenerate pair --, and a slot that cannot evaluate the order it meets is a lost (damped)
+    // sweep and, as a rule, a stalled solve: every slot but the last one gets the twelfth-order launches, the last one the
+    // two-product fourth-order form when the last generator there was 4x below its limit)
+    q.cap = (i + 1 < n || i < 2 || s.order >= 8 || rsu > 5e-4 || s.damped) ? 12 : 4;   // (never the first two: a short solve
+                                                                                        // is followed by longer ones)
     if (q.cap == 12) {
       int need = s.sq + (s.damped ? 1 : 0);
       if (rsu * std::ldexp(1.0, -s.sq) > 0.3) ++need;
-      q.nsq = std::min(2, need);
+      // (at least one: with Jacobi angles an isolated near-degenerate pair puts up to pi / 4 into a row sum from one epoch
+      // to the next -- twice the twelfth-order limit; without the squaring that sweep is a damped one and the plan runs out)
+      q.nsq = std::min(2, std::max(1, need));
     }
     // a band pass behind the sweep when it is expected to be a masked one (near the rule's thresholds counts)
     q.band_after = (s.masked || s.c > 2e-4 || s.rs > 0.3) ? 1 : 0;
     q.so = s.masked ? 0 : 1;
   }
-  // the spare: with second-order sweeps in front of it, a sweep MORE than last time starts at |X| ~ 1e-7 -- the second-order
-  // polynomial (gram, decide, one product, G R: four launches when it is not needed) is enough; should it not be, the sweep is a
-  // damped one, the solve stalls and is continued
-  p.slot[n] = EighSlot{2, 0, 0, 0};
+  // the spare (runs when the solve needs a sweep more than last time: as a rule the final one, |X| ~ 1e-7 .. 1e-4)
+  p.slot[n] = EighSlot{4, 0, 0, 1};
   // the band pass in front pays while near-degenerate neighbours are far from separated (profiles/tools/eigh_proto.py)
   p.lead_band = (r.sweep[0].masked && r.sweep[0].c > 1e-3) ? 1 : 0;
 }

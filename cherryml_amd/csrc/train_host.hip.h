@@ -134,7 +134,9 @@ static int run_fused_training_large(cb_bank *h, double *pi_param, double *up_par
     mark(h, EV_START);
     // Every solve after the first is a PLAN (eigh_planned_host.hip.h): the device takes the sweep decisions, the host enqueues
     // the whole epoch and only then looks at the solve's record -- with K1 .. K4 queued behind it, so the GPU never waits.
-    const bool use_plan = planned && h->have_prev;
+    // (the first warm solves of an optimisation start far from converged -- cosines of 1e-2, every sweep damped --: they stay
+    // with the host-driven solver, whose tournament sweeps are made for that; plans from the fourth epoch on)
+    const bool use_plan = planned && h->have_prev && e0 + e >= 3;
     rc = large_eval(h, flags & CB_NORMALIZE, h->loss, h->Mt, true, nullptr, false, use_plan ? &plan : nullptr);
     if (rc == CB_OK && use_plan) {
       EighRecord rec;

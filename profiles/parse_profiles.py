@@ -25,7 +25,7 @@ def newest(pattern):
 
 
 tag = sys.argv[1] if len(sys.argv) > 1 else "final"
-rnd = sys.argv[2] if len(sys.argv) > 2 else "r02"
+rnd = sys.argv[2] if len(sys.argv) > 2 else "r04"
 here = os.path.dirname(os.path.abspath(__file__))
 root = os.path.dirname(here)
 import datetime
@@ -35,7 +35,8 @@ out = {**STAMP, "bytes_per_launch": {}, "detail": {}, "calibration": {},
 NAMES = ["k1_pt_loss_gt", "k2_t_eq_g_u", "k3_w_phi", "lgj_round", "lg_transpose_pad", "small_train_kernel", "small_bank_kernel",
          "lg_prepare", "lg_bank", "lg_finish", "count_transitions_lds_kernel", "count_reduce_slabs", "k3_reduce", "sp_prepare",
          "sp_bank", "sp_finish", "sp_step", "sg_gemm", "co_bucket_kernel", "co_plan_kernel", "co_expand_kernel", "co_count_lds_kernel", "lgx_build", "ble_branch_lengths_kernel", "ble_site_rates_kernel",
-         "siterm_raw_counts_kernel", "siterm_mix_kernel", "tl_mfma_kernel", "tl_leaf_kernel", "tl_group_kernel", "lg_cast_f32"]
+         "siterm_raw_counts_kernel", "siterm_mix_kernel", "tl_mfma_kernel", "tl_leaf_kernel", "tl_group_kernel", "lg_cast_f32", "lge_gram", "lge_gemm", "lge_so", "lge_decide", "lge_poly",
+         "jtt_stats_partial"]
 WORKLOADS = ["coevo400", "coevo400_mixed", "coevo400_f32", "coevo400_demo", "lg20", "siterm", "counting", "co_counting", "ble", "assembly",
              "likelihood"]
 

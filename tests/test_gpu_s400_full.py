@@ -292,18 +292,59 @@ def test_planned_eigensolves_match_the_host_driven_solver_and_survive_short_plan
             r["counters"] = bank.eigh_counters()
         runs[name] = r
     a, b, c, d = runs["planned"], runs["host"], runs["short"], runs["damped"]
-    assert a["counters"]["planned_solves"] == E - 1       # every solve but the cold first one
-    assert a["counters"]["stalls"] <= 6                   # (the first warm solves of a training start far from converged)
+    assert a["counters"]["planned_solves"] == E - 3       # every solve from the fourth epoch on
+    assert a["counters"]["stalls"] <= 2
     assert b["counters"]["planned_solves"] == 0
-    assert c["counters"]["planned_solves"] == E - 1 and c["counters"]["stalls"] >= E - 1
+    assert c["counters"]["planned_solves"] == E - 3 and c["counters"]["stalls"] >= E - 3
     # (d) the one sweep of every plan can only evaluate the second-order polynomial: it applies exp(alpha X) with alpha << 1 --
     # a DAMPED, still exactly orthogonal rotation (a slot that under-provides is never wrong, only slower) -- and stalls
-    assert d["counters"]["stalls"] >= E - 1
+    assert d["counters"]["stalls"] >= E - 3
     for other in (b, c, d):
         assert np.all(np.isfinite(other["loss"]))
         assert np.allclose(a["loss"], other["loss"], rtol=1e-11, atol=0)
         for key in ("Q_last", "Q_best"):
             assert relerr(a[key], other[key]) < 1e-9, key
+
+
+@pytest.mark.parametrize("S", [64, 100, 200])
+def test_planned_eigensolves_at_other_sizes(S, monkeypatch):
+    """The device-controlled plans at other matrix sizes (LD = 64, 112, 208: 4, 7 and 13 tiles of 16; 8, 14 and 26 column
+    blocks, the smallest size that takes the plans at all): a random reversible model's expected counts, 20 epochs planned
+    and with the host-driven solver -- same loss curve (1e-11), same matrices (1e-9); and against the float64 oracle
+    (torch.matrix_exp + autograd + Adam) over the first 6 epochs."""
+    from cherryml_amd import CherryBank
+    from oracle import ratelearn_oracle as orc
+    rng = np.random.default_rng(S)
+    B = 9
+    t = np.geomspace(0.02, 2.0, B)
+    R = rng.gamma(2.0, 0.5, size=(S, S))
+    R = 0.5 * (R + R.T)
+    pi = rng.dirichlet(np.full(S, 5.0))
+    Q = R * pi[None, :]
+    np.fill_diagonal(Q, 0.0)
+    np.fill_diagonal(Q, -Q.sum(1))
+    Q /= -(pi * np.diag(Q)).sum()
+    w, V = np.linalg.eigh(np.sqrt(pi)[:, None] * Q / np.sqrt(pi)[None, :])
+    C = np.stack([pi[:, None] * ((V * np.exp(tb * w)) @ V.T) * np.sqrt(pi)[None, :] / np.sqrt(pi)[:, None] for tb in t]) * 1e5
+    C = 0.5 * (C + C.transpose(0, 2, 1))
+    mask = np.ones((S, S))
+    u0 = rng.normal(0.0, 0.3, S * (S - 1) // 2)
+    p0 = rng.normal(0.0, 0.2, S)
+    runs = {}
+    for name, env in (("planned", None), ("host", "1")):
+        if env is None:
+            monkeypatch.delenv("CB_EIGH_HOST", raising=False)
+        else:
+            monkeypatch.setenv("CB_EIGH_HOST", env)
+        with CherryBank(t, C) as bank:
+            runs[name] = bank.train_pande_reversible(u0, p0, mask=mask, num_epochs=20, lr=0.1)
+            runs[name]["counters"] = bank.eigh_counters()
+    a, b = runs["planned"], runs["host"]
+    assert a["counters"]["planned_solves"] == 17 and b["counters"]["planned_solves"] == 0
+    assert np.all(np.isfinite(a["loss"])) and np.allclose(a["loss"], b["loss"], rtol=1e-11, atol=0)
+    assert relerr(a["Q_last"], b["Q_last"]) < 1e-9 and relerr(a["Q_best"], b["Q_best"]) < 1e-9
+    o = orc.train(t, C, mask=mask, upper_diag=u0, log_pi=p0, num_epochs=6, lr=0.1)
+    assert np.allclose(a["loss"][:6], o["loss"], rtol=1e-10, atol=0)
 
 
 def test_two_queue_bank_option_gives_the_same_bits(dense, tmp_path):
