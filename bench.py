@@ -518,38 +518,67 @@ def main():
             # dominant MFMA kernels: K1/K2/K3 are one batched 2 S^3 B GEMM each
             flops = 2.0 * S ** 3 * B_local
             names = {"k1": "k1_pt_loss_gt", "k2": "k2_t_eq_g_u", "k3": "k3_w_phi"}
-            dom = max(names, key=lambda k: tm[k])
-            achieved = flops / (tm[dom] * 1e-3) / 1e12 if tm[dom] > 0 else 0.0
             tn_ = -(-S // 80)
             tri = (tn_ * (tn_ + 1) / 2) / float(tn_ * tn_)   # share of 80x80 tiles actually multiplied
             # whole epoch: SURVEY 8d's algorithmic flops of one epoch (6 B S^3 bank + ~13 S^3 eigensolver
             # and back-rotation; 49.6 GFLOP at S = 400, B = 129) over the WALL time of one step
             epoch_flops = 6.0 * wl.get("live", wl["C"].shape[0]) * S ** 3 + 13.0 * S ** 3
             epoch_tflops = epoch_flops / (dt / steps) / 1e12
-            # (mixed: the dominant kernel is then K1 in float64; K2 / K3 run on the f32 MFMA)
-            dom_f32 = bank_dtype == "f32" or (bank_dtype == "mixed" and dom != "k1")
-            peak = F32_PEAK_TFLOPS if dom_f32 else F64_PEAK_TFLOPS
-            peak_of = lambda k: (F32_PEAK_TFLOPS if (bank_dtype == "f32" or (bank_dtype == "mixed" and k != "k1"))  # noqa: E731
-                                 else F64_PEAK_TFLOPS)
             util, util_src = _mfma_util(bank_dtype)
-            roofline = dict(bound="mfma", kernel=names[dom] + ("<float>" if dom_f32 else "<double>"),
-                            achieved=achieved, peak=peak, unit="TFLOP/s", frac=achieved / peak,
-                            epoch_frac=epoch_tflops / (peak * world), epoch_tflops=epoch_tflops,
-                            epoch_flops=epoch_flops,
-                            traffic=traffic.get(names[dom] + ("_f32" if dom_f32 else "_mixed" if bank_dtype == "mixed" else ""))
-                            if world == 1 else None,
-                            traffic_source=_traffic_source() if world == 1 else None,
-                            ms_per_launch=tm[dom], flops_per_launch=flops,
-                            note="achieved = algorithmic 2 S^3 B flops (SURVEY 8d) / launch time; k1 (Pt symmetric) "
-                                 f"and k3 (symmetric counts) multiply only the upper-triangular tiles, {tri:.2f} of "
-                                 "those flops; k2 multiplies all of them",
-                            per_kernel_tflops={k: round(flops / (tm[k] * 1e-3) / 1e12, 2) for k in names if tm[k] > 0},
-                            # what the matrix pipe really executes: k1 / k3 run `tri` of the algorithmic flops
-                            per_kernel_executed_tflops={k: round((flops if k == "k2" else flops * tri) / (tm[k] * 1e-3) / 1e12, 2)
-                                                        for k in names if tm[k] > 0},
-                            per_kernel_executed_frac={k: round((flops if k == "k2" else flops * tri) / (tm[k] * 1e-3) / 1e12 / peak_of(k), 3)
-                                                      for k in names if tm[k] > 0},
-                            per_kernel_mfma_util=util, mfma_util_source=util_src)
+            fused = tm["k1"] > 0 and tm["k2"] == 0 and tm["k3"] == 0   # CB_T_K1 = the one span of the fused launch
+            if fused:
+                # K1 -> K2 -> K3 as ONE persistent launch (k123_bank): algorithmic flops = the three products, 6 B S^3
+                # (SURVEY 8d); executed = (tri + 1 + tri) of 2 B S^3: Pt and, with symmetric counts, W are symmetric
+                sym3 = tri   # (bench banks have symmetric counts; an asymmetric bank runs all K3 tiles)
+                executed = flops * (tri + 1.0 + sym3)
+                achieved = 3.0 * flops / (tm["k1"] * 1e-3) / 1e12
+                peak = F32_PEAK_TFLOPS if bank_dtype == "f32" else F64_PEAK_TFLOPS
+                kname = {"f64": "k123_bank<double, double>", "f32": "k123_bank<float, float>",
+                         "mixed": "k123_bank<double, float>"}[bank_dtype]
+                # mixed: K1 on the f64 pipe, K2 / K3 on the f32 pipe (twice the rate): time-weighted peak of the launch
+                if bank_dtype == "mixed":
+                    t64, t32 = tri / F64_PEAK_TFLOPS, (1.0 + sym3) / F32_PEAK_TFLOPS
+                    peak = (tri + 1.0 + sym3) / (t64 + t32)
+                exec_tflops = executed / (tm["k1"] * 1e-3) / 1e12
+                roofline = dict(bound="mfma", kernel=kname, achieved=achieved, peak=peak, unit="TFLOP/s", frac=achieved / peak,
+                                executed_tflops=exec_tflops, executed_frac=exec_tflops / peak,
+                                epoch_frac=epoch_tflops / (peak * world), epoch_tflops=epoch_tflops, epoch_flops=epoch_flops,
+                                traffic=traffic.get("k123_bank" + ("_f32" if bank_dtype == "f32" else "_mixed" if bank_dtype == "mixed" else ""))
+                                if world == 1 else None,
+                                traffic_source=_traffic_source() if world == 1 else None,
+                                ms_per_launch=tm["k1"], flops_per_launch=3.0 * flops, executed_flops_per_launch=executed,
+                                note="ONE persistent launch for the three bank products (tickets per XCD, large_bank.hip.h); "
+                                     "ms_per_launch = HIP events from the end of the eigensolver to the end of the launch "
+                                     "(includes lg_tables, ~4 us).  achieved = algorithmic 6 S^3 B flops (SURVEY 8d) / launch "
+                                     f"time; executed = what the matrix pipe multiplies: {tri:.2f} of K1's and K3's tiles "
+                                     "(Pt and W symmetric) + all of K2's; executed_frac is the pipe's own utilisation",
+                                mfma_util=util.get("k123"), mfma_util_source=util_src)
+            else:
+                dom = max(names, key=lambda k: tm[k])
+                achieved = flops / (tm[dom] * 1e-3) / 1e12 if tm[dom] > 0 else 0.0
+                # (mixed: the dominant kernel is then K1 in float64; K2 / K3 run on the f32 MFMA)
+                dom_f32 = bank_dtype == "f32" or (bank_dtype == "mixed" and dom != "k1")
+                peak = F32_PEAK_TFLOPS if dom_f32 else F64_PEAK_TFLOPS
+                peak_of = lambda k: (F32_PEAK_TFLOPS if (bank_dtype == "f32" or (bank_dtype == "mixed" and k != "k1"))  # noqa: E731
+                                     else F64_PEAK_TFLOPS)
+                roofline = dict(bound="mfma", kernel=names[dom] + ("<float>" if dom_f32 else "<double>"),
+                                achieved=achieved, peak=peak, unit="TFLOP/s", frac=achieved / peak,
+                                epoch_frac=epoch_tflops / (peak * world), epoch_tflops=epoch_tflops,
+                                epoch_flops=epoch_flops,
+                                traffic=traffic.get(names[dom] + ("_f32" if dom_f32 else "_mixed" if bank_dtype == "mixed" else ""))
+                                if world == 1 else None,
+                                traffic_source=_traffic_source() if world == 1 else None,
+                                ms_per_launch=tm[dom], flops_per_launch=flops,
+                                note="achieved = algorithmic 2 S^3 B flops (SURVEY 8d) / launch time; k1 (Pt symmetric) "
+                                     f"and k3 (symmetric counts) multiply only the upper-triangular tiles, {tri:.2f} of "
+                                     "those flops; k2 multiplies all of them",
+                                per_kernel_tflops={k: round(flops / (tm[k] * 1e-3) / 1e12, 2) for k in names if tm[k] > 0},
+                                # what the matrix pipe really executes: k1 / k3 run `tri` of the algorithmic flops
+                                per_kernel_executed_tflops={k: round((flops if k == "k2" else flops * tri) / (tm[k] * 1e-3) / 1e12, 2)
+                                                            for k in names if tm[k] > 0},
+                                per_kernel_executed_frac={k: round((flops if k == "k2" else flops * tri) / (tm[k] * 1e-3) / 1e12 / peak_of(k), 3)
+                                                          for k in names if tm[k] > 0},
+                                per_kernel_mfma_util=util, mfma_util_source=util_src)
         else:
             Lb = wl["C"].shape[0] if wl["kind"] == "sites" else 1
             nbytes = float(Lb) * B_local * S * S * 8  # C streamed once per epoch

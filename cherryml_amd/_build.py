@@ -6,8 +6,10 @@ import subprocess
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG_DIR, "csrc")
 # one translation unit per subsystem (kernels live in the *.hip.h headers each of them includes)
-SRCS = [os.path.join(CSRC, f) for f in ("cherrybank.hip", "cb_counting.hip", "cb_ble.hip", "cb_likelihood.hip",
-                                        "cb_host_io.hip")]
+SRCS = [os.path.join(CSRC, f) for f in ("cherrybank.hip", "cb_bank_fused.hip", "cb_counting.hip", "cb_ble.hip",
+                                        "cb_likelihood.hip", "cb_host_io.hip")]
+# per-file flags (cb_bank_fused.hip says why)
+FILE_FLAGS = {"cb_bank_fused.hip": ["-mllvm", "-disable-machine-licm"]}
 LIB = os.path.join(PKG_DIR, "libcherrybank.so")
 
 
@@ -59,7 +61,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
     procs = []
     for src in SRCS:
         obj = os.path.join(objdir, os.path.basename(src) + ".o")
-        cmd = [hipcc] + flags + ["-c", src, "-o", obj]
+        cmd = [hipcc] + flags + FILE_FLAGS.get(os.path.basename(src), []) + ["-c", src, "-o", obj]
         if verbose:
             print(" ".join(cmd))
         procs.append((obj, cmd, subprocess.Popen(cmd)))

@@ -149,6 +149,8 @@ static int launch_small(cb_bank *h, const SmallArgs &a) {
 // `dA_padded` is false, else dL/dA itself as a padded LD x LD matrix.
 // `plan`: a warm solve enqueued as a device-controlled plan (eigh_planned_host.hip.h) instead of the host-driven loop; the
 // caller reads the record of solve `h->eseq` afterwards and repeats the evaluation without a plan if the solve stalled.
+int cb_launch_bank_fused(int variant, const void *args, int grid, hipStream_t stream);   // cb_bank_fused.hip
+
 static int large_eval(cb_bank *h, bool normalize, double *lossd, double *out, bool dA_padded, double *Pd,
                       bool reuse_eigh = false, const EighPlan *plan = nullptr, int plan_first_slot = 0) {
   const int S = h->S, LD = h->LD;
@@ -164,23 +166,96 @@ static int large_eval(cb_bank *h, bool normalize, double *lossd, double *out, bo
   else if (!(reuse_eigh && h->have_prev)) rc = large_eigh(h, true);   // reuse: same matrix as the previous call (CB_REUSE_EIGH)
   if (rc != CB_OK) return rc;
   mark(h, EV_EIGH);
-  hipLaunchKernelGGL(lg_tables, dim3((unsigned)(((size_t)B * LD + 255) / 256)), dim3(256), 0,
-                     h->stream, LD, B, tb, h->lam, h->sigma, h->F, h->E, h->H);
   const int tm = (LD + LG_TM - 1) / LG_TM, tn = (LD + LG_TN - 1) / LG_TN, tiles = tm * tn;
   const double inv_n = normalize ? 1.0 / (h->comm ? h->n_global[0] : h->n_host[0]) : 1.0;
   const int tiles_k1 = tn * (tn + 1) / 2;  // Pt is symmetric: upper-triangular tiles only
   const int tiles_k3 = h->sym_counts ? tiles_k1 : tiles;
+  static const int n_parts = getenv("CB_BANK_STREAMS") ? std::min(4, std::max(1, atoi(getenv("CB_BANK_STREAMS")))) : 1;
+  // K1 -> K2 -> K3 as ONE persistent launch (k123_bank, large_bank.hip.h) whenever the gradient is wanted; CB_BANK_UNFUSED=1
+  // keeps the three launches (per-kernel profiles, and the reference point of tests/test_gpu_s400_full.py)
+  const bool unfused_env = getenv("CB_BANK_UNFUSED") != nullptr;   // (read per call: the tests switch it inside one process)
+  const bool fused = !Pd && dQd && !unfused_env && n_parts == 1;
+  if (fused && !h->bank_queue) {
+    ALLOC(h->bank_queue, (size_t)LG_NQ + 2 * (size_t)h->B);
+    ALLOC(h->bank_args, sizeof(K123Args<double, double>));   // (the three instantiations have one layout)
+    int dev = 0, cus = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    h->bank_slots = 4 * std::max(cus, 1);
+  }
+  h->bank_fused = fused;
+  const dim3 tables_grid((unsigned)(((size_t)B * LD + 255) / 256));
+  if (!fused)
+    hipLaunchKernelGGL(lg_tables<NoBankArgs>, tables_grid, dim3(256), 0, h->stream, LD, B, tb, h->lam, h->sigma, h->F, h->E, h->H,
+                       NoBankArgs{}, (NoBankArgs *)nullptr, 0);
   // float32 bank (cb_create(dtype = CB_F32)): the loss / gradient products run on the f32 MFMA from f32
   // copies of this epoch's U, U^T, A and F; cb_expm_bank (Pd) always takes the float64 kernels
   // CB_MIXED: P_b, the loss and G_b in float64 (the O(t^2) entries of P_b keep their relative accuracy),
   // G_b rounded to float32 once, the two contractions on the float32 MFMA
   const bool f32 = h->dtype == CB_F32 && !Pd, mixed = h->dtype == CB_MIXED && !Pd;
-  static const int n_parts = getenv("CB_BANK_STREAMS") ? std::min(4, std::max(1, atoi(getenv("CB_BANK_STREAMS")))) : 1;
-  if (f32 || mixed)
+  if ((f32 || mixed) && !fused)
     hipLaunchKernelGGL(lg_cast_f32, dim3((unsigned)((std::max(LL, (size_t)B * LD) + 255) / 256)), dim3(256), 0, h->stream, LL,
                        (size_t)B * LD, h->U, h->Vc, h->A, h->F, h->Uf, h->Utf, h->Af, h->Ff);
   // (no event between the spectral tables and K1: a hipEventRecord costs ~6 us of idle GPU between two kernels; CB_T_K1
   // is the span from the end of the eigensolver to the end of K1 = lg_tables (4 us) [+ the float32 casts] + K1)
+  if (fused) {
+    // lg_tables (+ the argument block and the zeroed queues), then one launch of 4 workgroups per CU (fewer when the bank is
+    // small); the loss partials are summed after it
+    const int total = B * (tiles_k1 + tiles + tiles_k3), grid = std::min(h->bank_slots, total);
+    const int sym = h->sym_counts ? 1 : 0;
+    auto launch = [&](auto args) {
+      typedef decltype(args) A;
+      A *dst = reinterpret_cast<A *>(h->bank_args);
+      hipLaunchKernelGGL(lg_tables<A>, tables_grid, dim3(256), 0, h->stream, LD, B, tb, h->lam, h->sigma, h->F, h->E, h->H, args, dst, grid);
+      return dst;
+    };
+    static_assert(sizeof(K123Args<float, float>) == sizeof(K123Args<double, double>) &&
+                  sizeof(K123Args<double, float>) == sizeof(K123Args<double, double>), "one argument block for all");
+    if (f32) {
+      // (the float32 casts read F: the tables first, then the casts, then the bank -- as in the separate launches)
+      K123Args<float, float> a{{S, LD, B, h->Utf, h->Af, tb, h->Ff, h->sigma, h->Ct32, h->Gt32, h->loss_part, inv_n, h->dsq, nullptr, skipw},
+                               {LD, h->Gt32, h->Uf, h->T32, skipw},
+                               {LD, B, h->T32, h->Uf, tb, h->lam, h->E, h->H, h->Gt32, sym, skipw},
+                               {h->bank_queue, B, tiles_k1, tiles, tiles_k3}};
+      auto *dst = launch(a);
+      hipLaunchKernelGGL(lg_cast_f32, dim3((unsigned)((std::max(LL, (size_t)B * LD) + 255) / 256)), dim3(256), 0, h->stream, LL,
+                         (size_t)B * LD, h->U, h->Vc, h->A, h->F, h->Uf, h->Utf, h->Af, h->Ff);
+      if (cb_launch_bank_fused(1, dst, grid, h->stream) != 0) return fail(CB_EHIP, "k123_bank: launch failed");
+    } else if (mixed) {
+      K123Args<double, float> a{{S, LD, B, h->Vc, h->A, tb, h->F, h->sigma, h->Ct, h->Gt32, h->loss_part, inv_n, h->dsq, nullptr, skipw},
+                                {LD, h->Gt32, h->Uf, h->T32, skipw},
+                                {LD, B, h->T32, h->Uf, tb, h->lam, h->E, h->H, h->Gt32, sym, skipw},
+                                {h->bank_queue, B, tiles_k1, tiles, tiles_k3}};
+      auto *dst = launch(a);
+      hipLaunchKernelGGL(lg_cast_f32, dim3((unsigned)((std::max(LL, (size_t)B * LD) + 255) / 256)), dim3(256), 0, h->stream, LL,
+                         (size_t)B * LD, h->U, h->Vc, h->A, h->F, h->Uf, h->Utf, h->Af, h->Ff);
+      if (cb_launch_bank_fused(2, dst, grid, h->stream) != 0) return fail(CB_EHIP, "k123_bank: launch failed");
+    } else {
+      K123Args<double, double> a{{S, LD, B, h->Vc, h->A, tb, h->F, h->sigma, h->Ct, h->Gt, h->loss_part, inv_n, h->dsq, nullptr, skipw},
+                                 {LD, h->Gt, h->U, h->T, skipw},
+                                 {LD, B, h->T, h->U, tb, h->lam, h->E, h->H, h->Gt, sym, skipw},
+                                 {h->bank_queue, B, tiles_k1, tiles, tiles_k3}};
+      auto *dst = launch(a);
+      if (cb_launch_bank_fused(0, dst, grid, h->stream) != 0) return fail(CB_EHIP, "k123_bank: launch failed");
+    }
+    if (h->profile) h->ev_rec[EV_K1] = h->ev_rec[EV_K2] = false;   // CB_T_K1 = the whole launch (+ tables), see read_phase_times
+    mark(h, EV_K3);
+    hipLaunchKernelGGL(lg_finish_loss, dim3(1), dim3(256), 0, h->stream, h->loss_part, B * tiles_k1, S,
+                       h->dsq, h->dirsum, inv_n, lossd);
+    if (f32 || mixed)
+      hipLaunchKernelGGL(k3_reduce<float>, dim3((unsigned)((LL + 255) / 256)), dim3(256), 0, h->stream,
+                         h->Gt32, B, LL, h->Mt, h->sym_counts ? LD : 0);
+    else
+      hipLaunchKernelGGL(k3_reduce<double>, dim3((unsigned)((LL + 255) / 256)), dim3(256), 0, h->stream,
+                         h->Gt, B, LL, h->Mt, h->sym_counts ? LD : 0);
+    K4Args k4a{S, LD, h->Mt, h->Vc, h->X, nullptr, nullptr, nullptr};
+    launch_sg(h, k4a, 0);
+    K4Args k4b{S, LD, h->Vc, h->X, dQd, dA_padded ? nullptr : h->dsq, nullptr, nullptr};
+    launch_sg(h, k4b, 0);
+    mark(h, EV_K4);
+    HIP_TRY(hipGetLastError());
+    return CB_OK;
+  }
   if (f32) {
     K1Args<float> k1{S, LD, B, h->Utf, h->Af, tb, h->Ff, h->sigma, h->Ct32, h->Gt32, h->loss_part, inv_n, h->dsq, nullptr};
     hipLaunchKernelGGL(k1_pt_loss_gt<float>, dim3(tiles_k1 * B), dim3(LG4_THREADS), 0, h->stream, k1);
@@ -537,6 +612,13 @@ extern "C" int cb_timing_sums(cb_handle h, double *ms_sum, int n, int *calls) {
 }
 
 extern "C" int cb_last_sweeps(cb_handle h) { return h ? h->last_sweeps : 0; }
+#ifdef CB_CLOCK_STAMP
+// diagnostic build only (large_bank.hip.h): out[3][4096][6]: the last launch's stamps per workgroup of K1..K3
+extern "C" int cb_debug_clock_stamps(unsigned long long *out) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(cb_clock_stamps), sizeof(unsigned long long) * 3 * 4096 * 6) == hipSuccess ? 0 : -1;
+}
+#endif
+
 extern "C" int cb_eigh_counters(cb_handle h, int *counts, int n) {
   if (!h || !counts || n < 0) return fail(CB_EINVAL, "cb_eigh_counters: NULL argument");
   const int v[3] = {h->planned_solves, h->planned_stalls, h->last_sweeps};
@@ -573,9 +655,13 @@ static int read_phase_times(cb_bank *h, double (&v)[CB_T_COUNT]) {
   };
   if (h->large) {
     v[CB_T_EIGH] = span(EV_START, EV_EIGH);
-    v[CB_T_K1] = span(EV_EIGH, EV_K1);
-    v[CB_T_K2] = span(EV_K1, EV_K2);
-    v[CB_T_K3] = span(EV_K2, EV_K3);
+    if (h->ev_rec[EV_K3] && !h->ev_rec[EV_K1] && !h->ev_rec[EV_K2]) {
+      v[CB_T_K1] = span(EV_EIGH, EV_K3);   // fused bank launch (k123_bank): K1 + K2 + K3 (+ the spectral tables) in one span
+    } else {
+      v[CB_T_K1] = span(EV_EIGH, EV_K1);
+      v[CB_T_K2] = span(EV_K1, EV_K2);
+      v[CB_T_K3] = span(EV_K2, EV_K3);
+    }
     v[CB_T_K4] = span(EV_K3, EV_K4);
     v[CB_T_ALLREDUCE] = span(EV_K4, EV_AR);
     v[CB_T_TOTAL] = span(EV_START, h->ev_rec[EV_K4] ? EV_K4 : EV_K1);

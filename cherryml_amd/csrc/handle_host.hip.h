@@ -76,6 +76,10 @@ struct cb_bank {
   EighPlan eplan;            // the next solve's plan: part of the optimisation's state (a resumed call continues with it,
                              // so W + K epochs in two calls equal one call bit for bit)
   int k3_chunk = 0, k3_nchunks = 0;
+  unsigned int *bank_queue = nullptr;   // fused bank kernel (k123_bank): ticket queues + tile counters, 8 + 2 B words
+  unsigned char *bank_args = nullptr;   // ... and its argument block (written by lg_tables in front of every launch)
+  int bank_slots = 0;                   // its grid: resident workgroups of the device (4 per CU)
+  bool bank_fused = false;              // the last evaluation ran K1 -> K2 -> K3 as one launch
   int last_sweeps = 0;
   double *gn_scratch = nullptr, *gn_partial = nullptr;  // general path, allocated on first use
   int gn_nw = 0;

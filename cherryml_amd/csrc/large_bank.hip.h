@@ -85,10 +85,10 @@ template <typename T> struct Panel {
 template <typename T, bool SCALE>
 __device__ __forceinline__ void lg4_load_panel(const T *__restrict__ P, int ld, int rows_total, int cols_total,
                                                int k0, int c0, typename Mfma<T>::vec_t (&reg)[Panel<T>::NL],
-                                               const T *__restrict__ kscale, T &sc) {
+                                               const T *__restrict__ kscale, T &sc, int tid) {
   typedef typename Mfma<T>::vec_t vec_t;
   constexpr int VEC = Panel<T>::VEC, NL = Panel<T>::NL, LAST = Panel<T>::LAST;
-  const int kr = threadIdx.x >> 4, cq = threadIdx.x & 15;
+  const int kr = tid >> 4, cq = tid & 15;
   const int k = k0 + kr;
   const T *row = P + (size_t)k * ld + c0 + VEC * cq;
 #pragma unroll
@@ -102,10 +102,10 @@ __device__ __forceinline__ void lg4_load_panel(const T *__restrict__ P, int ld, 
   if (SCALE) sc = k < rows_total ? kscale[k] : T(0);
 }
 template <typename T, bool SCALE>
-__device__ __forceinline__ void lg4_store_panel(T *s, const typename Mfma<T>::vec_t (&reg)[Panel<T>::NL], T sc) {
+__device__ __forceinline__ void lg4_store_panel(T *s, const typename Mfma<T>::vec_t (&reg)[Panel<T>::NL], T sc, int tid) {
   typedef typename Mfma<T>::vec_t vec_t;
   constexpr int VEC = Panel<T>::VEC, NL = Panel<T>::NL, LAST = Panel<T>::LAST;
-  const int kr = threadIdx.x >> 4, cq = threadIdx.x & 15;
+  const int kr = tid >> 4, cq = tid & 15;
   T *row = s + kr * LG_TM + VEC * cq;
 #pragma unroll
   for (int u = 0; u < NL; ++u) {
@@ -123,10 +123,14 @@ __device__ __forceinline__ void lg4_store_panel(T *s, const typename Mfma<T>::ve
 template <typename T, bool SCALE, bool ZERO = true>
 __device__ __forceinline__ void lg4_gemm_tile(const GemmOperands<T> &g, int m0, int n0, T *sA, T *sB,
                                               typename Mfma<T>::acc_t (&acc)[5], typename Mfma<T>::acc_t &ax0,
-                                              typename Mfma<T>::acc_t &ax1) {
+                                              typename Mfma<T>::acc_t &ax1, int tid = threadIdx.x,
+                                              unsigned int *deferred = nullptr) {
+  // (tid: threadIdx.x -- or an opaque copy of it, k123_bank: what is derived from it then stays inside the tile)
+  // deferred (k123_bank): the counter that announces the PREVIOUS tile of this workgroup; bumped here, behind the wait for
+  // this tile's first panels, where the wait for the previous tile's stores costs nothing
   typedef typename Mfma<T>::acc_t acc_t;
   typedef typename Mfma<T>::vec_t vec_t;
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, lo = lane & 15, hi = lane >> 4;
+  const int wave = tid >> 6, lane = tid & 63, lo = lane & 15, hi = lane >> 4;
   if (ZERO) {
 #pragma unroll
     for (int j = 0; j < 5; ++j) acc[j] = acc_t{};
@@ -136,17 +140,19 @@ __device__ __forceinline__ void lg4_gemm_tile(const GemmOperands<T> &g, int m0, 
   vec_t ra[Panel<T>::NL], rb[Panel<T>::NL];
   T sc = T(1), one = T(1);
   const int nk = g.K / LG_KT;
-  lg4_load_panel<T, SCALE>(g.A, g.lda, g.K, g.M, 0, m0, ra, g.kscale, sc);
-  lg4_load_panel<T, false>(g.B, g.ldb, g.K, g.N, 0, n0, rb, nullptr, one);
+  lg4_load_panel<T, SCALE>(g.A, g.lda, g.K, g.M, 0, m0, ra, g.kscale, sc, tid);
+  lg4_load_panel<T, false>(g.B, g.ldb, g.K, g.N, 0, n0, rb, nullptr, one, tid);
   __syncthreads();  // the previous tile's readers of buffer 0 are done
-  lg4_store_panel<T, SCALE>(sA, ra, sc);
-  lg4_store_panel<T, false>(sB, rb, one);
+  lg4_store_panel<T, SCALE>(sA, ra, sc, tid);
+  lg4_store_panel<T, false>(sB, rb, one, tid);
+  if (deferred) __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): this wave's stores of the previous tile have been performed
   __syncthreads();
+  if (deferred && tid == 0) __hip_atomic_fetch_add(deferred, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   for (int kt = 0; kt < nk; ++kt) {
     const T *cA = sA + (kt & 1) * (LG_KT * LG_TM), *cB = sB + (kt & 1) * (LG_KT * LG_TN);
     if (kt + 1 < nk) {
-      lg4_load_panel<T, SCALE>(g.A, g.lda, g.K, g.M, (kt + 1) * LG_KT, m0, ra, g.kscale, sc);
-      lg4_load_panel<T, false>(g.B, g.ldb, g.K, g.N, (kt + 1) * LG_KT, n0, rb, nullptr, one);
+      lg4_load_panel<T, SCALE>(g.A, g.lda, g.K, g.M, (kt + 1) * LG_KT, m0, ra, g.kscale, sc, tid);
+      lg4_load_panel<T, false>(g.B, g.ldb, g.K, g.N, (kt + 1) * LG_KT, n0, rb, nullptr, one, tid);
     }
 #pragma unroll
     for (int s = 0; s < LG_KT / 4; ++s) {
@@ -165,8 +171,8 @@ __device__ __forceinline__ void lg4_gemm_tile(const GemmOperands<T> &g, int m0, 
       if ((kt & 3) == wave) ax1 = Mfma<T>::mma(a4, bv[4], ax1);
     }
     if (kt + 1 < nk) {
-      lg4_store_panel<T, SCALE>(sA + ((kt + 1) & 1) * (LG_KT * LG_TM), ra, sc);
-      lg4_store_panel<T, false>(sB + ((kt + 1) & 1) * (LG_KT * LG_TN), rb, one);
+      lg4_store_panel<T, SCALE>(sA + ((kt + 1) & 1) * (LG_KT * LG_TM), ra, sc, tid);
+      lg4_store_panel<T, false>(sB + ((kt + 1) & 1) * (LG_KT * LG_TN), rb, one, tid);
     }
     __syncthreads();
   }
@@ -184,12 +190,44 @@ __device__ __forceinline__ void lg4_gemm_tile(const GemmOperands<T> &g, int m0, 
   __syncthreads();   // sA is free again (callers reuse it)
 }
 
+// Diagnostic build only (-DCB_CLOCK_STAMP, profiles/tools/clock_probe.py): the clock the chip holds inside the K loops of
+// K1..K3 = delta s_memtime / delta s_memrealtime * 100 MHz per workgroup (guide, 'DVFS give-back' item 6).  The stamps go to a
+// buffer of their own that no kernel reads; the shipped library has none of this.
+#ifdef CB_CLOCK_STAMP
+// per tile (index = bucket * tiles of the stage + tile): [0] cycles of the K loop, [1] 100 MHz ticks of the K loop, [2] tick
+// at the start of the tile, [3] tick at the end of the K loop, [4] tick at the end of the tile, [5] HW_ID | XCC_ID << 32
+__device__ unsigned long long cb_clock_stamps[3][4096][6];
+#define CB_STAMP_BEGIN(id)                                                                         \
+  const int cs_id = (id);                                                                          \
+  const unsigned long long cs_c0 = __builtin_amdgcn_s_memtime(), cs_r0 = __builtin_amdgcn_s_memrealtime()
+#define CB_STAMP_END(kid)                                                                          \
+  do {                                                                                             \
+    const unsigned long long cs_c1 = __builtin_amdgcn_s_memtime(), cs_r1 = __builtin_amdgcn_s_memrealtime(); \
+    if (threadIdx.x == 0 && cs_id < 4096) {                                                        \
+      cb_clock_stamps[kid][cs_id][0] = cs_c1 - cs_c0;                                              \
+      cb_clock_stamps[kid][cs_id][1] = cs_r1 - cs_r0;                                              \
+      cb_clock_stamps[kid][cs_id][2] = cs_r0;                                                      \
+      cb_clock_stamps[kid][cs_id][3] = cs_r1;                                                      \
+      cb_clock_stamps[kid][cs_id][5] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) |               \
+                                       (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32;         \
+    }                                                                                              \
+  } while (0)
+#define CB_STAMP_FINISH(kid)                                                                       \
+  do {                                                                                             \
+    if (threadIdx.x == 0 && cs_id < 4096) cb_clock_stamps[kid][cs_id][4] = __builtin_amdgcn_s_memrealtime(); \
+  } while (0)
+#else
+#define CB_STAMP_BEGIN(id) do { } while (0)
+#define CB_STAMP_END(kid) do { } while (0)
+#define CB_STAMP_FINISH(kid) do { } while (0)
+#endif
+
 // f(row, col, value) for every element of the tile this lane owns
 template <typename T, typename F>
 __device__ __forceinline__ void lg_for_each(int m0, int n0, const typename Mfma<T>::acc_t (&acc)[5],
                                             const typename Mfma<T>::acc_t &ax0, const typename Mfma<T>::acc_t &ax1,
-                                            F &&f) {
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, lo = lane & 15, hi = lane >> 4;
+                                            F &&f, int tid = threadIdx.x) {
+  const int wave = tid >> 6, lane = tid & 63, lo = lane & 15, hi = lane >> 4;
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int rr = Mfma<T>::row(hi, r);
@@ -236,27 +274,37 @@ struct K1Args {
 // Pt_b is symmetric: only the tilesN (tilesN + 1) / 2 tiles with tm <= tn run the main loop; an
 // off-diagonal tile serves both (row, col) and (col, row) in its epilogue (same Pt value, its own
 // count and its own Gt^T entry).  40 % fewer MFMAs than the full grid at LD = 400.
-template <typename T, typename TG = T, bool EXPM = false>   // EXPM: write P_b (cb_expm_bank) instead of loss / Gt
-__global__ __launch_bounds__(LG4_THREADS, 4) void k1_pt_loss_gt(K1Args<T, TG> a) {  // four workgroups per CU
-  if (a.skip && *a.skip != 0ull) return;
-  __shared__ T sAB[4 * LG_KT * LG_TM];   // A panels | B panels (two K-steps each); after the K loop: the transposition buffer
+// WT (the fused bank kernel k123_bank below): the outputs another workgroup of the SAME launch reads are written through to
+// memory (agent-scope stores), see there.
+template <bool WT, typename T>
+__device__ __forceinline__ void bank_store(T *p, T v) {
+  if (WT) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  else *p = v;
+}
+
+// one (bucket b, upper-triangular tile `tile`) of K1; sAB: 4 * LG_KT * LG_TM elements of LDS (A panels | B panels, two K-steps
+// each; after the K loop: the transposition buffer); vid = b * tiles + tile indexes the loss partial
+template <typename T, typename TG, bool EXPM, bool WT>
+__device__ __forceinline__ void k1_tile(const K1Args<T, TG> &a, int b, int tile, T *sAB, int tid,
+                                        unsigned int *deferred = nullptr) {
   T *sA = sAB, *sB = sAB + 2 * LG_KT * LG_TM;
   typedef typename Mfma<T>::acc_t acc_t;
   const int tilesN = (a.LD + LG_TN - 1) / LG_TN, tiles = tilesN * (tilesN + 1) / 2;
-  const int vid = xcd_swizzle(blockIdx.x, gridDim.x);
-  const int b = vid / tiles;
-  int tile = vid - b * tiles, tm = 0;
+  const int vid = b * tiles + tile;
+  int tm = 0;
   while (tile >= tilesN - tm) {  // row tm of the upper triangle holds tilesN - tm tiles
     tile -= tilesN - tm;
     ++tm;
   }
   const int tn = tm + tile;
   const int m0 = tm * LG_TM, n0 = tn * LG_TN;
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int wave = tid >> 6, lane = tid & 63;
   const size_t boff = (size_t)b * a.LD * a.LD;
   GemmOperands<T> g{a.Ut, a.Ut, a.LD, a.LD, a.LD, a.LD, a.LD, a.F + (size_t)b * a.LD};
   acc_t acc[5], ax0, ax1;
-  lg4_gemm_tile<T, true>(g, m0, n0, sA, sB, acc, ax0, ax1);
+  CB_STAMP_BEGIN(vid);
+  lg4_gemm_tile<T, true>(g, m0, n0, sA, sB, acc, ax0, ax1, tid, deferred);
+  CB_STAMP_END(0);
 
   const double tb = a.t[b];
   const T tbT = (T)tb, inv_nT = (T)a.inv_n;
@@ -343,7 +391,7 @@ __global__ __launch_bounds__(LG4_THREADS, 4) void k1_pt_loss_gt(K1Args<T, TG> a)
       g1[r] = (TG)(nz ? -c1[r] * inv_nT * rc[r] : T(0));
     }
 #pragma unroll
-    for (int r = 0; r < 4; ++r) Gt[idx[r]] = g1[r];
+    for (int r = 0; r < 4; ++r) bank_store<WT>(&Gt[idx[r]], g1[r]);
     if (mirror) {
       // value(row = rbase + rl[r], col = cbase + lo) -> patch[lo][rl[r]]; read back patch[rl[r]][lo] =
       // value(row = rbase + lo, col = cbase + rl[r]), that of the mirrored entry this lane now owns
@@ -363,7 +411,7 @@ __global__ __launch_bounds__(LG4_THREADS, 4) void k1_pt_loss_gt(K1Args<T, TG> a)
         g2[r] = (TG)(nz ? -c2[r] * inv_nT * rm : T(0));
       }
 #pragma unroll
-      for (int r = 0; r < 4; ++r) Gt[idm[r]] = g2[r];
+      for (int r = 0; r < 4; ++r) bank_store<WT>(&Gt[idm[r]], g2[r]);
     }
   };
 #pragma unroll
@@ -377,7 +425,18 @@ __global__ __launch_bounds__(LG4_THREADS, 4) void k1_pt_loss_gt(K1Args<T, TG> a)
   double *sRed = reinterpret_cast<double *>(sAB);
   if (lane == 0) sRed[wave] = lossacc;
   __syncthreads();
-  if (threadIdx.x == 0) a.loss_part[vid] = (sRed[0] + sRed[1]) + (sRed[2] + sRed[3]);
+  if (tid == 0) a.loss_part[vid] = (sRed[0] + sRed[1]) + (sRed[2] + sRed[3]);
+  CB_STAMP_FINISH(0);
+}
+
+template <typename T, typename TG = T, bool EXPM = false>   // EXPM: write P_b (cb_expm_bank) instead of loss / Gt
+__global__ __launch_bounds__(LG4_THREADS, 4) void k1_pt_loss_gt(K1Args<T, TG> a) {  // four workgroups per CU
+  if (a.skip && *a.skip != 0ull) return;
+  __shared__ T sAB[4 * LG_KT * LG_TM];
+  const int tilesN = (a.LD + LG_TN - 1) / LG_TN, tiles = tilesN * (tilesN + 1) / 2;
+  const int vid = xcd_swizzle(blockIdx.x, gridDim.x);
+  const int b = vid / tiles;
+  k1_tile<T, TG, EXPM, false>(a, b, vid - b * tiles, sAB, threadIdx.x);
 }
 
 // ------------------------------------------------------------------ K2
@@ -390,25 +449,35 @@ struct K2Args {
   const unsigned long long *skip = nullptr;   // as K1Args::skip
 };
 
-template <typename T>
-__global__ __launch_bounds__(LG4_THREADS, 4) void k2_t_eq_g_u(K2Args<T> a) {
-  if (a.skip && *a.skip != 0ull) return;
-  __shared__ T sA[2 * LG_KT * LG_TM];
-  __shared__ T sB[2 * LG_KT * LG_TN];
+// one (bucket b, tile) of K2; sAB as in k1_tile
+template <typename T, bool WT>
+__device__ __forceinline__ void k2_tile(const K2Args<T> &a, int b, int tile, T *sAB, int tid, unsigned int *deferred = nullptr) {
+  T *sA = sAB, *sB = sAB + 2 * LG_KT * LG_TM;
   typedef typename Mfma<T>::acc_t acc_t;
-  const int tilesN = (a.LD + LG_TN - 1) / LG_TN, tiles = tilesN * tilesN;
-  const int vid = xcd_swizzle(blockIdx.x, gridDim.x);
-  const int b = vid / tiles, tile = vid - b * tiles;
+  const int tilesN = (a.LD + LG_TN - 1) / LG_TN;
   const int tm = tile / tilesN, tn = tile - tm * tilesN;
   const int m0 = tm * LG_TM, n0 = tn * LG_TN;
   const size_t boff = (size_t)b * a.LD * a.LD;
   GemmOperands<T> g{a.Gt + boff, a.U, a.LD, a.LD, a.LD, a.LD, a.LD, nullptr};
   acc_t acc[5], ax0, ax1;
-  lg4_gemm_tile<T, false>(g, m0, n0, sA, sB, acc, ax0, ax1);
+  CB_STAMP_BEGIN(b * tilesN * tilesN + tile);
+  lg4_gemm_tile<T, false>(g, m0, n0, sA, sB, acc, ax0, ax1, tid, deferred);
+  CB_STAMP_END(1);
   T *__restrict__ Tm = a.Tm + boff;
   lg_for_each<T>(m0, n0, acc, ax0, ax1, [&](int row, int col, T v) {
-    if (row < a.LD && col < a.LD) Tm[(size_t)row * a.LD + col] = v;
-  });
+    if (row < a.LD && col < a.LD) bank_store<WT>(&Tm[(size_t)row * a.LD + col], v);
+  }, tid);
+  CB_STAMP_FINISH(1);
+}
+
+template <typename T>
+__global__ __launch_bounds__(LG4_THREADS, 4) void k2_t_eq_g_u(K2Args<T> a) {
+  if (a.skip && *a.skip != 0ull) return;
+  __shared__ T sAB[4 * LG_KT * LG_TM];
+  const int tilesN = (a.LD + LG_TN - 1) / LG_TN, tiles = tilesN * tilesN;
+  const int vid = xcd_swizzle(blockIdx.x, gridDim.x);
+  const int b = vid / tiles;
+  k2_tile<T, false>(a, b, vid - b * tiles, sAB, threadIdx.x);
 }
 
 // ------------------------------------------------------------------ K3
@@ -430,17 +499,13 @@ struct K3Args {
   const unsigned long long *skip = nullptr;   // as K1Args::skip
 };
 
+// one (bucket b, tile) of K3; sAB as in k1_tile
 template <typename T>
-__global__ __launch_bounds__(LG4_THREADS, 4) void k3_w_phi(K3Args<T> a) {
-  if (a.skip && *a.skip != 0ull) return;
-  __shared__ T sA[2 * LG_KT * LG_TM];
-  __shared__ T sB[2 * LG_KT * LG_TN];
+__device__ __forceinline__ void k3_tile(const K3Args<T> &a, int b, int tile, T *sAB, int tid, unsigned int *deferred = nullptr) {
+  T *sA = sAB, *sB = sAB + 2 * LG_KT * LG_TM;
   typedef typename Mfma<T>::acc_t acc_t;
   const int tilesN = (a.LD + LG_TN - 1) / LG_TN;
-  const int tiles = a.sym ? tilesN * (tilesN + 1) / 2 : tilesN * tilesN;
-  const int vid = xcd_swizzle(blockIdx.x, gridDim.x);
-  const int b = vid / tiles;
-  int tile = vid - b * tiles, tm, tn;
+  int tm, tn;
   if (a.sym) {
     tm = 0;
     while (tile >= tilesN - tm) {
@@ -456,12 +521,14 @@ __global__ __launch_bounds__(LG4_THREADS, 4) void k3_w_phi(K3Args<T> a) {
   const size_t boff = (size_t)b * a.LD * a.LD;
   GemmOperands<T> g{a.Tm + boff, a.U, a.LD, a.LD, a.LD, a.LD, a.LD, nullptr};
   acc_t acc[5], ax0, ax1;
-  lg4_gemm_tile<T, false>(g, m0, n0, sA, sB, acc, ax0, ax1);
+  CB_STAMP_BEGIN(b * tilesN * tilesN + tm * tilesN + tn);
+  lg4_gemm_tile<T, false>(g, m0, n0, sA, sB, acc, ax0, ax1, tid, deferred);
+  CB_STAMP_END(2);
   const double tb = a.t[b];
   const double *__restrict__ Eb = a.E + (size_t)b * a.LD, *__restrict__ Hb = a.H + (size_t)b * a.LD;
   const double *__restrict__ lam = a.lam;
   T *__restrict__ W = a.W + boff;
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, lo = lane & 15, hi = lane >> 4;
+  const int wave = tid >> 6, lane = tid & 63, lo = lane & 15, hi = lane >> 4;
   // per MFMA tile: the spectral tables of its rows and column first (all loads of the tile in flight
   // together; element by element they compiled to load -> wait -> store chains), then Phi, then the stores.
   // (the divided difference is evaluated in float64 in both widths: its cancellation-free form needs it)
@@ -488,6 +555,217 @@ __global__ __launch_bounds__(LG4_THREADS, 4) void k3_w_phi(K3Args<T> a) {
   for (int j = 0; j < 5; ++j) tile_epilogue(m0 + 16 * wave, n0 + 16 * j, acc[j]);
   tile_epilogue(m0 + 64, n0 + 16 * wave, ax0);
   if (wave == 0) tile_epilogue(m0 + 64, n0 + 64, ax1);
+  CB_STAMP_FINISH(2);
+}
+
+template <typename T>
+__global__ __launch_bounds__(LG4_THREADS, 4) void k3_w_phi(K3Args<T> a) {
+  if (a.skip && *a.skip != 0ull) return;
+  __shared__ T sAB[4 * LG_KT * LG_TM];
+  const int tilesN = (a.LD + LG_TN - 1) / LG_TN;
+  const int tiles = a.sym ? tilesN * (tilesN + 1) / 2 : tilesN * tilesN;
+  const int vid = xcd_swizzle(blockIdx.x, gridDim.x);
+  const int b = vid / tiles;
+  k3_tile<T>(a, b, vid - b * tiles, sAB, threadIdx.x);
+}
+
+// ------------------------------------------------------------------ K1 -> K2 -> K3 in ONE launch
+// Measured with in-kernel stamps (-DCB_CLOCK_STAMP, profiles/tools/clock_probe.py + stamp_timeline.py,
+// profiles/r04_bank_tile_timeline_*.txt): as three launches each of K1 / K2 / K3 spends its last ~90 us draining -- the four
+// workgroups of a CU finish one after the other, and a workgroup that is alone on its CU keeps the f64 matrix pipe 25-35 %
+// busy (its K loop is a latency chain: 70 us for 17 us of MFMAs) -- which is 30 % of K1; the chip's clock is NOT the limit
+// (2.36-2.38 GHz inside the K loops).  Here the three products are ONE persistent launch of 4 workgroups per CU that draw
+// (stage, bucket, tile) tickets, so that K2's tiles fill K1's drain and K3's fill K2's; only K3's own drain is left.
+//  * Tickets: one queue per XCD (workgroups go round-robin over the XCDs: blockIdx.x % 8 is the home queue -- checked with
+//    XCC_ID stamps: every queue was served by one XCD), holding the three stages of that XCD's share of the buckets in
+//    order: all its K1 tiles, then its K2 tiles, then its K3 tiles, bucket by bucket, so that the tiles that share an operand
+//    block run side by side on one L2 (what xcd_swizzle does for the separate kernels).  A workgroup whose queue is empty
+//    draws from the next XCD's.
+//  * Dependencies: K2 of bucket b reads ALL of Gt_b, K3 of bucket b all of T_b: one counter per (stage, bucket), bumped by
+//    every finished tile; a K2 / K3 ticket waits until its bucket's counter is complete.  A queue hands out every K1 ticket
+//    before its first K2 ticket, K1 tickets wait for nothing and a drawn ticket belongs to a RUNNING workgroup (the ticket
+//    drawn ahead, below, is held by a workgroup whose current tile has all its inputs): no deadlock whatever the number of
+//    resident workgroups.  In practice nobody waits: bucket b's K1 tiles are drawn ~one stage (150 us) before its K2 tiles.
+//  * Visibility: the L2s of the XCDs are not coherent with each other inside a launch.  An agent-scope release (write back
+//    the L2) per tile costs +55 us on K2, an acquire (invalidate it: U is gone) +48 us (measured with a fence in K2); so Gt
+//    and T are written THROUGH to memory instead (agent-scope stores: +0 us), the producer waits for its stores (vmcnt)
+//    before it bumps the counter, and the consumer needs no invalidate because no cache can hold an older copy of those
+//    lines: inside this launch they are read only after they were written, and the launch boundary invalidated whatever
+//    the previous epoch left.  (The counters are agent-scope atomics.)  W_b (K3's output, over Gt_b) is read by the NEXT
+//    launch (k3_reduce): plain stores.  tests/test_gpu_s400_full.py compares this launch with the three separate ones bit
+//    for bit (CB_BANK_UNFUSED=1).
+struct BankQueueArgs {
+  unsigned int *queue;   // [8] tickets drawn per XCD queue | [B] finished K1 tiles | [B] finished K2 tiles, set by lg_tables
+  int B, tiles1, tiles2, tiles3;
+};
+
+// Ticket `idx` of a queue that owns `nb` buckets -> (stage 0 / 1 / 2, local bucket, tile): the queue's K1 tiles bucket by
+// bucket, then its K2 tiles, then its K3 tiles.  (Measured and dropped: a software pipeline over the buckets -- round r = the K1
+// tiles of bucket r, the K2 tiles of bucket r - lag, the K3 tiles of bucket r - 2 lag, mixed in the proportion of their
+// counts so that K1's long epilogues run beside K2 tiles -- 0.84 / 0.81 / 0.79 ms at lag 4 / 6 / 8 against 0.74 ms: a K2
+// ticket ~250 tickets behind its bucket's K1 tickets still finds them in flight and waits.)
+struct BankTicket { int stage, b, tile; };
+__device__ __forceinline__ BankTicket bank_decode(const BankQueueArgs &a, int nb, int idx) {
+  const int t1 = a.tiles1, t2 = a.tiles2, t3 = a.tiles3;
+  BankTicket k;
+  if (idx < nb * t1) k.stage = 0, k.b = idx / t1, k.tile = idx - k.b * t1;
+  else if (idx < nb * (t1 + t2)) k.stage = 1, k.b = (idx - nb * t1) / t2, k.tile = idx - nb * t1 - k.b * t2;
+  else k.stage = 2, k.b = (idx - nb * (t1 + t2)) / t3, k.tile = idx - nb * (t1 + t2) - k.b * t3;
+  return k;
+}
+template <typename T1, typename TG>
+struct K123Args {
+  K1Args<T1, TG> k1;
+  K2Args<TG> k2;
+  K3Args<TG> k3;
+  BankQueueArgs q;
+};
+
+#define LG_NQ 8   // ticket queues = XCDs
+
+// a wave-uniform copy (in SGPRs) of an argument block read from device memory
+template <typename S>
+__device__ __forceinline__ S uniform_copy(const S *p) {
+  static_assert(sizeof(S) % 4 == 0, "dwords");
+  S out;
+  const unsigned int *src = reinterpret_cast<const unsigned int *>(p);
+  unsigned int *dst = reinterpret_cast<unsigned int *>(&out);
+#pragma unroll
+  for (size_t i = 0; i < sizeof(S) / 4; ++i) dst[i] = (unsigned int)__builtin_amdgcn_readfirstlane((int)src[i]);
+  return out;
+}
+
+// A pointer read from memory is a GENERIC pointer to the compiler (flat_load / flat_store: both wait counters, no
+// global-only addressing modes): say that it points to global memory, as it knows of a pointer kernel argument.
+template <typename P>
+__device__ __forceinline__ P *as_global(P *p) {
+  // (a plain cast to address_space(1) and back is folded away before the address-space inference runs; through an empty
+  // asm the global pointer is opaque, and being an "s" operand it is in SGPRs)
+  __attribute__((address_space(1))) P *g = (__attribute__((address_space(1))) P *)p;
+  asm("" : "+s"(g));
+  return (P *)g;
+}
+template <typename T, typename TG>
+__device__ __forceinline__ void globalize(K1Args<T, TG> &a) {
+  a.Ut = as_global(a.Ut); a.A = as_global(a.A); a.t = as_global(a.t); a.F = as_global(a.F); a.sigma = as_global(a.sigma);
+  a.Ct = as_global(a.Ct); a.Gt = as_global(a.Gt); a.loss_part = as_global(a.loss_part); a.dsq = as_global(a.dsq);
+  a.P = as_global(a.P); a.skip = as_global(a.skip);
+}
+template <typename T>
+__device__ __forceinline__ void globalize(K2Args<T> &a) {
+  a.Gt = as_global(a.Gt); a.U = as_global(a.U); a.Tm = as_global(a.Tm); a.skip = as_global(a.skip);
+}
+template <typename T>
+__device__ __forceinline__ void globalize(K3Args<T> &a) {
+  a.Tm = as_global(a.Tm); a.U = as_global(a.U); a.t = as_global(a.t); a.lam = as_global(a.lam); a.E = as_global(a.E);
+  a.H = as_global(a.H); a.W = as_global(a.W); a.skip = as_global(a.skip);
+}
+
+// The argument block lives in DEVICE memory (lg_tables, the launch in front, copies it there from its own kernel arguments):
+// as kernel arguments the ~40 pointers and sizes of the three stages stayed in SGPRs across the ticket loop (106 + 111
+// spilled, and 57 spilled VGPRs in their wake); read where a stage needs them (uniform_copy: loads + v_readfirstlane, so that
+// they are SGPRs again inside the stage) they cost a few loads per tile.
+template <typename T1, typename TG>
+__global__ __launch_bounds__(LG4_THREADS, 4) void k123_bank(const K123Args<T1, TG> *ap) {
+  BankQueueArgs a = uniform_copy(&ap->q);
+  a.queue = as_global(a.queue);
+  {
+    const unsigned long long *skip = ap->k1.skip;
+    if (skip && *skip != 0ull) return;
+  }
+  constexpr size_t ELT = sizeof(T1) > sizeof(TG) ? sizeof(T1) : sizeof(TG);
+  __shared__ __attribute__((aligned(16))) unsigned char smem[4 * LG_KT * LG_TM * ELT];   // 40 KB in float64: four per CU
+  int *s_ticket = reinterpret_cast<int *>(smem);   // (queue, ticket) of this round, in the panel buffer: every thread has read
+                                                   // them before the tile routine's first barrier, which precedes its first store
+  unsigned int *tick = a.queue, *done1 = a.queue + LG_NQ, *done2 = done1 + a.B;
+  const int per_bucket = a.tiles1 + a.tiles2 + a.tiles3;
+  // Workgroups go round-robin over the XCDs (xcd_swizzle's assumption): blockIdx.x % 8 names the home queue.  The FIRST
+  // ticket of a workgroup is index blockIdx.x / 8 of that queue without asking (lg_tables starts the counters at
+  // gridDim.x / 8: 128 draws on one counter at the start of the launch took 40 us to serve).
+  const int home = blockIdx.x & (LG_NQ - 1);
+  auto queue_len = [&](int q) { return (a.B * (q + 1) / LG_NQ - a.B * q / LG_NQ) * per_bucket; };
+  // Between two tiles of a workgroup lay ~9 us of dependent round trips (the announcement of the finished tile behind a
+  // wait for its stores, the draw, the dependency word, the argument block): 16 % of the launch.  So the NEXT ticket is drawn
+  // while the current tile runs (thread 0 issues the atomic in front of the K loop and looks at the answer after the
+  // epilogue), and the finished tile is announced from inside the next tile's K loop (lg4_gemm_tile, `deferred`).
+  // The first TWO tickets of a workgroup are its own without asking: index blockIdx.x / 8 and, one "row" of workgroups
+  // further, n_home + blockIdx.x / 8 of its home queue (lg_tables starts the counters at 2 n_home): the 128 workgroups of a
+  // queue start together, and 128 draws on one counter take 40 us to serve -- the second tiles start spread out.
+  const int n_home = ((int)gridDim.x - home + LG_NQ - 1) / LG_NQ;   // workgroups of this launch whose home is this queue
+  int nq = home, ni = (int)(blockIdx.x / LG_NQ);   // thread 0: the ticket drawn for the next round (queue, raw index)
+  int round = 0;
+  unsigned int *pending = nullptr;                 // the finished tile that is still to be announced
+  for (;; ++round) {
+    __syncthreads();   // the previous ticket's last readers of smem / s_ticket are done
+    if (threadIdx.x == 0) {
+      int q = nq, idx = ni < queue_len(nq) ? ni : -1;
+      for (int tries = 0; idx < 0 && tries < LG_NQ; ++tries) {   // own queue empty: the next XCD's
+        q = (q + 1) & (LG_NQ - 1);
+        const int len = queue_len(q);
+        if ((int)__hip_atomic_load(tick + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= len) continue;
+        const int i = (int)__hip_atomic_fetch_add(tick + q, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (i < len) idx = i;
+      }
+      int stage = -1, b = 0, tile = 0, ready = 1;
+      if (idx >= 0) {
+        const int b0 = a.B * q / LG_NQ, nb = a.B * (q + 1) / LG_NQ - b0;
+        const BankTicket k = bank_decode(a, nb, idx);
+        stage = k.stage, b = b0 + k.b, tile = k.tile;
+        const unsigned int *dep = stage == 1 ? done1 + b : stage == 2 ? done2 + b : nullptr;
+        const unsigned int need = (unsigned int)(stage == 1 ? a.tiles1 : a.tiles2);
+        if (dep && __hip_atomic_load(dep, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) ready = 0;
+        // the draw for the round after this one, answered while this tile runs
+        nq = q;
+        if (round == 0 && q == home) ni = n_home + (int)(blockIdx.x / LG_NQ);
+        else ni = (int)__hip_atomic_fetch_add(tick + q, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      s_ticket[0] = stage;
+      s_ticket[1] = b;
+      s_ticket[2] = tile;
+      s_ticket[3] = ready;
+    }
+    __syncthreads();
+    const int stage = s_ticket[0], b = s_ticket[1], tile = s_ticket[2];
+    const bool ready = s_ticket[3] != 0;
+    if (stage < 0 || !ready) {
+      // nothing left, or the ticket's inputs are not complete (rare: see above): announce the finished tile NOW -- the
+      // inputs waited for may include it -- and wait
+      if (pending) {
+        __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): this wave's stores have been performed
+        __syncthreads();                      // ... and every wave's
+        if (threadIdx.x == 0) __hip_atomic_fetch_add(pending, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        pending = nullptr;
+      }
+      if (stage < 0) return;
+      if (threadIdx.x == 0) {
+        const unsigned int *dep = stage == 1 ? done1 + b : done2 + b;
+        const unsigned int need = (unsigned int)(stage == 1 ? a.tiles1 : a.tiles2);
+        while (__hip_atomic_load(dep, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) __builtin_amdgcn_s_sleep(4);
+      }
+      __syncthreads();
+    }
+    // an opaque copy of threadIdx.x per ticket: otherwise the lane offsets, panel addresses ... of ALL three stages are
+    // computed once in front of the loop and stay live through every stage (50 spilled VGPRs in K1's epilogue)
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));
+    unsigned int *signal = nullptr;
+    if (stage == 0) {
+      K1Args<T1, TG> k1 = uniform_copy(&ap->k1);
+      globalize(k1);
+      k1_tile<T1, TG, false, true>(k1, b, tile, reinterpret_cast<T1 *>(smem), tid, pending);
+      signal = done1 + b;
+    } else if (stage == 1) {
+      K2Args<TG> k2 = uniform_copy(&ap->k2);
+      globalize(k2);
+      k2_tile<TG, true>(k2, b, tile, reinterpret_cast<TG *>(smem), tid, pending);
+      signal = done2 + b;
+    } else {
+      K3Args<TG> k3 = uniform_copy(&ap->k3);
+      globalize(k3);
+      k3_tile<TG>(k3, b, tile, reinterpret_cast<TG *>(smem), tid, pending);
+    }
+    pending = signal;
+  }
 }
 
 // Mt = sum over chunks (fixed order => bitwise reproducible), always accumulated in float64.  sym
@@ -631,6 +909,7 @@ __global__ __launch_bounds__(NW * 64) void sg_gemm(K4Args a1, K4Args a2, int ns,
   }
 }
 
+#ifndef CB_BANK_FUSED_TU   // (cb_bank_fused.hip compiles k123_bank only: the non-template kernels below have one home)
 // ------------------------------------------------------------------ small helpers
 // A = sym(D^1/2 Q D^-1/2) into padded LD x LD, dsq = sqrt(pi) (1 on the pad)
 __global__ void lg_build_A(int S, int LD, const double *Q, const double *pi, double *A,
@@ -648,9 +927,20 @@ __global__ void lg_build_A(int S, int LD, const double *Q, const double *pi, dou
 }
 
 // spectral tables F = phi2(t lam), E = exp(t lam), H = exp(t lam / 2): [B][LD]
+// (+ for the fused bank kernel that follows: its ticket queues and tile counters zeroed, its argument block copied to device
+// memory)
+struct NoBankArgs { BankQueueArgs q; };
+template <typename ARGS = NoBankArgs>
 __global__ void lg_tables(int LD, int B, const double *t, const double *lam,
-                          const double *sigma, double *F, double *E, double *H) {
+                          const double *sigma, double *F, double *E, double *H, ARGS bank = ARGS{}, ARGS *bank_dst = nullptr,
+                          int bank_grid = 0) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (bank_dst) {
+    // queue q starts behind the tickets its workgroups take without asking (k123_bank: two each, for a grid of `bank_grid`
+    // workgroups)
+    if (idx < LG_NQ + 2 * bank.q.B) bank.q.queue[idx] = idx < LG_NQ ? 2u * (unsigned int)((bank_grid - idx + LG_NQ - 1) / LG_NQ) : 0u;
+    if (idx == 0) *bank_dst = bank;
+  }
   if (idx >= B * LD) return;
   const int b = idx / LD, k = idx - b * LD;
   const double x = t[b] * lam[k];
@@ -715,3 +1005,4 @@ __global__ void lg_cast_f32(size_t LL, size_t BL, const double *U, const double 
   }
   if (i < BL) Ff[i] = (float)F[i];
 }
+#endif  // CB_BANK_FUSED_TU

@@ -1,0 +1,26 @@
+"""Timeline of the bank's tiles from the in-kernel stamps of a -DCB_CLOCK_STAMP build (profiles/tools/clock_probe.py writes
+gpurun_out/clock_stamps_*.npy): per stage first / last start, K-loop and epilogue medians, and every `step` us the number of
+tiles inside their K loop / inside their epilogue.   python profiles/tools/stamp_timeline.py <stamps.npy> [step_us]"""
+import sys
+import numpy as np
+
+b = np.load(sys.argv[1]).astype(np.int64)
+step = float(sys.argv[2]) if len(sys.argv) > 2 else 25.0
+S = []
+for kid in range(3):
+    s = b[kid]
+    S.append(s[(s[:, 2] > 0) & (s[:, 4] > 0)])
+t0 = min(s[:, 2].min() for s in S)
+for kid, s in enumerate(S):
+    st, ke, en = [(s[:, c] - t0) * 0.01 for c in (2, 3, 4)]
+    print("K%d: %d tiles, first start %.1f, last start %.1f, last end %.1f us; K loop median %.1f us (clock %.2f GHz), epilogue "
+          "median %.1f us" % (kid + 1, len(s), st.min(), st.max(), en.max(), np.median(ke - st),
+                              np.median(s[:, 0] / np.maximum(s[:, 1], 1) * 0.1), np.median(en - ke)))
+tend = max(((s[:, 4] - t0) * 0.01).max() for s in S)
+print("   t us | tiles in flight | (in K loop, in epilogue) per stage")
+for t in np.arange(5, tend + step, step):
+    row = []
+    for s in S:
+        st, ke, en = [(s[:, c] - t0) * 0.01 for c in (2, 3, 4)]
+        row.append((int(np.sum((st <= t) & (ke > t))), int(np.sum((ke <= t) & (en > t)))))
+    print(f"  {t:6.0f} | {sum(a + c for a, c in row):5d} | K1 {row[0]}  K2 {row[1]}  K3 {row[2]}")

@@ -367,3 +367,92 @@ def test_two_queue_bank_option_gives_the_same_bits(dense, tmp_path):
         outs.append(np.load(out))
     assert np.array_equal(outs[0]["loss"], outs[1]["loss"]) and np.array_equal(outs[0]["Q"], outs[1]["Q"])
     assert np.allclose(outs[0]["loss"], z["loss_f64"][:12], rtol=1e-9, atol=0)
+
+
+def _random_bank(S, B, seed, sym=True):
+    rng = np.random.default_rng(seed)
+    t = np.geomspace(0.02, 2.0, B)
+    R = rng.gamma(2.0, 0.5, size=(S, S))
+    R = 0.5 * (R + R.T)
+    pi = rng.dirichlet(np.full(S, 5.0))
+    Q = R * pi[None, :]
+    np.fill_diagonal(Q, 0.0)
+    np.fill_diagonal(Q, -Q.sum(1))
+    Q /= -(pi * np.diag(Q)).sum()
+    w, V = np.linalg.eigh(np.sqrt(pi)[:, None] * Q / np.sqrt(pi)[None, :])
+    C = np.stack([pi[:, None] * ((V * np.exp(tb * w)) @ V.T) * np.sqrt(pi)[None, :] / np.sqrt(pi)[:, None] for tb in t]) * 1e5
+    if sym:
+        C = 0.5 * (C + C.transpose(0, 2, 1))
+    else:
+        C = C * rng.uniform(0.5, 1.5, size=C.shape)     # C_b != C_b^T: K3 then runs all its tiles
+    return t, C, Q, pi
+
+
+@pytest.mark.parametrize("dtype", ["f64", "mixed", "f32"])
+def test_fused_bank_launch_gives_the_bits_of_the_three_launches_on_the_bench_bank(dense, dtype, monkeypatch):
+    """K1 -> K2 -> K3 as ONE persistent launch of ticket-drawing workgroups (k123_bank, the default) against the three
+    separate launches (CB_BANK_UNFUSED=1) on the bank bench.py times: every tile is computed by the same instructions in the
+    same order, only WHEN and WHERE it runs differs, so loss, dL/dQ and 12 epochs of training agree bit for bit.  (This is
+    the test that would see a tile read before its inputs were visible: the fused launch publishes Gt_b / T_b to the other
+    XCDs with write-through stores and per-bucket counters instead of a launch boundary.)"""
+    from cherryml_amd import CherryBank
+    from cherryml_amd.estimation._jtt_ipw import jtt_ipw_from_arrays
+    import cherryml_amd
+    import torch
+    wl = dense
+    S = 400
+    init = jtt_ipw_from_arrays(wl["t"], wl["C"], wl["mask"])
+    mod = cherryml_amd.RateMatrix(num_states=S, mode="pande_reversible", mask=torch.tensor(wl["mask"]),
+                                  pi=torch.ones(S, dtype=torch.float64) / S, pi_requires_grad=True, initialization=init)
+    u0, p0 = mod.upper_diag.detach().numpy().copy(), mod._pi.detach().numpy().copy()
+    Q0, pi0 = mod().detach().numpy(), mod.stationary().detach().numpy()
+    out = {}
+    for name, env in (("fused", None), ("separate", "1")):
+        if env is None:
+            monkeypatch.delenv("CB_BANK_UNFUSED", raising=False)
+        else:
+            monkeypatch.setenv("CB_BANK_UNFUSED", env)
+        with CherryBank(wl["t"], wl["C"], dtype=dtype) as bank:
+            loss, dQ = bank.loss_grad(Q0, pi0)
+            loss2, dQ2 = bank.loss_grad(Q0, pi0)          # the queues are reset by every evaluation (the second one starts
+            assert np.allclose(loss, loss2, rtol=1e-6) and relerr(dQ, dQ2) < 1e-4      # its eigensolve warm: last bits differ)
+            bank.profile(True)
+            r = bank.train_pande_reversible(u0, p0, mask=wl["mask"], num_epochs=12, lr=0.1)
+            tm = bank.timing_means()
+            bank.profile(False)
+        out[name] = (loss, dQ, r, tm)
+    (la, da, ra, ta), (lb, db, rb, tb) = out["fused"], out["separate"]
+    assert np.all(np.isfinite(la)) and np.array_equal(la, lb)
+    assert np.array_equal(da, db)
+    assert np.array_equal(ra["loss"], rb["loss"])
+    assert np.array_equal(ra["Q_last"], rb["Q_last"]) and np.array_equal(ra["Q_best"], rb["Q_best"])
+    # the phase report says which form ran: one span for the fused launch, three for the separate ones
+    assert ta["k1"] > 0 and ta["k2"] == 0 and ta["k3"] == 0
+    assert tb["k1"] > 0 and tb["k2"] > 0 and tb["k3"] > 0
+
+
+@pytest.mark.parametrize("S,B,sym", [(100, 3, True), (100, 9, False), (64, 1, True), (200, 20, True), (400, 7, False)])
+def test_fused_bank_launch_on_small_and_ragged_banks(S, B, sym, monkeypatch):
+    """Fewer buckets than ticket queues (empty queues, every ticket drawn from a neighbour's queue), one bucket, fewer tickets
+    than resident workgroups, LD = 112 / 64 / 208 (2 / 1 / 3 tiles a side), asymmetric counts (K3 runs all its tiles): the
+    fused launch against the three launches bit for bit, and against the float64 oracle."""
+    from cherryml_amd import CherryBank
+    from oracle import ratelearn_oracle as orc
+    t, C, Q, pi = _random_bank(S, B, 1000 * S + B, sym)
+    out = {}
+    for name, env in (("fused", None), ("separate", "1")):
+        if env is None:
+            monkeypatch.delenv("CB_BANK_UNFUSED", raising=False)
+        else:
+            monkeypatch.setenv("CB_BANK_UNFUSED", env)
+        with CherryBank(t, C) as bank:
+            out[name] = bank.loss_grad(Q * 0.9, pi)
+    (la, da), (lb, db) = out["fused"], out["separate"]
+    assert np.all(np.isfinite(la)) and np.array_equal(la, lb) and np.array_equal(da, db)
+    import torch
+    Qt = torch.tensor(Q * 0.9, dtype=torch.float64, requires_grad=True)
+    lo = orc.bank_loss(Qt, torch.tensor(t, dtype=torch.float64), torch.tensor(C, dtype=torch.float64))
+    lo.backward()
+    lo = float(lo.detach())
+    assert abs(float(la[0]) - lo) <= 1e-12 * abs(lo)
+    assert relerr(da[0], Qt.grad.numpy()) < 1e-10
