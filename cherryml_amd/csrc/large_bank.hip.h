@@ -635,6 +635,19 @@ __device__ __forceinline__ S uniform_copy(const S *p) {
   return out;
 }
 
+// the same with the loads addressed to constant memory (scalar loads where the compiler sees a uniform address; the block
+// is not written inside the launch that reads it)
+template <typename S>
+__device__ __forceinline__ S const_copy(const S *p) {
+  static_assert(sizeof(S) % 4 == 0, "dwords");
+  S out;
+  const __attribute__((address_space(4))) unsigned int *src = (const __attribute__((address_space(4))) unsigned int *)p;
+  unsigned int *dst = reinterpret_cast<unsigned int *>(&out);
+#pragma unroll
+  for (size_t i = 0; i < sizeof(S) / 4; ++i) dst[i] = (unsigned int)__builtin_amdgcn_readfirstlane((int)src[i]);
+  return out;
+}
+
 // A pointer read from memory is a GENERIC pointer to the compiler (flat_load / flat_store: both wait counters, no
 // global-only addressing modes): say that it points to global memory, as it knows of a pointer kernel argument.
 template <typename P>
@@ -687,7 +700,10 @@ __global__ __launch_bounds__(LG4_THREADS, 4) void k123_bank(const K123Args<T1, T
   // Between two tiles of a workgroup lay ~9 us of dependent round trips (the announcement of the finished tile behind a
   // wait for its stores, the draw, the dependency word, the argument block): 16 % of the launch.  So the NEXT ticket is drawn
   // while the current tile runs (thread 0 issues the atomic in front of the K loop and looks at the answer after the
-  // epilogue), and the finished tile is announced from inside the next tile's K loop (lg4_gemm_tile, `deferred`).
+  // epilogue), the finished tile is announced from inside the next tile's K loop (lg4_gemm_tile, `deferred`), and the
+  // argument blocks come through the scalar cache: 3 us are left.  (Drawing TWO tickets ahead, so that the dependency word
+  // is in flight during a tile as well, was slower, 0.81 against 0.74 ms: a ticket then waits up to two tile times in its
+  // holder's pipeline, and the K2 tickets of a queue's last buckets find their K1 tiles not even started.)
   // The first TWO tickets of a workgroup are its own without asking: index blockIdx.x / 8 and, one "row" of workgroups
   // further, n_home + blockIdx.x / 8 of its home queue (lg_tables starts the counters at 2 n_home): the 128 workgroups of a
   // queue start together, and 128 draws on one counter take 40 us to serve -- the second tiles start spread out.
@@ -748,19 +764,21 @@ __global__ __launch_bounds__(LG4_THREADS, 4) void k123_bank(const K123Args<T1, T
     // computed once in front of the loop and stay live through every stage (50 spilled VGPRs in K1's epilogue)
     int tid = threadIdx.x;
     asm volatile("" : "+v"(tid));
+    const K123Args<T1, TG> *cap = ap;   // (the same for the argument block: its scalar loads would all be hoisted)
+    asm volatile("" : "+s"(cap));
     unsigned int *signal = nullptr;
     if (stage == 0) {
-      K1Args<T1, TG> k1 = uniform_copy(&ap->k1);
+      K1Args<T1, TG> k1 = const_copy(&cap->k1);
       globalize(k1);
       k1_tile<T1, TG, false, true>(k1, b, tile, reinterpret_cast<T1 *>(smem), tid, pending);
       signal = done1 + b;
     } else if (stage == 1) {
-      K2Args<TG> k2 = uniform_copy(&ap->k2);
+      K2Args<TG> k2 = const_copy(&cap->k2);
       globalize(k2);
       k2_tile<TG, true>(k2, b, tile, reinterpret_cast<TG *>(smem), tid, pending);
       signal = done2 + b;
     } else {
-      K3Args<TG> k3 = uniform_copy(&ap->k3);
+      K3Args<TG> k3 = const_copy(&cap->k3);
       globalize(k3);
       k3_tile<TG>(k3, b, tile, reinterpret_cast<TG *>(smem), tid, pending);
     }
