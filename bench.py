@@ -45,6 +45,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8.0 TB/s spec
 F64_PEAK_TFLOPS = 78.6     # 256 CU x 4 SIMD x 32 flop/clk x 2.4 GHz (f64 MFMA = f64 vector rate)
+PREWARM_EPOCHS = 30   # throw-away epochs in front of the W warm-up epochs of the 400-state trainer (see main)
 F32_PEAK_TFLOPS = 157.3    # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 / 32x32x2, 64 flop/clk/SIMD (exact f32)
 LDS_ATOMIC_PEAK_G = 9830.4  # G lane-atomics/s: 16 lanes per clock per CU (LDS table: a 4-byte LDS write / atomic = 4 cycles per
                             # wave-instruction) x 256 CUs x 2.4 GHz, conflict-free
@@ -414,6 +415,7 @@ def main():
                 call = lambda E, resume=False: sharded.train_pande_reversible(  # noqa: E731
                     u0, p0, mask=wl["mask"], num_epochs=E, lr=0.1, resume=resume)
                 if warmup > 0:
+                    call(PREWARM_EPOCHS)   # (see the single-GPU branch below: one-time events of a fresh process)
                     call(warmup)
                 bank.profile(True)
                 fence()
@@ -480,6 +482,12 @@ def main():
                 th0, Th0 = _invert(wl["init"])
                 sharding = f"sites x{world} (no collective)"
                 call = lambda E, resume=False: bank.train_siterm(th0, Th0, E, lr=0.1)  # noqa: E731
+            if S > 32 and warmup > 0:
+                # One-time events of a fresh process (first launch of every kernel, the runtime's lazily grown pools: a host
+                # stall of 70-95 ms once per process, at a random place in its first ~10 epochs: CB_TRACE_SLOW) are taken
+                # out of the way by a throw-away optimisation BEFORE the W warm-up epochs; the W + K epochs that follow start
+                # from scratch again (resume = False), so the timed epochs are still epochs W .. W+K-1 of one optimisation.
+                call(PREWARM_EPOCHS)
             if warmup > 0:
                 call(warmup)
             bank.profile(True)
@@ -603,7 +611,9 @@ def main():
                        **({"non_empty_buckets": wl["live"]} if "live" in wl else {}), "sharding": sharding,
                        "epoch": glue,
                        **({"timed_epochs": f"{warmup} .. {warmup + steps - 1} of one optimisation from the JTT-IPW start "
-                                           "(the warm-up epochs are its first ones; CB_TRAIN_RESUME)"} if resumed else {}),
+                                           "(the warm-up epochs are its first ones; CB_TRAIN_RESUME)",
+                           "prewarm": f"{PREWARM_EPOCHS} throw-away epochs of the same optimisation in front of the warm-up "
+                                      "(one-time host stalls of a fresh process: DESIGN.md section 11)"} if resumed else {}),
                        **({"arithmetic": "float32 operands + float32 MFMA accumulation in P_b, G_b U, (T_b^T U) o Phi_b; "
                                          "eigensolver, loss sums, divided differences, bucket sum, Adam in float64"}
                           if bank_dtype == "f32" else {})},

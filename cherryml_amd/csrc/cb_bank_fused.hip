@@ -5,22 +5,24 @@
 // it, where they stay live through every stage: 26 spilled VGPRs, and a spill reload behind an epilogue's stores waits for
 // those stores (vmcnt counts them in order) -- K3's epilogue took 41 us instead of 11.  Without that pass: no spill.
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #define CB_BANK_FUSED_TU 1
 #include "common.hip.h"
 #include "large_bank.hip.h"
 #include "cb_internal.hip.h"
 
-// variant: 0 = float64 bank, 1 = CB_F32, 2 = CB_MIXED; `args` = the argument block in device memory (written by lg_tables)
-int cb_launch_bank_fused(int variant, const void *args, int grid, hipStream_t stream) {
-  if (variant == 1)
-    hipLaunchKernelGGL((k123_bank<float, float>), dim3(grid), dim3(LG4_THREADS), 0, stream,
-                       static_cast<const K123Args<float, float> *>(args));
-  else if (variant == 2)
-    hipLaunchKernelGGL((k123_bank<double, float>), dim3(grid), dim3(LG4_THREADS), 0, stream,
-                       static_cast<const K123Args<double, float> *>(args));
-  else
-    hipLaunchKernelGGL((k123_bank<double, double>), dim3(grid), dim3(LG4_THREADS), 0, stream,
-                       static_cast<const K123Args<double, double> *>(args));
+// variant: 0 = float64 bank, 1 = CB_F32, 2 = CB_MIXED; `args` = the argument block in device memory (written by lg_tables);
+// stop: null, or the event that takes the launch's end time (the phase timer: handle_host.hip.h, stop_event())
+template <typename T1, typename TG>
+static void launch(const void *args, int grid, hipStream_t stream, hipEvent_t stop) {
+  const K123Args<T1, TG> *a = static_cast<const K123Args<T1, TG> *>(args);
+  if (stop) hipExtLaunchKernelGGL((k123_bank<T1, TG>), dim3(grid), dim3(LG4_THREADS), 0, stream, nullptr, stop, 0, a);
+  else hipLaunchKernelGGL((k123_bank<T1, TG>), dim3(grid), dim3(LG4_THREADS), 0, stream, a);
+}
+int cb_launch_bank_fused(int variant, const void *args, int grid, hipStream_t stream, hipEvent_t stop) {
+  if (variant == 1) launch<float, float>(args, grid, stream, stop);
+  else if (variant == 2) launch<double, float>(args, grid, stream, stop);
+  else launch<double, double>(args, grid, stream, stop);
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 

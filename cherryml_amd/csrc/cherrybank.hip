@@ -149,7 +149,7 @@ static int launch_small(cb_bank *h, const SmallArgs &a) {
 // `dA_padded` is false, else dL/dA itself as a padded LD x LD matrix.
 // `plan`: a warm solve enqueued as a device-controlled plan (eigh_planned_host.hip.h) instead of the host-driven loop; the
 // caller reads the record of solve `h->eseq` afterwards and repeats the evaluation without a plan if the solve stalled.
-int cb_launch_bank_fused(int variant, const void *args, int grid, hipStream_t stream);   // cb_bank_fused.hip
+int cb_launch_bank_fused(int variant, const void *args, int grid, hipStream_t stream, hipEvent_t stop);   // cb_bank_fused.hip
 
 static int large_eval(cb_bank *h, bool normalize, double *lossd, double *out, bool dA_padded, double *Pd,
                       bool reuse_eigh = false, const EighPlan *plan = nullptr, int plan_first_slot = 0) {
@@ -165,7 +165,8 @@ static int large_eval(cb_bank *h, bool normalize, double *lossd, double *out, bo
   if (planned_now) rc = enqueue_planned_solve(h, *plan, ++h->eseq, plan_first_slot);
   else if (!(reuse_eigh && h->have_prev)) rc = large_eigh(h, true);   // reuse: same matrix as the previous call (CB_REUSE_EIGH)
   if (rc != CB_OK) return rc;
-  mark(h, EV_EIGH);
+  SlowScope scope_bank("large_eval: tables, bank, K4 enqueue");
+  if (!planned_now) mark(h, EV_EIGH);   // (a planned solve's last launch carries the mark)
   const int tm = (LD + LG_TM - 1) / LG_TM, tn = (LD + LG_TN - 1) / LG_TN, tiles = tm * tn;
   const double inv_n = normalize ? 1.0 / (h->comm ? h->n_global[0] : h->n_host[0]) : 1.0;
   const int tiles_k1 = tn * (tn + 1) / 2;  // Pt is symmetric: upper-triangular tiles only
@@ -174,15 +175,8 @@ static int large_eval(cb_bank *h, bool normalize, double *lossd, double *out, bo
   // K1 -> K2 -> K3 as ONE persistent launch (k123_bank, large_bank.hip.h) whenever the gradient is wanted; CB_BANK_UNFUSED=1
   // keeps the three launches (per-kernel profiles, and the reference point of tests/test_gpu_s400_full.py)
   const bool unfused_env = getenv("CB_BANK_UNFUSED") != nullptr;   // (read per call: the tests switch it inside one process)
-  const bool fused = !Pd && dQd && !unfused_env && n_parts == 1;
-  if (fused && !h->bank_queue) {
-    ALLOC(h->bank_queue, (size_t)LG_NQ + 2 * (size_t)h->B);
-    ALLOC(h->bank_args, sizeof(K123Args<double, double>));   // (the three instantiations have one layout)
-    int dev = 0, cus = 0;
-    HIP_TRY(hipGetDevice(&dev));
-    HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-    h->bank_slots = 4 * std::max(cus, 1);
-  }
+  const bool fused = !Pd && dQd && !unfused_env && n_parts == 1 && h->bank_queue;
+  // (queues and argument block: allocated with the handle, create_host.hip.h)
   h->bank_fused = fused;
   const dim3 tables_grid((unsigned)(((size_t)B * LD + 255) / 256));
   if (!fused)
@@ -203,6 +197,9 @@ static int large_eval(cb_bank *h, bool normalize, double *lossd, double *out, bo
     // small); the loss partials are summed after it
     const int total = B * (tiles_k1 + tiles + tiles_k3), grid = std::min(h->bank_slots, total);
     const int sym = h->sym_counts ? 1 : 0;
+    // (the phase marks ride on the launches as stop events: handle_host.hip.h, stop_event())
+    if (h->profile) h->ev_rec[EV_K1] = h->ev_rec[EV_K2] = false;   // CB_T_K1 = the whole launch (+ tables), see read_phase_times
+    const hipEvent_t bank_stop = stop_event(h, EV_K3);
     auto launch = [&](auto args) {
       typedef decltype(args) A;
       A *dst = reinterpret_cast<A *>(h->bank_args);
@@ -220,7 +217,7 @@ static int large_eval(cb_bank *h, bool normalize, double *lossd, double *out, bo
       auto *dst = launch(a);
       hipLaunchKernelGGL(lg_cast_f32, dim3((unsigned)((std::max(LL, (size_t)B * LD) + 255) / 256)), dim3(256), 0, h->stream, LL,
                          (size_t)B * LD, h->U, h->Vc, h->A, h->F, h->Uf, h->Utf, h->Af, h->Ff);
-      if (cb_launch_bank_fused(1, dst, grid, h->stream) != 0) return fail(CB_EHIP, "k123_bank: launch failed");
+      if (cb_launch_bank_fused(1, dst, grid, h->stream, bank_stop) != 0) return fail(CB_EHIP, "k123_bank: launch failed");
     } else if (mixed) {
       K123Args<double, float> a{{S, LD, B, h->Vc, h->A, tb, h->F, h->sigma, h->Ct, h->Gt32, h->loss_part, inv_n, h->dsq, nullptr, skipw},
                                 {LD, h->Gt32, h->Uf, h->T32, skipw},
@@ -229,17 +226,15 @@ static int large_eval(cb_bank *h, bool normalize, double *lossd, double *out, bo
       auto *dst = launch(a);
       hipLaunchKernelGGL(lg_cast_f32, dim3((unsigned)((std::max(LL, (size_t)B * LD) + 255) / 256)), dim3(256), 0, h->stream, LL,
                          (size_t)B * LD, h->U, h->Vc, h->A, h->F, h->Uf, h->Utf, h->Af, h->Ff);
-      if (cb_launch_bank_fused(2, dst, grid, h->stream) != 0) return fail(CB_EHIP, "k123_bank: launch failed");
+      if (cb_launch_bank_fused(2, dst, grid, h->stream, bank_stop) != 0) return fail(CB_EHIP, "k123_bank: launch failed");
     } else {
       K123Args<double, double> a{{S, LD, B, h->Vc, h->A, tb, h->F, h->sigma, h->Ct, h->Gt, h->loss_part, inv_n, h->dsq, nullptr, skipw},
                                  {LD, h->Gt, h->U, h->T, skipw},
                                  {LD, B, h->T, h->U, tb, h->lam, h->E, h->H, h->Gt, sym, skipw},
                                  {h->bank_queue, B, tiles_k1, tiles, tiles_k3}};
       auto *dst = launch(a);
-      if (cb_launch_bank_fused(0, dst, grid, h->stream) != 0) return fail(CB_EHIP, "k123_bank: launch failed");
+      if (cb_launch_bank_fused(0, dst, grid, h->stream, bank_stop) != 0) return fail(CB_EHIP, "k123_bank: launch failed");
     }
-    if (h->profile) h->ev_rec[EV_K1] = h->ev_rec[EV_K2] = false;   // CB_T_K1 = the whole launch (+ tables), see read_phase_times
-    mark(h, EV_K3);
     hipLaunchKernelGGL(lg_finish_loss, dim3(1), dim3(256), 0, h->stream, h->loss_part, B * tiles_k1, S,
                        h->dsq, h->dirsum, inv_n, lossd);
     if (f32 || mixed)
@@ -251,8 +246,7 @@ static int large_eval(cb_bank *h, bool normalize, double *lossd, double *out, bo
     K4Args k4a{S, LD, h->Mt, h->Vc, h->X, nullptr, nullptr, nullptr};
     launch_sg(h, k4a, 0);
     K4Args k4b{S, LD, h->Vc, h->X, dQd, dA_padded ? nullptr : h->dsq, nullptr, nullptr};
-    launch_sg(h, k4b, 0);
-    mark(h, EV_K4);
+    launch_sg(h, k4b, 0, 0.0, 0.0, nullptr, stop_event(h, EV_K4));
     HIP_TRY(hipGetLastError());
     return CB_OK;
   }

@@ -325,6 +325,29 @@ extern "C" int cb_create(int device, int S, int L, int B, int dtype, const doubl
       free_tmp();
       return cleanup(CB_ENOMEM);
     }
+    // Everything an evaluation will need is allocated HERE, not on first use: a hipHostMalloc in the middle of an epoch (the
+    // 64 bytes the first-order sweeps publish their statistics to; found with CB_TRACE_SLOW) blocks the host for ~80 ms --
+    // and when its first use fell into a timed region, one bench run in five read 4.5 ms per epoch instead of 1.3.
+    {
+      void *q = nullptr;
+      if (hipHostMalloc(&q, 8 * sizeof(unsigned long long), hipHostMallocCoherent | hipHostMallocMapped) == hipSuccess) {
+        h->poll = (unsigned long long *)q;
+        memset(q, 0, 8 * sizeof(unsigned long long));
+      } else {
+        (void)hipGetLastError();   // (the sweeps then read their statistics through the stream)
+      }
+    }
+    if (!expm_only) {
+      if (dev_alloc(h, &h->bank_queue, (size_t)LG_NQ + 2 * (size_t)B) != CB_OK ||
+          dev_alloc(h, &h->bank_args, sizeof(K123Args<double, double>)) != CB_OK) {
+        free_tmp();
+        return cleanup(CB_ENOMEM);
+      }
+      int dev = 0, cus = 0;
+      if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
+        cus = 256;
+      h->bank_slots = 4 * std::max(cus, 1);
+    }
     if (!expm_only) {
     hipLaunchKernelGGL(prep_counts_large_tot, dim3((unsigned)((SS + 255) / 256)), dim3(256), 0,
                        h->stream, S, B, Cdev, tot);

@@ -8,7 +8,7 @@
 // --------------------------------------------------------------- large path
 // `second`: an independent product of the same kind (ns, alpha, beta) enqueued in the same launch (grid.y = 2)
 static void launch_sg(cb_bank *h, const K4Args &g, int ns, double alpha = 0.0, double beta = 0.0,
-                      const K4Args *second = nullptr) {
+                      const K4Args *second = nullptr, hipEvent_t stop = nullptr) {   // stop: handle_host.hip.h, stop_event()
   // ONE 16 x 16 tile per workgroup, K split over its 8 waves, 7 k-steps in flight.  Shapes measured in situ in round 2
   // (200 epochs of the bench bank, eigh ms per epoch): 16 x 80 strips with 8 waves x 4 k-steps 0.343; 16 x 48 strips
   // 0.320; 16 x 32 0.332; this one 0.300; the same with 16 waves 0.324, with 4 waves 0.310.  These launches are latency
@@ -16,10 +16,38 @@ static void launch_sg(cb_bank *h, const K4Args &g, int ns, double alpha = 0.0, d
   // product against 38 MB for the strips and is still the fastest.  (The other shapes were removed with their switch.)
   const dim3 n1((unsigned)((h->LD / 16) * ((h->LD + 15) / 16)), second ? 2 : 1);
   const K4Args &g2 = second ? *second : g;
-  hipLaunchKernelGGL((sg_gemm<8, 7, 1>), n1, dim3(512), 0, h->stream, g, g2, ns, alpha, beta);
+  LAUNCH_STOP(stop, (sg_gemm<8, 7, 1>), n1, dim3(512), 0, h->stream, g, g2, ns, alpha, beta);
+}
+
+// a scope that reports itself when it took longer than CB_TRACE_SLOW ms (train_host.hip.h)
+struct SlowScope {
+  const char *what;
+  double slow;
+  std::chrono::steady_clock::time_point t0;
+  explicit SlowScope(const char *w) : what(w) {
+    static const double lim = getenv("CB_TRACE_SLOW") ? atof(getenv("CB_TRACE_SLOW")) : 0.0;
+    slow = lim;
+    if (slow > 0.0) t0 = std::chrono::steady_clock::now();
+  }
+  ~SlowScope() {
+    if (slow <= 0.0) return;
+    const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    if (ms > slow) fprintf(stderr, "[cherrybank] slow scope (%s): %.2f ms\n", what, ms);
+  }
+};
+// hipStreamSynchronize with a report when it took longer than CB_TRACE_SLOW ms
+static hipError_t sync_traced(cb_bank *h, const char *where) {
+  static const double slow = getenv("CB_TRACE_SLOW") ? atof(getenv("CB_TRACE_SLOW")) : 0.0;
+  if (slow <= 0.0) return hipStreamSynchronize(h->stream);
+  const auto t0 = std::chrono::steady_clock::now();
+  const hipError_t e = hipStreamSynchronize(h->stream);
+  const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  if (ms > slow) fprintf(stderr, "[cherrybank] slow synchronize (%s): %.2f ms\n", where, ms);
+  return e;
 }
 
 static int large_eigh(cb_bank *h, bool warm) {
+  SlowScope scope_all("large_eigh, host side");
   const int LD = h->LD;
   const size_t LL = (size_t)LD * LD;
   hipLaunchKernelGGL(lgj_sigma, dim3(1), dim3(256), 0, h->stream, LD, h->A, h->sigma, h->off_bits);
@@ -76,6 +104,7 @@ static int large_eigh(cb_bank *h, bool warm) {
   const int ns_from = 2;   // squarings allowed without a Newton-Schulz polish
   const bool dbg_e = getenv("CB_DEBUG") != nullptr;
   auto light_sweep = [&](bool hybrid_ok, double trigger) -> int {
+    SlowScope scope_ls("eigh: one first-order sweep, host side");
     double *Gr = h->gx, *Gam = h->gx + LL, *X = h->gx + 2 * LL, *Xf = h->gx + 3 * LL, *P4 = h->gx + 4 * LL,
            *lo = h->gx + 5 * LL, *hiT = h->gx + 6 * LL, *R = h->gx + 7 * LL, *Rt = h->gx + 8 * LL, *R2 = h->gx + 9 * LL, *Rt2 = h->gx + 10 * LL, *dg = h->gx + 11 * LL;
     const int nt32 = (LD + 31) / 32;
@@ -92,15 +121,7 @@ static int large_eigh(cb_bank *h, bool warm) {
     }
     gr_valid = false;
     launch_sg(h, K4Args{h->S, LD, Gr, Gr, Gam, nullptr, nullptr, nullptr, nullptr, dg}, 0);
-    if (!h->poll) {
-      void *q = nullptr;
-      if (hipHostMalloc(&q, 8 * sizeof(unsigned long long), hipHostMallocCoherent | hipHostMallocMapped) == hipSuccess) {
-        h->poll = (unsigned long long *)q;
-        memset(q, 0, 8 * sizeof(unsigned long long));
-      } else {
-        (void)hipGetLastError();
-      }
-    }
+    // (h->poll: 64 bytes of coherent pinned host memory, allocated with the handle)
     const unsigned long long seq = ++h->poll_seq;
     hipLaunchKernelGGL(lgx_build, dim3((LD + 3) / 4), dim3(256), 0, h->stream, LD, Gam, dg, X, Xf, band, h->off_bits,
                        (volatile unsigned long long *)h->poll, seq, hybrid_ok ? 1 : 0, trigger,
@@ -147,7 +168,7 @@ static int large_eigh(cb_bank *h, bool warm) {
       }
     }
     if (!got && h->poll) {   // a long queue ahead of the sweep: wait for the stream, the words are there then
-      HIP_TRY(hipStreamSynchronize(h->stream));
+      HIP_TRY(sync_traced(h, "eigh: pinned words timed out"));
       volatile unsigned long long *pl = h->poll;
       if (pl[0] != seq) return fail(CB_EHIP, "eigensolver: the sweep statistics never reached the host");
       std::atomic_thread_fence(std::memory_order_acquire);
@@ -159,7 +180,7 @@ static int large_eigh(cb_bank *h, bool warm) {
     }
     if (!got) {
       HIP_TRY(hipMemcpyAsync(m, h->off_bits + 4, 3 * sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
-      HIP_TRY(hipStreamSynchronize(h->stream));
+      HIP_TRY(sync_traced(h, "eigh: first-order sweep statistics"));
     }
     double cosmax, rowsum, rowsum_far;
     memcpy(&cosmax, &m[0], sizeof cosmax);
@@ -298,9 +319,10 @@ static int large_eigh(cb_bank *h, bool warm) {
   bool cold_hybrid_pending = !warm_started && hybrid_on;
   const double cold_switch = 3e-2;
   for (; !converged;) {
-    for (int i = 0; i < batch && enq < max_sweeps; ++i) enqueue_sweep(enq++);
+    { SlowScope scope_ts("eigh: enqueue of tournament sweeps");
+    for (int i = 0; i < batch && enq < max_sweeps; ++i) enqueue_sweep(enq++); }
     HIP_TRY(hipMemcpyAsync(st, h->off_bits, sizeof st, hipMemcpyDeviceToHost, h->stream));
-    HIP_TRY(hipStreamSynchronize(h->stream));
+    HIP_TRY(sync_traced(h, "eigh: tournament sweep statistics"));
     sweep = (int)st[2];
     double c_last = 1.0;
     for (int k = 0; k < sweep && k < 48; ++k) {

@@ -174,7 +174,7 @@ static int enqueue_planned_solve(cb_bank *h, const EighPlan &p, unsigned long lo
   }
   volatile unsigned long long *pin = h->epin + (size_t)(seq & 1ull) * (EC_WORDS + 16);
   hipLaunchKernelGGL(lge_norms, dim3((LD + 3) / 4), dim3(256), 0, h->stream, LD, Gb[0], Gb[1], h->X, ctl, pin, seq);
-  hipLaunchKernelGGL(lge_finish, dim3((LD + 3) / 4), dim3(256), 0, h->stream, LD, Gb[0], Gb[1], h->X, h->sigma, h->lam, h->U, h->Vc,
+  LAUNCH_STOP(stop_event(h, EV_EIGH), lge_finish, dim3((LD + 3) / 4), dim3(256), 0, h->stream, LD, Gb[0], Gb[1], h->X, h->sigma, h->lam, h->U, h->Vc,
                      ctl);
   HIP_TRY(hipGetLastError());
   return CB_OK;

@@ -1,6 +1,7 @@
 // The handle (`struct cb_bank`) and its host-side helpers: event sets of the phase timer, device / workspace /
 // pinned-staging allocation.  Included by cherrybank.hip (one translation unit; see eigh_large_host.hip.h).
 #pragma once
+#include <hip/hip_ext.h>
 // ------------------------------------------------------------------ handle
 // plan of a device-controlled warm eigensolve (eigh_planned_host.hip.h)
 struct EighSlot {
@@ -131,6 +132,23 @@ static void mark(cb_bank *h, int which) {
   (void)hipEventRecord(h->ev[which], h->stream);
   h->ev_rec[which] = true;
 }
+
+// The same mark WITHOUT a packet of its own between two kernels (hipEventRecord costs ~4-6 us of idle GPU there, 23 us per
+// epoch for the four phase marks): the event rides on the phase's LAST kernel as its stop event (hipExtLaunchKernelGGL;
+// profiles/tools/ext_event_probe: +0.0 us per launch, a START event costs 5 us).  stop_event() returns the event to pass --
+// null when the call is not profiled, and the launch is then a plain one.
+static hipEvent_t stop_event(cb_bank *h, int which) {
+  if (!h->profile) return nullptr;
+  if (!h->ev[which] && hipEventCreate(&h->ev[which]) != hipSuccess) return nullptr;
+  h->ev_rec[which] = true;
+  return h->ev[which];
+}
+#define LAUNCH_STOP(ev, kernel, grid, block, shmem, stream, ...)                                              \
+  do {                                                                                                        \
+    hipEvent_t ev_ = (ev);                                                                                    \
+    if (ev_) hipExtLaunchKernelGGL(kernel, grid, block, shmem, stream, nullptr, ev_, 0, __VA_ARGS__);         \
+    else hipLaunchKernelGGL(kernel, grid, block, shmem, stream, __VA_ARGS__);                                 \
+  } while (0)
 
 template <typename T>
 static int dev_alloc(cb_bank *h, T **p, size_t count) {

@@ -123,21 +123,27 @@ static int run_fused_training_large(cb_bank *h, double *pi_param, double *up_par
     if (short_plans >= 2) plan.slot[0] = EighSlot{2, 0, plan.slot[0].band_after, 0};
   };
   shorten();
+  // CB_TRACE_SLOW=<ms>: report every epoch whose HOST side took longer than that (where the host waited: the fold of an older
+  // epoch's events, the enqueue, the planned solve's record) -- the tool for "one run in five is 3x slower"
+  const double trace_slow = getenv("CB_TRACE_SLOW") ? atof(getenv("CB_TRACE_SLOW")) : 0.0;
   for (int e = 0; e < E && rc == CB_OK; ++e) {
+    const double te0 = trace_slow > 0.0 ? now() : 0.0;
+    double te_fold = 0.0, te_enq = 0.0, te_rec = 0.0;
     if (h->profile) {  // fold the epoch before the previous one (its events are long complete), then re-record that set
       swap_event_sets(h);
       fold_pending(h);
     }
+    if (trace_slow > 0.0) te_fold = now();
     for (bool &b : h->ev_rec) b = false;
     hipLaunchKernelGGL(lt_pi, dim3(1), dim3(256), 0, h->stream, a);
-    hipLaunchKernelGGL(lt_build, dim3(LD), dim3(256), 0, h->stream, a, e0 + e);
-    mark(h, EV_START);
+    LAUNCH_STOP(stop_event(h, EV_START), lt_build, dim3(LD), dim3(256), 0, h->stream, a, e0 + e);
     // Every solve after the first is a PLAN (eigh_planned_host.hip.h): the device takes the sweep decisions, the host enqueues
     // the whole epoch and only then looks at the solve's record -- with K1 .. K4 queued behind it, so the GPU never waits.
     // (the first warm solves of an optimisation start far from converged -- cosines of 1e-2, every sweep damped --: they stay
     // with the host-driven solver, whose tournament sweeps are made for that; plans from the fourth epoch on)
     const bool use_plan = planned && h->have_prev && e0 + e >= 3;
     rc = large_eval(h, flags & CB_NORMALIZE, h->loss, h->Mt, true, nullptr, false, use_plan ? &plan : nullptr);
+    if (trace_slow > 0.0) te_enq = now();
     if (rc == CB_OK && use_plan) {
       EighRecord rec;
       rc = eigh_planned_record(h, h->eseq, rec);
@@ -170,6 +176,12 @@ static int run_fused_training_large(cb_bank *h, double *pi_param, double *up_par
         shorten();
         h->last_sweeps = rec.nsweep;
       }
+    }
+    if (trace_slow > 0.0) {
+      te_rec = now();
+      if (te_rec - te0 > trace_slow)
+        fprintf(stderr, "[cherrybank] slow epoch %d (host): fold %.2f ms, enqueue %.2f ms, record / continuations %.2f ms\n", e0 + e,
+                te_fold - te0, te_enq - te_fold, te_rec - te_enq);
     }
     if (rc == CB_OK && fault_epoch == e) rc = fail(CB_ENUMERIC, "injected fault at epoch %d (CB_FAULT_INJECT)", e);
     if (rc != CB_OK && h->comm) {
