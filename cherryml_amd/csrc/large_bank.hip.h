@@ -128,6 +128,8 @@ __device__ __forceinline__ void lg4_gemm_tile(const GemmOperands<T> &g, int m0, 
   // (tid: threadIdx.x -- or an opaque copy of it, k123_bank: what is derived from it then stays inside the tile)
   // deferred (k123_bank): the counter that announces the PREVIOUS tile of this workgroup; bumped here, behind the wait for
   // this tile's first panels, where the wait for the previous tile's stores costs nothing
+  // (Measured and dropped: K1 reading one element of every cache line of its two count tiles during its last four K-steps, so
+  // that the epilogue's count loads hit the L2 -- +20 us, 0.726 against 0.706 ms: those K-steps' vmcnt(0) then waits for HBM.)
   typedef typename Mfma<T>::acc_t acc_t;
   typedef typename Mfma<T>::vec_t vec_t;
   const int wave = tid >> 6, lane = tid & 63, lo = lane & 15, hi = lane >> 4;
