@@ -29,3 +29,22 @@ for dt in f64 mixed f32; do
     --output-format csv -d $R/gpurun_out/${TAG}_pmc_sq_$dt -- \
     python3 $R/bench.py --dtype $dt --steps 3 --warmup 1 --no-cpu-baseline --no-secondary > /dev/null 2>&1
 done
+# the three bank products as separate launches (CB_BANK_UNFUSED=1): the per-kernel reference of the fused launch
+export CB_BANK_UNFUSED=1
+python3 $R/bench.py --no-cpu-baseline --no-secondary --steps 20 --warmup 5 > $R/gpurun_out/${TAG}_bench_coevo400_unfused.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${TAG}_trace_coevo400_unfused -- \
+  python3 $R/bench.py --no-cpu-baseline --no-secondary --steps 20 --warmup 5 > $R/gpurun_out/${TAG}_benchprof_coevo400_unfused.log 2>&1
+unset CB_BANK_UNFUSED
+# in-kernel stamps of the bank's tiles (diagnostic build, -DCB_CLOCK_STAMP): tile timelines of the fused launch and of the three
+# separate ones, and the clock held inside the K loops; the shipped build is restored afterwards
+cd $R
+export CB_EXTRA_HIPCC_FLAGS=-DCB_CLOCK_STAMP
+python3 -c "from cherryml_amd import _build; _build.build()" > gpurun_out/${TAG}_stamp_build.log 2>&1
+python3 profiles/tools/clock_probe.py 60 > gpurun_out/${TAG}_clock_probe_fused.json 2>> gpurun_out/${TAG}_stamp_build.log
+python3 profiles/tools/stamp_timeline.py gpurun_out/clock_stamps_60_epochs.npy 25 > gpurun_out/${TAG}_tile_timeline_fused.txt
+export CB_BANK_UNFUSED=1
+python3 profiles/tools/clock_probe.py 60 > gpurun_out/${TAG}_clock_probe_separate.json 2>> gpurun_out/${TAG}_stamp_build.log
+python3 profiles/tools/stamp_timeline.py gpurun_out/clock_stamps_60_epochs.npy 25 > gpurun_out/${TAG}_tile_timeline_separate.txt
+unset CB_BANK_UNFUSED
+unset CB_EXTRA_HIPCC_FLAGS
+python3 -c "from cherryml_amd import _build; _build.build()" >> gpurun_out/${TAG}_stamp_build.log 2>&1

@@ -32,7 +32,7 @@ import datetime
 STAMP = {"round": rnd, "collected": datetime.datetime.now(datetime.timezone.utc).strftime("%Y-%m-%d")}
 out = {**STAMP, "bytes_per_launch": {}, "detail": {}, "calibration": {},
        "source": f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), gpurun_out/{tag}_pmc_*"}
-NAMES = ["k1_pt_loss_gt", "k2_t_eq_g_u", "k3_w_phi", "lgj_round", "lg_transpose_pad", "small_train_kernel", "small_bank_kernel",
+NAMES = ["k123_bank", "k1_pt_loss_gt", "k2_t_eq_g_u", "k3_w_phi", "lgj_round", "lg_transpose_pad", "small_train_kernel", "small_bank_kernel",
          "lg_prepare", "lg_bank", "lg_finish", "count_transitions_lds_kernel", "count_reduce_slabs", "k3_reduce", "sp_prepare",
          "sp_bank", "sp_finish", "sp_step", "sg_gemm", "co_bucket_kernel", "co_plan_kernel", "co_expand_kernel", "co_count_lds_kernel", "lgx_build", "ble_branch_lengths_kernel", "ble_site_rates_kernel",
          "siterm_raw_counts_kernel", "siterm_mix_kernel", "tl_mfma_kernel", "tl_leaf_kernel", "tl_group_kernel", "lg_cast_f32", "lge_gram", "lge_gemm", "lge_so", "lge_decide", "lge_poly",
@@ -45,10 +45,10 @@ def kshort(full):
     """kernel family + element type of the templated bank kernels (k2_t_eq_g_u<float> -> k2_t_eq_g_u_f32)"""
     for short in NAMES:
         if short in full:
-            if short in ("k1_pt_loss_gt", "k2_t_eq_g_u", "k3_w_phi", "k3_reduce"):
+            if short in ("k123_bank", "k1_pt_loss_gt", "k2_t_eq_g_u", "k3_w_phi", "k3_reduce"):
                 if "<float" in full:
                     return short + "_f32"
-                if short == "k1_pt_loss_gt" and "<double, float" in full:
+                if short in ("k1_pt_loss_gt", "k123_bank") and "<double, float" in full:
                     return short + "_mixed"
             return short
     return None
@@ -99,7 +99,16 @@ co = ("co_bucket_kernel", "co_plan_kernel", "co_expand_kernel", "co_count_lds_ke
 if all(f"{k}:co_counting" in bpl for k in co):
     bpl["pass:co_counting"] = sum(bpl[f"{k}:co_counting"] for k in co)
 json.dump(out, open(f"{here}/pmc_traffic.json", "w"), indent=1)
-for name in ("bench_default", "bench_driver"):
+for src, dst in ((f"{tag}_tile_timeline_fused.txt", f"{rnd}_bank_tile_timeline_fused.txt"),
+                 (f"{tag}_tile_timeline_separate.txt", f"{rnd}_bank_tile_timeline_separate.txt"),
+                 (f"{tag}_clock_probe_fused.json", f"{rnd}_bank_clock_probe_fused.json"),
+                 (f"{tag}_clock_probe_separate.json", f"{rnd}_bank_clock_probe_separate.json")):
+    if os.path.exists(f"{root}/gpurun_out/{src}"):
+        shutil.copy(f"{root}/gpurun_out/{src}", f"{here}/{dst}")
+st = newest(f"{root}/gpurun_out/{tag}_trace_coevo400_unfused/*/*_kernel_stats.csv")
+if st:
+    shutil.copy(st[0], f"{here}/{rnd}_{tag}_coevo400_unfused_kernel_stats.csv")
+for name in ("bench_default", "bench_driver", "bench_coevo400_unfused"):
     d = f"{root}/gpurun_out/{tag}_{name}.log"
     if os.path.exists(d):
         line = [l for l in open(d) if l.startswith("{")]
@@ -122,7 +131,7 @@ for dt, w in (("f64", "coevo400"), ("mixed", "coevo400_mixed"), ("f32", "coevo40
     agg = collections.defaultdict(lambda: collections.defaultdict(list))
     for r in csv.DictReader(open(fs[0])):
         short = kshort(r["Kernel_Name"])
-        if short and short.startswith(("k1_", "k2_", "k3_w")):
+        if short and short.startswith(("k123_", "k1_", "k2_", "k3_w")):
             agg[short][r["Counter_Name"]].append(float(r["Counter_Value"]))
     for k, d in agg.items():
         m = {c: sum(v) / len(v) for c, v in d.items()}

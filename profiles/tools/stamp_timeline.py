@@ -24,3 +24,21 @@ for t in np.arange(5, tend + step, step):
         st, ke, en = [(s[:, c] - t0) * 0.01 for c in (2, 3, 4)]
         row.append((int(np.sum((st <= t) & (ke > t))), int(np.sum((ke <= t) & (en > t)))))
     print(f"  {t:6.0f} | {sum(a + c for a, c in row):5d} | K1 {row[0]}  K2 {row[1]}  K3 {row[2]}")
+# slots (CU, wave slot of wave 0): how busy, and the gap between consecutive tiles of one slot (fused launch: ticket draw etc.)
+allt = np.concatenate(S)
+hw = allt[:, 5]
+key = (hw >> 32) * 100000 + ((hw >> 13) & 7) * 10000 + ((hw >> 12) & 1) * 1000 + ((hw >> 8) & 0xf) * 10 + (hw & 0xf) % 4
+busy = float(((allt[:, 4] - allt[:, 2]) * 0.01).sum())
+nslots = len(np.unique(key))
+gaps, ends = [], []
+for k in np.unique(key):
+    t = allt[key == k]
+    t = t[np.argsort(t[:, 2])]
+    gaps.extend(((t[1:, 2] - t[:-1, 4]) * 0.01).tolist())
+    ends.append((t[-1, 4] - t0) * 0.01)
+gaps, ends = np.array(gaps), np.array(ends)
+print(f"{nslots} slots; busy slot-time / slots = {busy / nslots:.1f} us of {tend:.1f} us ({busy / nslots / tend:.2f}); "
+      f"sum of K-loop matrix work at 100 % = {sum(len(s) for s in S) * 625 * 64 * 4 / 1024 / 2400.0:.1f} us (625 MFMAs of 64 cycles per wave and tile, 1024 SIMDs at 2.4 GHz)")
+if len(gaps):
+    print(f"gap between consecutive tiles of a slot: median {np.median(gaps):.2f} us, mean {gaps.mean():.2f}, p90 {np.percentile(gaps, 90):.2f}"
+          f"; slots finish at p10 {np.percentile(ends, 10):.0f} / median {np.median(ends):.0f} / max {ends.max():.0f} us")
