@@ -132,7 +132,8 @@ __device__ __forceinline__ void lg4_gemm_tile(const GemmOperands<T> &g, int m0, 
   // that the epilogue's count loads hit the L2 -- +20 us, 0.726 against 0.706 ms: those K-steps' vmcnt(0) then waits for HBM.)
   typedef typename Mfma<T>::acc_t acc_t;
   typedef typename Mfma<T>::vec_t vec_t;
-  const int wave = tid >> 6, lane = tid & 63, lo = lane & 15, hi = lane >> 4;
+  // (the wave index as a SCALAR: the tests on it in the K loop are then scalar branches, not v_cmp + exec masks)
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, lo = lane & 15, hi = lane >> 4;
   if (ZERO) {
 #pragma unroll
     for (int j = 0; j < 5; ++j) acc[j] = acc_t{};
@@ -166,7 +167,9 @@ __device__ __forceinline__ void lg4_gemm_tile(const GemmOperands<T> &g, int m0, 
 #pragma unroll
       for (int j = 0; j < 5; ++j) acc[j] = Mfma<T>::mma(av, bv[j], acc[j]);
       // tile (4, wave): column block `wave` (a wave-uniform choice among registers)
-      const T bx = wave == 0 ? bv[0] : wave == 1 ? bv[1] : wave == 2 ? bv[2] : bv[3];
+      // (read from LDS again rather than chosen among bv[0..3] with six v_cndmask per sub-step: the MFMAs share the vector
+      // issue port, every VALU instruction of the K loop costs matrix time -- 0.707 -> 0.685 ms for the bank)
+      const T bx = cB[(4 * s + hi) * LG_TN + 16 * wave + lo];
       ax0 = Mfma<T>::mma(a4, bx, ax0);
       // tile (4, 4): its K range is dealt round-robin to the four waves (6.25 MFMA tiles each
       // instead of 7/6/6/6); the partial sums meet in wave 0 below
