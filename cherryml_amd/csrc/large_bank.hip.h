@@ -87,19 +87,20 @@ __device__ __forceinline__ void lg4_load_panel(const T *__restrict__ P, int ld, 
                                                int k0, int c0, typename Mfma<T>::vec_t (&reg)[Panel<T>::NL],
                                                const T *__restrict__ kscale, T &sc, int tid) {
   typedef typename Mfma<T>::vec_t vec_t;
-  constexpr int VEC = Panel<T>::VEC, NL = Panel<T>::NL, LAST = Panel<T>::LAST;
+  constexpr int VEC = Panel<T>::VEC, NL = Panel<T>::NL;
   const int kr = tid >> 4, cq = tid & 15;
-  const int k = k0 + kr;
-  const T *row = P + (size_t)k * ld + c0 + VEC * cq;
+  // No bounds logic and no vector address arithmetic in the K loop (the MFMAs share the vector issue port: the checks -- six
+  // exec-mask branches and two dozen v_mov of zero fill per K-step -- cost 22 us of the bank's 680).  K (= rows_total) is a
+  // multiple of the K-step; a column past the matrix (a tile that hangs over its edge, the idle lanes of the last chunk) is
+  // CLAMPED to the row's last chunk instead of zero-filled: what it brings only reaches outputs past the edge, which every
+  // epilogue discards.  Address = (uniform base of the K-step, advanced with scalar adds) + (this thread's offsets, the same
+  // in every K-step).
+  (void)rows_total;
+  const T *base = P + (size_t)k0 * ld;
 #pragma unroll
-  for (int u = 0; u < NL; ++u) {
-    const int c = c0 + VEC * (cq + 16 * u);
-    if ((u < NL - 1 || cq < LAST) && k < rows_total && c < cols_total)
-      reg[u] = *reinterpret_cast<const vec_t *>(row + 16 * VEC * u);
-    else
-      reg[u] = vec_t{};
-  }
-  if (SCALE) sc = k < rows_total ? kscale[k] : T(0);
+  for (int u = 0; u < NL; ++u)
+    reg[u] = *reinterpret_cast<const vec_t *>(base + (kr * ld + min(c0 + VEC * (cq + 16 * u), cols_total - VEC)));
+  if (SCALE) sc = kscale[k0 + kr];
 }
 template <typename T, bool SCALE>
 __device__ __forceinline__ void lg4_store_panel(T *s, const typename Mfma<T>::vec_t (&reg)[Panel<T>::NL], T sc, int tid) {
