@@ -82,25 +82,38 @@ template <typename T> struct Panel {
   static constexpr int NL = (CH + 15) / 16;        // loads per thread: 3 / 2
   static constexpr int LAST = CH - 16 * (NL - 1);  // threads (of 16 per row) that take part in the last one: 8 / 4
 };
-template <typename T, bool SCALE>
-__device__ __forceinline__ void lg4_load_panel(const T *__restrict__ P, int ld, int rows_total, int cols_total,
-                                               int k0, int c0, typename Mfma<T>::vec_t (&reg)[Panel<T>::NL],
-                                               const T *__restrict__ kscale, T &sc, int tid) {
-  typedef typename Mfma<T>::vec_t vec_t;
+// Panel loads are BUFFER loads: address = resource (the operand's base, four SGPRs, made once per tile) + this thread's
+// byte offsets (the same in every K-step) + the K-step's byte offset (a scalar): no vector address arithmetic in the K loop,
+// and no bounds logic -- the MFMAs share the vector issue port, and the checks (six exec-mask branches, two dozen v_mov of
+// zero fill per K-step) cost 22 us of the bank's 680.  K is a multiple of the K-step; a column past the matrix (a tile that
+// hangs over its edge, the idle lanes of the last chunk) is CLAMPED to the row's last chunk instead of zero-filled: what it
+// brings only reaches outputs past the edge, which every epilogue discards.
+typedef unsigned int lg_u4 __attribute__((ext_vector_type(4)));
+template <typename T> struct PanelSrc {
+  __amdgpu_buffer_rsrc_t rsrc;
+  int voff[Panel<T>::NL];   // bytes
+};
+template <typename T>
+__device__ __forceinline__ PanelSrc<T> lg4_panel_src(const T *P, int ld, int cols_total, int c0, int tid) {
   constexpr int VEC = Panel<T>::VEC, NL = Panel<T>::NL;
   const int kr = tid >> 4, cq = tid & 15;
-  // No bounds logic and no vector address arithmetic in the K loop (the MFMAs share the vector issue port: the checks -- six
-  // exec-mask branches and two dozen v_mov of zero fill per K-step -- cost 22 us of the bank's 680).  K (= rows_total) is a
-  // multiple of the K-step; a column past the matrix (a tile that hangs over its edge, the idle lanes of the last chunk) is
-  // CLAMPED to the row's last chunk instead of zero-filled: what it brings only reaches outputs past the edge, which every
-  // epilogue discards.  Address = (uniform base of the K-step, advanced with scalar adds) + (this thread's offsets, the same
-  // in every K-step).
-  (void)rows_total;
-  const T *base = P + (size_t)k0 * ld;
+  PanelSrc<T> s;
+  // (raw buffer, stride 0, range = 2 GB: the offsets below stay inside one LD x LD matrix)
+  s.rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<T *>(P), 0, 0x7fffffff, 0x00027000);
+#pragma unroll
+  for (int u = 0; u < NL; ++u) s.voff[u] = (kr * ld + min(c0 + VEC * (cq + 16 * u), cols_total - VEC)) * (int)sizeof(T);
+  return s;
+}
+template <typename T, bool SCALE>
+__device__ __forceinline__ void lg4_load_panel(const PanelSrc<T> &src, int ld, int k0, typename Mfma<T>::vec_t (&reg)[Panel<T>::NL],
+                                               const T *__restrict__ kscale, T &sc, int tid) {
+  typedef typename Mfma<T>::vec_t vec_t;
+  constexpr int NL = Panel<T>::NL;
+  const int soff = k0 * ld * (int)sizeof(T);
 #pragma unroll
   for (int u = 0; u < NL; ++u)
-    reg[u] = *reinterpret_cast<const vec_t *>(base + (kr * ld + min(c0 + VEC * (cq + 16 * u), cols_total - VEC)));
-  if (SCALE) sc = kscale[k0 + kr];
+    reg[u] = __builtin_bit_cast(vec_t, __builtin_amdgcn_raw_buffer_load_b128(src.rsrc, src.voff[u], soff, 0));
+  if (SCALE) sc = kscale[k0 + (tid >> 4)];
 }
 template <typename T, bool SCALE>
 __device__ __forceinline__ void lg4_store_panel(T *s, const typename Mfma<T>::vec_t (&reg)[Panel<T>::NL], T sc, int tid) {
@@ -144,8 +157,9 @@ __device__ __forceinline__ void lg4_gemm_tile(const GemmOperands<T> &g, int m0, 
   vec_t ra[Panel<T>::NL], rb[Panel<T>::NL];
   T sc = T(1), one = T(1);
   const int nk = g.K / LG_KT;
-  lg4_load_panel<T, SCALE>(g.A, g.lda, g.K, g.M, 0, m0, ra, g.kscale, sc, tid);
-  lg4_load_panel<T, false>(g.B, g.ldb, g.K, g.N, 0, n0, rb, nullptr, one, tid);
+  const PanelSrc<T> srcA = lg4_panel_src<T>(g.A, g.lda, g.M, m0, tid), srcB = lg4_panel_src<T>(g.B, g.ldb, g.N, n0, tid);
+  lg4_load_panel<T, SCALE>(srcA, g.lda, 0, ra, g.kscale, sc, tid);
+  lg4_load_panel<T, false>(srcB, g.ldb, 0, rb, nullptr, one, tid);
   __syncthreads();  // the previous tile's readers of buffer 0 are done
   lg4_store_panel<T, SCALE>(sA, ra, sc, tid);
   lg4_store_panel<T, false>(sB, rb, one, tid);
@@ -155,8 +169,8 @@ __device__ __forceinline__ void lg4_gemm_tile(const GemmOperands<T> &g, int m0, 
   for (int kt = 0; kt < nk; ++kt) {
     const T *cA = sA + (kt & 1) * (LG_KT * LG_TM), *cB = sB + (kt & 1) * (LG_KT * LG_TN);
     if (kt + 1 < nk) {
-      lg4_load_panel<T, SCALE>(g.A, g.lda, g.K, g.M, (kt + 1) * LG_KT, m0, ra, g.kscale, sc, tid);
-      lg4_load_panel<T, false>(g.B, g.ldb, g.K, g.N, (kt + 1) * LG_KT, n0, rb, nullptr, one, tid);
+      lg4_load_panel<T, SCALE>(srcA, g.lda, (kt + 1) * LG_KT, ra, g.kscale, sc, tid);
+      lg4_load_panel<T, false>(srcB, g.ldb, (kt + 1) * LG_KT, rb, nullptr, one, tid);
     }
 #pragma unroll
     for (int s = 0; s < LG_KT / 4; ++s) {
