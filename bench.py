@@ -38,7 +38,41 @@ import os
 import sys
 import time
 
-import numpy as np
+
+def cpu_budget() -> int:
+    """CPUs this process may really use: the affinity mask capped by the container's CFS quota (cgroup v2 cpu.max, v1
+    cpu.cfs_quota_us).  The GPU boxes report 256 CPUs under a quota of 16: numpy / torch then start 256 threads, the cgroup
+    is throttled (cpu.stat: ~35 throttled periods and 60 s of throttled thread time per bench run) and the throttled
+    periods land on the thread that feeds the GPU -- 70-95 ms with nothing enqueued, anywhere in the first epochs, so that
+    one run in five read 4.5 ms per epoch instead of 1.2 (found with CB_TRACE_SLOW)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        n = os.cpu_count() or 1
+    for path_q, path_p in (("/sys/fs/cgroup/cpu.max", None), ("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "/sys/fs/cgroup/cpu/cpu.cfs_period_us")):
+        try:
+            if path_p is None:
+                q, p = open(path_q).read().split()[:2]
+            else:
+                q, p = open(path_q).read().strip(), open(path_p).read().strip()
+            if q not in ("max", "-1") and int(p) > 0:
+                n = min(n, max(1, int(q) // int(p)))
+            break
+        except (OSError, ValueError):
+            continue
+    return max(1, n)
+
+
+# host threads: the budget shared by the ranks of this job, one core of each rank left to the thread that feeds the GPU; idle
+# OpenMP workers sleep instead of spinning (set BEFORE numpy / torch load their thread pools)
+CPU_BUDGET = cpu_budget()
+HOST_THREADS = max(1, CPU_BUDGET // max(1, int(os.environ.get("WORLD_SIZE", "1"))) - 1)
+for _k in ("OMP_NUM_THREADS", "MKL_NUM_THREADS", "OPENBLAS_NUM_THREADS"):
+    os.environ.setdefault(_k, str(HOST_THREADS))
+os.environ.setdefault("KMP_BLOCKTIME", "0")
+os.environ.setdefault("OMP_WAIT_POLICY", "PASSIVE")
+
+import numpy as np   # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -262,6 +296,8 @@ def launch_ranks(n, argv, child=None, grace=15.0, poll=0.05, _attempt=0):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), CB_BENCH_LAUNCHER="1")
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC only on these hosts (RCCL across processes)
+        for k in ("OMP_NUM_THREADS", "MKL_NUM_THREADS", "OPENBLAS_NUM_THREADS"):   # the ranks SHARE the CPU budget
+            env[k] = str(max(1, CPU_BUDGET // n - 1))
         # rank 0's stdout is the result; the other ranks' stdout joins the launcher's stderr
         procs.append(subprocess.Popen(cmd + list(argv), env=env, stdout=subprocess.PIPE if r == 0 else sys.stderr))
     import threading

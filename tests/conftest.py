@@ -1,8 +1,30 @@
 import os
 import sys
 
-import numpy as np
-import pytest
+
+def _cpu_budget():
+    """CPUs the container's CFS quota really grants (bench.py, cpu_budget(): the GPU boxes report 256 CPUs under a quota of
+    16; 256 numpy / torch threads get the whole cgroup throttled)"""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        n = os.cpu_count() or 1
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max" and int(p) > 0:
+            n = min(n, max(1, int(q) // int(p)))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
+
+
+for _k in ("OMP_NUM_THREADS", "MKL_NUM_THREADS", "OPENBLAS_NUM_THREADS"):   # before numpy / torch load their thread pools
+    os.environ.setdefault(_k, str(max(1, _cpu_budget() - 1)))
+os.environ.setdefault("KMP_BLOCKTIME", "0")
+os.environ.setdefault("OMP_WAIT_POLICY", "PASSIVE")
+
+import numpy as np   # noqa: E402
+import pytest   # noqa: E402
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
