@@ -94,7 +94,7 @@ static int run_fused_training_large(cb_bank *h, double *pi_param, double *up_par
     TRYH(hipMemsetAsync(d_Ql, 0, SS * sizeof(double), h->stream));
   }
   if (mask && !resume) TRYH(h2d_staged(h, d_mask, mask, SS * sizeof(double)));   // (a resumed call: the same mask, see `sig`, still there)
-  const double init_state[2] = {INFINITY, 0.0};
+  const double init_state[2] = {INFINITY, INFINITY};   // best loss so far, two words in turn (lt_step)
   LargeTrain a{};
   a.S = S; a.LD = LD; a.do_adam = do_adam; a.n_pow2 = d_Qp ? n_pow2 : 0;
   a.epoch0 = e0;
@@ -145,7 +145,6 @@ static int run_fused_training_large(cb_bank *h, double *pi_param, double *up_par
     }
     if (trace_slow > 0.0) te_fold = now();
     for (bool &b : h->ev_rec) b = false;
-    hipLaunchKernelGGL(lt_pi, dim3(1), dim3(256), 0, h->stream, a);
     LAUNCH_STOP(stop_event(h, EV_START), lt_build, dim3(LD), dim3(256), 0, h->stream, a, e0 + e);
     // Every solve after the first is a PLAN (eigh_planned_host.hip.h): the device takes the sweep decisions, the host enqueues
     // the whole epoch and only then looks at the solve's record -- with K1 .. K4 queued behind it, so the GPU never waits.
@@ -225,8 +224,7 @@ static int run_fused_training_large(cb_bank *h, double *pi_param, double *up_par
     pow_b1 *= a.beta1;
     pow_b2 *= a.beta2;
     hipLaunchKernelGGL(lt_gd, dim3((S + 3) / 4), dim3(256), 0, h->stream, a);
-    hipLaunchKernelGGL(lt_step_pi, dim3(1), dim3(256), 0, h->stream, a, e0 + e, 1.0 - pow_b1, std::sqrt(1.0 - pow_b2));
-    hipLaunchKernelGGL(lt_step_up, dim3(S), dim3(256), 0, h->stream, a, 1.0 - pow_b1, std::sqrt(1.0 - pow_b2));
+    hipLaunchKernelGGL(lt_step, dim3(S + 1), dim3(256), 0, h->stream, a, e0 + e, 1.0 - pow_b1, std::sqrt(1.0 - pow_b2));
     if (hipGetLastError() != hipSuccess) rc = fail(CB_EHIP, "fused training launch failed");
   }
   TRYH(hipStreamSynchronize(h->stream));

@@ -2,14 +2,12 @@
 // (trainer.py:156-218 with rate.py:167-188, "pande_reversible") driven from C, no torch in the
 // loop.  Same closed-form chain rule as train_small.hip.h, spread over the chip:
 //
-//   lt_pi        pi = softmax(log_pi), d = sqrt(pi)                          1 workgroup
-//   lt_build     A (padded, symmetric) straight from the parameters,
+//   lt_build     pi = softmax(log_pi), d = sqrt(pi); A (padded, symmetric) straight from the parameters,
 //                Q of this epoch -> Q_last (+ power-of-two snapshot)        1 workgroup per row
 //   eigh, K1..K4 loss and G = dL/dA                                          (large_bank.hip.h)
 //   lt_gd        dL/d log d_k (one wave per k)
-//   lt_step_pi   loss curve, best-iterate flag, Adam / SGD on log_pi         1 workgroup
-//   lt_step_up   Adam / SGD on the S(S-1)/2 upper-diagonal logits,
-//                Q_best <- Q_last when this epoch improved                   1 workgroup per row
+//   lt_step      Adam / SGD on the S(S-1)/2 upper-diagonal logits, Q_best <- Q_last when this epoch
+//                improved (1 workgroup per row) + loss curve, best loss, Adam / SGD on log_pi (1 workgroup)
 //
 //   A_ij = R_ij = softplus(up_k) mask_ij,  A_ii = -sum_j R_ij d_j / d_i,  Q_ij = R_ij d_j / d_i
 //   dR_ij = mask_ij (G_ij - G_ii d_j / d_i);  dup_k = sigmoid(up_k) (dR_ij + dR_ji)
@@ -32,7 +30,7 @@ struct LargeTrain {
   const double *dirsum;                 // [S]
   double inv_n;
   double *gd;                           // [S] scratch: dL/d log d
-  double *state;                        // [0] best loss so far, [1] improved flag of this epoch
+  double *state;                        // [epoch & 1]: best loss before that epoch (lt_step)
   double *loss_curve;                   // [E]
   double *Q_last, *Q_best, *Q_pow2;     // [S][S], [S][S], [n_pow2][S][S]
 };
@@ -49,43 +47,52 @@ __device__ __forceinline__ double lt_block_sum(double v, double *s) {  // 256 th
   return r;
 }
 
-__global__ __launch_bounds__(256) void lt_pi(LargeTrain a) {
-  __shared__ double s[256];
-  const int S = a.S;
-  double mx = -INFINITY;
-  for (int k = threadIdx.x; k < S; k += 256) mx = fmax(mx, a.p_pi[k]);
-  s[threadIdx.x] = mx;
-  __syncthreads();
-  for (int st = 128; st >= 1; st >>= 1) {
-    if ((int)threadIdx.x < st) s[threadIdx.x] = fmax(s[threadIdx.x], s[threadIdx.x + st]);
-    __syncthreads();
-  }
-  mx = s[0];
-  __syncthreads();
-  double acc = 0.0;
-  for (int k = threadIdx.x; k < S; k += 256) acc += exp(a.p_pi[k] - mx);
-  const double sum = lt_block_sum(acc, s);
-  for (int k = threadIdx.x; k < a.LD; k += 256) {
-    const double p = k < S ? exp(a.p_pi[k] - mx) / sum : 0.0;
-    a.pi[k] = p;
-    a.dsq[k] = k < S ? sqrt(p) : 1.0;
-  }
-}
-
+// pi = softmax(log_pi) and d = sqrt(pi) are recomputed by EVERY row's workgroup (400 exponentials: nothing) with the same
+// fixed-order reductions, so that the build needs no launch in front of it; workgroup i publishes pi_i, d_i for the kernels
+// behind it (pad rows: 0 / 1).
 __global__ __launch_bounds__(256) void lt_build(LargeTrain a, int epoch) {
   __shared__ double s[256];
+  __shared__ double sd[1024];   // d_j (LD <= 1024)
   const int S = a.S, LD = a.LD, i = blockIdx.x;
   double *Arow = a.A + (size_t)i * LD;
   if (i >= S) {
     for (int j = threadIdx.x; j < LD; j += 256) Arow[j] = 0.0;
+    if (threadIdx.x == 0) {
+      a.pi[i] = 0.0;
+      a.dsq[i] = 1.0;
+    }
     return;
+  }
+  {
+    double mx = -INFINITY;
+    for (int k = threadIdx.x; k < S; k += 256) mx = fmax(mx, a.p_pi[k]);
+    s[threadIdx.x] = mx;
+    __syncthreads();
+    for (int st = 128; st >= 1; st >>= 1) {
+      if ((int)threadIdx.x < st) s[threadIdx.x] = fmax(s[threadIdx.x], s[threadIdx.x + st]);
+      __syncthreads();
+    }
+    mx = s[0];
+    __syncthreads();
+    double acc = 0.0;
+    for (int k = threadIdx.x; k < S; k += 256) acc += exp(a.p_pi[k] - mx);
+    const double sum = lt_block_sum(acc, s);
+    for (int k = threadIdx.x; k < LD; k += 256) {
+      const double p = k < S ? exp(a.p_pi[k] - mx) / sum : 0.0;
+      sd[k] = k < S ? sqrt(p) : 1.0;
+      if (k == i) {
+        a.pi[i] = p;
+        a.dsq[i] = sd[k];
+      }
+    }
+    __syncthreads();
   }
   const bool pow2 = a.Q_pow2 && ((epoch & (epoch + 1)) == 0);  // epochs 1, 2, 4, ... (1-based)
   int pidx = 0;
   for (int e1 = epoch + 1; e1 > 1; e1 >>= 1) ++pidx;
   double *Qp = (pow2 && pidx < a.n_pow2) ? a.Q_pow2 + (size_t)pidx * S * S + (size_t)i * S : nullptr;
   double *Ql = a.Q_last + (size_t)i * S;
-  const double di = a.dsq[i], inv_di = 1.0 / di;
+  const double di = sd[i], inv_di = 1.0 / di;
   double acc = 0.0;
   for (int j = threadIdx.x; j < LD; j += 256) {
     double r = 0.0;
@@ -93,7 +100,7 @@ __global__ __launch_bounds__(256) void lt_build(LargeTrain a, int epoch) {
       const int lo_ = min(i, j), hi_ = max(i, j);
       const size_t k = (size_t)lo_ * S - (size_t)lo_ * (lo_ + 1) / 2 + (hi_ - lo_ - 1);
       r = softplus_t(a.p_up[k]) * (a.mask ? a.mask[(size_t)i * S + j] : 1.0);
-      const double rd = r * a.dsq[j];
+      const double rd = r * sd[j];
       acc += rd;
       const double q = rd * inv_di;
       Ql[j] = q;
@@ -123,28 +130,30 @@ __global__ __launch_bounds__(256) void lt_gd(LargeTrain a) {
     a.gd[k] = -a.dsq[k] * acc - a.G[(size_t)k * LD + k] * a.A[(size_t)k * LD + k] - a.dirsum[k] * a.inv_n;
 }
 
-__global__ __launch_bounds__(256) void lt_step_pi(LargeTrain a, int epoch, double bc1, double bc2s) {
+// The parameter step, ONE launch: workgroups 0 .. S-1 take the rows of the upper-diagonal logits (and copy Q_last -> Q_best
+// when this epoch improved), workgroup S the stationary logits, the loss curve and the best-loss word.  Every workgroup decides
+// "improved" by itself from the loss and the best loss BEFORE this epoch, state[epoch & 1]; workgroup S leaves the best loss
+// after it in state[(epoch + 1) & 1] (two words in turn, so that no workgroup can read the updated one).
+__global__ __launch_bounds__(256) void lt_step(LargeTrain a, int epoch, double bc1, double bc2s) {
   __shared__ double s[256];
-  const int S = a.S;
-  if (threadIdx.x == 0) {
-    const double loss = *a.loss;
-    a.loss_curve[epoch - a.epoch0] = loss;   // (the curve of THIS call)
-    const bool better = epoch == 0 || loss < a.state[0];  // strict <, first iterate always taken (trainer.py:179)
-    a.state[1] = better ? 1.0 : 0.0;
-    if (better) a.state[0] = loss;
-  }
-  double acc = 0.0;
-  for (int k = threadIdx.x; k < S; k += 256) acc += a.gd[k];
-  const double tot = lt_block_sum(acc, s);
-  for (int k = threadIdx.x; k < S; k += 256) {
-    const double g = 0.5 * (a.gd[k] - a.pi[k] * tot);
-    adam_update(a.p_pi[k], a.m_pi[k], a.v_pi[k], g, a.lr, a.beta1, a.beta2, a.eps, bc1, bc2s, a.do_adam);
-  }
-}
-
-__global__ __launch_bounds__(256) void lt_step_up(LargeTrain a, double bc1, double bc2s) {
   const int S = a.S, LD = a.LD, i = blockIdx.x;
-  if (a.state[1] != 0.0)  // this epoch's (pre-step) Q is the best so far
+  const double loss = *a.loss, best = a.state[epoch & 1];
+  const bool better = epoch == 0 || loss < best;  // strict <, first iterate always taken (trainer.py:179)
+  if (i == S) {
+    if (threadIdx.x == 0) {
+      a.loss_curve[epoch - a.epoch0] = loss;   // (the curve of THIS call)
+      a.state[(epoch + 1) & 1] = better ? loss : best;
+    }
+    double acc = 0.0;
+    for (int k = threadIdx.x; k < S; k += 256) acc += a.gd[k];
+    const double tot = lt_block_sum(acc, s);
+    for (int k = threadIdx.x; k < S; k += 256) {
+      const double g = 0.5 * (a.gd[k] - a.pi[k] * tot);
+      adam_update(a.p_pi[k], a.m_pi[k], a.v_pi[k], g, a.lr, a.beta1, a.beta2, a.eps, bc1, bc2s, a.do_adam);
+    }
+    return;
+  }
+  if (better)  // this epoch's (pre-step) Q is the best so far
     for (int j = threadIdx.x; j < S; j += 256) a.Q_best[(size_t)i * S + j] = a.Q_last[(size_t)i * S + j];
   const double di = a.dsq[i], gii = a.G[(size_t)i * LD + i];
   const size_t kbase = (size_t)i * S - (size_t)i * (i + 1) / 2;

@@ -146,7 +146,9 @@ int cb_eigh(cb_handle h, const double *A, int flags, double *lam, double *U);
 enum {
   CB_T_TOTAL = 0,   /* whole call                                   */
   CB_T_EIGH = 1,    /* symmetrise + eigendecomposition              */
-  CB_T_K1 = 2,      /* large path: spectral tables (4 us) + the Pt / loss / Gt kernel */
+  CB_T_K1 = 2,      /* large path: spectral tables (4 us) + the Pt / loss / Gt kernel; when the three bank products ran as
+                       ONE launch (k123_bank, the default whenever the gradient is wanted): that whole launch, and
+                       CB_T_K2 = CB_T_K3 = 0 */
   CB_T_K2 = 3,      /* large path: T = Gt U (one launch)            */
   CB_T_K3 = 4,      /* large path: Mt accumulation (one launch)     */
   CB_T_K4 = 5,      /* large path: reduce + back-rotation           */

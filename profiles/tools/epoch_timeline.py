@@ -3,7 +3,7 @@ start offset, duration, gap to the previous kernel's end.  python epoch_timeline
 import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 ev = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"].split("(")[0].replace("void ", "")) for r in rows)
-idx = [i for i, e in enumerate(ev) if e[2].startswith("lt_pi")]
+idx = [i for i, e in enumerate(ev) if e[2].startswith("lt_pi")] or [i for i, e in enumerate(ev) if e[2].startswith("lt_build")]
 print("epochs", len(idx))
 for e in ([] if sys.argv[2:3] == ["spans"] else [int(x) for x in sys.argv[2:]] or [15]):
     if e + 1 >= len(idx):
