@@ -819,8 +819,18 @@ __global__ void k3_reduce(const T *part, int nchunks, size_t n, double *out, int
     col = (int)(i - (size_t)row * LD);
     if (row / LG_TM > col / LG_TN) return;
   }
-  double s0 = 0.0, s1 = 0.0;   // two interleaved partial sums: twice the loads in flight
+  double s0 = 0.0, s1 = 0.0;   // two interleaved partial sums (even / odd chunks); eight loads in flight per thread
   int c = 0;
+  for (; c + 7 < nchunks; c += 8) {
+    T v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = part[(size_t)(c + u) * n + i];
+#pragma unroll
+    for (int u = 0; u < 8; u += 2) {
+      s0 += (double)v[u];
+      s1 += (double)v[u + 1];
+    }
+  }
   for (; c + 1 < nchunks; c += 2) {
     s0 += (double)part[(size_t)c * n + i];
     s1 += (double)part[(size_t)(c + 1) * n + i];
