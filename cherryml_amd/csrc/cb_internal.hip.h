@@ -1,6 +1,6 @@
 // Shared by the translation units of libcherrybank: error reporting and small host-side helpers.
-// (cherrybank.hip: handle, bank entry points, trainers; cb_counting.hip; cb_ble.hip; cb_likelihood.hip;
-// cb_host_io.hip.)
+// (cherrybank.hip: handle, bank entry points, trainers; cb_bank_fused.hip: the one-launch bank kernel; cb_counting.hip;
+// cb_ble.hip; cb_likelihood.hip; cb_host_io.hip.)
 #pragma once
 #include "../../include/cherrybank.h"
 
@@ -36,6 +36,10 @@ int cb_internal_expm_bank(cb_handle h, const double *Q, const double *pi, int fl
 // new branch lengths for a counts-free (CB_EXPM_ONLY) single-bank handle, B <= its creation B (cherrybank.hip);
 // t_dev != NULL: the same values already on the device -- copied on the handle's stream, no host wait
 int cb_internal_set_times(cb_handle h, const double *t_host, int B, const double *t_dev);
+
+// the fused bank launch k123_bank (cb_bank_fused.hip): variant 0 = float64, 1 = CB_F32, 2 = CB_MIXED; `args` = the argument
+// block in device memory; stop = null or the event that takes the launch's end time.  Returns 0 or -1.
+int cb_launch_bank_fused(int variant, const void *args, int grid, hipStream_t stream, hipEvent_t stop);
 
 // device buffers of one call of the per-family entry points (uploaded on the default stream, freed on return)
 struct CbDevBufs {

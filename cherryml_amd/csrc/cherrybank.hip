@@ -149,8 +149,6 @@ static int launch_small(cb_bank *h, const SmallArgs &a) {
 // `dA_padded` is false, else dL/dA itself as a padded LD x LD matrix.
 // `plan`: a warm solve enqueued as a device-controlled plan (eigh_planned_host.hip.h) instead of the host-driven loop; the
 // caller reads the record of solve `h->eseq` afterwards and repeats the evaluation without a plan if the solve stalled.
-int cb_launch_bank_fused(int variant, const void *args, int grid, hipStream_t stream, hipEvent_t stop);   // cb_bank_fused.hip
-
 static int large_eval(cb_bank *h, bool normalize, double *lossd, double *out, bool dA_padded, double *Pd,
                       bool reuse_eigh = false, const EighPlan *plan = nullptr, int plan_first_slot = 0) {
   const int S = h->S, LD = h->LD;

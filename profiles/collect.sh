@@ -34,6 +34,9 @@ export CB_BANK_UNFUSED=1
 python3 $R/bench.py --no-cpu-baseline --no-secondary --steps 20 --warmup 5 > $R/gpurun_out/${TAG}_bench_coevo400_unfused.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${TAG}_trace_coevo400_unfused -- \
   python3 $R/bench.py --no-cpu-baseline --no-secondary --steps 20 --warmup 5 > $R/gpurun_out/${TAG}_benchprof_coevo400_unfused.log 2>&1
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA \
+  --output-format csv -d $R/gpurun_out/${TAG}_pmc_sq_f64_unfused -- \
+  python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-secondary > /dev/null 2>&1
 unset CB_BANK_UNFUSED
 # in-kernel stamps of the bank's tiles (diagnostic build, -DCB_CLOCK_STAMP): tile timelines of the fused launch and of the three
 # separate ones, and the clock held inside the K loops; the shipped build is restored afterwards

@@ -118,9 +118,10 @@ for name in ("bench_default", "bench_driver", "bench_coevo400_unfused"):
 # ---- MFMA utilisation (north_star: "rocprof HBM GB/s and MFMA utilisation vs gfx950 peak")
 util = {**STAMP, "source": f"rocprofv3 --pmc SQ_* (one pass of 8 counters), gpurun_out/{tag}_pmc_sq_*; durations from the "
                   "--kernel-trace --stats summaries of the same workloads", "simds": 1024, "clock_GHz": 2.4, "kernels": {}}
-for dt, w in (("f64", "coevo400"), ("mixed", "coevo400_mixed"), ("f32", "coevo400_f32")):
+for dt, w in (("f64", "coevo400"), ("mixed", "coevo400_mixed"), ("f32", "coevo400_f32"), ("f64_unfused", "coevo400_unfused")):
     fs = newest(f"{root}/gpurun_out/{tag}_pmc_sq_{dt}/*/*counter_collection.csv")
     st = newest(f"{root}/gpurun_out/{tag}_trace_{w}/*/*_kernel_stats.csv")
+    dt = dt.replace("_unfused", "")   # (CB_BANK_UNFUSED=1: the three launches of the float64 bank, keys k1_ / k2_ / k3_ ... :f64)
     if not fs or not st:
         continue
     dur = {}
