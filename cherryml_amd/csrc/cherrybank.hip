@@ -233,14 +233,12 @@ static int large_eval(cb_bank *h, bool normalize, double *lossd, double *out, bo
       auto *dst = launch(a);
       if (cb_launch_bank_fused(0, dst, grid, h->stream, bank_stop) != 0) return fail(CB_EHIP, "k123_bank: launch failed");
     }
-    hipLaunchKernelGGL(lg_finish_loss, dim3(1), dim3(256), 0, h->stream, h->loss_part, B * tiles_k1, S,
-                       h->dsq, h->dirsum, inv_n, lossd);
+    const LossArgs la{h->loss_part, B * tiles_k1, S, h->dsq, h->dirsum, inv_n, lossd};
+    const dim3 red_grid((unsigned)((LL + 255) / 256) + 1);   // (+ the workgroup that sums the loss partials)
     if (f32 || mixed)
-      hipLaunchKernelGGL(k3_reduce<float>, dim3((unsigned)((LL + 255) / 256)), dim3(256), 0, h->stream,
-                         h->Gt32, B, LL, h->Mt, h->sym_counts ? LD : 0);
+      hipLaunchKernelGGL(k3_reduce_loss<float>, red_grid, dim3(256), 0, h->stream, h->Gt32, B, LL, h->Mt, h->sym_counts ? LD : 0, la);
     else
-      hipLaunchKernelGGL(k3_reduce<double>, dim3((unsigned)((LL + 255) / 256)), dim3(256), 0, h->stream,
-                         h->Gt, B, LL, h->Mt, h->sym_counts ? LD : 0);
+      hipLaunchKernelGGL(k3_reduce_loss<double>, red_grid, dim3(256), 0, h->stream, h->Gt, B, LL, h->Mt, h->sym_counts ? LD : 0, la);
     K4Args k4a{S, LD, h->Mt, h->Vc, h->X, nullptr, nullptr, nullptr};
     launch_sg(h, k4a, 0);
     K4Args k4b{S, LD, h->Vc, h->X, dQd, dA_padded ? nullptr : h->dsq, nullptr, nullptr};

@@ -810,7 +810,7 @@ __global__ __launch_bounds__(LG4_THREADS, 4) void k123_bank(const K123Args<T1, T
 // (LD > 0): only the 80x80 tiles on or above the diagonal were written by k3_w_phi; sum those and
 // mirror the SUM into the lower tiles (40 % less to read, and no mirrored stores per bucket).
 template <typename T>
-__global__ void k3_reduce(const T *part, int nchunks, size_t n, double *out, int LD = 0) {
+__device__ __forceinline__ void k3_reduce_body(const T *part, int nchunks, size_t n, double *out, int LD) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   int row = 0, col = 0;
@@ -839,6 +839,43 @@ __global__ void k3_reduce(const T *part, int nchunks, size_t n, double *out, int
   const double s = s0 + s1;
   out[i] = s;
   if (LD > 0 && row / LG_TM < col / LG_TN) out[(size_t)col * LD + row] = s;
+}
+
+template <typename T>
+__global__ void k3_reduce(const T *part, int nchunks, size_t n, double *out, int LD = 0) {
+  k3_reduce_body<T>(part, nchunks, n, out, LD);
+}
+
+// loss = (sum of partials - direct term) * inv_n, one workgroup, fixed order
+__device__ __forceinline__ void lg_finish_loss_body(const double *part, int nparts, int S, const double *dsq,
+                                                    const double *dirsum, double inv_n, double *loss) {
+  __shared__ double s[256];
+  double acc = 0.0;
+  for (int i = threadIdx.x; i < nparts; i += 256) acc += part[i];
+  double dir = 0.0;
+  for (int k = threadIdx.x; k < S; k += 256) dir = fma(log(dsq[k]), dirsum[k], dir);
+  s[threadIdx.x] = acc - dir;
+  __syncthreads();
+  for (int st = 128; st >= 1; st >>= 1) {
+    if ((int)threadIdx.x < st) s[threadIdx.x] += s[threadIdx.x + st];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *loss = s[0] * inv_n;
+}
+
+// the bucket sum and the loss in ONE launch (they do not depend on each other; behind the fused bank launch): the last
+// workgroup takes the loss
+struct LossArgs {
+  const double *part;
+  int nparts, S;
+  const double *dsq, *dirsum;
+  double inv_n;
+  double *loss;
+};
+template <typename T>
+__global__ __launch_bounds__(256) void k3_reduce_loss(const T *part, int nchunks, size_t n, double *out, int LD, LossArgs l) {
+  if (blockIdx.x + 1 == gridDim.x) lg_finish_loss_body(l.part, l.nparts, l.S, l.dsq, l.dirsum, l.inv_n, l.loss);
+  else k3_reduce_body<T>(part, nchunks, n, out, LD);
 }
 
 // ------------------------------------------------------------------ K4 (plain / dQ epilogue)
@@ -998,21 +1035,9 @@ __global__ void lg_tables(int LD, int B, const double *t, const double *lam,
   H[idx] = exp(0.5 * x);
 }
 
-// loss = (sum of partials - direct term) * inv_n, single thread-block, fixed order
 __global__ void lg_finish_loss(const double *part, int nparts, int S, const double *dsq,
                                const double *dirsum, double inv_n, double *loss) {
-  __shared__ double s[256];
-  double acc = 0.0;
-  for (int i = threadIdx.x; i < nparts; i += 256) acc += part[i];
-  double dir = 0.0;
-  for (int k = threadIdx.x; k < S; k += 256) dir = fma(log(dsq[k]), dirsum[k], dir);
-  s[threadIdx.x] = acc - dir;
-  __syncthreads();
-  for (int st = 128; st >= 1; st >>= 1) {
-    if ((int)threadIdx.x < st) s[threadIdx.x] += s[threadIdx.x + st];
-    __syncthreads();
-  }
-  if (threadIdx.x == 0) *loss = s[0] * inv_n;
+  lg_finish_loss_body(part, nparts, S, dsq, dirsum, inv_n, loss);
 }
 
 // flag[0] |= 1 when some live bucket has C_b != C_b^T
