@@ -211,7 +211,7 @@ static int large_eval(cb_bank *h, bool normalize, double *lossd, double *out, bo
       K123Args<float, float> a{{S, LD, B, h->Utf, h->Af, tb, h->Ff, h->sigma, h->Ct32, h->Gt32, h->loss_part, inv_n, h->dsq, nullptr, skipw},
                                {LD, h->Gt32, h->Uf, h->T32, skipw},
                                {LD, B, h->T32, h->Uf, tb, h->lam, h->E, h->H, h->Gt32, sym, skipw},
-                               {h->bank_queue, B, tiles_k1, tiles, tiles_k3}};
+                               {h->bank_queue, B, tiles_k1, tiles, tiles_k3, h->bank_claims}};
       auto *dst = launch(a);
       hipLaunchKernelGGL(lg_cast_f32, dim3((unsigned)((std::max(LL, (size_t)B * LD) + 255) / 256)), dim3(256), 0, h->stream, LL,
                          (size_t)B * LD, h->U, h->Vc, h->A, h->F, h->Uf, h->Utf, h->Af, h->Ff);
@@ -220,7 +220,7 @@ static int large_eval(cb_bank *h, bool normalize, double *lossd, double *out, bo
       K123Args<double, float> a{{S, LD, B, h->Vc, h->A, tb, h->F, h->sigma, h->Ct, h->Gt32, h->loss_part, inv_n, h->dsq, nullptr, skipw},
                                 {LD, h->Gt32, h->Uf, h->T32, skipw},
                                 {LD, B, h->T32, h->Uf, tb, h->lam, h->E, h->H, h->Gt32, sym, skipw},
-                                {h->bank_queue, B, tiles_k1, tiles, tiles_k3}};
+                                {h->bank_queue, B, tiles_k1, tiles, tiles_k3, h->bank_claims}};
       auto *dst = launch(a);
       hipLaunchKernelGGL(lg_cast_f32, dim3((unsigned)((std::max(LL, (size_t)B * LD) + 255) / 256)), dim3(256), 0, h->stream, LL,
                          (size_t)B * LD, h->U, h->Vc, h->A, h->F, h->Uf, h->Utf, h->Af, h->Ff);
@@ -229,7 +229,7 @@ static int large_eval(cb_bank *h, bool normalize, double *lossd, double *out, bo
       K123Args<double, double> a{{S, LD, B, h->Vc, h->A, tb, h->F, h->sigma, h->Ct, h->Gt, h->loss_part, inv_n, h->dsq, nullptr, skipw},
                                  {LD, h->Gt, h->U, h->T, skipw},
                                  {LD, B, h->T, h->U, tb, h->lam, h->E, h->H, h->Gt, sym, skipw},
-                                 {h->bank_queue, B, tiles_k1, tiles, tiles_k3}};
+                                 {h->bank_queue, B, tiles_k1, tiles, tiles_k3, h->bank_claims}};
       auto *dst = launch(a);
       if (cb_launch_bank_fused(0, dst, grid, h->stream, bank_stop) != 0) return fail(CB_EHIP, "k123_bank: launch failed");
     }

@@ -338,15 +338,16 @@ extern "C" int cb_create(int device, int S, int L, int B, int dtype, const doubl
       }
     }
     if (!expm_only) {
-      if (dev_alloc(h, &h->bank_queue, (size_t)LG_NQ + 2 * (size_t)B) != CB_OK ||
-          dev_alloc(h, &h->bank_args, sizeof(K123Args<double, double>)) != CB_OK) {
-        free_tmp();
-        return cleanup(CB_ENOMEM);
-      }
       int dev = 0, cus = 0;
       if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
         cus = 256;
       h->bank_slots = 4 * std::max(cus, 1);
+      h->bank_claims = (h->bank_slots + LG_NQ - 1) / LG_NQ;   // reserved first tickets per queue (k123_bank)
+      if (dev_alloc(h, &h->bank_queue, (size_t)LG_NQ + 2 * (size_t)B + (size_t)LG_NQ * h->bank_claims) != CB_OK ||
+          dev_alloc(h, &h->bank_args, sizeof(K123Args<double, double>)) != CB_OK) {
+        free_tmp();
+        return cleanup(CB_ENOMEM);
+      }
     }
     if (!expm_only) {
     hipLaunchKernelGGL(prep_counts_large_tot, dim3((unsigned)((SS + 255) / 256)), dim3(256), 0,

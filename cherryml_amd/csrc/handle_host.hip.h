@@ -80,6 +80,7 @@ struct cb_bank {
   unsigned int *bank_queue = nullptr;   // fused bank kernel (k123_bank): ticket queues + tile counters, 8 + 2 B words
   unsigned char *bank_args = nullptr;   // ... and its argument block (written by lg_tables in front of every launch)
   int bank_slots = 0;                   // its grid: resident workgroups of the device (4 per CU)
+  int bank_claims = 0;                  // reserved first tickets per queue
   bool bank_fused = false;              // the last evaluation ran K1 -> K2 -> K3 as one launch
   int last_sweeps = 0;
   double *gn_scratch = nullptr, *gn_partial = nullptr;  // general path, allocated on first use

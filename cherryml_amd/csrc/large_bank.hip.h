@@ -128,6 +128,17 @@ __device__ __forceinline__ void lg4_store_panel(T *s, const typename Mfma<T>::ve
     if (u < NL - 1 || cq < LAST) *reinterpret_cast<vec_t *>(row + 16 * VEC * u) = v;
   }
 }
+// What the ticket loop of k123_bank has a tile do on the side, from inside its K loop where the round trips cost nothing:
+//   deferred: the counter that announces the PREVIOUS tile of this workgroup, bumped behind the wait for this tile's first
+//             panels (the wait for the previous tile's stores is then free);
+//   draw:     the ticket counter the NEXT ticket is drawn from, in the middle of the loop; the answer is left in
+//             *drawn_lds (a word of the panel buffer that no epilogue uses) once the loop is over.
+struct BankHooks {
+  unsigned int *deferred = nullptr;
+  unsigned int *draw = nullptr;
+  int *drawn_lds = nullptr;
+};
+
 // sA / sB hold TWO K-steps each (double buffer): one barrier per K-step; the global loads of step
 // k+1 are in flight during the MFMAs of step k.  LDS row stride 80 elements is conflict-free for the
 // operand reads in both widths (f64: 2 * 80 mod 64 = 32; f32: 80 mod 64 = 16, four k rows per read).
@@ -138,12 +149,8 @@ template <typename T, bool SCALE, bool ZERO = true>
 __device__ __forceinline__ void lg4_gemm_tile(const GemmOperands<T> &g, int m0, int n0, T *sA, T *sB,
                                               typename Mfma<T>::acc_t (&acc)[5], typename Mfma<T>::acc_t &ax0,
                                               typename Mfma<T>::acc_t &ax1, int tid = threadIdx.x,
-                                              unsigned int *deferred = nullptr) {
+                                              const BankHooks &hooks = BankHooks{}) {
   // (tid: threadIdx.x -- or an opaque copy of it, k123_bank: what is derived from it then stays inside the tile)
-  // deferred (k123_bank): the counter that announces the PREVIOUS tile of this workgroup; bumped here, behind the wait for
-  // this tile's first panels, where the wait for the previous tile's stores costs nothing
-  // (Measured and dropped: K1 reading one element of every cache line of its two count tiles during its last four K-steps, so
-  // that the epilogue's count loads hit the L2 -- +20 us, 0.726 against 0.706 ms: those K-steps' vmcnt(0) then waits for HBM.)
   typedef typename Mfma<T>::acc_t acc_t;
   typedef typename Mfma<T>::vec_t vec_t;
   // (the wave index as a SCALAR: the tests on it in the K loop are then scalar branches, not v_cmp + exec masks)
@@ -163,11 +170,17 @@ __device__ __forceinline__ void lg4_gemm_tile(const GemmOperands<T> &g, int m0, 
   __syncthreads();  // the previous tile's readers of buffer 0 are done
   lg4_store_panel<T, SCALE>(sA, ra, sc, tid);
   lg4_store_panel<T, false>(sB, rb, one, tid);
+  unsigned int *deferred = hooks.deferred;
   if (deferred) __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): this wave's stores of the previous tile have been performed
   __syncthreads();
   if (deferred && tid == 0) __hip_atomic_fetch_add(deferred, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  int drawn = -1;
+  const int draw_kt = nk / 2;   // (mid-loop: the workgroups of a launch start together but are spread out by then, and half a
+                                // K loop is left for the answer: drawn four K-steps before the end, K3's epilogue waited 9 us for it)
   for (int kt = 0; kt < nk; ++kt) {
     const T *cA = sA + (kt & 1) * (LG_KT * LG_TM), *cB = sB + (kt & 1) * (LG_KT * LG_TN);
+    if (hooks.draw && kt == draw_kt && tid == 0)
+      drawn = (int)__hip_atomic_fetch_add(hooks.draw, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (kt + 1 < nk) {
       lg4_load_panel<T, SCALE>(srcA, g.lda, (kt + 1) * LG_KT, ra, g.kscale, sc, tid);
       lg4_load_panel<T, false>(srcB, g.ldb, (kt + 1) * LG_KT, rb, nullptr, one, tid);
@@ -208,6 +221,7 @@ __device__ __forceinline__ void lg4_gemm_tile(const GemmOperands<T> &g, int m0, 
     ax1 = acc_t{};     // (the partial sums now live in wave 0)
   }
   __syncthreads();   // sA is free again (callers reuse it)
+  if (hooks.draw && tid == 0) *hooks.drawn_lds = drawn;
 }
 
 // Diagnostic build only (-DCB_CLOCK_STAMP, profiles/tools/clock_probe.py): the clock the chip holds inside the K loops of
@@ -306,7 +320,7 @@ __device__ __forceinline__ void bank_store(T *p, T v) {
 // each; after the K loop: the transposition buffer); vid = b * tiles + tile indexes the loss partial
 template <typename T, typename TG, bool EXPM, bool WT>
 __device__ __forceinline__ void k1_tile(const K1Args<T, TG> &a, int b, int tile, T *sAB, int tid,
-                                        unsigned int *deferred = nullptr) {
+                                        const BankHooks &hooks = BankHooks{}) {
   T *sA = sAB, *sB = sAB + 2 * LG_KT * LG_TM;
   typedef typename Mfma<T>::acc_t acc_t;
   const int tilesN = (a.LD + LG_TN - 1) / LG_TN, tiles = tilesN * (tilesN + 1) / 2;
@@ -323,7 +337,7 @@ __device__ __forceinline__ void k1_tile(const K1Args<T, TG> &a, int b, int tile,
   GemmOperands<T> g{a.Ut, a.Ut, a.LD, a.LD, a.LD, a.LD, a.LD, a.F + (size_t)b * a.LD};
   acc_t acc[5], ax0, ax1;
   CB_STAMP_BEGIN(vid);
-  lg4_gemm_tile<T, true>(g, m0, n0, sA, sB, acc, ax0, ax1, tid, deferred);
+  lg4_gemm_tile<T, true>(g, m0, n0, sA, sB, acc, ax0, ax1, tid, hooks);
   CB_STAMP_END(0);
 
   const double tb = a.t[b];
@@ -471,7 +485,7 @@ struct K2Args {
 
 // one (bucket b, tile) of K2; sAB as in k1_tile
 template <typename T, bool WT>
-__device__ __forceinline__ void k2_tile(const K2Args<T> &a, int b, int tile, T *sAB, int tid, unsigned int *deferred = nullptr) {
+__device__ __forceinline__ void k2_tile(const K2Args<T> &a, int b, int tile, T *sAB, int tid, const BankHooks &hooks = BankHooks{}) {
   T *sA = sAB, *sB = sAB + 2 * LG_KT * LG_TM;
   typedef typename Mfma<T>::acc_t acc_t;
   const int tilesN = (a.LD + LG_TN - 1) / LG_TN;
@@ -481,7 +495,7 @@ __device__ __forceinline__ void k2_tile(const K2Args<T> &a, int b, int tile, T *
   GemmOperands<T> g{a.Gt + boff, a.U, a.LD, a.LD, a.LD, a.LD, a.LD, nullptr};
   acc_t acc[5], ax0, ax1;
   CB_STAMP_BEGIN(b * tilesN * tilesN + tile);
-  lg4_gemm_tile<T, false>(g, m0, n0, sA, sB, acc, ax0, ax1, tid, deferred);
+  lg4_gemm_tile<T, false>(g, m0, n0, sA, sB, acc, ax0, ax1, tid, hooks);
   CB_STAMP_END(1);
   T *__restrict__ Tm = a.Tm + boff;
   lg_for_each<T>(m0, n0, acc, ax0, ax1, [&](int row, int col, T v) {
@@ -521,7 +535,7 @@ struct K3Args {
 
 // one (bucket b, tile) of K3; sAB as in k1_tile
 template <typename T>
-__device__ __forceinline__ void k3_tile(const K3Args<T> &a, int b, int tile, T *sAB, int tid, unsigned int *deferred = nullptr) {
+__device__ __forceinline__ void k3_tile(const K3Args<T> &a, int b, int tile, T *sAB, int tid, const BankHooks &hooks = BankHooks{}) {
   T *sA = sAB, *sB = sAB + 2 * LG_KT * LG_TM;
   typedef typename Mfma<T>::acc_t acc_t;
   const int tilesN = (a.LD + LG_TN - 1) / LG_TN;
@@ -542,7 +556,7 @@ __device__ __forceinline__ void k3_tile(const K3Args<T> &a, int b, int tile, T *
   GemmOperands<T> g{a.Tm + boff, a.U, a.LD, a.LD, a.LD, a.LD, a.LD, nullptr};
   acc_t acc[5], ax0, ax1;
   CB_STAMP_BEGIN(b * tilesN * tilesN + tm * tilesN + tn);
-  lg4_gemm_tile<T, false>(g, m0, n0, sA, sB, acc, ax0, ax1, tid, deferred);
+  lg4_gemm_tile<T, false>(g, m0, n0, sA, sB, acc, ax0, ax1, tid, hooks);
   CB_STAMP_END(2);
   const double tb = a.t[b];
   const double *__restrict__ Eb = a.E + (size_t)b * a.LD, *__restrict__ Hb = a.H + (size_t)b * a.LD;
@@ -615,8 +629,10 @@ __global__ __launch_bounds__(LG4_THREADS, 4) void k3_w_phi(K3Args<T> a) {
 //    launch (k3_reduce): plain stores.  tests/test_gpu_s400_full.py compares this launch with the three separate ones bit
 //    for bit (CB_BANK_UNFUSED=1).
 struct BankQueueArgs {
-  unsigned int *queue;   // [8] tickets drawn per XCD queue | [B] finished K1 tiles | [B] finished K2 tiles, set by lg_tables
+  unsigned int *queue;   // [LG_NQ] tickets drawn per queue | [B] finished K1 tiles | [B] finished K2 tiles | [LG_NQ][claims] claim
+                         // flags of the reserved first tickets; all set by lg_tables in front of the launch
   int B, tiles1, tiles2, tiles3;
+  int claims;            // reserved tickets per queue (>= the workgroups of a launch that call one queue home)
 };
 
 // Ticket `idx` of a queue that owns `nb` buckets -> (stage 0 / 1 / 2, local bucket, tile): the queue's K1 tiles bucket by
@@ -641,7 +657,9 @@ struct K123Args {
   BankQueueArgs q;
 };
 
-#define LG_NQ 8   // ticket queues = XCDs
+#ifndef LG_NQ
+#define LG_NQ 8   // ticket queues (a multiple of the 8 XCDs: queue q is served by the workgroups with blockIdx.x % LG_NQ == q, all on XCD q % 8)
+#endif
 
 // a wave-uniform copy (in SGPRs) of an argument block read from device memory
 template <typename S>
@@ -712,60 +730,86 @@ __global__ __launch_bounds__(LG4_THREADS, 4) void k123_bank(const K123Args<T1, T
                                                    // them before the tile routine's first barrier, which precedes its first store
   unsigned int *tick = a.queue, *done1 = a.queue + LG_NQ, *done2 = done1 + a.B;
   const int per_bucket = a.tiles1 + a.tiles2 + a.tiles3;
-  // Workgroups go round-robin over the XCDs (xcd_swizzle's assumption): blockIdx.x % 8 names the home queue.  The FIRST
-  // ticket of a workgroup is index blockIdx.x / 8 of that queue without asking (lg_tables starts the counters at
-  // gridDim.x / 8: 128 draws on one counter at the start of the launch took 40 us to serve).
+  // Workgroups go round-robin over the XCDs (xcd_swizzle's assumption): blockIdx.x % 8 names the home queue.
   const int home = blockIdx.x & (LG_NQ - 1);
   auto queue_len = [&](int q) { return (a.B * (q + 1) / LG_NQ - a.B * q / LG_NQ) * per_bucket; };
+  // Who may run a ticket.  A ticket DRAWN from a queue's counter belongs to a running workgroup, so whatever waits for it
+  // will see it finished, with any number of resident workgroups.  Only the 128 workgroups of a queue all drawing their first
+  // ticket in the first microsecond of the launch serialise on the counter (15-40 us before the last one starts).  So the
+  // first n = min(home workgroups, K1 tickets of the queue) tickets -- K1 tiles, which wait for nothing -- are RESERVED:
+  // workgroup blockIdx.x takes ticket blockIdx.x / 8 of its home queue by setting that ticket's claim flag (one uncontended
+  // atomic), the counter starts at n.  A reserved ticket whose workgroup is not resident is not lost: a workgroup that waits
+  // for a bucket's K1 tiles claims the bucket's unclaimed reserved tickets itself and runs them first (`help` below).
+  // (Round 4 first handed out the first two tickets by index without claim flags: two such launches on one GPU -- two ranks
+  // of the test hook sharing it -- then waited for tiles owned by workgroups that were not resident, each launch holding the
+  // slots the other needed, until the scheduler's preemption timer let them through: 7.9 s per epoch.)
   // Between two tiles of a workgroup lay ~9 us of dependent round trips (the announcement of the finished tile behind a
   // wait for its stores, the draw, the dependency word, the argument block): 16 % of the launch.  So the NEXT ticket is drawn
-  // while the current tile runs (thread 0 issues the atomic in front of the K loop and looks at the answer after the
-  // epilogue), the finished tile is announced from inside the next tile's K loop (lg4_gemm_tile, `deferred`), and the
-  // argument blocks come through the scalar cache: 3 us are left.  (Drawing TWO tickets ahead, so that the dependency word
+  // from inside the current tile's K loop and the finished tile is announced from inside the next tile's (BankHooks), and the
+  // argument blocks come through the scalar cache: 3-4 us are left.  (Drawing TWO tickets ahead, so that the dependency word
   // is in flight during a tile as well, was slower, 0.81 against 0.74 ms: a ticket then waits up to two tile times in its
   // holder's pipeline, and the K2 tickets of a queue's last buckets find their K1 tiles not even started.)
-  // The first TWO tickets of a workgroup are its own without asking: index blockIdx.x / 8 and, one "row" of workgroups
-  // further, n_home + blockIdx.x / 8 of its home queue (lg_tables starts the counters at 2 n_home): the 128 workgroups of a
-  // queue start together, and 128 draws on one counter take 40 us to serve -- the second tiles start spread out.
-  const int n_home = ((int)gridDim.x - home + LG_NQ - 1) / LG_NQ;   // workgroups of this launch whose home is this queue
-  int nq = home, ni = (int)(blockIdx.x / LG_NQ);   // thread 0: the ticket drawn for the next round (queue, raw index)
-  int round = 0;
+  unsigned int *claim = done2 + a.B;
+  auto reserved = [&](int q) {   // reserved first tickets of queue q (lg_tables starts the counter there)
+    const int homes = ((int)gridDim.x - q + LG_NQ - 1) / LG_NQ, k1 = (a.B * (q + 1) / LG_NQ - a.B * q / LG_NQ) * a.tiles1;
+    return min(min(homes, k1), a.claims);
+  };
+  int *drawn_lds = reinterpret_cast<int *>(smem + sizeof(smem) - 16);   // the draw made inside the K loop (no epilogue uses
+                                                                        // the end of the panel buffer)
+  int nq = home, ni = -1;   // thread 0: the ticket drawn for this round (queue, raw index; -1: none yet)
+  int own_stage = -1, own_b = 0, own_tile = 0, own_q = 0;   // a ticket put aside while this workgroup helps with its inputs
   unsigned int *pending = nullptr;                 // the finished tile that is still to be announced
-  for (;; ++round) {
+  bool first = true;
+  for (;;) {
     __syncthreads();   // the previous ticket's last readers of smem / s_ticket are done
     if (threadIdx.x == 0) {
-      int q = nq, idx = ni < queue_len(nq) ? ni : -1;
-      for (int tries = 0; idx < 0 && tries < LG_NQ; ++tries) {   // own queue empty: the next XCD's
-        q = (q + 1) & (LG_NQ - 1);
-        const int len = queue_len(q);
-        if ((int)__hip_atomic_load(tick + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= len) continue;
-        const int i = (int)__hip_atomic_fetch_add(tick + q, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (i < len) idx = i;
+      int stage = -1, b = 0, tile = 0, ready = 1, q = nq;
+      if (own_stage >= 0) {   // back from helping: the ticket put aside
+        stage = own_stage, b = own_b, tile = own_tile, q = own_q;
+      } else {
+        int idx = ni;
+        if (first) {   // the reserved first ticket, if nobody has run it for us
+          const int i0 = (int)(blockIdx.x / LG_NQ);
+          if (i0 < reserved(home) &&
+              __hip_atomic_exchange(claim + home * a.claims + i0, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u)
+            idx = i0;
+        }
+        if (idx < 0 && q == home) idx = (int)__hip_atomic_fetch_add(tick + q, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (idx >= queue_len(q)) idx = -1;
+        for (int tries = 0; idx < 0 && tries < LG_NQ; ++tries) {   // own queue empty: the next XCD's
+          q = (q + 1) & (LG_NQ - 1);
+          const int len = queue_len(q);
+          if ((int)__hip_atomic_load(tick + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= len) continue;
+          const int i = (int)__hip_atomic_fetch_add(tick + q, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (i < len) idx = i;
+        }
+        if (idx >= 0) {
+          const int b0 = a.B * q / LG_NQ, nb = a.B * (q + 1) / LG_NQ - b0;
+          const BankTicket k = bank_decode(a, nb, idx);
+          stage = k.stage, b = b0 + k.b, tile = k.tile;
+        }
       }
-      int stage = -1, b = 0, tile = 0, ready = 1;
-      if (idx >= 0) {
-        const int b0 = a.B * q / LG_NQ, nb = a.B * (q + 1) / LG_NQ - b0;
-        const BankTicket k = bank_decode(a, nb, idx);
-        stage = k.stage, b = b0 + k.b, tile = k.tile;
+      if (stage >= 0) {
         const unsigned int *dep = stage == 1 ? done1 + b : stage == 2 ? done2 + b : nullptr;
         const unsigned int need = (unsigned int)(stage == 1 ? a.tiles1 : a.tiles2);
         if (dep && __hip_atomic_load(dep, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) ready = 0;
-        // the draw for the round after this one, answered while this tile runs
-        nq = q;
-        if (round == 0 && q == home) ni = n_home + (int)(blockIdx.x / LG_NQ);
-        else ni = (int)__hip_atomic_fetch_add(tick + q, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
       s_ticket[0] = stage;
       s_ticket[1] = b;
       s_ticket[2] = tile;
       s_ticket[3] = ready;
+      s_ticket[4] = q;
     }
+    first = false;
     __syncthreads();
-    const int stage = s_ticket[0], b = s_ticket[1], tile = s_ticket[2];
+    int stage = s_ticket[0], b = s_ticket[1], tile = s_ticket[2];
+    const int q = s_ticket[4];
     const bool ready = s_ticket[3] != 0;
+    own_stage = -1;
     if (stage < 0 || !ready) {
       // nothing left, or the ticket's inputs are not complete (rare: see above): announce the finished tile NOW -- the
-      // inputs waited for may include it -- and wait
+      // inputs waited for may include it -- and wait; a K2 ticket that waits looks for unclaimed reserved K1 tickets of its
+      // bucket meanwhile and, when it finds one, puts itself aside and runs that first
       if (pending) {
         __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): this wave's stores have been performed
         __syncthreads();                      // ... and every wave's
@@ -773,12 +817,29 @@ __global__ __launch_bounds__(LG4_THREADS, 4) void k123_bank(const K123Args<T1, T
         pending = nullptr;
       }
       if (stage < 0) return;
+      __syncthreads();   // (s_ticket has been read by every thread)
       if (threadIdx.x == 0) {
         const unsigned int *dep = stage == 1 ? done1 + b : done2 + b;
         const unsigned int need = (unsigned int)(stage == 1 ? a.tiles1 : a.tiles2);
-        while (__hip_atomic_load(dep, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) __builtin_amdgcn_s_sleep(4);
+        const int bl = b - a.B * q / LG_NQ, nres = reserved(q);
+        int help = -1;
+        for (unsigned int spins = 0; __hip_atomic_load(dep, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need; ++spins) {
+          __builtin_amdgcn_s_sleep(4);
+          if (stage != 1 || (spins & 63u) != 63u) continue;
+          for (int i = bl * a.tiles1; i < (bl + 1) * a.tiles1 && i < nres && help < 0; ++i)
+            if (__hip_atomic_load(claim + q * a.claims + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u &&
+                __hip_atomic_exchange(claim + q * a.claims + i, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u)
+              help = i - bl * a.tiles1;
+          if (help >= 0) break;
+        }
+        s_ticket[5] = help;
       }
       __syncthreads();
+      const int help = s_ticket[5];
+      if (help >= 0) {   // this round: the reserved K1 tile nobody had started; next round: the ticket put aside
+        own_stage = stage, own_b = b, own_tile = tile, own_q = q;
+        stage = 0, tile = help;
+      }
     }
     // an opaque copy of threadIdx.x per ticket: otherwise the lane offsets, panel addresses ... of ALL three stages are
     // computed once in front of the loop and stay live through every stage (50 spilled VGPRs in K1's epilogue)
@@ -786,23 +847,33 @@ __global__ __launch_bounds__(LG4_THREADS, 4) void k123_bank(const K123Args<T1, T
     asm volatile("" : "+v"(tid));
     const K123Args<T1, TG> *cap = ap;   // (the same for the argument block: its scalar loads would all be hoisted)
     asm volatile("" : "+s"(cap));
+    BankHooks hooks;
+    hooks.deferred = pending;
+    if (own_stage < 0) {   // (a helper already holds its next ticket)
+      hooks.draw = tick + q;
+      hooks.drawn_lds = drawn_lds;
+    }
     unsigned int *signal = nullptr;
     if (stage == 0) {
       K1Args<T1, TG> k1 = const_copy(&cap->k1);
       globalize(k1);
-      k1_tile<T1, TG, false, true>(k1, b, tile, reinterpret_cast<T1 *>(smem), tid, pending);
+      k1_tile<T1, TG, false, true>(k1, b, tile, reinterpret_cast<T1 *>(smem), tid, hooks);
       signal = done1 + b;
     } else if (stage == 1) {
       K2Args<TG> k2 = const_copy(&cap->k2);
       globalize(k2);
-      k2_tile<TG, true>(k2, b, tile, reinterpret_cast<TG *>(smem), tid, pending);
+      k2_tile<TG, true>(k2, b, tile, reinterpret_cast<TG *>(smem), tid, hooks);
       signal = done2 + b;
     } else {
       K3Args<TG> k3 = const_copy(&cap->k3);
       globalize(k3);
-      k3_tile<TG>(k3, b, tile, reinterpret_cast<TG *>(smem), tid, pending);
+      k3_tile<TG>(k3, b, tile, reinterpret_cast<TG *>(smem), tid, hooks);
     }
     pending = signal;
+    if (own_stage < 0 && threadIdx.x == 0) {
+      nq = q;
+      ni = *drawn_lds;   // (thread 0 wrote it itself, behind the K loop)
+    }
   }
 }
 
@@ -1021,9 +1092,16 @@ __global__ void lg_tables(int LD, int B, const double *t, const double *lam,
                           int bank_grid = 0) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   if (bank_dst) {
-    // queue q starts behind the tickets its workgroups take without asking (k123_bank: two each, for a grid of `bank_grid`
-    // workgroups)
-    if (idx < LG_NQ + 2 * bank.q.B) bank.q.queue[idx] = idx < LG_NQ ? 2u * (unsigned int)((bank_grid - idx + LG_NQ - 1) / LG_NQ) : 0u;
+    // (queue q's counter starts behind its reserved first tickets, k123_bank: min(home workgroups, K1 tickets, claims))
+    // (a grid-stride loop: a small bank has fewer table entries than queue words)
+    for (int i = idx; i < LG_NQ + 2 * bank.q.B + LG_NQ * bank.q.claims; i += (int)(gridDim.x * blockDim.x)) {
+      unsigned int v = 0u;
+      if (i < LG_NQ) {
+        const int homes = (bank_grid - i + LG_NQ - 1) / LG_NQ, k1 = (bank.q.B * (i + 1) / LG_NQ - bank.q.B * i / LG_NQ) * bank.q.tiles1;
+        v = (unsigned int)min(min(homes, k1), bank.q.claims);
+      }
+      bank.q.queue[i] = v;
+    }
     if (idx == 0) *bank_dst = bank;
   }
   if (idx >= B * LD) return;
