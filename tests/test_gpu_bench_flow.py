@@ -33,6 +33,11 @@ def test_two_ranks_share_the_gpu_through_the_gloo_hook():
     # weak scaling: both ranks' events are in the counted total (10,000 families x 64 cherries x ~65 contacts each)
     assert cc["value"] * cc["ms_per_step"] * 1e-3 > 6.0e7
     assert "secondary" not in d      # the LG replica line belongs to N = 1
+    # two ranks on ONE device = two persistent bank launches (k123_bank) sharing it: each must make progress with whatever
+    # share of the slots it gets (every ticket drawn or claimed by the workgroup that runs it).  The first fused version, which
+    # handed tickets to workgroups by index, took 7.9 SECONDS per epoch here -- the two launches waited for each other's
+    # non-resident workgroups until the scheduler's preemption timer let them through.
+    assert d["ms_per_step"] < 100.0, d["ms_per_step"]
     # round 4: the N > 1 line is self-diagnosing -- which transport carried the per-epoch all-reduce (None: torch's, because
     # the raw RCCL communicator could not be made here), per-phase maxima over the ranks, and every widened row of SURVEY 8f
     assert "rccl_ranks" in d and d["rccl_ranks"] is None
