@@ -329,3 +329,125 @@ def test_jtt_ipw_from_two_reduced_sums_equals_the_tensor_form():
                 X = Cs if sym else C
                 got = jtt_ipw_from_statistics(X.sum(0), (X / t[:, None, None]).sum(0), t, m, use_ipw=ipw)
                 assert np.allclose(got, orc.jtt_ipw(t, C, m, use_ipw=ipw, symmetrize=sym), rtol=1e-12, atol=1e-14)
+
+
+def test_bank_ticket_protocol_finishes_with_any_number_of_resident_workgroups():
+    """A model of the ticket protocol of the fused bank launch (csrc/large_bank.hip.h, k123_bank): per-queue counters, the
+    reserved first tickets with claim flags, the per-bucket completion counters, deferred announcements and the `help` path.
+    Only R of the launch's workgroups are ever resident (persistent workgroups leave only when no ticket is left, so the others
+    never start -- two launches sharing a GPU); a random scheduler advances one resident workgroup at a time.  Every tile must
+    run exactly once, after its inputs, and the launch must end: with tickets handed out by index (the first fused version)
+    this model deadlocks as the GPU did."""
+    import random
+
+    def run(B, t1, t2, t3, grid, resident, seed, claimable=True):
+        NQ = 8
+        rng = random.Random(seed)
+        per = t1 + t2 + t3
+        nb = [B * (q + 1) // NQ - B * q // NQ for q in range(NQ)]
+        b0 = [B * q // NQ for q in range(NQ)]
+        qlen = [n * per for n in nb]
+        homes = [(grid - q + NQ - 1) // NQ for q in range(NQ)]
+        reserved = [min(homes[q], nb[q] * t1) for q in range(NQ)]
+        tick = list(reserved)
+        claim = [[0] * max(reserved[q], 1) for q in range(NQ)]
+        done1, done2 = [0] * B, [0] * B
+        ran = {}
+
+        def decode(q, idx):
+            n = nb[q]
+            if idx < n * t1:
+                return 0, b0[q] + idx // t1, idx % t1
+            if idx < n * (t1 + t2):
+                i = idx - n * t1
+                return 1, b0[q] + i // t2, i % t2
+            i = idx - n * (t1 + t2)
+            return 2, b0[q] + i // t3, i % t3
+
+        class WG:
+            def __init__(self, bid):
+                self.bid, self.home, self.first = bid, bid % NQ, True
+                self.q, self.ticket, self.stash, self.pending, self.done = bid % NQ, None, None, None, False
+
+            def flush(self):
+                if self.pending is not None:
+                    arr, b = self.pending
+                    arr[b] += 1
+                    self.pending = None
+
+            def step(self):
+                if self.ticket is None:
+                    if self.stash is not None:
+                        self.ticket, self.stash = self.stash, None
+                    else:
+                        idx, q = -1, self.q
+                        if self.first:
+                            i0 = self.bid // NQ
+                            if i0 < reserved[self.home]:
+                                if not claimable or claim[self.home][i0] == 0:
+                                    claim[self.home][i0] = 1
+                                    idx = i0
+                            self.first = False
+                        if idx < 0 and q == self.home:
+                            idx, tick[q] = tick[q], tick[q] + 1
+                        if idx >= qlen[q]:
+                            idx = -1
+                        tries = 0
+                        while idx < 0 and tries < NQ:
+                            q = (q + 1) % NQ
+                            tries += 1
+                            if tick[q] >= qlen[q]:
+                                continue
+                            i, tick[q] = tick[q], tick[q] + 1
+                            if i < qlen[q]:
+                                idx = i
+                        if idx < 0:
+                            self.flush()
+                            self.done = True
+                            return
+                        self.q = q
+                        self.ticket = decode(q, idx) + (q,)
+                    return
+                stage, b, tile, q = self.ticket
+                ready = stage == 0 or (stage == 1 and done1[b] >= t1) or (stage == 2 and done2[b] >= t2)
+                if not ready:
+                    self.flush()
+                    if stage == 1 and claimable:   # help: an unclaimed reserved K1 ticket of this bucket
+                        bl = b - b0[q]
+                        for i in range(bl * t1, (bl + 1) * t1):
+                            if i < reserved[q] and claim[q][i] == 0:
+                                claim[q][i] = 1
+                                self.stash, self.ticket = self.ticket, (0, b, i - bl * t1, q)
+                                return
+                    return   # spin
+                assert (stage, b, tile) not in ran
+                if stage == 1:
+                    assert done1[b] == t1
+                if stage == 2:
+                    assert done2[b] == t2
+                ran[(stage, b, tile)] = True
+                self.flush()   # (the device announces the previous tile from inside this one)
+                self.pending = (done1, b) if stage == 0 else (done2, b) if stage == 1 else None
+                self.ticket = None
+
+        # without claim flags the reserved tickets belong to their workgroups by index, resident or not
+        wgs = [WG(i) for i in range(grid)]
+        running = wgs[:resident]
+        waiting = wgs[resident:]
+        for _ in range(400000):
+            if not running:
+                break
+            w = rng.choice(running)
+            w.step()
+            if w.done:
+                running.remove(w)
+                if waiting:
+                    running.append(waiting.pop(0))
+        return not running and not waiting and len(ran) == B * per
+
+    for B, t1, t2, t3, grid in ((129, 15, 25, 15, 1024), (9, 1, 1, 1, 27), (3, 3, 4, 3, 30), (20, 6, 9, 6, 420)):
+        for resident in (grid, max(1, grid // 2), max(1, grid // 7), 1):
+            for seed in (1, 2):
+                assert run(B, t1, t2, t3, grid, resident, seed), (B, grid, resident, seed)
+    # the first fused version (tickets by index, no claim flags): half the workgroups resident is a deadlock
+    assert not run(129, 15, 25, 15, 1024, 512, 1, claimable=False)
