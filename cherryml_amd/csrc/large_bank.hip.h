@@ -131,7 +131,7 @@ __device__ __forceinline__ void lg4_store_panel(T *s, const typename Mfma<T>::ve
 // What the ticket loop of k123_bank has a tile do on the side, from inside its K loop where the round trips cost nothing:
 //   deferred: the counter that announces the PREVIOUS tile of this workgroup, bumped behind the wait for this tile's first
 //             panels (the wait for the previous tile's stores is then free);
-//   draw:     the ticket counter the NEXT ticket is drawn from, in the middle of the loop; the answer is left in
+//   draw:     the ticket counter the NEXT ticket is drawn from, at the third K-step; the answer is left in
 //             *drawn_lds (a word of the panel buffer that no epilogue uses) once the loop is over.
 struct BankHooks {
   unsigned int *deferred = nullptr;
@@ -175,8 +175,9 @@ __device__ __forceinline__ void lg4_gemm_tile(const GemmOperands<T> &g, int m0, 
   __syncthreads();
   if (deferred && tid == 0) __hip_atomic_fetch_add(deferred, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   int drawn = -1;
-  const int draw_kt = nk / 2;   // (mid-loop: the workgroups of a launch start together but are spread out by then, and half a
-                                // K loop is left for the answer: drawn four K-steps before the end, K3's epilogue waited 9 us for it)
+  const int draw_kt = nk > 2 ? 2 : 0;   // (early: the answer has the rest of the tile; drawn in the middle of the loop or four
+                                         // K-steps before its end, the epilogues waited 5-9 us for it -- a counter serves ~1.5
+                                         // draws per us, the answers queue up)
   for (int kt = 0; kt < nk; ++kt) {
     const T *cA = sA + (kt & 1) * (LG_KT * LG_TM), *cB = sB + (kt & 1) * (LG_KT * LG_TN);
     if (hooks.draw && kt == draw_kt && tid == 0)
