@@ -195,6 +195,7 @@ static int large_eval(cb_bank *h, bool normalize, double *lossd, double *out, bo
     // small); the loss partials are summed after it
     const int total = B * (tiles_k1 + tiles + tiles_k3), grid = std::min(h->bank_slots, total);
     const int sym = h->sym_counts ? 1 : 0;
+    const int test_no_claim = getenv("CB_BANK_TEST_NO_CLAIM") ? 1 : 0;   // (tests/test_gpu_s400_full.py: the help path)
     // (the phase marks ride on the launches as stop events: handle_host.hip.h, stop_event())
     if (h->profile) h->ev_rec[EV_K1] = h->ev_rec[EV_K2] = false;   // CB_T_K1 = the whole launch (+ tables), see read_phase_times
     const hipEvent_t bank_stop = stop_event(h, EV_K3);
@@ -211,7 +212,7 @@ static int large_eval(cb_bank *h, bool normalize, double *lossd, double *out, bo
       K123Args<float, float> a{{S, LD, B, h->Utf, h->Af, tb, h->Ff, h->sigma, h->Ct32, h->Gt32, h->loss_part, inv_n, h->dsq, nullptr, skipw},
                                {LD, h->Gt32, h->Uf, h->T32, skipw},
                                {LD, B, h->T32, h->Uf, tb, h->lam, h->E, h->H, h->Gt32, sym, skipw},
-                               {h->bank_queue, B, tiles_k1, tiles, tiles_k3, h->bank_claims}};
+                               {h->bank_queue, B, tiles_k1, tiles, tiles_k3, h->bank_claims, test_no_claim}};
       auto *dst = launch(a);
       hipLaunchKernelGGL(lg_cast_f32, dim3((unsigned)((std::max(LL, (size_t)B * LD) + 255) / 256)), dim3(256), 0, h->stream, LL,
                          (size_t)B * LD, h->U, h->Vc, h->A, h->F, h->Uf, h->Utf, h->Af, h->Ff);
@@ -220,7 +221,7 @@ static int large_eval(cb_bank *h, bool normalize, double *lossd, double *out, bo
       K123Args<double, float> a{{S, LD, B, h->Vc, h->A, tb, h->F, h->sigma, h->Ct, h->Gt32, h->loss_part, inv_n, h->dsq, nullptr, skipw},
                                 {LD, h->Gt32, h->Uf, h->T32, skipw},
                                 {LD, B, h->T32, h->Uf, tb, h->lam, h->E, h->H, h->Gt32, sym, skipw},
-                                {h->bank_queue, B, tiles_k1, tiles, tiles_k3, h->bank_claims}};
+                                {h->bank_queue, B, tiles_k1, tiles, tiles_k3, h->bank_claims, test_no_claim}};
       auto *dst = launch(a);
       hipLaunchKernelGGL(lg_cast_f32, dim3((unsigned)((std::max(LL, (size_t)B * LD) + 255) / 256)), dim3(256), 0, h->stream, LL,
                          (size_t)B * LD, h->U, h->Vc, h->A, h->F, h->Uf, h->Utf, h->Af, h->Ff);
@@ -229,7 +230,7 @@ static int large_eval(cb_bank *h, bool normalize, double *lossd, double *out, bo
       K123Args<double, double> a{{S, LD, B, h->Vc, h->A, tb, h->F, h->sigma, h->Ct, h->Gt, h->loss_part, inv_n, h->dsq, nullptr, skipw},
                                  {LD, h->Gt, h->U, h->T, skipw},
                                  {LD, B, h->T, h->U, tb, h->lam, h->E, h->H, h->Gt, sym, skipw},
-                                 {h->bank_queue, B, tiles_k1, tiles, tiles_k3, h->bank_claims}};
+                                 {h->bank_queue, B, tiles_k1, tiles, tiles_k3, h->bank_claims, test_no_claim}};
       auto *dst = launch(a);
       if (cb_launch_bank_fused(0, dst, grid, h->stream, bank_stop) != 0) return fail(CB_EHIP, "k123_bank: launch failed");
     }

@@ -634,6 +634,8 @@ struct BankQueueArgs {
                          // flags of the reserved first tickets; all set by lg_tables in front of the launch
   int B, tiles1, tiles2, tiles3;
   int claims;            // reserved tickets per queue (>= the workgroups of a launch that call one queue home)
+  int test_no_claim;     // test hook (CB_BANK_TEST_NO_CLAIM): no workgroup takes its reserved ticket -- as if none of their owners
+                         // were resident; they are then run by the workgroups that wait for them (the `help` path)
 };
 
 // Ticket `idx` of a queue that owns `nb` buckets -> (stage 0 / 1 / 2, local bucket, tile): the queue's K1 tiles bucket by
@@ -771,7 +773,7 @@ __global__ __launch_bounds__(LG4_THREADS, 4) void k123_bank(const K123Args<T1, T
         int idx = ni;
         if (first) {   // the reserved first ticket, if nobody has run it for us
           const int i0 = (int)(blockIdx.x / LG_NQ);
-          if (i0 < reserved(home) &&
+          if (i0 < reserved(home) && !a.test_no_claim &&
               __hip_atomic_exchange(claim + home * a.claims + i0, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u)
             idx = i0;
         }

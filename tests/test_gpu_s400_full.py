@@ -456,3 +456,31 @@ def test_fused_bank_launch_on_small_and_ragged_banks(S, B, sym, monkeypatch):
     lo = float(lo.detach())
     assert abs(float(la[0]) - lo) <= 1e-12 * abs(lo)
     assert relerr(da[0], Qt.grad.numpy()) < 1e-10
+
+
+def test_reserved_tickets_nobody_claims_are_run_by_the_workgroups_that_wait_for_them(dense, monkeypatch):
+    """The fused bank launch reserves the first K1 tickets of every queue for its workgroups (one uncontended claim instead of
+    128 draws on one counter); a reserved ticket whose workgroup is not resident -- another launch holds its slot -- must not be
+    waited for forever.  Test hook CB_BANK_TEST_NO_CLAIM=1: no workgroup takes its reserved ticket; every one of them (128 per
+    queue on the bench bank) is then found and run by a workgroup that waits for its bucket.  Same bits as the three separate
+    launches, on the bench bank and on a small one."""
+    from cherryml_amd import CherryBank
+    for t, C, Q, pi in ((dense["t"], dense["C"], None, None), _random_bank(100, 9, 77)):
+        if Q is None:
+            import cherryml_amd
+            import torch
+            from cherryml_amd.estimation._jtt_ipw import jtt_ipw_from_arrays
+            init = jtt_ipw_from_arrays(dense["t"], dense["C"], dense["mask"])
+            mod = cherryml_amd.RateMatrix(num_states=400, mode="pande_reversible", mask=torch.tensor(dense["mask"]),
+                                          pi=torch.ones(400, dtype=torch.float64) / 400, pi_requires_grad=True, initialization=init)
+            Q, pi = mod().detach().numpy(), mod.stationary().detach().numpy()
+        out = {}
+        for name, env in (("helped", {"CB_BANK_TEST_NO_CLAIM": "1"}), ("separate", {"CB_BANK_UNFUSED": "1"})):
+            for k in ("CB_BANK_TEST_NO_CLAIM", "CB_BANK_UNFUSED"):
+                monkeypatch.delenv(k, raising=False)
+            for k, v in env.items():
+                monkeypatch.setenv(k, v)
+            with CherryBank(t, C) as bank:
+                out[name] = bank.loss_grad(Q, pi)
+        (la, da), (lb, db) = out["helped"], out["separate"]
+        assert np.all(np.isfinite(la)) and np.array_equal(la, lb) and np.array_equal(da, db)
