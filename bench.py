@@ -63,10 +63,12 @@ def cpu_budget() -> int:
     return max(1, n)
 
 
-# host threads: the budget shared by the ranks of this job, one core of each rank left to the thread that feeds the GPU; idle
-# OpenMP workers sleep instead of spinning (set BEFORE numpy / torch load their thread pools)
+# host threads: the budget shared by the ranks of this job, a quarter of each rank's share (at least one core) left to the thread
+# that feeds the GPU and the runtime's own threads (with one core left, 3 throttled periods in six driver commands and one of
+# them 9 % slower); idle OpenMP workers sleep instead of spinning (set BEFORE numpy / torch load their thread pools)
 CPU_BUDGET = cpu_budget()
-HOST_THREADS = max(1, CPU_BUDGET // max(1, int(os.environ.get("WORLD_SIZE", "1"))) - 1)
+_share = CPU_BUDGET // max(1, int(os.environ.get("WORLD_SIZE", "1")))
+HOST_THREADS = max(1, _share - max(1, _share // 4))
 for _k in ("OMP_NUM_THREADS", "MKL_NUM_THREADS", "OPENBLAS_NUM_THREADS"):
     os.environ.setdefault(_k, str(HOST_THREADS))
 os.environ.setdefault("KMP_BLOCKTIME", "0")
@@ -239,7 +241,7 @@ def cpu_baseline(wl, name):
         u, p = orc.invert_pande_reversible(init, wl["mask"])
         # >= 3 timed evaluations each way; the MEDIAN is the baseline and the spread is reported (a single evaluation of
         # the 400-state sample varied by 70 % between two runs of the same command in round 2)
-        reps, inner = (3, 1) if wl["S"] == 400 else (5, 40)
+        reps, inner = (7, 1) if wl["S"] == 400 else (5, 40)   # (400 states: ~0.6 s per evaluation of the 32-bucket sample on 15 threads)
         orc.evaluate(u, p, wl["mask"], t[:1], C[:1], torch.float32)  # warm up
         samples = []
         for _ in range(reps):
@@ -297,7 +299,7 @@ def launch_ranks(n, argv, child=None, grace=15.0, poll=0.05, _attempt=0):
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), CB_BENCH_LAUNCHER="1")
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC only on these hosts (RCCL across processes)
         for k in ("OMP_NUM_THREADS", "MKL_NUM_THREADS", "OPENBLAS_NUM_THREADS"):   # the ranks SHARE the CPU budget
-            env[k] = str(max(1, CPU_BUDGET // n - 1))
+            env[k] = str(max(1, CPU_BUDGET // n - max(1, CPU_BUDGET // n // 4)))
         # rank 0's stdout is the result; the other ranks' stdout joins the launcher's stderr
         procs.append(subprocess.Popen(cmd + list(argv), env=env, stdout=subprocess.PIPE if r == 0 else sys.stderr))
     import threading

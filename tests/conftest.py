@@ -19,7 +19,7 @@ def _cpu_budget():
 
 
 for _k in ("OMP_NUM_THREADS", "MKL_NUM_THREADS", "OPENBLAS_NUM_THREADS"):   # before numpy / torch load their thread pools
-    os.environ.setdefault(_k, str(max(1, _cpu_budget() - 1)))
+    os.environ.setdefault(_k, str(max(1, _cpu_budget() - max(1, _cpu_budget() // 4))))
 os.environ.setdefault("KMP_BLOCKTIME", "0")
 os.environ.setdefault("OMP_WAIT_POLICY", "PASSIVE")
 
