@@ -352,6 +352,10 @@ def main():
     ap.add_argument("--no-secondary", action="store_true")
     ap.add_argument("--force-sharded", action="store_true",
                     help="run the multi-GPU code path (ShardedBank + collectives) even at N = 1")
+    ap.add_argument("--shard-of", type=int, default=0, metavar="N",
+                    help="coevo400 / coevo400_demo on ONE GPU: rank 0's share of an N-rank job -- its buckets of the N-way deal "
+                         "of the non-empty buckets + the replicated eigensolve, the C-driven loop with the in-library "
+                         "all-reduce (a single-rank communicator) -- i.e. what one GPU of N does per epoch, measured")
     ap.add_argument("--torch-glue", action="store_true",
                     help="multi-GPU co-evolution: keep theta->Q / Adam in torch and the collective in "
                          "torch.distributed instead of the C-driven loop with the in-library ncclAllReduce")
@@ -404,7 +408,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def run(workload, steps, warmup, with_cpu):
+    def run(workload, steps, warmup, with_cpu, shard_of=0):
         import cherryml_amd
         from cherryml_amd.distributed import ShardedBank
         from cherryml_amd.estimation import jtt_ipw_from_arrays
@@ -414,7 +418,9 @@ def main():
         S = wl["S"]
         bank_dtype = args.dtype if S > 32 else "f64"   # the small-state kernels are float64
         resumed = False   # the timed epochs continue the warm-up's optimisation (C-driven 400-state loop)
-        if wl["kind"] == "single" and S > 32 and (world > 1 or args.force_sharded):
+        if shard_of and not (wl["kind"] == "single" and S > 32 and world == 1):
+            raise SystemExit("--shard-of: one 400-state bank on one GPU (coevo400 / coevo400_demo, --gpus 1)")
+        if wl["kind"] == "single" and S > 32 and (world > 1 or args.force_sharded or shard_of):
             # ---- co-evolution on N > 1 GPUs: torch keeps theta -> Q and Adam (the collective is
             #      torch.distributed's), HIP does loss + dL/dQ; buckets sharded over the ranks,
             #      one all-reduce of S^2 + 1 doubles per epoch
@@ -429,11 +435,24 @@ def main():
             # the sufficient statistics of its 1/N of the families (here: 1/N of the bank's counts); ONE
             # reduce-scatter over the non-empty buckets sums them and leaves each rank with the buckets
             # it owns; then per epoch one all-reduce of S^2 + 1 doubles.
-            sharded = ShardedBank.from_rank_counts(wl["t"], torch.tensor(wl["C"] / world, device=dev), dtype=bank_dtype)
+            if shard_of:
+                # ONE rank's share of a shard_of-rank job, alone on this GPU: the buckets rank 0 would own (every
+                # shard_of-th non-empty bucket), the whole replicated part, the same C-driven loop and enqueue sequence
+                # (the two ncclAllReduce calls go to a single-rank communicator).  A self-consistent smaller problem: the
+                # loss is normalised by the share's own count, so its Adam trajectory -- and with it the warm eigensolver's
+                # work -- is that of a bank with an eighth of the buckets spread over the same branch lengths.
+                sharded = ShardedBank(wl["t"], wl["C"], dtype=bank_dtype, emulate=(0, shard_of))
+                n_pairs_total = sharded.total_count
+                sharding = (f"rank 0's share of a {shard_of}-rank job, alone on one GPU: {len(sharded.local_buckets)} of "
+                            f"{wl.get('live', wl['C'].shape[0])} non-empty buckets + the replicated eigensolver / K4 / "
+                            "parameter step; in-library all-reduce on a single-rank communicator")
+            else:
+                sharded = ShardedBank.from_rank_counts(wl["t"], torch.tensor(wl["C"] / world, device=dev), dtype=bank_dtype)
+                n_pairs_total = wl["n_pairs"]
+                sharding = (f"one bank; families x{world} -> reduce-scatter of the counts over buckets (once), "
+                            f"buckets x{world}, all-reduce(loss, dL/dA) per epoch; eigensolver replicated")
             bank = sharded.bank
-            n_pairs_total, scaling = wl["n_pairs"], "strong"
-            sharding = (f"one bank; families x{world} -> reduce-scatter of the counts over buckets (once), "
-                        f"buckets x{world}, all-reduce(loss, dL/dA) per epoch; eigensolver replicated")
+            scaling = "strong"
             B_local = len(sharded.local_buckets)
             in_library = not args.torch_glue
             if in_library:
@@ -545,7 +564,7 @@ def main():
             final_loss = float(np.sum(r["loss"][-1]) if "loss" in r
                                else np.sum(r["loss_per_epoch_per_site"][-1]))
         tm_max, rccl_ranks = None, None
-        if world > 1 or args.force_sharded:
+        if world > 1 or args.force_sharded or shard_of:
             rccl_ranks = getattr(getattr(bank, "rccl", None), "count", None)   # ncclCommCount of the raw communicator
         if world > 1:
             tdt = torch.tensor([dt], dtype=torch.float64, device=dev)
@@ -568,7 +587,7 @@ def main():
             tri = (tn_ * (tn_ + 1) / 2) / float(tn_ * tn_)   # share of 80x80 tiles actually multiplied
             # whole epoch: SURVEY 8d's algorithmic flops of one epoch (6 B S^3 bank + ~13 S^3 eigensolver
             # and back-rotation; 49.6 GFLOP at S = 400, B = 129) over the WALL time of one step
-            epoch_flops = 6.0 * wl.get("live", wl["C"].shape[0]) * S ** 3 + 13.0 * S ** 3
+            epoch_flops = 6.0 * (B_local if shard_of else wl.get("live", wl["C"].shape[0])) * S ** 3 + 13.0 * S ** 3
             epoch_tflops = epoch_flops / (dt / steps) / 1e12
             util, util_src = _mfma_util(bank_dtype)
             fused = tm["k1"] > 0 and tm["k2"] == 0 and tm["k3"] == 0   # CB_T_K1 = the one span of the fused launch
@@ -660,9 +679,15 @@ def main():
             "phase_ms": {k: round(v, 4) for k, v in tm.items()},
             "final_loss": final_loss,
         }
+        if S > 32:
+            # planned (device-controlled) warm eigensolves of the timed call: how many, continuations, host spins
+            out["eigh"] = (bank.bank if hasattr(bank, "bank") else bank).eigh_counters()
         if tm_max is not None:
             out["phase_ms_max_over_ranks"] = tm_max
-        if world > 1 or args.force_sharded:
+        if shard_of:
+            out["shard_of"] = shard_of
+            out["config"]["share_buckets"] = int(B_local)
+        if world > 1 or args.force_sharded or shard_of:
             # which transport carried the per-epoch all-reduce: the raw RCCL communicator's own rank count (None: torch's)
             out["rccl_ranks"] = rccl_ranks
         if S <= 32 and wl["kind"] == "single":
@@ -685,9 +710,12 @@ def main():
                 "measured_on_ranks": world,
                 "note": "per epoch on rank 0: replicated = eigensolver + K4 (every rank, whole matrix), sharded = K1 + K2 + K3 "
                         "(this rank's buckets), other = theta->A, parameter kernels, all-reduce, gaps",
-                **({"projected_speedup_at_8": round((rep + shd + other) / (rep + shd / 8.0 + other), 2),
-                    "projection": "(replicated + sharded + other) / (replicated + sharded / 8 + other), all-reduce not "
-                                  "included: an upper bound for one bank on 8 GPUs"} if world == 1 else {})}
+                **({"projected_speedup_at_8_arithmetic": round((rep + shd + other) / (rep + shd / 8.0 + other), 2),
+                    "projection_arithmetic": "(replicated + sharded + other) / (replicated + sharded / 8 + other), all-reduce "
+                                             "not included: an upper bound for one bank on 8 GPUs"}
+                   if world == 1 and not shard_of else {})}
+            if shard_of:
+                out["amdahl"]["measured_rank_ms"] = round(dt / steps * 1e3, 4)
         if with_cpu:
             out["cpu_baseline"] = cpu_baseline(wl, workload)
         bank.close()
@@ -728,12 +756,27 @@ def main():
                            world == 1 and not args.no_cpu_baseline)
         finish(out)
         return
-    out = run(args.workload, steps, warmup, world == 1 and not args.no_cpu_baseline)
+    out = run(args.workload, steps, warmup, world == 1 and not args.no_cpu_baseline and not args.shard_of, shard_of=args.shard_of)
     keep = ("value", "unit", "n_gpus", "scaling", "ms_per_step", "steps", "warmup", "dtype", "config", "roofline",
-            "cpu_baseline", "phase_ms")
+            "cpu_baseline", "phase_ms", "shard_of", "amdahl", "eigh")
     if args.workload == "coevo400" and not args.no_secondary:
         # every rank takes part (the multi-rank runs end in collectives); rank 0 attaches the lines
         extra = {}
+        if world == 1 and not args.shard_of:
+            # what ONE rank of an 8-rank job does per epoch, measured on this GPU (same steps / warm-up as the headline):
+            # the projection of the strong-scaling speed-up of one bank comes from this line, not from dividing phase times
+            sh = run(args.workload, steps, warmup, False, shard_of=8)
+            extra["secondary_shard8"] = sh
+            if rank == 0 and sh is not None and "amdahl" in out:
+                rank_ms = sh["ms_per_step"]
+                out["amdahl"].update({
+                    "measured_rank_ms": round(rank_ms, 4),
+                    "measured_rank_phase_ms": sh["phase_ms"],
+                    "projected_speedup_at_8": round(out["ms_per_step"] / rank_ms, 2),
+                    "projection": "ms_per_step of the whole bank on this GPU / ms_per_step of rank 0's share of an 8-rank job "
+                                  "measured alone on this GPU (secondary_shard8: every 8th non-empty bucket + the replicated "
+                                  "eigensolver, K4, parameter step, the loop's own enqueue sequence); the 1.28 MB all-reduce "
+                                  "over xGMI is NOT in it (single-rank communicator): an upper bound"})
         if world == 1:
             # BASELINE.json's metric names both sizes: the line always carries the 20x20 LG configuration
             # too (its own epoch counts: an LG epoch takes < 0.1 ms)

@@ -44,6 +44,7 @@ SIGNATURES = {
     "cb_train_pande_reversible": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, C.c_double, C.c_int,
                                             C.c_int, _vp, _vp, _vp, _vp, C.c_int]),
     "cb_train_siterm": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_double, C.c_int, _vp, _vp]),
+    "cb_train_epoch_times": (C.c_int, [_vp, _vp, C.c_int]),
     "cb_count_transitions": (C.c_int, [C.c_int, C.c_int, C.c_int, _vp, _vp, C.c_int64, _vp, C.c_int64,
                                        _vp, C.c_int64, C.c_int, C.c_int, _vp]),
     "cb_jtt_ipw_stats": (C.c_int, [C.c_int, C.c_int, C.c_int, _vp, C.c_int, _vp, C.c_double, C.c_int, C.c_int, _vp, _vp]),

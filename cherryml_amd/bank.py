@@ -169,9 +169,16 @@ class CherryBank:
     def eigh_counters(self) -> dict:
         """planned (device-controlled) warm eigensolves of the S > 32 trainer: how many, how many had to be continued,
         sweeps of the last one (cb_eigh_counters)."""
-        v = np.zeros(3, dtype=np.int32)
-        _lib.check(_lib.load().cb_eigh_counters(self._h, v.ctypes.data, 3), "cb_eigh_counters")
-        return {"planned_solves": int(v[0]), "stalls": int(v[1]), "last_sweeps": int(v[2])}
+        v = np.zeros(4, dtype=np.int32)
+        _lib.check(_lib.load().cb_eigh_counters(self._h, v.ctypes.data, 4), "cb_eigh_counters")
+        return {"planned_solves": int(v[0]), "stalls": int(v[1]), "last_sweeps": int(v[2]), "record_spins": int(v[3])}
+
+    def epoch_times(self, num_epochs: int) -> np.ndarray:
+        """seconds from the entry of the last train_* call to the end of each of its epochs on the device
+        (cb_train_epoch_times; the reference's df_res `time` column, trainer.py:207-217)."""
+        s = np.zeros(int(num_epochs))
+        _lib.check(_lib.load().cb_train_epoch_times(self._h, s.ctypes.data, s.size), "cb_train_epoch_times")
+        return s
 
     def last_kernel_form(self) -> int:
         """which trainer kernels the last train_* call launched (cb_last_kernel_form: 1000 + 100 TS + 10 sym + w3, ...)"""
@@ -250,7 +257,7 @@ class CherryBank:
             loss.ctypes.data, Qb.ctypes.data, Ql.ctypes.data, Qp.ctypes.data if n_pow2 else None, n_pow2)
         _lib.check(rc, "cb_train_pande_reversible")
         snaps = {1 << i: Qp[i] for i in range(n_pow2) if (1 << i) <= E}
-        return dict(loss=loss, Q_best=Qb, Q_last=Ql, Q_pow2=snaps, upper_diag=up, log_pi=lp)
+        return dict(loss=loss, Q_best=Qb, Q_last=Ql, Q_pow2=snaps, upper_diag=up, log_pi=lp, time=self.epoch_times(E))
 
     def train_siterm(self, theta, Theta, num_epochs, lr=0.1):
         """SiteRM loop (_cherryml_vectorized.py:351-383) for all sites in one launch.
@@ -263,7 +270,7 @@ class CherryBank:
         rc = _lib.load().cb_train_siterm(self._h, th.ctypes.data, Th.ctypes.data, E, float(lr), 0,
                                          res.ctypes.data, lpeps.ctypes.data)
         _lib.check(rc, "cb_train_siterm")
-        return dict(res=res, loss_per_epoch_per_site=lpeps[:E], theta=th, Theta=Th)
+        return dict(res=res, loss_per_epoch_per_site=lpeps[:E], theta=th, Theta=Th, time=self.epoch_times(E))
 
     # -- device-pointer API (torch ROCm tensors, zero copy) -----------------
     def loss_grad_torch(self, Q, pi, normalize: bool = True, want_grad: bool = True):

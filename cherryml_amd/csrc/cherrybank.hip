@@ -234,15 +234,19 @@ static int large_eval(cb_bank *h, bool normalize, double *lossd, double *out, bo
       auto *dst = launch(a);
       if (cb_launch_bank_fused(0, dst, grid, h->stream, bank_stop) != 0) return fail(CB_EHIP, "k123_bank: launch failed");
     }
-    const LossArgs la{h->loss_part, B * tiles_k1, S, h->dsq, h->dirsum, inv_n, lossd};
+    const LossArgs la{h->loss_part, B * tiles_k1, S, h->dsq, h->dirsum, inv_n, lossd, skipw};
     const dim3 red_grid((unsigned)((LL + 255) / 256) + 1);   // (+ the workgroup that sums the loss partials)
     if (f32 || mixed)
       hipLaunchKernelGGL(k3_reduce_loss<float>, red_grid, dim3(256), 0, h->stream, h->Gt32, B, LL, h->Mt, h->sym_counts ? LD : 0, la);
     else
       hipLaunchKernelGGL(k3_reduce_loss<double>, red_grid, dim3(256), 0, h->stream, h->Gt, B, LL, h->Mt, h->sym_counts ? LD : 0, la);
+    // (a stalled planned solve: the reduction and K4 return at once too -- nothing runs on stale Gt / T, and h->loss / h->Mt
+    // are only written by the evaluation that follows a finished solve)
     K4Args k4a{S, LD, h->Mt, h->Vc, h->X, nullptr, nullptr, nullptr};
+    k4a.skip = skipw;
     launch_sg(h, k4a, 0);
     K4Args k4b{S, LD, h->Vc, h->X, dQd, dA_padded ? nullptr : h->dsq, nullptr, nullptr};
+    k4b.skip = skipw;
     launch_sg(h, k4b, 0, 0.0, 0.0, nullptr, stop_event(h, EV_K4));
     HIP_TRY(hipGetLastError());
     return CB_OK;
@@ -612,8 +616,9 @@ extern "C" int cb_debug_clock_stamps(unsigned long long *out) {
 
 extern "C" int cb_eigh_counters(cb_handle h, int *counts, int n) {
   if (!h || !counts || n < 0) return fail(CB_EINVAL, "cb_eigh_counters: NULL argument");
-  const int v[3] = {h->planned_solves, h->planned_stalls, h->last_sweeps};
-  for (int i = 0; i < n && i < 3; ++i) counts[i] = v[i];
+  const int v[4] = {h->planned_solves, h->planned_stalls, h->last_sweeps,
+                    (int)std::min<long long>(h->record_spins, 0x7fffffff)};
+  for (int i = 0; i < n && i < 4; ++i) counts[i] = v[i];
   return CB_OK;
 }
 extern "C" int cb_last_kernel_form(cb_handle h) { return h ? h->last_form : 0; }

@@ -76,6 +76,10 @@ static void eigh_plan_continue(const EighRecord &r, EighPlan &p) {
 
 static bool eigh_planned_setup(cb_bank *h) {
   if (h->ectl) return true;
+  // a failed attempt is not repeated: what it did allocate stays with the handle (freed with it), and a second attempt
+  // would allocate everything again -- the pinned block without anyone left to free the first one
+  if (h->planned_unavailable) return false;
+  h->planned_unavailable = true;   // (cleared at the end)
   const int LD = h->LD, nt = LD / 16;
   void *q = nullptr;
   if (hipMalloc(&q, EC_WORDS * sizeof(unsigned long long)) != hipSuccess) return false;
@@ -84,18 +88,21 @@ static bool eigh_planned_setup(cb_bank *h) {
   if (hipMalloc(&q, ((size_t)2 * nt * LD + (size_t)nt * nt + 8 + LD) * sizeof(double)) != hipSuccess) return false;
   h->allocs.push_back(q);
   h->epart = static_cast<double *>(q);
-  if (hipHostMalloc(&q, 2 * (EC_WORDS + 16) * sizeof(unsigned long long), hipHostMallocCoherent | hipHostMallocMapped) != hipSuccess) {
-    (void)hipGetLastError();
-    return false;
+  if (!h->epin) {
+    if (hipHostMalloc(&q, 2 * (EC_WORDS + 16) * sizeof(unsigned long long), hipHostMallocCoherent | hipHostMallocMapped) != hipSuccess) {
+      (void)hipGetLastError();
+      return false;
+    }
+    memset(q, 0, 2 * (EC_WORDS + 16) * sizeof(unsigned long long));
+    h->epin = static_cast<unsigned long long *>(q);
   }
-  memset(q, 0, 2 * (EC_WORDS + 16) * sizeof(unsigned long long));
-  h->epin = static_cast<unsigned long long *>(q);
   const int RS = LD + ((2 - LD % 32 + 32) % 32);
   const size_t lds = (size_t)(16 * RS + 3 * 16 * 17 + JB_WAVES * 256) * sizeof(double);
   if (hipFuncSetAttribute(reinterpret_cast<const void *>(lgj_round), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
     return false;
   if (hipMemsetAsync(ctl, 0, EC_WORDS * sizeof(unsigned long long), h->stream) != hipSuccess) return false;
   h->ectl = ctl;
+  h->planned_unavailable = false;
   return true;
 }
 
@@ -191,6 +198,7 @@ static int eigh_planned_record(cb_bank *h, unsigned long long seq, EighRecord &r
       got = true;
       break;
     }
+    if (it == 0) ++h->record_spins;   // (cb_eigh_counters: the host looked before the record was there)
 #if defined(__x86_64__)
     __builtin_ia32_pause();
 #endif

@@ -73,7 +73,11 @@ struct cb_bank {
   unsigned long long *ectl = nullptr, *epin = nullptr;
   double *epart = nullptr;
   unsigned long long eseq = 0;
+  bool planned_unavailable = false;   // eigh_planned_setup failed once on this handle: not tried again (host-driven solver)
   int planned_solves = 0, planned_stalls = 0;   // counters (cb_eigh_counters)
+  long long record_spins = 0;         // ... and how often the host found a solve's record not yet published when it looked
+  std::vector<double> epoch_seconds;  // cb_train_epoch_times: seconds from the entry of the last training call to the end of
+                                      // each of its epochs on the device
   EighPlan eplan;            // the next solve's plan: part of the optimisation's state (a resumed call continues with it,
                              // so W + K epochs in two calls equal one call bit for bit)
   int k3_chunk = 0, k3_nchunks = 0;

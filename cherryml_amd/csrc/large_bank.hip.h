@@ -945,9 +945,12 @@ struct LossArgs {
   const double *dsq, *dirsum;
   double inv_n;
   double *loss;
+  const unsigned long long *skip = nullptr;   // as K1Args::skip: the bank launch in front returned at once (stalled solve),
+                                              // h->loss / h->Mt keep the previous evaluation's values until the retry
 };
 template <typename T>
 __global__ __launch_bounds__(256) void k3_reduce_loss(const T *part, int nchunks, size_t n, double *out, int LD, LossArgs l) {
+  if (l.skip && *l.skip != 0ull) return;
   if (blockIdx.x + 1 == gridDim.x) lg_finish_loss_body(l.part, l.nparts, l.S, l.dsq, l.dirsum, l.inv_n, l.loss);
   else k3_reduce_body<T>(part, nchunks, n, out, LD);
 }
@@ -967,6 +970,7 @@ struct K4Args {
   // (all pairs or far pairs only) lgx_build decided on.
   const unsigned long long *sel = nullptr;
   const double *Aalt = nullptr, *Balt = nullptr;
+  const unsigned long long *skip = nullptr;   // as K1Args::skip (K4 behind a bank launch that returned at once)
 };
 
 // Single-matrix products (K4a, K4b, the warm-start G0 = A' U_prev, the first-order eigen
@@ -988,6 +992,7 @@ template <int NW, int UU, int NJ = 5>
 __global__ __launch_bounds__(NW * 64) void sg_gemm(K4Args a1, K4Args a2, int ns, double alpha, double beta) {
   __shared__ double sRed[NW / 2 > 4 ? NW / 2 : 4][NJ][256];
   const K4Args &a = blockIdx.y ? a2 : a1;
+  if (a.skip && *a.skip != 0ull) return;
   const int LD = a.LD, tilesN = (LD + 16 * NJ - 1) / (16 * NJ);
   const int tm = blockIdx.x / tilesN, tn = blockIdx.x - tm * tilesN;
   const int m0 = tm * 16, n0 = tn * 16 * NJ;

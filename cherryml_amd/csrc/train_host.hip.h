@@ -16,6 +16,21 @@ static int launch_train_nw(cb_bank *h, const TrainArgs &a) {
   return CB_OK;
 }
 
+// the 100 MHz wall clock at the head of a training call's epochs (the reference point of TrainArgs / LargeTrain::time_curve)
+__global__ void tr_stamp(double *out) { *out = (double)__builtin_amdgcn_s_memrealtime(); }
+
+// df_res's `time` column (trainer.py:207-217: seconds since the start at the end of every epoch) without returning to the
+// host between epochs: the device stamps its constant 100 MHz clock at the end of every epoch's parameter step
+// (time_curve[e]) and once at the head of the loop (time_curve[E], tr_stamp -- enqueued on an idle stream `t_first` seconds
+// after the call was entered).
+static void set_epoch_seconds(cb_bank *h, const char *ticks, int E, double t_first_s) {
+  h->epoch_seconds.assign((size_t)std::max(E, 0), 0.0);
+  if (!ticks || E <= 0) return;
+  std::vector<double> tk((size_t)E + 1);
+  memcpy(tk.data(), ticks, ((size_t)E + 1) * sizeof(double));
+  for (int e = 0; e < E; ++e) h->epoch_seconds[e] = t_first_s + (tk[e] - tk[E]) * 1e-8;
+}
+
 // S > 32 (one bank, pande_reversible): the epoch loop driven from here, kernels of train_large.hip.h
 static int run_fused_training_large(cb_bank *h, double *pi_param, double *up_param, const double *mask, int E,
                                     double lr, int do_adam, int flags, double *loss_curve, double *Q_best,
@@ -62,13 +77,14 @@ static int run_fused_training_large(cb_bank *h, double *pi_param, double *up_par
   auto alloc = [&](double **p, size_t n) -> bool { return ws_get(h, slot++, n, p); };
   auto release = [&]() { (void)hipStreamSynchronize(h->stream); };
   double *d_pi = nullptr, *d_up = nullptr, *d_mom = nullptr, *d_mask = nullptr, *d_loss = nullptr, *d_Qb = nullptr,
-         *d_Ql = nullptr, *d_Qp = nullptr, *d_vec = nullptr;
+         *d_Ql = nullptr, *d_Qp = nullptr, *d_vec = nullptr, *d_time = nullptr;
   const size_t nmom = 2 * (S + nup);
   // fixed slots (an optional buffer keeps its number): a resumed call finds the state where the first call put it
   auto at = [&](int s, double **p, size_t n) -> bool { return ws_get(h, s, n, p); };
   bool ok = at(0, &d_pi, S) && at(1, &d_up, nup) && at(2, &d_mom, nmom) && at(3, &d_loss, E) && at(4, &d_Qb, SS) &&
             at(5, &d_Ql, SS) && (!mask || at(6, &d_mask, SS)) &&
-            (!(Q_pow2 && n_pow2 > 0) || at(7, &d_Qp, std::max<size_t>(n_pow2, 16) * SS)) && at(8, &d_vec, (size_t)LD + S + 8);
+            (!(Q_pow2 && n_pow2 > 0) || at(7, &d_Qp, std::max<size_t>(n_pow2, 16) * SS)) && at(8, &d_vec, (size_t)LD + S + 8) &&
+            at(9, &d_time, (size_t)E + 1);
   (void)alloc;
   if (!ok) {
     release();
@@ -80,7 +96,7 @@ static int run_fused_training_large(cb_bank *h, double *pi_param, double *up_par
   if (rc == CB_OK && (expr) != hipSuccess) rc = fail(CB_EHIP, "%s failed", #expr)
   {
     const size_t up_bytes = (S + nup + SS + 64) * sizeof(double);
-    const size_t down_bytes = (S + nup + (size_t)E + (2 + (size_t)(d_Qp ? n_pow2 : 0)) * SS + 64) * sizeof(double);
+    const size_t down_bytes = (S + nup + 2 * (size_t)E + 16 + (2 + (size_t)(d_Qp ? n_pow2 : 0)) * SS + 64) * sizeof(double);
     if (!pin_reserve(h, std::max(up_bytes, down_bytes) + 1024)) {
       release();
       return fail(CB_ENOMEM, "fused training: pinned staging allocation failed");
@@ -107,7 +123,7 @@ static int run_fused_training_large(cb_bank *h, double *pi_param, double *up_par
   // all-reduced every epoch below, the count margins and the normaliser are the job-wide ones
   a.dirsum = h->comm ? h->dirsum_g : h->dirsum;
   a.inv_n = (flags & CB_NORMALIZE) ? 1.0 / (h->comm ? h->n_global[0] : h->n_host[0]) : 1.0;
-  a.loss_curve = d_loss; a.Q_last = d_Ql; a.Q_best = d_Qb; a.Q_pow2 = d_Qp;
+  a.loss_curve = d_loss; a.time_curve = d_time; a.Q_last = d_Ql; a.Q_best = d_Qb; a.Q_pow2 = d_Qp;
   if (dbg) fprintf(stderr, "[cherrybank] large trainer: copies enqueued after %.2f ms\n", now() - t_enter);
   if (!resume) TRYH(h2d_staged(h, a.state, init_state, sizeof init_state));
   TRYH(hipStreamSynchronize(h->stream));  // init_state is on this stack frame
@@ -136,6 +152,8 @@ static int run_fused_training_large(cb_bank *h, double *pi_param, double *up_par
   // CB_TRACE_SLOW=<ms>: report every epoch whose HOST side took longer than that (where the host waited: the fold of an older
   // epoch's events, the enqueue, the planned solve's record) -- the tool for "one run in five is 3x slower"
   const double trace_slow = getenv("CB_TRACE_SLOW") ? atof(getenv("CB_TRACE_SLOW")) : 0.0;
+  const double t_first_s = (now() - t_enter) * 1e-3;   // (the stream is idle: synchronised above)
+  hipLaunchKernelGGL(tr_stamp, dim3(1), dim3(1), 0, h->stream, d_time + E);
   for (int e = 0; e < E && rc == CB_OK; ++e) {
     const double te0 = trace_slow > 0.0 ? now() : 0.0;
     double te_fold = 0.0, te_enq = 0.0, te_rec = 0.0;
@@ -173,11 +191,13 @@ static int run_fused_training_large(cb_bank *h, double *pi_param, double *up_par
         if (rc == CB_OK && rec.err == 2) rc = fail(CB_ENUMERIC, "eigensolver: non-finite input");
       }
       if (rc == CB_OK && rec.stall) {   // still not converged: the host-driven solver, from the previous eigenvectors
-        HIP_TRY(hipStreamSynchronize(h->stream));
-        HIP_TRY(hipMemsetAsync(h->ectl, 0, sizeof(unsigned long long), h->stream));
+        // (errors flow through rc: a sharded job's failure protocol and the clean-up below depend on it)
+        if (hipStreamSynchronize(h->stream) != hipSuccess) rc = fail(CB_EHIP, "hipStreamSynchronize failed (host-driven solver fallback)");
+        else if (hipMemsetAsync(h->ectl, 0, sizeof(unsigned long long), h->stream) != hipSuccess)
+          rc = fail(CB_EHIP, "hipMemsetAsync failed (host-driven solver fallback)");
         for (bool &b : h->ev_rec) b = false;
         mark(h, EV_START);
-        rc = large_eval(h, flags & CB_NORMALIZE, h->loss, h->Mt, true, nullptr);
+        if (rc == CB_OK) rc = large_eval(h, flags & CB_NORMALIZE, h->loss, h->Mt, true, nullptr);
       }
       if (rc == CB_OK) {
         const EighPlan prev = plan;
@@ -241,7 +261,10 @@ static int run_fused_training_large(cb_bank *h, double *pi_param, double *up_par
   if (Q_best) TRYH(d2h_staged(h, d_Qb, SS * sizeof(double), &s_Qb));
   if (Q_last) TRYH(d2h_staged(h, d_Ql, SS * sizeof(double), &s_Ql));
   if (d_Qp) TRYH(d2h_staged(h, d_Qp, n_pow2 * SS * sizeof(double), &s_Qp));
+  char *s_time = nullptr;
+  TRYH(d2h_staged(h, d_time, ((size_t)E + 1) * sizeof(double), &s_time));
   TRYH(hipStreamSynchronize(h->stream));
+  set_epoch_seconds(h, rc == CB_OK ? s_time : nullptr, E, t_first_s);
   if (rc == CB_OK) {
     memcpy(pi_param, s_pi, S * sizeof(double));
     memcpy(up_param, s_up, nup * sizeof(double));
@@ -283,14 +306,16 @@ static int run_fused_training(cb_bank *h, int kind, double *pi_param, double *up
   const int S = h->S, L = h->L;
   const size_t SS = (size_t)S * S, nup = kind == 0 ? (size_t)S * (S - 1) / 2 : SS;
   double *d_pi = nullptr, *d_up = nullptr, *d_mom = nullptr, *d_mask = nullptr, *d_loss = nullptr,
-         *d_Qb = nullptr, *d_Ql = nullptr, *d_Qp = nullptr;
+         *d_Qb = nullptr, *d_Ql = nullptr, *d_Qp = nullptr, *d_time = nullptr;
+  const auto t_enter = std::chrono::steady_clock::now();
   int slot = 0;
   auto alloc = [&](double **p, size_t n) -> bool { return ws_get(h, slot++, n, p); };
   auto release = [&]() { (void)hipStreamSynchronize(h->stream); };
   const size_t nmom = 2 * ((size_t)L * S + (size_t)L * nup);
   bool ok = alloc(&d_pi, (size_t)L * S) && alloc(&d_up, L * nup) && alloc(&d_mom, nmom) &&
             alloc(&d_loss, (size_t)E * L) && alloc(&d_Qb, L * SS) && alloc(&d_Ql, L * SS) &&
-            (!mask || alloc(&d_mask, SS)) && (!(Q_pow2 && n_pow2 > 0) || alloc(&d_Qp, std::max<size_t>(n_pow2, 16) * SS));
+            (!mask || alloc(&d_mask, SS)) && (!(Q_pow2 && n_pow2 > 0) || alloc(&d_Qp, std::max<size_t>(n_pow2, 16) * SS)) &&
+            alloc(&d_time, (size_t)E + 1);
   if (!ok) {
     release();
     return fail(CB_ENOMEM, "fused training: device allocation failed");
@@ -300,7 +325,7 @@ static int run_fused_training(cb_bank *h, int kind, double *pi_param, double *up
   if (rc == CB_OK && (expr) != hipSuccess) rc = fail(CB_EHIP, "%s failed", #expr)
   {
     const size_t up_bytes = ((size_t)L * S + L * nup + SS + 64) * sizeof(double);
-    const size_t down_bytes = ((size_t)L * S + L * nup + (size_t)E * L + 2 * L * SS + (size_t)(d_Qp ? n_pow2 : 0) * SS + 64) * sizeof(double);
+    const size_t down_bytes = ((size_t)L * S + L * nup + (size_t)E * L + E + 16 + 2 * L * SS + (size_t)(d_Qp ? n_pow2 : 0) * SS + 64) * sizeof(double);
     if (!pin_reserve(h, std::max(up_bytes, down_bytes) + 1024)) {
       release();
       return fail(CB_ENOMEM, "fused training: pinned staging allocation failed");
@@ -312,6 +337,12 @@ static int run_fused_training(cb_bank *h, int kind, double *pi_param, double *up
   TRYH(hipMemsetAsync(d_Qb, 0, L * SS * sizeof(double), h->stream));
   TRYH(hipMemsetAsync(d_Ql, 0, L * SS * sizeof(double), h->stream));
   if (mask) TRYH(h2d_staged(h, d_mask, mask, SS * sizeof(double)));
+  double t_first_s = 0.0;
+  if (rc == CB_OK) {
+    // (the uploads above are a few hundred kilobytes on an otherwise idle stream: the stamp runs microseconds after this)
+    t_first_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_enter).count();
+    hipLaunchKernelGGL(tr_stamp, dim3(1), dim3(1), 0, h->stream, d_time + E);
+  }
   if (rc == CB_OK) {
     TrainArgs a{};
     a.S = S; a.L = L; a.B = h->Bl; a.E = E; a.kind = kind; a.do_adam = do_adam; a.n_pow2 = d_Qp ? n_pow2 : 0;
@@ -320,7 +351,7 @@ static int run_fused_training(cb_bank *h, int kind, double *pi_param, double *up
     a.m_pi = d_mom; a.v_pi = d_mom + (size_t)L * S;
     a.m_up = d_mom + 2 * (size_t)L * S; a.v_up = a.m_up + L * nup;
     a.mask = d_mask; a.lr = lr; a.beta1 = 0.9; a.beta2 = 0.999; a.eps = 1e-8;
-    a.loss_curve = d_loss; a.Q_best = d_Qb; a.Q_last = d_Ql; a.Q_pow2 = d_Qp;
+    a.loss_curve = d_loss; a.time_curve = d_time; a.Q_best = d_Qb; a.Q_last = d_Ql; a.Q_pow2 = d_Qp;
     a.sym = (S <= 24 && h->sym_counts) ? 1 : 0;
     for (bool &b : h->ev_rec) b = false;
     mark(h, EV_START);
@@ -448,7 +479,10 @@ static int run_fused_training(cb_bank *h, int kind, double *pi_param, double *up
   if (Q_best) TRYH(d2h_staged(h, d_Qb, L * SS * sizeof(double), &s_Qb));
   if (Q_last) TRYH(d2h_staged(h, d_Ql, L * SS * sizeof(double), &s_Ql));
   if (d_Qp) TRYH(d2h_staged(h, d_Qp, n_pow2 * SS * sizeof(double), &s_Qp));
+  char *s_time = nullptr;
+  TRYH(d2h_staged(h, d_time, ((size_t)E + 1) * sizeof(double), &s_time));
   TRYH(hipStreamSynchronize(h->stream));
+  set_epoch_seconds(h, rc == CB_OK ? s_time : nullptr, E, t_first_s);
   if (rc == CB_OK) {
     memcpy(pi_param, s_pi, (size_t)L * S * sizeof(double));
     memcpy(up_param, s_up, L * nup * sizeof(double));
@@ -484,6 +518,15 @@ extern "C" int cb_train_pande_reversible(cb_handle h, double *upper_diag, double
                                        "(a non-symmetric mask makes Q non-reversible)");
   return run_fused_training(h, 0, log_pi, upper_diag, mask, num_epochs, lr, do_adam, flags,
                             loss_curve, Q_best, Q_last, Q_pow2, n_pow2);
+}
+
+extern "C" int cb_train_epoch_times(cb_handle h, double *seconds, int n) {
+  if (!h || !seconds || n < 0) return fail(CB_EINVAL, "cb_train_epoch_times: NULL argument");
+  if ((size_t)n > h->epoch_seconds.size())
+    return fail(CB_EINVAL, "cb_train_epoch_times: the last training call on this handle ran %zu epoch(s), %d asked for",
+                h->epoch_seconds.size(), n);
+  if (n > 0) memcpy(seconds, h->epoch_seconds.data(), (size_t)n * sizeof(double));
+  return CB_OK;
 }
 
 extern "C" int cb_train_siterm(cb_handle h, double *theta, double *Theta, int num_epochs, double lr,

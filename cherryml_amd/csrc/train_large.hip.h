@@ -32,6 +32,7 @@ struct LargeTrain {
   double *gd;                           // [S] scratch: dL/d log d
   double *state;                        // [epoch & 1]: best loss before that epoch (lt_step)
   double *loss_curve;                   // [E]
+  double *time_curve;                   // [E] or null: the 100 MHz wall clock at the end of each epoch's parameter step
   double *Q_last, *Q_best, *Q_pow2;     // [S][S], [S][S], [n_pow2][S][S]
 };
 
@@ -142,6 +143,7 @@ __global__ __launch_bounds__(256) void lt_step(LargeTrain a, int epoch, double b
   if (i == S) {
     if (threadIdx.x == 0) {
       a.loss_curve[epoch - a.epoch0] = loss;   // (the curve of THIS call)
+      if (a.time_curve) a.time_curve[epoch - a.epoch0] = (double)__builtin_amdgcn_s_memrealtime();
       a.state[(epoch + 1) & 1] = better ? loss : best;
     }
     double acc = 0.0;

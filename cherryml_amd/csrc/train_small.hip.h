@@ -34,6 +34,7 @@ struct TrainArgs {
   const double *mask;               // [S][S] or null
   double lr, beta1, beta2, eps;
   double *loss_curve;               // [E][L]
+  double *time_curve;               // [E] or null: the 100 MHz wall clock when site 0 finished each epoch (cb_train_epoch_times)
   double *Q_best, *Q_last;          // [L][S][S]
   double *Q_pow2;                   // [n_pow2][S][S] (site 0) or null
   int sym;                          // all count matrices symmetric: sp_bank's symmetric form, sp_finish mirrors M
@@ -132,6 +133,7 @@ __device__ __forceinline__ void tr_update(const TrainArgs &a, int l, int epoch, 
   const double *dirsum = a.dirsum + (size_t)l * S;
   if (tid == 0) {
     a.loss_curve[(size_t)epoch * a.L + l] = loss;
+    if (l == 0 && a.time_curve) a.time_curve[epoch] = (double)__builtin_amdgcn_s_memrealtime();
     // strict <, as trainer.py:179; there the first iterate is always taken (`best_loss is None`), also
     // when its loss is NaN; the SiteRM loop starts from +inf instead (_cherryml_vectorized.py:366)
     const bool better = (a.kind == 0 && epoch == 0) || loss < *best;

@@ -135,7 +135,11 @@ class ShardedBank:
     this rank's GPU; the CPU tests inject an oracle-backed stand-in with the
     same `loss_grad_torch` method)."""
 
-    def __init__(self, t, C, make_bank: Optional[Callable] = None, group=None, dtype: str = "f64"):
+    def __init__(self, t, C, make_bank: Optional[Callable] = None, group=None, dtype: str = "f64", emulate=None):
+        """`emulate = (rank, world)`: deal the buckets as that rank of a `world`-rank job WITHOUT those peers (the
+        collectives run over the real group, alone): ONE rank's share of an N-rank job on the one GPU there is
+        (`bench.py --shard-of N`).  The loss normaliser is then the share's own count -- a self-consistent smaller
+        problem, not a partial sum of the whole bank."""
         t = np.asarray(t, dtype=np.float64).reshape(-1)
         C = np.asarray(C, dtype=np.float64)
         if C.ndim != 3:
@@ -152,8 +156,13 @@ class ShardedBank:
             raise ValueError("the bank has no counts")
         if live.size < self.world:   # known to every rank alike: all raise, none is left waiting in a collective
             raise ValueError(f"{live.size} non-empty buckets < world={self.world}: some rank would own no bucket")
-        mine = live[bucket_shard(live.size, self.rank, self.world)]
-        self.total_count = float(C.sum())  # every rank sees the full host array here
+        deal_rank, deal_world = (self.rank, self.world) if emulate is None else (int(emulate[0]), int(emulate[1]))
+        if not 0 <= deal_rank < deal_world or live.size < deal_world:
+            raise ValueError(f"emulate={emulate}: needs 0 <= rank < world <= {live.size} non-empty buckets")
+        mine = live[bucket_shard(live.size, deal_rank, deal_world)]
+        self.emulate = None if emulate is None else (deal_rank, deal_world)
+        # every rank sees the full host array here (an emulated share normalises by its own count)
+        self.total_count = float(C.sum()) if emulate is None else float(C[mine].sum())
         self.local_buckets = mine
         self.bank = self._make(make_bank, dtype)(t[mine], C[mine])
 

@@ -68,20 +68,20 @@ def _train_fused(rate_module, bank, optimizer, num_epochs, loss_normalization, r
     else:
         lr, do_adam = optimizer.param_groups[0]["lr"], isinstance(optimizer, torch.optim.Adam)
     start = time.time()
-    r = bank.train_pande_reversible(
-        rate_module.upper_diag.detach().cpu().numpy(), rate_module._pi.detach().cpu().numpy(),
-        mask=rate_module.mask.detach().cpu().numpy(), num_epochs=num_epochs, lr=lr,
-        do_adam=do_adam, normalize=loss_normalization)
-    elapsed = time.time() - start
+    up0, pi0, mask0 = (rate_module.upper_diag.detach().cpu().numpy(), rate_module._pi.detach().cpu().numpy(),
+                       rate_module.mask.detach().cpu().numpy())
+    t_call = time.time()
+    r = bank.train_pande_reversible(up0, pi0, mask=mask0, num_epochs=num_epochs, lr=lr, do_adam=do_adam,
+                                    normalize=loss_normalization)
     with torch.no_grad():  # leave the module at the final parameters, like the torch loop does
         rate_module.upper_diag.copy_(torch.as_tensor(r["upper_diag"]))
         rate_module._pi.copy_(torch.as_tensor(r["log_pi"]))
     E = num_epochs
-    # `time`: the loop never returns to the host between epochs, so there are no per-epoch timestamps
-    # to record (the reference's column is seconds since the start, trainer.py:213); only the last
-    # row carries a measurement -- the wall time of all E epochs -- the others are NaN, not invented
-    rows = [(0.0, 0.0, float(r["loss"][e]), elapsed if e == E - 1 else float("nan"), e, 0.0, 0.0)
-            for e in range(E)]
+    # `time` (trainer.py:207-217: seconds since the start, at the end of every epoch): the loop never returns to the
+    # host between epochs, so the DEVICE stamps its 100 MHz wall clock at the end of every epoch's parameter step
+    # (cb_train_epoch_times: seconds since the C call was entered); `lead` = what passed on the host before that
+    lead = t_call - start
+    rows = [(0.0, 0.0, float(r["loss"][e]), lead + float(r["time"][e]), e, 0.0, 0.0) for e in range(E)]
     Q_dict = {f"Q_{k}": v.copy() for k, v in r["Q_pow2"].items()}
     if E > 0:
         Q_dict["Q_best"] = r["Q_best"].copy()

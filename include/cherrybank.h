@@ -168,7 +168,9 @@ int cb_last_sweeps(cb_handle h);
  * the sweep decisions are taken on the device and the host only looks at a solve's record while the epoch's bank kernels
  * are queued (csrc/eigh_planned.hip.h).  counts[0] = planned solves so far on this handle, counts[1] = how many of them
  * ran out of plan before converging and were continued with more slots ("stalls"; rare), counts[2] = sweeps of the last
- * planned solve.  CB_EIGH_HOST=1 in the environment keeps the host-driven solver of rounds 1-3 (counts stay 0). */
+ * planned solve, counts[3] = how often the host looked for a solve's record before the device had published it (each such
+ * look is a spin on pinned memory with the epoch's bank kernels queued behind the solve).  CB_EIGH_HOST=1 in the
+ * environment keeps the host-driven solver of rounds 1-3 (counts stay 0). */
 int cb_eigh_counters(cb_handle h, int *counts, int n);
 /* Which kernels the last cb_train_* call on this handle launched (tests pin the form they compare): 1000 + 100 TS +
  * 10 sym + w3 = the site-parallel split sp_prepare / sp_bank<TS, sym, w3> / sp_finish (TS = ceil(S / 4) tiles, sym =
@@ -217,6 +219,14 @@ int cb_train_pande_reversible(cb_handle h, double *upper_diag, double *log_pi,
 int cb_train_siterm(cb_handle h, double *theta, double *Theta, int num_epochs,
                     double lr, int flags, double *res,
                     double *loss_per_epoch_per_site);
+
+/*
+ * The `time` column of the reference's df_res (trainer.py:207-217: seconds since the start of the loop, taken at the end
+ * of every epoch) for the last cb_train_pande_reversible / cb_train_siterm call on this handle: seconds[e] = seconds from
+ * the entry of that call to the end of epoch e's parameter step ON THE DEVICE (the loops never return to the host between
+ * epochs: the device stamps its constant 100 MHz clock; site 0's epochs for L > 1).  n <= the epochs of that call.
+ */
+int cb_train_epoch_times(cb_handle h, double *seconds, int n);
 
 /* ------------------------------------------------------------------------------
  * Counting stage: the producer of the bank.  Replaces the hot loops

@@ -2,7 +2,9 @@
 
 Diagnostic build only:
 
-    CB_EXTRA_HIPCC_FLAGS=-DCB_CLOCK_STAMP python profiles/tools/clock_probe.py [epochs] > gpurun_out/clock_probe.json
+    CB_EXTRA_HIPCC_FLAGS=-DCB_CLOCK_STAMP python profiles/tools/clock_probe.py [epochs [workload [shard_of]]] > gpurun_out/clock_probe.json
+
+(workload: coevo400 (default) or coevo400_demo; shard_of N: only rank 0's buckets of an N-way deal, as `bench.py --shard-of N`)
 
 (the stamps: csrc/large_bank.hip.h, CB_STAMP_BEGIN / CB_STAMP_END; the shipped library has none).  Runs the bench's
 co-evolution workload (400 x 400, B = 129) for `epochs` epochs on the device-driven loop and reads the LAST epoch's stamps:
@@ -30,15 +32,21 @@ def main():
     from cherryml_amd.estimation._jtt_ipw import jtt_ipw_from_arrays
 
     rng = np.random.default_rng(0)
-    wl = bench.make_workload("coevo400", 0, rng)
+    wl = bench.make_workload(sys.argv[2] if len(sys.argv) > 2 else "coevo400", 0, rng)
     S = 400
+    shard_of = int(sys.argv[3]) if len(sys.argv) > 3 else 0
+    if shard_of:
+        live = np.flatnonzero(np.any(wl["C"].reshape(wl["C"].shape[0], -1) != 0.0, axis=1))
+        mine = live[np.arange(0, live.size, shard_of)]
+        wl["t"], wl["C"] = wl["t"][mine], wl["C"][mine]
     bank = cherryml_amd.CherryBank(wl["t"], wl["C"], device=0, dtype="f64")
+    nB = int(bank.live_buckets[0])
     init = jtt_ipw_from_arrays(wl["t"], wl["C"], wl["mask"])
     mod = cherryml_amd.RateMatrix(num_states=S, mode="pande_reversible", mask=torch.tensor(wl["mask"]),
                                   pi=torch.ones(S, dtype=torch.float64) / S, pi_requires_grad=True, initialization=init)
     u0 = mod.upper_diag.detach().numpy().copy()
     p0 = mod._pi.detach().numpy().copy()
-    out = {"epochs": epochs, "workload": wl["desc"], "kernels": {}}
+    out = {"epochs": epochs, "workload": wl["desc"], "live_buckets": nB, "shard_of": shard_of, "kernels": {}}
     lib = _lib.load()
     # the fused bank launch (k123_bank, the default) lives in a translation unit of its own with its own stamp buffer
     fn = lib.cb_debug_clock_stamps if os.environ.get("CB_BANK_UNFUSED") else lib.cb_debug_clock_stamps_fused
@@ -55,7 +63,7 @@ def main():
         np.save(os.path.join(ROOT, "gpurun_out", f"clock_stamps_{label}.npy"), buf)
         res = {}
         # MFMAs per wave in one tile's K loop: 25 K-steps x 4 sub-steps x (5 + 1 + 1/4) = 625
-        for kid, (name, nwg) in enumerate((("k1_pt_loss_gt", 129 * 15), ("k2_t_eq_g_u", 129 * 25), ("k3_w_phi", 129 * 15))):
+        for kid, (name, nwg) in enumerate((("k1_pt_loss_gt", nB * 15), ("k2_t_eq_g_u", nB * 25), ("k3_w_phi", nB * 15))):
             n = min(nwg, 4096)
             cyc = buf[kid, :n, 0].astype(np.float64)
             tick = buf[kid, :n, 1].astype(np.float64)

@@ -90,6 +90,10 @@ def test_learner_class_lg_bank_100_epochs():
     learner.train(lr=0.1, num_epochs=int(g["num_epochs"]), do_adam=True, loss_normalization=True,
                   return_best_iter=True)
     assert np.allclose(learner.df_res.loss.to_numpy(), g["loss_f64"], rtol=1e-9, atol=0)
+    # every row's `time` is filled (trainer.py:207-217): seconds since the start, from the device's own clock stamps
+    tt = learner.df_res.time.to_numpy()
+    assert np.all(np.isfinite(tt)) and tt[0] > 0 and np.all(np.diff(tt) > 0) and tt[-1] < 60.0
+    assert 1e-6 < np.median(np.diff(tt)) < 5e-3      # an LG epoch is tens of microseconds
     Q = learner.get_learnt_rate_matrix()
     assert list(Q.index) == states
     assert relerr(Q.to_numpy(), g["Q_best_f64"]) < 1e-6
@@ -139,6 +143,8 @@ def test_coevolution_400_states_three_epochs(fused):
     assert relerr(Qd["Q_best"], g["Q_best_f64"]) < 1e-8
     assert relerr(Qd["Q_last"], g["Q_last_f64"]) < 1e-8
     assert set(Qd) >= {"Q_1", "Q_2", "Q_best", "Q_last"}
+    tt = df.time.to_numpy()   # fused: device clock stamps per epoch; torch glue: host time per epoch
+    assert np.all(np.isfinite(tt)) and tt[0] > 0 and np.all(np.diff(tt) > 0)
 
 
 def test_fused_large_trainer_matches_torch_glue_over_40_epochs():
@@ -166,6 +172,8 @@ def test_fused_large_trainer_matches_torch_glue_over_40_epochs():
     for k, Qk in r["Q_pow2"].items():
         assert relerr(Qk, ref[f"Q_{k}"]) < 1e-6, k
     assert np.allclose(r["upper_diag"], ref["upper_diag"], rtol=1e-6, atol=1e-8)
+    # cb_train_epoch_times: one stamp per epoch, increasing, of the size of an epoch
+    assert r["time"].shape == (E,) and np.all(np.diff(r["time"]) > 0) and 0 < r["time"][0] < r["time"][-1] < 30.0
 
 
 def test_siterm_vectorized_matches_reference():

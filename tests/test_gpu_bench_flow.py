@@ -48,6 +48,24 @@ def test_two_ranks_share_the_gpu_through_the_gloo_hook():
     assert d["secondary_counting"]["roofline"]["bound"] == "lds_atomic" and d["secondary_ble"]["roofline"]["bound"] == "l2_gather"
 
 
+def test_shard_of_line_measures_one_ranks_share_on_one_gpu():
+    """`bench.py --shard-of 8`: rank 0's buckets of an 8-way deal of the bench bank (17 of 129) + the whole replicated part,
+    through the C-driven sharded loop with a single-rank RCCL communicator -- what ONE GPU of eight does per epoch."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--shard-of", "8", "--steps", "6", "--warmup", "2",
+                        "--no-secondary"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads(r.stdout.strip().splitlines()[-1])
+    assert d["n_gpus"] == 1 and d["shard_of"] == 8 and d["config"]["share_buckets"] == 17
+    assert d["rccl_ranks"] == 1 and "in-library ncclAllReduce" in d["config"]["epoch"]
+    assert d["amdahl"]["measured_rank_ms"] == pytest.approx(d["ms_per_step"], rel=1e-3)
+    assert 0 < d["ms_per_step"] < 5.0 and d["final_loss"] == d["final_loss"]
+    assert "cpu_baseline" not in d      # a share of a bank has no CPU twin
+    # the share's bank launch is a sixth of the whole bank's work or less: well under the 0.66 ms of the 129-bucket launch
+    bank_ms = d["phase_ms"]["k1"] + d["phase_ms"]["k2"] + d["phase_ms"]["k3"]
+    assert 0 < bank_ms < 0.4, d["phase_ms"]
+
+
 _RESIDENT_WORKER = r'''
 import os, sys, numpy as np
 sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], "tests"))
