@@ -11,18 +11,24 @@
 #include "large_bank.hip.h"
 #include "cb_internal.hip.h"
 
-// variant: 0 = float64 bank, 1 = CB_F32, 2 = CB_MIXED; `args` = the argument block in device memory (written by lg_tables);
-// stop: null, or the event that takes the launch's end time (the phase timer: handle_host.hip.h, stop_event())
-template <typename T1, typename TG>
+// variant: 0 = float64 bank, 1 = CB_F32, 2 = CB_MIXED; kg: 1 = four-wave tiles (four workgroups per CU), 2 = eight-wave tiles
+// (two K-groups, two workgroups per CU: large_bank.hip.h, lg4_gemm_tile); `args` = the argument block in device memory
+// (written by lg_tables); stop: null, or the event that takes the launch's end time (the phase timer: handle_host.hip.h)
+template <typename T1, typename TG, int KG>
 static void launch(const void *args, int grid, hipStream_t stream, hipEvent_t stop) {
   const K123Args<T1, TG> *a = static_cast<const K123Args<T1, TG> *>(args);
-  if (stop) hipExtLaunchKernelGGL((k123_bank<T1, TG>), dim3(grid), dim3(LG4_THREADS), 0, stream, nullptr, stop, 0, a);
-  else hipLaunchKernelGGL((k123_bank<T1, TG>), dim3(grid), dim3(LG4_THREADS), 0, stream, a);
+  if (stop) hipExtLaunchKernelGGL((k123_bank<T1, TG, KG>), dim3(grid), dim3(LG4_THREADS * KG), 0, stream, nullptr, stop, 0, a);
+  else hipLaunchKernelGGL((k123_bank<T1, TG, KG>), dim3(grid), dim3(LG4_THREADS * KG), 0, stream, a);
 }
-int cb_launch_bank_fused(int variant, const void *args, int grid, hipStream_t stream, hipEvent_t stop) {
-  if (variant == 1) launch<float, float>(args, grid, stream, stop);
-  else if (variant == 2) launch<double, float>(args, grid, stream, stop);
-  else launch<double, double>(args, grid, stream, stop);
+template <int KG>
+static void launch_variant(int variant, const void *args, int grid, hipStream_t stream, hipEvent_t stop) {
+  if (variant == 1) launch<float, float, KG>(args, grid, stream, stop);
+  else if (variant == 2) launch<double, float, KG>(args, grid, stream, stop);
+  else launch<double, double, KG>(args, grid, stream, stop);
+}
+int cb_launch_bank_fused(int variant, int kg, const void *args, int grid, hipStream_t stream, hipEvent_t stop) {
+  if (kg == 2) launch_variant<2>(variant, args, grid, stream, stop);
+  else launch_variant<1>(variant, args, grid, stream, stop);
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 

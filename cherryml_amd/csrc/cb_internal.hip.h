@@ -37,9 +37,18 @@ int cb_internal_expm_bank(cb_handle h, const double *Q, const double *pi, int fl
 // t_dev != NULL: the same values already on the device -- copied on the handle's stream, no host wait
 int cb_internal_set_times(cb_handle h, const double *t_host, int B, const double *t_dev);
 
-// the fused bank launch k123_bank (cb_bank_fused.hip): variant 0 = float64, 1 = CB_F32, 2 = CB_MIXED; `args` = the argument
-// block in device memory; stop = null or the event that takes the launch's end time.  Returns 0 or -1.
-int cb_launch_bank_fused(int variant, const void *args, int grid, hipStream_t stream, hipEvent_t stop);
+// the fused bank launch k123_bank (cb_bank_fused.hip): variant 0 = float64, 1 = CB_F32, 2 = CB_MIXED; kg = 1 (four-wave
+// tiles) or 2 (eight-wave tiles); `args` = the argument block in device memory; stop = null or the event that takes the
+// launch's end time.  Returns 0 or -1.
+int cb_launch_bank_fused(int variant, int kg, const void *args, int grid, hipStream_t stream, hipEvent_t stop);
+
+// Test hooks (tests/, profiles/): environment variables that change WHICH kernels run or inject faults are honoured only
+// when CB_TEST_HOOKS=1 is set as well -- a stray CB_NO_SYM in a user's shell must not change the path.  (CB_DEBUG and
+// CB_TRACE_SLOW only log; CB_BANK_STREAMS is a documented opt-in.)
+static inline const char *cb_test_hook(const char *name) {
+  const char *on = getenv("CB_TEST_HOOKS");
+  return (on && on[0] == '1') ? getenv(name) : nullptr;
+}
 
 // device buffers of one call of the per-family entry points (uploaded on the default stream, freed on return)
 struct CbDevBufs {

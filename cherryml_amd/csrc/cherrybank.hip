@@ -145,6 +145,12 @@ static int launch_small(cb_bank *h, const SmallArgs &a) {
 #include "eigh_large_host.hip.h"   // launch_sg, large_eigh
 #include "eigh_planned_host.hip.h" // EighPlan, enqueue_planned_solve, eigh_planned_record
 
+#ifndef CB_BANK_FUSED_MIN_B
+#define CB_BANK_FUSED_MIN_B 64   // live buckets from which K1 -> K2 -> K3 run as ONE persistent launch
+#endif
+#ifndef CB_BANK_KG2_MAX_B
+#define CB_BANK_KG2_MAX_B 20     // live buckets below which the tiles run on eight waves (two K-groups)
+#endif
 // h->A (padded, symmetric) and h->dsq are filled.  Output: dQ (S x S, dQ = D^1/2 dA D^-1/2) when
 // `dA_padded` is false, else dL/dA itself as a padded LD x LD matrix.
 // `plan`: a warm solve enqueued as a device-controlled plan (eigh_planned_host.hip.h) instead of the host-driven loop; the
@@ -172,8 +178,27 @@ static int large_eval(cb_bank *h, bool normalize, double *lossd, double *out, bo
   static const int n_parts = getenv("CB_BANK_STREAMS") ? std::min(4, std::max(1, atoi(getenv("CB_BANK_STREAMS")))) : 1;
   // K1 -> K2 -> K3 as ONE persistent launch (k123_bank, large_bank.hip.h) whenever the gradient is wanted; CB_BANK_UNFUSED=1
   // keeps the three launches (per-kernel profiles, and the reference point of tests/test_gpu_s400_full.py)
-  const bool unfused_env = getenv("CB_BANK_UNFUSED") != nullptr;   // (read per call: the tests switch it inside one process)
-  const bool fused = !Pd && dQd && !unfused_env && n_parts == 1 && h->bank_queue;
+  // (test hooks, read per call: the tests switch them inside one process)
+  const bool f32 = h->dtype == CB_F32 && !Pd, mixed = h->dtype == CB_MIXED && !Pd;
+  // Which form the three bank products take is decided by the SHAPE (live buckets; profiles/tools/r5_bank_sweep.py, round 5):
+  // the persistent launch k123_bank pays when the bank fills the chip several times over (its gain is the two drains it
+  // hides); a short bank -- the reference's real bank has 43 live buckets, one rank's share of an 8-rank job 17 -- is a chain
+  // of three tile latencies whatever is launched, and the persistent launch's 1024 resident workgroups (most of them waiting)
+  // make its tiles slower: 0.40 against 0.29 ms at 43 buckets, 0.24 against 0.14 at 17.  CB_BANK_UNFUSED=1 / CB_BANK_FUSED=1
+  // force a form (test hooks).
+  const bool unfused_env = cb_test_hook("CB_BANK_UNFUSED") != nullptr, fused_env = cb_test_hook("CB_BANK_FUSED") != nullptr;
+  const bool fused = !Pd && dQd && !unfused_env && n_parts == 1 && h->bank_queue && (fused_env || B >= CB_BANK_FUSED_MIN_B);
+  // tile form of K1 .. K3 (large_bank.hip.h, lg4_gemm_tile): eight waves per 80 x 80 tile (two K-groups, two workgroups per
+  // CU) or four (four workgroups per CU); CB_BANK_KG=1 / 2 forces one (test hook).  cb_expm_bank keeps
+  // the four-wave form.
+  // Below ~20 buckets every stage has at most two tiles per CU and the eight-wave tile's shorter latency wins (0.141 against
+  // 0.152 ms at 17 buckets); above, four independent four-wave workgroups per CU overlap better than two eight-wave ones whose
+  // K-groups share their barriers (0.75 against 0.65 ms at 129).  The float32 bank keeps the four-wave form: its P_b entries
+  // of O(t^2) are sums with cancellation whose SIGN in float32 depends on the summation order (DESIGN / EXPERIMENTS, round 5).
+  int kg = (B < CB_BANK_KG2_MAX_B && !f32) ? 2 : 1;
+  if (const char *k = cb_test_hook("CB_BANK_KG")) kg = atoi(k) == 1 ? 1 : 2;
+  if (Pd) kg = 1;
+  h->bank_kg = kg;
   // (queues and argument block: allocated with the handle, create_host.hip.h)
   h->bank_fused = fused;
   const dim3 tables_grid((unsigned)(((size_t)B * LD + 255) / 256));
@@ -184,7 +209,6 @@ static int large_eval(cb_bank *h, bool normalize, double *lossd, double *out, bo
   // copies of this epoch's U, U^T, A and F; cb_expm_bank (Pd) always takes the float64 kernels
   // CB_MIXED: P_b, the loss and G_b in float64 (the O(t^2) entries of P_b keep their relative accuracy),
   // G_b rounded to float32 once, the two contractions on the float32 MFMA
-  const bool f32 = h->dtype == CB_F32 && !Pd, mixed = h->dtype == CB_MIXED && !Pd;
   if ((f32 || mixed) && !fused)
     hipLaunchKernelGGL(lg_cast_f32, dim3((unsigned)((std::max(LL, (size_t)B * LD) + 255) / 256)), dim3(256), 0, h->stream, LL,
                        (size_t)B * LD, h->U, h->Vc, h->A, h->F, h->Uf, h->Utf, h->Af, h->Ff);
@@ -193,9 +217,9 @@ static int large_eval(cb_bank *h, bool normalize, double *lossd, double *out, bo
   if (fused) {
     // lg_tables (+ the argument block and the zeroed queues), then one launch of 4 workgroups per CU (fewer when the bank is
     // small); the loss partials are summed after it
-    const int total = B * (tiles_k1 + tiles + tiles_k3), grid = std::min(h->bank_slots, total);
+    const int total = B * (tiles_k1 + tiles + tiles_k3), grid = std::min(h->bank_slots / kg, total);
     const int sym = h->sym_counts ? 1 : 0;
-    const int test_no_claim = getenv("CB_BANK_TEST_NO_CLAIM") ? 1 : 0;   // (tests/test_gpu_s400_full.py: the help path)
+    const int test_no_claim = cb_test_hook("CB_BANK_TEST_NO_CLAIM") ? 1 : 0;   // (tests/test_gpu_s400_full.py: the help path)
     // (the phase marks ride on the launches as stop events: handle_host.hip.h, stop_event())
     if (h->profile) h->ev_rec[EV_K1] = h->ev_rec[EV_K2] = false;   // CB_T_K1 = the whole launch (+ tables), see read_phase_times
     const hipEvent_t bank_stop = stop_event(h, EV_K3);
@@ -216,7 +240,7 @@ static int large_eval(cb_bank *h, bool normalize, double *lossd, double *out, bo
       auto *dst = launch(a);
       hipLaunchKernelGGL(lg_cast_f32, dim3((unsigned)((std::max(LL, (size_t)B * LD) + 255) / 256)), dim3(256), 0, h->stream, LL,
                          (size_t)B * LD, h->U, h->Vc, h->A, h->F, h->Uf, h->Utf, h->Af, h->Ff);
-      if (cb_launch_bank_fused(1, dst, grid, h->stream, bank_stop) != 0) return fail(CB_EHIP, "k123_bank: launch failed");
+      if (cb_launch_bank_fused(1, kg, dst, grid, h->stream, bank_stop) != 0) return fail(CB_EHIP, "k123_bank: launch failed");
     } else if (mixed) {
       K123Args<double, float> a{{S, LD, B, h->Vc, h->A, tb, h->F, h->sigma, h->Ct, h->Gt32, h->loss_part, inv_n, h->dsq, nullptr, skipw},
                                 {LD, h->Gt32, h->Uf, h->T32, skipw},
@@ -225,14 +249,14 @@ static int large_eval(cb_bank *h, bool normalize, double *lossd, double *out, bo
       auto *dst = launch(a);
       hipLaunchKernelGGL(lg_cast_f32, dim3((unsigned)((std::max(LL, (size_t)B * LD) + 255) / 256)), dim3(256), 0, h->stream, LL,
                          (size_t)B * LD, h->U, h->Vc, h->A, h->F, h->Uf, h->Utf, h->Af, h->Ff);
-      if (cb_launch_bank_fused(2, dst, grid, h->stream, bank_stop) != 0) return fail(CB_EHIP, "k123_bank: launch failed");
+      if (cb_launch_bank_fused(2, kg, dst, grid, h->stream, bank_stop) != 0) return fail(CB_EHIP, "k123_bank: launch failed");
     } else {
       K123Args<double, double> a{{S, LD, B, h->Vc, h->A, tb, h->F, h->sigma, h->Ct, h->Gt, h->loss_part, inv_n, h->dsq, nullptr, skipw},
                                  {LD, h->Gt, h->U, h->T, skipw},
                                  {LD, B, h->T, h->U, tb, h->lam, h->E, h->H, h->Gt, sym, skipw},
                                  {h->bank_queue, B, tiles_k1, tiles, tiles_k3, h->bank_claims, test_no_claim}};
       auto *dst = launch(a);
-      if (cb_launch_bank_fused(0, dst, grid, h->stream, bank_stop) != 0) return fail(CB_EHIP, "k123_bank: launch failed");
+      if (cb_launch_bank_fused(0, kg, dst, grid, h->stream, bank_stop) != 0) return fail(CB_EHIP, "k123_bank: launch failed");
     }
     const LossArgs la{h->loss_part, B * tiles_k1, S, h->dsq, h->dirsum, inv_n, lossd, skipw};
     const dim3 red_grid((unsigned)((LL + 255) / 256) + 1);   // (+ the workgroup that sums the loss partials)
@@ -251,12 +275,21 @@ static int large_eval(cb_bank *h, bool normalize, double *lossd, double *out, bo
     HIP_TRY(hipGetLastError());
     return CB_OK;
   }
+  // (the separate launches in the tile form `kg`: same bits as the fused launch of that form)
+  // (the phase marks ride on the kernels as stop events -- a hipEventRecord between two kernels costs ~5 us of idle GPU)
+#define LAUNCH_KG_ON(st_, ev_, kern1, kern2, grid_, args_)                                                     \
+  do {                                                                                                         \
+    if (kg == 2) LAUNCH_STOP(ev_, kern2, grid_, dim3(2 * LG4_THREADS), 0, st_, args_);                         \
+    else LAUNCH_STOP(ev_, kern1, grid_, dim3(LG4_THREADS), 0, st_, args_);                                     \
+  } while (0)
+#define LAUNCH_KG(ev_, kern1, kern2, grid_, args_) LAUNCH_KG_ON(h->stream, ev_, kern1, kern2, grid_, args_)
+  const hipEvent_t ev_k1 = stop_event(h, EV_K1);   // (null when the call is not profiled)
   if (f32) {
-    K1Args<float> k1{S, LD, B, h->Utf, h->Af, tb, h->Ff, h->sigma, h->Ct32, h->Gt32, h->loss_part, inv_n, h->dsq, nullptr};
-    hipLaunchKernelGGL(k1_pt_loss_gt<float>, dim3(tiles_k1 * B), dim3(LG4_THREADS), 0, h->stream, k1);
+    K1Args<float> k1{S, LD, B, h->Utf, h->Af, tb, h->Ff, h->sigma, h->Ct32, h->Gt32, h->loss_part, inv_n, h->dsq, nullptr, skipw};
+    LAUNCH_KG(ev_k1, (k1_pt_loss_gt<float, float, false, 1>), (k1_pt_loss_gt<float, float, false, 2>), dim3(tiles_k1 * B), k1);
   } else if (mixed) {
-    K1Args<double, float> k1{S, LD, B, h->Vc, h->A, tb, h->F, h->sigma, h->Ct, h->Gt32, h->loss_part, inv_n, h->dsq, nullptr};
-    hipLaunchKernelGGL((k1_pt_loss_gt<double, float>), dim3(tiles_k1 * B), dim3(LG4_THREADS), 0, h->stream, k1);
+    K1Args<double, float> k1{S, LD, B, h->Vc, h->A, tb, h->F, h->sigma, h->Ct, h->Gt32, h->loss_part, inv_n, h->dsq, nullptr, skipw};
+    LAUNCH_KG(ev_k1, (k1_pt_loss_gt<double, float, false, 1>), (k1_pt_loss_gt<double, float, false, 2>), dim3(tiles_k1 * B), k1);
   } else if (n_parts > 1 && !Pd && dQd && B >= 4 * n_parts && !h->comm && !h->profile) {
     // OPT-IN (CB_BANK_STREAMS=n, float64 bank, no profile markers): the buckets in n equal parts on n queues,
     // K1 -> K2 -> K3 each, so that the drain of one part's kernel overlaps the other parts' kernels; same results bit
@@ -281,20 +314,20 @@ static int large_eval(cb_bank *h, bool normalize, double *lossd, double *out, bo
       part_of(p, b0, Bs, st);
       K1Args<double> k1{S, LD, Bs, h->Vc, h->A, tb + b0, h->F + (size_t)b0 * LD, h->sigma, h->Ct + b0 * LL, h->Gt + b0 * LL,
                         h->loss_part + (size_t)b0 * tiles_k1, inv_n, h->dsq, nullptr};
-      hipLaunchKernelGGL((k1_pt_loss_gt<double, double, false>), dim3(tiles_k1 * Bs), dim3(LG4_THREADS), 0, st, k1);
+      LAUNCH_KG_ON(st, nullptr, (k1_pt_loss_gt<double, double, false, 1>), (k1_pt_loss_gt<double, double, false, 2>), dim3(tiles_k1 * Bs), k1);
     }
     for (int p = 0; p < n_parts; ++p) {
       int b0, Bs; hipStream_t st;
       part_of(p, b0, Bs, st);
       K2Args<double> k2{LD, h->Gt + b0 * LL, h->U, h->T + b0 * LL};
-      hipLaunchKernelGGL(k2_t_eq_g_u<double>, dim3(tiles * Bs), dim3(LG4_THREADS), 0, st, k2);
+      LAUNCH_KG_ON(st, nullptr, (k2_t_eq_g_u<double, 1>), (k2_t_eq_g_u<double, 2>), dim3(tiles * Bs), k2);
     }
     for (int p = 0; p < n_parts; ++p) {
       int b0, Bs; hipStream_t st;
       part_of(p, b0, Bs, st);
       K3Args<double> k3{LD, Bs, h->T + b0 * LL, h->U, tb + b0, h->lam, h->E + (size_t)b0 * LD, h->H + (size_t)b0 * LD,
                         h->Gt + b0 * LL, h->sym_counts ? 1 : 0};
-      hipLaunchKernelGGL(k3_w_phi<double>, dim3(tiles_k3 * Bs), dim3(LG4_THREADS), 0, st, k3);
+      LAUNCH_KG_ON(st, nullptr, (k3_w_phi<double, 1>), (k3_w_phi<double, 2>), dim3(tiles_k3 * Bs), k3);
     }
     for (int p = 1; p < n_parts; ++p) {
       HIP_TRY(hipEventRecord(h->ev_join[p - 1], h->xstream[p - 1]));
@@ -312,42 +345,46 @@ static int large_eval(cb_bank *h, bool normalize, double *lossd, double *out, bo
     return CB_OK;
   } else {
     K1Args<double> k1{S, LD, B, h->Vc, h->A, tb, h->F, h->sigma, h->Ct, h->Gt, h->loss_part, inv_n, h->dsq, Pd, skipw};
-    if (Pd) hipLaunchKernelGGL((k1_pt_loss_gt<double, double, true>), dim3(tiles_k1 * B), dim3(LG4_THREADS), 0, h->stream, k1);
-    else hipLaunchKernelGGL((k1_pt_loss_gt<double, double, false>), dim3(tiles_k1 * B), dim3(LG4_THREADS), 0, h->stream, k1);
+    if (Pd) LAUNCH_STOP(ev_k1, (k1_pt_loss_gt<double, double, true>), dim3(tiles_k1 * B), dim3(LG4_THREADS), 0, h->stream, k1);
+    else LAUNCH_KG(ev_k1, (k1_pt_loss_gt<double, double, false, 1>), (k1_pt_loss_gt<double, double, false, 2>), dim3(tiles_k1 * B), k1);
   }
-  mark(h, EV_K1);
   if (Pd) {
     HIP_TRY(hipGetLastError());
     return CB_OK;
   }
-  hipLaunchKernelGGL(lg_finish_loss, dim3(1), dim3(256), 0, h->stream, h->loss_part, B * tiles_k1, S,
-                     h->dsq, h->dirsum, inv_n, lossd);
-  if (dQd) {
-    if (f32 || mixed) {
-      K2Args<float> k2{LD, h->Gt32, h->Uf, h->T32};
-      hipLaunchKernelGGL(k2_t_eq_g_u<float>, dim3(tiles * B), dim3(LG4_THREADS), 0, h->stream, k2);
-      mark(h, EV_K2);
-      K3Args<float> k3{LD, B, h->T32, h->Uf, tb, h->lam, h->E, h->H, h->Gt32, h->sym_counts ? 1 : 0};
-      hipLaunchKernelGGL(k3_w_phi<float>, dim3(tiles_k3 * B), dim3(LG4_THREADS), 0, h->stream, k3);
-      mark(h, EV_K3);
-      hipLaunchKernelGGL(k3_reduce<float>, dim3((unsigned)((LL + 255) / 256)), dim3(256), 0, h->stream,
-                         h->Gt32, B, LL, h->Mt, h->sym_counts ? LD : 0);
-    } else {
-      K2Args<double> k2{LD, h->Gt, h->U, h->T, skipw};
-      hipLaunchKernelGGL(k2_t_eq_g_u<double>, dim3(tiles * B), dim3(LG4_THREADS), 0, h->stream, k2);
-      mark(h, EV_K2);
-      K3Args<double> k3{LD, B, h->T, h->U, tb, h->lam, h->E, h->H, h->Gt, h->sym_counts ? 1 : 0, skipw};
-      hipLaunchKernelGGL(k3_w_phi<double>, dim3(tiles_k3 * B), dim3(LG4_THREADS), 0, h->stream, k3);
-      mark(h, EV_K3);
-      hipLaunchKernelGGL(k3_reduce<double>, dim3((unsigned)((LL + 255) / 256)), dim3(256), 0, h->stream,
-                         h->Gt, B, LL, h->Mt, h->sym_counts ? LD : 0);
-    }
+  if (!dQd) {   // the loss alone
+    hipLaunchKernelGGL(lg_finish_loss, dim3(1), dim3(256), 0, h->stream, h->loss_part, B * tiles_k1, S,
+                       h->dsq, h->dirsum, inv_n, lossd);
+    HIP_TRY(hipGetLastError());
+    return CB_OK;
+  }
+  // K1 -> K2 -> K3 back to back (the loss partials are summed beside the bucket sum, behind K3: a one-workgroup launch between
+  // K1 and K2 would sit on the chain), then the bucket sum + loss, then K4 -- the sequence of the fused path as three launches
+  const LossArgs la{h->loss_part, B * tiles_k1, S, h->dsq, h->dirsum, inv_n, lossd, skipw};
+  const dim3 red_grid((unsigned)((LL + 255) / 256) + 1);   // (+ the workgroup that sums the loss partials)
+  if (f32 || mixed) {
+    K2Args<float> k2{LD, h->Gt32, h->Uf, h->T32, skipw};
+    LAUNCH_KG(stop_event(h, EV_K2), (k2_t_eq_g_u<float, 1>), (k2_t_eq_g_u<float, 2>), dim3(tiles * B), k2);
+    K3Args<float> k3{LD, B, h->T32, h->Uf, tb, h->lam, h->E, h->H, h->Gt32, h->sym_counts ? 1 : 0, skipw};
+    LAUNCH_KG(stop_event(h, EV_K3), (k3_w_phi<float, 1>), (k3_w_phi<float, 2>), dim3(tiles_k3 * B), k3);
+    hipLaunchKernelGGL(k3_reduce_loss<float>, red_grid, dim3(256), 0, h->stream, h->Gt32, B, LL, h->Mt, h->sym_counts ? LD : 0, la);
+  } else {
+    K2Args<double> k2{LD, h->Gt, h->U, h->T, skipw};
+    LAUNCH_KG(stop_event(h, EV_K2), (k2_t_eq_g_u<double, 1>), (k2_t_eq_g_u<double, 2>), dim3(tiles * B), k2);
+    K3Args<double> k3{LD, B, h->T, h->U, tb, h->lam, h->E, h->H, h->Gt, h->sym_counts ? 1 : 0, skipw};
+    LAUNCH_KG(stop_event(h, EV_K3), (k3_w_phi<double, 1>), (k3_w_phi<double, 2>), dim3(tiles_k3 * B), k3);
+    hipLaunchKernelGGL(k3_reduce_loss<double>, red_grid, dim3(256), 0, h->stream, h->Gt, B, LL, h->Mt, h->sym_counts ? LD : 0, la);
+  }
+  {
     K4Args k4a{S, LD, h->Mt, h->Vc, h->X, nullptr, nullptr, nullptr};
+    k4a.skip = skipw;
     launch_sg(h, k4a, 0);
     K4Args k4b{S, LD, h->Vc, h->X, dQd, dA_padded ? nullptr : h->dsq, nullptr, nullptr};
-    launch_sg(h, k4b, 0);
-    mark(h, EV_K4);
+    k4b.skip = skipw;
+    launch_sg(h, k4b, 0, 0.0, 0.0, nullptr, stop_event(h, EV_K4));
   }
+#undef LAUNCH_KG
+#undef LAUNCH_KG_ON
   HIP_TRY(hipGetLastError());
   return CB_OK;
 }
@@ -414,7 +451,7 @@ extern "C" int cb_loss_grad(cb_handle h, const double *Q, const double *pi, int 
     rc = launch_small<SMALL_LOSSGRAD>(h, a);
     mark(h, EV_SMALL);
   }
-  if (rc == CB_OK && getenv("CB_FAULT_INJECT") && atoi(getenv("CB_FAULT_INJECT")) == -1)
+  if (rc == CB_OK && cb_test_hook("CB_FAULT_INJECT") && atoi(cb_test_hook("CB_FAULT_INJECT")) == -1)
     rc = fail(CB_ENUMERIC, "injected fault (CB_FAULT_INJECT)");
   if (rc != CB_OK && h->comm) {   // keep this rank's place in the collective (NaN payload): the peers get NaN, not a hang
     const std::string first_error = g_err;

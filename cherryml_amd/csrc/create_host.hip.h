@@ -292,7 +292,7 @@ extern "C" int cb_create(int device, int S, int L, int B, int dtype, const doubl
       int hf = 1;
       if (hipMemcpyAsync(&hf, flag, sizeof hf, hipMemcpyDeviceToHost, h->stream) == hipSuccess &&
           hipStreamSynchronize(h->stream) == hipSuccess)
-        h->sym_counts = hf == 0 && !getenv("CB_NO_SYM");
+        h->sym_counts = hf == 0 && !cb_test_hook("CB_NO_SYM");
       (void)hipMemsetAsync(flag, 0, sizeof(int), h->stream);
     }
   } else {
@@ -367,7 +367,7 @@ extern "C" int cb_create(int device, int S, int L, int B, int dtype, const doubl
       int hf = 1;
       if (hipMemcpyAsync(&hf, flag, sizeof hf, hipMemcpyDeviceToHost, h->stream) == hipSuccess &&
           hipStreamSynchronize(h->stream) == hipSuccess)
-        h->sym_counts = hf == 0 && !getenv("CB_NO_SYM");
+        h->sym_counts = hf == 0 && !cb_test_hook("CB_NO_SYM");
     }
     }
   }

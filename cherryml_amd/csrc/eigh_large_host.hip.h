@@ -305,7 +305,7 @@ static int large_eigh(cb_bank *h, bool warm) {
     HIP_TRY(hipMemsetAsync(h->off_bits, 0, sizeof(unsigned long long), h->stream));   // the sweep's running maximum
     return 0;
   };
-  const bool hybrid_on = use_light && nb >= 8 && !getenv("CB_NO_HYBRID");
+  const bool hybrid_on = use_light && nb >= 8 && !cb_test_hook("CB_NO_HYBRID");
   if (warm_started && hybrid_on) {
     const int hr = run_hybrid();
     if (hr < 0) return hr;

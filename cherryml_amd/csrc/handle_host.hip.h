@@ -86,6 +86,7 @@ struct cb_bank {
   int bank_slots = 0;                   // its grid: resident workgroups of the device (4 per CU)
   int bank_claims = 0;                  // reserved first tickets per queue
   bool bank_fused = false;              // the last evaluation ran K1 -> K2 -> K3 as one launch
+  int bank_kg = 1;                      // ... with four-wave (1) or eight-wave (2) tiles
   int last_sweeps = 0;
   double *gn_scratch = nullptr, *gn_partial = nullptr;  // general path, allocated on first use
   int gn_nw = 0;

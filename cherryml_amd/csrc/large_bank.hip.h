@@ -145,16 +145,41 @@ struct BankHooks {
 // ZERO = false: accumulate onto the tile the registers already hold (a second operand pair of the same
 // output tile: general_large.hip.h); ax1 must then be complete in wave 0 and ZERO elsewhere on entry, which
 // is how this routine leaves it.
-template <typename T, bool SCALE, bool ZERO = true>
+//
+// KG = 2 (round 5): the SAME tile on EIGHT waves -- two K-groups of four waves, group g takes the K-steps g, g + 2, ... with
+// its own pair of panel buffers (sA / sB of group g = the caller's + g * 4 * LG_KT * LG_TM) and every wave the same seven
+// accumulators as before.  Why: one 80 x 80 x 400 tile is 16.7 us of matrix pipe per SIMD, but a four-wave workgroup ALONE on
+// its CU takes 30 us for it (one wave per SIMD: every K-step exposes its LDS round trip and barrier), and 65-70 us beside three
+// others.  A launch is a chain of K1 -> K2 -> K3 tiles per bucket; with few buckets (the reference's real bank: 43; one rank's
+// share of an 8-rank job: 17) the chip is never full and the chain of three 30-45 us tiles IS the launch, and the long bank
+// ends in a drain of half-empty CUs at a third of the pipe.  Two waves per SIMD on ONE tile halve the tile's latency at the
+// same occupancy (two workgroups of 80 KB per CU instead of four of 40 KB).  After the K loop the groups exchange partial
+// accumulators through the (free) panel buffers and SHARE the epilogue: group 0 finishes the wave's tiles 0 .. 2 of its strip
+// and tile (4, 4), group 1 tiles 3, 4 and (4, wave) -- see lg_owns_*.  Sums are commutative pairs: the bits do not depend on
+// which group finishes a tile.  KG = 1 is the four-wave routine of rounds 2-4, bit for bit.
+template <int KG> __device__ __forceinline__ bool lg_owns_acc(int kg, int j) { return KG == 1 || (kg == 0) == (j < 3); }
+template <int KG> __device__ __forceinline__ bool lg_owns_ax0(int kg) { return KG == 1 || kg == 1; }
+template <int KG> __device__ __forceinline__ bool lg_owns_ax1(int kg) { return KG == 1 || kg == 0; }   // (and wave 0 of the group)
+
+template <typename T, bool SCALE, bool ZERO = true, int KG = 1>
 __device__ __forceinline__ void lg4_gemm_tile(const GemmOperands<T> &g, int m0, int n0, T *sA, T *sB,
                                               typename Mfma<T>::acc_t (&acc)[5], typename Mfma<T>::acc_t &ax0,
                                               typename Mfma<T>::acc_t &ax1, int tid = threadIdx.x,
                                               const BankHooks &hooks = BankHooks{}) {
   // (tid: threadIdx.x -- or an opaque copy of it, k123_bank: what is derived from it then stays inside the tile)
+  static_assert(KG == 1 || KG == 2, "one or two K-groups of four waves");
+  static_assert(KG == 1 || ZERO, "the accumulate-onto form exists for four waves only");
   typedef typename Mfma<T>::acc_t acc_t;
   typedef typename Mfma<T>::vec_t vec_t;
   // (the wave index as a SCALAR: the tests on it in the K loop are then scalar branches, not v_cmp + exec masks)
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, lo = lane & 15, hi = lane >> 4;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int kg = KG == 1 ? 0 : wv >> 2, wave = wv & 3, t4 = tid & 255;   // K-group, wave of the group, thread of the group
+  const int lane = tid & 63, lo = lane & 15, hi = lane >> 4;
+  T *const sAll = sA;   // the whole panel buffer (KG groups x (A | B) x two K-steps): the exchange area behind the K loop
+  if (KG > 1) {
+    sA += kg * (4 * LG_KT * LG_TM);
+    sB += kg * (4 * LG_KT * LG_TM);
+  }
   if (ZERO) {
 #pragma unroll
     for (int j = 0; j < 5; ++j) acc[j] = acc_t{};
@@ -163,65 +188,122 @@ __device__ __forceinline__ void lg4_gemm_tile(const GemmOperands<T> &g, int m0, 
   }
   vec_t ra[Panel<T>::NL], rb[Panel<T>::NL];
   T sc = T(1), one = T(1);
-  const int nk = g.K / LG_KT;
-  const PanelSrc<T> srcA = lg4_panel_src<T>(g.A, g.lda, g.M, m0, tid), srcB = lg4_panel_src<T>(g.B, g.ldb, g.N, n0, tid);
-  lg4_load_panel<T, SCALE>(srcA, g.lda, 0, ra, g.kscale, sc, tid);
-  lg4_load_panel<T, false>(srcB, g.ldb, 0, rb, nullptr, one, tid);
+  const int nk = g.K / LG_KT, nit = (nk + KG - 1) / KG;   // K-steps; iterations of a group (group kg runs step it * KG + kg)
+  const PanelSrc<T> srcA = lg4_panel_src<T>(g.A, g.lda, g.M, m0, t4), srcB = lg4_panel_src<T>(g.B, g.ldb, g.N, n0, t4);
+  if (kg < nk) {
+    lg4_load_panel<T, SCALE>(srcA, g.lda, kg * LG_KT, ra, g.kscale, sc, t4);
+    lg4_load_panel<T, false>(srcB, g.ldb, kg * LG_KT, rb, nullptr, one, t4);
+  }
   __syncthreads();  // the previous tile's readers of buffer 0 are done
-  lg4_store_panel<T, SCALE>(sA, ra, sc, tid);
-  lg4_store_panel<T, false>(sB, rb, one, tid);
+  if (kg < nk) {
+    lg4_store_panel<T, SCALE>(sA, ra, sc, t4);
+    lg4_store_panel<T, false>(sB, rb, one, t4);
+  }
   unsigned int *deferred = hooks.deferred;
   if (deferred) __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): this wave's stores of the previous tile have been performed
   __syncthreads();
   if (deferred && tid == 0) __hip_atomic_fetch_add(deferred, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   int drawn = -1;
-  const int draw_kt = nk > 2 ? 2 : 0;   // (early: the answer has the rest of the tile; drawn in the middle of the loop or four
-                                         // K-steps before its end, the epilogues waited 5-9 us for it -- a counter serves ~1.5
-                                         // draws per us, the answers queue up)
-  for (int kt = 0; kt < nk; ++kt) {
-    const T *cA = sA + (kt & 1) * (LG_KT * LG_TM), *cB = sB + (kt & 1) * (LG_KT * LG_TN);
-    if (hooks.draw && kt == draw_kt && tid == 0)
+  const int draw_it = nit > 2 ? 2 / KG : 0;   // (early: the answer has the rest of the tile; drawn in the middle of the loop or four
+                                              // K-steps before its end, the epilogues waited 5-9 us for it -- a counter serves ~1.5
+                                              // draws per us, the answers queue up)
+  for (int it = 0; it < nit; ++it) {
+    const int kt = it * KG + kg;
+    const T *cA = sA + (it & 1) * (LG_KT * LG_TM), *cB = sB + (it & 1) * (LG_KT * LG_TN);
+    if (hooks.draw && it == draw_it && tid == 0)
       drawn = (int)__hip_atomic_fetch_add(hooks.draw, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (kt + 1 < nk) {
-      lg4_load_panel<T, SCALE>(srcA, g.lda, (kt + 1) * LG_KT, ra, g.kscale, sc, tid);
-      lg4_load_panel<T, false>(srcB, g.ldb, (kt + 1) * LG_KT, rb, nullptr, one, tid);
+    const bool more = kt + KG < nk;   // (wave-uniform: kg is a scalar)
+    if (more) {
+      lg4_load_panel<T, SCALE>(srcA, g.lda, (kt + KG) * LG_KT, ra, g.kscale, sc, t4);
+      lg4_load_panel<T, false>(srcB, g.ldb, (kt + KG) * LG_KT, rb, nullptr, one, t4);
     }
+    if (KG == 1 || kt < nk) {
 #pragma unroll
-    for (int s = 0; s < LG_KT / 4; ++s) {
-      const T av = cA[(4 * s + hi) * LG_TM + 16 * wave + lo];
-      const T a4 = cA[(4 * s + hi) * LG_TM + 64 + lo];
-      T bv[5];
+      for (int s = 0; s < LG_KT / 4; ++s) {
+        const T av = cA[(4 * s + hi) * LG_TM + 16 * wave + lo];
+        const T a4 = cA[(4 * s + hi) * LG_TM + 64 + lo];
+        T bv[5];
 #pragma unroll
-      for (int j = 0; j < 5; ++j) bv[j] = cB[(4 * s + hi) * LG_TN + 16 * j + lo];
+        for (int j = 0; j < 5; ++j) bv[j] = cB[(4 * s + hi) * LG_TN + 16 * j + lo];
 #pragma unroll
-      for (int j = 0; j < 5; ++j) acc[j] = Mfma<T>::mma(av, bv[j], acc[j]);
-      // tile (4, wave): column block `wave` (a wave-uniform choice among registers)
-      // (read from LDS again rather than chosen among bv[0..3] with six v_cndmask per sub-step: the MFMAs share the vector
-      // issue port, every VALU instruction of the K loop costs matrix time -- 0.707 -> 0.685 ms for the bank)
-      const T bx = cB[(4 * s + hi) * LG_TN + 16 * wave + lo];
-      ax0 = Mfma<T>::mma(a4, bx, ax0);
-      // tile (4, 4): its K range is dealt round-robin to the four waves (6.25 MFMA tiles each
-      // instead of 7/6/6/6); the partial sums meet in wave 0 below
-      if ((kt & 3) == wave) ax1 = Mfma<T>::mma(a4, bv[4], ax1);
+        for (int j = 0; j < 5; ++j) acc[j] = Mfma<T>::mma(av, bv[j], acc[j]);
+        // tile (4, wave): column block `wave` (a wave-uniform choice among registers)
+        // (read from LDS again rather than chosen among bv[0..3] with six v_cndmask per sub-step: the MFMAs share the vector
+        // issue port, every VALU instruction of the K loop costs matrix time -- 0.707 -> 0.685 ms for the bank)
+        const T bx = cB[(4 * s + hi) * LG_TN + 16 * wave + lo];
+        ax0 = Mfma<T>::mma(a4, bx, ax0);
+        // tile (4, 4): its K range is dealt round-robin to the four waves of the group (6.25 MFMA tiles each
+        // instead of 7/6/6/6); the partial sums meet in wave 0 below
+        if ((it & 3) == wave) ax1 = Mfma<T>::mma(a4, bv[4], ax1);
+      }
     }
-    if (kt + 1 < nk) {
-      lg4_store_panel<T, SCALE>(sA + ((kt + 1) & 1) * (LG_KT * LG_TM), ra, sc, tid);
-      lg4_store_panel<T, false>(sB + ((kt + 1) & 1) * (LG_KT * LG_TN), rb, one, tid);
+    if (more) {
+      lg4_store_panel<T, SCALE>(sA + ((it + 1) & 1) * (LG_KT * LG_TM), ra, sc, t4);
+      lg4_store_panel<T, false>(sB + ((it + 1) & 1) * (LG_KT * LG_TN), rb, one, t4);
     }
     __syncthreads();
   }
-  if (wave != 0) {
+  if (KG == 1) {
+    if (wave != 0) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) sA[(wave - 1) * 256 + r * 64 + lane] = ax1[r];
-  }
-  __syncthreads();
-  if (wave == 0) {
+      for (int r = 0; r < 4; ++r) sA[(wave - 1) * 256 + r * 64 + lane] = ax1[r];
+    }
+    __syncthreads();
+    if (wave == 0) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) ax1[r] += (sA[r * 64 + lane] + sA[256 + r * 64 + lane]) + sA[512 + r * 64 + lane];
+      for (int r = 0; r < 4; ++r) ax1[r] += (sA[r * 64 + lane] + sA[256 + r * 64 + lane]) + sA[512 + r * 64 + lane];
+    } else {
+      ax1 = acc_t{};     // (the partial sums now live in wave 0)
+    }
   } else {
-    ax1 = acc_t{};     // (the partial sums now live in wave 0)
+    // exchange area (the panel buffers are free: every wave is past the loop's last barrier): [7][256] the partial sums of
+    // tile (4, 4) of every wave but (0, 0) | [4][3][256] group 0's partials of the tiles group 1 finishes (acc[3], acc[4],
+    // ax0 of wave w) | [4][3][256] group 1's partials of acc[0 .. 2]: 7936 elements of the buffer's 10240
+    T *px = sAll, *to1 = sAll + 7 * 256, *to0 = to1 + 12 * 256;
+    if (wv != 0) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) px[(wv - 1) * 256 + r * 64 + lane] = ax1[r];
+    }
+    if (kg == 0) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        to1[(wave * 3 + 0) * 256 + r * 64 + lane] = acc[3][r];
+        to1[(wave * 3 + 1) * 256 + r * 64 + lane] = acc[4][r];
+        to1[(wave * 3 + 2) * 256 + r * 64 + lane] = ax0[r];
+      }
+    } else {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        to0[(wave * 3 + 0) * 256 + r * 64 + lane] = acc[0][r];
+        to0[(wave * 3 + 1) * 256 + r * 64 + lane] = acc[1][r];
+        to0[(wave * 3 + 2) * 256 + r * 64 + lane] = acc[2][r];
+      }
+    }
+    __syncthreads();
+    if (kg == 0) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        acc[0][r] += to0[(wave * 3 + 0) * 256 + r * 64 + lane];
+        acc[1][r] += to0[(wave * 3 + 1) * 256 + r * 64 + lane];
+        acc[2][r] += to0[(wave * 3 + 2) * 256 + r * 64 + lane];
+      }
+      if (wave == 0) {   // fixed order: ((own + w1) + (w2 + w3)) + ((w4 + w5) + (w6 + w7))
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int o = r * 64 + lane;
+          ax1[r] = ((ax1[r] + px[o]) + (px[256 + o] + px[512 + o])) + ((px[768 + o] + px[1024 + o]) + (px[1280 + o] + px[1536 + o]));
+        }
+      }
+    } else {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        acc[3][r] += to1[(wave * 3 + 0) * 256 + r * 64 + lane];
+        acc[4][r] += to1[(wave * 3 + 1) * 256 + r * 64 + lane];
+        ax0[r] += to1[(wave * 3 + 2) * 256 + r * 64 + lane];
+      }
+    }
   }
-  __syncthreads();   // sA is free again (callers reuse it)
+  __syncthreads();   // the panel buffer is free again (callers reuse it)
   if (hooks.draw && tid == 0) *hooks.drawn_lds = drawn;
 }
 
@@ -257,21 +339,23 @@ __device__ unsigned long long cb_clock_stamps[3][4096][6];
 #define CB_STAMP_FINISH(kid) do { } while (0)
 #endif
 
-// f(row, col, value) for every element of the tile this lane owns
-template <typename T, typename F>
+// f(row, col, value) for every element of the tile this lane owns (KG = 2: of the MFMA tiles its K-group finishes)
+template <typename T, int KG = 1, typename F>
 __device__ __forceinline__ void lg_for_each(int m0, int n0, const typename Mfma<T>::acc_t (&acc)[5],
                                             const typename Mfma<T>::acc_t &ax0, const typename Mfma<T>::acc_t &ax1,
                                             F &&f, int tid = threadIdx.x) {
-  const int wave = tid >> 6, lane = tid & 63, lo = lane & 15, hi = lane >> 4;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), kg = KG == 1 ? 0 : wv >> 2, wave = wv & 3;
+  const int lane = tid & 63, lo = lane & 15, hi = lane >> 4;
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int rr = Mfma<T>::row(hi, r);
     const int row = m0 + 16 * wave + rr;
 #pragma unroll
-    for (int j = 0; j < 5; ++j) f(row, n0 + 16 * j + lo, acc[j][r]);
+    for (int j = 0; j < 5; ++j)
+      if (lg_owns_acc<KG>(kg, j)) f(row, n0 + 16 * j + lo, acc[j][r]);
     const int row4 = m0 + 64 + rr;
-    f(row4, n0 + 16 * wave + lo, ax0[r]);
-    if (wave == 0) f(row4, n0 + 64 + lo, ax1[r]);
+    if (lg_owns_ax0<KG>(kg)) f(row4, n0 + 16 * wave + lo, ax0[r]);
+    if (wave == 0 && lg_owns_ax1<KG>(kg)) f(row4, n0 + 64 + lo, ax1[r]);
   }
 }
 
@@ -319,7 +403,7 @@ __device__ __forceinline__ void bank_store(T *p, T v) {
 
 // one (bucket b, upper-triangular tile `tile`) of K1; sAB: 4 * LG_KT * LG_TM elements of LDS (A panels | B panels, two K-steps
 // each; after the K loop: the transposition buffer); vid = b * tiles + tile indexes the loss partial
-template <typename T, typename TG, bool EXPM, bool WT>
+template <typename T, typename TG, bool EXPM, bool WT, int KG = 1>
 __device__ __forceinline__ void k1_tile(const K1Args<T, TG> &a, int b, int tile, T *sAB, int tid,
                                         const BankHooks &hooks = BankHooks{}) {
   T *sA = sAB, *sB = sAB + 2 * LG_KT * LG_TM;
@@ -333,12 +417,12 @@ __device__ __forceinline__ void k1_tile(const K1Args<T, TG> &a, int b, int tile,
   }
   const int tn = tm + tile;
   const int m0 = tm * LG_TM, n0 = tn * LG_TN;
-  const int wave = tid >> 6, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), kg = KG == 1 ? 0 : wv >> 2, wave = wv & 3, lane = tid & 63;
   const size_t boff = (size_t)b * a.LD * a.LD;
   GemmOperands<T> g{a.Ut, a.Ut, a.LD, a.LD, a.LD, a.LD, a.LD, a.F + (size_t)b * a.LD};
   acc_t acc[5], ax0, ax1;
   CB_STAMP_BEGIN(vid);
-  lg4_gemm_tile<T, true>(g, m0, n0, sA, sB, acc, ax0, ax1, tid, hooks);
+  lg4_gemm_tile<T, true, true, KG>(g, m0, n0, sA, sB, acc, ax0, ax1, tid, hooks);
   CB_STAMP_END(0);
 
   const double tb = a.t[b];
@@ -364,7 +448,7 @@ __device__ __forceinline__ void k1_tile(const K1Args<T, TG> &a, int b, int tile,
   // arithmetic -- a software pipeline over the 7 tiles of a wave -- costs 4 .. 56 spilled registers at the 128 the
   // four-workgroup occupancy allows and measured 0.240 against 0.236 ms without it: the other three workgroups of
   // the CU already cover those latencies.)
-  T *sW = sAB + wave * (2 * 16 * 17);   // two patches per wave: log Pt, 1 / Pt
+  T *sW = sAB + wv * (2 * 16 * 17);   // two patches per wave: log Pt, 1 / Pt
   auto tile_epilogue = [&](int rbase, int cbase, const acc_t &v) {   // wave-uniform tile origin
     if (rbase >= a.LD || cbase >= a.LD) return;
     const int col = cbase + lo;
@@ -449,29 +533,35 @@ __device__ __forceinline__ void k1_tile(const K1Args<T, TG> &a, int b, int tile,
       for (int r = 0; r < 4; ++r) bank_store<WT>(&Gt[idm[r]], g2[r]);
     }
   };
+  // (KG = 2: the MFMA tiles this wave's K-group finishes -- wave-uniform scalar branches)
 #pragma unroll
-  for (int j = 0; j < 5; ++j) tile_epilogue(m0 + 16 * wave, n0 + 16 * j, acc[j]);
-  tile_epilogue(m0 + 64, n0 + 16 * wave, ax0);
-  if (wave == 0) tile_epilogue(m0 + 64, n0 + 64, ax1);
+  for (int j = 0; j < 5; ++j)
+    if (lg_owns_acc<KG>(kg, j)) tile_epilogue(m0 + 16 * wave, n0 + 16 * j, acc[j]);
+  if (lg_owns_ax0<KG>(kg)) tile_epilogue(m0 + 64, n0 + 16 * wave, ax0);
+  if (wave == 0 && lg_owns_ax1<KG>(kg)) tile_epilogue(m0 + 64, n0 + 64, ax1);
   if (EXPM) return;
   __syncthreads();   // the patches are read no more: the loss partials reuse the buffer
   lossacc = wave_sum(lossacc);
   // the LDS panels are free after the K loop (the tile routine ends with a barrier)
   double *sRed = reinterpret_cast<double *>(sAB);
-  if (lane == 0) sRed[wave] = lossacc;
+  if (lane == 0) sRed[wv] = lossacc;
   __syncthreads();
-  if (tid == 0) a.loss_part[vid] = (sRed[0] + sRed[1]) + (sRed[2] + sRed[3]);
+  if (tid == 0) {
+    double l = (sRed[0] + sRed[1]) + (sRed[2] + sRed[3]);
+    if (KG == 2) l += (sRed[4] + sRed[5]) + (sRed[6] + sRed[7]);
+    a.loss_part[vid] = l;
+  }
   CB_STAMP_FINISH(0);
 }
 
-template <typename T, typename TG = T, bool EXPM = false>   // EXPM: write P_b (cb_expm_bank) instead of loss / Gt
-__global__ __launch_bounds__(LG4_THREADS, 4) void k1_pt_loss_gt(K1Args<T, TG> a) {  // four workgroups per CU
+template <typename T, typename TG = T, bool EXPM = false, int KG = 1>   // EXPM: write P_b (cb_expm_bank) instead of loss / Gt
+__global__ __launch_bounds__(LG4_THREADS * KG, 4) void k1_pt_loss_gt(K1Args<T, TG> a) {  // sixteen waves per CU
   if (a.skip && *a.skip != 0ull) return;
-  __shared__ T sAB[4 * LG_KT * LG_TM];
+  __shared__ T sAB[KG * 4 * LG_KT * LG_TM];
   const int tilesN = (a.LD + LG_TN - 1) / LG_TN, tiles = tilesN * (tilesN + 1) / 2;
   const int vid = xcd_swizzle(blockIdx.x, gridDim.x);
   const int b = vid / tiles;
-  k1_tile<T, TG, EXPM, false>(a, b, vid - b * tiles, sAB, threadIdx.x);
+  k1_tile<T, TG, EXPM, false, KG>(a, b, vid - b * tiles, sAB, threadIdx.x);
 }
 
 // ------------------------------------------------------------------ K2
@@ -485,7 +575,7 @@ struct K2Args {
 };
 
 // one (bucket b, tile) of K2; sAB as in k1_tile
-template <typename T, bool WT>
+template <typename T, bool WT, int KG = 1>
 __device__ __forceinline__ void k2_tile(const K2Args<T> &a, int b, int tile, T *sAB, int tid, const BankHooks &hooks = BankHooks{}) {
   T *sA = sAB, *sB = sAB + 2 * LG_KT * LG_TM;
   typedef typename Mfma<T>::acc_t acc_t;
@@ -496,23 +586,23 @@ __device__ __forceinline__ void k2_tile(const K2Args<T> &a, int b, int tile, T *
   GemmOperands<T> g{a.Gt + boff, a.U, a.LD, a.LD, a.LD, a.LD, a.LD, nullptr};
   acc_t acc[5], ax0, ax1;
   CB_STAMP_BEGIN(b * tilesN * tilesN + tile);
-  lg4_gemm_tile<T, false>(g, m0, n0, sA, sB, acc, ax0, ax1, tid, hooks);
+  lg4_gemm_tile<T, false, true, KG>(g, m0, n0, sA, sB, acc, ax0, ax1, tid, hooks);
   CB_STAMP_END(1);
   T *__restrict__ Tm = a.Tm + boff;
-  lg_for_each<T>(m0, n0, acc, ax0, ax1, [&](int row, int col, T v) {
+  lg_for_each<T, KG>(m0, n0, acc, ax0, ax1, [&](int row, int col, T v) {
     if (row < a.LD && col < a.LD) bank_store<WT>(&Tm[(size_t)row * a.LD + col], v);
   }, tid);
   CB_STAMP_FINISH(1);
 }
 
-template <typename T>
-__global__ __launch_bounds__(LG4_THREADS, 4) void k2_t_eq_g_u(K2Args<T> a) {
+template <typename T, int KG = 1>
+__global__ __launch_bounds__(LG4_THREADS * KG, 4) void k2_t_eq_g_u(K2Args<T> a) {
   if (a.skip && *a.skip != 0ull) return;
-  __shared__ T sAB[4 * LG_KT * LG_TM];
+  __shared__ T sAB[KG * 4 * LG_KT * LG_TM];
   const int tilesN = (a.LD + LG_TN - 1) / LG_TN, tiles = tilesN * tilesN;
   const int vid = xcd_swizzle(blockIdx.x, gridDim.x);
   const int b = vid / tiles;
-  k2_tile<T, false>(a, b, vid - b * tiles, sAB, threadIdx.x);
+  k2_tile<T, false, KG>(a, b, vid - b * tiles, sAB, threadIdx.x);
 }
 
 // ------------------------------------------------------------------ K3
@@ -535,7 +625,7 @@ struct K3Args {
 };
 
 // one (bucket b, tile) of K3; sAB as in k1_tile
-template <typename T>
+template <typename T, int KG = 1>
 __device__ __forceinline__ void k3_tile(const K3Args<T> &a, int b, int tile, T *sAB, int tid, const BankHooks &hooks = BankHooks{}) {
   T *sA = sAB, *sB = sAB + 2 * LG_KT * LG_TM;
   typedef typename Mfma<T>::acc_t acc_t;
@@ -557,13 +647,14 @@ __device__ __forceinline__ void k3_tile(const K3Args<T> &a, int b, int tile, T *
   GemmOperands<T> g{a.Tm + boff, a.U, a.LD, a.LD, a.LD, a.LD, a.LD, nullptr};
   acc_t acc[5], ax0, ax1;
   CB_STAMP_BEGIN(b * tilesN * tilesN + tm * tilesN + tn);
-  lg4_gemm_tile<T, false>(g, m0, n0, sA, sB, acc, ax0, ax1, tid, hooks);
+  lg4_gemm_tile<T, false, true, KG>(g, m0, n0, sA, sB, acc, ax0, ax1, tid, hooks);
   CB_STAMP_END(2);
   const double tb = a.t[b];
   const double *__restrict__ Eb = a.E + (size_t)b * a.LD, *__restrict__ Hb = a.H + (size_t)b * a.LD;
   const double *__restrict__ lam = a.lam;
   T *__restrict__ W = a.W + boff;
-  const int wave = tid >> 6, lane = tid & 63, lo = lane & 15, hi = lane >> 4;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), kg = KG == 1 ? 0 : wv >> 2, wave = wv & 3;
+  const int lane = tid & 63, lo = lane & 15, hi = lane >> 4;
   // per MFMA tile: the spectral tables of its rows and column first (all loads of the tile in flight
   // together; element by element they compiled to load -> wait -> store chains), then Phi, then the stores.
   // (the divided difference is evaluated in float64 in both widths: its cancellation-free form needs it)
@@ -587,21 +678,22 @@ __device__ __forceinline__ void k3_tile(const K3Args<T> &a, int b, int tile, T *
     for (int r = 0; r < 4; ++r) W[(size_t)row[r] * a.LD + col] = w[r];   // (symmetric case: k3_reduce mirrors the sum, not every bucket)
   };
 #pragma unroll
-  for (int j = 0; j < 5; ++j) tile_epilogue(m0 + 16 * wave, n0 + 16 * j, acc[j]);
-  tile_epilogue(m0 + 64, n0 + 16 * wave, ax0);
-  if (wave == 0) tile_epilogue(m0 + 64, n0 + 64, ax1);
+  for (int j = 0; j < 5; ++j)
+    if (lg_owns_acc<KG>(kg, j)) tile_epilogue(m0 + 16 * wave, n0 + 16 * j, acc[j]);
+  if (lg_owns_ax0<KG>(kg)) tile_epilogue(m0 + 64, n0 + 16 * wave, ax0);
+  if (wave == 0 && lg_owns_ax1<KG>(kg)) tile_epilogue(m0 + 64, n0 + 64, ax1);
   CB_STAMP_FINISH(2);
 }
 
-template <typename T>
-__global__ __launch_bounds__(LG4_THREADS, 4) void k3_w_phi(K3Args<T> a) {
+template <typename T, int KG = 1>
+__global__ __launch_bounds__(LG4_THREADS * KG, 4) void k3_w_phi(K3Args<T> a) {
   if (a.skip && *a.skip != 0ull) return;
-  __shared__ T sAB[4 * LG_KT * LG_TM];
+  __shared__ T sAB[KG * 4 * LG_KT * LG_TM];
   const int tilesN = (a.LD + LG_TN - 1) / LG_TN;
   const int tiles = a.sym ? tilesN * (tilesN + 1) / 2 : tilesN * tilesN;
   const int vid = xcd_swizzle(blockIdx.x, gridDim.x);
   const int b = vid / tiles;
-  k3_tile<T>(a, b, vid - b * tiles, sAB, threadIdx.x);
+  k3_tile<T, KG>(a, b, vid - b * tiles, sAB, threadIdx.x);
 }
 
 // ------------------------------------------------------------------ K1 -> K2 -> K3 in ONE launch
@@ -719,8 +811,8 @@ __device__ __forceinline__ void globalize(K3Args<T> &a) {
 // as kernel arguments the ~40 pointers and sizes of the three stages stayed in SGPRs across the ticket loop (106 + 111
 // spilled, and 57 spilled VGPRs in their wake); read where a stage needs them (uniform_copy: loads + v_readfirstlane, so that
 // they are SGPRs again inside the stage) they cost a few loads per tile.
-template <typename T1, typename TG>
-__global__ __launch_bounds__(LG4_THREADS, 4) void k123_bank(const K123Args<T1, TG> *ap) {
+template <typename T1, typename TG, int KG = 1>
+__global__ __launch_bounds__(LG4_THREADS * KG, 4) void k123_bank(const K123Args<T1, TG> *ap) {
   BankQueueArgs a = uniform_copy(&ap->q);
   a.queue = as_global(a.queue);
   {
@@ -728,7 +820,7 @@ __global__ __launch_bounds__(LG4_THREADS, 4) void k123_bank(const K123Args<T1, T
     if (skip && *skip != 0ull) return;
   }
   constexpr size_t ELT = sizeof(T1) > sizeof(TG) ? sizeof(T1) : sizeof(TG);
-  __shared__ __attribute__((aligned(16))) unsigned char smem[4 * LG_KT * LG_TM * ELT];   // 40 KB in float64: four per CU
+  __shared__ __attribute__((aligned(16))) unsigned char smem[KG * 4 * LG_KT * LG_TM * ELT];   // 40 KB x KG in float64: sixteen waves per CU
   int *s_ticket = reinterpret_cast<int *>(smem);   // (queue, ticket) of this round, in the panel buffer: every thread has read
                                                    // them before the tile routine's first barrier, which precedes its first store
   unsigned int *tick = a.queue, *done1 = a.queue + LG_NQ, *done2 = done1 + a.B;
@@ -860,17 +952,17 @@ __global__ __launch_bounds__(LG4_THREADS, 4) void k123_bank(const K123Args<T1, T
     if (stage == 0) {
       K1Args<T1, TG> k1 = const_copy(&cap->k1);
       globalize(k1);
-      k1_tile<T1, TG, false, true>(k1, b, tile, reinterpret_cast<T1 *>(smem), tid, hooks);
+      k1_tile<T1, TG, false, true, KG>(k1, b, tile, reinterpret_cast<T1 *>(smem), tid, hooks);
       signal = done1 + b;
     } else if (stage == 1) {
       K2Args<TG> k2 = const_copy(&cap->k2);
       globalize(k2);
-      k2_tile<TG, true>(k2, b, tile, reinterpret_cast<TG *>(smem), tid, hooks);
+      k2_tile<TG, true, KG>(k2, b, tile, reinterpret_cast<TG *>(smem), tid, hooks);
       signal = done2 + b;
     } else {
       K3Args<TG> k3 = const_copy(&cap->k3);
       globalize(k3);
-      k3_tile<TG>(k3, b, tile, reinterpret_cast<TG *>(smem), tid, hooks);
+      k3_tile<TG, KG>(k3, b, tile, reinterpret_cast<TG *>(smem), tid, hooks);
     }
     pending = signal;
     if (own_stage < 0 && threadIdx.x == 0) {

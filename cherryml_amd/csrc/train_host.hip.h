@@ -134,15 +134,15 @@ static int run_fused_training_large(cb_bank *h, double *pi_param, double *up_par
   h->last_form = 4000;
   h->tr_epochs = 0;   // (set again when this call succeeds)
   // fault injection for the tests of the collective failure protocol: this rank's evaluation "fails" at that epoch
-  const int fault_epoch = getenv("CB_FAULT_INJECT") ? atoi(getenv("CB_FAULT_INJECT")) : -1000;
+  const int fault_epoch = cb_test_hook("CB_FAULT_INJECT") ? atoi(cb_test_hook("CB_FAULT_INJECT")) : -1000;
   // planned solves: float64 work on LD x LD matrices with LD a multiple of 16 and at least 8 column blocks (the hybrid
   // scheme's own condition); CB_EIGH_HOST=1 keeps the host-driven loop of rounds 1-3
-  const bool planned = !getenv("CB_EIGH_HOST") && !getenv("CB_NO_HYBRID") && LD % 16 == 0 && LD / JB_W >= 8 && eigh_planned_setup(h);
+  const bool planned = !cb_test_hook("CB_EIGH_HOST") && !cb_test_hook("CB_NO_HYBRID") && LD % 16 == 0 && LD / JB_W >= 8 && eigh_planned_setup(h);
   EighPlan &plan = h->eplan;
   if (!resume) eigh_plan_default(plan);
   // test hook: every plan cut down to one sweep, so that every solve stalls and is continued (tests/test_gpu_s400_full.py)
   // (= 2: that one sweep with the second-order polynomial only, so that it is also a DAMPED one -- exp(alpha X), alpha << 1)
-  const int short_plans = getenv("CB_EIGH_SHORT_PLAN") ? std::max(1, atoi(getenv("CB_EIGH_SHORT_PLAN"))) : 0;
+  const int short_plans = cb_test_hook("CB_EIGH_SHORT_PLAN") ? std::max(1, atoi(cb_test_hook("CB_EIGH_SHORT_PLAN"))) : 0;
   auto shorten = [&]() {
     if (!short_plans) return;
     plan.nslots = 1;

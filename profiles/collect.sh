@@ -5,6 +5,7 @@
 # runs; FETCH_SIZE / WRITE_SIZE are collected in separate passes (TCC slot budget) and the SQ counters
 # (MFMA busy cycles, wave cycles, waits) in one pass of 8, as MI355X_MICROARCH.md prescribes.
 set -u
+export CB_TEST_HOOKS=1   # CB_BANK_UNFUSED / CB_BANK_KG are test hooks (csrc/cb_internal.hip.h)
 R=${GRAFT_REPO_ROOT:-$PWD}
 cd /tmp && export TMPDIR=/tmp
 TAG=${1:-final}

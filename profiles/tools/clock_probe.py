@@ -49,6 +49,10 @@ def main():
     out = {"epochs": epochs, "workload": wl["desc"], "live_buckets": nB, "shard_of": shard_of, "kernels": {}}
     lib = _lib.load()
     # the fused bank launch (k123_bank, the default) lives in a translation unit of its own with its own stamp buffer
+    # (large_eval picks the form by the bank's shape; the probe pins it: CB_BANK_UNFUSED=1 or, else, CB_BANK_FUSED=1)
+    os.environ["CB_TEST_HOOKS"] = "1"
+    if not os.environ.get("CB_BANK_UNFUSED"):
+        os.environ["CB_BANK_FUSED"] = "1"
     fn = lib.cb_debug_clock_stamps if os.environ.get("CB_BANK_UNFUSED") else lib.cb_debug_clock_stamps_fused
     fn.restype = ctypes.c_int
     fn.argtypes = [ctypes.c_void_p]

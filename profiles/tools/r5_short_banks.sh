@@ -5,6 +5,7 @@
 R=${GRAFT_REPO_ROOT:-$PWD}
 cd $R
 TAG=${1:-r5a}
+export CB_TEST_HOOKS=1   # CB_BANK_UNFUSED / CB_BANK_KG are test hooks (csrc/cb_internal.hip.h)
 O=gpurun_out
 line() { python3 -c "
 import json,sys

@@ -20,6 +20,9 @@ def _cpu_budget():
 
 for _k in ("OMP_NUM_THREADS", "MKL_NUM_THREADS", "OPENBLAS_NUM_THREADS"):   # before numpy / torch load their thread pools
     os.environ.setdefault(_k, str(max(1, _cpu_budget() - max(1, _cpu_budget() // 4))))
+# the library honours its test hooks (CB_BANK_UNFUSED, CB_BANK_KG, CB_EIGH_HOST, CB_NO_HYBRID, CB_NO_SYM, CB_FAULT_INJECT,
+# CB_EIGH_SHORT_PLAN, CB_BANK_TEST_NO_CLAIM) only together with this gate (csrc/cb_internal.hip.h, cb_test_hook)
+os.environ.setdefault("CB_TEST_HOOKS", "1")
 os.environ.setdefault("KMP_BLOCKTIME", "0")
 os.environ.setdefault("OMP_WAIT_POLICY", "PASSIVE")
 

@@ -407,11 +407,10 @@ def test_fused_bank_launch_gives_the_bits_of_the_three_launches_on_the_bench_ban
     u0, p0 = mod.upper_diag.detach().numpy().copy(), mod._pi.detach().numpy().copy()
     Q0, pi0 = mod().detach().numpy(), mod.stationary().detach().numpy()
     out = {}
-    for name, env in (("fused", None), ("separate", "1")):
-        if env is None:
-            monkeypatch.delenv("CB_BANK_UNFUSED", raising=False)
-        else:
-            monkeypatch.setenv("CB_BANK_UNFUSED", env)
+    for name, env in (("fused", "CB_BANK_FUSED"), ("separate", "CB_BANK_UNFUSED")):
+        for k in ("CB_BANK_FUSED", "CB_BANK_UNFUSED"):
+            monkeypatch.delenv(k, raising=False)
+        monkeypatch.setenv(env, "1")
         with CherryBank(wl["t"], wl["C"], dtype=dtype) as bank:
             loss, dQ = bank.loss_grad(Q0, pi0)
             loss2, dQ2 = bank.loss_grad(Q0, pi0)          # the queues are reset by every evaluation (the second one starts
@@ -431,24 +430,33 @@ def test_fused_bank_launch_gives_the_bits_of_the_three_launches_on_the_bench_ban
     assert tb["k1"] > 0 and tb["k2"] > 0 and tb["k3"] > 0
 
 
-@pytest.mark.parametrize("S,B,sym", [(100, 3, True), (100, 9, False), (64, 1, True), (200, 20, True), (400, 7, False)])
-def test_fused_bank_launch_on_small_and_ragged_banks(S, B, sym, monkeypatch):
+@pytest.mark.parametrize("kg", [1, 2])
+@pytest.mark.parametrize("dtype", ["f64", "mixed", "f32"])
+@pytest.mark.parametrize("S,B,sym", [(100, 3, True), (100, 9, False), (64, 1, True), (200, 20, True), (400, 7, False),
+                                     (400, 17, True), (400, 43, True)])
+def test_fused_bank_launch_on_small_and_ragged_banks(S, B, sym, dtype, kg, monkeypatch):
     """Fewer buckets than ticket queues (empty queues, every ticket drawn from a neighbour's queue), one bucket, fewer tickets
-    than resident workgroups, LD = 112 / 64 / 208 (2 / 1 / 3 tiles a side), asymmetric counts (K3 runs all its tiles): the
-    fused launch against the three launches bit for bit, and against the float64 oracle."""
+    than resident workgroups, LD = 112 / 64 / 208 (2 / 1 / 3 tiles a side), asymmetric counts (K3 runs all its tiles), the
+    sizes of one rank's share of an 8-rank job (17 buckets) and of the reference's real bank (43): the fused launch
+    (CB_BANK_FUSED=1: by itself large_eval picks the three launches below 64 live buckets) against the three launches bit for
+    bit, in every arithmetic (with float32 outputs a tile edge falls inside a 128-byte line, so two workgroups on
+    different XCDs write through parts of the same line) and both tile forms (four / eight waves per tile, CB_BANK_KG); the
+    float64 result also against the oracle."""
     from cherryml_amd import CherryBank
     from oracle import ratelearn_oracle as orc
     t, C, Q, pi = _random_bank(S, B, 1000 * S + B, sym)
+    monkeypatch.setenv("CB_BANK_KG", str(kg))
     out = {}
-    for name, env in (("fused", None), ("separate", "1")):
-        if env is None:
-            monkeypatch.delenv("CB_BANK_UNFUSED", raising=False)
-        else:
-            monkeypatch.setenv("CB_BANK_UNFUSED", env)
-        with CherryBank(t, C) as bank:
+    for name, env in (("fused", "CB_BANK_FUSED"), ("separate", "CB_BANK_UNFUSED")):
+        for k in ("CB_BANK_FUSED", "CB_BANK_UNFUSED"):
+            monkeypatch.delenv(k, raising=False)
+        monkeypatch.setenv(env, "1")
+        with CherryBank(t, C, dtype=dtype) as bank:
             out[name] = bank.loss_grad(Q * 0.9, pi)
     (la, da), (lb, db) = out["fused"], out["separate"]
     assert np.all(np.isfinite(la)) and np.array_equal(la, lb) and np.array_equal(da, db)
+    if dtype != "f64" or S * B > 4000:   # (the oracle: float64, sizes it finishes in seconds)
+        return
     import torch
     Qt = torch.tensor(Q * 0.9, dtype=torch.float64, requires_grad=True)
     lo = orc.bank_loss(Qt, torch.tensor(t, dtype=torch.float64), torch.tensor(C, dtype=torch.float64))
@@ -458,7 +466,8 @@ def test_fused_bank_launch_on_small_and_ragged_banks(S, B, sym, monkeypatch):
     assert relerr(da[0], Qt.grad.numpy()) < 1e-10
 
 
-def test_reserved_tickets_nobody_claims_are_run_by_the_workgroups_that_wait_for_them(dense, monkeypatch):
+@pytest.mark.parametrize("dtype", ["f64", "mixed", "f32"])
+def test_reserved_tickets_nobody_claims_are_run_by_the_workgroups_that_wait_for_them(dense, dtype, monkeypatch):
     """The fused bank launch reserves the first K1 tickets of every queue for its workgroups (one uncontended claim instead of
     128 draws on one counter); a reserved ticket whose workgroup is not resident -- another launch holds its slot -- must not be
     waited for forever.  Test hook CB_BANK_TEST_NO_CLAIM=1: no workgroup takes its reserved ticket; every one of them (128 per
@@ -475,12 +484,12 @@ def test_reserved_tickets_nobody_claims_are_run_by_the_workgroups_that_wait_for_
                                           pi=torch.ones(400, dtype=torch.float64) / 400, pi_requires_grad=True, initialization=init)
             Q, pi = mod().detach().numpy(), mod.stationary().detach().numpy()
         out = {}
-        for name, env in (("helped", {"CB_BANK_TEST_NO_CLAIM": "1"}), ("separate", {"CB_BANK_UNFUSED": "1"})):
-            for k in ("CB_BANK_TEST_NO_CLAIM", "CB_BANK_UNFUSED"):
+        for name, env in (("helped", {"CB_BANK_TEST_NO_CLAIM": "1", "CB_BANK_FUSED": "1"}), ("separate", {"CB_BANK_UNFUSED": "1"})):
+            for k in ("CB_BANK_TEST_NO_CLAIM", "CB_BANK_UNFUSED", "CB_BANK_FUSED"):
                 monkeypatch.delenv(k, raising=False)
             for k, v in env.items():
                 monkeypatch.setenv(k, v)
-            with CherryBank(t, C) as bank:
+            with CherryBank(t, C, dtype=dtype) as bank:
                 out[name] = bank.loss_grad(Q, pi)
         (la, da), (lb, db) = out["helped"], out["separate"]
         assert np.all(np.isfinite(la)) and np.array_equal(la, lb) and np.array_equal(da, db)
