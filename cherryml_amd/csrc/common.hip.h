@@ -48,6 +48,16 @@ __device__ __forceinline__ double phi2(double x) {
   return expm1(x) - x;
 }
 
+// sinh(z)/z for |z| < 1/16 (Taylor to z^8: the next term, z^10 / 11!, is below 3e-20)
+__device__ __forceinline__ double sinhc_tiny(double z) {
+  const double w = z * z;
+  double p = 1.0 / 362880.0;                 // 1/9!
+  p = fma(p, w, 1.0 / 5040.0);               // 1/7!
+  p = fma(p, w, 1.0 / 120.0);                // 1/5!
+  p = fma(p, w, 1.0 / 6.0);                  // 1/3!
+  return fma(p, w, 1.0);
+}
+
 // sinh(z)/z for |z| < 0.5 (Taylor to z^14).
 __device__ __forceinline__ double sinhc_small(double z) {
   const double w = z * z;
@@ -180,6 +190,25 @@ __device__ __forceinline__ void fast_log_table_fill(double *ltab, int tid, int n
     ltab[2 * j + 1] = -log(c) - (j >= 64 ? 6.93147180559945286227e-01 : 0.0);
   }
 }
+// the polynomial alone: x must be a positive finite number (small_quad checks the class of its argument with ONE compare,
+// is_pos_finite_nonzero, and selects NaN otherwise -- two compares and two selects less per logarithm than the form below)
+__device__ __forceinline__ double fast_log_table_unchecked(double x, const double *ltab) {
+  const int hi = __double2hiint(x), lo = __double2loint(x);
+  const int j = (hi >> 13) & 127;
+  const int k = ((hi >> 20) & 0x7FF) - 1023 + (j >> 6);
+  const double m = __hiloint2double((hi & 0x000FFFFF) | 0x3FF00000, lo);
+  const double2 ct = *reinterpret_cast<const double2 *>(ltab + 2 * j);
+  const double r = fma(m, ct.x, -1.0);
+  double p = fma(r, -1.0 / 6.0, 0.2);
+  p = fma(p, r, -0.25);
+  p = fma(p, r, 1.0 / 3.0);
+  p = fma(p, r, -0.5);
+  p = fma(p * r, r, r);
+  return fma((double)k, 6.93147180559945286227e-01, ct.y + p);
+}
+// x is a positive normal or denormal number (v_cmp_class_f64: one instruction)
+__device__ __forceinline__ bool is_pos_finite_nonzero(double x) { return __builtin_amdgcn_class(x, 0x100 | 0x080); }
+
 __device__ __forceinline__ double fast_log_table(double x, const double *ltab) {
   const int hi = __double2hiint(x), lo = __double2loint(x);
   const int j = (hi >> 13) & 127;

@@ -290,6 +290,11 @@ __device__ __forceinline__ void quad_load_counts(double (&cv)[TS][TS], const dou
 // banks): 2.06 conflict cycles per LDS instruction in sp_bank<5, true, true> (profiles/r03_sp_bank_sq_counters.json), in a
 // kernel whose four SIMDs share one LDS.  36 / 100 (both = 4 mod 32) make every read of the quad conflict-free: the lanes of a
 // 32-lane group address q * 36 + r, r * 36 + q or blk * 100 + {q, r} -- disjoint words.
+// Round 5 (sp_bank is bound by vector-instruction ISSUE: 292 M VALU against 45 M MFMA instructions per launch,
+// profiles/r04_sp_bank_sq_counters.json): the P epilogue sanitises its argument once (a zero count contributes 0 * log 1 and
+// 0 * 1 without further selects), the table logarithm is guarded by ONE class compare and one select (NaN for anything but a
+// positive finite argument) instead of three compares and three selects, and the divided difference takes its Taylor form only below |z| = 1/16 (five terms; above, the
+// quotient loses at most three bits).
 template <int TS, bool LANEM, bool SYM = false, bool ULDS = false, bool LOGT = false, int QLS = CB_LS, int TABS = 96>
 __device__ __forceinline__ void small_quad(int S, double tb, const double *__restrict__ Cq, double inv_n,
                                            const double *sA, const double *sV, double *tabw,
@@ -353,14 +358,20 @@ __device__ __forceinline__ void small_quad(int S, double tb, const double *__res
 #pragma unroll
       for (int J = SYM ? I : 0; J < TS; ++J) {
         const int row = 4 * I + q, col = 4 * J + r;
-        const bool valid = (row < S) && (col < S);
         double pt = g[I][J] + tsplit * sA[min(row, 31) * QLS + min(col, 31)] + (row == col ? isplit : 0.0);
-        pt = valid ? pt : 1.0;
-        const double c = cv[I][J];
-        const bool nz = c != 0.0;
+        const double c = cv[I][J];   // (0 on padded slots: pack_counts_quad)
+        // a zero count (a padded slot, an unobserved pair -- where rounding may leave Pt <= 0) contributes 0 * log 1 and 0 / 1
+        const bool use = c != 0.0;
+        pt = use ? pt : 1.0;
         // (SYM: an off-diagonal tile stands for its mirror image too)
-        lossacc = fma((SYM && J > I) ? -2.0 * c : -c, LOGT ? fast_log_table(nz ? pt : 1.0, ltab) : fast_log(nz ? pt : 1.0), lossacc);
-        g[I][J] = nz ? -c * inv_n * fast_rcp(pt) : 0.0;
+        if (LOGT) {
+          // (anything but a positive finite argument: NaN -- the loss must never look finite then)
+          const double lg = is_pos_finite_nonzero(pt) ? fast_log_table_unchecked(pt, ltab) : NAN;
+          lossacc = fma((SYM && J > I) ? -2.0 * c : -c, lg, lossacc);
+        } else {
+          lossacc = fma((SYM && J > I) ? -2.0 * c : -c, fast_log(pt), lossacc);
+        }
+        g[I][J] = -c * inv_n * fast_rcp(pt);
       }
       // pin the loss here: otherwise the compiler sinks all TS^2 logarithms (they feed nothing but
       // lossacc) to the end of the quad and keeps TS^2 Pt values alive across the T and W phases
@@ -419,8 +430,9 @@ __device__ __forceinline__ void small_quad(int S, double tb, const double *__res
       const double ER = tab[32 + ra], HR = tab[64 + ra];
       const double dl = sLam[ra] - LC;
       const double z = 0.5 * tb * dl;
-      const bool near = fabs(z) < 0.5;
-      const double taylor = tb * HR * HC * sinhc_small(near ? z : 0.0);
+      // Taylor form below |z| = 1/16 only: above, (e^a - e^b) / (a - b) loses log2(1 / (1 - e^-2|z|)) <= 3.1 bits
+      const bool near = fabs(z) < 0.0625;
+      const double taylor = tb * HR * HC * sinhc_tiny(near ? z : 0.0);
       const double quot = (ER - EC) * fast_rcp(near ? 1.0 : dl);
       double m = acc[At] * (near ? taylor : quot);
       if (LANEM) {
