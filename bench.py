@@ -585,6 +585,7 @@ def main():
             bank.close()   # every rank releases its handle (and its RCCL communicator)
             return None
         traffic = _pmc_traffic()
+        bank_form = (bank.bank if hasattr(bank, "bank") else bank).last_bank_form() if S > 32 else None
         if S > 32:
             # dominant MFMA kernels: K1/K2/K3 are one batched 2 S^3 B GEMM each
             flops = 2.0 * S ** 3 * B_local
@@ -596,13 +597,17 @@ def main():
             epoch_flops = 6.0 * (B_local if shard_of else wl.get("live", wl["C"].shape[0])) * S ** 3 + 13.0 * S ** 3
             epoch_tflops = epoch_flops / (dt / steps) / 1e12
             util, util_src = _mfma_util(bank_dtype)
-            fused = tm["k1"] > 0 and tm["k2"] == 0 and tm["k3"] == 0   # CB_T_K1 = the one span of the fused launch
+            fused = bank_form["fused"]   # CB_T_K1 = the one span of the fused launch
+            # symmetric counts (every bench bank): the buckets are summed BEFORE the last product -- no third product per
+            # bucket ("bucket sum first"): the launch then holds K1 and K2 only
+            sum_first = bank_form["bucket_sum_first"]
+            n_prod = 2.0 if sum_first else 3.0
             if fused:
-                # K1 -> K2 -> K3 as ONE persistent launch (k123_bank): algorithmic flops = the three products, 6 B S^3
-                # (SURVEY 8d); executed = (tri + 1 + tri) of 2 B S^3: Pt and, with symmetric counts, W are symmetric
-                sym3 = tri   # (bench banks have symmetric counts; an asymmetric bank runs all K3 tiles)
+                # K1 -> K2 (-> K3) as ONE persistent launch (k123_bank): algorithmic flops = its products, 2 B S^3 each
+                # (SURVEY 8d); executed = (tri + 1 [+ tri]) of 2 B S^3: Pt and, with symmetric counts, W are symmetric
+                sym3 = 0.0 if sum_first else tri
                 executed = flops * (tri + 1.0 + sym3)
-                achieved = 3.0 * flops / (tm["k1"] * 1e-3) / 1e12
+                achieved = n_prod * flops / (tm["k1"] * 1e-3) / 1e12
                 peak = F32_PEAK_TFLOPS if bank_dtype == "f32" else F64_PEAK_TFLOPS
                 kname = {"f64": "k123_bank<double, double>", "f32": "k123_bank<float, float>",
                          "mixed": "k123_bank<double, float>"}[bank_dtype]
@@ -617,14 +622,19 @@ def main():
                                 traffic=traffic.get("k123_bank" + ("_f32" if bank_dtype == "f32" else "_mixed" if bank_dtype == "mixed" else ""))
                                 if world == 1 else None,
                                 traffic_source=_traffic_source() if world == 1 else None,
-                                ms_per_launch=tm["k1"], flops_per_launch=3.0 * flops, executed_flops_per_launch=executed,
-                                note="ONE persistent launch for the three bank products (tickets per XCD, large_bank.hip.h); "
+                                ms_per_launch=tm["k1"], flops_per_launch=n_prod * flops, executed_flops_per_launch=executed,
+                                products_in_launch="K1, K2 (buckets summed before the last product: no K3)" if sum_first else "K1, K2, K3",
+                                note="ONE persistent launch for the bank products (tickets per XCD, large_bank.hip.h); "
                                      "ms_per_launch = HIP events from the end of the eigensolver to the end of the launch "
-                                     "(includes lg_tables, ~4 us).  achieved = algorithmic 6 S^3 B flops (SURVEY 8d) / launch "
-                                     f"time; executed = what the matrix pipe multiplies: {tri:.2f} of K1's and K3's tiles "
-                                     "(Pt and W symmetric) + all of K2's; executed_frac is the pipe's own utilisation",
+                                     "(includes lg_tables, ~4 us).  achieved = the algorithmic 2 S^3 B flops (SURVEY 8d) of each "
+                                     f"product IN the launch / launch time; executed = what the matrix pipe multiplies: {tri:.2f} "
+                                     "of K1's tiles (Pt symmetric) + all of K2's" + ("" if sum_first else f" + {tri:.2f} of K3's") +
+                                     "; executed_frac is the pipe's own utilisation.  epoch_frac prices the WHOLE epoch at "
+                                     "SURVEY's 6 B S^3 + 13 S^3 whatever is executed",
                                 mfma_util=util.get("k123"), mfma_util_source=util_src)
             else:
+                if sum_first:
+                    names.pop("k3")   # (CB_T_K3 is then the bucket sums + their 7 single products + the combination: no B-fold product)
                 dom = max(names, key=lambda k: tm[k])
                 achieved = flops / (tm[dom] * 1e-3) / 1e12 if tm[dom] > 0 else 0.0
                 # (mixed: the dominant kernel is then K1 in float64; K2 / K3 run on the f32 MFMA)
@@ -691,6 +701,7 @@ def main():
             "roofline": roofline,
             "epochs_per_s": steps / dt,   # the epoch's cost does not depend on the pair count
             "phase_ms": {k: round(v, 4) for k, v in tm.items()},
+            **({"bank_form": bank_form} if bank_form else {}),
             "final_loss": final_loss,
         }
         if resumed and prewarm_ms is not None:
@@ -780,7 +791,7 @@ def main():
         return
     out = run(args.workload, steps, warmup, world == 1 and not args.no_cpu_baseline and not args.shard_of, shard_of=args.shard_of)
     keep = ("value", "unit", "n_gpus", "scaling", "ms_per_step", "steps", "warmup", "dtype", "config", "roofline",
-            "cpu_baseline", "phase_ms", "shard_of", "amdahl", "eigh", "prewarm")
+            "cpu_baseline", "phase_ms", "shard_of", "amdahl", "eigh", "prewarm", "bank_form")
     if args.workload == "coevo400" and not args.no_secondary:
         # every rank takes part (the multi-rank runs end in collectives); rank 0 attaches the lines
         extra = {}

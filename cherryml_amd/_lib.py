@@ -10,6 +10,7 @@ CB_NORMALIZE = 2
 CB_TRAIN_RESUME = 16
 CB_NO_SYNC = 4
 CB_EXPM_ONLY = 8
+CB_PER_BUCKET_PRODUCTS = 32
 CB_F64, CB_F32, CB_MIXED = 0, 1, 2
 
 CB_EINVAL, CB_EHIP, CB_ENOMEM, CB_ENUMERIC, CB_EUNSUPPORTED = -1, -2, -3, -4, -5
@@ -41,6 +42,7 @@ SIGNATURES = {
     "cb_last_sweeps": (C.c_int, [_vp]),
     "cb_eigh_counters": (C.c_int, [_vp, _vp, C.c_int]),
     "cb_last_kernel_form": (C.c_int, [_vp]),
+    "cb_last_bank_form": (C.c_int, [_vp]),
     "cb_train_pande_reversible": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, C.c_double, C.c_int,
                                             C.c_int, _vp, _vp, _vp, _vp, C.c_int]),
     "cb_train_siterm": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_double, C.c_int, _vp, _vp]),

@@ -148,6 +148,9 @@ static int launch_small(cb_bank *h, const SmallArgs &a) {
 #ifndef CB_BANK_FUSED_MIN_B
 #define CB_BANK_FUSED_MIN_B 64   // live buckets from which K1 -> K2 -> K3 run as ONE persistent launch
 #endif
+#ifndef CB_BANK_SUM_FIRST_MIN_B
+#define CB_BANK_SUM_FIRST_MIN_B 24   // live buckets from which the buckets are summed before the last product (symmetric counts)
+#endif
 #ifndef CB_BANK_KG2_MAX_B
 #define CB_BANK_KG2_MAX_B 20     // live buckets below which the tiles run on eight waves (two K-groups)
 #endif
@@ -174,8 +177,35 @@ static int large_eval(cb_bank *h, bool normalize, double *lossd, double *out, bo
   const int tm = (LD + LG_TM - 1) / LG_TM, tn = (LD + LG_TN - 1) / LG_TN, tiles = tm * tn;
   const double inv_n = normalize ? 1.0 / (h->comm ? h->n_global[0] : h->n_host[0]) : 1.0;
   const int tiles_k1 = tn * (tn + 1) / 2;  // Pt is symmetric: upper-triangular tiles only
-  const int tiles_k3 = h->sym_counts ? tiles_k1 : tiles;
   static const int n_parts = getenv("CB_BANK_STREAMS") ? std::min(4, std::max(1, atoi(getenv("CB_BANK_STREAMS")))) : 1;
+  // Symmetric counts: the buckets are summed BEFORE the last product (large_bank.hip.h, ky_reduce_loss / kphi_combine: one
+  // streaming pass over T and 1 + CB_PHI_TERMS single products instead of a third product per bucket); CB_BANK_K3=1 keeps
+  // the per-bucket third product (test hook: the reference point of the accuracy test).  Other banks: K3 on all tiles.
+  // float64 banks only (with T_b in float32 the difference Le - Le^T amplifies its 1e-7 to 7e-3 in dL/dQ on the demo bank), and
+  // from CB_BANK_SUM_FIRST_MIN_B live buckets on: the tail -- one pass over T, seven single products, the combination: ~45 us --
+  // is dearer than the third product of a short bank (17 buckets: 0.160 against 0.153 ms); CB_BANK_K3=0 forces it on.
+  const char *k3_hook = cb_test_hook("CB_BANK_K3");
+  const bool accum = h->sym_counts && !h->per_bucket_products && !Pd && dQd != nullptr && h->Yk && n_parts == 1 && h->dtype == CB_F64 &&
+                     (k3_hook ? atoi(k3_hook) == 0 : (B >= CB_BANK_SUM_FIRST_MIN_B && h->phi_delta >= 4e-3));
+  // (phi_delta = 0.2 / max t: a grid that reaches branch lengths beyond 50 -- the reference's ends at 13.7 -- would push the
+  // quotient (Le_ij - Le_ji) / dlam down to eigenvalue distances where its cancellation costs more than six digits)
+  const int tiles_k3 = accum ? 0 : h->sym_counts ? tiles_k1 : tiles;
+  // M from the bucket sums: Y_k = sum_b T_b diag(c_bk) (+ the loss), Lt_k = Y_k^T U (one launch), M = combine(Lt, lam)
+  auto accumulated_tail = [&](bool narrow, hipEvent_t stop) {
+    const LossArgs la{h->loss_part, B * tiles_k1, S, h->dsq, h->dirsum, inv_n, lossd, skipw};
+    const dim3 red_grid((unsigned)((LL + 255) / 256) + 1);   // (+ the workgroup that sums the loss partials)
+    const YArgs ya{LD, B, tb, h->E, h->Yk};
+    if (narrow) hipLaunchKernelGGL(ky_reduce_loss<float>, red_grid, dim3(256), 0, h->stream, h->T32, ya, la);
+    else hipLaunchKernelGGL(ky_reduce_loss<double>, red_grid, dim3(256), 0, h->stream, h->T, ya, la);
+    K4Args gl{S, LD, h->Yk, h->U, h->Lk, nullptr, nullptr, nullptr};
+    gl.skip = skipw;
+    gl.ystride = LL;
+    launch_sg(h, gl, 0, 0.0, 0.0, nullptr, nullptr, 1 + CB_PHI_TERMS);
+    double delta = h->phi_delta;
+    if (const char *z = cb_test_hook("CB_PHI_Z")) delta *= atof(z) / 0.1;   // (experiment: the series' range |z| <= CB_PHI_Z)
+    LAUNCH_STOP(stop, kphi_combine<CB_PHI_TERMS>, dim3((unsigned)((LL + 255) / 256)), dim3(256), 0, h->stream, LD, h->Lk, h->lam, delta,
+                h->Mt, skipw);
+  };
   // K1 -> K2 -> K3 as ONE persistent launch (k123_bank, large_bank.hip.h) whenever the gradient is wanted; CB_BANK_UNFUSED=1
   // keeps the three launches (per-kernel profiles, and the reference point of tests/test_gpu_s400_full.py)
   // (test hooks, read per call: the tests switch them inside one process)
@@ -199,6 +229,7 @@ static int large_eval(cb_bank *h, bool normalize, double *lossd, double *out, bo
   if (const char *k = cb_test_hook("CB_BANK_KG")) kg = atoi(k) == 1 ? 1 : 2;
   if (Pd) kg = 1;
   h->bank_kg = kg;
+  h->bank_accum = accum;
   // (queues and argument block: allocated with the handle, create_host.hip.h)
   h->bank_fused = fused;
   const dim3 tables_grid((unsigned)(((size_t)B * LD + 255) / 256));
@@ -260,7 +291,9 @@ static int large_eval(cb_bank *h, bool normalize, double *lossd, double *out, bo
     }
     const LossArgs la{h->loss_part, B * tiles_k1, S, h->dsq, h->dirsum, inv_n, lossd, skipw};
     const dim3 red_grid((unsigned)((LL + 255) / 256) + 1);   // (+ the workgroup that sums the loss partials)
-    if (f32 || mixed)
+    if (accum)
+      accumulated_tail(f32 || mixed, nullptr);
+    else if (f32 || mixed)
       hipLaunchKernelGGL(k3_reduce_loss<float>, red_grid, dim3(256), 0, h->stream, h->Gt32, B, LL, h->Mt, h->sym_counts ? LD : 0, la);
     else
       hipLaunchKernelGGL(k3_reduce_loss<double>, red_grid, dim3(256), 0, h->stream, h->Gt, B, LL, h->Mt, h->sym_counts ? LD : 0, la);
@@ -365,15 +398,23 @@ static int large_eval(cb_bank *h, bool normalize, double *lossd, double *out, bo
   if (f32 || mixed) {
     K2Args<float> k2{LD, h->Gt32, h->Uf, h->T32, skipw};
     LAUNCH_KG(stop_event(h, EV_K2), (k2_t_eq_g_u<float, 1>), (k2_t_eq_g_u<float, 2>), dim3(tiles * B), k2);
-    K3Args<float> k3{LD, B, h->T32, h->Uf, tb, h->lam, h->E, h->H, h->Gt32, h->sym_counts ? 1 : 0, skipw};
-    LAUNCH_KG(stop_event(h, EV_K3), (k3_w_phi<float, 1>), (k3_w_phi<float, 2>), dim3(tiles_k3 * B), k3);
-    hipLaunchKernelGGL(k3_reduce_loss<float>, red_grid, dim3(256), 0, h->stream, h->Gt32, B, LL, h->Mt, h->sym_counts ? LD : 0, la);
+    if (accum) {
+      accumulated_tail(true, stop_event(h, EV_K3));   // (CB_T_K3: the bucket sums, their products and the combination)
+    } else {
+      K3Args<float> k3{LD, B, h->T32, h->Uf, tb, h->lam, h->E, h->H, h->Gt32, h->sym_counts ? 1 : 0, skipw};
+      LAUNCH_KG(stop_event(h, EV_K3), (k3_w_phi<float, 1>), (k3_w_phi<float, 2>), dim3(tiles_k3 * B), k3);
+      hipLaunchKernelGGL(k3_reduce_loss<float>, red_grid, dim3(256), 0, h->stream, h->Gt32, B, LL, h->Mt, h->sym_counts ? LD : 0, la);
+    }
   } else {
     K2Args<double> k2{LD, h->Gt, h->U, h->T, skipw};
     LAUNCH_KG(stop_event(h, EV_K2), (k2_t_eq_g_u<double, 1>), (k2_t_eq_g_u<double, 2>), dim3(tiles * B), k2);
-    K3Args<double> k3{LD, B, h->T, h->U, tb, h->lam, h->E, h->H, h->Gt, h->sym_counts ? 1 : 0, skipw};
-    LAUNCH_KG(stop_event(h, EV_K3), (k3_w_phi<double, 1>), (k3_w_phi<double, 2>), dim3(tiles_k3 * B), k3);
-    hipLaunchKernelGGL(k3_reduce_loss<double>, red_grid, dim3(256), 0, h->stream, h->Gt, B, LL, h->Mt, h->sym_counts ? LD : 0, la);
+    if (accum) {
+      accumulated_tail(false, stop_event(h, EV_K3));
+    } else {
+      K3Args<double> k3{LD, B, h->T, h->U, tb, h->lam, h->E, h->H, h->Gt, h->sym_counts ? 1 : 0, skipw};
+      LAUNCH_KG(stop_event(h, EV_K3), (k3_w_phi<double, 1>), (k3_w_phi<double, 2>), dim3(tiles_k3 * B), k3);
+      hipLaunchKernelGGL(k3_reduce_loss<double>, red_grid, dim3(256), 0, h->stream, h->Gt, B, LL, h->Mt, h->sym_counts ? LD : 0, la);
+    }
   }
   {
     K4Args k4a{S, LD, h->Mt, h->Vc, h->X, nullptr, nullptr, nullptr};
@@ -659,6 +700,9 @@ extern "C" int cb_eigh_counters(cb_handle h, int *counts, int n) {
   return CB_OK;
 }
 extern "C" int cb_last_kernel_form(cb_handle h) { return h ? h->last_form : 0; }
+extern "C" int cb_last_bank_form(cb_handle h) {
+  return h ? (h->bank_fused ? 1 : 0) | (h->bank_kg == 2 ? 2 : 0) | (h->bank_accum ? 4 : 0) : 0;
+}
 
 extern "C" int cb_last_timings(cb_handle h, double *ms, int n) {
   if (!h || !ms) return fail(CB_EINVAL, "cb_last_timings: NULL argument");

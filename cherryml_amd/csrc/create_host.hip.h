@@ -154,6 +154,7 @@ extern "C" int cb_create(int device, int S, int L, int B, int dtype, const doubl
   h->large = S > 32 || narrow;
   h->dtype = expm_only ? CB_F64 : dtype;   // a counts-free handle has no bank products to narrow
   h->expm_only = expm_only;
+  h->per_bucket_products = (flags & CB_PER_BUCKET_PRODUCTS) != 0;
   h->LD = (S + 15) / 16 * 16;
   auto cleanup = [&](int rc) {
     cb_destroy(h);
@@ -244,6 +245,11 @@ extern "C" int cb_create(int device, int S, int L, int B, int dtype, const doubl
         }
     }
     h->t_live_host = tl;
+    {   // kphi_combine (large_bank.hip.h): |t dlam / 2| <= 0.1 for every bucket
+      double tmax = 0.0;
+      for (double v : tl) tmax = std::max(tmax, v);
+      h->phi_delta = tmax > 0.0 ? 0.2 / tmax : 0.0;
+    }
     if ((rc = dev_alloc(h, &src_idx, nl)) != CB_OK || (rc = dev_alloc(h, &h->t_live, nl)) != CB_OK) {
       free_tmp();
       return cleanup(rc);
@@ -320,7 +326,9 @@ extern "C" int cb_create(int device, int S, int L, int B, int dtype, const doubl
               dev_alloc(h, &h->Gt, per_bucket) == CB_OK &&
               dev_alloc(h, &h->T, per_bucket) == CB_OK &&
               dev_alloc(h, &h->Mt, LL) == CB_OK && dev_alloc(h, &h->X, LL) == CB_OK &&
-              dev_alloc(h, &h->loss_part, (size_t)B * tiles) == CB_OK;
+              dev_alloc(h, &h->loss_part, (size_t)B * tiles) == CB_OK &&
+              dev_alloc(h, &h->Yk, expm_only ? 0 : (1 + CB_PHI_TERMS) * LL) == CB_OK &&
+              dev_alloc(h, &h->Lk, expm_only ? 0 : (1 + CB_PHI_TERMS) * LL) == CB_OK;
     if (!ok) {
       free_tmp();
       return cleanup(CB_ENOMEM);

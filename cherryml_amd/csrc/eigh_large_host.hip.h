@@ -7,14 +7,15 @@
 
 // --------------------------------------------------------------- large path
 // `second`: an independent product of the same kind (ns, alpha, beta) enqueued in the same launch (grid.y = 2)
+// g.ystride != 0: `ny` products from the one argument block (large_bank.hip.h, K4Args::ystride)
 static void launch_sg(cb_bank *h, const K4Args &g, int ns, double alpha = 0.0, double beta = 0.0,
-                      const K4Args *second = nullptr, hipEvent_t stop = nullptr) {   // stop: handle_host.hip.h, stop_event()
+                      const K4Args *second = nullptr, hipEvent_t stop = nullptr, int ny = 1) {   // stop: handle_host.hip.h, stop_event()
   // ONE 16 x 16 tile per workgroup, K split over its 8 waves, 7 k-steps in flight.  Shapes measured in situ in round 2
   // (200 epochs of the bench bank, eigh ms per epoch): 16 x 80 strips with 8 waves x 4 k-steps 0.343; 16 x 48 strips
   // 0.320; 16 x 32 0.332; this one 0.300; the same with 16 waves 0.324, with 4 waves 0.310.  These launches are latency
   // chains (launch floor 2.6 us + load -> MFMA -> LDS reduce), not bandwidth: the 16 x 16 shape reads 64 MB from L2 per
   // product against 38 MB for the strips and is still the fastest.  (The other shapes were removed with their switch.)
-  const dim3 n1((unsigned)((h->LD / 16) * ((h->LD + 15) / 16)), second ? 2 : 1);
+  const dim3 n1((unsigned)((h->LD / 16) * ((h->LD + 15) / 16)), g.ystride ? (unsigned)ny : (second ? 2u : 1u));
   const K4Args &g2 = second ? *second : g;
   LAUNCH_STOP(stop, (sg_gemm<8, 7, 1>), n1, dim3(512), 0, h->stream, g, g2, ns, alpha, beta);
 }

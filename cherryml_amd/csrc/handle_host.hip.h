@@ -59,6 +59,7 @@ struct cb_bank {
   double *inv_n_global = nullptr;  // [L] 1 / n_total
   std::vector<double> n_global;
   bool expm_only = false;   // created with CB_EXPM_ONLY: no counts, no loss / training entry points
+  bool per_bucket_products = false;   // created with CB_PER_BUCKET_PRODUCTS: never sum the buckets before the last product
   bool sym_counts = false;  // every live bucket has C_b == C_b^T (cherry counts are, by construction)
   int spec_sweeps = 0;  // Jacobi sweeps to enqueue before the first host check (learned from the previous solve)
   double *A = nullptr, *dsq = nullptr, *Gc = nullptr, *Vc = nullptr, *U = nullptr, *lam = nullptr,
@@ -81,12 +82,16 @@ struct cb_bank {
   EighPlan eplan;            // the next solve's plan: part of the optimisation's state (a resumed call continues with it,
                              // so W + K epochs in two calls equal one call bit for bit)
   int k3_chunk = 0, k3_nchunks = 0;
+  double *Yk = nullptr, *Lk = nullptr;   // the bucket sum without the third product (large_bank.hip.h, ky_reduce_loss):
+                                         // [1 + CB_PHI_TERMS][LD][LD] each
+  double phi_delta = 0.0;                // eigenvalue distance below which kphi_combine takes the series: 0.2 / max t
   unsigned int *bank_queue = nullptr;   // fused bank kernel (k123_bank): ticket queues + tile counters, 8 + 2 B words
   unsigned char *bank_args = nullptr;   // ... and its argument block (written by lg_tables in front of every launch)
   int bank_slots = 0;                   // its grid: resident workgroups of the device (4 per CU)
   int bank_claims = 0;                  // reserved first tickets per queue
   bool bank_fused = false;              // the last evaluation ran K1 -> K2 -> K3 as one launch
   int bank_kg = 1;                      // ... with four-wave (1) or eight-wave (2) tiles
+  bool bank_accum = false;              // ... and summed the buckets before the last product (no K3)
   int last_sweeps = 0;
   double *gn_scratch = nullptr, *gn_partial = nullptr;  // general path, allocated on first use
   int gn_nw = 0;

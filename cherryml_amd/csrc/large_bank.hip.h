@@ -1047,6 +1047,103 @@ __global__ __launch_bounds__(256) void k3_reduce_loss(const T *part, int nchunks
   else k3_reduce_body<T>(part, nchunks, n, out, LD);
 }
 
+// ------------------------------------------------------------------ the bucket sum WITHOUT the third product (round 5)
+// M = sum_b W_b o Phi_b with W_b = U^T G~_b U needs one S^3 product per bucket (K3) only because Phi_b sits between the
+// product and the sum.  But Phi_b,ij = (E_bi - E_bj) / (lam_i - lam_j), E_b = exp(t_b lam), is a difference of ONE-SIDED
+// scalings, and for symmetric counts (G~_b = G~_b^T, so U^T G~_b = T_b^T with T_b = G~_b U, K2's output):
+//     sum_b diag(E_b) W_b = [sum_b diag(E_b) T_b^T] U = Y^T U =: Le,      Y = sum_b T_b diag(E_b)      (no product per bucket)
+//     M_ij = (Le_ij - Le_ji) / (lam_i - lam_j)
+// i.e. the buckets are summed BEFORE the product: one streaming pass over T (ky_reduce_loss, the successor of k3_reduce_loss)
+// and ONE S^3 product instead of B.  The difference Le - Le^T cancels for close eigenvalues (error ~ eps / (t |dlam|)), so
+// pairs with |lam_i - lam_j| < delta take the series of the same function in (dlam)^2, whose terms are one-sided as well:
+//     Phi_ij = t e^{t (lam_i + lam_j) / 2} sinhc(z) = t (E_i + E_j) / 2 * tanh(z) / z,   z = t dlam / 2
+//     tanh(z) / z = sum_k a_k z^2k      =>      M_ij = sum_k a_k (dlam^2 / 4)^k (Lt_k,ij + Lt_k,ji) / 2,
+//     Lt_k = sum_b diag(t_b^{2k+1} E_b) W_b = Y_k^T U,   Y_k = sum_b T_b diag(t_b^{2k+1} E_b)
+// (the diagonal is the k = 0 term).  delta = 0.2 / max_b t_b keeps |z| <= 0.1 for every bucket: CB_PHI_TERMS = 6 terms leave
+// 4e-15.  Measured against an 80-bit evaluation on the bench bank (profiles/tools/accumulated_phi_model.py): dL/dA within
+// 6e-14 .. 3e-12 (the per-bucket form: 3e-16; the parity bar is 1e-10).  MFMA tiles per bucket: 40 (K1 15 + K2 25) instead
+// of 55.  Symmetric counts only (cherry counts are, by construction); other banks keep K3.
+#define CB_PHI_TERMS 6
+struct YArgs {
+  int LD, B;
+  const double *t;     // [B]
+  const double *E;     // [B][LD] exp(t lam)
+  double *Y;           // [1 + CB_PHI_TERMS][LD][LD]: Y (scaling E_b), then Y_k (scaling t_b^{2k+1} E_b)
+};
+template <typename T>
+__global__ __launch_bounds__(256) void ky_reduce_loss(const T *__restrict__ Tm, YArgs y, LossArgs l) {
+  if (l.skip && *l.skip != 0ull) return;
+  if (blockIdx.x + 1 == gridDim.x) {   // the last workgroup sums the loss partials (as k3_reduce_loss)
+    lg_finish_loss_body(l.part, l.nparts, l.S, l.dsq, l.dirsum, l.inv_n, l.loss);
+    return;
+  }
+  const size_t LL = (size_t)y.LD * y.LD, i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= LL) return;
+  const int col = (int)(i % y.LD);
+  double acc[1 + CB_PHI_TERMS];
+#pragma unroll
+  for (int k = 0; k <= CB_PHI_TERMS; ++k) acc[k] = 0.0;
+  // buckets in their stored order, four in flight: the sums do not depend on the launch geometry
+  int b = 0;
+  for (; b + 3 < y.B; b += 4) {
+    double v[4], e[4], tb[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      v[u] = (double)Tm[(size_t)(b + u) * LL + i];
+      e[u] = y.E[(size_t)(b + u) * y.LD + col];
+      tb[u] = y.t[b + u];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const double ve = v[u] * e[u], t2 = tb[u] * tb[u];
+      acc[0] += ve;
+      double c = ve * tb[u];
+#pragma unroll
+      for (int k = 1; k <= CB_PHI_TERMS; ++k) {
+        acc[k] += c;
+        c *= t2;
+      }
+    }
+  }
+  for (; b < y.B; ++b) {
+    const double ve = (double)Tm[(size_t)b * LL + i] * y.E[(size_t)b * y.LD + col], tb = y.t[b], t2 = tb * tb;
+    acc[0] += ve;
+    double c = ve * tb;
+#pragma unroll
+    for (int k = 1; k <= CB_PHI_TERMS; ++k) {
+      acc[k] += c;
+      c *= t2;
+    }
+  }
+#pragma unroll
+  for (int k = 0; k <= CB_PHI_TERMS; ++k) y.Y[(size_t)k * LL + i] = acc[k];
+}
+
+// M from Le = L[0] and Lt_k = L[1 + k] (each [LD][LD]); see above.  M is symmetric: written whole (K4a reads it as M^T).
+template <int NT = CB_PHI_TERMS>   // (a template: the header is included by two translation units)
+__global__ __launch_bounds__(256) void kphi_combine(int LD, const double *__restrict__ L, const double *__restrict__ lam,
+                                                    double delta, double *__restrict__ Mt, const unsigned long long *skip) {
+  if (skip && *skip != 0ull) return;
+  const size_t LL = (size_t)LD * LD, idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= LL) return;
+  const int i = (int)(idx / LD), j = (int)(idx - (size_t)i * LD);
+  const size_t tr = (size_t)j * LD + i;
+  const double dl = lam[i] - lam[j];
+  double m;
+  if (fabs(dl) < delta) {
+    // tanh(z) / z = 1 - z^2/3 + 2 z^4/15 - 17 z^6/315 + 62 z^8/2835 - 1382 z^10/155925
+    static_assert(NT == 6, "six series coefficients below");
+    const double ak[NT] = {1.0, -1.0 / 3.0, 2.0 / 15.0, -17.0 / 315.0, 62.0 / 2835.0, -1382.0 / 155925.0};
+    const double w = 0.25 * dl * dl;
+    m = 0.0;
+#pragma unroll
+    for (int k = NT - 1; k >= 0; --k) m = fma(m, w, ak[k] * 0.5 * (L[(size_t)(1 + k) * LL + idx] + L[(size_t)(1 + k) * LL + tr]));
+  } else {
+    m = (L[idx] - L[tr]) / dl;
+  }
+  Mt[idx] = m;
+}
+
 // ------------------------------------------------------------------ K4 (plain / dQ epilogue)
 struct K4Args {
   int S, LD;
@@ -1063,6 +1160,8 @@ struct K4Args {
   const unsigned long long *sel = nullptr;
   const double *Aalt = nullptr, *Balt = nullptr;
   const unsigned long long *skip = nullptr;   // as K1Args::skip (K4 behind a bank launch that returned at once)
+  size_t ystride = 0;       // sg_gemm only, != 0: gridDim.y independent products of the same kind from ONE argument block --
+                            // product y reads Aop + y * ystride and writes out + y * ystride (the Lt_k = Y_k^T U of the bucket sum)
 };
 
 // Single-matrix products (K4a, K4b, the warm-start G0 = A' U_prev, the first-order eigen
@@ -1083,7 +1182,7 @@ struct K4Args {
 template <int NW, int UU, int NJ = 5>
 __global__ __launch_bounds__(NW * 64) void sg_gemm(K4Args a1, K4Args a2, int ns, double alpha, double beta) {
   __shared__ double sRed[NW / 2 > 4 ? NW / 2 : 4][NJ][256];
-  const K4Args &a = blockIdx.y ? a2 : a1;
+  const K4Args &a = (blockIdx.y && a1.ystride == 0) ? a2 : a1;
   if (a.skip && *a.skip != 0ull) return;
   const int LD = a.LD, tilesN = (LD + 16 * NJ - 1) / (16 * NJ);
   const int tm = blockIdx.x / tilesN, tn = blockIdx.x - tm * tilesN;
@@ -1099,7 +1198,7 @@ __global__ __launch_bounds__(NW * 64) void sg_gemm(K4Args a1, K4Args a2, int ns,
   const bool alt = a.sel && *a.sel != 0ull;
   // (Gram-type products -- G^T G, X^T X, P2^T P2 -- are symmetric; computing only the tiles on or above the
   // diagonal and mirroring them was measured: no gain, eigh 0.300 -> 0.310 ms; the launches are latency chains.)
-  const double *Ap = (alt && a.Aalt ? a.Aalt : a.Aop) + m0 + lo, *Bp = alt && a.Balt ? a.Balt : a.Bop;
+  const double *Ap = (alt && a.Aalt ? a.Aalt : a.Aop) + m0 + lo + (size_t)blockIdx.y * a.ystride, *Bp = alt && a.Balt ? a.Balt : a.Bop;
   for (int s0 = wave; s0 < nsteps; s0 += UU * NW) {   // UU k-steps of this wave in flight
     double av[UU], bv[UU][NJ];
 #pragma unroll
@@ -1153,7 +1252,7 @@ __global__ __launch_bounds__(NW * 64) void sg_gemm(K4Args a1, K4Args a2, int ns,
     if (a.dsq) {
       if (row < a.S && col < a.S) a.out[(size_t)row * a.S + col] = a.dsq[row] * v / a.dsq[col];
     } else {
-      const size_t idx = (size_t)row * LD + col;
+      const size_t idx = (size_t)row * LD + col + (size_t)blockIdx.y * a.ystride;
       double o;
       if (ns == 1) o = (row == col ? 1.0 : 0.0) + a.sub[idx] - 0.5 * v;
       else if (ns == 2) o = fma(alpha, v, beta * a.sub[idx]);

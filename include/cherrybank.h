@@ -50,8 +50,15 @@ enum {
                         (trainer.py:176-177 `loss_normalization`)     */
   CB_NO_SYNC = 4,    /* with CB_PTR_DEVICE: enqueue only, do not wait  */
   CB_EXPM_ONLY = 8,  /* cb_create: no counts (C may be NULL); the handle serves cb_expm_bank / cb_eigh only */
-  CB_TRAIN_RESUME = 16 /* cb_train_pande_reversible, S > 32: continue the optimisation the previous call on this
-                        * handle ended (see there) */
+  CB_TRAIN_RESUME = 16, /* cb_train_pande_reversible, S > 32: continue the optimisation the previous call on this
+                         * handle ended (see there) */
+  CB_PER_BUCKET_PRODUCTS = 32 /* cb_create, S > 32: always form W_b = U^T G_b U bucket by bucket.  By default a float64 bank
+                        * with symmetric counts and >= 24 live buckets sums the buckets BEFORE the last product (one pass over
+                        * T_b = G_b U and seven single products instead of a third S^3 product per bucket: 10 % off the
+                        * 129-bucket epoch); its dL/dQ is then accurate to 1e-13 .. 1e-11 of its norm instead of 3e-16
+                        * (differences of one-sided sums cancel for close eigenvalues), which Adam's per-parameter scaling
+                        * turns into trajectories 1e-11 .. 1e-10 from the per-bucket ones after 50 epochs -- four orders inside the
+                        * 1e-6 bar on the learned matrix.  csrc/large_bank.hip.h (ky_reduce_loss), DESIGN.md section 2. */
 };
 
 /* ABI version of the loaded library (bumped on incompatible change). */
@@ -177,6 +184,11 @@ int cb_eigh_counters(cb_handle h, int *counts, int n);
  * symmetric-count form, w3 = three workgroups per CU); 2000 = lg_prepare / lg_bank / lg_finish (one bank, 24 < S <= 32);
  * 3000 = the one-kernel trainer; 4000 = the C-driven S > 32 loop; 0 = none yet. */
 int cb_last_kernel_form(cb_handle h);
+/* How the last S > 32 evaluation on this handle ran its three bank products (chosen from the bank's shape, csrc/cherrybank.hip,
+ * large_eval): bit 0 = K1 -> K2 (-> K3) as ONE persistent launch (k123_bank; else separate launches), bit 1 = eight-wave tiles
+ * (two K-groups; else four waves per tile), bit 2 = the buckets were summed BEFORE the last product (symmetric counts: no
+ * third product per bucket, csrc/large_bank.hip.h ky_reduce_loss / kphi_combine).  0 before the first evaluation. */
+int cb_last_bank_form(cb_handle h);
 
 /*
  * Fused optimiser for the reference's `pande_reversible` parameterisation

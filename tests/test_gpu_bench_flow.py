@@ -113,6 +113,9 @@ def test_resident_chain_two_ranks_equal_one_rank(tmp_path):
     script.write_text(_RESIDENT_WORKER)
     base = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
     base.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29577")
+    # one rank holds all live buckets, each of two ranks half of them: large_eval would sum the buckets before the last product
+    # on the one (>= 24 buckets) and not on the two.  The comparison is about the sharding, so both keep the per-bucket form.
+    base.update(CB_TEST_HOOKS="1", CB_BANK_K3="1")
     subprocess.run([sys.executable, str(script), ROOT, str(spec), str(tmp_path / "one")], env=dict(base, RANK="0", WORLD_SIZE="1"),
                    check=True, timeout=600)
     procs = [subprocess.Popen([sys.executable, str(script), ROOT, str(spec), str(tmp_path / "two")],

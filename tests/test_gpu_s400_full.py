@@ -466,6 +466,64 @@ def test_fused_bank_launch_on_small_and_ragged_banks(S, B, sym, dtype, kg, monke
     assert relerr(da[0], Qt.grad.numpy()) < 1e-10
 
 
+def _product_model_bank(S1, B, seed):
+    """Q (x) I + I (x) Q on S1^2 states: every eigenvalue lam_a + lam_b with a != b is EXACTLY degenerate (a, b) / (b, a)"""
+    t, _, Q1, pi1 = _random_bank(S1, B, seed)
+    I = np.eye(S1)
+    Q = np.kron(Q1, I) + np.kron(I, Q1)
+    pi = np.kron(pi1, pi1)
+    d = np.sqrt(pi)
+    w, V = np.linalg.eigh(d[:, None] * Q / d[None, :])
+    C = np.stack([pi[:, None] * ((V * np.exp(tb * w)) @ V.T) * d[None, :] / d[:, None] for tb in t]) * 1e5
+    return t, 0.5 * (C + C.transpose(0, 2, 1)), Q, pi
+
+
+@pytest.mark.parametrize("case", ["bench", "demo", "ragged", "product", "long_branches"])
+def test_bucket_sum_before_the_last_product_matches_the_per_bucket_third_product(case, dense, monkeypatch):  # noqa: C901
+    """Symmetric counts (round 5): M = sum_b (U^T G_b U) o Phi_b is evaluated as differences / series of the ONE-SIDED sums
+    sum_b diag(c_b) U^T G_b U = (sum_b T_b diag(c_b))^T U -- the buckets are summed before the product, K3 disappears
+    (csrc/large_bank.hip.h, ky_reduce_loss / kphi_combine).  Against the per-bucket third product (test hook CB_BANK_K3=1):
+    the loss is the same number (K1 is untouched) and dL/dQ agrees to 1e-11 (the reference's real bank: 5e-11 -- its G~_b
+    hold entries of 1e9 where a counted double substitution meets P ~ 1e-11, and the difference Le - Le^T cancels three digits
+    more than on the synthetic banks; the bar against the reference itself is 1e-10, where the per-bucket form measured
+    2.9e-11) -- on the bench bank, the reference's real bank,
+    a small ragged bank, a product model (exactly degenerate eigenvalue pairs: the series branch at dlam = 0) and a bank
+    with a branch length of 500 (delta = 0.2 / t_max = 4e-4: nearly every pair takes the quotient)."""
+    from cherryml_amd import CherryBank
+    if case == "bench":
+        import cherryml_amd
+        import torch
+        from cherryml_amd.estimation._jtt_ipw import jtt_ipw_from_arrays
+        t, C = dense["t"], dense["C"]
+        init = jtt_ipw_from_arrays(t, C, dense["mask"])
+        mod = cherryml_amd.RateMatrix(num_states=400, mode="pande_reversible", mask=torch.tensor(dense["mask"]),
+                                      pi=torch.ones(400, dtype=torch.float64) / 400, pi_requires_grad=True, initialization=init)
+        Q, pi = mod().detach().numpy(), mod.stationary().detach().numpy()
+    elif case == "demo":
+        z = load_golden("coevo_demo_full.npz")
+        t, C = _demo_bank(z)
+        Q, pi = _from_support(z["Q_support_f64"], _mask_of(z)), _pi_of(z["log_pi"])
+    elif case == "ragged":
+        t, C, Q, pi = _random_bank(100, 9, 77)
+    elif case == "product":
+        t, C, Q, pi = _product_model_bank(10, 12, 3)
+    else:
+        t, C, Q, pi = _random_bank(64, 7, 11)
+        t = t.copy()
+        t[-1] = 500.0
+    out = {}
+    for name, hook in (("summed", "0"), ("per_bucket", "1")):   # (forced both ways: by itself large_eval sums first from 24 buckets on)
+        monkeypatch.setenv("CB_BANK_K3", hook)
+        with CherryBank(t, C) as bank:
+            out[name] = bank.loss_grad(Q * 0.95, pi)
+            form = bank.last_bank_form()
+        assert form["bucket_sum_first"] == (hook == "0"), form
+    (la, da), (lb, db) = out["summed"], out["per_bucket"]
+    assert np.all(np.isfinite(da)) and la[0] == lb[0]
+    print(f"bucket sum first vs per-bucket third product ({case}): dL/dQ rel. Frobenius {relerr(da[0], db[0]):.2e}")
+    assert relerr(da[0], db[0]) < (5e-11 if case == "demo" else 1e-11), relerr(da[0], db[0])
+
+
 @pytest.mark.parametrize("dtype", ["f64", "mixed", "f32"])
 def test_reserved_tickets_nobody_claims_are_run_by_the_workgroups_that_wait_for_them(dense, dtype, monkeypatch):
     """The fused bank launch reserves the first K1 tickets of every queue for its workgroups (one uncontended claim instead of
