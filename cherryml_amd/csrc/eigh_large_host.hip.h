@@ -15,8 +15,15 @@ static void launch_sg(cb_bank *h, const K4Args &g, int ns, double alpha = 0.0, d
   // 0.320; 16 x 32 0.332; this one 0.300; the same with 16 waves 0.324, with 4 waves 0.310.  These launches are latency
   // chains (launch floor 2.6 us + load -> MFMA -> LDS reduce), not bandwidth: the 16 x 16 shape reads 64 MB from L2 per
   // product against 38 MB for the strips and is still the fastest.  (The other shapes were removed with their switch.)
-  const dim3 n1((unsigned)((h->LD / 16) * ((h->LD + 15) / 16)), g.ystride ? (unsigned)ny : (second ? 2u : 1u));
   const K4Args &g2 = second ? *second : g;
+  if (g.ystride) {
+    // `ny` products in one launch (the bucket sums' Lt_k = Y_k^T U): enough workgroups for 16 x 80 strips -- 125 per product,
+    // 10.5 us for the launch -- where the 16 x 16 shape would queue 4375 workgroups in four rounds (37 us at ny = 7)
+    const dim3 ns_grid((unsigned)((h->LD / 16) * ((h->LD + 79) / 80)), (unsigned)ny);
+    LAUNCH_STOP(stop, (sg_gemm<8, 4, 5>), ns_grid, dim3(512), 0, h->stream, g, g2, ns, alpha, beta);
+    return;
+  }
+  const dim3 n1((unsigned)((h->LD / 16) * ((h->LD + 15) / 16)), second ? 2u : 1u);
   LAUNCH_STOP(stop, (sg_gemm<8, 7, 1>), n1, dim3(512), 0, h->stream, g, g2, ns, alpha, beta);
 }
 
