@@ -694,7 +694,7 @@ def main():
                        **({"timed_epochs": f"{warmup} .. {warmup + steps - 1} of one optimisation from the JTT-IPW start "
                                            "(the warm-up epochs are its first ones; CB_TRAIN_RESUME)",
                            "prewarm": f"{PREWARM_EPOCHS} throw-away epochs of the same optimisation in front of the warm-up "
-                                      "(one-time host stalls of a fresh process: DESIGN.md section 11)"} if resumed else {}),
+                                      "(one-time host stalls of a fresh process: EXPERIMENTS.md section 11)"} if resumed else {}),
                        **({"arithmetic": "float32 operands + float32 MFMA accumulation in P_b, G_b U, (T_b^T U) o Phi_b; "
                                          "eigensolver, loss sums, divided differences, bucket sum, Adam in float64"}
                           if bank_dtype == "f32" else {})},
@@ -733,7 +733,7 @@ def main():
                         "sp_bank (one quad per wave over the chip: ~13 us); launch floor = a dependent empty kernel on this "
                         "box (profiles/tools/launch_probe2)"}
         if S > 32:
-            # the Amdahl arithmetic of sharding ONE bank over ranks (DESIGN section 5): the eigensolver and K4 run on the
+            # the Amdahl arithmetic of sharding ONE bank over ranks (DESIGN.md section 7): the eigensolver and K4 run on the
             # whole matrix on every rank, K1-K3 on the rank's buckets only; `other` = theta -> A, parameter kernels,
             # the all-reduce (N > 1) and launch gaps
             rep, shd = tm["eigh"] + tm["k4"], tm["k1"] + tm["k2"] + tm["k3"]

@@ -1,7 +1,7 @@
 // Host driver of the large-path eigensolver (S > 32): which kernels of jacobi_block.hip.h /
 // large_bank.hip.h run in which order -- tournament sweeps, hybrid sweeps (one first-order rotation of
 // the far pairs + banded Jacobi passes over the near ones), first-order sweeps, their statistics
-// through pinned host memory, the speculated powers of X.  DESIGN.md section 2 has the reasoning and the
+// through pinned host memory, the speculated powers of X.  EXPERIMENTS.md section 2 has the reasoning and the
 // measurements.  Included by cherrybank.hip after `struct cb_bank`, HIP_TRY, fail() and dev_alloc.
 #pragma once
 

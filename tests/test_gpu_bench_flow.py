@@ -2,7 +2,7 @@
 `data` field) lets two ranks share the device, which RCCL refuses.  Everything but the RCCL transport runs for real: the
 launcher starts two rank processes, the bank is sharded over them (family counts -> collective over the non-empty buckets ->
 per-epoch all-reduce of (loss, dL/dA)), the raw RCCL communicator cannot be made on a duplicated GPU and EVERY rank falls back
-to torch's collective together (the failure protocol of DESIGN section 5), the weak-scaling secondaries run with their
+to torch's collective together (the failure protocol of DESIGN.md section 7), the weak-scaling secondaries run with their
 collectives on device tensors, and rank 0's JSON line is relayed.  A real N > 1 run over RCCL / xGMI is the driver's."""
 import json
 import os
