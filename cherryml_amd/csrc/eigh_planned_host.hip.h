@@ -15,7 +15,13 @@ struct EighRecord {
   } sweep[EC_MAXREC];
 };
 
-static const int kPlannedBand = 2;   // blocks: pairs nearer than this are rotated exactly by the band passes
+#ifndef CB_PLANNED_BAND
+#define CB_PLANNED_BAND 2
+#endif
+#ifndef CB_LEAD_INNER
+#define CB_LEAD_INNER 2
+#endif
+static const int kPlannedBand = CB_PLANNED_BAND;   // blocks: pairs nearer than this are rotated exactly by the band passes
 
 static void eigh_plan_default(EighPlan &p, int extra = 0) {
   p = EighPlan{};
@@ -132,7 +138,7 @@ static int enqueue_planned_solve(cb_bank *h, const EighPlan &p, unsigned long lo
   auto band_pass = [&](double *G, const unsigned long long *must_nonzero) {
     for (int w = 0; w < 2; ++w)
       hipLaunchKernelGGL(lgj_round, dim3(nb / 2), dim3(JB_THREADS), lds, h->stream, LD, ((shift + w) & 1) && nb > 2 ? -2 : -1,
-                         must_nonzero ? 1 : 2, G,   // (inner sweeps: two in front of the first sweep, one behind a masked one)
+                         must_nonzero ? 1 : CB_LEAD_INNER, G,   // (inner sweeps: two in front of the first sweep, one behind a masked one)
                          jstate, ctl + EC_STALL, must_nonzero);
     for (int k = 2; k <= kPlannedBand && k < nb; ++k)
       for (int par = 0; par < 2; ++par)

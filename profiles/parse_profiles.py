@@ -25,7 +25,7 @@ def newest(pattern):
 
 
 tag = sys.argv[1] if len(sys.argv) > 1 else "final"
-rnd = sys.argv[2] if len(sys.argv) > 2 else "r04"
+rnd = sys.argv[2] if len(sys.argv) > 2 else "r05"
 here = os.path.dirname(os.path.abspath(__file__))
 root = os.path.dirname(here)
 import datetime
@@ -36,9 +36,9 @@ NAMES = ["k123_bank", "k1_pt_loss_gt", "k2_t_eq_g_u", "k3_w_phi", "lgj_round", "
          "lg_prepare", "lg_bank", "lg_finish", "count_transitions_lds_kernel", "count_reduce_slabs", "k3_reduce", "sp_prepare",
          "sp_bank", "sp_finish", "sp_step", "sg_gemm", "co_bucket_kernel", "co_plan_kernel", "co_expand_kernel", "co_count_lds_kernel", "lgx_build", "ble_branch_lengths_kernel", "ble_site_rates_kernel",
          "siterm_raw_counts_kernel", "siterm_mix_kernel", "tl_mfma_kernel", "tl_leaf_kernel", "tl_group_kernel", "lg_cast_f32", "lge_gram", "lge_gemm", "lge_so", "lge_decide", "lge_poly",
-         "jtt_stats_partial"]
-WORKLOADS = ["coevo400", "coevo400_mixed", "coevo400_f32", "coevo400_demo", "lg20", "siterm", "counting", "co_counting", "ble", "assembly",
-             "likelihood"]
+         "jtt_stats_partial", "ky_reduce_loss", "kphi_combine", "k3_reduce_loss"]
+WORKLOADS = ["coevo400", "coevo400_mixed", "coevo400_f32", "coevo400_demo", "coevo400_shard8", "lg20", "siterm", "counting", "co_counting",
+             "ble", "assembly", "likelihood"]
 
 
 def kshort(full):
@@ -78,7 +78,7 @@ for w in WORKLOADS:
                 vals[short][c + "_launches"] = len(v)
     for k, d in vals.items():
         if "FETCH_SIZE" in d and "WRITE_SIZE" in d:
-            key = k if w.startswith("coevo400") and w != "coevo400_demo" else f"{k}:{w}"
+            key = k if w in ("coevo400", "coevo400_mixed", "coevo400_f32") else f"{k}:{w}"
             b = (2.0 * d["FETCH_SIZE"] + d["WRITE_SIZE"]) * 1024.0
             out["detail"][key] = {"fetch_KB_raw": d["FETCH_SIZE"], "write_KB": d["WRITE_SIZE"], "bytes": b,
                                   "launches_seen": d["FETCH_SIZE_launches"], "workload": w}

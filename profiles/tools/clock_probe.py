@@ -72,6 +72,9 @@ def main():
             cyc = buf[kid, :n, 0].astype(np.float64)
             tick = buf[kid, :n, 1].astype(np.float64)
             ok = tick > 0
+            if not ok.any():   # (no tile of this stage ran: K3 is gone when the buckets are summed before the last product)
+                res[name] = {"workgroups_stamped": 0}
+                continue
             clk = cyc[ok] / tick[ok] * 0.1   # GHz
             res[name] = {
                 "workgroups_stamped": int(ok.sum()),

@@ -10,13 +10,16 @@ S = []
 for kid in range(3):
     s = b[kid]
     S.append(s[(s[:, 2] > 0) & (s[:, 4] > 0)])
-t0 = min(s[:, 2].min() for s in S)
+t0 = min(s[:, 2].min() for s in S if len(s))
 for kid, s in enumerate(S):
+    if not len(s):   # (K3 is gone when the buckets are summed before the last product)
+        print("K%d: no tiles" % (kid + 1))
+        continue
     st, ke, en = [(s[:, c] - t0) * 0.01 for c in (2, 3, 4)]
     print("K%d: %d tiles, first start %.1f, last start %.1f, last end %.1f us; K loop median %.1f us (clock %.2f GHz), epilogue "
           "median %.1f us" % (kid + 1, len(s), st.min(), st.max(), en.max(), np.median(ke - st),
                               np.median(s[:, 0] / np.maximum(s[:, 1], 1) * 0.1), np.median(en - ke)))
-tend = max(((s[:, 4] - t0) * 0.01).max() for s in S)
+tend = max(((s[:, 4] - t0) * 0.01).max() for s in S if len(s))
 print("   t us | tiles in flight | (in K loop, in epilogue) per stage")
 for t in np.arange(5, tend + step, step):
     row = []

@@ -131,6 +131,30 @@ def test_family_sharded_counts_reduce_scatter_two_ranks(tmp_path):
     assert relerr(r0["grad"].numpy(), Q.grad.numpy()) < 1e-11
 
 
+def test_emulated_share_deals_the_buckets_of_one_rank_without_its_peers():
+    """`ShardedBank(emulate = (rank, world))` (bench.py --shard-of N): the non-empty buckets rank `rank` of a `world`-rank job
+    would own, built without a process group; the share normalises by its own count (a self-consistent smaller problem)."""
+    from cherryml_amd.distributed import ShardedBank
+    rng = np.random.default_rng(2)
+    B, S = 23, 6
+    t = np.sort(rng.uniform(0.01, 2.0, size=B))
+    C = rng.poisson(3.0, size=(B, S, S)).astype(np.float64)
+    C[[1, 7, 8, 20]] = 0.0                                  # empty buckets are never dealt
+    live = np.flatnonzero(C.reshape(B, -1).any(axis=1))
+    seen = []
+    for r in range(4):
+        sb = ShardedBank(t, C, make_bank=lambda tt, CC: OracleBank(tt, CC), emulate=(r, 4))
+        assert sb.world == 1 and sb.emulate == (r, 4)
+        assert np.array_equal(sb.local_buckets, live[r::4])
+        assert sb.total_count == C[sb.local_buckets].sum()
+        seen.extend(sb.local_buckets.tolist())
+    assert sorted(seen) == live.tolist()                    # the four shares partition the live buckets
+    with pytest.raises(ValueError):
+        ShardedBank(t, C, make_bank=lambda tt, CC: OracleBank(tt, CC), emulate=(4, 4))
+    with pytest.raises(ValueError):
+        ShardedBank(t, C, make_bank=lambda tt, CC: OracleBank(tt, CC), emulate=(0, 64))
+
+
 def test_bucket_shard_partition():
     from cherryml_amd.distributed import bucket_shard
     for world in (1, 2, 3, 8):
