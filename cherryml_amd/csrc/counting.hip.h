@@ -419,6 +419,12 @@ __global__ __launch_bounds__(256) void co_plan_kernel(int B, int nrb, int target
 // step whatever the pairs' contact counts are (a pair with 65 contacts would otherwise cost a second, almost empty,
 // pass), four steps in flight -- every load of a step is independent of the previous step.
 #define CO_XP 256
+#ifndef CO_CU
+#define CO_CU 16  // events a thread of co_count_lds_kernel keeps in flight
+#endif
+#ifndef CO_XU
+#define CO_XU 8   // steps of 64 events a wave keeps in flight
+#endif
 __global__ __launch_bounds__(CO_XP) void co_expand_kernel(
     int B, const int8_t *__restrict__ seqs, const int32_t *__restrict__ contacts,
     const cb_count_pair *__restrict__ pairs, long long n_pairs, const int *__restrict__ qbuf,
@@ -468,11 +474,11 @@ __global__ __launch_bounds__(CO_XP) void co_expand_kernel(
   __syncthreads();
   const int total = woff[64];
   int pl = 0;   // this lane's pair inside the wave (monotone over the steps)
-  for (int e0 = 0; e0 < total; e0 += 4 * 64) {
-    int pi[4], ci[4];
-    bool on[4];
+  for (int e0 = 0; e0 < total; e0 += CO_XU * 64) {
+    int pi[CO_XU], ci[CO_XU];
+    bool on[CO_XU];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < CO_XU; ++u) {
       const int e = e0 + 64 * u + lane;
       on[u] = e < total;
       const int ec = on[u] ? e : total - 1;
@@ -480,12 +486,12 @@ __global__ __launch_bounds__(CO_XP) void co_expand_kernel(
       pi[u] = w0 + pl;
       ci[u] = ec - woff[pl];
     }
-    int2 ij[4];
+    int2 ij[CO_XU];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) ij[u] = *reinterpret_cast<const int2 *>(contacts + 2 * ((size_t)p_aux[pi[u]] + ci[u]));
-    int code[4][4];
+    for (int u = 0; u < CO_XU; ++u) ij[u] = *reinterpret_cast<const int2 *>(contacts + 2 * ((size_t)p_aux[pi[u]] + ci[u]));
+    int code[CO_XU][4];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < CO_XU; ++u) {
       const int8_t *sa = seqs + p_sa[pi[u]], *sb = seqs + p_sb[pi[u]];
       code[u][0] = sa[ij[u].x];
       code[u][1] = sa[ij[u].y];
@@ -493,7 +499,7 @@ __global__ __launch_bounds__(CO_XP) void co_expand_kernel(
       code[u][3] = sb[ij[u].y];
     }
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < CO_XU; ++u) {
       if (on[u]) {
         const bool gap = (code[u][0] | code[u][1] | code[u][2] | code[u][3]) < 0;
         events[p_base[pi[u]] + ci[u]] = gap ? CO_EVENT_GAP
@@ -524,15 +530,15 @@ __global__ __launch_bounds__(CO_THREADS) void co_count_lds_kernel(int S, int R, 
     const unsigned rr = (unsigned)(row - r0);
     if (rr < urows) atomicAdd(&co_hist[rr * S2 + col], 1u);
   };
-  for (unsigned long long e = w.e0 + threadIdx.x; e < w.e1; e += 4ull * CO_THREADS) {
-    unsigned ev[4];
+  for (unsigned long long e = w.e0 + threadIdx.x; e < w.e1; e += (unsigned long long)CO_CU * CO_THREADS) {
+    unsigned ev[CO_CU];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < CO_CU; ++u) {
       const unsigned long long eu = e + (unsigned long long)u * CO_THREADS;
       ev[u] = eu < w.e1 ? events[eu] : CO_EVENT_GAP;
     }
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < CO_CU; ++u) {
       if (ev[u] == CO_EVENT_GAP) continue;
       const int ai = ev[u] & 0xFF, aj = (ev[u] >> 8) & 0xFF, bi = (ev[u] >> 16) & 0xFF, bj = ev[u] >> 24;
       const int s1 = ai * S + aj, s1r = aj * S + ai, s2 = bi * S + bj, s2r = bj * S + bi;
