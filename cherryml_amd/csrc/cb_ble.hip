@@ -9,11 +9,13 @@ extern "C" int cb_ble_log_bank(int device, int S, int T, int R, const double *Q,
   if (!Q || !grid || !rates || !logP) return fail(CB_EINVAL, "cb_ble_log_bank: NULL argument");
   if (S < 2 || T < 1 || R < 1) return fail(CB_EINVAL, "cb_ble_log_bank: bad sizes");
   const size_t nb = (size_t)T * R, SS = (size_t)S * S;
-  std::vector<double> tt(nb), ones(nb * SS, 1.0);
+  std::vector<double> tt(nb);
   for (int t = 0; t < T; ++t)
     for (int r = 0; r < R; ++r) tt[(size_t)t * R + r] = grid[t] * rates[r];   // as io_helpers.cpp:161
   cb_handle h = nullptr;
-  int rc = cb_create(device, S, 1, (int)nb, CB_F64, tt.data(), ones.data(), 0, &h);
+  // a counts-free handle: the bank alone (with dummy counts the handle staged 8 MB and ran the count preparation -- 1.2 ms of
+  // kernels for nothing, more than the thirteen bisection passes of a family)
+  int rc = cb_create(device, S, 1, (int)nb, CB_F64, tt.data(), nullptr, CB_EXPM_ONLY, &h);
   if (rc != CB_OK) return rc;
   rc = cb_expm_bank(h, Q, pi, 0, logP);
   cb_destroy(h);
@@ -78,7 +80,7 @@ extern "C" int cb_ble_site_rates(int device, int S, int T, int R, const double *
   int *dout = d.up<int>(nullptr, L, rc);
   if (rc != CB_OK) return rc;
   HIP_TRY(hipStreamSynchronize(0));  // xT / yT are locals
-  hipLaunchKernelGGL(ble_site_rates_kernel, dim3((L + 3) / 4), dim3(256), 0, 0, S, T, R, n, L, dP, dxT, dyT, dl, dpr, dout);
+  ble_launch_site_rates(S, T, R, n, L, dP, dxT, dyT, dl, dpr, dout);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipMemcpy(rate_index, dout, L * sizeof(int), hipMemcpyDeviceToHost));
   return CB_OK;
@@ -149,7 +151,7 @@ extern "C" int cb_ble(int device, int S, int T, int R, const double *logP, const
   while (!match && max_iters) {
     ++iters;
     HIP_TRY(hipMemsetAsync(dflag, 0, sizeof(int), 0));
-    hipLaunchKernelGGL(ble_site_rates_kernel, gs, blk, 0, 0, S, T, R, n, L, dP, dxT, dyT, (const int *)dl0, dpr, ds);
+    ble_launch_site_rates(S, T, R, n, L, dP, dxT, dyT, (const int *)dl0, dpr, ds);
     hipLaunchKernelGGL(ble_branch_lengths_kernel, gb, blk, 0, 0, S, T, R, n, L, dP, dx, dy, (const int *)ds,
                        (const int *)dl0, dl1, dflag);
     int flag = 0;
@@ -238,8 +240,7 @@ extern "C" int cb_ble_batch(int device, int S, int T, int R, const double *logP,
   for (int round = 0; round < max_iters && !active.empty(); ++round) {
     HIP_TRY(hipMemsetAsync(dflag, 0, n_fam * sizeof(int), 0));
     for (int f : active) {
-      hipLaunchKernelGGL(ble_site_rates_kernel, dim3((L[f] + 3) / 4), blk, 0, 0, S, T, R, n[f], L[f], dP, dxT + off_c[f],
-                         dyT + off_c[f], (const int *)cur[f], dpr, ds + off_L[f]);
+      ble_launch_site_rates(S, T, R, n[f], L[f], dP, dxT + off_c[f], dyT + off_c[f], (const int *)cur[f], dpr, ds + off_L[f]);
       hipLaunchKernelGGL(ble_branch_lengths_kernel, dim3((n[f] + 3) / 4), blk, 0, 0, S, T, R, n[f], L[f], dP, dx + off_c[f],
                          dy + off_c[f], (const int *)(ds + off_L[f]), (const int *)cur[f], nxt[f], dflag + f);
     }
