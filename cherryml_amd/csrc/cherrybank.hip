@@ -116,7 +116,7 @@ static int launch_small_nw(cb_bank *h, const SmallArgs &a) {
     auto kern = small_bank_kernel<NT, KS, NW, MODE>;                                            \
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),                           \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));         \
-    hipLaunchKernelGGL(kern, dim3(h->L), dim3(NW * 64), lds, h->stream, a);                     \
+    hipLaunchKernelGGL(kern, dim3(h->L * (MODE == SMALL_EXPM && a.nchunk > 1 ? a.nchunk : 1)), dim3(NW * 64), lds, h->stream, a); \
   } while (0)
   if (S <= 4) LAUNCH(1, 1);
   else if (S <= 8) LAUNCH(1, 2);
@@ -557,6 +557,8 @@ int cb_internal_expm_bank(cb_handle h, const double *Q, const double *pi, int fl
     a.loss = h->loss;
     a.P = Pd;
     a.status = h->status;
+    // workgroups per site (SmallArgs::nchunk): ~32 buckets each while the launch stays below ~1024 workgroups
+    a.nchunk = std::max(1, std::min((h->B + 31) / 32, std::max(1, 1024 / h->L)));
     rc = launch_small<SMALL_EXPM>(h, a);
   }
   if (rc == CB_OK && !devp) {

@@ -42,6 +42,10 @@ struct SmallArgs {
   double *lam_out;    // [L,S] (eigh mode) or null
   double *U_out;      // [L,S,S] (eigh mode) or null
   int *status;        // [L] sweeps used by the eigensolver
+  int nchunk = 1;     // SMALL_EXPM only: workgroups per site -- each repeats the site's (cheap, deterministic) eigensolve and
+                      // writes its share of the buckets.  A bank of a few sites with thousands of buckets (the 20 rate
+                      // categories x 2047 nodes of a likelihood family, FastCherries' 129 x 20 log-bank as ONE site) otherwise
+                      // runs on as many CUs as it has sites: 0.76 ms on 20 CUs, 0.9 ms on one.
 };
 
 // LDS carve-up (doubles)
@@ -499,8 +503,9 @@ __device__ __forceinline__ void small_site_eval(double *lds, int S, int B,
                                                 const double *__restrict__ dirsum_l,
                                                 double *__restrict__ P_l, bool want_grad,
                                                 int *sweeps_out, bool warm = false,
-                                                const double *__restrict__ Cq_l = nullptr) {
+                                                const double *__restrict__ Cq_l = nullptr, int b_lo = 0, int b_hi = -1) {
   using LD = SmallLds<NW>;
+  if (b_hi < 0) b_hi = B;   // SMALL_EXPM: this workgroup's buckets [b_lo, b_hi)
   double *sA = lds + LD::A, *sG = lds + LD::G, *sV = lds + LD::V, *sLam = lds + LD::LAM,
          *sD = lds + LD::D;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -562,7 +567,7 @@ __device__ __forceinline__ void small_site_eval(double *lds, int S, int B,
   double lossacc = 0.0;
   double cval[NT][NT][4];
   if (MODE == SMALL_LOSSGRAD && wave < B) load_counts<NT, KS>(cval, S, Ct_l + (size_t)wave * S * S);
-  for (int b = wave; b < B; b += NW) {
+  for (int b = (MODE == SMALL_EXPM ? b_lo : 0) + wave; b < (MODE == SMALL_EXPM ? b_hi : B); b += NW) {
     const double *next =
         (MODE == SMALL_LOSSGRAD && b + NW < B) ? Ct_l + (size_t)(b + NW) * S * S : nullptr;
     small_bucket<NT, KS, MODE>(f, S, t_l[b], cval, next, inv_n, sA, sD, sV, tab, sLam, rho, M,
@@ -635,7 +640,8 @@ __global__ __launch_bounds__(NW * 64, (KS >= 6 && NW == 4) ? 1 : CB_SMALL_MIN_WG
   using LD = SmallLds<NW>;
   double *sA = lds + LD::A, *sG = lds + LD::G, *sV = lds + LD::V, *sLam = lds + LD::LAM,
          *sD = lds + LD::D;
-  const int l = blockIdx.x, S = a.S, B = a.B;
+  const int nch = (MODE == SMALL_EXPM && a.nchunk > 1) ? a.nchunk : 1;
+  const int l = blockIdx.x / nch, chunk = blockIdx.x - l * nch, S = a.S, B = a.B;
 
   if (MODE == SMALL_EIGH) {
     // a.Q holds the symmetric matrices themselves
@@ -659,8 +665,9 @@ __global__ __launch_bounds__(NW * 64, (KS >= 6 && NW == 4) ? 1 : CB_SMALL_MIN_WG
   small_site_eval<NT, KS, NW, MODE>(lds, S, a.nlive ? a.nlive[l] : B, a.t + lb, a.Ct + lb * S * S, a.inv_n[l],
                                     a.dirsum + (size_t)l * S,
                                     MODE == SMALL_EXPM ? a.P + lb * S * S : nullptr,
-                                    a.dQ != nullptr, a.status ? a.status + l : nullptr, false,
-                                    a.Cq ? a.Cq + (size_t)l * a.nq * (KS * KS * 64) : nullptr);
+                                    a.dQ != nullptr, (a.status && chunk == 0) ? a.status + l : nullptr, false,
+                                    a.Cq ? a.Cq + (size_t)l * a.nq * (KS * KS * 64) : nullptr,
+                                    (int)((long long)B * chunk / nch), (int)((long long)B * (chunk + 1) / nch));
   if (MODE == SMALL_EXPM) return;
   if (threadIdx.x == 0) a.loss[l] = lds[LD::LOSSTOT];
   if (a.dQ == nullptr) return;
