@@ -6,7 +6,7 @@ import subprocess
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG_DIR, "csrc")
 # one translation unit per subsystem (kernels live in the *.hip.h headers each of them includes)
-SRCS = [os.path.join(CSRC, f) for f in ("cherrybank.hip", "cb_bank_fused.hip", "cb_counting.hip", "cb_ble.hip",
+SRCS = [os.path.join(CSRC, f) for f in ("cherrybank.hip", "cb_bank_fused.hip", "cb_tbasis.hip", "cb_counting.hip", "cb_ble.hip",
                                         "cb_likelihood.hip", "cb_host_io.hip")]
 # per-file flags (cb_bank_fused.hip says why)
 FILE_FLAGS = {"cb_bank_fused.hip": ["-mllvm", "-disable-machine-licm"]}

@@ -43,6 +43,8 @@ SIGNATURES = {
     "cb_eigh_counters": (C.c_int, [_vp, _vp, C.c_int]),
     "cb_last_kernel_form": (C.c_int, [_vp]),
     "cb_last_bank_form": (C.c_int, [_vp]),
+    "cb_time_basis_info": (C.c_int, [_vp, _vp, _vp]),
+    "cb_time_basis": (C.c_int, [C.c_int, _vp, C.c_double, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "cb_train_pande_reversible": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, C.c_double, C.c_int,
                                             C.c_int, _vp, _vp, _vp, _vp, C.c_int]),
     "cb_train_siterm": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_double, C.c_int, _vp, _vp]),

@@ -42,6 +42,37 @@ int cb_internal_set_times(cb_handle h, const double *t_host, int B, const double
 // launch's end time.  Returns 0 or -1.
 int cb_launch_bank_fused(int variant, int kg, const void *args, int grid, hipStream_t stream, hipEvent_t stop);
 
+// ---- the bank in a time basis (cb_tbasis.hip, tbasis.hip.h): host builder, spectral tables, the elementwise kernel ----
+#define CB_TB_RS_MAX 24   // skeleton buckets of the short-branch forward family (psi), at most
+#define CB_TB_RG_MAX 40   // skeleton buckets of the gradient family (e^{t mu}), at most
+struct CbTimeBasisHost {
+  int B = 0, ns = 0, nd = 0, ng = 0;   // live buckets; forward skeleton, direct (long-branch) buckets, gradient skeleton
+  double rho_max = 0.0;                // the basis serves spectra inside [-rho_max, 0]
+  double res_s = 0.0, res_g = 0.0;     // largest interpolation residuals on the sample grid
+  std::vector<int> kind;               // [B]: -1 = expanded in the psi family, k >= 0 = direct bucket k
+  std::vector<int> skel_s, direct, skel_g;   // live-bucket indices
+  std::vector<double> tf, tg;          // branch lengths of the virtual buckets: [ns + nd], [ng]
+  std::vector<double> Ls, Lg;          // [B][CB_TB_RS_MAX], [B][CB_TB_RG_MAX] (zero padded; Lg carries t_b / t_skeleton)
+};
+// false: the grid / range needs more skeleton buckets than the maxima (the caller keeps the per-bucket products)
+bool cb_tb_build(int B, const double *t, double rho_max, CbTimeBasisHost &out);
+struct CbTbEwArgs {
+  int S, LD, B, ns, nd, ng;
+  const double *Ct;     // [B][LD][LD] counts (transposed per bucket; symmetric banks only)
+  const double *Psi;    // [ns + nd][LD][LD]: Psi_r of the forward skeleton, then P_b of the direct buckets
+  const double *A;      // [LD][LD]
+  const double *t;      // [B]
+  const double *Ls, *Lg;
+  const int *kind;      // [B]
+  double *Gh;           // [ng][LD][LD] out
+  double *loss_part;    // [LD * LD / 256] out
+  double inv_n;
+  const unsigned long long *skip;   // device word: non-zero => return at once
+};
+int cb_tb_launch_tables(int LD, int ns, int nd, int ng, const double *tf, const double *tg, const double *lam, double *F, double *E,
+                        double *H, const unsigned long long *skip, hipStream_t stream);
+int cb_tb_launch_ew(const CbTbEwArgs &a, hipStream_t stream, hipEvent_t stop);
+
 // Test hooks (tests/, profiles/): environment variables that change WHICH kernels run or inject faults are honoured only
 // when CB_TEST_HOOKS=1 is set as well -- a stray CB_NO_SYM in a user's shell must not change the path.  (CB_DEBUG and
 // CB_TRACE_SLOW only log; CB_BANK_STREAMS is a documented opt-in.)

@@ -154,6 +154,44 @@ static int launch_small(cb_bank *h, const SmallArgs &a) {
 #ifndef CB_BANK_KG2_MAX_B
 #define CB_BANK_KG2_MAX_B 20     // live buckets below which the tiles run on eight waves (two K-groups)
 #endif
+#ifndef CB_TB_MIN_B
+#define CB_TB_MIN_B 64           // live buckets from which the bank runs in a time basis (tbasis.hip.h; float64, symmetric counts)
+#endif
+#ifndef CB_TB_GROWTH
+#define CB_TB_GROWTH 3.0         // a basis is built for spectra up to GROWTH x the Gershgorin bound 2 max|Q_ii| of its first matrix
+#endif
+// The time basis serves 2 sigma = 2 max|Q_ii| (>= the spectral radius) with a quarter of headroom left -- one optimiser step
+// moves sigma by a few per cent --, and is not kept when the spectrum has shrunk to 1/64 of its range (ranks larger than needed).
+static bool tb_in_range(const cb_bank *h, int B, double two_sigma) {
+  return h->tb.B == B && two_sigma * 1.25 <= h->tb.rho_max && two_sigma * 64.0 >= h->tb.rho_max;
+}
+// (Re)build it on the host for the live buckets' grid and upload it to the idle device set (the kernels of an epoch that is
+// still queued read the other one).  A grid that needs more skeleton buckets than the maxima switches the form off for good.
+static int tb_rebuild(cb_bank *h, int B, double two_sigma) {
+  if (!(two_sigma > 0.0) || !std::isfinite(two_sigma)) return fail(CB_ENUMERIC, "time basis: max |Q_ii| = %g", 0.5 * two_sigma);
+  const auto t0 = std::chrono::steady_clock::now();
+  CbTimeBasisHost nb;
+  if (!cb_tb_build(B, h->t_live_host.data(), two_sigma * CB_TB_GROWTH, nb)) {
+    h->tb_failed = true;
+    h->tb = CbTimeBasisHost{};
+    return CB_OK;
+  }
+  const int set = h->tb_set ^ 1;
+  HIP_TRY(hipMemcpy(h->tb_Ls[set], nb.Ls.data(), nb.Ls.size() * sizeof(double), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(h->tb_Lg[set], nb.Lg.data(), nb.Lg.size() * sizeof(double), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(h->tb_tf[set], nb.tf.data(), nb.tf.size() * sizeof(double), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(h->tb_tg[set], nb.tg.data(), nb.tg.size() * sizeof(double), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(h->tb_kind[set], nb.kind.data(), nb.kind.size() * sizeof(int), hipMemcpyHostToDevice));
+  h->tb = std::move(nb);
+  h->tb_set = set;
+  ++h->tb_builds;
+  if (getenv("CB_DEBUG"))
+    fprintf(stderr, "[cherrybank] time basis %d: rho_max %.3f, %d skeleton + %d direct forward, %d gradient buckets of %d; residuals %.1e / %.1e; %.1f ms\n",
+            h->tb_builds, h->tb.rho_max, h->tb.ns, h->tb.nd, h->tb.ng, B, h->tb.res_s, h->tb.res_g,
+            std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+  return CB_OK;
+}
+
 // h->A (padded, symmetric) and h->dsq are filled.  Output: dQ (S x S, dQ = D^1/2 dA D^-1/2) when
 // `dA_padded` is false, else dL/dA itself as a padded LD x LD matrix.
 // `plan`: a warm solve enqueued as a device-controlled plan (eigh_planned_host.hip.h) instead of the host-driven loop; the
@@ -167,17 +205,67 @@ static int large_eval(cb_bank *h, bool normalize, double *lossd, double *out, bo
   double *dQd = out;
   int rc = CB_OK;
   const bool planned_now = plan && h->have_prev;
+  static const int n_parts = getenv("CB_BANK_STREAMS") ? std::min(4, std::max(1, atoi(getenv("CB_BANK_STREAMS")))) : 1;
+  // The bank in a TIME BASIS (tbasis.hip.h): float64 banks with symmetric counts from CB_TB_MIN_B live buckets on; CB_BANK_TB=0 / 1
+  // forces it off / on (test hook), CB_PER_BUCKET_PRODUCTS at cb_create keeps every bucket's own products.  Behind a planned
+  // solve the basis is the one the trainer kept in range with the previous epoch's sigma (lge_norms guards this epoch's: EC_SKIP);
+  // otherwise the host reads sigma below (the host-driven solver has waited for the device several times by then).
+  const char *tb_hook = cb_test_hook("CB_BANK_TB");
+  bool use_tb = h->sym_counts && !h->per_bucket_products && !h->tb_block && !h->tb_failed && !Pd && dQd != nullptr && h->tb_Ls[0] &&
+                n_parts == 1 && h->dtype == CB_F64 && !h->comm && (tb_hook ? atoi(tb_hook) != 0 : B >= CB_TB_MIN_B);
+  if (use_tb && planned_now && h->tb.B != B) use_tb = false;
   // (the three bank kernels return at once when the planned solve in front of them stalled: EC_STALL)
-  const unsigned long long *skipw = planned_now ? h->ectl + EC_STALL : nullptr;
-  if (planned_now) rc = enqueue_planned_solve(h, *plan, ++h->eseq, plan_first_slot);
+  const unsigned long long *skipw = planned_now ? h->ectl + (use_tb ? EC_SKIP : EC_STALL) : nullptr;
+  if (planned_now) rc = enqueue_planned_solve(h, *plan, ++h->eseq, plan_first_slot, use_tb ? h->tb.rho_max : 0.0);
   else if (!(reuse_eigh && h->have_prev)) rc = large_eigh(h, true);   // reuse: same matrix as the previous call (CB_REUSE_EIGH)
   if (rc != CB_OK) return rc;
+  if (use_tb && !planned_now) {
+    double sg = 0.0;
+    HIP_TRY(hipMemcpyAsync(&sg, h->sigma, sizeof sg, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    if (!tb_in_range(h, B, 2.0 * sg)) {
+      rc = tb_rebuild(h, B, 2.0 * sg);
+      if (rc != CB_OK) return rc;
+      if (h->tb_failed) use_tb = false;
+    }
+  }
   SlowScope scope_bank("large_eval: tables, bank, K4 enqueue");
   if (!planned_now) mark(h, EV_EIGH);   // (a planned solve's last launch carries the mark)
   const int tm = (LD + LG_TM - 1) / LG_TM, tn = (LD + LG_TN - 1) / LG_TN, tiles = tm * tn;
   const double inv_n = normalize ? 1.0 / (h->comm ? h->n_global[0] : h->n_host[0]) : 1.0;
   const int tiles_k1 = tn * (tn + 1) / 2;  // Pt is symmetric: upper-triangular tiles only
-  static const int n_parts = getenv("CB_BANK_STREAMS") ? std::min(4, std::max(1, atoi(getenv("CB_BANK_STREAMS")))) : 1;
+  h->bank_tb = use_tb;
+  if (use_tb) {
+    // tables of the virtual buckets -> K1' (Psi_r of the forward skeleton, P_b of the long-branch buckets: ns + nd products
+    // into h->T) -> tb_ew (every element of every bucket: P_b, loss, G_b, the ng sums Gh_r into h->Gt) -> K2' (Th_r = Gh_r U
+    // over h->T) -> K3' (W_r = (Th_r^T U) o Phi(t_r) over h->Gt) -> the sum over r + the loss -> K4: the kernels of the per-bucket
+    // form on ns + nd and ng buckets instead of B.
+    const CbTimeBasisHost &bas = h->tb;
+    const int set = h->tb_set, nf = bas.ns + bas.nd, ng = bas.ng;
+    h->bank_fused = false;
+    h->bank_accum = false;
+    h->bank_kg = 1;
+    if (cb_tb_launch_tables(LD, bas.ns, bas.nd, ng, h->tb_tf[set], h->tb_tg[set], h->lam, h->F, h->E, h->H, skipw, h->stream) != 0)
+      return fail(CB_EHIP, "tb_tables: launch failed");
+    K1Args<double> k1{S, LD, nf, h->Vc, h->A, h->tb_tf[set], h->F, h->sigma, h->Ct, h->T, h->loss_part, inv_n, h->dsq, nullptr, skipw};
+    LAUNCH_STOP(stop_event(h, EV_K1), (k1_pt_loss_gt<double, double, false, 1, true>), dim3(tiles_k1 * nf), dim3(LG4_THREADS), 0, h->stream, k1);
+    const CbTbEwArgs ew{S, LD, B, bas.ns, bas.nd, ng, h->Ct, h->T, h->A, tb, h->tb_Ls[set], h->tb_Lg[set], h->tb_kind[set], h->Gt, h->loss_part, inv_n, skipw};
+    if (cb_tb_launch_ew(ew, h->stream, nullptr) != 0) return fail(CB_EHIP, "tb_ew: launch failed");
+    K2Args<double> k2{LD, h->Gt, h->U, h->T, skipw};
+    LAUNCH_STOP(stop_event(h, EV_K2), (k2_t_eq_g_u<double, 1>), dim3(tiles * ng), dim3(LG4_THREADS), 0, h->stream, k2);
+    K3Args<double> k3{LD, ng, h->T, h->U, h->tb_tg[set], h->lam, h->E, h->H, h->Gt, 1, skipw};
+    LAUNCH_STOP(stop_event(h, EV_K3), (k3_w_phi<double, 1>), dim3(tiles_k1 * ng), dim3(LG4_THREADS), 0, h->stream, k3);
+    const LossArgs la{h->loss_part, (int)(LL / 256), S, h->dsq, h->dirsum, inv_n, lossd, skipw};
+    hipLaunchKernelGGL(k3_reduce_loss<double>, dim3((unsigned)((LL + 255) / 256) + 1), dim3(256), 0, h->stream, h->Gt, ng, LL, h->Mt, LD, la);
+    K4Args k4a{S, LD, h->Mt, h->Vc, h->X, nullptr, nullptr, nullptr};
+    k4a.skip = skipw;
+    launch_sg(h, k4a, 0);
+    K4Args k4b{S, LD, h->Vc, h->X, dQd, dA_padded ? nullptr : h->dsq, nullptr, nullptr};
+    k4b.skip = skipw;
+    launch_sg(h, k4b, 0, 0.0, 0.0, nullptr, stop_event(h, EV_K4));
+    HIP_TRY(hipGetLastError());
+    return CB_OK;
+  }
   // Symmetric counts: the buckets are summed BEFORE the last product (large_bank.hip.h, ky_reduce_loss / kphi_combine: one
   // streaming pass over T and 1 + CB_PHI_TERMS single products instead of a third product per bucket); CB_BANK_K3=1 keeps
   // the per-bucket third product (test hook: the reference point of the accuracy test).  Other banks: K3 on all tiles.
@@ -703,7 +791,16 @@ extern "C" int cb_eigh_counters(cb_handle h, int *counts, int n) {
 }
 extern "C" int cb_last_kernel_form(cb_handle h) { return h ? h->last_form : 0; }
 extern "C" int cb_last_bank_form(cb_handle h) {
-  return h ? (h->bank_fused ? 1 : 0) | (h->bank_kg == 2 ? 2 : 0) | (h->bank_accum ? 4 : 0) : 0;
+  return h ? (h->bank_fused ? 1 : 0) | (h->bank_kg == 2 ? 2 : 0) | (h->bank_accum ? 4 : 0) | (h->bank_tb ? 8 : 0) : 0;
+}
+extern "C" int cb_time_basis_info(cb_handle h, int *n, double *rho_max) {
+  if (!h || !n || !rho_max) return fail(CB_EINVAL, "cb_time_basis_info: NULL argument");
+  n[0] = h->tb.ns;
+  n[1] = h->tb.nd;
+  n[2] = h->tb.ng;
+  n[3] = h->tb_builds;
+  *rho_max = h->tb.rho_max;
+  return CB_OK;
 }
 
 extern "C" int cb_last_timings(cb_handle h, double *ms, int n) {

@@ -40,6 +40,9 @@ enum {
   EC_MASKED = 7,   // the last sweep rotated far pairs only (the band pass behind it runs)
   EC_SC = 8,       // bits of the scale s: Y = s X
   EC_BANDS = 9,    // band passes run so far
+  EC_SIGMA = 10,   // bits of sigma = max |A_ii| (lge_begin): the host follows 2 sigma >= rho, the range of the bank's time basis
+  EC_TBSTALE = 11, // lge_norms: 2 sigma left the range the time basis was built for (tbasis.hip.h); the bank returns at once
+  EC_SKIP = 12,    // EC_STALL | EC_TBSTALE: the word the kernels of a time-basis bank look at
   EC_REC = 16,     // 4 words per sweep: cosine, row sum (all pairs), row sum (far pairs), EC_MODE | sq << 24
   EC_MAXREC = 12,
   EC_JSTATE = 64,  // two words of lgj_round's own (running maximum; "finished", which stays zero here)
@@ -529,7 +532,11 @@ __global__ void lge_begin(int LD, const double *A, double *sigma, unsigned long 
     if ((int)threadIdx.x < st) s[threadIdx.x] = fmax(s[threadIdx.x], s[threadIdx.x + st]);
     __syncthreads();
   }
-  if (threadIdx.x == 0) *sigma = s[0] > 0.0 ? s[0] : 1.0;
+  if (threadIdx.x == 0) {
+    const double sg = s[0] > 0.0 ? s[0] : 1.0;
+    *sigma = sg;
+    ctl[EC_SIGMA] = dbl_bits(sg);   // (a different word than the ones zeroed above by this thread's neighbours)
+  }
 }
 
 // A stalled solve continues (more slots on the same G): the stall word cleared, everything else kept.
@@ -540,18 +547,24 @@ __global__ void lge_resume(unsigned long long *ctl) {
 // |g_k| per column of the buffer the final sweep wrote; workgroup 0 also settles the solve's outcome (STALL when the plan
 // ended before a sweep started below 1e-8) and publishes the record of the solve to pinned host memory, where the host
 // looks BEHIND the kernels it has already enqueued (one epoch of the bank is queued at that point).
+// tb_rho_max > 0: the bank behind this solve runs in a time basis that serves spectra inside [-tb_rho_max, 0]; 2 sigma bounds
+// the spectral radius (Gershgorin on the rate matrix), so 2 sigma > tb_rho_max makes the bank return at once (EC_SKIP) and
+// the host repeat the evaluation with per-bucket products (train_host.hip.h).
 __global__ void lge_norms(int LD, const double *G0, const double *G1, double *nrm, unsigned long long *ctl,
-                          volatile unsigned long long *pin, unsigned long long seq) {
+                          volatile unsigned long long *pin, unsigned long long seq, const double *sigma, double tb_rho_max) {
   const unsigned long long fin = ctl[EC_FINAL];
   const bool stall = ctl[EC_STALL] != 0ull || fin == EC_NONE;
+  const bool stale = tb_rho_max > 0.0 && !(2.0 * (*sigma) <= tb_rho_max);
   if (blockIdx.x == 0) {   // (blockDim.x == 256)
     if (pin && threadIdx.x < EC_WORDS) {
       const int i = threadIdx.x;
-      pin[i] = i == EC_STALL ? (stall ? 1ull : 0ull) : ctl[i];
+      pin[i] = i == EC_STALL ? (stall ? 1ull : 0ull) : i == EC_TBSTALE ? (stale ? 1ull : 0ull) : i == EC_SKIP ? ((stall || stale) ? 1ull : 0ull) : ctl[i];
       __threadfence_system();
     }
     __syncthreads();
     if (threadIdx.x == 0) {
+      ctl[EC_TBSTALE] = stale ? 1ull : 0ull;
+      ctl[EC_SKIP] = (stall || stale) ? 1ull : 0ull;
       if (stall) ctl[EC_STALL] = 1ull;
       if (pin) {
         pin[EC_WORDS] = seq;   // the word the host watches, written last

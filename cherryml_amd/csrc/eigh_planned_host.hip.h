@@ -8,6 +8,8 @@
 struct EighRecord {
   bool stall = false;
   int err = 0, nsweep = 0, final_slot = -1;
+  double sigma = 0.0;      // max |A_ii| of the matrix the solve was given
+  bool tb_stale = false;   // ... left the range of the bank's time basis: the bank behind the solve returned at once
   struct {
     double c, rs, rsf;
     int order, sq, slot;
@@ -115,7 +117,7 @@ static bool eigh_planned_setup(cb_bank *h) {
 // Enqueue one warm solve (h->U / h->Vc hold the previous eigenvectors, h->A the new matrix).  `seq` is what lge_norms
 // leaves in the record's sequence word.  first_slot > 0: the CONTINUATION of a stalled solve -- its G buffers hold a valid,
 // partly converged state (every rotation applied so far was orthogonal), so the new slots simply carry on from it.
-static int enqueue_planned_solve(cb_bank *h, const EighPlan &p, unsigned long long seq, int first_slot = 0) {
+static int enqueue_planned_solve(cb_bank *h, const EighPlan &p, unsigned long long seq, int first_slot = 0, double tb_rho_max = 0.0) {
   const int LD = h->LD, nt = LD / 16, nb = LD / JB_W;
   const size_t LL = (size_t)LD * LD;
   unsigned long long *ctl = h->ectl;
@@ -186,7 +188,7 @@ static int enqueue_planned_solve(cb_bank *h, const EighPlan &p, unsigned long lo
     if (q.band_after) band_pass(Gout, ctl + EC_MASKED);
   }
   volatile unsigned long long *pin = h->epin + (size_t)(seq & 1ull) * (EC_WORDS + 16);
-  hipLaunchKernelGGL(lge_norms, dim3((LD + 3) / 4), dim3(256), 0, h->stream, LD, Gb[0], Gb[1], h->X, ctl, pin, seq);
+  hipLaunchKernelGGL(lge_norms, dim3((LD + 3) / 4), dim3(256), 0, h->stream, LD, Gb[0], Gb[1], h->X, ctl, pin, seq, h->sigma, tb_rho_max);
   LAUNCH_STOP(stop_event(h, EV_EIGH), lge_finish, dim3((LD + 3) / 4), dim3(256), 0, h->stream, LD, Gb[0], Gb[1], h->X, h->sigma, h->lam, h->U, h->Vc,
                      ctl);
   HIP_TRY(hipGetLastError());
@@ -223,6 +225,11 @@ static int eigh_planned_record(cb_bank *h, unsigned long long seq, EighRecord &r
     r.nsweep = (int)(ns < (unsigned long long)EC_MAXREC ? ns : (unsigned long long)EC_MAXREC);
   }
   r.final_slot = pin[EC_FINAL] == EC_NONE ? -1 : (int)pin[EC_FINAL];
+  {
+    const unsigned long long sb = pin[EC_SIGMA];
+    memcpy(&r.sigma, &sb, 8);
+  }
+  r.tb_stale = pin[EC_TBSTALE] != 0ull;
   for (int k = 0; k < r.nsweep; ++k) {
     unsigned long long w[4] = {pin[EC_REC + 4 * k], pin[EC_REC + 4 * k + 1], pin[EC_REC + 4 * k + 2], pin[EC_REC + 4 * k + 3]};
     memcpy(&r.sweep[k].c, &w[0], 8);

@@ -92,6 +92,16 @@ struct cb_bank {
   bool bank_fused = false;              // the last evaluation ran K1 -> K2 -> K3 as one launch
   int bank_kg = 1;                      // ... with four-wave (1) or eight-wave (2) tiles
   bool bank_accum = false;              // ... and summed the buckets before the last product (no K3)
+  // the bank in a time basis (tbasis.hip.h): host copy of the interpolative decomposition (tb.B == 0: none), two device sets
+  // (a rebuild fills the idle one while the kernels of the epoch in flight still read the other)
+  CbTimeBasisHost tb;
+  int tb_set = 0;
+  double *tb_Ls[2] = {}, *tb_Lg[2] = {}, *tb_tf[2] = {}, *tb_tg[2] = {};
+  int *tb_kind[2] = {};
+  int tb_builds = 0;                    // cb_time_basis_info
+  bool tb_failed = false;               // the grid needs more skeleton buckets than the maxima: the per-bucket forms, for good
+  bool tb_block = false;                // this evaluation repeats one whose basis was out of range: per-bucket products
+  bool bank_tb = false;                 // the last evaluation ran in the time basis
   int last_sweeps = 0;
   double *gn_scratch = nullptr, *gn_partial = nullptr;  // general path, allocated on first use
   int gn_nw = 0;

@@ -403,7 +403,9 @@ __device__ __forceinline__ void bank_store(T *p, T v) {
 
 // one (bucket b, upper-triangular tile `tile`) of K1; sAB: 4 * LG_KT * LG_TM elements of LDS (A panels | B panels, two K-steps
 // each; after the K loop: the transposition buffer); vid = b * tiles + tile indexes the loss partial
-template <typename T, typename TG, bool EXPM, bool WT, int KG = 1>
+// RAW (the time-basis bank, tbasis.hip.h): the product U diag(F_b) U^T ITSELF -- no I + t A, no counts -- written whole
+// (both triangles) to Gt[b] as a padded LD x LD matrix: Psi_r of a skeleton bucket, or P_b of a long-branch bucket.
+template <typename T, typename TG, bool EXPM, bool WT, int KG = 1, bool RAW = false>
 __device__ __forceinline__ void k1_tile(const K1Args<T, TG> &a, int b, int tile, T *sAB, int tid,
                                         const BankHooks &hooks = BankHooks{}) {
   T *sA = sAB, *sB = sAB + 2 * LG_KT * LG_TM;
@@ -427,7 +429,7 @@ __device__ __forceinline__ void k1_tile(const K1Args<T, TG> &a, int b, int tile,
 
   const double tb = a.t[b];
   const T tbT = (T)tb, inv_nT = (T)a.inv_n;
-  const bool split = tb * 2.0 * (*a.sigma) <= 1.0;  // see small_bank.hip.h
+  const bool split = !RAW && tb * 2.0 * (*a.sigma) <= 1.0;  // see small_bank.hip.h
   const bool mirror = tm != tn;
   double lossacc = 0.0;
   const int lo = lane & 15, hi = lane >> 4;
@@ -465,6 +467,20 @@ __device__ __forceinline__ void k1_tile(const K1Args<T, TG> &a, int b, int tile,
       row[r] = rbase + rl[r];
       idx[r] = idx0 + r * step;
       idm[r] = idm0 + r * step;
+    }
+    if constexpr (RAW) {
+      // direct entries, then the mirrored ones through the wave's patch (lanes along THEIR rows, as below)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) Gt[idx[r]] = (TG)v[r];
+      if (mirror) {
+        lg_wave_lds_fence();
+#pragma unroll
+        for (int r = 0; r < 4; ++r) sW[lo * 17 + rl[r]] = v[r];
+        lg_wave_lds_fence();
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Gt[idm[r]] = (TG)sW[rl[r] * 17 + lo];
+      }
+      return;
     }
     T c1[4], c2[4], av[4], pt[4];
     if (!EXPM) {
@@ -539,7 +555,7 @@ __device__ __forceinline__ void k1_tile(const K1Args<T, TG> &a, int b, int tile,
     if (lg_owns_acc<KG>(kg, j)) tile_epilogue(m0 + 16 * wave, n0 + 16 * j, acc[j]);
   if (lg_owns_ax0<KG>(kg)) tile_epilogue(m0 + 64, n0 + 16 * wave, ax0);
   if (wave == 0 && lg_owns_ax1<KG>(kg)) tile_epilogue(m0 + 64, n0 + 64, ax1);
-  if (EXPM) return;
+  if (EXPM || RAW) return;
   __syncthreads();   // the patches are read no more: the loss partials reuse the buffer
   lossacc = wave_sum(lossacc);
   // the LDS panels are free after the K loop (the tile routine ends with a barrier)
@@ -554,14 +570,14 @@ __device__ __forceinline__ void k1_tile(const K1Args<T, TG> &a, int b, int tile,
   CB_STAMP_FINISH(0);
 }
 
-template <typename T, typename TG = T, bool EXPM = false, int KG = 1>   // EXPM: write P_b (cb_expm_bank) instead of loss / Gt
+template <typename T, typename TG = T, bool EXPM = false, int KG = 1, bool RAW = false>   // EXPM: write P_b (cb_expm_bank) instead of loss / Gt
 __global__ __launch_bounds__(LG4_THREADS * KG, 4) void k1_pt_loss_gt(K1Args<T, TG> a) {  // sixteen waves per CU
   if (a.skip && *a.skip != 0ull) return;
   __shared__ T sAB[KG * 4 * LG_KT * LG_TM];
   const int tilesN = (a.LD + LG_TN - 1) / LG_TN, tiles = tilesN * (tilesN + 1) / 2;
   const int vid = xcd_swizzle(blockIdx.x, gridDim.x);
   const int b = vid / tiles;
-  k1_tile<T, TG, EXPM, false, KG>(a, b, vid - b * tiles, sAB, threadIdx.x);
+  k1_tile<T, TG, EXPM, false, KG, RAW>(a, b, vid - b * tiles, sAB, threadIdx.x);
 }
 
 // ------------------------------------------------------------------ K2

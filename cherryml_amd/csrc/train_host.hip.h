@@ -140,6 +140,12 @@ static int run_fused_training_large(cb_bank *h, double *pi_param, double *up_par
   const bool planned = !cb_test_hook("CB_EIGH_HOST") && !cb_test_hook("CB_NO_HYBRID") && LD % 16 == 0 && LD / JB_W >= 8 && eigh_planned_setup(h);
   EighPlan &plan = h->eplan;
   if (!resume) eigh_plan_default(plan);
+  // the bank's time basis (tbasis.hip.h) is part of the optimisation's state as well: a fresh optimisation builds its own from
+  // its first matrix (the same bits whatever ran on the handle before), a resumed one continues with the one it has
+  if (!resume) {
+    h->tb = CbTimeBasisHost{};
+    h->tb_failed = false;
+  }
   // test hook: every plan cut down to one sweep, so that every solve stalls and is continued (tests/test_gpu_s400_full.py)
   // (= 2: that one sweep with the second-order polynomial only, so that it is also a DAMPED one -- exp(alpha X), alpha << 1)
   const int short_plans = cb_test_hook("CB_EIGH_SHORT_PLAN") ? std::max(1, atoi(cb_test_hook("CB_EIGH_SHORT_PLAN"))) : 0;
@@ -190,7 +196,9 @@ static int run_fused_training_large(cb_bank *h, double *pi_param, double *up_par
         if (rc == CB_OK) rc = eigh_planned_record(h, h->eseq, rec);
         if (rc == CB_OK && rec.err == 2) rc = fail(CB_ENUMERIC, "eigensolver: non-finite input");
       }
+      bool host_solved = false;
       if (rc == CB_OK && rec.stall) {   // still not converged: the host-driven solver, from the previous eigenvectors
+        host_solved = true;
         // (errors flow through rc: a sharded job's failure protocol and the clean-up below depend on it)
         if (hipStreamSynchronize(h->stream) != hipSuccess) rc = fail(CB_EHIP, "hipStreamSynchronize failed (host-driven solver fallback)");
         else if (hipMemsetAsync(h->ectl, 0, sizeof(unsigned long long), h->stream) != hipSuccess)
@@ -198,6 +206,19 @@ static int run_fused_training_large(cb_bank *h, double *pi_param, double *up_par
         for (bool &b : h->ev_rec) b = false;
         mark(h, EV_START);
         if (rc == CB_OK) rc = large_eval(h, flags & CB_NORMALIZE, h->loss, h->Mt, true, nullptr);
+      }
+      if (rc == CB_OK && !host_solved && h->bank_tb) {
+        // The time basis against this solve's sigma.  Out of range (lge_norms saw it too: the bank, the reduction and K4 returned
+        // at once): the evaluation is repeated on the finished decomposition with per-bucket products.  Close to the end of
+        // the range, or far below it: a new basis for the next epoch (host: ~25 ms, a few times per optimisation at most).
+        if (rec.tb_stale) {
+          for (bool &b : h->ev_rec) b = false;
+          mark(h, EV_START);
+          h->tb_block = true;
+          rc = large_eval(h, flags & CB_NORMALIZE, h->loss, h->Mt, true, nullptr, true, nullptr);
+          h->tb_block = false;
+        }
+        if (rc == CB_OK && !tb_in_range(h, h->Bl, 2.0 * rec.sigma)) rc = tb_rebuild(h, h->Bl, 2.0 * rec.sigma);
       }
       if (rc == CB_OK) {
         const EighPlan prev = plan;

@@ -58,7 +58,9 @@ enum {
                         * 129-bucket epoch); its dL/dQ is then accurate to 1e-13 .. 1e-11 of its norm instead of 3e-16
                         * (differences of one-sided sums cancel for close eigenvalues), which Adam's per-parameter scaling
                         * turns into trajectories 1e-11 .. 1e-10 from the per-bucket ones after 50 epochs -- four orders inside the
-                        * 1e-6 bar on the learned matrix.  csrc/large_bank.hip.h (ky_reduce_loss), DESIGN.md section 2. */
+                        * 1e-6 bar on the learned matrix.  csrc/large_bank.hip.h (ky_reduce_loss), DESIGN.md section 2.
+                        * The flag also keeps the bank out of the TIME BASIS (below): every bucket then has its own three
+                        * products, the reference point of the accuracy tests. */
 };
 
 /* ABI version of the loaded library (bumped on incompatible change). */
@@ -187,8 +189,25 @@ int cb_last_kernel_form(cb_handle h);
 /* How the last S > 32 evaluation on this handle ran its three bank products (chosen from the bank's shape, csrc/cherrybank.hip,
  * large_eval): bit 0 = K1 -> K2 (-> K3) as ONE persistent launch (k123_bank; else separate launches), bit 1 = eight-wave tiles
  * (two K-groups; else four waves per tile), bit 2 = the buckets were summed BEFORE the last product (symmetric counts: no
- * third product per bucket, csrc/large_bank.hip.h ky_reduce_loss / kphi_combine).  0 before the first evaluation. */
+ * third product per bucket, csrc/large_bank.hip.h ky_reduce_loss / kphi_combine), bit 3 = the bank ran in the TIME BASIS
+ * (csrc/tbasis.hip.h: the products on a few skeleton buckets, one elementwise kernel over all buckets in between; bits 0 and 2
+ * are then clear).  0 before the first evaluation. */
 int cb_last_bank_form(cb_handle h);
+/* The time basis of the last evaluation that used one: n[0] = skeleton buckets of the short-branch forward family, n[1] =
+ * long-branch buckets that keep their own product, n[2] = skeleton buckets of the gradient family, n[3] = how often the
+ * basis has been built on this handle; rho_max = the spectral bound it serves.  All zero when none has been built. */
+int cb_time_basis_info(cb_handle h, int *n, double *rho_max);
+/* HOST-ONLY (no GPU needed): the interpolative decomposition over the branch-length grid that the S > 32 bank uses when it has
+ * >= 64 live buckets with symmetric counts (float64).  Every per-bucket quantity of the bank is a smooth function of t_b on
+ * the spectrum [-rho_max, 0]:  phi2(t_b lam) / t_b^2 = sum_r Ls[b][r] phi2(t_s(r) lam) / t_s(r)^2  (buckets with
+ * t_b rho_max <= 8; kind[b] = -1), and  e^{t_b mu} = sum_r (Lg[b][r] t_g(r) / t_b) e^{t_g(r) mu}  (all buckets), to 1e-16.
+ * n_out[0..2] = ns, nd, ng; kind[B] (-1, or the index k >= 0 of a long-branch bucket that keeps its own product);
+ * skel_s[ns], skel_g[ng] = the skeleton buckets; Ls [B][24], Lg [B][40] zero padded; resid[2] = largest residuals on the
+ * builder's sample grid.  Any output pointer but n_out may be NULL.  CB_EUNSUPPORTED when the grid needs more than 24 / 40
+ * skeleton buckets.  Replaces nothing in the reference: there every bucket is an independent matrix exponential
+ * (cherryml/estimation/_ratelearn/trainer.py:170-172). */
+int cb_time_basis(int B, const double *t, double rho_max, int *n_out, int *kind, int *skel_s, int *skel_g, double *Ls,
+                  double *Lg, double *resid);
 
 /*
  * Fused optimiser for the reference's `pande_reversible` parameterisation
