@@ -22,8 +22,8 @@ class CherryBank:
 
     def __init__(self, t, C, device: int = 0, dtype: str = "f64", per_bucket_products: bool = False):
         """per_bucket_products (S > 32, cb_create's CB_PER_BUCKET_PRODUCTS): always form U^T G_b U bucket by bucket; by default a
-        float64 bank with symmetric counts and >= 24 live buckets sums the buckets before the last product (10 % faster
-        epochs at 129 buckets; dL/dQ to 1e-13 .. 1e-11 of its norm instead of 3e-16 -- see include/cherrybank.h).
+        float64 bank with symmetric counts runs in a TIME BASIS from 64 live buckets on (products on ~30 skeleton buckets,
+        csrc/tbasis.hip.h) and sums the buckets before the last product from 24 on (see include/cherrybank.h).
         dtype: element type of the bank products (cb_create's `dtype`): "f64"; "f32" -- the
         reference's own arithmetic, ratelearner.py:98,107 -- for S > 32 (float32 MFMA; the
         eigendecomposition, loss accumulation and everything crossing the ABI stay float64); or "mixed":
@@ -192,7 +192,19 @@ class CherryBank:
         """how the last S > 32 evaluation ran the bank products (cb_last_bank_form): one persistent launch or separate
         ones, four- or eight-wave tiles, buckets summed before the last product (symmetric counts) or a third product each"""
         v = int(_lib.load().cb_last_bank_form(self._h))
-        return {"fused": bool(v & 1), "waves_per_tile": 8 if v & 2 else 4, "bucket_sum_first": bool(v & 4)}
+        return {"fused": bool(v & 1), "waves_per_tile": 8 if v & 2 else 4, "bucket_sum_first": bool(v & 4),
+                "time_basis": bool(v & 8)}
+
+    def time_basis_info(self) -> dict:
+        """the time basis of the last evaluation that ran in one (cb_time_basis_info; csrc/tbasis.hip.h): skeleton buckets of
+        the short-branch forward family, long-branch buckets that keep their own product, skeleton buckets of the gradient
+        family, bases built so far, epochs repeated with per-bucket products, the spectral bound the basis serves"""
+        import ctypes as Ct
+        n = np.zeros(5, dtype=np.int32)
+        rho = Ct.c_double(0.0)
+        _lib.check(_lib.load().cb_time_basis_info(self._h, n.ctypes.data, Ct.byref(rho)), "cb_time_basis_info")
+        return {"forward_skeleton": int(n[0]), "direct": int(n[1]), "gradient_skeleton": int(n[2]), "builds": int(n[3]),
+                "repeated_epochs": int(n[4]), "rho_max": float(rho.value)}
 
     # -- host-pointer API (numpy) -----------------------------------------
     def _shape_Q(self, Q, pi):
@@ -305,3 +317,20 @@ class CherryBank:
                                       dQ.data_ptr() if want_grad else None)
         _lib.check(rc, "cb_loss_grad")
         return loss, dQ
+
+
+def time_basis(t, rho_max: float) -> dict:
+    """HOST-ONLY (no GPU): the interpolative decomposition over the branch-length grid `t` (ascending) that the S > 32 bank
+    uses for spectra inside [-rho_max, 0] (cb_time_basis, include/cherrybank.h): kind[B] (-1: expanded in the short-branch
+    family, k >= 0: long-branch bucket k), the skeleton buckets, the interpolation matrices and the builder's residuals."""
+    t = _as_f64(t).reshape(-1)
+    B = t.size
+    n = np.zeros(3, dtype=np.int32)
+    kind = np.zeros(B, dtype=np.int32)
+    sks, skg = np.zeros(24, dtype=np.int32), np.zeros(40, dtype=np.int32)
+    Ls, Lg, res = np.zeros((B, 24)), np.zeros((B, 40)), np.zeros(2)
+    _lib.check(_lib.load().cb_time_basis(B, t.ctypes.data, float(rho_max), n.ctypes.data, kind.ctypes.data, sks.ctypes.data,
+                                         skg.ctypes.data, Ls.ctypes.data, Lg.ctypes.data, res.ctypes.data), "cb_time_basis")
+    ns, nd, ng = (int(x) for x in n)
+    return {"ns": ns, "nd": nd, "ng": ng, "kind": kind, "skel_s": sks[:ns].copy(), "skel_g": skg[:ng].copy(),
+            "Ls": Ls[:, :ns].copy(), "Lg": Lg[:, :ng].copy(), "residuals": res}

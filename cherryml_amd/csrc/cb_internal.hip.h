@@ -58,12 +58,12 @@ struct CbTimeBasisHost {
 bool cb_tb_build(int B, const double *t, double rho_max, CbTimeBasisHost &out);
 struct CbTbEwArgs {
   int S, LD, B, ns, nd, ng;
+  int nsmall;           // buckets 0 .. nsmall - 1 are expanded in the psi family, bucket b >= nsmall is direct bucket b - nsmall
   const double *Ct;     // [B][LD][LD] counts (transposed per bucket; symmetric banks only)
   const double *Psi;    // [ns + nd][LD][LD]: Psi_r of the forward skeleton, then P_b of the direct buckets
   const double *A;      // [LD][LD]
   const double *t;      // [B]
   const double *Ls, *Lg;
-  const int *kind;      // [B]
   double *Gh;           // [ng][LD][LD] out
   double *loss_part;    // [LD * LD / 256] out
   double inv_n;
@@ -71,7 +71,12 @@ struct CbTbEwArgs {
 };
 int cb_tb_launch_tables(int LD, int ns, int nd, int ng, const double *tf, const double *tg, const double *lam, double *F, double *E,
                         double *H, const unsigned long long *skip, hipStream_t stream);
-int cb_tb_launch_ew(const CbTbEwArgs &a, hipStream_t stream, hipEvent_t stop);
+// LDS bytes tb_ew needs for a bank of B live buckets (its interpolation matrices live there); above CB_TB_LDS_MAX the bank keeps
+// the per-bucket forms
+#define CB_TB_LDS_MAX (144u << 10)
+size_t cb_tb_ew_lds_bytes(int B, int ns, int ng);
+// (*nparts: the loss partials the launch writes)
+int cb_tb_launch_ew(const CbTbEwArgs &a, hipStream_t stream, hipEvent_t stop, int *nparts);
 
 // Test hooks (tests/, profiles/): environment variables that change WHICH kernels run or inject faults are honoured only
 // when CB_TEST_HOOKS=1 is set as well -- a stray CB_NO_SYM in a user's shell must not change the path.  (CB_DEBUG and

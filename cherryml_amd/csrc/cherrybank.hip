@@ -162,16 +162,22 @@ static int launch_small(cb_bank *h, const SmallArgs &a) {
 #endif
 // The time basis serves 2 sigma = 2 max|Q_ii| (>= the spectral radius) with a quarter of headroom left -- one optimiser step
 // moves sigma by a few per cent --, and is not kept when the spectrum has shrunk to 1/64 of its range (ranks larger than needed).
-static bool tb_in_range(const cb_bank *h, int B, double two_sigma) {
-  return h->tb.B == B && two_sigma * 1.25 <= h->tb.rho_max && two_sigma * 64.0 >= h->tb.rho_max;
+static bool tb_in_range(const cb_bank *h, int B, double two_sigma, double headroom = 1.25) {
+  return h->tb.B == B && two_sigma * headroom <= h->tb.rho_max && two_sigma * 64.0 >= h->tb.rho_max;
 }
 // (Re)build it on the host for the live buckets' grid and upload it to the idle device set (the kernels of an epoch that is
 // still queued read the other one).  A grid that needs more skeleton buckets than the maxima switches the form off for good.
-static int tb_rebuild(cb_bank *h, int B, double two_sigma) {
-  if (!(two_sigma > 0.0) || !std::isfinite(two_sigma)) return fail(CB_ENUMERIC, "time basis: max |Q_ii| = %g", 0.5 * two_sigma);
-  const auto t0 = std::chrono::steady_clock::now();
-  CbTimeBasisHost nb;
-  if (!cb_tb_build(B, h->t_live_host.data(), two_sigma * CB_TB_GROWTH, nb)) {
+static double tb_growth() {
+  if (const char *g = cb_test_hook("CB_TB_TEST_GROWTH")) return std::max(1.0, atof(g));   // (tests: a basis that is outgrown at once)
+  return CB_TB_GROWTH;
+}
+static void tb_drop_next(cb_bank *h) {   // (a helper thread still building: wait for it, forget its result)
+  if (h->tb_next_pending) (void)h->tb_next.get();
+  h->tb_next_pending = false;
+}
+// upload a built basis to the idle device set and make it the current one
+static int tb_install(cb_bank *h, int B, CbTimeBasisHost &&nb, double ms) {
+  if (nb.B != B || cb_tb_ew_lds_bytes(B, nb.ns, nb.ng) > CB_TB_LDS_MAX) {
     h->tb_failed = true;
     h->tb = CbTimeBasisHost{};
     return CB_OK;
@@ -181,14 +187,65 @@ static int tb_rebuild(cb_bank *h, int B, double two_sigma) {
   HIP_TRY(hipMemcpy(h->tb_Lg[set], nb.Lg.data(), nb.Lg.size() * sizeof(double), hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(h->tb_tf[set], nb.tf.data(), nb.tf.size() * sizeof(double), hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(h->tb_tg[set], nb.tg.data(), nb.tg.size() * sizeof(double), hipMemcpyHostToDevice));
-  HIP_TRY(hipMemcpy(h->tb_kind[set], nb.kind.data(), nb.kind.size() * sizeof(int), hipMemcpyHostToDevice));
   h->tb = std::move(nb);
   h->tb_set = set;
   ++h->tb_builds;
   if (getenv("CB_DEBUG"))
-    fprintf(stderr, "[cherrybank] time basis %d: rho_max %.3f, %d skeleton + %d direct forward, %d gradient buckets of %d; residuals %.1e / %.1e; %.1f ms\n",
-            h->tb_builds, h->tb.rho_max, h->tb.ns, h->tb.nd, h->tb.ng, B, h->tb.res_s, h->tb.res_g,
-            std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+    fprintf(stderr, "[cherrybank] time basis %d: rho_max %.3f, %d skeleton + %d direct forward, %d gradient buckets of %d; residuals %.1e / %.1e; %.1f ms%s\n",
+            h->tb_builds, h->tb.rho_max, h->tb.ns, h->tb.nd, h->tb.ng, B, h->tb.res_s, h->tb.res_g, ms, ms < 0.0 ? " (built beside the epochs)" : "");
+  return CB_OK;
+}
+// (Re)build it NOW on the host for the live buckets' grid.  A grid that needs more skeleton buckets than the maxima switches
+// the form off for good.
+static int tb_rebuild(cb_bank *h, int B, double two_sigma) {
+  if (!(two_sigma > 0.0) || !std::isfinite(two_sigma)) return fail(CB_ENUMERIC, "time basis: max |Q_ii| = %g", 0.5 * two_sigma);
+  tb_drop_next(h);
+  const auto t0 = std::chrono::steady_clock::now();
+  CbTimeBasisHost nb;
+  if (!cb_tb_build(B, h->t_live_host.data(), two_sigma * tb_growth(), nb)) nb = CbTimeBasisHost{};
+  return tb_install(h, B, std::move(nb), std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+}
+// After every planned epoch of the trainer (`epoch` counts the optimisation's epochs, sigma is the finished solve's): keep a
+// basis in range WITHOUT stopping for the ~30 ms its construction takes.  When 2 sigma comes within a factor 1.6 of the range's
+// end (or has fallen 64 times below it) a helper thread starts on the next basis, for the sigma of that epoch; it is swapped in
+// CB_TB_LEAD epochs later -- or at once when 2 sigma reaches the headroom of 1.25 first (the thread is then waited for) --, i.e. at
+// an epoch that depends on the sigma sequence only: the optimisation's bits do not depend on the thread's timing.
+#ifndef CB_TB_LEAD
+#define CB_TB_LEAD 64
+#endif
+static int tb_maintain(cb_bank *h, int B, int epoch, double two_sigma, bool stale) {
+  if (cb_test_hook("CB_TB_TEST_GROWTH")) {   // (tests: no helper thread, no headroom -- the device finds the basis out of range)
+    if (stale) return tb_rebuild(h, B, two_sigma);
+    return CB_OK;
+  }
+  if (h->tb_failed) return CB_OK;
+  if (stale || !tb_in_range(h, B, two_sigma)) {
+    if (h->tb_next_pending) {   // the next one is under way (or done): take it now
+      CbTimeBasisHost nb = h->tb_next.get();
+      h->tb_next_pending = false;
+      int rc = tb_install(h, B, std::move(nb), -1.0);
+      if (rc != CB_OK || h->tb_failed) return rc;
+    }
+    if (stale || !tb_in_range(h, B, two_sigma)) return tb_rebuild(h, B, two_sigma);
+    return CB_OK;
+  }
+  if (h->tb_next_pending && epoch >= h->tb_next_epoch) {
+    CbTimeBasisHost nb = h->tb_next.get();
+    h->tb_next_pending = false;
+    int rc = tb_install(h, B, std::move(nb), -1.0);
+    if (rc != CB_OK || h->tb_failed) return rc;
+  }
+  if (!h->tb_next_pending && !tb_in_range(h, B, two_sigma, 1.6)) {
+    std::vector<double> t(h->t_live_host.begin(), h->t_live_host.begin() + B);
+    const double rho = two_sigma * tb_growth();
+    h->tb_next = std::async(std::launch::async, [t, rho, B]() {
+      CbTimeBasisHost nb;
+      if (!cb_tb_build(B, t.data(), rho, nb)) nb = CbTimeBasisHost{};
+      return nb;
+    });
+    h->tb_next_pending = true;
+    h->tb_next_epoch = epoch + CB_TB_LEAD;
+  }
   return CB_OK;
 }
 
@@ -210,9 +267,12 @@ static int large_eval(cb_bank *h, bool normalize, double *lossd, double *out, bo
   // forces it off / on (test hook), CB_PER_BUCKET_PRODUCTS at cb_create keeps every bucket's own products.  Behind a planned
   // solve the basis is the one the trainer kept in range with the previous epoch's sigma (lge_norms guards this epoch's: EC_SKIP);
   // otherwise the host reads sigma below (the host-driven solver has waited for the device several times by then).
+  // (a test hook that pins one of the per-bucket forms -- CB_BANK_FUSED / _UNFUSED / _K3 / _KG / _TEST_NO_CLAIM -- means those forms)
   const char *tb_hook = cb_test_hook("CB_BANK_TB");
+  const bool form_hooks = cb_test_hook("CB_BANK_FUSED") || cb_test_hook("CB_BANK_UNFUSED") || cb_test_hook("CB_BANK_K3") ||
+                          cb_test_hook("CB_BANK_KG") || cb_test_hook("CB_BANK_TEST_NO_CLAIM");
   bool use_tb = h->sym_counts && !h->per_bucket_products && !h->tb_block && !h->tb_failed && !Pd && dQd != nullptr && h->tb_Ls[0] &&
-                n_parts == 1 && h->dtype == CB_F64 && !h->comm && (tb_hook ? atoi(tb_hook) != 0 : B >= CB_TB_MIN_B);
+                n_parts == 1 && h->dtype == CB_F64 && !h->comm && (tb_hook ? atoi(tb_hook) != 0 : (!form_hooks && B >= CB_TB_MIN_B));
   if (use_tb && planned_now && h->tb.B != B) use_tb = false;
   // (the three bank kernels return at once when the planned solve in front of them stalled: EC_STALL)
   const unsigned long long *skipw = planned_now ? h->ectl + (use_tb ? EC_SKIP : EC_STALL) : nullptr;
@@ -249,13 +309,16 @@ static int large_eval(cb_bank *h, bool normalize, double *lossd, double *out, bo
       return fail(CB_EHIP, "tb_tables: launch failed");
     K1Args<double> k1{S, LD, nf, h->Vc, h->A, h->tb_tf[set], h->F, h->sigma, h->Ct, h->T, h->loss_part, inv_n, h->dsq, nullptr, skipw};
     LAUNCH_STOP(stop_event(h, EV_K1), (k1_pt_loss_gt<double, double, false, 1, true>), dim3(tiles_k1 * nf), dim3(LG4_THREADS), 0, h->stream, k1);
-    const CbTbEwArgs ew{S, LD, B, bas.ns, bas.nd, ng, h->Ct, h->T, h->A, tb, h->tb_Ls[set], h->tb_Lg[set], h->tb_kind[set], h->Gt, h->loss_part, inv_n, skipw};
-    if (cb_tb_launch_ew(ew, h->stream, nullptr) != 0) return fail(CB_EHIP, "tb_ew: launch failed");
+    const CbTbEwArgs ew{S, LD, B, bas.ns, bas.nd, ng, B - bas.nd, h->Ct, h->T, h->A, tb, h->tb_Ls[set], h->tb_Lg[set], h->Gt, h->loss_part, inv_n, skipw};
+    int ew_parts = 0;
+    // (phase marks of a time-basis evaluation: CB_T_K1 = tables + forward products, CB_T_K2 = the elementwise kernel,
+    // CB_T_K3 = the two gradient products, CB_T_K4 = the sum over the virtual buckets + K4)
+    if (cb_tb_launch_ew(ew, h->stream, stop_event(h, EV_K2), &ew_parts) != 0) return fail(CB_EHIP, "tb_ew: launch failed");
     K2Args<double> k2{LD, h->Gt, h->U, h->T, skipw};
-    LAUNCH_STOP(stop_event(h, EV_K2), (k2_t_eq_g_u<double, 1>), dim3(tiles * ng), dim3(LG4_THREADS), 0, h->stream, k2);
+    hipLaunchKernelGGL((k2_t_eq_g_u<double, 1>), dim3(tiles * ng), dim3(LG4_THREADS), 0, h->stream, k2);
     K3Args<double> k3{LD, ng, h->T, h->U, h->tb_tg[set], h->lam, h->E, h->H, h->Gt, 1, skipw};
     LAUNCH_STOP(stop_event(h, EV_K3), (k3_w_phi<double, 1>), dim3(tiles_k1 * ng), dim3(LG4_THREADS), 0, h->stream, k3);
-    const LossArgs la{h->loss_part, (int)(LL / 256), S, h->dsq, h->dirsum, inv_n, lossd, skipw};
+    const LossArgs la{h->loss_part, ew_parts, S, h->dsq, h->dirsum, inv_n, lossd, skipw};
     hipLaunchKernelGGL(k3_reduce_loss<double>, dim3((unsigned)((LL + 255) / 256) + 1), dim3(256), 0, h->stream, h->Gt, ng, LL, h->Mt, LD, la);
     K4Args k4a{S, LD, h->Mt, h->Vc, h->X, nullptr, nullptr, nullptr};
     k4a.skip = skipw;
@@ -799,6 +862,7 @@ extern "C" int cb_time_basis_info(cb_handle h, int *n, double *rho_max) {
   n[1] = h->tb.nd;
   n[2] = h->tb.ng;
   n[3] = h->tb_builds;
+  n[4] = h->tb_stale_epochs;
   *rho_max = h->tb.rho_max;
   return CB_OK;
 }

@@ -332,7 +332,7 @@ extern "C" int cb_create(int device, int S, int L, int B, int dtype, const doubl
     if (ok && !expm_only && !narrow)   // the time basis (tbasis.hip.h): interpolation matrices, bucket kinds, virtual branch lengths
       for (int k = 0; k < 2 && ok; ++k)
         ok = dev_alloc(h, &h->tb_Ls[k], (size_t)Bl * CB_TB_RS_MAX) == CB_OK && dev_alloc(h, &h->tb_Lg[k], (size_t)Bl * CB_TB_RG_MAX) == CB_OK &&
-             dev_alloc(h, &h->tb_tf[k], Bl) == CB_OK && dev_alloc(h, &h->tb_tg[k], Bl) == CB_OK && dev_alloc(h, &h->tb_kind[k], Bl) == CB_OK;
+             dev_alloc(h, &h->tb_tf[k], Bl) == CB_OK && dev_alloc(h, &h->tb_tg[k], Bl) == CB_OK;
     if (!ok) {
       free_tmp();
       return cleanup(CB_ENOMEM);
@@ -402,6 +402,7 @@ extern "C" int cb_create(int device, int S, int L, int B, int dtype, const doubl
 
 extern "C" void cb_destroy(cb_handle h) {
   if (!h) return;
+  if (h->tb_next_pending) (void)h->tb_next.get();   // (a helper thread still building the next time basis)
   (void)hipSetDevice(h->dev);
   if (h->own_stream) (void)hipStreamSynchronize(h->own_stream);
   for (hipEvent_t e : h->ev)

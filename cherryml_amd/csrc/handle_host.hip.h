@@ -2,6 +2,7 @@
 // pinned-staging allocation.  Included by cherrybank.hip (one translation unit; see eigh_large_host.hip.h).
 #pragma once
 #include <hip/hip_ext.h>
+#include <future>
 // ------------------------------------------------------------------ handle
 // plan of a device-controlled warm eigensolve (eigh_planned_host.hip.h)
 struct EighSlot {
@@ -97,8 +98,13 @@ struct cb_bank {
   CbTimeBasisHost tb;
   int tb_set = 0;
   double *tb_Ls[2] = {}, *tb_Lg[2] = {}, *tb_tf[2] = {}, *tb_tg[2] = {};
-  int *tb_kind[2] = {};
-  int tb_builds = 0;                    // cb_time_basis_info
+  // the NEXT basis, built by a helper thread while the optimisation runs on the current one (train_host.hip.h, tb_maintain):
+  // started when sigma comes within 1.6 of the range's end, swapped in at a fixed epoch -- results do not depend on how long
+  // the thread took
+  std::future<CbTimeBasisHost> tb_next;
+  bool tb_next_pending = false;
+  int tb_next_epoch = 0;
+  int tb_builds = 0, tb_stale_epochs = 0;   // cb_time_basis_info: bases built; evaluations repeated because theirs was out of range
   bool tb_failed = false;               // the grid needs more skeleton buckets than the maxima: the per-bucket forms, for good
   bool tb_block = false;                // this evaluation repeats one whose basis was out of range: per-bucket products
   bool bank_tb = false;                 // the last evaluation ran in the time basis

@@ -138,6 +138,8 @@ bool cb_tb_build(int B, const double *t, double rho_max, CbTimeBasisHost &out) {
   for (int i = 1; i < N; ++i) mu[i] = -(ld)rho_max * powl(10.0L, -6.0L + 6.0L * (ld)(i - 1) / (ld)(N - 2));
   out.B = B;
   out.rho_max = rho_max;
+  for (int b = 1; b < B; ++b)   // (an ascending grid -- the reference's is: the short-branch buckets are then a prefix)
+    if (!(t[b] >= t[b - 1])) return false;
   out.kind.assign(B, -1);
   std::vector<int> small_idx;
   for (int b = 0; b < B; ++b) {
@@ -212,88 +214,206 @@ __global__ void tb_tables(int LD, int ns, int nd, int ng, const double *__restri
   }
 }
 
-// One element (row, col) of ALL buckets per thread.  RS / RG: compile-time bounds of ns / ng (the arrays live in registers).
-// Loss partial per workgroup (fixed order inside: thread sums over b, wave sum, four waves), summed by lg_finish_loss_body.
+// The elementwise kernel.  A wavefront owns 16 consecutive elements (one row, columns c0 .. c0 + 15) of ALL buckets; lane
+// (j = l & 15, k = l >> 4) works on element j and, in every step of 16 buckets b0 .. b0 + 15, on the four buckets b0 + k + 4 m.
+// That is the register layout of v_mfma_f64_16x16x4, so the two contractions over the basis run on the matrix pipe while the
+// vector pipe does what is left per (element, bucket) -- P, log P, 1 / P, the loss term, G:
+//   forward   acc[b][e] = sum_r Ls[b][r] Psi_r(e):   A = Ls[b0 + (l & 15)][4 q + (l >> 4)], B = Psi_{4 q + k}(e_j) (RS / 4 registers
+//             per lane, loaded once), D register m = acc of bucket b0 + k + 4 m at element j -- exactly the lane's four pairs;
+//   backward  Gh_r(e) += sum_b Lg[b][r] G_b(e):      for m = 0 .. 3 the K-step {b0 + 4 m + k}: B = the lane's G of register m (no
+//             shuffle), A = Lg[b0 + 4 m + (l >> 4)][16 rho + (l & 15)], D tile rho register q = Gh of row 16 rho + k + 4 q at element j.
+// (As 48 v_fma_f64 per pair with the coefficients in SGPRs -- one element per thread, 96 accumulator VGPRs, the scalar loads of
+// every bucket's 48 coefficients waited for in place -- the kernel took 0.20 ms; the matrix pipe is idle otherwise.)
+// Ls / Lg / t live in LDS (zero rows behind the last bucket: a step that hangs over B adds nothing), shared by the 16 waves of
+// a workgroup.  The short-branch buckets are a PREFIX of the (ascending) grid: steps behind it skip the forward product and
+// read P_b of the long-branch buckets.  Loss partial per workgroup in a fixed order.
 template <int RS, int RG>
-__global__ __launch_bounds__(256) void tb_ew(CbTbEwArgs a) {
-  __shared__ double ltab[256];
-  __shared__ double sred[4];
-  if (a.skip && *a.skip != 0ull) return;
-  fast_log_table_fill(ltab, threadIdx.x, 256);
-  __syncthreads();
-  const size_t LL = (size_t)a.LD * a.LD, e = (size_t)blockIdx.x * 256 + threadIdx.x;   // (LD % 16 == 0: LL % 256 == 0)
-  const int row = (int)(e / a.LD), col = (int)(e - (size_t)row * a.LD);
-  const double *__restrict__ Ct = a.Ct + e;
-  const double *__restrict__ Psi = a.Psi + e;
-  const double *__restrict__ Ls = a.Ls;
-  const double *__restrict__ Lg = a.Lg;
-  const double *__restrict__ tb = a.t;
-  const int *__restrict__ kind = a.kind;
-  double psi[RS], G[RG];
+struct TbEwLds {
+  static constexpr int SS = RS + 1, SG = RG + 2;   // row strides (doubles)
+  int BP, LS, LG, TT, LT, RED, TOTAL;              // bucket rows (B rounded up to whole steps) and the offsets (doubles)
+  __host__ __device__ explicit TbEwLds(int B) {
+    BP = (B + 15) & ~15;
+    LS = 0;
+    LG = LS + BP * SS;
+    TT = LG + BP * SG;
+    LT = TT + BP;
+    RED = LT + 256;
+    TOTAL = RED + 16;
+  }
+};
+
+// One step of 16 buckets for the lane's four (element, bucket) pairs.  A step whose buckets are all short-branch ones skips the
+// P_b loads, one whose buckets are all long-branch ones the forward product (wave-uniform branches); the step that holds the
+// boundary does both and chooses per lane.
+// The logarithm is the table form WITHOUT its argument checks (it is finite for every bit pattern) and P is clamped at 1e-300
+// from below (v_max_f64: a NaN becomes 1e-300 as well): a pair with C = 0 then contributes 0 * finite = 0 to the loss and G = 0
+// whatever P is (a tiny entry rounded to <= 0, the pad, a bucket past the end) without a select; a pair with C != 0 whose P is
+// not a positive number sets `bad`, and the wave's loss partial becomes NaN.
+template <int RS, int RG>
+__device__ __forceinline__ void tb_ew_step(int b0, int j, int k, int nsm, const double *sLs, const double *sLg, const double *sT,
+                                           const double *ltab, const double (&psi)[RS / 4], double a_e, double dl, double inv_n,
+                                           const double (&c)[4], const double (&pd)[4], d4 (&D)[RG / 16], double &loss, int &bad) {
+  typedef TbEwLds<RS, RG> Lds;
+  const bool any_small = b0 < nsm, any_direct = b0 + 16 > nsm;   // (wave-uniform)
+  double P[4];
+  if (any_small) {
+    d4 acc = {0.0, 0.0, 0.0, 0.0};
+#ifndef TB_NO_FWD
 #pragma unroll
-  for (int r = 0; r < RS; ++r) psi[r] = r < a.ns ? Psi[(size_t)r * LL] : 0.0;
+    for (int q = 0; q < RS / 4; ++q) acc = mfma_f64(sLs[(b0 + j) * Lds::SS + 4 * q + k], psi[q], acc);
+#endif
 #pragma unroll
-  for (int r = 0; r < RG; ++r) G[r] = 0.0;
-  const double a_e = a.A[e], dl = row == col ? 1.0 : 0.0;
-  const double *__restrict__ Pd = Psi + (size_t)a.ns * LL;   // the direct buckets' P_b
-  double loss = 0.0;
-  constexpr int U = 4;   // buckets per group; the next group's counts (and direct P_b) are loaded before this group's arithmetic
-  double c[U], pd[U], cn[U], pn[U];
-  auto load = [&](int b0, double (&cc)[U], double (&pp)[U]) {
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int b = min(b0 + u, a.B - 1);
-      cc[u] = Ct[(size_t)b * LL];
-      const int k = kind[b];   // (wave-uniform)
-      pp[u] = k >= 0 ? Pd[(size_t)k * LL] : 0.0;
+    for (int m = 0; m < 4; ++m) {
+      const double t = sT[b0 + k + 4 * m];
+      P[m] = fma(t, fma(t, acc[m], a_e), dl);   // I + t A + t^2 sum_r Ls Psi_r: the t^2 outside keeps the O(t^2) entries' digits
     }
-  };
-  load(0, c, pd);
-  for (int b0 = 0; b0 < a.B; b0 += U) {
-    if (b0 + U < a.B) load(b0 + U, cn, pn);
+    if (any_direct) {
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int b = b0 + u;
-      if (b < a.B) {   // (wave-uniform)
-        double P;
-        if (kind[b] < 0) {
-          const double *__restrict__ l = Ls + (size_t)b * CB_TB_RS_MAX;
-          double s0 = 0.0, s1 = 0.0;   // two chains
+      for (int m = 0; m < 4; ++m) P[m] = (b0 + k + 4 * m < nsm) ? P[m] : pd[m];
+    }
+  } else {
 #pragma unroll
-          for (int r = 0; r + 1 < RS; r += 2) {
-            s0 = fma(l[r], psi[r], s0);
-            s1 = fma(l[r + 1], psi[r + 1], s1);
-          }
-          if (RS & 1) s0 = fma(l[RS - 1], psi[RS - 1], s0);
-          const double t = tb[b];
-          P = fma(t, fma(t, s0 + s1, a_e), dl);   // I + t A + t^2 sum_r Ls Psi_r: the t^2 outside keeps the O(t^2) entries' digits
-        } else {
-          P = pd[u];
-        }
-        const double cv = c[u];
-        const bool nz = cv != 0.0;   // (P <= 0 only where C = 0: rounding of a tiny entry, or the pad)
-        const double lg = fast_log_table(P, ltab), rc = fast_rcp(P);
-        loss = fma(-cv, nz ? lg : 0.0, loss);
-        const double g = nz ? -cv * a.inv_n * rc : 0.0;
-        const double *__restrict__ w = Lg + (size_t)b * CB_TB_RG_MAX;
+    for (int m = 0; m < 4; ++m) P[m] = pd[m];
+  }
+  double g[4];
 #pragma unroll
-        for (int r = 0; r < RG; ++r) G[r] = fma(w[r], g, G[r]);
+  for (int m = 0; m < 4; ++m) {
+    const double cv = c[m];
+    bad |= (!(P[m] >= 1e-300) && cv != 0.0) ? 1 : 0;
+    const double Pu = fmax(P[m], 1e-300);
+#ifdef TB_NO_LOG
+    loss = fma(-cv, Pu, loss);
+    g[m] = (-cv * inv_n) * Pu;
+#else
+    loss = fma(-cv, fast_log_table_unchecked(Pu, ltab), loss);
+    g[m] = (-cv * inv_n) * fast_rcp(Pu);
+#endif
+  }
+#ifdef TB_NO_BWD
+#pragma unroll
+  for (int m = 0; m < 4; ++m) D[0][m] += g[m];
+#else
+#pragma unroll
+  for (int m = 0; m < 4; ++m) {
+    const double *w = sLg + (b0 + 4 * m + k) * Lds::SG + j;
+#pragma unroll
+    for (int q = 0; q < RG / 16; ++q) D[q] = mfma_f64(w[16 * q], g[m], D[q]);
+  }
+#endif
+}
+
+template <int RS, int RG>
+__global__ __launch_bounds__(1024) void tb_ew(CbTbEwArgs a) {
+  typedef TbEwLds<RS, RG> Lds;
+  extern __shared__ double smem[];
+  if (a.skip && *a.skip != 0ull) return;
+  const Lds o(a.B);
+  double *sLs = smem + o.LS, *sLg = smem + o.LG, *sT = smem + o.TT, *ltab = smem + o.LT, *sred = smem + o.RED;
+  const int tid = threadIdx.x;
+  for (int i = tid; i < o.BP * RS; i += 1024) {
+    const int b = i / RS, r = i - b * RS;
+    sLs[b * Lds::SS + r] = b < a.B ? a.Ls[(size_t)b * CB_TB_RS_MAX + r] : 0.0;
+  }
+  for (int i = tid; i < o.BP * RG; i += 1024) {
+    const int b = i / RG, r = i - b * RG;
+    sLg[b * Lds::SG + r] = (b < a.B && r < CB_TB_RG_MAX) ? a.Lg[(size_t)b * CB_TB_RG_MAX + r] : 0.0;
+  }
+  for (int i = tid; i < o.BP; i += 1024) sT[i] = i < a.B ? a.t[i] : 0.0;
+  fast_log_table_fill(ltab, tid, 1024);
+  __syncthreads();
+  const size_t LL = (size_t)a.LD * a.LD;
+  const int wave = tid >> 6, lane = tid & 63, j = lane & 15, k = lane >> 4;
+  const size_t e = ((size_t)blockIdx.x * 16 + wave) * 16 + j;     // (LD % 16 == 0: the 16 elements share a row)
+  const bool live = e < LL;                                       // (a whole wave: LL % 16 == 0)
+  const size_t ec = live ? e : 0;
+  const int row = (int)(ec / a.LD), col = (int)(ec - (size_t)row * a.LD);
+  const double *__restrict__ Psi = a.Psi + ec;
+  double psi[RS / 4];
+#pragma unroll
+  for (int q = 0; q < RS / 4; ++q) psi[q] = (4 * q + k < a.ns) ? Psi[(size_t)(4 * q + k) * LL] : 0.0;
+  const double a_e = a.A[ec], dl = row == col ? 1.0 : 0.0;
+  d4 D[RG / 16];
+#pragma unroll
+  for (int q = 0; q < RG / 16; ++q) D[q] = d4{0.0, 0.0, 0.0, 0.0};
+  double loss = 0.0;
+  int bad = 0;
+  const int nsm = a.nsmall, B = a.B;
+  // counts and long-branch P_b through BUFFER loads: the lane's byte offsets inside a step are fixed (element + bucket k + 4 m of
+  // the step) and the step is a scalar offset -- no address arithmetic in the loop.  Only the step that hangs over the end of
+  // the bank (and, for P_b, the one that holds the first long-branch bucket) checks its buckets, behind a wave-uniform branch.
+  // (LD <= 1024 and (B + 32) 8 LD^2 < 2^31 keep the offsets inside 31 bits: cb_tb_launch_ew checks)
+  const unsigned plane = (unsigned)(LL * sizeof(double));
+  const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(a.Ct), 0, 0x7fffffff, 0x00027000);
+  const __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(a.Psi + (size_t)a.ns * LL), 0, 0x7fffffff, 0x00027000);
+  const int eoff = (int)(ec * sizeof(double));
+  int voff[4];
+#pragma unroll
+  for (int m = 0; m < 4; ++m) voff[m] = (int)((unsigned)(k + 4 * m) * plane) + eoff;
+  auto load = [&](int b0, double (&cc)[4], double (&pp)[4]) {
+    if (b0 >= B) return;
+#ifdef TB_NO_LOAD
+    for (int m = 0; m < 4; ++m) cc[m] = 1.0 + b0 + m, pp[m] = 0.5;
+    return;
+#endif
+    if (b0 + 16 <= B) {   // (wave-uniform)
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+        cc[m] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rc, voff[m], (int)((unsigned)b0 * plane), 0));
+      if (b0 >= nsm) {
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+          pp[m] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rp, voff[m], (int)((unsigned)(b0 - nsm) * plane), 0));
+        return;
+      }
+      if (b0 + 16 <= nsm) return;   // short-branch buckets only: no P_b
+    } else {
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        const bool in = b0 + k + 4 * m < B;
+        const double v = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rc, in ? voff[m] + (int)((unsigned)b0 * plane) : eoff, 0, 0));
+        cc[m] = in ? v : 0.0;
       }
     }
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-      c[u] = cn[u];
-      pd[u] = pn[u];
+    for (int m = 0; m < 4; ++m) {   // the boundary step, or the last one: every bucket checked
+      const int b = b0 + k + 4 * m;
+      const bool in = b >= nsm && b < B;
+      const double v = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rp, (int)((unsigned)(in ? b - nsm : 0) * plane) + eoff, 0, 0));
+      pp[m] = in ? v : 1.0;
     }
+  };
+  // two steps per iteration: the loads of the next step in flight during a step's arithmetic, ping-pong registers
+  double c0[4] = {0.0, 0.0, 0.0, 0.0}, c1[4] = {0.0, 0.0, 0.0, 0.0}, p0[4] = {1.0, 1.0, 1.0, 1.0}, p1[4] = {1.0, 1.0, 1.0, 1.0};
+  load(0, c0, p0);
+  for (int b0 = 0; b0 < B; b0 += 32) {
+    load(b0 + 16, c1, p1);
+    tb_ew_step<RS, RG>(b0, j, k, nsm, sLs, sLg, sT, ltab, psi, a_e, dl, a.inv_n, c0, p0, D, loss, bad);
+    if (b0 + 16 >= B) break;
+    load(b0 + 32, c0, p0);
+    tb_ew_step<RS, RG>(b0 + 16, j, k, nsm, sLs, sLg, sT, ltab, psi, a_e, dl, a.inv_n, c1, p1, D, loss, bad);
   }
-  double *__restrict__ Gh = a.Gh + e;
+  if (live) {
+    double *__restrict__ Gh = a.Gh + e;
 #pragma unroll
-  for (int r = 0; r < RG; ++r)
-    if (r < a.ng) Gh[(size_t)r * LL] = G[r];
+    for (int q = 0; q < RG / 16; ++q)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int rr = 16 * q + k + 4 * r;
+        if (rr < a.ng) Gh[(size_t)rr * LL] = D[q][r];
+      }
+  } else {
+    loss = 0.0;
+    bad = 0;
+  }
+  if (bad) loss = NAN;
   loss = wave_sum(loss);
-  if ((threadIdx.x & 63) == 0) sred[threadIdx.x >> 6] = loss;
+  if (lane == 0) sred[wave] = loss;
   __syncthreads();
-  if (threadIdx.x == 0) a.loss_part[blockIdx.x] = (sred[0] + sred[1]) + (sred[2] + sred[3]);
+  if (tid == 0) {
+    double s = 0.0;
+    for (int w = 0; w < 16; ++w) s += sred[w];
+    a.loss_part[blockIdx.x] = s;
+  }
 }
 
 int cb_tb_launch_tables(int LD, int ns, int nd, int ng, const double *tf, const double *tg, const double *lam, double *F, double *E,
@@ -303,25 +423,35 @@ int cb_tb_launch_tables(int LD, int ns, int nd, int ng, const double *tf, const 
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
-int cb_tb_launch_ew(const CbTbEwArgs &a, hipStream_t stream, hipEvent_t stop) {
-  const unsigned grid = (unsigned)(((size_t)a.LD * a.LD) / 256);
-  if (a.ns > CB_TB_RS_MAX || a.ng > CB_TB_RG_MAX) return -1;
-#define TB_GO(RS_, RG_)                                                                                        \
-  do {                                                                                                         \
-    if (stop) hipExtLaunchKernelGGL((tb_ew<RS_, RG_>), dim3(grid), dim3(256), 0, stream, nullptr, stop, 0, a); \
-    else hipLaunchKernelGGL((tb_ew<RS_, RG_>), dim3(grid), dim3(256), 0, stream, a);                           \
+size_t cb_tb_ew_lds_bytes(int B, int ns, int ng) {
+  const int RS = ns <= 16 ? 16 : 24, RG = ng <= 32 ? 32 : 48;
+  const int BP = (B + 15) & ~15;
+  return ((size_t)BP * (RS + 1 + RG + 2 + 1) + 256 + 16) * sizeof(double);
+}
+
+int cb_tb_launch_ew(const CbTbEwArgs &a, hipStream_t stream, hipEvent_t stop, int *nparts) {
+  const size_t LL = (size_t)a.LD * a.LD;
+  const unsigned grid = (unsigned)((LL / 16 + 15) / 16);   // 16 waves of 16 elements per workgroup
+  if (nparts) *nparts = (int)grid;
+  if (a.ns > CB_TB_RS_MAX || a.ng > CB_TB_RG_MAX || a.LD % 16 != 0 || cb_tb_ew_lds_bytes(a.B, a.ns, a.ng) > CB_TB_LDS_MAX ||
+      (double)(a.B + 32) * (double)LL * 8.0 >= 2147483648.0)   // (the buffer loads' 31-bit offsets)
+    return -1;
+#define TB_GO(RS_, RG_)                                                                                                  \
+  do {                                                                                                                   \
+    const size_t lds = (size_t)TbEwLds<RS_, RG_>(a.B).TOTAL * sizeof(double);                                            \
+    static size_t attr_set = 0;   /* (the largest size asked for so far) */                                              \
+    if (lds > attr_set) {                                                                                                \
+      if (hipFuncSetAttribute(reinterpret_cast<const void *>(tb_ew<RS_, RG_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) \
+        return -1;                                                                                                       \
+      attr_set = lds;                                                                                                    \
+    }                                                                                                                    \
+    if (stop) hipExtLaunchKernelGGL((tb_ew<RS_, RG_>), dim3(grid), dim3(1024), lds, stream, nullptr, stop, 0, a);        \
+    else hipLaunchKernelGGL((tb_ew<RS_, RG_>), dim3(grid), dim3(1024), lds, stream, a);                                  \
   } while (0)
-#define TB_RG(RS_)                  \
-  do {                              \
-    if (a.ng <= 24) TB_GO(RS_, 24); \
-    else if (a.ng <= 28) TB_GO(RS_, 28); \
-    else if (a.ng <= 32) TB_GO(RS_, 32); \
-    else if (a.ng <= 36) TB_GO(RS_, 36); \
-    else TB_GO(RS_, 40);            \
-  } while (0)
-  if (a.ns <= 16) TB_RG(16);
-  else TB_RG(24);
-#undef TB_RG
+  if (a.ns <= 16 && a.ng <= 32) TB_GO(16, 32);
+  else if (a.ns <= 16) TB_GO(16, 48);
+  else if (a.ng <= 32) TB_GO(24, 32);
+  else TB_GO(24, 48);
 #undef TB_GO
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }

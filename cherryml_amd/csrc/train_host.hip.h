@@ -143,6 +143,7 @@ static int run_fused_training_large(cb_bank *h, double *pi_param, double *up_par
   // the bank's time basis (tbasis.hip.h) is part of the optimisation's state as well: a fresh optimisation builds its own from
   // its first matrix (the same bits whatever ran on the handle before), a resumed one continues with the one it has
   if (!resume) {
+    tb_drop_next(h);
     h->tb = CbTimeBasisHost{};
     h->tb_failed = false;
   }
@@ -210,7 +211,7 @@ static int run_fused_training_large(cb_bank *h, double *pi_param, double *up_par
       if (rc == CB_OK && !host_solved && h->bank_tb) {
         // The time basis against this solve's sigma.  Out of range (lge_norms saw it too: the bank, the reduction and K4 returned
         // at once): the evaluation is repeated on the finished decomposition with per-bucket products.  Close to the end of
-        // the range, or far below it: a new basis for the next epoch (host: ~25 ms, a few times per optimisation at most).
+        // the range, or far below it: a new basis, built by a helper thread beside the epochs (tb_maintain, cherrybank.hip).
         if (rec.tb_stale) {
           for (bool &b : h->ev_rec) b = false;
           mark(h, EV_START);
@@ -218,7 +219,8 @@ static int run_fused_training_large(cb_bank *h, double *pi_param, double *up_par
           rc = large_eval(h, flags & CB_NORMALIZE, h->loss, h->Mt, true, nullptr, true, nullptr);
           h->tb_block = false;
         }
-        if (rc == CB_OK && !tb_in_range(h, h->Bl, 2.0 * rec.sigma)) rc = tb_rebuild(h, h->Bl, 2.0 * rec.sigma);
+        if (rc == CB_OK) rc = tb_maintain(h, h->Bl, e0 + e, 2.0 * rec.sigma, rec.tb_stale);
+        if (rc == CB_OK && rec.tb_stale) ++h->tb_stale_epochs;
       }
       if (rc == CB_OK) {
         const EighPlan prev = plan;

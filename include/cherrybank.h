@@ -195,7 +195,9 @@ int cb_last_kernel_form(cb_handle h);
 int cb_last_bank_form(cb_handle h);
 /* The time basis of the last evaluation that used one: n[0] = skeleton buckets of the short-branch forward family, n[1] =
  * long-branch buckets that keep their own product, n[2] = skeleton buckets of the gradient family, n[3] = how often the
- * basis has been built on this handle; rho_max = the spectral bound it serves.  All zero when none has been built. */
+ * basis has been built on this handle, n[4] = how many training epochs found their matrix outside the basis' range on the
+ * device and were repeated with per-bucket products (n has room for 5 ints); rho_max = the spectral bound it serves.  All
+ * zero when none has been built. */
 int cb_time_basis_info(cb_handle h, int *n, double *rho_max);
 /* HOST-ONLY (no GPU needed): the interpolative decomposition over the branch-length grid that the S > 32 bank uses when it has
  * >= 64 live buckets with symmetric counts (float64).  Every per-bucket quantity of the bank is a smooth function of t_b on

@@ -50,3 +50,15 @@ def test_site_bank_kernel_keeps_three_workgroups_per_cu(meta):
     assert hits, "sp_bank<5, true, true> not found"
     for name, c in hits.items():
         assert c["vgpr"] <= 168 and c["vgpr_spill"] <= 12, (name, c)   # (9 today: outside the tile loops)
+
+
+def test_time_basis_kernels(meta):
+    # tb_ew: 16 waves of one workgroup per CU = four per SIMD -> <= 128 VGPRs; nothing spilled inside its loop (a couple of
+    # dwords around it is what it has today); the skeleton products are k1_pt_loss_gt's RAW form (checked above with its siblings)
+    hits = _find(meta, "void tb_ew<")
+    assert len(hits) == 4, sorted(hits)
+    for name, c in hits.items():
+        # (the forms with 24 forward / 48 gradient skeleton slots -- wider spectral ranges than any bank so far -- hold more
+        # accumulators and spill a few of them around the loop)
+        assert c["vgpr"] <= 128 and c["vgpr_spill"] <= (8 if "<16, 32>" in name else 64), (name, c)
+    assert any("k1_pt_loss_gt<double, double, false, 1, true>" in n for n in meta)
