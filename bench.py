@@ -598,11 +598,64 @@ def main():
             epoch_tflops = epoch_flops / (dt / steps) / 1e12
             util, util_src = _mfma_util(bank_dtype)
             fused = bank_form["fused"]   # CB_T_K1 = the one span of the fused launch
+            tbasis = bank_form.get("time_basis", False)
             # symmetric counts (every bench bank): the buckets are summed BEFORE the last product -- no third product per
             # bucket ("bucket sum first"): the launch then holds K1 and K2 only
             sum_first = bank_form["bucket_sum_first"]
             n_prod = 2.0 if sum_first else 3.0
-            if fused:
+            if tbasis:
+                # The bank in a TIME BASIS (csrc/tbasis.hip.h): products on ns + nd forward and ng gradient VIRTUAL buckets,
+                # one elementwise kernel over all B buckets in between.  Phases: k1 = tables + the forward products, k2 = the
+                # elementwise kernel, k3 = the two gradient products (two launches), k4 = sum over the virtual buckets + K4.
+                info = (bank.bank if hasattr(bank, "bank") else bank).time_basis_info()
+                ns, nd, ng = info["forward_skeleton"], info["direct"], info["gradient_skeleton"]
+                one = 2.0 * S ** 3                                   # one S^3 product
+                LDp = -(-S // 16) * 16
+                ew_pairs = float(LDp) * LDp * B_local                # (element, bucket) pairs the elementwise kernel visits
+                ew_mfma = 2.0 * ew_pairs * ((16 if ns <= 16 else 24) + (32 if ng <= 32 else 48))   # its two contractions on MFMA
+                kern = {
+                    "k1": dict(kernel="k1_pt_loss_gt<double, RAW> (forward products: %d skeleton + %d long-branch buckets)" % (ns, nd),
+                               bound="mfma", algorithmic=(ns + nd) * one, executed=(ns + nd) * one * tri, unit="TFLOP/s", peak=F64_PEAK_TFLOPS),
+                    "k2": dict(kernel="tb_ew (every element of all %d buckets: P, log P, 1 / P, loss, G, the %d sums)" % (B_local, ng),
+                               bound="hbm", algorithmic=8.0 * S * S * (B_local + ns + nd + ng), executed=None, unit="GB/s", peak=HBM_PEAK_GBS),
+                    "k3": dict(kernel="k2_t_eq_g_u<double> + k3_w_phi<double> (gradient products on %d virtual buckets, two launches)" % ng,
+                               bound="mfma", algorithmic=2 * ng * one, executed=ng * one * (1.0 + tri), unit="TFLOP/s", peak=F64_PEAK_TFLOPS),
+                }
+                for k, d in kern.items():
+                    sc = 1e12 if d["unit"] == "TFLOP/s" else 1e9
+                    d["ms"] = tm[k]
+                    d["achieved"] = d["algorithmic"] / (tm[k] * 1e-3) / sc if tm[k] > 0 else 0.0
+                    d["frac"] = d["achieved"] / d["peak"]
+                    if d["executed"] is not None:
+                        d["executed_frac"] = d["executed"] / (tm[k] * 1e-3) / sc / d["peak"] if tm[k] > 0 else 0.0
+                kern["k2"]["fp64_pipe_frac"] = (ew_mfma + 60.0 * ew_pairs) / (tm["k2"] * 1e-3) / 1e12 / F64_PEAK_TFLOPS if tm["k2"] > 0 else 0.0
+                dom = max(kern, key=lambda k: tm[k])
+                t_bank = tm["k1"] + tm["k2"] + tm["k3"]
+                d = kern[dom]
+                roofline = dict(bound=d["bound"], kernel=d["kernel"], achieved=d["achieved"], peak=d["peak"], unit=d["unit"], frac=d["frac"],
+                                **({"executed_frac": d["executed_frac"]} if "executed_frac" in d else {}),
+                                epoch_frac=epoch_tflops / (F64_PEAK_TFLOPS * world), epoch_tflops=epoch_tflops, epoch_flops=epoch_flops,
+                                traffic=traffic.get("tb:" + dom) if world == 1 else None,
+                                traffic_source=_traffic_source() if world == 1 else None,
+                                ms_per_launch=tm[dom], algorithmic_per_launch=d["algorithmic"],
+                                time_basis=dict(forward_skeleton=ns, long_branch_buckets=nd, gradient_skeleton=ng, rho_max=info["rho_max"],
+                                                bases_built=info["builds"], repeated_epochs=info["repeated_epochs"]),
+                                bank_vs_per_bucket_pricing=dict(
+                                    ms=round(t_bank, 4), flops_6BS3=3.0 * flops, tflops=3.0 * flops / (t_bank * 1e-3) / 1e12,
+                                    x_f64_peak=3.0 * flops / (t_bank * 1e-3) / 1e12 / F64_PEAK_TFLOPS,
+                                    executed_flops=kern["k1"]["executed"] + kern["k3"]["executed"] + ew_mfma,
+                                    executed_frac=(kern["k1"]["executed"] + kern["k3"]["executed"] + ew_mfma) / (t_bank * 1e-3) / 1e12 / F64_PEAK_TFLOPS,
+                                    note="SURVEY 8d prices the bank at 6 B S^3 (three products per bucket); the time basis needs "
+                                         "(ns + nd) + 2 ng products instead of 3 B, so the bank as a whole runs ABOVE the f64 peak "
+                                         "at that price (x_f64_peak) -- the algorithm got cheaper; executed_frac is what the "
+                                         "matrix pipe multiplies in the three phases over their time"),
+                                per_kernel={k: {kk: (round(vv, 4) if isinstance(vv, float) else vv) for kk, vv in v.items()} for k, v in kern.items()},
+                                note="the dominant bank phase of a time-basis evaluation (phase_ms: k1 = forward products, k2 = "
+                                     "elementwise kernel, k3 = gradient products); achieved = that phase's OWN algorithmic work "
+                                     "(S^3 products on its virtual buckets, Pt / W symmetric halves counted whole; bytes the "
+                                     "elementwise kernel must move once) / its time; epoch_frac prices the WHOLE epoch at SURVEY's "
+                                     "6 B S^3 + 13 S^3 whatever is executed")
+            elif fused:
                 # K1 -> K2 (-> K3) as ONE persistent launch (k123_bank): algorithmic flops = its products, 2 B S^3 each
                 # (SURVEY 8d); executed = (tri + 1 [+ tri]) of 2 B S^3: Pt and, with symmetric counts, W are symmetric
                 sym3 = 0.0 if sum_first else tri

@@ -315,8 +315,10 @@ static int large_eval(cb_bank *h, bool normalize, double *lossd, double *out, bo
     // CB_T_K3 = the two gradient products, CB_T_K4 = the sum over the virtual buckets + K4)
     if (cb_tb_launch_ew(ew, h->stream, stop_event(h, EV_K2), &ew_parts) != 0) return fail(CB_EHIP, "tb_ew: launch failed");
     K2Args<double> k2{LD, h->Gt, h->U, h->T, skipw};
-    hipLaunchKernelGGL((k2_t_eq_g_u<double, 1>), dim3(tiles * ng), dim3(LG4_THREADS), 0, h->stream, k2);
     K3Args<double> k3{LD, ng, h->T, h->U, h->tb_tg[set], h->lam, h->E, h->H, h->Gt, 1, skipw};
+    // (as ONE persistent launch -- k123_bank with an empty first stage, K3' tiles of a virtual bucket filling the drain of its
+    // K2' tiles -- the pair took 0.227 ms against 0.146 for the two launches: ~30 buckets are a short bank, EXPERIMENTS section 13)
+    hipLaunchKernelGGL((k2_t_eq_g_u<double, 1>), dim3(tiles * ng), dim3(LG4_THREADS), 0, h->stream, k2);
     LAUNCH_STOP(stop_event(h, EV_K3), (k3_w_phi<double, 1>), dim3(tiles_k1 * ng), dim3(LG4_THREADS), 0, h->stream, k3);
     const LossArgs la{h->loss_part, ew_parts, S, h->dsq, h->dirsum, inv_n, lossd, skipw};
     hipLaunchKernelGGL(k3_reduce_loss<double>, dim3((unsigned)((LL + 255) / 256) + 1), dim3(256), 0, h->stream, h->Gt, ng, LL, h->Mt, LD, la);

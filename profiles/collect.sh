@@ -13,9 +13,11 @@ export HSA_ENABLE_IPC_MODE_LEGACY=${HSA_ENABLE_IPC_MODE_LEGACY:-0}
 # plain (unprofiled) lines first, on the fresh box, as the driver runs them
 python3 $R/bench.py --steps 20 --warmup 5 > $R/gpurun_out/${TAG}_bench_driver.log 2>&1
 python3 $R/bench.py > $R/gpurun_out/${TAG}_bench_default.log 2>&1
-for v in "coevo400 f64" "coevo400 mixed" "coevo400 f32" "coevo400_demo f64" "coevo400 f64 shard8" "lg20 f64" "siterm f64" "counting f64" "co_counting f64" "ble f64" "assembly f64" "likelihood f64"; do
+for v in "coevo400 f64" "coevo400 f64 perbucket" "coevo400 mixed" "coevo400 f32" "coevo400_demo f64" "coevo400 f64 shard8" "lg20 f64" "siterm f64" "counting f64" "co_counting f64" "ble f64" "assembly f64" "likelihood f64"; do
   set -- $v; w=$1; dt=$2; name=$w; [ "$dt" != "f64" ] && name=${w}_$dt
   extra=""; if [ "${3:-}" = "shard8" ]; then name=${w}_shard8; extra="--shard-of 8"; fi   # rank 0's share of an 8-rank job on this GPU
+  # the same bank with three products per bucket (test hook CB_BANK_TB=0): the form the time basis replaced
+  unset CB_BANK_TB; if [ "${3:-}" = "perbucket" ]; then name=${w}_perbucket; export CB_BANK_TB=0; fi
   # the bench line of this workload UNPROFILED (kernel tracing adds a few percent to launch-bound epochs) ...
   python3 $R/bench.py --workload $w --dtype $dt $extra --no-cpu-baseline --no-secondary > $R/gpurun_out/${TAG}_bench_$name.log 2>&1
   # ... and the same command under the kernel trace for the per-kernel statistics
@@ -26,6 +28,7 @@ for v in "coevo400 f64" "coevo400 mixed" "coevo400 f32" "coevo400_demo f64" "coe
       python3 $R/bench.py --workload $w --dtype $dt $extra --steps 3 --warmup 1 --no-cpu-baseline --no-secondary > /dev/null 2>&1
   done
 done
+unset CB_BANK_TB
 for dt in f64 mixed f32; do
   rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA \
     --output-format csv -d $R/gpurun_out/${TAG}_pmc_sq_$dt -- \

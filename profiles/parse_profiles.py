@@ -36,8 +36,8 @@ NAMES = ["k123_bank", "k1_pt_loss_gt", "k2_t_eq_g_u", "k3_w_phi", "lgj_round", "
          "lg_prepare", "lg_bank", "lg_finish", "count_transitions_lds_kernel", "count_reduce_slabs", "k3_reduce", "sp_prepare",
          "sp_bank", "sp_finish", "sp_step", "sg_gemm", "co_bucket_kernel", "co_plan_kernel", "co_expand_kernel", "co_count_lds_kernel", "lgx_build", "ble_branch_lengths_kernel", "ble_site_rates_kernel",
          "siterm_raw_counts_kernel", "siterm_mix_kernel", "tl_mfma_kernel", "tl_leaf_kernel", "tl_group_kernel", "lg_cast_f32", "lge_gram", "lge_gemm", "lge_so", "lge_decide", "lge_poly",
-         "jtt_stats_partial", "ky_reduce_loss", "kphi_combine", "k3_reduce_loss"]
-WORKLOADS = ["coevo400", "coevo400_mixed", "coevo400_f32", "coevo400_demo", "coevo400_shard8", "lg20", "siterm", "counting", "co_counting",
+         "jtt_stats_partial", "ky_reduce_loss", "kphi_combine", "k3_reduce_loss", "tb_ew", "tb_tables"]
+WORKLOADS = ["coevo400", "coevo400_perbucket", "coevo400_mixed", "coevo400_f32", "coevo400_demo", "coevo400_shard8", "lg20", "siterm", "counting", "co_counting",
              "ble", "assembly", "likelihood"]
 
 
@@ -98,6 +98,11 @@ if all(f"{k}:counting" in bpl for k in ("count_transitions_lds_kernel", "count_r
 co = ("co_bucket_kernel", "co_plan_kernel", "co_expand_kernel", "co_count_lds_kernel")
 if all(f"{k}:co_counting" in bpl for k in co):
     bpl["pass:co_counting"] = sum(bpl[f"{k}:co_counting"] for k in co)
+if "tb_ew" in bpl:   # the time-basis bank (default float64 form of the headline): its three phases as bench.py names them
+    bpl["tb:k1"] = bpl.get("k1_pt_loss_gt")
+    bpl["tb:k2"] = bpl["tb_ew"]
+    if "k2_t_eq_g_u" in bpl and "k3_w_phi" in bpl:
+        bpl["tb:k3"] = bpl["k2_t_eq_g_u"] + bpl["k3_w_phi"]
 json.dump(out, open(f"{here}/pmc_traffic.json", "w"), indent=1)
 for src, dst in ((f"{tag}_tile_timeline_fused.txt", f"{rnd}_bank_tile_timeline_fused.txt"),
                  (f"{tag}_tile_timeline_separate.txt", f"{rnd}_bank_tile_timeline_separate.txt"),
@@ -132,7 +137,7 @@ for dt, w in (("f64", "coevo400"), ("mixed", "coevo400_mixed"), ("f32", "coevo40
     agg = collections.defaultdict(lambda: collections.defaultdict(list))
     for r in csv.DictReader(open(fs[0])):
         short = kshort(r["Kernel_Name"])
-        if short and short.startswith(("k123_", "k1_", "k2_", "k3_w")):
+        if short and short.startswith(("k123_", "k1_", "k2_", "k3_w", "tb_ew")):
             agg[short][r["Counter_Name"]].append(float(r["Counter_Value"]))
     for k, d in agg.items():
         m = {c: sum(v) / len(v) for c, v in d.items()}
