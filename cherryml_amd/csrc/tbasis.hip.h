@@ -302,29 +302,51 @@ __device__ __forceinline__ void tb_ew_step(int b0, int j, int k, int nsm, const 
 #endif
 }
 
-template <int RS, int RG>
-__global__ __launch_bounds__(1024) void tb_ew(CbTbEwArgs a) {
+// SYM (the bank's counts are symmetric -- the only banks the time basis serves --, so is every P_b, G_b and Gh_r): only the
+// 16 x 16 blocks (I, J >= I) of the upper block triangle are visited -- item = (block, row of the block), workgroup = eight rows
+// of a block (two workgroups per CU) --, the loss terms of an off-diagonal block count twice, and tb_mirror copies the blocks of
+// Gh_r across the diagonal afterwards: 52 % of the pairs, reads and products of the full matrix.
+template <int RS, int RG, int NWAVE, bool SYM>
+__global__ __launch_bounds__(NWAVE * 64, 4) void tb_ew(CbTbEwArgs a) {   // (four waves per SIMD: 128 registers)
+  constexpr int NT = NWAVE * 64;
   typedef TbEwLds<RS, RG> Lds;
   extern __shared__ double smem[];
   if (a.skip && *a.skip != 0ull) return;
   const Lds o(a.B);
   double *sLs = smem + o.LS, *sLg = smem + o.LG, *sT = smem + o.TT, *ltab = smem + o.LT, *sred = smem + o.RED;
   const int tid = threadIdx.x;
-  for (int i = tid; i < o.BP * RS; i += 1024) {
+  for (int i = tid; i < o.BP * RS; i += NT) {
     const int b = i / RS, r = i - b * RS;
     sLs[b * Lds::SS + r] = b < a.B ? a.Ls[(size_t)b * CB_TB_RS_MAX + r] : 0.0;
   }
-  for (int i = tid; i < o.BP * RG; i += 1024) {
+  for (int i = tid; i < o.BP * RG; i += NT) {
     const int b = i / RG, r = i - b * RG;
     sLg[b * Lds::SG + r] = (b < a.B && r < CB_TB_RG_MAX) ? a.Lg[(size_t)b * CB_TB_RG_MAX + r] : 0.0;
   }
-  for (int i = tid; i < o.BP; i += 1024) sT[i] = i < a.B ? a.t[i] : 0.0;
-  fast_log_table_fill(ltab, tid, 1024);
+  for (int i = tid; i < o.BP; i += NT) sT[i] = i < a.B ? a.t[i] : 0.0;
+  fast_log_table_fill(ltab, tid, NT);
   __syncthreads();
   const size_t LL = (size_t)a.LD * a.LD;
   const int wave = tid >> 6, lane = tid & 63, j = lane & 15, k = lane >> 4;
-  const size_t e = ((size_t)blockIdx.x * 16 + wave) * 16 + j;     // (LD % 16 == 0: the 16 elements share a row)
-  const bool live = e < LL;                                       // (a whole wave: LL % 16 == 0)
+  size_t e;
+  bool live;
+  double lossw = 1.0;
+  if (SYM) {
+    // item -> (block (I, J >= I) of the upper block triangle, row of the block): row I of the triangle holds nb - I blocks
+    const int nb = a.LD / 16, item = (int)blockIdx.x * NWAVE + wave, blk = item >> 4, rr = item & 15;
+    int I = 0, rest = blk;
+    while (I < nb && rest >= nb - I) {
+      rest -= nb - I;
+      ++I;
+    }
+    live = I < nb;
+    const int J = I + rest;
+    e = live ? ((size_t)(16 * I + rr) * a.LD + 16 * J + j) : 0;
+    lossw = J > I ? 2.0 : 1.0;
+  } else {
+    e = ((size_t)blockIdx.x * NWAVE + wave) * 16 + j;     // (LD % 16 == 0: the 16 elements share a row)
+    live = e < LL;                                       // (a whole wave: LL % 16 == 0)
+  }
   const size_t ec = live ? e : 0;
   const int row = (int)(ec / a.LD), col = (int)(ec - (size_t)row * a.LD);
   const double *__restrict__ Psi = a.Psi + ec;
@@ -406,14 +428,32 @@ __global__ __launch_bounds__(1024) void tb_ew(CbTbEwArgs a) {
     bad = 0;
   }
   if (bad) loss = NAN;
-  loss = wave_sum(loss);
+  loss = wave_sum(loss) * lossw;
   if (lane == 0) sred[wave] = loss;
   __syncthreads();
   if (tid == 0) {
     double s = 0.0;
-    for (int w = 0; w < 16; ++w) s += sred[w];
+    for (int w = 0; w < NWAVE; ++w) s += sred[w];
     a.loss_part[blockIdx.x] = s;
   }
+}
+
+// Gh_r(16 J + c, 16 I + r) = Gh_r(16 I + r, 16 J + c) for the blocks I < J: one workgroup per (block, virtual bucket), the block
+// through LDS so that both sides move in 128-byte rows.
+__global__ __launch_bounds__(256) void tb_mirror(int LD, double *__restrict__ Gh, const unsigned long long *skip) {
+  __shared__ double tile[16][17];
+  if (skip && *skip != 0ull) return;
+  const int nb = LD / 16;
+  int I = 0, rest = (int)blockIdx.x;   // off-diagonal blocks only: row I of the strict triangle holds nb - 1 - I
+  while (rest >= nb - 1 - I) {
+    rest -= nb - 1 - I;
+    ++I;
+  }
+  const int J = I + 1 + rest, r = threadIdx.x >> 4, c = threadIdx.x & 15;
+  double *G = Gh + (size_t)blockIdx.y * LD * LD;
+  tile[r][c] = G[(size_t)(16 * I + r) * LD + 16 * J + c];
+  __syncthreads();
+  G[(size_t)(16 * J + r) * LD + 16 * I + c] = tile[c][r];
 }
 
 int cb_tb_launch_tables(int LD, int ns, int nd, int ng, const double *tf, const double *tg, const double *lam, double *F, double *E,
@@ -431,27 +471,35 @@ size_t cb_tb_ew_lds_bytes(int B, int ns, int ng) {
 
 int cb_tb_launch_ew(const CbTbEwArgs &a, hipStream_t stream, hipEvent_t stop, int *nparts) {
   const size_t LL = (size_t)a.LD * a.LD;
-  const unsigned grid = (unsigned)((LL / 16 + 15) / 16);   // 16 waves of 16 elements per workgroup
-  if (nparts) *nparts = (int)grid;
   if (a.ns > CB_TB_RS_MAX || a.ng > CB_TB_RG_MAX || a.LD % 16 != 0 || cb_tb_ew_lds_bytes(a.B, a.ns, a.ng) > CB_TB_LDS_MAX ||
       (double)(a.B + 32) * (double)LL * 8.0 >= 2147483648.0)   // (the buffer loads' 31-bit offsets)
     return -1;
+  // the symmetric form: eight-wave workgroups (two per CU), items of the upper block triangle, then the mirror copies
+  const int nb = a.LD / 16, nblk = nb * (nb + 1) / 2;
+  const unsigned grid = (unsigned)(nblk * 2);   // 16 rows per block, 8 per workgroup
+  if (nparts) *nparts = (int)grid;
 #define TB_GO(RS_, RG_)                                                                                                  \
   do {                                                                                                                   \
     const size_t lds = (size_t)TbEwLds<RS_, RG_>(a.B).TOTAL * sizeof(double);                                            \
     static size_t attr_set = 0;   /* (the largest size asked for so far) */                                              \
     if (lds > attr_set) {                                                                                                \
-      if (hipFuncSetAttribute(reinterpret_cast<const void *>(tb_ew<RS_, RG_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) \
+      if (hipFuncSetAttribute(reinterpret_cast<const void *>(tb_ew<RS_, RG_, 8, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) \
         return -1;                                                                                                       \
       attr_set = lds;                                                                                                    \
     }                                                                                                                    \
-    if (stop) hipExtLaunchKernelGGL((tb_ew<RS_, RG_>), dim3(grid), dim3(1024), lds, stream, nullptr, stop, 0, a);        \
-    else hipLaunchKernelGGL((tb_ew<RS_, RG_>), dim3(grid), dim3(1024), lds, stream, a);                                  \
+    hipLaunchKernelGGL((tb_ew<RS_, RG_, 8, true>), dim3(grid), dim3(512), lds, stream, a);                               \
   } while (0)
   if (a.ns <= 16 && a.ng <= 32) TB_GO(16, 32);
   else if (a.ns <= 16) TB_GO(16, 48);
   else if (a.ng <= 32) TB_GO(24, 32);
   else TB_GO(24, 48);
 #undef TB_GO
+  if (nb > 1) {
+    const dim3 mg((unsigned)(nb * (nb - 1) / 2), (unsigned)a.ng);
+    if (stop) hipExtLaunchKernelGGL(tb_mirror, mg, dim3(256), 0, stream, nullptr, stop, 0, a.LD, a.Gh, a.skip);
+    else hipLaunchKernelGGL(tb_mirror, mg, dim3(256), 0, stream, a.LD, a.Gh, a.skip);
+  } else if (stop) {
+    (void)hipEventRecord(stop, stream);
+  }
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
