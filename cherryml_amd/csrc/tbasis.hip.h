@@ -121,6 +121,12 @@ static int id_rows(int B, int N, const std::vector<ld> &F, int Rmax, ld tol, std
 #ifndef CB_TB_SAMPLES
 #define CB_TB_SAMPLES 512      // log-spaced sample points of the spectrum in [-rho_max, 0) (+ the point 0)
 #endif
+#ifndef CB_TB_TOL_G
+#define CB_TB_TOL_G 2e-15L     // largest remaining row of the gradient family / largest row at which its skeleton is complete: entries of
+                               // Phi_b / t_b in (0, 1] are then interpolated to ~1e-14, two orders below what dL/dQ carries anyway
+                               // (1e-12 on the bench bank); at 1e-16 the bench bank needs 31 virtual buckets instead of 30 -- 775
+                               // tiles for the first gradient product, a fourth tile on eight of the 256 CUs, which set its pace
+#endif
 #ifndef CB_TB_X_SMALL
 #define CB_TB_X_SMALL 8.0      // a bucket is expanded in the psi family while t_b rho_max <= this (|t A| <= 8: one digit of
                                // cancellation in I + t A + t^2 Psi at the very end of the basis' range, none where it was built)
@@ -177,7 +183,7 @@ bool cb_tb_build(int B, const double *t, double rho_max, CbTimeBasisHost &out) {
     std::vector<int> sk;
     std::vector<ld> L;
     ld res = 0.0L;
-    const int R = id_rows(B, N, F, std::min(CB_TB_RG_MAX, B), 1e-16L, sk, L, res);
+    const int R = id_rows(B, N, F, std::min(CB_TB_RG_MAX, B), CB_TB_TOL_G, sk, L, res);
     if (R < 0) return false;
     out.ng = R;
     out.res_g = (double)res;

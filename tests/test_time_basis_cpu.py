@@ -39,8 +39,10 @@ def test_decomposition_reproduces_both_families_between_the_sample_points(rho_ma
     Lg = tb["Lg"].astype(LD) * t[tb["skel_g"]][None, :] / t[:, None]      # (Lg carries t_b / t_skeleton)
     r_g = np.abs(E - Lg @ E[tb["skel_g"]]).max()
     print(f"rho_max {rho_max}: ns {ns} nd {nd} ng {ng}; residuals psi {float(r_s):.1e} (relative), exp {float(r_g):.1e}")
-    assert r_s < 1e-15 and r_g < 5e-15              # (the matrices are rounded to float64: a few ulps of their row sums)
-    assert tb["residuals"][0] < 1e-15 * float(np.abs(psi).max()) and tb["residuals"][1] < 2e-15
+    # (the forward family to rounding -- the O(t^2) entries of P_b rest on it --, the gradient family to 5e-14: its skeleton is
+    # complete when the largest remaining row is 2e-15 of the largest, csrc/tbasis.hip.h CB_TB_TOL_G)
+    assert r_s < 1e-15 and r_g < 5e-14
+    assert tb["residuals"][0] < 1e-15 * float(np.abs(psi).max()) and tb["residuals"][1] < 3e-14
     # a skeleton bucket is itself; interpolation weights stay of order one
     assert np.array_equal(tb["Ls"][tb["skel_s"]], np.eye(ns)) and np.abs(tb["Ls"]).max() < 4.0
     assert np.allclose(Lg[tb["skel_g"]].astype(np.float64), np.eye(ng), atol=0, rtol=0) and np.abs(Lg).max() < 4.0
@@ -50,7 +52,7 @@ def test_decomposition_reproduces_both_families_between_the_sample_points(rho_ma
 def test_rank_grows_slowly_with_the_spectral_bound():
     ranks = [(time_basis(GRID, r)["ns"], time_basis(GRID, r)["ng"]) for r in (1.0, 4.0, 16.0)]
     print(ranks)
-    assert all(a[1] <= b[1] for a, b in zip(ranks, ranks[1:])) and ranks[-1][1] <= 36 and max(r[0] for r in ranks) <= 18
+    assert all(a[1] <= b[1] for a, b in zip(ranks, ranks[1:])) and ranks[-1][1] <= 34 and max(r[0] for r in ranks) <= 18
 
 
 def test_short_and_odd_grids():
