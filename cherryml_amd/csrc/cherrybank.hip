@@ -177,7 +177,7 @@ static void tb_drop_next(cb_bank *h) {   // (a helper thread still building: wai
 }
 // upload a built basis to the idle device set and make it the current one
 static int tb_install(cb_bank *h, int B, CbTimeBasisHost &&nb, double ms) {
-  if (nb.B != B || cb_tb_ew_lds_bytes(B, nb.ns, nb.ng) > CB_TB_LDS_MAX) {
+  if (nb.B != B || !cb_tb_supported(B, h->LD, nb.ns, nb.ng)) {
     h->tb_failed = true;
     h->tb = CbTimeBasisHost{};
     return CB_OK;
@@ -319,6 +319,7 @@ static int large_eval(cb_bank *h, bool normalize, double *lossd, double *out, bo
     // (as ONE persistent launch -- k123_bank with an empty first stage, K3' tiles of a virtual bucket filling the drain of its
     // K2' tiles -- the pair took 0.227 ms against 0.146 for the two launches: ~30 buckets are a short bank, EXPERIMENTS section 13)
     hipLaunchKernelGGL((k2_t_eq_g_u<double, 1>), dim3(tiles * ng), dim3(LG4_THREADS), 0, h->stream, k2);
+    // (eight-wave tiles for the last product -- 450 tiles, fewer than two per CU -- measured: 0.1298 against 0.1306 ms, no gain)
     LAUNCH_STOP(stop_event(h, EV_K3), (k3_w_phi<double, 1>), dim3(tiles_k1 * ng), dim3(LG4_THREADS), 0, h->stream, k3);
     const LossArgs la{h->loss_part, ew_parts, S, h->dsq, h->dirsum, inv_n, lossd, skipw};
     hipLaunchKernelGGL(k3_reduce_loss<double>, dim3((unsigned)((LL + 255) / 256) + 1), dim3(256), 0, h->stream, h->Gt, ng, LL, h->Mt, LD, la);

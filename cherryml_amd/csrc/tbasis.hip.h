@@ -469,6 +469,12 @@ int cb_tb_launch_tables(int LD, int ns, int nd, int ng, const double *tf, const 
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
+// what tb_ew can serve: the interpolation matrices of B buckets in its LDS, the buffer loads' 31-bit offsets
+bool cb_tb_supported(int B, int LD, int ns, int ng) {
+  return ns <= CB_TB_RS_MAX && ng <= CB_TB_RG_MAX && LD % 16 == 0 && cb_tb_ew_lds_bytes(B, ns, ng) <= CB_TB_LDS_MAX &&
+         (double)(B + 32) * (double)LD * (double)LD * 8.0 < 2147483648.0;
+}
+
 size_t cb_tb_ew_lds_bytes(int B, int ns, int ng) {
   const int RS = ns <= 16 ? 16 : 24, RG = ng <= 32 ? 32 : 48;
   const int BP = (B + 15) & ~15;
@@ -476,10 +482,7 @@ size_t cb_tb_ew_lds_bytes(int B, int ns, int ng) {
 }
 
 int cb_tb_launch_ew(const CbTbEwArgs &a, hipStream_t stream, hipEvent_t stop, int *nparts) {
-  const size_t LL = (size_t)a.LD * a.LD;
-  if (a.ns > CB_TB_RS_MAX || a.ng > CB_TB_RG_MAX || a.LD % 16 != 0 || cb_tb_ew_lds_bytes(a.B, a.ns, a.ng) > CB_TB_LDS_MAX ||
-      (double)(a.B + 32) * (double)LL * 8.0 >= 2147483648.0)   // (the buffer loads' 31-bit offsets)
-    return -1;
+  if (!cb_tb_supported(a.B, a.LD, a.ns, a.ng)) return -1;
   // the symmetric form: eight-wave workgroups (two per CU), items of the upper block triangle, then the mirror copies
   const int nb = a.LD / 16, nblk = nb * (nb + 1) / 2;
   const unsigned grid = (unsigned)(nblk * 2);   // 16 rows per block, 8 per workgroup
