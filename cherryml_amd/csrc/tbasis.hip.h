@@ -503,6 +503,7 @@ int cb_tb_launch_ew(const CbTbEwArgs &a, hipStream_t stream, hipEvent_t stop, in
   else if (a.ng <= 32) TB_GO(24, 32);
   else TB_GO(24, 48);
 #undef TB_GO
+  // (the mirrored entries written straight from tb_ew -- eight-byte stores LD apart, no second launch -- measured: 0.069 against 0.066 ms)
   if (nb > 1) {
     const dim3 mg((unsigned)(nb * (nb - 1) / 2), (unsigned)a.ng);
     if (stop) hipExtLaunchKernelGGL(tb_mirror, mg, dim3(256), 0, stream, nullptr, stop, 0, a.LD, a.Gh, a.skip);
