@@ -274,6 +274,10 @@ static int large_eval(cb_bank *h, bool normalize, double *lossd, double *out, bo
   bool use_tb = h->sym_counts && !h->per_bucket_products && !h->tb_block && !h->tb_failed && !Pd && dQd != nullptr && h->tb_Ls[0] &&
                 n_parts == 1 && h->dtype == CB_F64 && !h->comm && (tb_hook ? atoi(tb_hook) != 0 : (!form_hooks && B >= CB_TB_MIN_B));
   if (use_tb && planned_now && h->tb.B != B) use_tb = false;
+  {   // (tb_ew leaves one loss partial per half block of the upper block triangle in h->loss_part, B x tiles doubles)
+    const size_t nb16 = (size_t)LD / 16, cap = (size_t)B * ((LD + LG_TM - 1) / LG_TM) * ((LD + LG_TN - 1) / LG_TN);
+    if (nb16 * (nb16 + 1) > cap) use_tb = false;
+  }
   // (the three bank kernels return at once when the planned solve in front of them stalled: EC_STALL)
   const unsigned long long *skipw = planned_now ? h->ectl + (use_tb ? EC_SKIP : EC_STALL) : nullptr;
   if (planned_now) rc = enqueue_planned_solve(h, *plan, ++h->eseq, plan_first_slot, use_tb ? h->tb.rho_max : 0.0);
