@@ -114,12 +114,19 @@ __global__ __launch_bounds__(512, 6) void lge_gram(GramArgs a) {   // 6 waves pe
   sDg[0][wave * 4 + hi][lo] = da;
   sDg[1][wave * 4 + hi][lo] = db;
   __syncthreads();
+  // (the 32 partials of a diagonal entry: four interleaved chains of eight and a fixed tree over them -- one chain of 32 dependent
+  // LDS reads was 3 us in the middle of every launch; the order is the same in the tile (n, m): X stays exactly antisymmetric)
   if (threadIdx.x < 32) {
     const int w = threadIdx.x >> 4, c = threadIdx.x & 15;
-    double s = 0.0;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
 #pragma unroll
-    for (int p = 0; p < 32; ++p) s += sDg[w][p][c];
-    sD[w][c] = s;
+    for (int p = 0; p < 32; p += 4) {
+      s0 += sDg[w][p][c];
+      s1 += sDg[w][p + 1][c];
+      s2 += sDg[w][p + 2][c];
+      s3 += sDg[w][p + 3][c];
+    }
+    sD[w][c] = (s0 + s1) + (s2 + s3);
   }
   __syncthreads();
   double mc2 = 0.0, rs = 0.0, rsf = 0.0;
