@@ -229,13 +229,18 @@ static int tb_maintain(cb_bank *h, int B, int epoch, double two_sigma, bool stal
     if (stale || !tb_in_range(h, B, two_sigma)) return tb_rebuild(h, B, two_sigma);
     return CB_OK;
   }
+  // (test hook CB_TB_TEST_WARN="<headroom> <lead>": e.g. "100 3" starts a helper thread on the next basis right after every swap
+  // and swaps three epochs later -- the path a real optimisation takes a few times in thousands of epochs)
+  double warn = 1.6;
+  int lead = CB_TB_LEAD;
+  if (const char *w = cb_test_hook("CB_TB_TEST_WARN")) sscanf(w, "%lf %d", &warn, &lead);
   if (h->tb_next_pending && epoch >= h->tb_next_epoch) {
     CbTimeBasisHost nb = h->tb_next.get();
     h->tb_next_pending = false;
     int rc = tb_install(h, B, std::move(nb), -1.0);
     if (rc != CB_OK || h->tb_failed) return rc;
   }
-  if (!h->tb_next_pending && !tb_in_range(h, B, two_sigma, 1.6)) {
+  if (!h->tb_next_pending && !tb_in_range(h, B, two_sigma, warn)) {
     std::vector<double> t(h->t_live_host.begin(), h->t_live_host.begin() + B);
     const double rho = two_sigma * tb_growth();
     h->tb_next = std::async(std::launch::async, [t, rho, B]() {
@@ -244,7 +249,7 @@ static int tb_maintain(cb_bank *h, int B, int epoch, double two_sigma, bool stal
       return nb;
     });
     h->tb_next_pending = true;
-    h->tb_next_epoch = epoch + CB_TB_LEAD;
+    h->tb_next_epoch = epoch + lead;
   }
   return CB_OK;
 }

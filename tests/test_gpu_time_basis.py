@@ -156,3 +156,45 @@ def test_an_optimisation_builds_its_own_basis_whatever_ran_on_the_handle_before(
     with CherryBank(t, C) as bank:   # ... and to the bit between two fresh handles
         c = bank.train_pande_reversible(u0, p0, mask=mask, num_epochs=8, lr=0.1)
     assert np.array_equal(a["loss"], c["loss"]) and np.array_equal(a["Q_last"], c["Q_last"])
+
+
+def test_the_next_basis_is_built_beside_the_epochs_and_swapped_at_a_fixed_epoch(dense, monkeypatch):
+    """CB_TB_TEST_WARN="100 3" (test hook): a helper thread starts on the next basis as soon as one is installed and the trainer
+    swaps it in three epochs later -- what a real optimisation does a few times in thousands of epochs when max |Q_ii| drifts.
+    The swap epoch depends on the sigma sequence only: two runs give the same bits however long the thread took, and the loss
+    curve is the one of the unhooked run to rounding (other bases, other sums)."""
+    from cherryml_amd import CherryBank
+    z = load_golden("coevo_dense_traj.npz")
+    t, C, mask = dense["t"], dense["C"], dense["mask"]
+    u0, p0 = z["upper_diag0"], z["log_pi0"]
+    E = 16
+    with CherryBank(t, C) as bank:
+        ref = bank.train_pande_reversible(u0, p0, mask=mask, num_epochs=E, lr=0.1)
+        assert bank.time_basis_info()["builds"] == 1
+    monkeypatch.setenv("CB_TB_TEST_WARN", "100 3")
+    runs = []
+    for _ in range(2):
+        with CherryBank(t, C) as bank:
+            a = bank.train_pande_reversible(u0, p0, mask=mask, num_epochs=10, lr=0.1)
+            b = bank.train_pande_reversible(u0, p0, mask=mask, num_epochs=E - 10, lr=0.1, resume=True)   # a build pending across calls
+            info = bank.time_basis_info()
+        runs.append((np.concatenate([a["loss"], b["loss"]]), b["Q_last"], info))
+    print(runs[0][2])
+    assert runs[0][2]["builds"] >= 4 and runs[0][2]["repeated_epochs"] == 0
+    assert np.array_equal(runs[0][0], runs[1][0]) and np.array_equal(runs[0][1], runs[1][1])
+    assert np.abs(runs[0][0] - ref["loss"]).max() < 1e-11 * np.abs(ref["loss"]).max()
+    assert relerr(runs[0][1], ref["Q_last"]) < 1e-8
+
+
+def test_a_grid_that_needs_too_many_skeleton_buckets_keeps_the_per_bucket_products():
+    from cherryml_amd import CherryBank
+    rng = np.random.default_rng(11)
+    S, B = 48, 100
+    Q, pi = _reversible(S, rng, 5.0)
+    t = np.geomspace(1e-8, 1e6, B)                 # fourteen decades: more than 40 gradient skeleton buckets
+    C = _sym_counts(S, B, rng)
+    with CherryBank(t, C) as a, CherryBank(t, C, per_bucket_products=True) as b:
+        la, ga = a.loss_grad(Q, pi)
+        assert not a.last_bank_form()["time_basis"] and a.time_basis_info()["builds"] == 0
+        lb, gb = b.loss_grad(Q, pi)
+    assert abs(la[0] - lb[0]) <= 1e-13 * abs(lb[0]) and relerr(ga[0], gb[0]) < 1e-11
