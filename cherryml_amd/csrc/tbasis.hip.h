@@ -44,6 +44,20 @@ static inline ld g_phi2(ld x) {
   return (expm1l(x) - x) / (x * x);
 }
 
+// dot product with four independent partial sums (x87 adds are 3-5 cycles deep: one running sum is a latency chain)
+static inline ld dot4(const ld *a, const ld *b, int n) {
+  ld s0 = 0.0L, s1 = 0.0L, s2 = 0.0L, s3 = 0.0L;
+  int i = 0;
+  for (; i + 3 < n; i += 4) {
+    s0 += a[i] * b[i];
+    s1 += a[i + 1] * b[i + 1];
+    s2 += a[i + 2] * b[i + 2];
+    s3 += a[i + 3] * b[i + 3];
+  }
+  for (; i < n; ++i) s0 += a[i] * b[i];
+  return (s0 + s1) + (s2 + s3);
+}
+
 // Rows of F [B][N] -> skeleton rows and L [B][R] with F ~ L F[skel]: pivoted modified Gram-Schmidt on the rows (each new
 // direction re-orthogonalised twice), stopped when the largest remaining row is below tol * the largest row.  Returns the rank,
 // or -1 when Rmax rows do not reach the tolerance.
@@ -57,9 +71,8 @@ static int id_rows(int B, int N, const std::vector<ld> &F, int Rmax, ld tol, std
     int p = -1;
     ld best = -1.0L;
     for (int b = 0; b < B; ++b) {
-      ld s = 0.0L;
       const ld *w = &W[(size_t)b * N];
-      for (int i = 0; i < N; ++i) s += w[i] * w[i];
+      const ld s = dot4(w, w, N);
       if (s > best) best = s, p = b;
     }
     if (r == 0) scale = sqrtl(best);
@@ -73,20 +86,17 @@ static int id_rows(int B, int N, const std::vector<ld> &F, int Rmax, ld tol, std
     for (int pass = 0; pass < 2; ++pass) {
       for (int k = 0; k < r; ++k) {
         const ld *qk = &Q[(size_t)k * N];
-        ld d = 0.0L;
-        for (int i = 0; i < N; ++i) d += qk[i] * q[i];
+        const ld d = dot4(qk, q.data(), N);
         for (int i = 0; i < N; ++i) q[i] -= d * qk[i];
       }
-      ld s = 0.0L;
-      for (int i = 0; i < N; ++i) s += q[i] * q[i];
+      const ld s = dot4(q.data(), q.data(), N);
       const ld in = 1.0L / sqrtl(s);
       for (int i = 0; i < N; ++i) q[i] *= in;
     }
     for (int i = 0; i < N; ++i) Q[(size_t)r * N + i] = q[i];
     for (int b = 0; b < B; ++b) {
       ld *w = &W[(size_t)b * N];
-      ld c = 0.0L;
-      for (int i = 0; i < N; ++i) c += w[i] * q[i];
+      const ld c = dot4(w, q.data(), N);
       Cq[(size_t)b * Rmax + r] = c;
       for (int i = 0; i < N; ++i) w[i] -= c * q[i];
     }
