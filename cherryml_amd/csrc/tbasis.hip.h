@@ -22,8 +22,8 @@
 // P_b(i, j), its logarithm and reciprocal, the loss term, G_b(i, j) and its ng accumulations -- reading the counts once.
 //
 // MFMA tiles of an evaluation: (ns + nd) 15 + ng 40 instead of 40 B (bench bank, B = 129: ~1 900 instead of 5 160); accuracy
-// of dL/dA against the per-bucket form 3e-13 .. 4e-12 (both are 7e-11 from a long-double evaluation: the eigendecomposition's
-// own backward error dominates; /tmp prototype recorded in EXPERIMENTS section 13).
+// of dL/dA against the per-bucket form 6e-13 .. 5e-12 (both are equally far, 7e-13 .. 7e-11, from a long-double evaluation of P_b:
+// the eigendecomposition's own backward error dominates; profiles/tools/tb_prototype.py, EXPERIMENTS section 13).
 #pragma once
 #include "cb_internal.hip.h"
 #include "common.hip.h"
@@ -239,8 +239,9 @@ __global__ void tb_tables(int LD, int ns, int nd, int ng, const double *__restri
 //   backward  Gh_r(e) += sum_b Lg[b][r] G_b(e):      for m = 0 .. 3 the K-step {b0 + 4 m + k}: B = the lane's G of register m (no
 //             shuffle), A = Lg[b0 + 4 m + (l >> 4)][16 rho + (l & 15)], D tile rho register q = Gh of row 16 rho + k + 4 q at element j.
 // (As 48 v_fma_f64 per pair with the coefficients in SGPRs -- one element per thread, 96 accumulator VGPRs, the scalar loads of
-// every bucket's 48 coefficients waited for in place -- the kernel took 0.20 ms; the matrix pipe is idle otherwise.)
-// Ls / Lg / t live in LDS (zero rows behind the last bucket: a step that hangs over B adds nothing), shared by the 16 waves of
+// every bucket's 48 coefficients waited for in place -- the kernel took 0.20 ms.  On gfx950 the f64 MFMA runs on the f64 vector
+// pipe: the MFMA form saves instruction issue, 80 registers and the scalar-load waits, not pipe time: EXPERIMENTS section 13.)
+// Ls / Lg / t live in LDS (zero rows behind the last bucket: a step that hangs over B adds nothing), shared by the waves of
 // a workgroup.  The short-branch buckets are a PREFIX of the (ascending) grid: steps behind it skip the forward product and
 // read P_b of the long-branch buckets.  Loss partial per workgroup in a fixed order.
 template <int RS, int RG>
