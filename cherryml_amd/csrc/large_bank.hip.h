@@ -403,8 +403,8 @@ __device__ __forceinline__ void bank_store(T *p, T v) {
 
 // one (bucket b, upper-triangular tile `tile`) of K1; sAB: 4 * LG_KT * LG_TM elements of LDS (A panels | B panels, two K-steps
 // each; after the K loop: the transposition buffer); vid = b * tiles + tile indexes the loss partial
-// RAW (the time-basis bank, tbasis.hip.h): the product U diag(F_b) U^T ITSELF -- no I + t A, no counts -- written whole
-// (both triangles) to Gt[b] as a padded LD x LD matrix: Psi_r of a skeleton bucket, or P_b of a long-branch bucket.
+// RAW (the time-basis bank, tbasis.hip.h): the product U diag(F_b) U^T ITSELF -- no I + t A, no counts -- written to Gt[b] as a
+// padded LD x LD matrix, its upper 80 x 80 tiles only: Psi_r of a skeleton bucket, or P_b of a long-branch bucket.
 template <typename T, typename TG, bool EXPM, bool WT, int KG = 1, bool RAW = false>
 __device__ __forceinline__ void k1_tile(const K1Args<T, TG> &a, int b, int tile, T *sAB, int tid,
                                         const BankHooks &hooks = BankHooks{}) {
@@ -469,17 +469,9 @@ __device__ __forceinline__ void k1_tile(const K1Args<T, TG> &a, int b, int tile,
       idm[r] = idm0 + r * step;
     }
     if constexpr (RAW) {
-      // direct entries, then the mirrored ones through the wave's patch (lanes along THEIR rows, as below)
+      // (the upper 80 x 80 tiles only: tb_ew, the one reader, visits the upper block triangle -- a diagonal tile is computed whole)
 #pragma unroll
       for (int r = 0; r < 4; ++r) Gt[idx[r]] = (TG)v[r];
-      if (mirror) {
-        lg_wave_lds_fence();
-#pragma unroll
-        for (int r = 0; r < 4; ++r) sW[lo * 17 + rl[r]] = v[r];
-        lg_wave_lds_fence();
-#pragma unroll
-        for (int r = 0; r < 4; ++r) Gt[idm[r]] = (TG)sW[rl[r] * 17 + lo];
-      }
       return;
     }
     T c1[4], c2[4], av[4], pt[4];
