@@ -285,7 +285,11 @@ static int large_eval(cb_bank *h, bool normalize, double *lossd, double *out, bo
   }
   // (the three bank kernels return at once when the planned solve in front of them stalled: EC_STALL)
   const unsigned long long *skipw = planned_now ? h->ectl + (use_tb ? EC_SKIP : EC_STALL) : nullptr;
-  if (planned_now) rc = enqueue_planned_solve(h, *plan, ++h->eseq, plan_first_slot, use_tb ? h->tb.rho_max : 0.0);
+  if (planned_now) {
+    TbTableArgs tbt;   // (the bank's spectral tables ride on the solve's last launch)
+    if (use_tb) tbt = TbTableArgs{h->tb.ns, h->tb.nd, h->tb.ng, h->tb_tf[h->tb_set], h->tb_tg[h->tb_set], h->F, h->E, h->H};
+    rc = enqueue_planned_solve(h, *plan, ++h->eseq, plan_first_slot, use_tb ? h->tb.rho_max : 0.0, tbt);
+  }
   else if (!(reuse_eigh && h->have_prev)) rc = large_eigh(h, true);   // reuse: same matrix as the previous call (CB_REUSE_EIGH)
   if (rc != CB_OK) return rc;
   if (use_tb && !planned_now) {
@@ -314,7 +318,10 @@ static int large_eval(cb_bank *h, bool normalize, double *lossd, double *out, bo
     h->bank_fused = false;
     h->bank_accum = false;
     h->bank_kg = 1;
-    if (cb_tb_launch_tables(LD, bas.ns, bas.nd, ng, h->tb_tf[set], h->tb_tg[set], h->lam, h->F, h->E, h->H, skipw, h->stream) != 0)
+    // (behind a planned solve the tables were written by its last launch, lge_finish: forward products 0.081 -> 0.076 ms, the
+    // solve +0.002)
+    if (!planned_now &&
+        cb_tb_launch_tables(LD, bas.ns, bas.nd, ng, h->tb_tf[set], h->tb_tg[set], h->lam, h->F, h->E, h->H, skipw, h->stream) != 0)
       return fail(CB_EHIP, "tb_tables: launch failed");
     K1Args<double> k1{S, LD, nf, h->Vc, h->A, h->tb_tf[set], h->F, h->sigma, h->Ct, h->T, h->loss_part, inv_n, h->dsq, nullptr, skipw};
     LAUNCH_STOP(stop_event(h, EV_K1), (k1_pt_loss_gt<double, double, false, 1, true>), dim3(tiles_k1 * nf), dim3(LG4_THREADS), 0, h->stream, k1);

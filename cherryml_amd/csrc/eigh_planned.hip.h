@@ -593,9 +593,30 @@ __global__ void lge_norms(int LD, const double *G0, const double *G1, double *nr
   if (lane == 0) nrm[k] = sqrt(nn);
 }
 
+// The spectral tables of a time-basis bank (tbasis.hip.h, tb_tables) depend on lambda_k only in column k: the wave that places
+// eigenvalue k writes them too, and the bank behind a planned solve needs no table launch of its own.
+struct TbTableArgs {
+  int ns = 0, nd = 0, ng = 0;            // all zero: no tables
+  const double *tf = nullptr, *tg = nullptr;
+  double *F = nullptr, *E = nullptr, *H = nullptr;
+};
+__device__ __forceinline__ void tb_table_column(const TbTableArgs &t, int LD, int k, double lk, int lane) {
+  const int nf = t.ns + t.nd;
+  for (int r = lane; r < nf + t.ng; r += 64) {
+    if (r < nf) {
+      const double tt = t.tf[r], x = tt * lk;
+      t.F[(size_t)r * LD + k] = r < t.ns ? phi2(x) / (tt * tt) : exp(x);
+    } else {
+      const double x = t.tg[r - nf] * lk;
+      t.E[(size_t)(r - nf) * LD + k] = exp(x);
+      t.H[(size_t)(r - nf) * LD + k] = exp(0.5 * x);
+    }
+  }
+}
+
 // lgj_finish on the buffer of the final sweep; leaves U / lambda alone after a stall
 __global__ void lge_finish(int LD, const double *G0, const double *G1, const double *nrm, const double *sigma, double *lam,
-                           double *U, double *Ut, const unsigned long long *ctl) {
+                           double *U, double *Ut, const unsigned long long *ctl, TbTableArgs tb) {
   if (ctl[EC_STALL] != 0ull) return;
   const double *Gc = ((ctl[EC_FINAL] + 1) & 1ull) ? G1 : G0;
   const int k = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
@@ -614,5 +635,7 @@ __global__ void lge_finish(int LD, const double *G0, const double *G1, const dou
     Ut[(size_t)pos * LD + r] = v;
     U[(size_t)r * LD + pos] = v;
   }
-  if (lane == 0) lam[pos] = *sigma - mine;
+  const double lk = *sigma - mine;
+  if (lane == 0) lam[pos] = lk;
+  if (tb.ns + tb.nd + tb.ng > 0) tb_table_column(tb, LD, pos, lk, lane);
 }

@@ -117,7 +117,8 @@ static bool eigh_planned_setup(cb_bank *h) {
 // Enqueue one warm solve (h->U / h->Vc hold the previous eigenvectors, h->A the new matrix).  `seq` is what lge_norms
 // leaves in the record's sequence word.  first_slot > 0: the CONTINUATION of a stalled solve -- its G buffers hold a valid,
 // partly converged state (every rotation applied so far was orthogonal), so the new slots simply carry on from it.
-static int enqueue_planned_solve(cb_bank *h, const EighPlan &p, unsigned long long seq, int first_slot = 0, double tb_rho_max = 0.0) {
+static int enqueue_planned_solve(cb_bank *h, const EighPlan &p, unsigned long long seq, int first_slot = 0, double tb_rho_max = 0.0,
+                                 const TbTableArgs &tbt = TbTableArgs{}) {
   const int LD = h->LD, nt = LD / 16, nb = LD / JB_W;
   const size_t LL = (size_t)LD * LD;
   unsigned long long *ctl = h->ectl;
@@ -190,7 +191,7 @@ static int enqueue_planned_solve(cb_bank *h, const EighPlan &p, unsigned long lo
   volatile unsigned long long *pin = h->epin + (size_t)(seq & 1ull) * (EC_WORDS + 16);
   hipLaunchKernelGGL(lge_norms, dim3((LD + 3) / 4), dim3(256), 0, h->stream, LD, Gb[0], Gb[1], h->X, ctl, pin, seq, h->sigma, tb_rho_max);
   LAUNCH_STOP(stop_event(h, EV_EIGH), lge_finish, dim3((LD + 3) / 4), dim3(256), 0, h->stream, LD, Gb[0], Gb[1], h->X, h->sigma, h->lam, h->U, h->Vc,
-                     ctl);
+                     ctl, tbt);
   HIP_TRY(hipGetLastError());
   return CB_OK;
 }
