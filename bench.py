@@ -618,8 +618,10 @@ def main():
                                bound="mfma", algorithmic=(ns + nd) * one, executed=(ns + nd) * one * tri, unit="TFLOP/s", peak=F64_PEAK_TFLOPS),
                     "k2": dict(kernel="tb_ew (every element of all %d buckets: P, log P, 1 / P, loss, G, the %d sums)" % (B_local, ng),
                                bound="hbm", algorithmic=8.0 * S * S * (B_local + ns + nd + ng), executed=None, unit="GB/s", peak=HBM_PEAK_GBS),
-                    "k3": dict(kernel="k2_t_eq_g_u<double> + k3_w_phi<double> (gradient products on %d virtual buckets, two launches)" % ng,
-                               bound="mfma", algorithmic=2 * ng * one, executed=ng * one * (1.0 + tri), unit="TFLOP/s", peak=F64_PEAK_TFLOPS),
+                    "k3": dict(kernel="k2_t_eq_g_u<%s> + k3_w_phi<%s> (gradient products on %d virtual buckets, two launches)"
+                                      % (("double", "double", ng) if bank_dtype == "f64" else ("float", "float", ng)),
+                               bound="mfma", algorithmic=2 * ng * one, executed=ng * one * (1.0 + tri), unit="TFLOP/s",
+                               peak=F64_PEAK_TFLOPS if bank_dtype == "f64" else F32_PEAK_TFLOPS),   # (mixed: float32 MFMA)
                 }
                 for k, d in kern.items():
                     sc = 1e12 if d["unit"] == "TFLOP/s" else 1e9

@@ -64,7 +64,8 @@ struct CbTbEwArgs {
   const double *A;      // [LD][LD]
   const double *t;      // [B]
   const double *Ls, *Lg;
-  double *Gh;           // [ng][LD][LD] out
+  double *Gh;           // [ng][LD][LD] out (float64 bank)
+  float *Gh32;          // ... or, when not null, the same rounded to float32 (CB_MIXED)
   double *loss_part;    // [LD * LD / 256] out
   double inv_n;
   const unsigned long long *skip;   // device word: non-zero => return at once

@@ -179,7 +179,8 @@ static void tb_drop_next(cb_bank *h) {   // (a helper thread still building: wai
 }
 // upload a built basis to the idle device set and make it the current one
 static int tb_install(cb_bank *h, int B, CbTimeBasisHost &&nb, double ms) {
-  if (nb.B != B || !cb_tb_supported(B, h->LD, nb.ns, nb.ng)) {
+  // (a CB_MIXED handle keeps Psi_r / P_b as doubles in its float32 T buffer: 2 (ns + nd) of its B planes)
+  if (nb.B != B || !cb_tb_supported(B, h->LD, nb.ns, nb.ng) || (h->dtype == CB_MIXED && 2 * (nb.ns + nb.nd) > B)) {
     h->tb_failed = true;
     h->tb = CbTimeBasisHost{};
     return CB_OK;
@@ -279,7 +280,8 @@ static int large_eval(cb_bank *h, bool normalize, double *lossd, double *out, bo
   const bool form_hooks = cb_test_hook("CB_BANK_FUSED") || cb_test_hook("CB_BANK_UNFUSED") || cb_test_hook("CB_BANK_K3") ||
                           cb_test_hook("CB_BANK_KG") || cb_test_hook("CB_BANK_TEST_NO_CLAIM");
   bool use_tb = h->sym_counts && !h->per_bucket_products && !h->tb_block && !h->tb_failed && !Pd && dQd != nullptr && h->tb_Ls[0] &&
-                n_parts == 1 && h->dtype == CB_F64 && !h->comm && (tb_hook ? atoi(tb_hook) != 0 : (!form_hooks && B >= CB_TB_MIN_B));
+                n_parts == 1 && (h->dtype == CB_F64 || h->dtype == CB_MIXED) && !h->comm &&
+                (tb_hook ? atoi(tb_hook) != 0 : (!form_hooks && B >= CB_TB_MIN_B));
   if (use_tb && planned_now && h->tb.B != B) use_tb = false;
   {   // (tb_ew leaves one loss partial per half block of the upper block triangle in h->loss_part, B x tiles doubles)
     const size_t nb16 = (size_t)LD / 16, cap = (size_t)B * ((LD + LG_TM - 1) / LG_TM) * ((LD + LG_TN - 1) / LG_TN);
@@ -325,22 +327,39 @@ static int large_eval(cb_bank *h, bool normalize, double *lossd, double *out, bo
     if (!planned_now &&
         cb_tb_launch_tables(LD, bas.ns, bas.nd, ng, h->tb_tf[set], h->tb_tg[set], h->lam, h->F, h->E, h->H, skipw, h->stream) != 0)
       return fail(CB_EHIP, "tb_tables: launch failed");
-    K1Args<double> k1{S, LD, nf, h->Vc, h->A, h->tb_tf[set], h->F, h->sigma, h->Ct, h->T, h->loss_part, inv_n, h->dsq, nullptr, skipw};
+    // CB_MIXED: everything up to G_b in float64 (the forward products, P_b, the loss), Gh_r rounded to float32 once by tb_ew,
+    // the two gradient products on the float32 MFMA.  A mixed handle has no float64 Gt / T: Psi_r / P_b live (as doubles) in
+    // the float32 T buffer -- dead once tb_ew has run, before K2' writes Th_r there -- and need 2 (ns + nd) <= B of its planes.
+    const bool tb_mixed = h->dtype == CB_MIXED;
+    double *psi_buf = tb_mixed ? reinterpret_cast<double *>(h->T32) : h->T;
+    K1Args<double> k1{S, LD, nf, h->Vc, h->A, h->tb_tf[set], h->F, h->sigma, h->Ct, psi_buf, h->loss_part, inv_n, h->dsq, nullptr, skipw};
     LAUNCH_STOP(stop_event(h, EV_K1), (k1_pt_loss_gt<double, double, false, 1, true>), dim3(tiles_k1 * nf), dim3(LG4_THREADS), 0, h->stream, k1);
-    const CbTbEwArgs ew{S, LD, B, bas.ns, bas.nd, ng, B - bas.nd, h->Ct, h->T, h->A, tb, h->tb_Ls[set], h->tb_Lg[set], h->Gt, h->loss_part, inv_n, skipw};
+    const CbTbEwArgs ew{S, LD, B, bas.ns, bas.nd, ng, B - bas.nd, h->Ct, psi_buf, h->A, tb, h->tb_Ls[set], h->tb_Lg[set], h->Gt,
+                        tb_mixed ? h->Gt32 : nullptr, h->loss_part, inv_n, skipw};
     int ew_parts = 0;
     // (phase marks of a time-basis evaluation: CB_T_K1 = tables + forward products, CB_T_K2 = the elementwise kernel,
     // CB_T_K3 = the two gradient products, CB_T_K4 = the sum over the virtual buckets + K4)
     if (cb_tb_launch_ew(ew, h->stream, stop_event(h, EV_K2), &ew_parts) != 0) return fail(CB_EHIP, "tb_ew: launch failed");
-    K2Args<double> k2{LD, h->Gt, h->U, h->T, skipw};
-    K3Args<double> k3{LD, ng, h->T, h->U, h->tb_tg[set], h->lam, h->E, h->H, h->Gt, 1, skipw};
-    // (as ONE persistent launch -- k123_bank with an empty first stage, K3' tiles of a virtual bucket filling the drain of its
-    // K2' tiles -- the pair took 0.227 ms against 0.146 for the two launches: ~30 buckets are a short bank, EXPERIMENTS section 13)
-    hipLaunchKernelGGL((k2_t_eq_g_u<double, 1>), dim3(tiles * ng), dim3(LG4_THREADS), 0, h->stream, k2);
-    // (eight-wave tiles for the last product -- 450 tiles, fewer than two per CU -- measured: 0.1298 against 0.1306 ms, no gain)
-    LAUNCH_STOP(stop_event(h, EV_K3), (k3_w_phi<double, 1>), dim3(tiles_k1 * ng), dim3(LG4_THREADS), 0, h->stream, k3);
     const LossArgs la{h->loss_part, ew_parts, S, h->dsq, h->dirsum, inv_n, lossd, skipw};
-    hipLaunchKernelGGL(k3_reduce_loss<double>, dim3((unsigned)((LL + 255) / 256) + 1), dim3(256), 0, h->stream, h->Gt, ng, LL, h->Mt, LD, la);
+    const dim3 red_grid((unsigned)((LL + 255) / 256) + 1);
+    // (as ONE persistent launch -- k123_bank with an empty first stage, K3' tiles of a virtual bucket filling the drain of its
+    // K2' tiles -- the pair took 0.227 ms against 0.146 for the two launches: ~30 buckets are a short bank, EXPERIMENTS section 13;
+    // eight-wave tiles for the last product -- 450 tiles, fewer than two per CU -- measured: 0.1298 against 0.1306 ms, no gain)
+    if (tb_mixed) {
+      hipLaunchKernelGGL(lg_cast_f32, dim3((unsigned)((LL + 255) / 256)), dim3(256), 0, h->stream, LL, (size_t)0, h->U, h->Vc, h->A, h->F,
+                         h->Uf, h->Utf, h->Af, h->Ff);
+      K2Args<float> k2{LD, h->Gt32, h->Uf, h->T32, skipw};
+      K3Args<float> k3{LD, ng, h->T32, h->Uf, h->tb_tg[set], h->lam, h->E, h->H, h->Gt32, 1, skipw};
+      hipLaunchKernelGGL((k2_t_eq_g_u<float, 1>), dim3(tiles * ng), dim3(LG4_THREADS), 0, h->stream, k2);
+      LAUNCH_STOP(stop_event(h, EV_K3), (k3_w_phi<float, 1>), dim3(tiles_k1 * ng), dim3(LG4_THREADS), 0, h->stream, k3);
+      hipLaunchKernelGGL(k3_reduce_loss<float>, red_grid, dim3(256), 0, h->stream, h->Gt32, ng, LL, h->Mt, LD, la);
+    } else {
+      K2Args<double> k2{LD, h->Gt, h->U, h->T, skipw};
+      K3Args<double> k3{LD, ng, h->T, h->U, h->tb_tg[set], h->lam, h->E, h->H, h->Gt, 1, skipw};
+      hipLaunchKernelGGL((k2_t_eq_g_u<double, 1>), dim3(tiles * ng), dim3(LG4_THREADS), 0, h->stream, k2);
+      LAUNCH_STOP(stop_event(h, EV_K3), (k3_w_phi<double, 1>), dim3(tiles_k1 * ng), dim3(LG4_THREADS), 0, h->stream, k3);
+      hipLaunchKernelGGL(k3_reduce_loss<double>, red_grid, dim3(256), 0, h->stream, h->Gt, ng, LL, h->Mt, LD, la);
+    }
     K4Args k4a{S, LD, h->Mt, h->Vc, h->X, nullptr, nullptr, nullptr};
     k4a.skip = skipw;
     launch_sg(h, k4a, 0);

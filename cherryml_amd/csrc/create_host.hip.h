@@ -329,7 +329,7 @@ extern "C" int cb_create(int device, int S, int L, int B, int dtype, const doubl
               dev_alloc(h, &h->loss_part, (size_t)B * tiles) == CB_OK &&
               dev_alloc(h, &h->Yk, expm_only ? 0 : (1 + CB_PHI_TERMS) * LL) == CB_OK &&
               dev_alloc(h, &h->Lk, expm_only ? 0 : (1 + CB_PHI_TERMS) * LL) == CB_OK;
-    if (ok && !expm_only && !narrow)   // the time basis (tbasis.hip.h): interpolation matrices, bucket kinds, virtual branch lengths
+    if (ok && !expm_only && !f32)   // the time basis (tbasis.hip.h): interpolation matrices, bucket kinds, virtual branch lengths
       for (int k = 0; k < 2 && ok; ++k)
         ok = dev_alloc(h, &h->tb_Ls[k], (size_t)Bl * CB_TB_RS_MAX) == CB_OK && dev_alloc(h, &h->tb_Lg[k], (size_t)Bl * CB_TB_RG_MAX) == CB_OK &&
              dev_alloc(h, &h->tb_tf[k], Bl) == CB_OK && dev_alloc(h, &h->tb_tg[k], Bl) == CB_OK;

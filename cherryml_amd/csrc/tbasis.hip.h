@@ -432,14 +432,25 @@ __global__ __launch_bounds__(NWAVE * 64, 4) void tb_ew(CbTbEwArgs a) {   // (fou
     tb_ew_step<RS, RG>(b0 + 16, j, k, nsm, sLs, sLg, sT, ltab, psi, a_e, dl, a.inv_n, c1, p1, D, loss, bad);
   }
   if (live) {
-    double *__restrict__ Gh = a.Gh + e;
+    if (a.Gh32) {   // (CB_MIXED: Gh_r rounded to float32 once, here; the two gradient products run on the float32 MFMA)
+      float *__restrict__ Gh = a.Gh32 + e;
 #pragma unroll
-    for (int q = 0; q < RG / 16; ++q)
+      for (int q = 0; q < RG / 16; ++q)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int rr = 16 * q + k + 4 * r;
-        if (rr < a.ng) Gh[(size_t)rr * LL] = D[q][r];
-      }
+        for (int r = 0; r < 4; ++r) {
+          const int rr = 16 * q + k + 4 * r;
+          if (rr < a.ng) Gh[(size_t)rr * LL] = (float)D[q][r];
+        }
+    } else {
+      double *__restrict__ Gh = a.Gh + e;
+#pragma unroll
+      for (int q = 0; q < RG / 16; ++q)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int rr = 16 * q + k + 4 * r;
+          if (rr < a.ng) Gh[(size_t)rr * LL] = D[q][r];
+        }
+    }
   } else {
     loss = 0.0;
     bad = 0;
@@ -457,8 +468,9 @@ __global__ __launch_bounds__(NWAVE * 64, 4) void tb_ew(CbTbEwArgs a) {   // (fou
 
 // Gh_r(16 J + c, 16 I + r) = Gh_r(16 I + r, 16 J + c) for the blocks I < J: one workgroup per (block, virtual bucket), the block
 // through LDS so that both sides move in 128-byte rows.
-__global__ __launch_bounds__(256) void tb_mirror(int LD, double *__restrict__ Gh, const unsigned long long *skip) {
-  __shared__ double tile[16][17];
+template <typename T>
+__global__ __launch_bounds__(256) void tb_mirror(int LD, T *__restrict__ Gh, const unsigned long long *skip) {
+  __shared__ T tile[16][17];
   if (skip && *skip != 0ull) return;
   const int nb = LD / 16;
   int I = 0, rest = (int)blockIdx.x;   // off-diagonal blocks only: row I of the strict triangle holds nb - 1 - I
@@ -467,7 +479,7 @@ __global__ __launch_bounds__(256) void tb_mirror(int LD, double *__restrict__ Gh
     ++I;
   }
   const int J = I + 1 + rest, r = threadIdx.x >> 4, c = threadIdx.x & 15;
-  double *G = Gh + (size_t)blockIdx.y * LD * LD;
+  T *G = Gh + (size_t)blockIdx.y * LD * LD;
   tile[r][c] = G[(size_t)(16 * I + r) * LD + 16 * J + c];
   __syncthreads();
   G[(size_t)(16 * J + r) * LD + 16 * I + c] = tile[c][r];
@@ -517,8 +529,13 @@ int cb_tb_launch_ew(const CbTbEwArgs &a, hipStream_t stream, hipEvent_t stop, in
   // (the mirrored entries written straight from tb_ew -- eight-byte stores LD apart, no second launch -- measured: 0.069 against 0.066 ms)
   if (nb > 1) {
     const dim3 mg((unsigned)(nb * (nb - 1) / 2), (unsigned)a.ng);
-    if (stop) hipExtLaunchKernelGGL(tb_mirror, mg, dim3(256), 0, stream, nullptr, stop, 0, a.LD, a.Gh, a.skip);
-    else hipLaunchKernelGGL(tb_mirror, mg, dim3(256), 0, stream, a.LD, a.Gh, a.skip);
+    if (a.Gh32) {
+      if (stop) hipExtLaunchKernelGGL(tb_mirror<float>, mg, dim3(256), 0, stream, nullptr, stop, 0, a.LD, a.Gh32, a.skip);
+      else hipLaunchKernelGGL(tb_mirror<float>, mg, dim3(256), 0, stream, a.LD, a.Gh32, a.skip);
+    } else {
+      if (stop) hipExtLaunchKernelGGL(tb_mirror<double>, mg, dim3(256), 0, stream, nullptr, stop, 0, a.LD, a.Gh, a.skip);
+      else hipLaunchKernelGGL(tb_mirror<double>, mg, dim3(256), 0, stream, a.LD, a.Gh, a.skip);
+    }
   } else if (stop) {
     (void)hipEventRecord(stop, stream);
   }
