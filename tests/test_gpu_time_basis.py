@@ -105,7 +105,7 @@ def test_shapes_the_time_basis_does_not_serve_keep_the_per_bucket_forms(monkeypa
         l3, g3 = a.loss_grad(Q, pi)
         assert not a.last_bank_form()["time_basis"]
     assert abs(l2[0] - l3[0]) < 1e-13 * abs(l3[0]) and relerr(g2[0], g3[0]) < 1e-11
-    with CherryBank(t, C, dtype="mixed") as a:    # the reduced arithmetics keep their kernels
+    with CherryBank(t, C, dtype="f32") as a:      # float32 P_b keeps its per-bucket kernels
         a.loss_grad(Q, pi)
         assert not a.last_bank_form()["time_basis"]
 
@@ -198,3 +198,28 @@ def test_a_grid_that_needs_too_many_skeleton_buckets_keeps_the_per_bucket_produc
         assert not a.last_bank_form()["time_basis"] and a.time_basis_info()["builds"] == 0
         lb, gb = b.loss_grad(Q, pi)
     assert abs(la[0] - lb[0]) <= 1e-13 * abs(lb[0]) and relerr(ga[0], gb[0]) < 1e-11
+
+
+def test_mixed_bank_in_the_time_basis(dense):
+    """CB_MIXED: forward products, P_b, loss and G_b in float64, Gh_r rounded to float32 once, the two gradient products on the
+    float32 MFMA -- against the float64 time basis (loss: the same arithmetic; gradient: float32 rounding of Gh_r and Th_r) and
+    against three float32 products per bucket (CB_PER_BUCKET_PRODUCTS), on the bench bank and on a ragged one"""
+    from cherryml_amd import CherryBank
+    z = load_golden("coevo_dense_eval.npz")
+    keep = (dense["mask"] != 0) | np.eye(400, dtype=bool)
+    Q = np.zeros((400, 400))
+    Q[keep] = z["Q_support_f64"]
+    p = np.exp(z["log_pi"] - z["log_pi"].max())
+    cases = [(dense["t"], dense["C"], Q, p / p.sum())]
+    rng = np.random.default_rng(3)
+    Qr, pir = _reversible(50, rng, 2.0)
+    cases.append((0.03 * 1.1 ** (np.arange(129) - 64), _sym_counts(50, 129, rng, 0.3), Qr, pir))
+    for t, C, Qx, pix in cases:
+        with CherryBank(t, C) as a, CherryBank(t, C, dtype="mixed") as m, CherryBank(t, C, dtype="mixed", per_bucket_products=True) as mb:
+            la, ga = a.loss_grad(Qx, pix)
+            lm, gm = m.loss_grad(Qx, pix)
+            lb, gb = mb.loss_grad(Qx, pix)
+            assert m.last_bank_form()["time_basis"] and not mb.last_bank_form()["time_basis"]
+        e64, eb = relerr(gm[0], ga[0]), relerr(gm[0], gb[0])
+        print(f"S {C.shape[1]}: mixed time basis: loss {abs(lm[0] - la[0]) / abs(la[0]):.1e}, dL/dQ {e64:.1e} from float64, {eb:.1e} from the mixed per-bucket products")
+        assert abs(lm[0] - la[0]) < 1e-13 * abs(la[0]) and e64 < 2e-6 and eb < 4e-6
