@@ -22,7 +22,7 @@ class CherryBank:
 
     def __init__(self, t, C, device: int = 0, dtype: str = "f64", per_bucket_products: bool = False):
         """per_bucket_products (S > 32, cb_create's CB_PER_BUCKET_PRODUCTS): always form U^T G_b U bucket by bucket; by default a
-        float64 bank with symmetric counts runs in a TIME BASIS from 40 live buckets on (products on ~30 skeleton buckets,
+        float64 bank with symmetric counts runs in a TIME BASIS from 28 live buckets on (products on ~30 skeleton buckets,
         csrc/tbasis.hip.h) and sums the buckets before the last product from 24 on (see include/cherrybank.h).
         dtype: element type of the bank products (cb_create's `dtype`): "f64"; "f32" -- the
         reference's own arithmetic, ratelearner.py:98,107 -- for S > 32 (float32 MFMA; the

@@ -155,9 +155,11 @@ static int launch_small(cb_bank *h, const SmallArgs &a) {
 #define CB_BANK_KG2_MAX_B 20     // live buckets below which the tiles run on eight waves (two K-groups)
 #endif
 #ifndef CB_TB_MIN_B
-#define CB_TB_MIN_B 40           // live buckets from which the bank runs in a time basis (tbasis.hip.h; float64, symmetric counts): the
-                                 // reference's real bank (43 live buckets) gains 2 % and, with a divided difference per virtual bucket instead
-                                 // of the bucket sums' differences, follows the reference to 1e-14 instead of 5e-11 over 50 epochs
+#define CB_TB_MIN_B 28           // live buckets from which the bank runs in a time basis (tbasis.hip.h; float64 / mixed, symmetric counts):
+                                 // 0.522 against 0.534 ms per epoch at 32 buckets, 0.524 against 0.563 at 40 (profiles/tools/
+                                 // r5_tb_short_banks.py); the reference's real bank (43 live buckets) gains 2 % and, with a divided difference
+                                 // per virtual bucket instead of the bucket sums' differences, follows the reference to 1e-14 instead of
+                                 // 5e-11 over 50 epochs
 #endif
 #ifndef CB_TB_GROWTH
 #define CB_TB_GROWTH 3.0         // a basis is built for spectra up to GROWTH x the Gershgorin bound 2 max|Q_ii| of its first matrix

@@ -200,7 +200,7 @@ int cb_last_bank_form(cb_handle h);
  * zero when none has been built. */
 int cb_time_basis_info(cb_handle h, int *n, double *rho_max);
 /* HOST-ONLY (no GPU needed): the interpolative decomposition over the branch-length grid that the S > 32 bank uses when it has
- * >= 40 live buckets with symmetric counts (CB_F64, CB_MIXED).  Every per-bucket quantity of the bank is a smooth function of t_b on
+ * >= 28 live buckets with symmetric counts (CB_F64, CB_MIXED).  Every per-bucket quantity of the bank is a smooth function of t_b on
  * the spectrum [-rho_max, 0]:  phi2(t_b lam) / t_b^2 = sum_r Ls[b][r] phi2(t_s(r) lam) / t_s(r)^2  (buckets with
  * t_b rho_max <= 8; kind[b] = -1), and  e^{t_b mu} = sum_r (Lg[b][r] t_g(r) / t_b) e^{t_g(r) mu}  (all buckets), to 1e-16.
  * n_out[0..2] = ns, nd, ng; kind[B] (-1, or the index k >= 0 of a long-branch bucket that keeps its own product);

@@ -95,7 +95,7 @@ def test_shapes_the_time_basis_does_not_serve_keep_the_per_bucket_forms(monkeypa
     with CherryBank(t, Ca) as a:
         a.loss_grad(Q, pi)
         assert not a.last_bank_form()["time_basis"]
-    with CherryBank(t[:30], C[:30]) as a:         # a short bank: by itself below the threshold, with the hook on
+    with CherryBank(t[:26], C[:26]) as a:         # a short bank: by itself below the threshold, with the hook on
         a.loss_grad(Q, pi)
         assert not a.last_bank_form()["time_basis"]
         monkeypatch.setenv("CB_BANK_TB", "1")
