@@ -277,12 +277,14 @@ static int large_eval(cb_bank *h, bool normalize, double *lossd, double *out, bo
   // forces it off / on (test hook), CB_PER_BUCKET_PRODUCTS at cb_create keeps every bucket's own products.  Behind a planned
   // solve the basis is the one the trainer kept in range with the previous epoch's sigma (lge_norms guards this epoch's: EC_SKIP);
   // otherwise the host reads sigma below (the host-driven solver has waited for the device several times by then).
+  // A rank of a sharded job runs ITS buckets in its own basis (every N-th bucket of an ascending grid is one; the partial sums it
+  // all-reduces are linear in its G_b whatever the form); sigma, hence every rebuild and repeat decision, is the same on all ranks.
   // (a test hook that pins one of the per-bucket forms -- CB_BANK_FUSED / _UNFUSED / _K3 / _KG / _TEST_NO_CLAIM -- means those forms)
   const char *tb_hook = cb_test_hook("CB_BANK_TB");
   const bool form_hooks = cb_test_hook("CB_BANK_FUSED") || cb_test_hook("CB_BANK_UNFUSED") || cb_test_hook("CB_BANK_K3") ||
                           cb_test_hook("CB_BANK_KG") || cb_test_hook("CB_BANK_TEST_NO_CLAIM");
   bool use_tb = h->sym_counts && !h->per_bucket_products && !h->tb_block && !h->tb_failed && !Pd && dQd != nullptr && h->tb_Ls[0] &&
-                n_parts == 1 && (h->dtype == CB_F64 || h->dtype == CB_MIXED) && !h->comm &&
+                n_parts == 1 && (h->dtype == CB_F64 || h->dtype == CB_MIXED) &&
                 (tb_hook ? atoi(tb_hook) != 0 : (!form_hooks && B >= CB_TB_MIN_B));
   if (use_tb && planned_now && h->tb.B != B) use_tb = false;
   {   // (tb_ew leaves one loss partial per half block of the upper block triangle in h->loss_part, B x tiles doubles)
