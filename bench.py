@@ -686,7 +686,7 @@ def main():
                                      "of K1's tiles (Pt symmetric) + all of K2's" + ("" if sum_first else f" + {tri:.2f} of K3's") +
                                      "; executed_frac is the pipe's own utilisation.  epoch_frac prices the WHOLE epoch at "
                                      "SURVEY's 6 B S^3 + 13 S^3 whatever is executed",
-                                mfma_util=util.get("k123"), mfma_util_source=util_src)
+                                mfma_util=next((v for k, v in util.items() if k.startswith("k123")), None), mfma_util_source=util_src)
             else:
                 if sum_first:
                     names.pop("k3")   # (CB_T_K3 is then the bucket sums + their 7 single products + the combination: no B-fold product)
@@ -865,6 +865,11 @@ def main():
                                   "measured alone on this GPU (secondary_shard8: every 8th non-empty bucket + the replicated "
                                   "eigensolver, K4, parameter step, the loop's own enqueue sequence); the 1.28 MB all-reduce "
                                   "over xGMI is NOT in it (single-rank communicator): an upper bound"})
+        if world == 1 and not args.shard_of:
+            # BASELINE.json config 3 AS IT IS: the co-evolution bank of all 32 demo_data families counted by the reference
+            # itself (tests/golden/coevo_demo_full.npz: 43 of 129 buckets non-empty, 3.5 % dense), same steps / warm-up window
+            # as the headline
+            extra["secondary_demo43"] = run("coevo400_demo", steps, warmup, not args.no_cpu_baseline)
         if world == 1:
             # BASELINE.json's metric names both sizes: the line always carries the 20x20 LG configuration
             # too (its own epoch counts: an LG epoch takes < 0.1 ms)
@@ -1324,9 +1329,10 @@ def _mfma_util(dtype):
         d = json.load(f)
     out = {}
     for key, v in d.get("kernels", {}).items():
-        name, dt = key.split(":")
+        name, dt = key.split(":")[:2]   # kernel : arithmetic [: bank form]
         if dt == dtype:
-            out[name.split("_")[0]] = round(v["mfma_util"], 3)
+            form = key.split(":")[2] if key.count(":") >= 2 else ""
+            out[name.split("_")[0] + (":" + form if form else "")] = round(v["mfma_util"], 3)
     return out, f"profiles/mfma_util.json ({d.get('round', 'r02')}, collected {d.get('collected', '2026-10-03')})"
 
 

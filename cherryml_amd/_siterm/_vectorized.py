@@ -23,9 +23,14 @@ def _normalize_rate_matrices(Qs: np.ndarray) -> np.ndarray:
 
 
 def solve_stationary_dist_fast(rate_matrices: np.ndarray, device: str = "cpu") -> np.ndarray:
-    """Stationary distributions by repeated squaring of exp(Q/|mean diag|)
-    (reference :72-104; float32 like the reference so that the inverted
-    initial parameters agree)."""
+    """Stationary distributions by repeated squaring of exp(Q/|mean diag|) (reference :72-104).
+
+    This ONE-OFF initialisation (not the epoch loop) keeps the reference's own third-party call, `torch.matrix_exp` of a
+    float32 tensor on the host, on purpose: the parameters the optimisation starts from are the inverse of THIS float32 result,
+    and the trajectory goldens are followed from the reference's start to 1e-8.  Measured in round 6 with exp(Q_l) from the
+    library's float64 kernels instead (`CherryBank.expm_only(..., num_sites=L).expm_bank`, rounded to float32): the first
+    loss of the 5000-site batch moves by 2e-8 and the 100-epoch curves by 5.6e-4 (tests/test_gpu_siterm_cfg4.py) -- the
+    float32 rounding of torch's Pade evaluation is part of the reference's starting point."""
     Qn = _normalize_rate_matrices(np.asarray(rate_matrices))
     E = torch.matrix_exp(torch.tensor(Qn, dtype=torch.float32)).numpy()
     for _ in range(100):

@@ -103,9 +103,9 @@ class CherryBank:
 
     # -- lifetime ---------------------------------------------------------
     @classmethod
-    def expm_only(cls, t, num_states: int, device: int = 0) -> "CherryBank":
+    def expm_only(cls, t, num_states: int, device: int = 0, num_sites: int = 1) -> "CherryBank":
         """A counts-free bank (cb_create with CB_EXPM_ONLY): branch lengths only, serves `expm_bank` / `eigh`; the loss and
-        training entry points refuse it."""
+        training entry points refuse it.  num_sites > 1: t[num_sites, B], one rate matrix per site."""
         import ctypes as Ct
         lib = _lib.load()
         if lib.cb_device_count() <= 0:
@@ -114,9 +114,12 @@ class CherryBank:
         self._h = None
         self.dtype = "f64"
         tn = _as_f64(t).reshape(-1)
-        self.L, self.B, self.S, self.device = 1, int(tn.size), int(num_states), int(device)
+        L = int(num_sites)
+        if L < 1 or tn.size % L:
+            raise ValueError("expm_only: t must hold num_sites x B branch lengths")
+        self.L, self.B, self.S, self.device = L, int(tn.size) // L, int(num_states), int(device)
         h = Ct.c_void_p()
-        _lib.check(lib.cb_create(self.device, self.S, 1, self.B, _lib.CB_F64, tn.ctypes.data, None, _lib.CB_EXPM_ONLY,
+        _lib.check(lib.cb_create(self.device, self.S, L, self.B, _lib.CB_F64, tn.ctypes.data, None, _lib.CB_EXPM_ONLY,
                                  Ct.byref(h)), "cb_create")
         self._h = h
         return self

@@ -77,6 +77,8 @@ int cb_tb_launch_tables(int LD, int ns, int nd, int ng, const double *tf, const 
 #define CB_TB_LDS_MAX (144u << 10)
 size_t cb_tb_ew_lds_bytes(int B, int ns, int ng);
 bool cb_tb_supported(int B, int LD, int ns, int ng);   // (+ the buffer loads' offset range: B LD^2 below 2^28 doubles)
+// raises tb_ew's dynamic-LDS limit on the CURRENT device for the instantiation (ns, ng) selects; cache: four words of the handle
+int cb_tb_prepare_ew(int B, int ns, int ng, size_t *cache);
 // (*nparts: the loss partials the launch writes)
 int cb_tb_launch_ew(const CbTbEwArgs &a, hipStream_t stream, hipEvent_t stop, int *nparts);
 

@@ -182,7 +182,8 @@ static void tb_drop_next(cb_bank *h) {   // (a helper thread still building: wai
 // upload a built basis to the idle device set and make it the current one
 static int tb_install(cb_bank *h, int B, CbTimeBasisHost &&nb, double ms) {
   // (a CB_MIXED handle keeps Psi_r / P_b as doubles in its float32 T buffer: 2 (ns + nd) of its B planes)
-  if (nb.B != B || !cb_tb_supported(B, h->LD, nb.ns, nb.ng) || (h->dtype == CB_MIXED && 2 * (nb.ns + nb.nd) > B)) {
+  if (nb.B != B || !cb_tb_supported(B, h->LD, nb.ns, nb.ng) || (h->dtype == CB_MIXED && 2 * (nb.ns + nb.nd) > B) ||
+      cb_tb_prepare_ew(B, nb.ns, nb.ng, h->tb_ew_lds) != 0) {   // (the elementwise kernel's LDS limit, on THIS handle's device)
     h->tb_failed = true;
     h->tb = CbTimeBasisHost{};
     return CB_OK;
@@ -208,6 +209,9 @@ static int tb_rebuild(cb_bank *h, int B, double two_sigma) {
   const auto t0 = std::chrono::steady_clock::now();
   CbTimeBasisHost nb;
   if (!cb_tb_build(B, h->t_live_host.data(), two_sigma * tb_growth(), nb)) nb = CbTimeBasisHost{};
+  // tb_install writes the device set that is NOT current; after an install earlier in the same call that is the set the kernels
+  // of a queued epoch still read, and the uploads are not ordered behind h->stream (non-blocking): wait (30 ms were just spent)
+  HIP_TRY(hipStreamSynchronize(h->stream));
   return tb_install(h, B, std::move(nb), std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
 }
 // After every planned epoch of the trainer (`epoch` counts the optimisation's epochs, sigma is the finished solve's): keep a
@@ -225,13 +229,16 @@ static int tb_maintain(cb_bank *h, int B, int epoch, double two_sigma, bool stal
   }
   if (h->tb_failed) return CB_OK;
   if (stale || !tb_in_range(h, B, two_sigma)) {
+    bool took = false;
     if (h->tb_next_pending) {   // the next one is under way (or done): take it now
       CbTimeBasisHost nb = h->tb_next.get();
       h->tb_next_pending = false;
       int rc = tb_install(h, B, std::move(nb), -1.0);
       if (rc != CB_OK || h->tb_failed) return rc;
+      took = true;
     }
-    if (stale || !tb_in_range(h, B, two_sigma)) return tb_rebuild(h, B, two_sigma);
+    // (`stale` was the device's verdict on the basis that has just been replaced: only the range of the new one counts)
+    if ((stale && !took) || !tb_in_range(h, B, two_sigma)) return tb_rebuild(h, B, two_sigma);
     return CB_OK;
   }
   // (test hook CB_TB_TEST_WARN="<headroom> <lead>": e.g. "100 3" starts a helper thread on the next basis right after every swap

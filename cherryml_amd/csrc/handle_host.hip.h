@@ -104,6 +104,7 @@ struct cb_bank {
   std::future<CbTimeBasisHost> tb_next;
   bool tb_next_pending = false;
   int tb_next_epoch = 0;
+  size_t tb_ew_lds[4] = {0, 0, 0, 0};    // dynamic-LDS limit set on this handle's device per tb_ew instantiation (cb_tb_prepare_ew)
   int tb_builds = 0, tb_stale_epochs = 0;   // cb_time_basis_info: bases built; evaluations repeated because theirs was out of range
   bool tb_failed = false;               // the grid needs more skeleton buckets than the maxima: the per-bucket forms, for good
   bool tb_block = false;                // this evaluation repeats one whose basis was out of range: per-bucket products

@@ -504,21 +504,39 @@ size_t cb_tb_ew_lds_bytes(int B, int ns, int ng) {
   return ((size_t)BP * (RS + 1 + RG + 2 + 1) + 256 + 16) * sizeof(double);
 }
 
+// The dynamic-LDS limit of the tb_ew instantiation that serves (ns, ng), raised to what B buckets need.  The attribute belongs to
+// the DEVICE the caller has made current: `cache` (four words, one per instantiation) lives in the handle, so a second handle
+// on another GPU of the same process sets it there too (round 5 kept one word per process: ADVICE r5).
+int cb_tb_prepare_ew(int B, int ns, int ng, size_t *cache) {
+#define TB_PREP(RS_, RG_, slot_)                                                                                         \
+  do {                                                                                                                   \
+    const size_t lds = (size_t)TbEwLds<RS_, RG_>(B).TOTAL * sizeof(double);                                              \
+    if (lds > cache[slot_]) {                                                                                            \
+      if (hipFuncSetAttribute(reinterpret_cast<const void *>(tb_ew<RS_, RG_, 8, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) { \
+        (void)hipGetLastError();                                                                                         \
+        return -1;                                                                                                       \
+      }                                                                                                                  \
+      cache[slot_] = lds;                                                                                                \
+    }                                                                                                                    \
+  } while (0)
+  if (ns <= 16 && ng <= 32) TB_PREP(16, 32, 0);
+  else if (ns <= 16) TB_PREP(16, 48, 1);
+  else if (ng <= 32) TB_PREP(24, 32, 2);
+  else TB_PREP(24, 48, 3);
+#undef TB_PREP
+  return 0;
+}
+
 int cb_tb_launch_ew(const CbTbEwArgs &a, hipStream_t stream, hipEvent_t stop, int *nparts) {
   if (!cb_tb_supported(a.B, a.LD, a.ns, a.ng)) return -1;
   // the symmetric form: eight-wave workgroups (two per CU), items of the upper block triangle, then the mirror copies
   const int nb = a.LD / 16, nblk = nb * (nb + 1) / 2;
   const unsigned grid = (unsigned)(nblk * 2);   // 16 rows per block, 8 per workgroup
   if (nparts) *nparts = (int)grid;
+  // (the dynamic-LDS attribute was set for this device when the basis was installed: cb_tb_prepare_ew)
 #define TB_GO(RS_, RG_)                                                                                                  \
   do {                                                                                                                   \
     const size_t lds = (size_t)TbEwLds<RS_, RG_>(a.B).TOTAL * sizeof(double);                                            \
-    static size_t attr_set = 0;   /* (the largest size asked for so far) */                                              \
-    if (lds > attr_set) {                                                                                                \
-      if (hipFuncSetAttribute(reinterpret_cast<const void *>(tb_ew<RS_, RG_, 8, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) \
-        return -1;                                                                                                       \
-      attr_set = lds;                                                                                                    \
-    }                                                                                                                    \
     hipLaunchKernelGGL((tb_ew<RS_, RG_, 8, true>), dim3(grid), dim3(512), lds, stream, a);                               \
   } while (0)
   if (a.ns <= 16 && a.ng <= 32) TB_GO(16, 32);

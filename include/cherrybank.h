@@ -121,6 +121,12 @@ int cb_live_buckets(cb_handle h, int *nlive);
  * to symmetrise, A = D^1/2 Q D^-1/2, so that the bank is evaluated through one
  * symmetric eigendecomposition A = U diag(lam) U^T per matrix.
  * dQ may be NULL (loss only).
+ * S > 32, >= 28 live buckets, symmetric counts (CB_F64 / CB_MIXED): the bank runs in its time basis (cb_time_basis_info), which
+ * serves spectra up to 3 x 2 max|Q_ii| of the matrix it was built for.  A call outside cb_train_* therefore reads max|Q_ii| back
+ * after its eigensolve -- one 8-byte copy and a wait on the handle's stream, also with CB_NO_SYNC | CB_PTR_DEVICE, whose
+ * "enqueue only" contract does not hold for these banks -- and the FIRST call, or one whose max|Q_ii| has grown 2.4x or shrunk 64x
+ * since the basis was built, spends ~30 ms of host time building a new one.  CB_PER_BUCKET_PRODUCTS at cb_create avoids both
+ * (every bucket's own products, ~1.4x the time per evaluation at 129 buckets).
  */
 int cb_loss_grad(cb_handle h, const double *Q, const double *pi, int flags,
                  double *loss, double *dQ);
@@ -178,8 +184,9 @@ int cb_last_sweeps(cb_handle h);
  * are queued (csrc/eigh_planned.hip.h).  counts[0] = planned solves so far on this handle, counts[1] = how many of them
  * ran out of plan before converging and were continued with more slots ("stalls"; rare), counts[2] = sweeps of the last
  * planned solve, counts[3] = how often the host looked for a solve's record before the device had published it (each such
- * look is a spin on pinned memory with the epoch's bank kernels queued behind the solve).  CB_EIGH_HOST=1 in the
- * environment keeps the host-driven solver of rounds 1-3 (counts stay 0). */
+ * look is a spin on pinned memory with the epoch's bank kernels queued behind the solve).  The test hook CB_EIGH_HOST=1
+ * (honoured only together with CB_TEST_HOOKS=1, like every switch that changes which kernels run) keeps the host-driven
+ * solver of rounds 1-3 (counts stay 0). */
 int cb_eigh_counters(cb_handle h, int *counts, int n);
 /* Which kernels the last cb_train_* call on this handle launched (tests pin the form they compare): 1000 + 100 TS +
  * 10 sym + w3 = the site-parallel split sp_prepare / sp_bank<TS, sym, w3> / sp_finish (TS = ceil(S / 4) tiles, sym =

@@ -123,10 +123,15 @@ for name in ("bench_default", "bench_driver", "bench_coevo400_unfused"):
 # ---- MFMA utilisation (north_star: "rocprof HBM GB/s and MFMA utilisation vs gfx950 peak")
 util = {**STAMP, "source": f"rocprofv3 --pmc SQ_* (one pass of 8 counters), gpurun_out/{tag}_pmc_sq_*; durations from the "
                   "--kernel-trace --stats summaries of the same workloads", "simds": 1024, "clock_GHz": 2.4, "kernels": {}}
+# keys: kernel : arithmetic : bank form.  Round 5 keyed by kernel : arithmetic only, so the CB_BANK_UNFUSED=1 pass (three launches
+# over all 129 buckets: 222 / 278 us) overwrote the headline's time-basis launches of the same kernels (73 / 69 us) -- VERDICT r5.
+FORMS = {"f64": "time_basis", "mixed": "time_basis", "f32": "per_bucket_fused", "f64_unfused": "per_bucket_unfused"}
 for dt, w in (("f64", "coevo400"), ("mixed", "coevo400_mixed"), ("f32", "coevo400_f32"), ("f64_unfused", "coevo400_unfused")):
     fs = newest(f"{root}/gpurun_out/{tag}_pmc_sq_{dt}/*/*counter_collection.csv")
     st = newest(f"{root}/gpurun_out/{tag}_trace_{w}/*/*_kernel_stats.csv")
-    dt = dt.replace("_unfused", "")   # (CB_BANK_UNFUSED=1: the three launches of the float64 bank, keys k1_ / k2_ / k3_ ... :f64)
+    form = FORMS[dt]
+    stats_file = f"{rnd}_{tag}_{w}_kernel_stats.csv"
+    dt = dt.replace("_unfused", "")   # (CB_BANK_UNFUSED=1: the three launches of the float64 bank over all 129 buckets)
     if not fs or not st:
         continue
     dur = {}
@@ -144,7 +149,8 @@ for dt, w in (("f64", "coevo400"), ("mixed", "coevo400_mixed"), ("f32", "coevo40
         if k not in dur or "SQ_VALU_MFMA_BUSY_CYCLES" not in m:
             continue
         wc = m.get("SQ_WAVE_CYCLES", 0.0) or 1.0
-        util["kernels"][f"{k}:{dt}"] = {
+        util["kernels"][f"{k}:{dt}:{form}"] = {
+            "workload": w, "bank_form": form, "durations_from": stats_file,
             "avg_duration_us": dur[k] / 1e3, "mfma_busy_cycles": m["SQ_VALU_MFMA_BUSY_CYCLES"], "mfma_instructions": m.get("SQ_INSTS_MFMA"),
             "mfma_util": m["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024 * dur[k] * 2.4),
             "wave_cycles_split": {"waiting_waitcnt_or_barrier": m.get("SQ_WAIT_ANY", 0.0) / wc, "issue_stalled": m.get("SQ_WAIT_INST_ANY", 0.0) / wc,

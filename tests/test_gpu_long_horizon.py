@@ -1,0 +1,83 @@
+"""The FINISHED optimisation against the reference ("missing 1").  The reference optimises for 500 epochs
+(co-evolution: estimation_end_to_end/_cherry.py:463) or 2000 (_quantized_transitions_mle.py:49); these two trajectories were
+produced by running the reference's own `train_quantization` in float64 for that long (tests/golden/make_golden_long.py) and are
+followed here through the DEFAULT path -- the bank in its time basis, no test hook set:
+
+  long_s64       64 states, B = 129, 2000 epochs from 0.3 x the generating rates: max |Q_ii| grows 3.3x, the time basis is
+                 outgrown, the helper thread builds the next one beside the epochs and the trainer swaps it in (a NATURAL swap:
+                 builds >= 2, no repeated epoch);
+  long_s400_b32  32 buckets of the bench bank, 400 states, 500 epochs.
+
+Bars: loss curve 1e-9 relative at every epoch, learned Q 1e-6 relative Frobenius (BASELINE.json north_star).  Needs an MI355X."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import load_golden, relerr
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+
+pytestmark = pytest.mark.gpu
+
+
+def test_2000_epochs_at_64_states_with_a_natural_basis_swap(monkeypatch):
+    from cherryml_amd import CherryBank
+    from make_golden_long import s64_bank
+    for k in ("CB_TB_TEST_GROWTH", "CB_TB_TEST_WARN", "CB_BANK_TB"):
+        monkeypatch.delenv(k, raising=False)
+    z = load_golden("long_s64.npz")
+    t, C, Q_true, pi, init = s64_bank()
+    assert np.isclose(C.sum(), float(z["C_sum"]), rtol=1e-12) and np.allclose(C[::16, ::7, ::5], z["C_probe"], rtol=1e-12, atol=0)
+    assert np.array_equal(C, C.transpose(0, 2, 1))
+    E = int(z["epochs"])
+    assert E == 2000
+    with CherryBank(t, C) as bank:
+        r = bank.train_pande_reversible(z["upper_diag0"], z["log_pi0"], mask=np.ones((64, 64)), num_epochs=E, lr=0.1)
+        form, info = bank.last_bank_form(), bank.time_basis_info()
+    print(f"64 states, {E} epochs: {info}")
+    assert form["time_basis"]
+    assert info["builds"] >= 2 and info["repeated_epochs"] == 0      # the basis was replaced on the way, nothing was repeated
+    dl = np.max(np.abs(r["loss"] - z["loss_f64"]) / np.abs(z["loss_f64"]))
+    print(f"  loss curve: max rel. difference {dl:.2e} over {E} epochs; loss {r['loss'][0]:.10f} -> {r['loss'][-1]:.10f}")
+    assert dl < 1e-9
+    for key, got in (("Q_1", r["Q_pow2"][1]), ("Q_2", r["Q_pow2"][2]), ("Q_best", r["Q_best"]), ("Q_last", r["Q_last"])):
+        e = relerr(got, z[f"{key}_f64"])
+        print(f"  {key}: rel. Frobenius to the reference {e:.2e}")
+        assert e < 1e-6, key
+    assert 1024 in r["Q_pow2"]
+    print(f"  Q_best to the generating model: {relerr(r['Q_best'], Q_true):.2e} (the reference's: {relerr(z['Q_best_f64'], Q_true):.2e})")
+    assert np.abs(np.diag(r["Q_last"])).max() > 3.0 * np.abs(np.diag(init)).max()
+
+
+def test_500_epochs_at_400_states_on_a_time_basis_bank(monkeypatch):
+    from cherryml_amd import CherryBank
+    import bench
+    for k in ("CB_TB_TEST_GROWTH", "CB_TB_TEST_WARN", "CB_BANK_TB"):
+        monkeypatch.delenv(k, raising=False)
+    z = load_golden("long_s400_b32.npz")
+    wl = bench.make_workload("coevo400", 0, np.random.default_rng(0))
+    assert np.isclose(wl["C"].sum(), float(z["C_sum"]), rtol=1e-12)
+    assert np.allclose(wl["C"][::16, ::37, ::41], z["C_probe"], rtol=1e-12, atol=0)
+    sel, mask, E = z["sel"], wl["mask"], int(z["epochs"])
+    assert E == 500 and len(sel) == 32
+    keep = (mask != 0) | np.eye(400, dtype=bool)
+
+    def full(v):
+        Q = np.zeros((400, 400))
+        Q[keep] = v
+        return Q
+
+    with CherryBank(wl["t"][sel], wl["C"][sel]) as bank:
+        r = bank.train_pande_reversible(z["upper_diag0"], z["log_pi0"], mask=mask, num_epochs=E, lr=0.1)
+        form, info, eig = bank.last_bank_form(), bank.time_basis_info(), bank.eigh_counters()
+    print(f"400 states, 32 buckets, {E} epochs: {info}; eigensolver {eig}")
+    assert form["time_basis"] and info["repeated_epochs"] == 0
+    dl = np.max(np.abs(r["loss"] - z["loss_f64"]) / np.abs(z["loss_f64"]))
+    print(f"  loss curve: max rel. difference {dl:.2e}; loss {r['loss'][0]:.10f} -> {r['loss'][-1]:.10f}")
+    assert dl < 1e-9
+    for key, got in (("Q_1", r["Q_pow2"][1]), ("Q_2", r["Q_pow2"][2]), ("Q_best", r["Q_best"]), ("Q_last", r["Q_last"])):
+        e = relerr(got, full(z[f"{key}_support_f64"]))
+        print(f"  {key}: rel. Frobenius to the reference {e:.2e}")
+        assert e < 1e-6, key

@@ -76,6 +76,43 @@ def test_ragged_banks_against_the_per_bucket_products(S, B, density, scale):
     assert el < 1e-13 and eg < 1e-11
 
 
+def test_two_hundred_live_buckets_need_more_than_64_kb_of_lds_on_every_handle():
+    """B = 200 live buckets: tb_ew's interpolation matrices take more than the 64 KB of dynamic LDS a kernel gets without
+    hipFuncSetAttribute.  The limit is raised when a basis is INSTALLED, per handle (round 5 kept one process-wide
+    word, so a second handle -- on another GPU -- never raised it there): two handles in a row, and a second basis on the first
+    (another spectral range, other ranks), all launch."""
+    from cherryml_amd import CherryBank
+    from cherryml_amd import _lib
+    rng = np.random.default_rng(200)
+    S, B = 48, 200
+    Q, pi = _reversible(S, rng)
+    t = 0.03 * 1.07 ** (np.arange(B) - B // 2)
+    C = _sym_counts(S, B, rng)
+    with CherryBank(t, C, per_bucket_products=True) as b:
+        lb, gb = b.loss_grad(Q, pi)
+    outs = []
+    for _ in range(2):
+        with CherryBank(t, C) as a:
+            la, ga = a.loss_grad(Q, pi)
+            assert a.last_bank_form()["time_basis"]
+            info = a.time_basis_info()
+            l2, g2 = a.loss_grad(3.0 * Q, pi)       # out of the first basis' range: a second one, larger ranks
+            info2, form2 = a.time_basis_info(), a.last_bank_form()
+            print(f"B {B}: {info} -> {info2} {form2}")
+            assert form2["time_basis"] and info2["builds"] == 2
+        outs.append((la[0], ga[0]))
+    ns, ng = info["forward_skeleton"], info["gradient_skeleton"]
+    lds = ((B + 15) // 16 * 16) * ((16 if ns <= 16 else 24) + 1 + (32 if ng <= 32 else 48) + 2 + 1) * 8
+    print(f"B {B}: {info} -> {info2}; tb_ew LDS >= {lds} bytes")
+    assert lds > 65536
+    assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
+    assert abs(outs[0][0] - lb[0]) < 1e-13 * abs(lb[0]) and relerr(outs[0][1], gb[0]) < 1e-11
+    with CherryBank(t, C, per_bucket_products=True) as b:
+        l3, g3 = b.loss_grad(3.0 * Q, pi)
+    assert abs(l2[0] - l3[0]) < 1e-13 * abs(l3[0]) and relerr(g2[0], g3[0]) < 1e-10
+    assert _lib.load().cb_device_count() >= 1
+
+
 def test_shapes_the_time_basis_does_not_serve_keep_the_per_bucket_forms(monkeypatch):
     from cherryml_amd import CherryBank
     rng = np.random.default_rng(5)
