@@ -46,8 +46,29 @@ enum {
   EC_REC = 16,     // 4 words per sweep: cosine, row sum (all pairs), row sum (far pairs), EC_MODE | sq << 24
   EC_MAXREC = 12,
   EC_JSTATE = 64,  // two words of lgj_round's own (running maximum; "finished", which stays zero here)
-  EC_WORDS = 80
+  EC_T0 = 80,      // s_memrealtime (100 MHz) when lge_begin ran, EC_TSWEEP + k: when sweep k's decision was taken, EC_TEND: lge_norms
+  EC_TSWEEP = 81,  //   -- where a solve's time goes WITHOUT a tracer attached (CB_DEBUG prints the differences)
+  EC_TEND = 93,
+  EC_NSTAMP = 95,  // -DCB_EIGH_STAMPS (diagnostic build): every kernel of the solve leaves (s_memrealtime << 8 | kernel id) at its entry
+  EC_STAMPS = 96,  //   in EC_STAMPS + i, i counted in EC_NSTAMP: the solve's launch-by-launch timeline with no tracer attached
+#ifdef CB_EIGH_STAMPS
+  EC_WORDS = 96 + 96
+#else
+  EC_WORDS = 96
+#endif
 };
+#ifdef CB_EIGH_STAMPS
+__device__ __forceinline__ void lge_stamp(unsigned long long *ctl, int id) {
+  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
+    const unsigned long long i = atomicAdd(ctl + EC_NSTAMP, 1ull);
+    if (i < 96ull) ctl[EC_STAMPS + i] = ((unsigned long long)__builtin_amdgcn_s_memrealtime() << 8) | (unsigned long long)id;
+  }
+}
+#define LGE_STAMP(ctl, id) lge_stamp(const_cast<unsigned long long *>(ctl), id)
+#else
+
+#define LGE_STAMP(ctl, id) ((void)0)
+#endif
 #define EC_NONE 0xFFFFFFFFull
 
 struct GramArgs {
@@ -78,6 +99,7 @@ __global__ __launch_bounds__(512, 6) void lge_gram(GramArgs a) {   // 6 waves pe
   __shared__ double sD[2][16];
   __shared__ double sStat[1][8];
   const unsigned long long *ctl = a.ctl;
+  LGE_STAMP(ctl, 4);
   if (ctl[EC_STALL] != 0ull || (unsigned long long)a.slot > ctl[EC_FINAL]) return;
   const int LD = a.LD, nt = LD / 16;
   const int tm = blockIdx.x / nt, tn = blockIdx.x - tm * nt;
@@ -85,6 +107,8 @@ __global__ __launch_bounds__(512, 6) void lge_gram(GramArgs a) {   // 6 waves pe
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, lo = lane & 15, hi = lane >> 4;
   const double *rowA = a.G + (size_t)(m0 + lo) * LD + 4 * hi, *rowB = a.G + (size_t)(n0 + lo) * LD + 4 * hi;
   // (two accumulators, not four: 96 registers would leave two workgroups per CU = 512 slots for the 625 tiles, i.e. two rounds)
+  // (requesting the first chunks BEFORE the control words are looked at, as lge_gemm does, was tried in round 6: the kernel sits at
+  // its 80-register budget and spilled 26)
   d4 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = acc0;
   double da = 0.0, db = 0.0;
   const int nchunks = LD / 16;
@@ -185,6 +209,7 @@ __global__ __launch_bounds__(512, 6) void lge_gram(GramArgs a) {   // 6 waves pe
 __global__ __launch_bounds__(512) void lge_decide(GramArgs a) {
   __shared__ double sStat[3][8];
   unsigned long long *ctl = a.ctl;
+  LGE_STAMP(ctl, 5);
   if (ctl[EC_STALL] != 0ull || (unsigned long long)a.slot > ctl[EC_FINAL]) return;
   const int LD = a.LD, nt = LD / 16;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -272,6 +297,7 @@ __global__ __launch_bounds__(512) void lge_decide(GramArgs a) {
   ctl[EC_SQ] = sq;
   ctl[EC_SC] = dbl_bits(sc);
   if (k < EC_MAXREC) {
+    ctl[EC_TSWEEP + k] = __builtin_amdgcn_s_memrealtime();
     ctl[EC_REC + 4 * k + 0] = dbl_bits(cosmax);
     ctl[EC_REC + 4 * k + 1] = dbl_bits(rowsum);
     ctl[EC_REC + 4 * k + 2] = dbl_bits(rowsum_far);
@@ -284,101 +310,37 @@ enum { EG_P2 = 0, EG_P34, EG_T1, EG_RP, EG_SQ, EG_GR, EG_R4 };
 
 struct EgArgs {
   int LD, slot, kind, q;             // q: index of an EG_SQ launch
+  int cap;                           // the slot's highest polynomial order: 4 (EG_P2, EG_R4, EG_GR) or 12
+  int early;                         // the plan expects this launch to RUN: operands that do not depend on the decision are requested
+                                     // before the control words are looked at (a launch that then returns has paid for 26 loads:
+                                     // 6 us instead of 4.4 -- so launches the plan expects to return at once do not do this)
   const unsigned long long *ctl;
-  const double *X, *Xf;              // EG_P2 / EG_P34: the generator (all pairs / far pairs)
-  double *P2, *P3, *P4;
-  const double *B0, *B1, *B2;        // lge_poly's outputs
-  double *T;                         // EG_T1's output (8th order: lge_poly writes it)
+  const double *X, *Xf;              // the generator (all pairs / far pairs or second order)
+  double *P2, *P4;
+  double *B0, *B1, *B2;              // lge_p34's outputs (the polynomial's coefficient matrices); cap 4: B0 = s X / 6 - s^2 P2 / 24
+  double *T;                         // EG_T1's output (8th order: lge_p34 writes it)
   double *R[2], *Rt[2];              // R_q lives in R[q & 1], its transpose in Rt[q & 1]
+  double *Rfin;                      // the rotation of the sweep (whichever launch completes it writes it HERE: EG_GR's operand is static)
   const double *Gin;                 // EG_GR
   double *Gout;
 };
 
-// out[m][n] = sum_k Aop[k][m] Bop[k][n]: sg_gemm<8, 7, 1>'s tile (one 16 x 16 tile per workgroup, K over 8 waves, seven
-// k-steps in flight) with the operands, the epilogue and the decision to run at all taken from the control block.
-// gridDim.y == 2 (EG_P34): blockIdx.y == 0 forms X^3, 1 forms X^4.
-__global__ __launch_bounds__(512) void lge_gemm(EgArgs a) {
-  __shared__ double sRed[4][256];
-  const unsigned long long *ctl = a.ctl;
-  if (ctl[EC_STALL] != 0ull || (unsigned long long)a.slot > ctl[EC_FINAL]) return;
-  const unsigned long long mode = ctl[EC_MODE];
-  if (!(mode >> 16)) return;
-  const int order = (int)(mode & 255ull);
-  const bool masked = (mode & (256ull | 1024ull)) != 0ull;   // far pairs only, OR the second-order generator: both live in Xf
-  const int sq = (int)ctl[EC_SQ];
-  double sc;
-  {
-    const unsigned long long b = ctl[EC_SC];
-    memcpy(&sc, &b, 8);
-  }
-  const int LD = a.LD;
-  const double *Ap, *Bp, *Bp2 = nullptr, *sub = nullptr, *sub2 = nullptr;
-  double *out, *outT = nullptr;
-  double alpha = 1.0, beta = 0.0, beta2 = 0.0, eye = 0.0, c1 = 1.0, c2 = 0.0;
-  const double *Xu = masked ? a.Xf : a.X;
-  switch (a.kind) {
-    case EG_P2:   // X^T X = -X^2; second order: R = I + Y + Y^2 / 2 = I + s X - s^2 X^T X / 2 at once (s < 1: a damped sweep)
-      Ap = Xu; Bp = Xu;
-      if (order == 2) { out = a.R[0]; sub = Xu; alpha = -0.5 * (sc * sc); beta = sc; eye = 1.0; }
-      else out = a.P2;
-      break;
-    case EG_R4:   // fourth order in one product (slots without the polynomial launches):
-      // R = I + Y + Y^2/2 + Y^2 (Y/6 + Y^2/24),  Y = s X,  Y^2 = -s^2 P2:  acc = P2 (s X / 6 - s^2 P2 / 24)
-      if (order != 4) return;
-      Ap = a.P2; Bp = Xu; Bp2 = a.P2; c1 = sc * (1.0 / 6.0); c2 = -(sc * sc) * (1.0 / 24.0);
-      out = a.R[0]; alpha = -(sc * sc); sub = Xu; beta = sc; sub2 = a.P2; beta2 = -0.5 * (sc * sc); eye = 1.0;
-      break;
-    case EG_P34:
-      if (order < 4) return;
-      if (blockIdx.y == 0) { Ap = Xu; Bp = a.P2; out = a.P3; }     // X^T P2 = X^3
-      else { Ap = a.P2; Bp = a.P2; out = a.P4; }                   // P2^T P2 = X^4
-      break;
-    case EG_T1:   // T = B1 + Y^4 B2   (Y^4 = s^4 P4, symmetric)
-      if (order != 12) return;
-      Ap = a.P4; Bp = a.B2; out = a.T; sub = a.B1; alpha = (sc * sc) * (sc * sc); beta = 1.0;
-      break;
-    case EG_RP:   // R_0 = B0 + Y^4 T
-      if (order < 8) return;
-      Ap = a.P4; Bp = a.T; out = a.R[0]; outT = a.Rt[0]; sub = a.B0; alpha = (sc * sc) * (sc * sc); beta = 1.0;
-      break;
-    case EG_SQ:   // R_{q+1} = R_q R_q
-      if (a.q >= sq) return;
-      Ap = a.Rt[a.q & 1]; Bp = a.R[a.q & 1]; out = a.R[(a.q + 1) & 1]; outT = a.Rt[(a.q + 1) & 1];
-      break;
-    default:      // EG_GR: Gout[c'][r] = sum_c R[c][c'] Gin[c][r]
-      Ap = a.R[sq & 1]; Bp = a.Gin; out = a.Gout;
-      break;
-  }
-  const int nt = LD / 16;
-  const int tm = blockIdx.x / nt, tn = blockIdx.x - tm * nt;
-  const int m0 = tm * 16, n0 = tn * 16;
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, lo = lane & 15, hi = lane >> 4;
-  d4 acc = {0.0, 0.0, 0.0, 0.0};
-  const int nsteps = LD / 4;
-  Ap += m0 + lo;
-  Bp += n0 + lo;
-  if (Bp2) Bp2 += n0 + lo;
-  for (int s0 = wave; s0 < nsteps; s0 += 7 * 8) {   // seven k-steps of this wave in flight
-    double av[7], bv[7];
-#pragma unroll
-    for (int u = 0; u < 7; ++u) {
-      const int s = min(s0 + 8 * u, nsteps - 1);
-      const size_t krow = (size_t)(4 * s + hi) * LD;
-      av[u] = Ap[krow];
-      bv[u] = Bp[krow];
-    }
-    if (Bp2) {   // (workgroup-uniform) second B operand: B = c1 Bp + c2 Bp2
-#pragma unroll
-      for (int u = 0; u < 7; ++u) {
-        const int s = min(s0 + 8 * u, nsteps - 1);
-        bv[u] = fma(c2, Bp2[(size_t)(4 * s + hi) * LD], c1 * bv[u]);
-      }
-    }
-#pragma unroll
-    for (int u = 0; u < 7; ++u)
-      if (s0 + 8 * u < nsteps) acc = mfma_f64(av[u], bv[u], acc);
-  }
-  // K was split over the 8 waves: fold the upper four into the lower four, then sum those
+// The polynomial coefficients of exp(Y), Y = s X, from X, P2 = -X^2, P3 = X^3, P4 = X^4 (elementwise):
+//   order 4:  R_0 = I + Y + Y^2/2 + Y^3/6 + Y^4/24
+//   order 8:  B0 = I + Y + Y^2/2 + Y^3/6,  T = I/4! + Y/5! + Y^2/6! + Y^3/7! + Y^4/8!          (R_0 = B0 + Y^4 T)
+//   order 12: B0, B1 = I/4! + .. + Y^3/7!, B2 = I/8! + Y/9! + Y^2/10! + Y^3/11! + Y^4/12!      (R_0 = B0 + Y^4 (B1 + Y^4 B2))
+// (round 5 had a launch of its own for them, lge_poly -- 5 us per sweep that needs them; now lge_p34's epilogue, which holds
+// X^3 and X^4 of its tile, forms them)
+
+// element [4 s + hi][c0 + lo] of a k-major LD x LD operand as a buffer load: resource = the matrix, scalar offset = the k-step's
+// rows (wave-uniform), vector offset = the lane's 32-bit byte offset -- thirteen loads in flight cost thirteen data registers
+__device__ __forceinline__ double lge_ld(const double *base, int s, int LD, int c0, unsigned lane_bytes) {
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(base), 0, 0x7fffffff, 0x00027000);
+  return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rs, (int)lane_bytes, (int)((unsigned)(4 * s * LD + c0) * 8u), 0));
+}
+
+// K was split over the 8 waves of a tile: fold the upper four partial tiles into the lower four, then sum those (fixed order)
+__device__ __forceinline__ double lge_fold8(double (*sRed)[256], d4 acc, int wave, int lane, int et) {
   if (wave >= 4) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) sRed[wave - 4][r * 64 + lane] = acc[r];
@@ -394,17 +356,219 @@ __global__ __launch_bounds__(512) void lge_gemm(EgArgs a) {
     for (int r = 0; r < 4; ++r) sRed[wave][r * 64 + lane] = acc[r];
   }
   __syncthreads();
-  if (threadIdx.x >= 256) return;
-  const int t = threadIdx.x, r = t >> 6, l = t & 63;
-  const int row = m0 + (l >> 4) + 4 * r, col = n0 + (l & 15);
-  const double v = (sRed[0][t] + sRed[1][t]) + (sRed[2][t] + sRed[3][t]);
+  return (sRed[0][et] + sRed[1][et]) + (sRed[2][et] + sRed[3][et]);
+}
+
+// out[m][n] = sum_k Aop[k][m] Bop[k][n]: one 16 x 16 tile per workgroup, K over 8 waves, with the operands, the epilogue and
+// the decision to run at all taken from the control block.  One instantiation per kind.
+// A launch is a chain of dependent memory latencies (~1 us each behind a kernel boundary, which leaves the L2 cold), not
+// arithmetic; round 6 took three links out of it: ALL k-steps of a wave are in flight at once (13 at LD = 400; round 5: two
+// batches of 7), operands that do not depend on the decision (P4, B2, T, R_q, G, what the epilogue adds) are requested BEFORE the
+// control words are looked at, and the epilogue's terms in front of the K loop instead of behind the reduction.
+#define LGE_UU 13
+template <int KIND>
+__global__ __launch_bounds__(512) void lge_gemm(EgArgs a) {
+  __shared__ double sRed[4][256];
+  const unsigned long long *ctl = a.ctl;
+  LGE_STAMP(ctl, 10 + KIND);
+  const int LD = a.LD, nt = LD / 16;
+  const int tm = blockIdx.x / nt, tn = blockIdx.x - tm * nt;
+  const int m0 = tm * 16, n0 = tn * 16;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, lo = lane & 15, hi = lane >> 4;
+  const int nsteps = LD / 4;
+  const unsigned loff = (unsigned)(hi * LD + lo) * 8u;
+  const int et = threadIdx.x & 255, er = et >> 6, el = et & 63;
+  const int row = m0 + (el >> 4) + 4 * er, col = n0 + (el & 15);
   const size_t idx = (size_t)row * LD + col;
-  double o = alpha * v;
-  if (sub) o = fma(beta, sub[idx], o);
-  if (sub2) o = fma(beta2, sub2[idx], o);
-  if (eye != 0.0 && row == col) o += eye;
-  out[idx] = o;
-  if (outT) outT[(size_t)col * LD + row] = o;
+  const bool ep = threadIdx.x < 256;
+  // ---- operands known without the control block
+  const double *Ap = nullptr, *Bp = nullptr, *Ep = nullptr;
+  if (KIND == EG_T1) { Ap = a.P4; Bp = a.B2; Ep = a.B1; }
+  if (KIND == EG_RP) { Ap = a.P4; Bp = a.T; Ep = a.B0; }
+  if (KIND == EG_SQ) { Ap = a.Rt[a.q & 1]; Bp = a.R[a.q & 1]; }
+  if (KIND == EG_GR) { Ap = a.Rfin; Bp = a.Gin; }
+  if (KIND == EG_R4) { Ap = a.P2; Bp = a.B0; Ep = a.P2; }
+  double av[LGE_UU], bv[LGE_UU], e1 = 0.0, ex = 0.0;
+  const bool early = KIND != EG_P2 && a.early != 0;
+  if (early) {
+#pragma unroll
+    for (int u = 0; u < LGE_UU; ++u) {
+      const int sk = min(wave + 8 * u, nsteps - 1);
+      av[u] = lge_ld(Ap, sk, LD, m0, loff);
+      bv[u] = lge_ld(Bp, sk, LD, n0, loff);
+    }
+    if (Ep && ep) e1 = Ep[idx];
+  }
+  // ---- the decision: five words of one cache line, requested BEHIND the early operand loads (scalar loads return out of order:
+  // a wait for the kernel's own arguments would be a wait for every scalar load issued before it)
+  const unsigned long long w_stall = ctl[EC_STALL], w_final = ctl[EC_FINAL], mode = ctl[EC_MODE], w_sq = ctl[EC_SQ], w_sc = ctl[EC_SC];
+  if (w_stall != 0ull || (unsigned long long)a.slot > w_final) return;
+  if (!(mode >> 16)) return;
+  const int order = (int)(mode & 255ull);
+  const bool masked = (mode & (256ull | 1024ull)) != 0ull;   // far pairs only, OR the second-order generator: both live in Xf
+  const int sq = (int)w_sq;
+  double sc;
+  memcpy(&sc, &w_sc, 8);
+  const double *Xu = masked ? a.Xf : a.X;
+  if (KIND == EG_R4 && order != 4) return;
+  if (KIND == EG_T1 && order != 12) return;
+  if (KIND == EG_RP && order < 8) return;      // (order 4 in a slot with the X^3 / X^4 launch: lge_p34 has written the rotation)
+  if (KIND == EG_SQ && a.q >= sq) return;
+  if (!early) {
+    const double *pa = KIND == EG_P2 ? Xu : Ap, *pb = KIND == EG_P2 ? Xu : Bp;
+#pragma unroll
+    for (int u = 0; u < LGE_UU; ++u) {
+      const int sk = min(wave + 8 * u, nsteps - 1);
+      av[u] = lge_ld(pa, sk, LD, m0, loff);
+      bv[u] = lge_ld(pb, sk, LD, n0, loff);
+    }
+    if (KIND != EG_P2 && Ep && ep) e1 = Ep[idx];
+  }
+  if ((KIND == EG_P2 || KIND == EG_R4) && ep) ex = Xu[idx];
+  d4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int u = 0; u < LGE_UU; ++u)
+    if (wave + 8 * u < nsteps) acc = mfma_f64(av[u], bv[u], acc);
+  for (int s0 = wave + 8 * LGE_UU; s0 < nsteps; s0 += 8 * LGE_UU) {   // (LD > 416)
+    const double *pa = KIND == EG_P2 ? Xu : Ap, *pb = KIND == EG_P2 ? Xu : Bp;
+#pragma unroll
+    for (int u = 0; u < LGE_UU; ++u) {
+      const int sk = min(s0 + 8 * u, nsteps - 1);
+      av[u] = lge_ld(pa, sk, LD, m0, loff);
+      bv[u] = lge_ld(pb, sk, LD, n0, loff);
+    }
+#pragma unroll
+    for (int u = 0; u < LGE_UU; ++u)
+      if (s0 + 8 * u < nsteps) acc = mfma_f64(av[u], bv[u], acc);
+  }
+  const double v = lge_fold8(sRed, acc, wave, lane, et);
+  if (!ep) return;
+  const double edl = row == col ? 1.0 : 0.0, s2 = sc * sc;
+  if (KIND == EG_P2) {
+    // X^T X = -X^2.  Second order: R = I + Y + Y^2 / 2 = I + s X - s^2 X^T X / 2 at once (s < 1: a damped sweep); a slot without
+    // the X^3 / X^4 launch also leaves the second operand of its fourth-order product, s X / 6 - s^2 P2 / 24
+    if (order == 2) {
+      a.Rfin[idx] = fma(-0.5 * s2, v, fma(sc, ex, edl));
+    } else {
+      a.P2[idx] = v;
+      if (a.cap == 4) a.B0[idx] = fma(-s2 * (1.0 / 24.0), v, (sc * (1.0 / 6.0)) * ex);
+    }
+  } else if (KIND == EG_R4) {
+    // fourth order in one product:  R = I + Y + Y^2/2 + Y^2 (Y/6 + Y^2/24),  Y = s X,  Y^2 = -s^2 P2:  acc = P2 (s X / 6 - s^2 P2 / 24)
+    a.Rfin[idx] = fma(-s2, v, fma(-0.5 * s2, e1, fma(sc, ex, edl)));
+  } else if (KIND == EG_T1) {
+    a.T[idx] = fma(s2 * s2, v, e1);                      // T = B1 + Y^4 B2   (Y^4 = s^4 P4, symmetric)
+  } else if (KIND == EG_RP) {
+    const double o = fma(s2 * s2, v, e1);                // R_0 = B0 + Y^4 T
+    if (sq == 0) a.Rfin[idx] = o;
+    else {
+      a.R[0][idx] = o;
+      a.Rt[0][(size_t)col * LD + row] = o;
+    }
+  } else if (KIND == EG_SQ) {                            // R_{q+1} = R_q R_q
+    if (a.q == sq - 1) a.Rfin[idx] = v;
+    else {
+      a.R[(a.q + 1) & 1][idx] = v;
+      a.Rt[(a.q + 1) & 1][(size_t)col * LD + row] = v;
+    }
+  } else {
+    a.Gout[idx] = v;                                     // EG_GR: Gout[c'][r] = sum_c R[c][c'] Gin[c][r]
+  }
+}
+
+// X^3 = X^T P2 and X^4 = P2^T P2 of one 16 x 16 tile in ONE workgroup (waves 0-3: X^3, waves 4-7: X^4, K over four waves each, two
+// batches of 13 / 12 k-steps), then the polynomial's coefficient matrices from the four powers the workgroup now holds for its
+// tile: B0, B1, B2 (order 12), B0, T (order 8) or the finished rotation (order 4).  The operands that are P2 are requested before
+// the control words are looked at.
+__global__ __launch_bounds__(512) void lge_p34(EgArgs a) {
+  __shared__ double sRed[8][256];
+  const unsigned long long *ctl = a.ctl;
+  LGE_STAMP(ctl, 17);
+  const int LD = a.LD, nt = LD / 16;
+  const int tm = blockIdx.x / nt, tn = blockIdx.x - tm * nt;
+  const int m0 = tm * 16, n0 = tn * 16;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, lo = lane & 15, hi = lane >> 4;
+  const int w4 = wave & 3;
+  const bool fourth = wave >= 4;   // (wave-uniform)
+  const int nsteps = LD / 4;
+  const unsigned loff = (unsigned)(hi * LD + lo) * 8u;
+  const int et = threadIdx.x & 255, er = et >> 6, el = et & 63;
+  const int row = m0 + (el >> 4) + 4 * er, col = n0 + (el & 15);
+  const size_t idx = (size_t)row * LD + col;
+  const bool ep = threadIdx.x < 256;
+  double av[LGE_UU], bv[LGE_UU], e2 = 0.0;
+  const bool early = a.early != 0;
+  if (early) {
+#pragma unroll
+    for (int u = 0; u < LGE_UU; ++u) {
+      const int sk = min(w4 + 4 * u, nsteps - 1);
+      bv[u] = lge_ld(a.P2, sk, LD, n0, loff);
+      if (fourth) av[u] = lge_ld(a.P2, sk, LD, m0, loff);
+    }
+    if (ep) e2 = a.P2[idx];
+  }
+  const unsigned long long w_stall = ctl[EC_STALL], w_final = ctl[EC_FINAL], mode = ctl[EC_MODE], w_sc = ctl[EC_SC];
+  if (w_stall != 0ull || (unsigned long long)a.slot > w_final) return;
+  if (!(mode >> 16)) return;
+  const int order = (int)(mode & 255ull);
+  if (order < 4) return;
+  const bool masked = (mode & (256ull | 1024ull)) != 0ull;
+  double sc;
+  memcpy(&sc, &w_sc, 8);
+  const double *Xu = masked ? a.Xf : a.X;
+  const double *Ap = fourth ? a.P2 : Xu;
+  if (!early) {
+#pragma unroll
+    for (int u = 0; u < LGE_UU; ++u) {
+      const int sk = min(w4 + 4 * u, nsteps - 1);
+      bv[u] = lge_ld(a.P2, sk, LD, n0, loff);
+      av[u] = lge_ld(Ap, sk, LD, m0, loff);
+    }
+    if (ep) e2 = a.P2[idx];
+  } else if (!fourth) {
+#pragma unroll
+    for (int u = 0; u < LGE_UU; ++u) av[u] = lge_ld(Xu, min(w4 + 4 * u, nsteps - 1), LD, m0, loff);
+  }
+  double ex = 0.0;
+  if (ep) ex = Xu[idx];
+  d4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int u = 0; u < LGE_UU; ++u)
+    if (w4 + 4 * u < nsteps) acc = mfma_f64(av[u], bv[u], acc);
+  for (int s0 = w4 + 4 * LGE_UU; s0 < nsteps; s0 += 4 * LGE_UU) {
+#pragma unroll
+    for (int u = 0; u < LGE_UU; ++u) {
+      const int sk = min(s0 + 4 * u, nsteps - 1);
+      av[u] = lge_ld(Ap, sk, LD, m0, loff);
+      bv[u] = lge_ld(a.P2, sk, LD, n0, loff);
+    }
+#pragma unroll
+    for (int u = 0; u < LGE_UU; ++u)
+      if (s0 + 4 * u < nsteps) acc = mfma_f64(av[u], bv[u], acc);
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) sRed[wave][r * 64 + lane] = acc[r];
+  __syncthreads();
+  if (!ep) return;
+  const double p3 = (sRed[0][et] + sRed[1][et]) + (sRed[2][et] + sRed[3][et]);
+  const double p4 = (sRed[4][et] + sRed[5][et]) + (sRed[6][et] + sRed[7][et]);
+  const double dl = row == col ? 1.0 : 0.0;
+  const double s2 = sc * sc;
+  const double y1 = sc * ex, y2 = -s2 * e2, y3 = s2 * sc * p3, y4 = s2 * s2 * p4;
+  const double b0 = dl + y1 + 0.5 * y2 + y3 * (1.0 / 6.0);
+  if (order == 4) {
+    a.Rfin[idx] = b0 + y4 * (1.0 / 24.0);
+    return;
+  }
+  a.P4[idx] = p4;
+  a.B0[idx] = b0;
+  const double b1 = dl * (1.0 / 24.0) + y1 * (1.0 / 120.0) + y2 * (1.0 / 720.0) + y3 * (1.0 / 5040.0);
+  if (order == 8) {
+    a.T[idx] = b1 + y4 * (1.0 / 40320.0);
+    return;
+  }
+  a.B1[idx] = b1;
+  a.B2[idx] = dl * (1.0 / 40320.0) + y1 * (1.0 / 362880.0) + y2 * (1.0 / 3628800.0) + y3 * (1.0 / 39916800.0) + y4 * (1.0 / 479001600.0);
 }
 
 // Second-order generator of an all-pairs sweep.  With Gamma = D + E (E off-diagonal) the rotation exp(X) that diagonalises
@@ -421,13 +585,13 @@ struct SoArgs {
   const unsigned long long *ctl;
   const double *Gm, *dg, *X;
   double *Xs;   // = Xf
+  int early;    // the plan expects the launch to run: its first operands are requested before the control block is looked at
 };
 
 __global__ __launch_bounds__(512) void lge_so(SoArgs a) {
   __shared__ double sRed[4][256];
   const unsigned long long *ctl = a.ctl;
-  if (ctl[EC_STALL] != 0ull || (unsigned long long)a.slot > ctl[EC_FINAL]) return;
-  if (!(ctl[EC_MODE] & 1024ull)) return;
+  LGE_STAMP(ctl, 6);
   const int LD = a.LD, nt = LD / 16;
   const int tm = blockIdx.x / nt, tn = blockIdx.x - tm * nt;
   const int m0 = tm * 16, n0 = tn * 16;
@@ -435,8 +599,8 @@ __global__ __launch_bounds__(512) void lge_so(SoArgs a) {
   d4 accA = {0.0, 0.0, 0.0, 0.0}, accB = accA;
   const int nsteps = LD / 4;
   const double *Em = a.Gm + m0 + lo, *En = a.Gm + n0 + lo, *Xm = a.X + m0 + lo, *Xn = a.X + n0 + lo;
-  for (int s0 = wave; s0 < nsteps; s0 += 7 * 8) {   // seven k-steps of this wave in flight
-    double e1[7], x1[7], x2[7], e2[7];
+  double e1[7], x1[7], x2[7], e2[7];
+  auto issue = [&](int s0) {
 #pragma unroll
     for (int u = 0; u < 7; ++u) {
       const int s = min(s0 + 8 * u, nsteps - 1);
@@ -447,6 +611,14 @@ __global__ __launch_bounds__(512) void lge_so(SoArgs a) {
       x2[u] = Xm[krow];
       e2[u] = k == n0 + lo ? 0.0 : En[krow];
     }
+  };
+  if (a.early) issue(wave);
+  // (the control words are requested BEHIND the early loads: see lge_gemm)
+  const unsigned long long w_stall = ctl[EC_STALL], w_final = ctl[EC_FINAL], w_mode = ctl[EC_MODE];
+  if (w_stall != 0ull || (unsigned long long)a.slot > w_final) return;
+  if (!(w_mode & 1024ull)) return;
+  for (int s0 = wave; s0 < nsteps; s0 += 7 * 8) {   // seven k-steps of this wave in flight
+    if (!(a.early && s0 == wave)) issue(s0);
 #pragma unroll
     for (int u = 0; u < 7; ++u)
       if (s0 + 8 * u < nsteps) {
@@ -482,55 +654,11 @@ __global__ __launch_bounds__(512) void lge_so(SoArgs a) {
   a.Xs[idx] = x1v + x2v;
 }
 
-// The polynomial coefficients of exp(Y), Y = s X, from X, P2 = -X^2, P3 = X^3, P4 = X^4 (elementwise):
-//   order 4:  R_0 = I + Y + Y^2/2 + Y^3/6 + Y^4/24
-//   order 8:  B0 = I + Y + Y^2/2 + Y^3/6,  T = I/4! + Y/5! + Y^2/6! + Y^3/7! + Y^4/8!          (R_0 = B0 + Y^4 T)
-//   order 12: B0, B1 = I/4! + .. + Y^3/7!, B2 = I/8! + Y/9! + Y^2/10! + Y^3/11! + Y^4/12!      (R_0 = B0 + Y^4 (B1 + Y^4 B2))
-struct PolyArgs {
-  int LD, slot;
-  const unsigned long long *ctl;
-  const double *X, *Xf, *P2, *P3, *P4;
-  double *B0, *B1, *B2, *T, *R0;
-};
-
-__global__ __launch_bounds__(256) void lge_poly(PolyArgs a) {
-  const unsigned long long *ctl = a.ctl;
-  if (ctl[EC_STALL] != 0ull || (unsigned long long)a.slot > ctl[EC_FINAL]) return;
-  const unsigned long long mode = ctl[EC_MODE];
-  const int order = (int)(mode & 255ull);
-  if (!(mode >> 16) || order < 4) return;
-  double sc;
-  {
-    const unsigned long long b = ctl[EC_SC];
-    memcpy(&sc, &b, 8);
-  }
-  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= (size_t)a.LD * a.LD) return;
-  const int i = idx / a.LD, j = idx - (size_t)i * a.LD;
-  const double dl = i == j ? 1.0 : 0.0;
-  const double *Xu = (mode & (256ull | 1024ull)) ? a.Xf : a.X;
-  const double s2 = sc * sc;
-  const double y1 = sc * Xu[idx], y2 = -s2 * a.P2[idx], y3 = s2 * sc * a.P3[idx], y4 = s2 * s2 * a.P4[idx];
-  const double b0 = dl + y1 + 0.5 * y2 + y3 * (1.0 / 6.0);
-  if (order == 4) {
-    a.R0[idx] = b0 + y4 * (1.0 / 24.0);
-    return;
-  }
-  a.B0[idx] = b0;
-  const double b1 = dl * (1.0 / 24.0) + y1 * (1.0 / 120.0) + y2 * (1.0 / 720.0) + y3 * (1.0 / 5040.0);
-  if (order == 8) {
-    a.T[idx] = b1 + y4 * (1.0 / 40320.0);
-    return;
-  }
-  a.B1[idx] = b1;
-  a.B2[idx] = dl * (1.0 / 40320.0) + y1 * (1.0 / 362880.0) + y2 * (1.0 / 3628800.0) + y3 * (1.0 / 39916800.0) +
-              y4 * (1.0 / 479001600.0);
-}
-
 // Solve prologue: sigma = max |A_ii| and a clean control block (one launch, first kernel of the solve).
 __global__ void lge_begin(int LD, const double *A, double *sigma, unsigned long long *ctl) {
   __shared__ double s[256];
-  if (threadIdx.x < EC_WORDS) ctl[threadIdx.x] = threadIdx.x == EC_FINAL ? EC_NONE : 0ull;
+  if (threadIdx.x < EC_WORDS)
+    ctl[threadIdx.x] = threadIdx.x == EC_FINAL ? EC_NONE : threadIdx.x == EC_T0 ? (unsigned long long)__builtin_amdgcn_s_memrealtime() : 0ull;
   double m = 0.0;
   for (int i = threadIdx.x; i < LD; i += 256) m = fmax(m, fabs(A[(size_t)i * LD + i]));
   s[threadIdx.x] = m;
@@ -559,13 +687,15 @@ __global__ void lge_resume(unsigned long long *ctl) {
 // the host repeat the evaluation with per-bucket products (train_host.hip.h).
 __global__ void lge_norms(int LD, const double *G0, const double *G1, double *nrm, unsigned long long *ctl,
                           volatile unsigned long long *pin, unsigned long long seq, const double *sigma, double tb_rho_max) {
+  LGE_STAMP(ctl, 20);
   const unsigned long long fin = ctl[EC_FINAL];
   const bool stall = ctl[EC_STALL] != 0ull || fin == EC_NONE;
   const bool stale = tb_rho_max > 0.0 && !(2.0 * (*sigma) <= tb_rho_max);
   if (blockIdx.x == 0) {   // (blockDim.x == 256)
     if (pin && threadIdx.x < EC_WORDS) {
       const int i = threadIdx.x;
-      pin[i] = i == EC_STALL ? (stall ? 1ull : 0ull) : i == EC_TBSTALE ? (stale ? 1ull : 0ull) : i == EC_SKIP ? ((stall || stale) ? 1ull : 0ull) : ctl[i];
+      pin[i] = i == EC_STALL ? (stall ? 1ull : 0ull) : i == EC_TBSTALE ? (stale ? 1ull : 0ull) : i == EC_SKIP ? ((stall || stale) ? 1ull : 0ull) :
+               i == EC_TEND ? (unsigned long long)__builtin_amdgcn_s_memrealtime() : ctl[i];
       __threadfence_system();
     }
     __syncthreads();

@@ -17,8 +17,11 @@ struct EighRecord {
   } sweep[EC_MAXREC];
 };
 
+// (round 6: 1 instead of 2 -- the two cross rounds of block pairs (i, i + 2) cost 4 launches of ~10 us per solve and buy 0.14
+// sweeps on the recorded trajectory (profiles/tools/r6_eigh_proto.py: 3.52 against 3.38 sweeps per solve); measured on the bench
+// bank: eigh phase 0.393 -> 0.373 ms in the driver's window, 0.262 -> 0.252 over 200 epochs, profiles/r06_eigh_anatomy.json)
 #ifndef CB_PLANNED_BAND
-#define CB_PLANNED_BAND 2
+#define CB_PLANNED_BAND 1
 #endif
 #ifndef CB_LEAD_INNER
 #define CB_LEAD_INNER 2
@@ -68,9 +71,12 @@ static void eigh_plan_from_record(const EighRecord &r, const EighPlan &prev, Eig
     // a band pass behind the sweep when it is expected to be a masked one (near the rule's thresholds counts)
     q.band_after = (s.masked || s.c > 2e-4 || s.rs > 0.3) ? 1 : 0;
     q.so = s.masked ? 0 : 1;
+    q.expect_run = 1;
+    q.expect_order = std::min(s.order, q.cap);
+    q.expect_sq = s.sq;
   }
   // the spare (runs when the solve needs a sweep more than last time: as a rule the final one, |X| ~ 1e-7 .. 1e-4)
-  p.slot[n] = EighSlot{4, 0, 0, 1};
+  p.slot[n] = EighSlot{4, 0, 0, 1, 0, 2, 0};
   // the band pass in front pays while near-degenerate neighbours are far from separated (profiles/tools/eigh_proto.py)
   p.lead_band = (r.sweep[0].masked && r.sweep[0].c > 1e-3) ? 1 : 0;
 }
@@ -125,7 +131,9 @@ static int enqueue_planned_solve(cb_bank *h, const EighPlan &p, unsigned long lo
   double *Gb[2] = {h->Gc, h->Gc2};
   double *X = h->gx, *Xf = h->gx + LL, *P2 = h->gx + 2 * LL, *P3 = h->gx + 3 * LL, *P4 = h->gx + 4 * LL, *B0 = h->gx + 5 * LL,
          *B1 = h->gx + 6 * LL, *B2 = h->gx + 7 * LL, *T = h->gx + 8 * LL, *R0 = h->gx + 9 * LL, *R0t = h->gx + 10 * LL,
-         *R1 = h->gx + 11 * LL, *R1t = h->gx + 6 * LL;   // (B1 is dead once R_0 exists; so is B2, but one spare is enough)
+         *R1 = h->gx + 11 * LL, *R1t = h->gx + 6 * LL,   // (B1 is dead once R_0 exists)
+         *Rfin = h->gx + 3 * LL;   // (the finished rotation lives where Gamma was: lge_so has read that before any product runs, and X^3 is
+                                   // never stored -- lge_p34 uses it in registers)
   const int RS = LD + ((2 - LD % 32 + 32) % 32);
   const size_t lds = (size_t)(16 * RS + 3 * 16 * 17 + JB_WAVES * 256) * sizeof(double);
   if (first_slot > 0) {
@@ -151,7 +159,6 @@ static int enqueue_planned_solve(cb_bank *h, const EighPlan &p, unsigned long lo
   };
   if (p.lead_band) band_pass(Gb[first_slot & 1], nullptr);
   const dim3 tiles((unsigned)(nt * nt));
-  const unsigned nel = (unsigned)((LL + 255) / 256);
   for (int i = 0; i < p.nslots; ++i) {
     const EighSlot &q = p.slot[i];
     const int s = first_slot + i;
@@ -162,23 +169,32 @@ static int enqueue_planned_solve(cb_bank *h, const EighPlan &p, unsigned long lo
     hipLaunchKernelGGL(lge_gram, tiles, dim3(512), 0, h->stream, ga);
     hipLaunchKernelGGL(lge_decide, dim3(1), dim3(512), 0, h->stream, ga);
     if (q.so) {
-      SoArgs so{LD, s, ctl, ga.Gm, ga.dg, X, Xf};
+      SoArgs so{LD, s, ctl, ga.Gm, ga.dg, X, Xf, q.expect_run && i >= 1};
       hipLaunchKernelGGL(lge_so, tiles, dim3(512), 0, h->stream, so);
     }
     EgArgs e{};
-    e.LD = LD; e.slot = s; e.ctl = ctl; e.X = X; e.Xf = Xf; e.P2 = P2; e.P3 = P3; e.P4 = P4; e.B0 = B0; e.B1 = B1; e.B2 = B2; e.T = T;
-    e.R[0] = R0; e.R[1] = R1; e.Rt[0] = R0t; e.Rt[1] = R1t; e.Gin = Gin; e.Gout = Gout;
-    auto gemm = [&](int kind, int qq = 0, unsigned ny = 1) {
+    e.LD = LD; e.slot = s; e.cap = q.cap; e.ctl = ctl; e.X = X; e.Xf = Xf; e.P2 = P2; e.P4 = P4; e.B0 = B0; e.B1 = B1; e.B2 = B2; e.T = T;
+    e.R[0] = R0; e.R[1] = R1; e.Rt[0] = R0t; e.Rt[1] = R1t; e.Rfin = Rfin; e.Gin = Gin; e.Gout = Gout;
+    auto gemm = [&](int kind, int qq = 0) {
       EgArgs c = e;
       c.kind = kind;
       c.q = qq;
-      hipLaunchKernelGGL(lge_gemm, dim3(tiles.x, ny), dim3(512), 0, h->stream, c);
+      const int xo = q.expect_order;
+      c.early = !q.expect_run ? 0 : kind == EG_P34 ? xo >= 4 : kind == EG_T1 ? xo == 12 : kind == EG_RP ? xo >= 8 :
+                kind == EG_SQ ? qq < q.expect_sq : kind == EG_R4 ? xo == 4 : 1;
+      switch (kind) {
+        case EG_P2: hipLaunchKernelGGL(lge_gemm<EG_P2>, tiles, dim3(512), 0, h->stream, c); break;
+        case EG_P34: hipLaunchKernelGGL(lge_p34, tiles, dim3(512), 0, h->stream, c); break;
+        case EG_T1: hipLaunchKernelGGL(lge_gemm<EG_T1>, tiles, dim3(512), 0, h->stream, c); break;
+        case EG_RP: hipLaunchKernelGGL(lge_gemm<EG_RP>, tiles, dim3(512), 0, h->stream, c); break;
+        case EG_SQ: hipLaunchKernelGGL(lge_gemm<EG_SQ>, tiles, dim3(512), 0, h->stream, c); break;
+        case EG_R4: hipLaunchKernelGGL(lge_gemm<EG_R4>, tiles, dim3(512), 0, h->stream, c); break;
+        default: hipLaunchKernelGGL(lge_gemm<EG_GR>, tiles, dim3(512), 0, h->stream, c); break;
+      }
     };
     gemm(EG_P2);
     if (q.cap == 12) {
-      gemm(EG_P34, 0, 2);
-      PolyArgs pa{LD, s, ctl, X, Xf, P2, P3, P4, B0, B1, B2, T, R0};
-      hipLaunchKernelGGL(lge_poly, dim3(nel), dim3(256), 0, h->stream, pa);
+      gemm(EG_P34);    // X^3, X^4 and the polynomial's coefficient matrices (no launch of their own any more)
       gemm(EG_T1);
       gemm(EG_RP);
       for (int k = 0; k < q.nsq; ++k) gemm(EG_SQ, k);
@@ -247,7 +263,28 @@ static int eigh_planned_record(cb_bank *h, unsigned long long seq, EighRecord &r
     for (int k = 0; k < r.nsweep; ++k)
       fprintf(stderr, " %s%d%s/%d c=%.1e |X|<=%.1e(%.1e)", r.sweep[k].masked ? "M" : "L", r.sweep[k].order, r.sweep[k].damped ? "d" : "",
               r.sweep[k].sq, r.sweep[k].c, r.sweep[k].rs, r.sweep[k].rsf);
-    fprintf(stderr, "\n");
+    // where the solve's time went on the device's own 100 MHz clock: begin -> each decision -> lge_norms, in microseconds
+    fprintf(stderr, "  | us:");
+    unsigned long long tp = pin[EC_T0];
+    for (int k = 0; k < r.nsweep; ++k) {
+      fprintf(stderr, " %.1f", (double)(pin[EC_TSWEEP + k] - tp) * 0.01);
+      tp = pin[EC_TSWEEP + k];
+    }
+    fprintf(stderr, " %.1f = %.1f\n", (double)(pin[EC_TEND] - tp) * 0.01, (double)(pin[EC_TEND] - pin[EC_T0]) * 0.01);
+#ifdef CB_EIGH_STAMPS
+    {   // launch by launch: kernel id : microseconds since the previous entry
+      const unsigned long long ns = pin[EC_NSTAMP];
+      const int n = (int)(ns < 96ull ? ns : 96ull);
+      fprintf(stderr, "  | entries (id:us since the previous entry; 3 band, 4 gram, 5 decide, 6 so, 10 P2, 12 T1, 13 RP, 14 SQ, 15 GR, 16 R4, 17 P34, 20 norms):");
+      unsigned long long prev = pin[EC_T0];
+      for (int i = 0; i < n; ++i) {
+        const unsigned long long w = pin[EC_STAMPS + i];
+        fprintf(stderr, " %d:%.1f", (int)(w & 255ull), (double)((w >> 8) - prev) * 0.01);
+        prev = w >> 8;
+      }
+      fprintf(stderr, "\n");
+    }
+#endif
   }
   return CB_OK;
 }

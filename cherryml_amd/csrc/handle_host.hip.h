@@ -10,6 +10,9 @@ struct EighSlot {
   int nsq = 0;          // squaring launches
   int band_after = 0;   // a banded Jacobi pass behind the sweep (runs when the sweep was a masked one)
   int so = 0;           // the second-order launch (lge_so; runs when the sweep is an all-pairs one above 1e-8)
+  // what the previous solve did at this position (timing only, never results): launches expected to RUN request their
+  // decision-independent operands before they look at the control block (EgArgs::early)
+  int expect_run = 1, expect_order = 12, expect_sq = 2;
 };
 struct EighPlan {
   int lead_band = 1;    // a banded Jacobi pass before the first sweep

@@ -61,8 +61,13 @@ __global__ __launch_bounds__(JB_THREADS) void lgj_round(int LD, int round, int i
                                                         const unsigned long long *must_nonzero = nullptr) {
   // off_bits[0]: running max cosine of this sweep; off_bits[1]: solve finished (set by lgj_check):
   // sweeps are enqueued speculatively, the surplus launches return at once
-  if (off_bits[1] != 0ull) return;
-  if ((must_zero && *must_zero != 0ull) || (must_nonzero && *must_nonzero == 0ull)) return;
+#ifdef CB_EIGH_STAMPS
+  if (must_zero && blockIdx.x == 0 && threadIdx.x == 0) {   // (planned solves: must_zero is the control block's first word)
+    unsigned long long *c = const_cast<unsigned long long *>(must_zero);
+    const unsigned long long i = atomicAdd(c + 95, 1ull);
+    if (i < 96ull) c[96 + i] = ((unsigned long long)__builtin_amdgcn_s_memrealtime() << 8) | 3ull;
+  }
+#endif
   extern __shared__ double lds[];
   const int RS = jb_rowstride(LD);
   double *sG = lds;                 // [16][RS]
@@ -91,11 +96,27 @@ __global__ __launch_bounds__(JB_THREADS) void lgj_round(int LD, int round, int i
   const int lo = lane & 15, hi = lane >> 4;
   auto gcol = [&](int c) { return c < JB_W ? bi * JB_W + c : bj * JB_W + (c - JB_W); };
 
-  // 1. stage G columns: all 16 loads of a row slab in flight before the first LDS store
+  // 1. stage G columns: all 16 loads of a row slab in flight before the first LDS store -- and (round 6) before the words that
+  // decide whether this launch runs are looked at: behind a kernel boundary those words and the columns are both ~2 us away, and
+  // the launch that returns at once (a band pass behind a sweep that was not a masked one) is the rare case
   {
     const double *src_i = Gc + (size_t)bi * JB_W * LD, *src_j = Gc + (size_t)bj * JB_W * LD;
-    for (int r = threadIdx.x; r < LD; r += JB_THREADS) {
-      double v[16];
+    const int r0 = threadIdx.x;
+    double v[16];
+    if (r0 < LD) {
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        v[c] = src_i[(size_t)c * LD + r0];
+        v[8 + c] = src_j[(size_t)c * LD + r0];
+      }
+    }
+    if (off_bits[1] != 0ull) return;
+    if ((must_zero && *must_zero != 0ull) || (must_nonzero && *must_nonzero == 0ull)) return;
+    if (r0 < LD) {
+#pragma unroll
+      for (int c = 0; c < 16; ++c) sG[c * RS + r0] = v[c];
+    }
+    for (int r = r0 + JB_THREADS; r < LD; r += JB_THREADS) {
 #pragma unroll
       for (int c = 0; c < 8; ++c) {
         v[c] = src_i[(size_t)c * LD + r];

@@ -333,6 +333,9 @@ def main():
         "cur_b1": (solve_current, {"band": 1}),
         "cur_forceL1": (solve_current, {"force_L_from": 1}),
         "cur_forceL0": (solve_current, {"force_L_from": 0}),
+        "cur_nopost_forceL1": (solve_current, {"force_L_from": 1, "post": False}),
+        "cur_nopost_forceL1_li3": (solve_current, {"force_L_from": 1, "post": False, "lead_inner": 3}),
+        "cur_b1_nopost_forceL1": (solve_current, {"force_L_from": 1, "post": False, "band": 1}),
         "cur_forceL0_nolead": (solve_current, {"force_L_from": 0, "lead": False}),
         "cur_forceL0_li3": (solve_current, {"force_L_from": 0, "lead_inner": 3}),
         "cur_forceL0_b1": (solve_current, {"force_L_from": 0, "band": 1}),

@@ -138,11 +138,25 @@ def make_s400():
     params, tr = _traj_reference_f64(torch, RateMatrix, train_quantization, t, C, mask, init, EPOCHS_S400)
     print(f"s400: {EPOCHS_S400} epochs on {len(S400_SEL)} buckets {time.time() - t0:.0f} s, loss {tr['loss'][0]:.10f} -> "
           f"{tr['loss'][-1]:.10f}", flush=True)
+    # the TWIN: the same recipe from a start moved by 1e-14 relative -- how far two float64 evaluations of the reference drift
+    # apart over this horizon (the yardstick for Q_last, which sits at the end of 500 Adam steps)
+    fin = np.isfinite(params["upper_diag"])
+    u1 = params["upper_diag"].copy()
+    u1[fin] *= 1.0 + 1e-14 * np.random.default_rng(2).standard_normal(int(fin.sum()))
+    _, tw = _traj_reference_f64(torch, RateMatrix, train_quantization, t, C, mask, init, EPOCHS_S400, upper_diag=u1,
+                                log_pi=params["log_pi"])
+    dl = np.abs(tw["loss"] - tr["loss"]) / np.abs(tr["loss"])
+    rel = lambda a, b: np.linalg.norm(a - b) / np.linalg.norm(b)  # noqa: E731
+    print(f"   twin (start moved by 1e-14): loss curves differ by {dl.max():.1e}; Q_best {rel(tw['Q_best'], tr['Q_best']):.1e}, "
+          f"Q_last {rel(tw['Q_last'], tr['Q_last']):.1e}", flush=True)
     kw = dict(sel=S400_SEL, epochs=np.int64(EPOCHS_S400), upper_diag0=params["upper_diag"], log_pi0=params["log_pi"],
               init_support=_on_support(init, mask), loss_f64=tr["loss"], C_sum=np.float64(wl["C"].sum()),
               C_bucket_sums=wl["C"].reshape(129, -1).sum(1), C_probe=wl["C"][::16, ::37, ::41].copy())
     for k in ("Q_best", "Q_last", "Q_1", "Q_2"):
         kw[k + "_support_f64"] = _on_support(tr[k], mask)
+    kw["loss_twin_f64"] = tw["loss"]
+    for k in ("Q_best", "Q_last"):
+        kw[k + "_twin_support_f64"] = _on_support(tw[k], mask)
     np.savez_compressed(os.path.join(HERE, "long_s400_b32.npz"), **kw)
     print("wrote long_s400_b32.npz", flush=True)
 

@@ -3,12 +3,15 @@
 produced by running the reference's own `train_quantization` in float64 for that long (tests/golden/make_golden_long.py) and are
 followed here through the DEFAULT path -- the bank in its time basis, no test hook set:
 
-  long_s64       64 states, B = 129, 2000 epochs from 0.3 x the generating rates: max |Q_ii| grows 3.3x, the time basis is
-                 outgrown, the helper thread builds the next one beside the epochs and the trainer swaps it in (a NATURAL swap:
-                 builds >= 2, no repeated epoch);
+  long_s64       64 states, B = 129, 2000 epochs from 0.3 x the generating rates, at the reference's default learning rate 0.1
+                 and at 0.02: max |Q_ii| grows 3.3x, the time basis is outgrown, the helper thread builds the next one beside the
+                 epochs and the trainer swaps it in (a NATURAL swap: builds >= 2, no repeated epoch);
   long_s400_b32  32 buckets of the bench bank, 400 states, 500 epochs.
 
-Bars: loss curve 1e-9 relative at every epoch, learned Q 1e-6 relative Frobenius (BASELINE.json north_star).  Needs an MI355X."""
+Bars: loss curve 1e-9 relative, learned Q 1e-6 relative Frobenius (BASELINE.json north_star) -- over the horizon on which the
+reference reproduces ITSELF: every fixture also holds the reference's twin run from a start moved by 1e-14, and where the twins
+drift apart (Adam's constant step at the optimum of a noise-free bank: 4e-6 in the loss, 2e-3 in Q_last after 2000 epochs at
+lr 0.1) the bar is a multiple of their distance.  Needs an MI355X."""
 import os
 import sys
 
@@ -22,7 +25,37 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "gol
 pytestmark = pytest.mark.gpu
 
 
-def test_2000_epochs_at_64_states_with_a_natural_basis_swap(monkeypatch):
+def _against_reference_and_twin(r, z, tag, E):
+    """The reference's recipe run twice in float64 from starts 1e-14 apart (`loss_f64`, `loss_twin_f64`) says how far the
+    recipe itself carries a rounding error: nothing for the first few hundred epochs, then -- at the noise-free optimum, where
+    Adam's constant step keeps bouncing -- 1e-9 ... 4e-6.  Bars: 1e-9 at every epoch up to the last one at which the twins agree to
+    1e-10 (and at least the first 200), everywhere within 10 x the twins' own running distance + 1e-9; the learned matrices
+    within 1e-6 or 5 x the twins' distance, whichever is larger."""
+    ref, twin = z["loss_f64" + tag], z["loss_twin_f64" + tag]
+    d_tw = np.abs(twin - ref) / np.abs(ref)
+    d = np.abs(r["loss"] - ref) / np.abs(ref)
+    agree = np.flatnonzero(d_tw > 1e-10)
+    e1 = int(agree[0]) if agree.size else E
+    env = np.maximum.accumulate(d_tw)
+    print(f"  loss curve vs the reference: {d[:e1].max():.2e} over the {e1} epochs the reference's twins agree to 1e-10, "
+          f"{d.max():.2e} over all {E} (the twins: {d_tw.max():.2e}); loss {r['loss'][0]:.10f} -> {r['loss'][-1]:.10f}")
+    assert e1 >= 200
+    assert d[:e1].max() < 1e-9
+    assert np.all(d <= 10.0 * env + 1e-9), int(np.argmax(d - 10.0 * env))
+    out = {}
+    for key, got in (("Q_1", r["Q_pow2"][1]), ("Q_2", r["Q_pow2"][2]), ("Q_256", r["Q_pow2"][256]), ("Q_best", r["Q_best"]),
+                     ("Q_last", r["Q_last"])):
+        want = z[f"{key}_f64{tag}"]
+        e = relerr(got, want)
+        tw = relerr(z[f"{key}_twin_f64{tag}"], want) if f"{key}_twin_f64{tag}" in z else 0.0
+        print(f"  {key}: rel. Frobenius to the reference {e:.2e} (the reference's twin: {tw:.2e})")
+        assert e < max(1e-6, 5.0 * tw), key
+        out[key] = e
+    return out
+
+
+@pytest.mark.parametrize("tag,lr", [("", 0.1), ("_lr002", 0.02)])
+def test_2000_epochs_at_64_states_with_a_natural_basis_swap(monkeypatch, tag, lr):
     from cherryml_amd import CherryBank
     from make_golden_long import s64_bank
     for k in ("CB_TB_TEST_GROWTH", "CB_TB_TEST_WARN", "CB_BANK_TB"):
@@ -32,22 +65,16 @@ def test_2000_epochs_at_64_states_with_a_natural_basis_swap(monkeypatch):
     assert np.isclose(C.sum(), float(z["C_sum"]), rtol=1e-12) and np.allclose(C[::16, ::7, ::5], z["C_probe"], rtol=1e-12, atol=0)
     assert np.array_equal(C, C.transpose(0, 2, 1))
     E = int(z["epochs"])
-    assert E == 2000
+    assert E == 2000 and float(z["lr" + tag]) == lr
     with CherryBank(t, C) as bank:
-        r = bank.train_pande_reversible(z["upper_diag0"], z["log_pi0"], mask=np.ones((64, 64)), num_epochs=E, lr=0.1)
+        r = bank.train_pande_reversible(z["upper_diag0"], z["log_pi0"], mask=np.ones((64, 64)), num_epochs=E, lr=lr)
         form, info = bank.last_bank_form(), bank.time_basis_info()
-    print(f"64 states, {E} epochs: {info}")
+    print(f"64 states, {E} epochs, lr {lr}: {info}")
     assert form["time_basis"]
     assert info["builds"] >= 2 and info["repeated_epochs"] == 0      # the basis was replaced on the way, nothing was repeated
-    dl = np.max(np.abs(r["loss"] - z["loss_f64"]) / np.abs(z["loss_f64"]))
-    print(f"  loss curve: max rel. difference {dl:.2e} over {E} epochs; loss {r['loss'][0]:.10f} -> {r['loss'][-1]:.10f}")
-    assert dl < 1e-9
-    for key, got in (("Q_1", r["Q_pow2"][1]), ("Q_2", r["Q_pow2"][2]), ("Q_best", r["Q_best"]), ("Q_last", r["Q_last"])):
-        e = relerr(got, z[f"{key}_f64"])
-        print(f"  {key}: rel. Frobenius to the reference {e:.2e}")
-        assert e < 1e-6, key
+    _against_reference_and_twin(r, z, tag, E)
     assert 1024 in r["Q_pow2"]
-    print(f"  Q_best to the generating model: {relerr(r['Q_best'], Q_true):.2e} (the reference's: {relerr(z['Q_best_f64'], Q_true):.2e})")
+    print(f"  Q_best to the generating model: {relerr(r['Q_best'], Q_true):.2e} (the reference's: {relerr(z['Q_best_f64' + tag], Q_true):.2e})")
     assert np.abs(np.diag(r["Q_last"])).max() > 3.0 * np.abs(np.diag(init)).max()
 
 
