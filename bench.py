@@ -734,8 +734,11 @@ def main():
                                 traffic=traffic.get("epoch:" + workload) if world == 1 else None,
                                 traffic_source=_traffic_source() if world == 1 else None,
                                 ms_per_epoch_in_kernel=tm["small"], bytes_per_epoch=nbytes,
-                                note="figures are per epoch; the kernels are VALU / MFMA bound (log, reciprocal, divided "
-                                     "differences on every count entry), HBM only streams the counts once")
+                                compute_floor=_siterm_compute_floor(),
+                                note="figures are per epoch; HBM only streams the counts once (counter traffic 1.02x algorithmic). "
+                                     "What bounds sp_bank is the float64 pipe, which on gfx950 the f64 MFMA and the f64 vector "
+                                     "instructions share (table logarithm, reciprocal, divided difference per count entry): "
+                                     "compute_floor = its SQ counters' MFMA-busy + vector-issue cycles over the chip's SIMD cycles")
         out = {
             "metric": "cherry-pairs/sec (whole node) per EM iter",
             "value": n_pairs_total / (dt / steps), "unit": "cherry-pairs/s", "n_gpus": world,
@@ -1318,6 +1321,23 @@ def _traffic_source():
         d = json.load(f)
     return (f"profiles/pmc_traffic.json ({d.get('round', 'r02')}, collected {d.get('collected', '2026-10-03')}; "
             "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes), not measured in this run")
+
+
+def _siterm_compute_floor():
+    """sp_bank's float64-pipe occupancy from its tracked SQ counters (profiles/r06_sp_bank_sq_counters.json, collected by
+    profiles/tools/r6_sq_counters_sp_bank.sh; not measured in this run)"""
+    path = os.path.join(ROOT, "profiles", "r06_sp_bank_sq_counters.json")
+    if not os.path.exists(path):
+        return None
+    with open(path) as f:
+        d = json.load(f).get("derived", {}).get("sp_bank<5, true, true>")
+    if not d:
+        return None
+    return {"kernel": "sp_bank<5, true, true>", "fp64_pipe_frac": round(d["fp64_pipe_frac"], 3),
+            "mfma_pipe_busy_frac": round(d["mfma_pipe_busy_frac"], 3), "valu_issue_frac": round(d["valu_issue_frac"], 3),
+            "floor_ms": round(d["compute_floor_ms"], 3), "measured_ms": round(d["avg_duration_us"] * 1e-3, 3),
+            "resident_waves_per_simd": round(d["mean_resident_waves_per_simd"], 2),
+            "source": "profiles/r06_sp_bank_sq_counters.json (rocprofv3 --pmc SQ_*, three passes; not measured in this run)"}
 
 
 def _mfma_util(dtype):

@@ -68,6 +68,8 @@ __global__ __launch_bounds__(JB_THREADS) void lgj_round(int LD, int round, int i
     if (i < 96ull) c[96 + i] = ((unsigned long long)__builtin_amdgcn_s_memrealtime() << 8) | 3ull;
   }
 #endif
+  if (off_bits[1] != 0ull) return;
+  if ((must_zero && *must_zero != 0ull) || (must_nonzero && *must_nonzero == 0ull)) return;
   extern __shared__ double lds[];
   const int RS = jb_rowstride(LD);
   double *sG = lds;                 // [16][RS]
@@ -96,27 +98,13 @@ __global__ __launch_bounds__(JB_THREADS) void lgj_round(int LD, int round, int i
   const int lo = lane & 15, hi = lane >> 4;
   auto gcol = [&](int c) { return c < JB_W ? bi * JB_W + c : bj * JB_W + (c - JB_W); };
 
-  // 1. stage G columns: all 16 loads of a row slab in flight before the first LDS store -- and (round 6) before the words that
-  // decide whether this launch runs are looked at: behind a kernel boundary those words and the columns are both ~2 us away, and
-  // the launch that returns at once (a band pass behind a sweep that was not a masked one) is the rare case
+  // 1. stage G columns: all 16 loads of a row slab in flight before the first LDS store
+  // (round 6 measured the loads issued BEFORE the words that decide whether the launch runs are looked at, as lge_gemm does with
+  // its operands: + 0.3 us per launch -- 25 workgroups do not queue behind a cold L2 the way 625 do; not kept)
   {
     const double *src_i = Gc + (size_t)bi * JB_W * LD, *src_j = Gc + (size_t)bj * JB_W * LD;
-    const int r0 = threadIdx.x;
-    double v[16];
-    if (r0 < LD) {
-#pragma unroll
-      for (int c = 0; c < 8; ++c) {
-        v[c] = src_i[(size_t)c * LD + r0];
-        v[8 + c] = src_j[(size_t)c * LD + r0];
-      }
-    }
-    if (off_bits[1] != 0ull) return;
-    if ((must_zero && *must_zero != 0ull) || (must_nonzero && *must_nonzero == 0ull)) return;
-    if (r0 < LD) {
-#pragma unroll
-      for (int c = 0; c < 16; ++c) sG[c * RS + r0] = v[c];
-    }
-    for (int r = r0 + JB_THREADS; r < LD; r += JB_THREADS) {
+    for (int r = threadIdx.x; r < LD; r += JB_THREADS) {
+      double v[16];
 #pragma unroll
       for (int c = 0; c < 8; ++c) {
         v[c] = src_i[(size_t)c * LD + r];
