@@ -848,7 +848,7 @@ def main():
         finish(out)
         return
     out = run(args.workload, steps, warmup, world == 1 and not args.no_cpu_baseline and not args.shard_of, shard_of=args.shard_of)
-    keep = ("value", "unit", "n_gpus", "scaling", "ms_per_step", "steps", "warmup", "dtype", "config", "roofline",
+    keep = ("value", "unit", "n_gpus", "scaling", "ms_per_step", "kernel_ms_per_step", "steps", "warmup", "dtype", "config", "roofline",
             "cpu_baseline", "phase_ms", "shard_of", "amdahl", "eigh", "prewarm", "bank_form")
     if args.workload == "coevo400" and not args.no_secondary:
         # every rank takes part (the multi-rank runs end in collectives); rank 0 attaches the lines
@@ -1174,8 +1174,17 @@ def run_ble(steps, warmup, world, rank, local_rank, fence, with_cpu):
     cy[gaps[1]] = -1
     seqs = np.concatenate([cx, cy])
     prof = {}
-    call = lambda: estimate_branch_lengths_and_site_rates(cx, cy, seqs, bank, grid, rates, weights, 50,  # noqa: E731
-                                                          device=local_rank, profile=prof)
+    # the caller's view (VERDICT r5 "missing 3"): the bank resident on the device, one call per family
+    # (cherryml_amd.phylogeny_estimation.BleBank = cb_ble_bank_create / cb_ble_bank_run); ms_per_step is the WALL time of a call
+    # -- sequences uploaded, transposed, site statistics, the coordinate ascent, results read back
+    from cherryml_amd.phylogeny_estimation import BleBank
+    cx8, cy8, seqs8 = (np.ascontiguousarray(a, dtype=np.int8) for a in (cx, cy, seqs))
+    resident = BleBank(bank, grid, rates, device=local_rank)
+    call = lambda: resident.estimate(cx8, cy8, seqs8, weights, 50, profile=prof)  # noqa: E731
+    # (the per-call entry with host arrays of the reference's own dtype: bank re-uploaded, workspace re-allocated, three host passes)
+    t0 = time.perf_counter()
+    estimate_branch_lengths_and_site_rates(cx, cy, seqs, bank, grid, rates, weights, 50, device=local_rank)
+    per_call_entry_ms = (time.perf_counter() - t0) * 1e3
     for _ in range(warmup):
         call()
     fence()
@@ -1188,10 +1197,12 @@ def run_ble(steps, warmup, world, rank, local_rank, fence, with_cpu):
     fence()
     dt = time.perf_counter() - t0
     kernel_ms = float(np.mean(kms))
+    call_ms = dt / steps * 1e3
+    resident.close()
     if world > 1:
-        tdt = torch.tensor([kernel_ms], dtype=torch.float64, device=torch.device("cuda", local_rank))
+        tdt = torch.tensor([kernel_ms, call_ms], dtype=torch.float64, device=torch.device("cuda", local_rank))
         dist.all_reduce(tdt, op=dist.ReduceOp.MAX)
-        kernel_ms = float(tdt.item())
+        kernel_ms, call_ms = (float(v) for v in tdt.tolist())
     if rank != 0:
         return None
     valid = int(((cx >= 0) & (cy >= 0)).sum())
@@ -1202,13 +1213,16 @@ def run_ble(steps, warmup, world, rank, local_rank, fence, with_cpu):
     gather_bytes = 16.0 * n * L * (steps_bl * (1 + int(np.mean(iters))) + steps_sr * int(np.mean(iters)))
     out = {
         "metric": "cherry-pairs/sec (whole node): cherry x site pairs fitted per coordinate ascent",
-        "value": valid * world / (kernel_ms * 1e-3), "unit": "cherry-pairs/s", "n_gpus": world, "steps": steps,
-        "warmup": warmup, "ms_per_step": kernel_ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "value": valid * world / (call_ms * 1e-3), "unit": "cherry-pairs/s", "n_gpus": world, "steps": steps,
+        "warmup": warmup, "ms_per_step": call_ms, "kernel_ms_per_step": kernel_ms, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None,
         "dtype": "f64", "data": "synthetic",
         "config": {"workload": f"FastCherries branch lengths + site rates: {n} cherries x {L} sites per GPU, "
                                f"129 grid points x {R} rate categories, LG", "iterations": int(np.mean(iters)),
                    "sharding": f"families x{world} (no collective)",
-                   "host_ms_per_call_including_uploads": dt / steps * 1e3},
+                   "entry": "BleBank.estimate (cb_ble_bank_run): log-transition bank resident on the device, sequences uploaded per call; "
+                            "ms_per_step = wall time of a call, kernel_ms_per_step = the coordinate ascent alone (HIP events)",
+                   "per_call_entry_ms": per_call_entry_ms},
         # Bound: 8-byte gathers from the L2-resident 8 MB log-transition bank -- two per (cherry, site, bisection step) --
         # not HBM.  Peak: rows gathered from a table every workgroup shares in the XCD's L2, 16.8 TB/s chip-wide
         # (MI355X_MICROARCH.md, "Indexed rows"); an 8-byte word costs a 64-byte sector there, which `sector_frac` prices.

@@ -61,6 +61,9 @@ SIGNATURES = {
                          C.c_int, _vp, _vp, _vp, _vp]),
     "cb_ble_batch": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, _vp, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                C.c_int, _vp, _vp, _vp, _vp]),
+    "cb_ble_bank_create": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp]),
+    "cb_ble_bank_run": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, _vp, C.c_int, _vp, C.c_int, _vp, _vp, _vp, _vp]),
+    "cb_ble_bank_destroy": (C.c_int, [_vp]),
     "cb_site_rate_gather": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp]),
     "cb_tree_likelihood": (C.c_int, [C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, C.c_int, _vp, _vp, _vp, C.c_int, _vp,
                                      C.c_int, _vp, _vp, _vp, _vp, _vp]),

@@ -191,3 +191,54 @@ __global__ __launch_bounds__(256) void site_rate_gather_kernel(int S, int R, int
   }
   if (lane == 0) best[s] = arg;
 }
+
+
+// ---- what the host did per call before round 6, as kernels (cb_ble_bank_run: the device-resident FastCherries entry) -----------
+// [rows][cols] int8 -> [cols][rows] through a 64 x 65 LDS tile; also raises *bad when a code is >= S (the range check of
+// ble_check, which read every byte on the host)
+__global__ __launch_bounds__(256) void ble_transpose_check_kernel(int rows, int cols, int S, const int8_t *__restrict__ in,
+                                                                  int8_t *__restrict__ out, int *bad) {
+  __shared__ int8_t tile[64][65];
+  const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  int flag = 0;
+  for (int r = ty; r < 64; r += 4) {
+    const int rr = r0 + r, cc = c0 + tx;
+    int8_t v = -1;
+    if (rr < rows && cc < cols) v = in[(size_t)rr * cols + cc];
+    flag |= v >= S ? 1 : 0;
+    tile[r][tx] = v;
+  }
+  __syncthreads();
+  for (int c = ty; c < 64; c += 4) {
+    const int cc = c0 + c, rr = r0 + tx;
+    if (cc < cols && rr < rows) out[(size_t)cc * rows + rr] = tile[tx][c];
+  }
+  if (flag) atomicOr(bad, 1);
+}
+
+// initial site-rate bins, first half (branch_length_estimation.cpp:10-34): per site the number of sequence PAIRS that differ,
+// total[j] = sum_k (non_missing_j - cnt_jk) cnt_jk with cnt_jk = sequences holding state k at site j.  One workgroup per 32
+// sites: 32 x (S + 1) LDS counters, eight sequence rows per step (32 consecutive bytes of a row per wave quarter).
+__global__ __launch_bounds__(256) void ble_site_totals_kernel(int n_seqs, int L, int S, const int8_t *__restrict__ seqs,
+                                                              long long *__restrict__ total, int *bad) {
+  extern __shared__ int cnt[];   // [32][S]
+  const int j0 = blockIdx.x * 32, sx = threadIdx.x & 31, sy = threadIdx.x >> 5;
+  for (int e = threadIdx.x; e < 32 * S; e += 256) cnt[e] = 0;
+  __syncthreads();
+  int flag = 0;
+  if (j0 + sx < L)
+    for (int i = sy; i < n_seqs; i += 8) {
+      const int v = seqs[(size_t)i * L + j0 + sx];
+      if (v >= S) flag = 1;
+      else if (v >= 0) atomicAdd(&cnt[sx * S + v], 1);
+    }
+  if (flag) atomicOr(bad, 1);
+  __syncthreads();
+  if (threadIdx.x < 32 && j0 + (int)threadIdx.x < L) {
+    long long nm = 0, t = 0;
+    for (int k = 0; k < S; ++k) nm += cnt[threadIdx.x * S + k];
+    for (int k = 0; k < S; ++k) t += (nm - cnt[threadIdx.x * S + k]) * (long long)cnt[threadIdx.x * S + k];
+    total[j0 + threadIdx.x] = t;
+  }
+}

@@ -272,6 +272,159 @@ extern "C" int cb_ble_batch(int device, int S, int T, int R, const double *logP,
   return CB_OK;
 }
 
+// ---- the device-resident entry (round 6; VERDICT r5 "missing 3") ------------------------------------------------------------
+// cb_ble pays, per family, for 8 MB of bank upload, ten device allocations and three passes over every sequence byte on the
+// host (range check, two transposes, the site statistics): 15 ms per call around 1 ms of kernels.  The reference computes the
+// bank once per rate matrix and then calls ble() per family (FastCherries main.cpp: read_rate_compute_log_transition_matrices, then
+// the loop over families) -- so does this handle: the bank lives on the device, the workspace is kept between calls, and the
+// per-call host work is one sort of L integers.
+struct cb_ble_bank_s {
+  int device = 0, S = 0, T = 0, R = 0;
+  double *logP = nullptr, *priors = nullptr;
+  // workspace, grown on demand
+  size_t cap_c = 0, cap_s = 0, cap_n = 0, cap_L = 0;
+  int8_t *x = nullptr, *y = nullptr, *xT = nullptr, *yT = nullptr, *seqs = nullptr;
+  int *s2r = nullptr, *l0 = nullptr, *l1 = nullptr, *flags = nullptr;
+  long long *totals = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+};
+
+static void ble_bank_free_ws(cb_ble_bank_s *b) {
+  for (void *p : {(void *)b->x, (void *)b->y, (void *)b->xT, (void *)b->yT, (void *)b->seqs, (void *)b->s2r, (void *)b->l0, (void *)b->l1,
+                  (void *)b->totals})
+    if (p) (void)hipFree(p);
+  b->x = b->y = b->xT = b->yT = b->seqs = nullptr;
+  b->s2r = b->l0 = b->l1 = nullptr;
+  b->totals = nullptr;
+  b->cap_c = b->cap_s = b->cap_n = b->cap_L = 0;
+}
+
+extern "C" int cb_ble_bank_destroy(cb_ble_bank_s *b) {
+  if (!b) return CB_OK;
+  (void)hipSetDevice(b->device);
+  ble_bank_free_ws(b);
+  if (b->logP) (void)hipFree(b->logP);
+  if (b->priors) (void)hipFree(b->priors);
+  if (b->flags) (void)hipFree(b->flags);
+  if (b->ev0) (void)hipEventDestroy(b->ev0);
+  if (b->ev1) (void)hipEventDestroy(b->ev1);
+  delete b;
+  return CB_OK;
+}
+
+extern "C" int cb_ble_bank_create(int device, int S, int T, int R, const double *logP, const double *rates, cb_ble_bank_s **out) {
+  if (!logP || !rates || !out) return fail(CB_EINVAL, "cb_ble_bank_create: NULL argument");
+  if (S < 2 || S > 127 || T < 1 || R < 1) return fail(CB_EINVAL, "cb_ble_bank_create: bad sizes");
+  const int ndev = cb_device_count();
+  if (ndev <= 0) return fail(CB_EHIP, "cb_ble_bank_create: no HIP device visible");
+  if (device < 0 || device >= ndev) return fail(CB_EINVAL, "cb_ble_bank_create: device %d out of range", device);
+  HIP_TRY(hipSetDevice(device));
+  cb_ble_bank_s *b = new cb_ble_bank_s;
+  b->device = device; b->S = S; b->T = T; b->R = R;
+  std::vector<double> priors(R);
+  for (int r = 0; r < R; ++r) priors[r] = 2 * std::log(rates[r]) - 3 * rates[r];   // branch_length_estimation.cpp:199-203
+  const size_t nb = (size_t)T * R * S * S;
+  bool ok = hipMalloc((void **)&b->logP, nb * sizeof(double)) == hipSuccess && hipMalloc((void **)&b->priors, R * sizeof(double)) == hipSuccess &&
+            hipMalloc((void **)&b->flags, 4 * sizeof(int)) == hipSuccess && hipEventCreate(&b->ev0) == hipSuccess &&
+            hipEventCreate(&b->ev1) == hipSuccess;
+  ok = ok && hipMemcpy(b->logP, logP, nb * sizeof(double), hipMemcpyHostToDevice) == hipSuccess &&
+       hipMemcpy(b->priors, priors.data(), R * sizeof(double), hipMemcpyHostToDevice) == hipSuccess;
+  if (!ok) {
+    (void)hipGetLastError();
+    cb_ble_bank_destroy(b);
+    return fail(CB_ENOMEM, "cb_ble_bank_create: device allocation or upload failed");
+  }
+  *out = b;
+  return CB_OK;
+}
+
+// the second half of the initial bins (branch_length_estimation.cpp:36-58) from the device's per-site totals
+static void ble_bins_from_totals(const long long *total, int L, int R, const double *weights, int *s2r) {
+  std::vector<std::pair<long long, int>> order(L);
+  for (int j = 0; j < L; ++j) order[j] = {total[j], j};
+  std::sort(order.begin(), order.end());
+  int cat = 0;
+  for (int i = 0; i < L; ++i) {
+    if (cat < R && i >= (long long)std::llround(weights[cat] * L)) ++cat;
+    s2r[order[i].second] = cat < R ? cat : R - 1;
+  }
+}
+
+extern "C" int cb_ble_bank_run(cb_ble_bank_s *b, const int8_t *cx, const int8_t *cy, int n, int L, const int8_t *all_seqs, int n_seqs,
+                               const double *weights, int max_iters, int *lengths_index, int *rate_index, int *iterations,
+                               double *kernel_ms) {
+  if (!b || !cx || !cy || !all_seqs || !weights || !lengths_index || !rate_index) return fail(CB_EINVAL, "cb_ble_bank_run: NULL argument");
+  if (n < 1 || L < 1 || n_seqs < 1 || max_iters < 0) return fail(CB_EINVAL, "cb_ble_bank_run: bad sizes");
+  HIP_TRY(hipSetDevice(b->device));
+  const int S = b->S, T = b->T, R = b->R;
+  const size_t nc = (size_t)n * L, ns = (size_t)n_seqs * L;
+  if (nc > b->cap_c || ns > b->cap_s || (size_t)n > b->cap_n || (size_t)L > b->cap_L) {   // (grow: everything anew, sizes kept as maxima)
+    const size_t cc = std::max(nc, b->cap_c), cs = std::max(ns, b->cap_s), cn = std::max((size_t)n, b->cap_n), cl = std::max((size_t)L, b->cap_L);
+    ble_bank_free_ws(b);
+    bool ok = hipMalloc((void **)&b->x, cc) == hipSuccess && hipMalloc((void **)&b->y, cc) == hipSuccess &&
+              hipMalloc((void **)&b->xT, cc) == hipSuccess && hipMalloc((void **)&b->yT, cc) == hipSuccess &&
+              hipMalloc((void **)&b->seqs, cs) == hipSuccess && hipMalloc((void **)&b->s2r, cl * sizeof(int)) == hipSuccess &&
+              hipMalloc((void **)&b->l0, cn * sizeof(int)) == hipSuccess && hipMalloc((void **)&b->l1, cn * sizeof(int)) == hipSuccess &&
+              hipMalloc((void **)&b->totals, cl * sizeof(long long)) == hipSuccess;
+    if (!ok) {
+      (void)hipGetLastError();
+      ble_bank_free_ws(b);
+      return fail(CB_ENOMEM, "cb_ble_bank_run: device allocation failed");
+    }
+    b->cap_c = cc; b->cap_s = cs; b->cap_n = cn; b->cap_L = cl;
+  }
+  HIP_TRY(hipMemsetAsync(b->flags, 0, 4 * sizeof(int), 0));
+  HIP_TRY(hipMemcpyAsync(b->seqs, all_seqs, ns, hipMemcpyHostToDevice, 0));
+  HIP_TRY(hipMemcpyAsync(b->x, cx, nc, hipMemcpyHostToDevice, 0));
+  HIP_TRY(hipMemcpyAsync(b->y, cy, nc, hipMemcpyHostToDevice, 0));
+  // site statistics, range checks and the transposed copies on the device
+  hipLaunchKernelGGL(ble_site_totals_kernel, dim3((L + 31) / 32), dim3(256), 32 * S * sizeof(int), 0, n_seqs, L, S, b->seqs, b->totals, b->flags + 1);
+  const dim3 tg((L + 63) / 64, (n + 63) / 64);
+  hipLaunchKernelGGL(ble_transpose_check_kernel, tg, dim3(256), 0, 0, n, L, S, b->x, b->xT, b->flags + 1);
+  hipLaunchKernelGGL(ble_transpose_check_kernel, tg, dim3(256), 0, 0, n, L, S, b->y, b->yT, b->flags + 1);
+  std::vector<long long> totals(L);
+  int bad = 0;
+  HIP_TRY(hipMemcpyAsync(totals.data(), b->totals, L * sizeof(long long), hipMemcpyDeviceToHost, 0));
+  HIP_TRY(hipMemcpyAsync(&bad, b->flags + 1, sizeof bad, hipMemcpyDeviceToHost, 0));
+  HIP_TRY(hipStreamSynchronize(0));
+  if (bad) return fail(CB_EINVAL, "cb_ble_bank_run: state code out of range");
+  std::vector<int> s2r(L);
+  ble_bins_from_totals(totals.data(), L, R, weights, s2r.data());
+  HIP_TRY(hipMemcpyAsync(b->s2r, s2r.data(), L * sizeof(int), hipMemcpyHostToDevice, 0));
+  const dim3 gb((n + 3) / 4), blk(256);
+  if (kernel_ms) HIP_TRY(hipEventRecord(b->ev0, 0));
+  int *dl0 = b->l0, *dl1 = b->l1, *dflag = b->flags;
+  hipLaunchKernelGGL(ble_branch_lengths_kernel, gb, blk, 0, 0, S, T, R, n, L, (const double *)b->logP, (const int8_t *)b->x, (const int8_t *)b->y,
+                     (const int *)b->s2r, (const int *)nullptr, dl0, (int *)nullptr);
+  bool match = false;
+  int iters = 0;
+  while (!match && max_iters) {
+    ++iters;
+    HIP_TRY(hipMemsetAsync(dflag, 0, sizeof(int), 0));
+    ble_launch_site_rates(S, T, R, n, L, b->logP, b->xT, b->yT, (const int *)dl0, b->priors, b->s2r);
+    hipLaunchKernelGGL(ble_branch_lengths_kernel, gb, blk, 0, 0, S, T, R, n, L, (const double *)b->logP, (const int8_t *)b->x,
+                       (const int8_t *)b->y, (const int *)b->s2r, (const int *)dl0, dl1, dflag);
+    int flag = 0;
+    HIP_TRY(hipMemcpy(&flag, dflag, sizeof flag, hipMemcpyDeviceToHost));
+    match = flag == 0;
+    std::swap(dl0, dl1);
+    --max_iters;
+  }
+  if (kernel_ms) {
+    float ms = 0.f;
+    HIP_TRY(hipEventRecord(b->ev1, 0));
+    HIP_TRY(hipEventSynchronize(b->ev1));
+    HIP_TRY(hipEventElapsedTime(&ms, b->ev0, b->ev1));
+    *kernel_ms = ms;
+  }
+  if (iterations) *iterations = iters;
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(lengths_index, dl0, n * sizeof(int), hipMemcpyDeviceToHost, 0));
+  HIP_TRY(hipMemcpyAsync(rate_index, b->s2r, L * sizeof(int), hipMemcpyDeviceToHost, 0));
+  HIP_TRY(hipStreamSynchronize(0));
+  return CB_OK;
+}
+
 extern "C" int cb_site_rate_gather(int device, int S, int R, int n, int L, const double *tens, const int8_t *cx,
                                    const int8_t *cy, const double *log_prior, int *best) {
   if (!tens || !cx || !cy || !log_prior || !best) return fail(CB_EINVAL, "cb_site_rate_gather: NULL argument");

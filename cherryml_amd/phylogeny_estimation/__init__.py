@@ -2,6 +2,7 @@
 two bisection passes, their coordinate ascent) and, around it, the reference's seeded divide-and-conquer
 cherry pairing (host) and tree / site-rate files (`fast_cherries`, `fast_cherries_family`)."""
 from ._ble import (  # noqa: F401
+    BleBank,
     branch_lengths,
     compute_log_transition_matrices,
     estimate_branch_lengths_and_site_rates,

@@ -153,3 +153,74 @@ def estimate_branch_lengths_and_site_rates_batch(families, log_transition_matric
         on += n
         oL += L
     return out
+
+
+class BleBank:
+    """The log-transition bank of ONE rate matrix resident on the device, and FastCherries' coordinate ascent on it family after
+    family (`cb_ble_bank_create` / `cb_ble_bank_run`).  The reference computes the bank once per run and calls `ble` per family
+    (FastCherries main.cpp; _fast_cherries.py:191); `estimate_branch_lengths_and_site_rates` follows the per-family signature and
+    re-uploads the 8 MB bank, re-allocates its workspace and passes over every sequence byte three times on the host on every
+    call -- 15 ms around 1 ms of kernels for a 2048-cherry family.  Here: `bank = BleBank(logP, grid, rates)` once, then
+    `bank.estimate(cx, cy, all_sequences, weights, max_iters)` per family, same results bit for bit."""
+
+    def __init__(self, log_transition_matrices, quantization_points: Sequence[float], rate_categories: Sequence[float],
+                 device: int = 0):
+        import ctypes
+        logP = _f64(log_transition_matrices)
+        if logP.ndim != 4 or logP.shape[2] != logP.shape[3]:
+            raise ValueError("log_transition_matrices must be [T,R,S,S]")
+        self.grid, self.rates = _f64(quantization_points), _f64(rate_categories)
+        T, R, S, _ = logP.shape
+        if self.grid.size != T or self.rates.size != R:
+            raise ValueError("inconsistent shapes")
+        self.T, self.R, self.S, self.device = T, R, S, int(device)
+        self._h = ctypes.c_void_p()
+        _lib.check(_lib.load().cb_ble_bank_create(self.device, S, T, R, logP.ctypes.data, self.rates.ctypes.data, ctypes.byref(self._h)),
+                   "cb_ble_bank_create")
+
+    @classmethod
+    def from_rate_matrix(cls, Q, quantization_points, rate_categories, device: int = 0, stationary_distribution=None) -> "BleBank":
+        logP = compute_log_transition_matrices(Q, quantization_points, rate_categories, device=device,
+                                               stationary_distribution=stationary_distribution)
+        return cls(logP, quantization_points, rate_categories, device=device)
+
+    def estimate(self, cx, cy, all_sequences, weights_for_initial_site_rates: Sequence[float], max_iters: int,
+                 profile: Optional[dict] = None) -> Tuple[np.ndarray, np.ndarray]:
+        """(cherry lengths [n], site rates [L]) as values of the grid / categories: `ble` (:146-241)"""
+        import ctypes
+        if self._h is None:
+            raise _lib.CherryBankError("BleBank: closed")
+        cx, cy = _i8(cx), _i8(cy)
+        if cx.shape != cy.shape or cx.ndim != 2:
+            raise ValueError("cherries must be two [n, L] arrays")
+        n, L = cx.shape
+        seqs = _i8(all_sequences)
+        w = _f64(weights_for_initial_site_rates)
+        if seqs.ndim != 2 or seqs.shape[1] != L or w.size != self.R:
+            raise ValueError("inconsistent shapes")
+        li, ri = np.zeros(n, dtype=np.int32), np.zeros(L, dtype=np.int32)
+        iters, ms = ctypes.c_int(0), ctypes.c_double(0.0)
+        rc = _lib.load().cb_ble_bank_run(self._h, cx.ctypes.data, cy.ctypes.data, n, L, seqs.ctypes.data, seqs.shape[0], w.ctypes.data,
+                                         int(max_iters), li.ctypes.data, ri.ctypes.data, ctypes.addressof(iters),
+                                         ctypes.addressof(ms) if profile is not None else None)
+        _lib.check(rc, "cb_ble_bank_run")
+        if profile is not None:
+            profile["iterations"], profile["kernel_ms"] = iters.value, ms.value
+        return self.grid[li], self.rates[ri]
+
+    def close(self):
+        if getattr(self, "_h", None) is not None:
+            _lib.load().cb_ble_bank_destroy(self._h)
+            self._h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

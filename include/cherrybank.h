@@ -413,6 +413,19 @@ int cb_ble_batch(int device, int S, int T, int R, const double *logP, int n_fam,
                  const int *L, const int8_t *cx, const int8_t *cy, const int8_t *all_seqs,
                  const int *n_seqs, const double *rates, const double *weights, int max_iters,
                  int *lengths_index, int *rate_index, int *iterations, double *kernel_ms);
+/* The DEVICE-RESIDENT form of cb_ble (round 6): the reference reads the rate matrix and computes its log-transition bank ONCE
+ * (FastCherries main.cpp -> io_helpers.cpp:150-174) and then runs ble() family after family
+ * (cherryml/phylogeny_estimation/_fast_cherries.py:191: one process per family, each with its own bank); cb_ble follows the
+ * per-family signature and pays for 8 MB of bank upload, ten allocations and three host passes over every sequence byte on every
+ * call (15 ms around 1 ms of kernels).  cb_ble_bank_create uploads logP [T][R][S][S] once and keeps it, with the Gamma(3, 3) rate
+ * priors of :199-203, on `device`; cb_ble_bank_run is cb_ble on that bank -- the workspace is kept between calls, the range
+ * check, both transposes and the per-site statistics of the initial bins (:10-34) run as kernels, the host sorts L integers.
+ * Same outputs as cb_ble, bit for bit.  One call at a time per bank; cb_ble_bank_destroy frees it. */
+typedef struct cb_ble_bank_s *cb_ble_bank;
+int cb_ble_bank_create(int device, int S, int T, int R, const double *logP, const double *rates, cb_ble_bank *out);
+int cb_ble_bank_run(cb_ble_bank bank, const int8_t *cx, const int8_t *cy, int n, int L, const int8_t *all_seqs, int n_seqs,
+                    const double *weights, int max_iters, int *lengths_index, int *rate_index, int *iterations, double *kernel_ms);
+int cb_ble_bank_destroy(cb_ble_bank bank);
 int cb_site_rate_gather(int device, int S, int R, int n, int L, const double *tens, const int8_t *cx,
                         const int8_t *cy, const double *log_prior, int *best);
 

@@ -55,6 +55,47 @@ def test_random_families_match_the_compiled_reference(k):
     assert np.array_equal(srates, z[f"rnd{k}_ble_rates"])
 
 
+def test_the_resident_bank_gives_the_compiled_reference_family_after_family():
+    """`BleBank` (cb_ble_bank_create / cb_ble_bank_run): the bank uploaded once, the range check, the transposes and the site
+    statistics of the initial bins as kernels, the workspace kept between calls -- the three golden families of the compiled
+    reference through ONE bank object, in both orders (a grown workspace, then a smaller family in it), and a ragged family
+    (n and L not multiples of the 64 x 64 / 32-site tiles) against the per-call entry."""
+    from cherryml_amd.phylogeny_estimation import (BleBank, compute_log_transition_matrices,
+                                                  estimate_branch_lengths_and_site_rates)
+    z = load_golden("ble.npz")
+    grid = z["grid_sr"]
+    for order in ((0, 1, 2), (2, 0, 1)):
+        banks = {}
+        for k in order:
+            rates = z[f"rnd{k}_rates"]
+            key = rates.tobytes()
+            if key not in banks:
+                banks[key] = BleBank.from_rate_matrix(z["Q"], grid, rates)
+            cx, cy = z[f"rnd{k}_x"], z[f"rnd{k}_y"]
+            prof = {}
+            lengths, srates = banks[key].estimate(cx, cy, np.concatenate([cx, cy]), z[f"rnd{k}_weights"], 50, profile=prof)
+            assert np.array_equal(lengths, z[f"rnd{k}_ble_lengths"]) and np.array_equal(srates, z[f"rnd{k}_ble_rates"]), k
+            assert prof["iterations"] >= 1 and prof["kernel_ms"] > 0
+        for b in banks.values():
+            b.close()
+    rng = np.random.default_rng(7)
+    rates = z["rnd0_rates"]
+    logP = compute_log_transition_matrices(z["Q"], grid, rates)
+    S = z["Q"].shape[0]
+    with BleBank(logP, grid, rates) as bank:
+        for n, L in ((37, 91), (130, 33), (5, 200)):
+            cx = rng.integers(-1, S, size=(n, L))
+            cy = np.where(rng.random((n, L)) < 0.7, cx, rng.integers(-1, S, size=(n, L)))
+            seqs = np.concatenate([cx, cy, rng.integers(-1, S, size=(3, L))])
+            w = z["rnd0_weights"]
+            a = bank.estimate(cx, cy, seqs, w, 50)
+            b = estimate_branch_lengths_and_site_rates(cx, cy, seqs, logP, grid, rates, w, 50)
+            assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]), (n, L)
+        with pytest.raises(Exception):
+            bad = np.full((4, 8), S, dtype=np.int8)       # a state code outside the alphabet
+            bank.estimate(bad, bad, bad, z["rnd0_weights"], 5)
+
+
 def test_siterm_site_rate_gather_matches_the_cython_reference():
     from cherryml_amd._siterm import compute_optimal_site_rates
     z = load_golden("ble.npz")
