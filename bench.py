@@ -1414,11 +1414,21 @@ def run_likelihood(steps, warmup, world, rank, local_rank, fence, with_cpu):
     rates = list(rng.choice(np.geomspace(0.05, 8.0, 20), size=L))
     prof = {}
 
+    # the caller's view (VERDICT r5 "missing 3"): both models resident on the device (LikelihoodModel = cb_tl_model_create /
+    # cb_tl_model_run), one call per family; ms_per_step is the WALL time of a call -- the family's tree arrays and state codes
+    # built and uploaded, the transition banks, the pruning, the per-site results read back
+    from cherryml_amd.evaluation import LikelihoodModel
+    model_1 = LikelihoodModel(lg, pi1, pairs=False, device=local_rank)
+    model_2 = LikelihoodModel(Q2, pi2, pairs=True, alphabet_size=20, device=local_rank)
+
     def call():
         prof.clear()
         return dp_likelihood_computation(tree, msa, cm, rates, aa, pi1, lg, pi_2=pi2, Q_2=Q2, device=local_rank,
-                                         profile=prof)
-    for _ in range(warmup):
+                                         profile=prof, model_1=model_1, model_2=model_2)
+    t0 = time.perf_counter()    # (the per-call entry: models made, used and freed by the call)
+    dp_likelihood_computation(tree, msa, cm, rates, aa, pi1, lg, pi_2=pi2, Q_2=Q2, device=local_rank)
+    per_call_entry_ms = (time.perf_counter() - t0) * 1e3
+    for _ in range(max(warmup, 1)):
         call()
     fence()
     kms, pms, sms = [], [], []
@@ -1431,10 +1441,13 @@ def run_likelihood(steps, warmup, world, rank, local_rank, fence, with_cpu):
     fence()
     dt = time.perf_counter() - t0
     kernel_ms = float(np.mean(kms))
+    call_ms = dt / steps * 1e3
+    model_1.close()
+    model_2.close()
     if world > 1:
-        tdt = torch.tensor([kernel_ms], dtype=torch.float64, device=torch.device("cuda", local_rank))
+        tdt = torch.tensor([kernel_ms, call_ms], dtype=torch.float64, device=torch.device("cuda", local_rank))
         dist.all_reduce(tdt, op=dist.ReduceOp.MAX)
-        kernel_ms = float(tdt.item())
+        kernel_ms, call_ms = (float(v) for v in tdt.tolist())
     if rank != 0:
         return None
     n_nodes = 2 * n_leaves - 1
@@ -1443,15 +1456,18 @@ def run_likelihood(steps, warmup, world, rank, local_rank, fence, with_cpu):
     ach = flops / (prune_pairs * 1e-3) / 1e12
     out = {
         "metric": "sites/sec (whole node): held-out log-likelihood, sites evaluated per second",
-        "value": L * world / (kernel_ms * 1e-3), "unit": "sites/s", "n_gpus": world, "steps": steps, "warmup": warmup,
-        "ms_per_step": kernel_ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
+        "value": L * world / (call_ms * 1e-3), "unit": "sites/s", "n_gpus": world, "steps": steps, "warmup": warmup,
+        "ms_per_step": call_ms, "kernel_ms_per_step": kernel_ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f64",
         "data": "synthetic",
         "config": {"workload": f"held-out log-likelihood: {n_leaves} leaves ({n_nodes} nodes), {n_single} independent "
                                f"sites (LG, 20 rate categories) + {n_pairs} contacting pairs (400 states) per GPU",
                    "sharding": f"families x{world} (no collective)", "log_likelihood": ll,
                    "prune_ms_pairs": prune_pairs, "prune_ms_sites": float(np.mean(sms)),
                    "bank_ms": kernel_ms - prune_pairs - float(np.mean(sms)),
-                   "host_ms_per_call_including_uploads": dt / steps * 1e3},
+                   "entry": "dp_likelihood_computation on two resident LikelihoodModels (cb_tl_model_run); ms_per_step = wall time "
+                            "of a call, kernel_ms_per_step = expm banks + pruning (HIP events)",
+                   "per_call_entry_ms": per_call_entry_ms},
         "roofline": {"bound": "mfma", "kernel": "tl_leaf_kernel + tl_mfma_kernel (all heights of the tree)", "achieved": ach,
                      "peak": F64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / F64_PEAK_TFLOPS, "traffic": None,
                      "flops_per_step": flops,

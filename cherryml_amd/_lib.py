@@ -69,6 +69,9 @@ SIGNATURES = {
                                      C.c_int, _vp, _vp, _vp, _vp, _vp]),
     "cb_tree_likelihood_batch": (C.c_int, [C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, C.c_int, _vp, _vp, _vp, _vp, _vp,
                                            _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "cb_tl_model_create": (C.c_int, [C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp]),
+    "cb_tl_model_run": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "cb_tl_model_destroy": (C.c_int, [_vp]),
     "cb_siterm_assemble_batch": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, C.c_int64, _vp, _vp, _vp, _vp,
                                            C.c_double, C.c_int, C.c_int, _vp, _vp]),
     "cb_siterm_assemble": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, C.c_int64, _vp, C.c_int64,

@@ -467,6 +467,18 @@ int cb_tree_likelihood_batch(int device, int S, int S1, const double *Q, const d
                              const int *parent, const double *length, const int *n_cats,
                              const double *cat_rate, const int *n_units, const int *unit_cat,
                              const int8_t *code_a, const int8_t *code_b, double *ll, double *kernel_ms);
+/* The model RESIDENT on the device (round 6): cb_tree_likelihood[_batch] takes the model with every call, like the reference's
+ * per-family processes (cherryml/evaluation/_likelihood.py:474-600) -- Q uploaded, a counts-free expm handle made, the transition
+ * bank ([cat][node][S][S]: 2.6 GB for a 1024-leaf family of the 400-state pair model) and the message buffer allocated and freed,
+ * the model's eigendecomposition recomputed: 21 ms per such family around 10.7 ms of kernels.  cb_tl_model_create keeps all of that
+ * on `device`; cb_tl_model_run is cb_tree_likelihood_batch's family arguments on that model (buffers grow to the largest family
+ * met, the eigendecomposition is computed by the first run); same results.  One call at a time per model. */
+typedef struct cb_tl_model_s *cb_tl_model;
+int cb_tl_model_create(int device, int S, int S1, const double *Q, const double *pi_rev, const double *pi_root, cb_tl_model *out);
+int cb_tl_model_run(cb_tl_model model, int n_fam, const int *n_nodes, const int *postorder, const int *parent, const double *length,
+                    const int *n_cats, const double *cat_rate, const int *n_units, const int *unit_cat, const int8_t *code_a,
+                    const int8_t *code_b, double *ll, double *kernel_ms);
+int cb_tl_model_destroy(cb_tl_model model);
 
 /* ---- count-matrix text format, host only ---------------------------------------
  * Replaces the tokenising loops of cherryml/io/_count_matrices.py:8-62 (read_count_matrices): `text` is the

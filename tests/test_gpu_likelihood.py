@@ -167,6 +167,37 @@ def test_likelihood_batch_of_families_equals_family_by_family(reversible_2):
             assert np.isnan(ll_o) if f == 3 else abs(got[f][0] - ll_o) <= RTOL * abs(ll_o)
 
 
+def test_resident_models_give_the_per_call_results_family_after_family():
+    """`LikelihoodModel` (cb_tl_model_create / cb_tl_model_run): the two models made once, ragged families evaluated one after
+    the other on them -- larger families after smaller ones (the transition bank's buffer and the expm handle grow), smaller after
+    larger (they stay) -- every per-site value equal to the per-call entry's bit for bit; a model refuses the other unit kind."""
+    from cherryml_amd.evaluation import LikelihoodModel, dp_likelihood_computation
+    z = load_golden("likelihood.npz")
+    aa = [str(a) for a in z["amino_acids"]]
+    rng = np.random.default_rng(77)
+    pi2, Q2 = _random_pair_model(rng)
+    with LikelihoodModel(z["wag"], z["pi_wag"], pairs=False) as m1, LikelihoodModel(Q2, pi2, pairs=True, alphabet_size=20) as m2:
+        for n_leaves, n_pairs, extra in [(9, 5, 3), (40, 12, 9), (4, 1, 0), (60, 23, 1), (17, 4, 6)]:
+            tree, names = _random_tree(rng, n_leaves)
+            L = 2 * n_pairs + extra
+            cm = np.zeros((L, L), dtype=int)
+            perm = rng.permutation(L)
+            for k in range(n_pairs):
+                i, j = perm[2 * k], perm[2 * k + 1]
+                cm[i, j] = cm[j, i] = 1
+            msa = _random_msa(rng, names, L, aa, gap=0.1)
+            rates = list(rng.choice(np.round(rng.uniform(0.1, 3.0, 4), 3), size=L))
+            prof = {}
+            got = dp_likelihood_computation(tree, msa, cm, rates, aa, z["pi_wag"], z["wag"], pi_2=pi2, Q_2=Q2, profile=prof,
+                                            model_1=m1, model_2=m2)
+            one = dp_likelihood_computation(tree, msa, cm, rates, aa, z["pi_wag"], z["wag"], pi_2=pi2, Q_2=Q2)
+            assert np.array_equal(np.array(got[1]), np.array(one[1]), equal_nan=True), (n_leaves, n_pairs, extra)
+            assert prof["kernel_ms"] > 0
+        tree, names = _random_tree(rng, 5)
+        with pytest.raises(ValueError):
+            m1.log_likelihoods([tree], [np.zeros((9, 2), dtype=np.int8)], [np.zeros((9, 2), dtype=np.int8)], [np.ones(2)])
+
+
 def test_likelihood_small_alphabet_pairs_and_general_S():
     """S1 = 4 (16 pair states, lane-group kernel with pair observations) and S1 = 9 (81 states, MFMA kernel,
     S not a multiple of 4 or 16)."""
