@@ -1468,12 +1468,14 @@ def run_likelihood(steps, warmup, world, rank, local_rank, fence, with_cpu):
                    "entry": "dp_likelihood_computation on two resident LikelihoodModels (cb_tl_model_run); ms_per_step = wall time "
                             "of a call, kernel_ms_per_step = expm banks + pruning (HIP events)",
                    "per_call_entry_ms": per_call_entry_ms},
-        "roofline": {"bound": "mfma", "kernel": "tl_leaf_kernel + tl_mfma_kernel (all heights of the tree)", "achieved": ach,
+        "roofline": {"bound": "mfma", "kernel": "tl_leaf_mfma_kernel + tl_mfma_kernel (all heights of the tree)", "achieved": ach,
                      "peak": F64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / F64_PEAK_TFLOPS, "traffic": None,
                      "flops_per_step": flops,
                      "note": "ALGORITHMIC 2 S^2 flops per (non-root node, pair) / time of all pruning launches of the pair "
-                             "model; the leaves (half of the nodes) are gathered from P_v's columns instead of multiplied "
-                             "(tl_leaf_kernel), internal nodes read P_v (1.28 MB) once per 32-pair block (tl_mfma_kernel)"},
+                             "model; a leaf's message is one [S x S] x [S x pairs] product with the model's eigenvectors as the "
+                             "streamed operand (tl_leaf_mfma_kernel: no P_v is formed for the leaves -- half of the nodes), internal "
+                             "nodes read their P_v (1.28 MB) once per 32-pair block (tl_mfma_kernel); the transition bank "
+                             "(config.bank_ms) holds the internal nodes only"},
     }
     if with_cpu:
         from oracle import likelihood_oracle as lo

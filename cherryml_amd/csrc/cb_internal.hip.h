@@ -36,6 +36,13 @@ int cb_internal_expm_bank(cb_handle h, const double *Q, const double *pi, int fl
 // new branch lengths for a counts-free (CB_EXPM_ONLY) single-bank handle, B <= its creation B (cherrybank.hip);
 // t_dev != NULL: the same values already on the device -- copied on the handle's stream, no host wait
 int cb_internal_set_times(cb_handle h, const double *t_host, int B, const double *t_dev);
+// the symmetric eigendecomposition a large (S > 32) handle's last reversible expm bank left on the device: A = D^1/2 Q D^-1/2
+// [LD][LD], U [LD][LD] row-major (columns = eigenvectors), lam [LD], dsq = sqrt(pi) [LD] (pad 1), sigma = max |A_ii| (a scalar)
+struct CbSpectral {
+  int S = 0, LD = 0;
+  const double *A = nullptr, *U = nullptr, *lam = nullptr, *dsq = nullptr, *sigma = nullptr;
+};
+int cb_internal_spectral(cb_handle h, CbSpectral *out);
 
 // the fused bank launch k123_bank (cb_bank_fused.hip): variant 0 = float64, 1 = CB_F32, 2 = CB_MIXED; kg = 1 (four-wave
 // tiles) or 2 (eight-wave tiles); `args` = the argument block in device memory; stop = null or the event that takes the

@@ -9,6 +9,8 @@ namespace {
 struct TlFamily {
   int n_nodes = 0, n_units = 0, n_cats = 0, root = 0, n_levels = 0;
   std::vector<int> level_ptr, level_nodes, child_ptr, child_idx, nchild;
+  std::vector<int> slot;   // bank slot of a node when the bank holds the INTERNAL non-root nodes only (-1: none); n_int of them
+  int n_int = 0;
 };
 
 int tl_prepare(int S, int S1, int n_nodes, const int *postorder, const int *parent, const double *length, int n_cats,
@@ -56,6 +58,10 @@ int tl_prepare(int S, int S1, int n_nodes, const int *postorder, const int *pare
     std::vector<int> at(f.level_ptr.begin(), f.level_ptr.end() - 1);
     for (int i = 0; i < n_nodes; ++i) f.level_nodes[at[height[postorder[i]]]++] = postorder[i];
   }
+  f.slot.assign(n_nodes, -1);
+  f.n_int = 0;
+  for (int v = 0; v < n_nodes; ++v)
+    if (f.nchild[v] > 0 && v != root) f.slot[v] = f.n_int++;
   for (int u = 0; u < n_units; ++u)
     if (unit_cat[u] < 0 || unit_cat[u] >= n_cats) return fail(CB_EINVAL, "cb_tree_likelihood: unit_cat[%d] = %d", u, unit_cat[u]);
   for (int c = 0; c < n_cats; ++c)
@@ -71,10 +77,16 @@ int tl_prepare(int S, int S1, int n_nodes, const int *postorder, const int *pare
 }
 
 // the pruning of one family: one launch per height over (nodes of that height) x (blocks of units), stream 0
+struct TlFactored {   // leaves from the eigendecomposition (tl_leaf_mfma_kernel); slot == nullptr: the round-5 path
+  const int *slot = nullptr;
+  const double *tnode = nullptr, *U = nullptr, *lam = nullptr, *dsq = nullptr, *sigma = nullptr, *TU = nullptr, *TA = nullptr;
+  int LD = 0;
+};
 int tl_prune(int S, int S1, const TlFamily &f, const double *dP, int cat_stride_nodes, const double *dproot, const int *duc,
              const int8_t *dca, const int8_t *dcb, const int *dlev, const int *dcp, const int *dci, double *dmsg, double *dll,
-             int NU) {
+             int NU, const TlFactored &fx = TlFactored{}) {
   TlArgs a{};
+  a.slot = fx.slot; a.tnode = fx.tnode; a.U = fx.U; a.lam = fx.lam; a.dsq = fx.dsq; a.sigma = fx.sigma; a.TU = fx.TU; a.TA = fx.TA; a.LD = fx.LD;
   a.S = S; a.S1 = S1; a.n_nodes = cat_stride_nodes; a.n_units = f.n_units; a.NU = NU; a.root = f.root;
   a.child_ptr = dcp; a.child_idx = dci; a.P = dP; a.unit_cat = duc;
   a.code_a = reinterpret_cast<const signed char *>(dca);
@@ -88,7 +100,10 @@ int tl_prune(int S, int S1, const TlFamily &f, const double *dP, int cat_stride_
     return fail(CB_EUNSUPPORTED, "cb_tree_likelihood: %d units per family at S > 64 (at most 50 000)", f.n_units);
   const void *mfma_fn = NB == 2 ? reinterpret_cast<const void *>(tl_mfma_kernel<2>)
                                 : reinterpret_cast<const void *>(tl_mfma_kernel<1>);
+  const void *leaf_fn = NB == 2 ? reinterpret_cast<const void *>(tl_leaf_mfma_kernel<2>)
+                                : reinterpret_cast<const void *>(tl_leaf_mfma_kernel<1>);
   if (S > 64 && (hipFuncSetAttribute(mfma_fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
+                 hipFuncSetAttribute(leaf_fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
                  hipFuncSetAttribute(reinterpret_cast<const void *>(tl_leaf_kernel),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_leaf) != hipSuccess))
     return fail(CB_EHIP, "cb_tree_likelihood: cannot reserve %zu bytes of LDS", lds);
@@ -96,8 +111,21 @@ int tl_prune(int S, int S1, const TlFamily &f, const double *dP, int cat_stride_
     const int nl = f.level_ptr[l + 1] - f.level_ptr[l];
     // height 0 = the leaves (never the root when the tree has an edge): gathered, not multiplied
     const bool leaves = S > 64 && l == 0 && f.n_levels > 1;
-    a.n_blocks = leaves ? 1 : S > 64 ? (f.n_units + 16 * NB - 1) / (16 * NB) : (f.n_units + 64 / S - 1) / (64 / S);
+    const bool leaves_fx = leaves && fx.slot != nullptr;
+    a.n_blocks = (leaves && !leaves_fx) ? 1 : S > 64 ? (f.n_units + 16 * NB - 1) / (16 * NB) : (f.n_units + 64 / S - 1) / (64 / S);
     a.RS = 1;
+    if (leaves_fx) {
+      const int per_launch = std::max(1, (1 << 30) / a.n_blocks);
+      for (int y0 = 0; y0 < nl; y0 += per_launch) {
+        TlArgs b = a;
+        b.level_nodes = dlev + f.level_ptr[l] + y0;
+        b.n_level = std::min(per_launch, nl - y0);
+        const dim3 grid((unsigned)b.n_level * (unsigned)a.n_blocks);
+        if (NB == 2) hipLaunchKernelGGL(tl_leaf_mfma_kernel<2>, grid, dim3(TL_NW * 64), lds, 0, b);
+        else hipLaunchKernelGGL(tl_leaf_mfma_kernel<1>, grid, dim3(TL_NW * 64), lds, 0, b);
+      }
+      continue;
+    }
     if (S > 64 && !leaves) {   // small levels: split the rows of a node over 2 or 4 workgroups (one per CU)
       const long wgs = (long)nl * a.n_blocks;
       a.RS = wgs * 4 <= 256 ? 4 : wgs * 2 <= 256 ? 2 : 1;
@@ -136,6 +164,9 @@ struct cb_tl_model_s {
   size_t cap_P = 0, cap_msg = 0, cap_bank = 0;
   cb_handle hl = nullptr;                   // S > 32: the counts-free expm handle
   bool eigh_done = false;
+  // S > 64, reversible: the leaves' tables (tl_tables_kernel), built behind the model's first eigensolve
+  double *dTU = nullptr, *dTA = nullptr;
+  bool tables_done = false;
 };
 
 // One run of the pruning over MANY families on a resident model.  MANY families under ONE model in one call (the reference maps families over a process pool,
@@ -156,6 +187,7 @@ static int tl_run(cb_tl_model_s &m, int n_fam, const int *n_nodes, const int *po
   const int device = m.device, S = m.S, S1 = m.S1;
   if (n_fam < 1) return fail(CB_EINVAL, "cb_tree_likelihood: bad sizes (S = %d, families = %d)", S, n_fam);
   if (S1 > 0 && !code_b) return fail(CB_EINVAL, "cb_tree_likelihood: pair model needs S = S1 * S1 and code_b");
+  const bool factored = S > 64 && !m.pi_rev.empty();
   std::vector<TlFamily> fam(n_fam);
   std::vector<size_t> off_n(n_fam + 1, 0), off_u(n_fam + 1, 0), off_c(n_fam + 1, 0), off_k(n_fam + 1, 0);
   int rc = CB_OK, max_nodes = 0;
@@ -173,7 +205,9 @@ static int tl_run(cb_tl_model_s &m, int n_fam, const int *n_nodes, const int *po
     const int NU = S > 64 ? (n_units[f] + 31) / 32 * 32 : n_units[f];   // (tl_mfma_kernel: 16 or 32 unit columns per workgroup)
     max_nodes = std::max(max_nodes, n_nodes[f]);
     max_msg = std::max(max_msg, (size_t)n_nodes[f] * S * NU);
-    max_bank = std::max(max_bank, (size_t)n_cats[f] * n_nodes[f]);
+    // (S > 64 with a reversible model: the bank holds the INTERNAL non-root nodes only -- the leaves take their messages from the
+    // eigendecomposition -- at least one slot, so that a family of leaves still triggers the model's eigensolve)
+    max_bank = std::max(max_bank, factored ? (size_t)std::max(fam[f].n_int, 1) : (size_t)n_cats[f] * n_nodes[f]);
   }
   const bool large = S > 32;
   const size_t SS = (size_t)S * S;
@@ -181,24 +215,6 @@ static int tl_run(cb_tl_model_s &m, int n_fam, const int *n_nodes, const int *po
   CbDevBufs d;
   // shared by all families AND all calls on this model: Q / pi on the device, the transition bank's and the messages' buffers
   // (2.6 GB for a 1024-leaf family of the 400-state pair model: allocating and freeing that per call was 8 of its 21 ms)
-  int max_cats = 1;
-  for (int f = 0; f < n_fam; ++f) max_cats = std::max(max_cats, n_cats[f]);
-  if (!large && max_cats > m.Lrep) {   // (S <= 32: one copy of Q per rate category)
-    if (m.dQ) (void)hipFree(m.dQ);
-    if (m.dpi) (void)hipFree(m.dpi);
-    m.dQ = m.dpi = nullptr;
-    std::vector<double> Qrep((size_t)max_cats * SS), pirep;
-    for (int l = 0; l < max_cats; ++l) std::copy(m.Q.begin(), m.Q.end(), Qrep.begin() + (size_t)l * SS);
-    if (hipMalloc((void **)&m.dQ, Qrep.size() * sizeof(double)) != hipSuccess) return fail(CB_ENOMEM, "cb_tree_likelihood: device allocation failed");
-    HIP_TRY(hipMemcpy(m.dQ, Qrep.data(), Qrep.size() * sizeof(double), hipMemcpyHostToDevice));
-    if (!m.pi_rev.empty()) {
-      pirep.resize((size_t)max_cats * S);
-      for (int l = 0; l < max_cats; ++l) std::copy(m.pi_rev.begin(), m.pi_rev.end(), pirep.begin() + (size_t)l * S);
-      if (hipMalloc((void **)&m.dpi, pirep.size() * sizeof(double)) != hipSuccess) return fail(CB_ENOMEM, "cb_tree_likelihood: device allocation failed");
-      HIP_TRY(hipMemcpy(m.dpi, pirep.data(), pirep.size() * sizeof(double), hipMemcpyHostToDevice));
-    }
-    m.Lrep = max_cats;
-  }
   if (max_bank * SS > m.cap_P) {
     if (m.dP) (void)hipFree(m.dP);
     m.dP = nullptr;
@@ -235,12 +251,14 @@ static int tl_run(cb_tl_model_s &m, int n_fam, const int *n_nodes, const int *po
   const int *dlev = d.up(lev_all.data(), lev_all.size(), rc), *dcp = d.up(cp_all.data(), cp_all.size(), rc);
   const int *dci = d.up(ci_all.data(), ci_all.size(), rc);
   if (rc != CB_OK) return rc;
-  // S > 32: one counts-free handle for all families and calls (capacity = the largest [category][node] bank met so far; 33 <= S <= 64
-  // has several rate categories), the model's eigensolve once
-  if (large && (!m.hl || max_bank > m.cap_bank)) {
+  // one counts-free handle for all families and calls: a single "site" whose buckets are the (category, node) pairs of a family --
+  // t[c][v] = rate_c x length_v, the layout of P -- with capacity for the largest family met so far; S > 32: the model's
+  // eigensolve once.  (Round 5 made, waited for and destroyed a handle per family at S <= 32: 2 of a call's 14 ms.)
+  if (!m.hl || max_bank > m.cap_bank) {
     if (m.hl) cb_destroy(m.hl);
     m.hl = nullptr;
     m.eigh_done = false;
+    m.tables_done = false;   // (the new handle's decomposition: the same solver on the same matrix, but not a promise kept here)
     std::vector<double> t0(max_bank, 0.0);
     if ((rc = cb_create(device, S, 1, (int)max_bank, CB_F64, t0.data(), nullptr, CB_EXPM_ONLY, &m.hl)) != CB_OK) return rc;
     if ((rc = cb_set_stream(m.hl, nullptr, 0)) != CB_OK) return rc;
@@ -259,40 +277,62 @@ static int tl_run(cb_tl_model_s &m, int n_fam, const int *n_nodes, const int *po
   // branch lengths x category rates of ALL families, uploaded once (S > 32: a family's bank then starts behind the
   // previous family's pruning on the stream without the host waiting for it)
   std::vector<size_t> off_t(n_fam + 1, 0);
-  for (int f = 0; f < n_fam; ++f) off_t[f + 1] = off_t[f] + (size_t)n_cats[f] * n_nodes[f];
-  std::vector<double> t_all(off_t[n_fam]);
+  for (int f = 0; f < n_fam; ++f)
+    off_t[f + 1] = off_t[f] + (factored ? (size_t)std::max(fam[f].n_int, 1) : (size_t)n_cats[f] * n_nodes[f]);
+  std::vector<double> t_all(off_t[n_fam], 0.0), t_node(factored ? off_n[n_fam] : 0);
+  std::vector<int> slot_all(factored ? off_n[n_fam] : 0);
   for (int f = 0; f < n_fam; ++f) {
     const TlFamily &F = fam[f];
     const double *len = length + off_n[f], *cr = cat_rate + off_k[f];
+    if (factored) {   // (one category at S > 64: tl_prepare)
+      for (int v = 0; v < F.n_nodes; ++v) {
+        const double tv = v == F.root ? 0.0 : cr[0] * len[v];
+        t_node[off_n[f] + v] = tv;
+        slot_all[off_n[f] + v] = F.slot[v];
+        if (F.slot[v] >= 0) t_all[off_t[f] + F.slot[v]] = tv;
+      }
+      continue;
+    }
     for (int c = 0; c < F.n_cats; ++c)
       for (int v = 0; v < F.n_nodes; ++v) t_all[off_t[f] + (size_t)c * F.n_nodes + v] = v == F.root ? 0.0 : cr[c] * len[v];
   }
-  const double *dt_all = large ? d.up(t_all.data(), t_all.size(), rc) : nullptr;
+  const double *dt_all = d.up(t_all.data(), t_all.size(), rc);
+  const double *dt_node = factored ? d.up(t_node.data(), t_node.size(), rc) : nullptr;
+  const int *dslot = factored ? d.up(slot_all.data(), slot_all.size(), rc) : nullptr;
   if (rc != CB_OK) return rc;
   for (int f = 0; f < n_fam && rc == CB_OK; ++f) {
     const TlFamily &F = fam[f];
     const double *t = t_all.data() + off_t[f];
     // ---- transition bank expm(rate_c * length_v * Q), [cat][node][S][S], by the bank's own expm kernels
-    if (large) {
-      if ((rc = cb_internal_set_times(hl, t, F.n_cats * F.n_nodes, dt_all + off_t[f])) != CB_OK) break;
-      rc = cb_internal_expm_bank(hl, dQ, dpi, CB_PTR_DEVICE | CB_NO_SYNC | (m.eigh_done && dpi ? CB_REUSE_EIGH : 0), dP);
-      if (rc == CB_OK) m.eigh_done = true;
-    } else {
-      cb_handle h = nullptr;
-      if ((rc = cb_create(device, S, F.n_cats, F.n_nodes, CB_F64, t, nullptr, CB_EXPM_ONLY, &h)) != CB_OK) break;
-      rc = cb_set_stream(h, nullptr, 0);
-      if (rc == CB_OK) rc = cb_expm_bank(h, dQ, dpi, CB_PTR_DEVICE | CB_NO_SYNC, dP);
-      if (rc == CB_OK && hipStreamSynchronize(0) != hipSuccess) rc = fail(CB_EHIP, "cb_tree_likelihood: bank failed");
-      cb_destroy(h);
-    }
+    if ((rc = cb_internal_set_times(hl, t, (int)(off_t[f + 1] - off_t[f]), dt_all + off_t[f])) != CB_OK) break;
+    rc = cb_internal_expm_bank(hl, dQ, dpi, CB_PTR_DEVICE | CB_NO_SYNC | (large && m.eigh_done && dpi ? CB_REUSE_EIGH : 0), dP);
+    if (rc == CB_OK) m.eigh_done = true;
     if (rc != CB_OK) break;
     // pruning time of this family: a marker pair around its launches (both or neither)
     hipEvent_t em = nullptr, ep = nullptr;
     const bool timed = kernel_ms && hipEventCreate(&em) == hipSuccess && hipEventCreate(&ep) == hipSuccess;
     if (timed) (void)hipEventRecord(em, 0);
     const int NU = S > 64 ? (F.n_units + 31) / 32 * 32 : F.n_units;
+    TlFactored fx;
+    if (factored) {
+      CbSpectral sp;
+      if ((rc = cb_internal_spectral(hl, &sp)) != CB_OK) break;
+      const int nJ = S + (S1 > 0 ? 2 * S1 : 0) + 1;
+      if (!m.tables_done) {   // once per model, behind its eigensolve on the stream
+        if (!m.dTU && (hipMalloc((void **)&m.dTU, (size_t)nJ * sp.LD * sizeof(double)) != hipSuccess ||
+                       hipMalloc((void **)&m.dTA, (size_t)nJ * sp.LD * sizeof(double)) != hipSuccess)) {
+          (void)hipGetLastError();
+          rc = fail(CB_ENOMEM, "cb_tree_likelihood: device allocation failed");
+          break;
+        }
+        hipLaunchKernelGGL(tl_tables_kernel, dim3(nJ), dim3(256), 0, 0, S, S1, sp.LD, nJ, sp.U, sp.A, sp.dsq, m.dTU, m.dTA);
+        m.tables_done = true;
+      }
+      fx.slot = dslot + off_n[f]; fx.tnode = dt_node + off_n[f]; fx.U = sp.U; fx.lam = sp.lam; fx.dsq = sp.dsq; fx.sigma = sp.sigma;
+      fx.TU = m.dTU; fx.TA = m.dTA; fx.LD = sp.LD;
+    }
     rc = tl_prune(S, S1, F, dP, F.n_nodes, dproot, duc + off_u[f], dca + off_c[f], dcb ? dcb + off_c[f] : nullptr,
-                  dlev + off_n[f], dcp + off_n[f] + f, dci + off_n[f], dmsg, dll + off_u[f], NU);
+                  dlev + off_n[f], dcp + off_n[f] + f, dci + off_n[f], dmsg, dll + off_u[f], NU, fx);
     if (timed) {
       (void)hipEventRecord(ep, 0);
       evm.push_back(em);
@@ -329,7 +369,7 @@ extern "C" int cb_tl_model_destroy(cb_tl_model_s *m) {
   if (!m) return CB_OK;
   (void)hipSetDevice(m->device);
   if (m->hl) cb_destroy(m->hl);
-  for (double *p : {m->dQ, m->dpi, m->dproot, m->dP, m->dmsg})
+  for (double *p : {m->dQ, m->dpi, m->dproot, m->dP, m->dmsg, m->dTU, m->dTA})
     if (p) (void)hipFree(p);
   delete m;
   return CB_OK;
@@ -351,7 +391,7 @@ extern "C" int cb_tl_model_create(int device, int S, int S1, const double *Q, co
   if (pi_rev) m->pi_rev.assign(pi_rev, pi_rev + S);
   bool ok = hipMalloc((void **)&m->dproot, S * sizeof(double)) == hipSuccess &&
             hipMemcpy(m->dproot, pi_root, S * sizeof(double), hipMemcpyHostToDevice) == hipSuccess;
-  if (ok && S > 32) {   // one copy of Q (S <= 32: per rate category, made by the first run that knows how many)
+  if (ok) {
     ok = hipMalloc((void **)&m->dQ, SS * sizeof(double)) == hipSuccess && hipMemcpy(m->dQ, Q, SS * sizeof(double), hipMemcpyHostToDevice) == hipSuccess;
     if (ok && pi_rev)
       ok = hipMalloc((void **)&m->dpi, S * sizeof(double)) == hipSuccess && hipMemcpy(m->dpi, pi_rev, S * sizeof(double), hipMemcpyHostToDevice) == hipSuccess;

@@ -778,6 +778,13 @@ int cb_internal_expm_bank(cb_handle h, const double *Q, const double *pi, int fl
 
 // internal (cb_internal.hip.h): new branch lengths for a counts-free handle, B <= the B it was created with --
 // lets cb_tree_likelihood_batch push family after family through ONE handle (one eigendecomposition)
+int cb_internal_spectral(cb_handle h, CbSpectral *out) {
+  if (!h || !out) return fail(CB_EINVAL, "cb_internal_spectral: NULL argument");
+  if (!h->large || !h->have_prev) return fail(CB_EINVAL, "cb_internal_spectral: no decomposition on this handle");
+  out->S = h->S; out->LD = h->LD; out->A = h->A; out->U = h->U; out->lam = h->lam; out->dsq = h->dsq; out->sigma = h->sigma;
+  return CB_OK;
+}
+
 int cb_internal_set_times(cb_handle h, const double *t_host, int B, const double *t_dev) {
   if (!h || !t_host) return fail(CB_EINVAL, "cb_internal_set_times: NULL argument");
   if (!h->expm_only || h->L != 1) return fail(CB_EINVAL, "cb_internal_set_times: counts-free single-bank handles only");

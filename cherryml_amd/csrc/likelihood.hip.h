@@ -31,6 +31,13 @@ struct TlArgs {
   const double *pi_root;       // [S]
   double *msg;                 // upward messages (layout per kernel)
   double *ll;                  // [n_units]
+  // S > 64 with a reversible model (round 6): the bank holds INTERNAL nodes only -- slot[v] (-1: none) -- and the leaves take their
+  // messages from the model's eigendecomposition (tl_leaf_mfma_kernel)
+  const int *slot;             // [n_nodes] or null (P indexed by node)
+  const double *tnode;         // [n_nodes] rate x branch length above the node
+  const double *U, *lam, *dsq, *sigma;   // U [LD][LD] row-major, lam [LD], dsq = sqrt(pi) [LD], sigma = max |A_ii|
+  const double *TU, *TA;       // [nJ][LD]: sum_{j in J} U[j][k] d_j  and  sum_{j in J} A[i][j] d_j  (tl_tables_kernel)
+  int LD;
 };
 
 __device__ __forceinline__ bool tl_observed(int S1, int k, int ca, int cb) {
@@ -104,9 +111,24 @@ struct TlProd {
   int u[NB];
   bool act[NB];
   double m[NB];
+  int ldp, Kc;                // row stride of Pv and its column (contraction) extent: S, S for a transition matrix; LD, LD for U -- when
+                              // LD > S the padding's eigenpairs (lam = 0, zero on the real rows) sit BETWEEN the real ones in the sorted order
+  // LEAF (tl_leaf_mfma_kernel): acc = sum_k U[i][k] F_k TU[J_u][k]; arg = (split ? [i in J_u] d_i + t TA[J_u][i] : 0) + acc) / d_i
+  const double *dsq, *ta[NB];
+  int J[NB], S1;
+  double tsplit;              // t when the split form I + tA + U phi2 U^T is used, else 0
+  bool split;
 };
 
-template <int NB, int G, bool VEC>
+// is state `row` in the observation set J?  J < S: that state; S + a: first letter a; S + S1 + b: second letter b; else all
+__device__ __forceinline__ bool tl_in_set(int S, int S1, int row, int J) {
+  if (J < S) return row == J;
+  if (S1 > 0 && J < S + S1) return row / S1 == J - S;
+  if (S1 > 0 && J < S + 2 * S1) return row % S1 == J - S - S1;
+  return true;
+}
+
+template <int NB, int G, bool VEC, bool LEAF = false>
 __device__ __forceinline__ void tl_product(const TlProd<NB> &p) {
   constexpr int DEPTH = NB == 1 ? TL_DEPTH - 1 : TL_DEPTH;   // (the 16-unit form is for tiny inputs; three stages spill there)
   const int S = p.S, lo = p.lo, hi = p.hi;
@@ -115,16 +137,16 @@ __device__ __forceinline__ void tl_product(const TlProd<NB> &p) {
   for (int j = 0; j < G; ++j) {
     int row = p.row0 + j * p.row_step + lo;
     row = row < S ? row : S - 1;             // rows beyond S: results discarded
-    prow[j] = p.Pv + (size_t)row * S;
+    prow[j] = p.Pv + (size_t)row * p.ldp;
   }
   // chunk kc of the lane's row of tile j; columns beyond S are clamped (W = 0 there)
   auto load_a = [&](int kc, int j, d4 &av) {
     const int k0 = 16 * kc + 4 * hi;
     if (VEC) {
-      av = *reinterpret_cast<const d4 *>(prow[j] + (k0 + 3 < S ? k0 : S - 4));
+      av = *reinterpret_cast<const d4 *>(prow[j] + (k0 + 3 < p.Kc ? k0 : p.Kc - 4));
     } else {
 #pragma unroll
-      for (int c = 0; c < 4; ++c) av[c] = prow[j][k0 + c < S ? k0 + c : S - 1];
+      for (int c = 0; c < 4; ++c) av[c] = prow[j][k0 + c < p.Kc ? k0 + c : p.Kc - 1];
     }
   };
   auto step = [&](int kc, const d4 (&ac)[G], d4 (&acc)[G][NB]) {
@@ -178,7 +200,12 @@ __device__ __forceinline__ void tl_product(const TlProd<NB> &p) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int row = p.row0 + j * p.row_step + hi + 4 * r;
-        const double arg = acc[j][nb][r];
+        double arg = acc[j][nb][r];
+        if (LEAF && row < S) {
+          const double di = p.dsq[row];
+          if (p.split) arg += fma(p.tsplit, p.ta[nb][row], tl_in_set(S, p.S1, row, p.J[nb]) ? di : 0.0);
+          arg /= di;
+        }
         if (row < S) mv[(size_t)row * p.NU] = log(arg < 0.0 ? 0.0 : arg) + p.m[nb];
       }
   }
@@ -309,13 +336,15 @@ __global__ __launch_bounds__(TL_NW * 64, 2) void tl_mfma_kernel(TlArgs a) {
     }
   }
   // arg[row][unit] = sum_k P_v[row][k] W[k][unit] (tl_product)
-  const double *Pv = a.P + ((size_t)a.unit_cat[act[0] ? u[0] : 0] * a.n_nodes + v) * S * S;
+  // (slot map: the bank then holds the internal nodes only, one category)
+  const double *Pv = a.slot ? a.P + (size_t)a.slot[v] * S * S : a.P + ((size_t)a.unit_cat[act[0] ? u[0] : 0] * a.n_nodes + v) * S * S;
   // all units of a block share the category (host contract: one category when S > 64)
   int g_tiles = 0;            // this wave's product tiles: (wave + TL_NW j) RS + rs, j < g_tiles
 #pragma unroll
   for (int j = 0; j < TL_MAXT; ++j)
     if ((wave + TL_NW * j) * RS + rs < nt) g_tiles = j + 1;
-  TlProd<NB> pr{Pv, sW, a.msg + (size_t)v * S * a.NU, S, Sp, a.NU, (wave * RS + rs) * 16, TL_NW * RS * 16, lo, hi, {}, {}, {}};
+  TlProd<NB> pr{Pv, sW, a.msg + (size_t)v * S * a.NU, S, Sp, a.NU, (wave * RS + rs) * 16, TL_NW * RS * 16, lo, hi, {}, {}, {}, S, S, nullptr,
+                {}, {}, 0, 0.0, false};
 #pragma unroll
   for (int nb = 0; nb < NB; ++nb) {
     pr.u[nb] = u[nb];
@@ -439,5 +468,111 @@ __global__ __launch_bounds__(TL_LT) void tl_leaf_kernel(TlArgs a) {
       }
     }
     __syncthreads();
+  }
+}
+
+
+// ---- leaves from the model's eigendecomposition (round 6) -------------------------------------------------------------------------
+// A leaf's message is log of a column of P_v (both sites observed), of a sum of S1 columns (one site a gap) or of a row sum
+// (both): sum_{j in J} P_v[i][j] for an observation set J that depends on the unit.  Round 5 formed ALL of P_v for every leaf --
+// half of the bank's 262 GFLOP and 1.3 GB of its traffic at 1024 leaves -- to gather 128 of its 400 columns.  With
+// P_v = D^-1/2 (I + t A + U phi2(t Lam) U^T) D^1/2 (t rho <= 1; else U e^{t Lam} U^T):
+//   sum_{j in J} P_v[i][j] = ( [i in J] d_i + t TA[J][i] + sum_k U[i][k] F_v[k] TU[J][k] ) / d_i,
+//   TU[J][k] = sum_{j in J} U[j][k] d_j,   TA[J][i] = sum_{j in J} A[i][j] d_j      (once per model: tl_tables_kernel)
+// i.e. ONE [S x S] x [S x units] product per leaf with U as the streamed operand (1.28 MB shared by all leaves: L2) and the other
+// formed in LDS from the unit's table row -- 41 instead of 77 MFLOP per leaf, no P_v.  The split keeps the relative accuracy of
+// the O(t^2) entries exactly as the bank does (same rule, t 2 sigma <= 1).
+__global__ __launch_bounds__(256) void tl_tables_kernel(int S, int S1, int LD, int nJ, const double *__restrict__ U,
+                                                        const double *__restrict__ A, const double *__restrict__ dsq,
+                                                        double *__restrict__ TU, double *__restrict__ TA) {
+  const int J = blockIdx.x;
+  for (int k = threadIdx.x; k < LD; k += 256) {
+    // TU over all LD eigenpairs k (the padding's are zero on the real rows j), TA over the real states i = k < S
+    double su = 0.0, sa = 0.0;
+    if (J < S) {
+      su = U[(size_t)J * LD + k] * dsq[J];
+      sa = k < S ? A[(size_t)k * LD + J] * dsq[J] : 0.0;
+    } else {
+      // a marginal: the states of the set in ascending order (fixed summation order)
+      for (int j = 0; j < S; ++j)
+        if (tl_in_set(S, S1, j, J)) {
+          su = fma(U[(size_t)j * LD + k], dsq[j], su);
+          if (k < S) sa = fma(A[(size_t)k * LD + j], dsq[j], sa);
+        }
+    }
+    TU[(size_t)J * LD + k] = su;
+    TA[(size_t)J * LD + k] = sa;
+  }
+  (void)nJ;
+}
+
+// grid = leaves of the family x unit blocks of 16 NB, TL_NW waves; msg layout [node][row][NU] as tl_mfma_kernel
+template <int NB>
+__global__ __launch_bounds__(TL_NW * 64, 2) void tl_leaf_mfma_kernel(TlArgs a) {
+  extern __shared__ double tl_lds[];
+  double *sW = tl_lds;                     // [(Sp NB + Sp / 4)][16]
+  const int S = a.S, nt = (S + 15) / 16, Sp = nt * 16, LD = a.LD;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, lo = lane & 15, hi = lane >> 4;
+  const int vid = xcd_swizzle(blockIdx.x, gridDim.x);
+  const int node_i = vid / a.n_blocks, blk = vid - node_i * a.n_blocks;
+  const int v = a.level_nodes[node_i];
+  const double t = a.tnode[v];
+  const bool split = t * 2.0 * (*a.sigma) <= 1.0;   // the bank's rule (k1_tile)
+  int u[NB], J[NB];
+  bool act[NB];
+  const int nJ_all = S + (a.S1 > 0 ? 2 * a.S1 : 0);
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb) {
+    u[nb] = (blk * NB + nb) * 16 + lo;
+    act[nb] = u[nb] < a.n_units;
+    int ca = -1, cb = -1;
+    if (act[nb]) {
+      const size_t ci = (size_t)v * a.n_units + u[nb];
+      ca = a.code_a[ci];
+      cb = a.S1 > 0 ? a.code_b[ci] : -1;
+    }
+    J[nb] = a.S1 > 0 ? (ca >= 0 && cb >= 0 ? ca * a.S1 + cb : ca >= 0 ? S + ca : cb >= 0 ? S + a.S1 + cb : nJ_all)
+                     : (ca >= 0 ? ca : nJ_all);
+  }
+  // W[k][unit] = F_v[k] TU[J_unit][k]: wave w fills the k tiles w, w + TL_NW, ...
+  for (int j = 0; j < TL_MAXT; ++j) {
+    const int kt = wave + TL_NW * j;
+    if (kt >= nt) break;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int k = kt * 16 + hi + 4 * r;
+      // (k runs over all LD eigenpairs: Sp == LD)
+      const double x = t * a.lam[k];
+      const double f = split ? phi2(x) : exp(x);
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) sW[tl_w_index<NB>(k, nb, lo)] = act[nb] ? f * a.TU[(size_t)J[nb] * LD + k] : 0.0;
+    }
+  }
+  __syncthreads();
+  int g_tiles = 0;
+#pragma unroll
+  for (int j = 0; j < TL_MAXT; ++j)
+    if (wave + TL_NW * j < nt) g_tiles = j + 1;
+  TlProd<NB> pr{a.U, sW, a.msg + (size_t)v * S * a.NU, S, Sp, a.NU, wave * 16, TL_NW * 16, lo, hi, {}, {}, {}, LD, LD, a.dsq, {}, {}, a.S1,
+                split ? t : 0.0, split};
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb) {
+    pr.u[nb] = u[nb];
+    pr.act[nb] = act[nb];
+    pr.m[nb] = 0.0;
+    pr.J[nb] = J[nb];
+    pr.ta[nb] = a.TA + (size_t)J[nb] * LD;
+  }
+  const bool vec = true;   // (U's rows are LD = 16 n doubles apart and LD long)
+  switch (g_tiles * 2 + (vec ? 1 : 0)) {
+    case 9: tl_product<NB, 4, true, true>(pr); break;
+    case 8: tl_product<NB, 4, false, true>(pr); break;
+    case 7: tl_product<NB, 3, true, true>(pr); break;
+    case 6: tl_product<NB, 3, false, true>(pr); break;
+    case 5: tl_product<NB, 2, true, true>(pr); break;
+    case 4: tl_product<NB, 2, false, true>(pr); break;
+    case 3: tl_product<NB, 1, true, true>(pr); break;
+    case 2: tl_product<NB, 1, false, true>(pr); break;
+    default: break;
   }
 }
