@@ -168,8 +168,10 @@ if os.environ.get("FAULT_RANK") == str(rank):
     os.environ["CB_FAULT_INJECT"] = "3"      # this rank's evaluation "fails" at epoch 3 (read by the library at the call)
 try:
     r = sb.train_pande_reversible(z["u0"], z["p0"], mask=z["mask"], num_epochs=E, lr=0.1)
+    form, info = sb.bank.last_bank_form(), sb.bank.time_basis_info()
     np.savez(sys.argv[3] + f".{rank}.npz", loss=r["loss"], Q_last=r["Q_last"], Q_best=r["Q_best"], calls=np.array(calls),
-             local=np.array(sb.local_buckets))
+             local=np.array(sb.local_buckets), time_basis=int(form["time_basis"]), builds=info["builds"],
+             repeated=info["repeated_epochs"])
 except Exception as exc:
     np.savez(sys.argv[3] + f".{rank}.npz", error=str(exc), calls=np.array(calls))
 sb.close()
@@ -213,6 +215,52 @@ def test_c_driven_sharded_loop_with_two_real_ranks(tmp_path):
         calls = list(g["calls"])
         assert calls[-2 * E:] == [1, 400 * 400] * E, calls
     assert np.array_equal(got[0]["Q_last"], got[1]["Q_last"])      # identical steps on both ranks
+
+
+@pytest.mark.parametrize("growth_hook", [False, True])
+def test_two_real_ranks_each_in_its_own_time_basis(tmp_path, growth_hook):
+    """the ranks of a sharded job run THEIR buckets in a time basis of their own since round 5 (every second bucket of
+    an ascending grid is one) and nothing tested a communicator and a time basis together.  The bench bank's 129 buckets over two
+    real ranks (65 / 64, both above the 28-bucket threshold): both ranks report the time-basis form, reproduce the single-process
+    trajectory (which runs the whole bank in ONE basis: other skeletons, other sums, hence rounding) and take identical steps.
+    With CB_TB_TEST_GROWTH (a basis with no room to grow) the device-side guard fires on both ranks in the same epochs -- sigma is
+    the same everywhere --, the epochs are repeated with per-bucket products, and the collectives still pair up."""
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from conftest import load_golden, relerr
+    from cherryml_amd import CherryBank
+    import bench
+    z = load_golden("coevo_dense_traj_full.npz")
+    wl = bench.make_workload("coevo400", 0, np.random.default_rng(0))
+    t, Cm, mask = wl["t"], wl["C"], wl["mask"]
+    E = 8
+    with CherryBank(t, Cm) as bank:
+        one = bank.train_pande_reversible(z["upper_diag0"], z["log_pi0"], mask=mask, num_epochs=E, lr=0.1)
+        assert bank.last_bank_form()["time_basis"]
+    spec = tmp_path / "spec.npz"
+    np.savez(spec, t=t, C=Cm, mask=mask, u0=z["upper_diag0"], p0=z["log_pi0"], E=E)
+    script = tmp_path / "worker.py"
+    script.write_text(_INLIB_WORKER)
+    base = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "CB_TB_TEST_GROWTH")}
+    base.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29581" if growth_hook else "29580", CB_TEST_HOOKS="1")
+    if growth_hook:
+        base["CB_TB_TEST_GROWTH"] = "1.0005"
+    procs = [subprocess.Popen([sys.executable, str(script), ROOT, str(spec), str(tmp_path / "tb")],
+                              env=dict(base, RANK=str(r), WORLD_SIZE="2")) for r in range(2)]
+    assert [p.wait(timeout=900) for p in procs] == [0, 0]
+    got = [np.load(str(tmp_path / "tb") + f".{r}.npz") for r in range(2)]
+    assert "error" not in got[0].files and "error" not in got[1].files, [str(g["error"]) for g in got if "error" in g.files]
+    assert sorted(len(g["local"]) for g in got) == [64, 65]
+    for g in got:
+        assert int(g["time_basis"]) == 1 and int(g["builds"]) >= 1
+        assert (int(g["repeated"]) >= 2) if growth_hook else (int(g["repeated"]) == 0)
+        assert np.allclose(g["loss"], one["loss"], rtol=1e-10, atol=0)
+        assert relerr(g["Q_last"], one["Q_last"]) < 1e-8 and relerr(g["Q_best"], one["Q_best"]) < 1e-8
+    assert int(got[0]["repeated"]) == int(got[1]["repeated"])
+    assert np.array_equal(got[0]["Q_last"], got[1]["Q_last"]) and list(got[0]["calls"]) == list(got[1]["calls"])
+    print(f"two ranks in their own time bases ({'growth hook' if growth_hook else 'default'}): loss to the single process "
+          f"{np.max(np.abs(got[0]['loss'] - one['loss']) / np.abs(one['loss'])):.1e}, Q_last {relerr(got[0]['Q_last'], one['Q_last']):.1e}, "
+          f"repeated epochs {int(got[0]['repeated'])}")
 
 
 def test_a_failing_rank_takes_its_peer_down_after_the_same_collectives(tmp_path):

@@ -60,5 +60,7 @@ def test_time_basis_kernels(meta):
     for name, c in hits.items():
         # (the forms with 24 forward / 48 gradient skeleton slots -- wider spectral ranges than any bank so far -- hold more
         # accumulators and spill a few of them around the loop)
-        assert c["vgpr"] <= 128 and c["vgpr_spill"] <= (8 if "<16, 32>" in name else 64), (name, c)
+        # (round 6: 4 / 6 spilled with 32 gradient slots, 19 / 27 with 48 -- tb_ew<16, 48> timed at 400 states:
+        # profiles/r06_tb_ew48_timing.json)
+        assert c["vgpr"] <= 128 and c["vgpr_spill"] <= (8 if ", 32, 8" in name else 32), (name, c)
     assert any("k1_pt_loss_gt<double, double, false, 1, true>" in n for n in meta)
