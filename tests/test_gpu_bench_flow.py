@@ -252,7 +252,8 @@ def test_two_real_ranks_each_in_its_own_time_basis(tmp_path, growth_hook):
     assert "error" not in got[0].files and "error" not in got[1].files, [str(g["error"]) for g in got if "error" in g.files]
     assert sorted(len(g["local"]) for g in got) == [64, 65]
     for g in got:
-        assert int(g["time_basis"]) == 1 and int(g["builds"]) >= 1
+        # (with the hook the LAST evaluation may be a repeated one, i.e. per-bucket products: the builds say the basis was in use)
+        assert int(g["builds"]) >= (2 if growth_hook else 1) and (growth_hook or int(g["time_basis"]) == 1)
         assert (int(g["repeated"]) >= 2) if growth_hook else (int(g["repeated"]) == 0)
         assert np.allclose(g["loss"], one["loss"], rtol=1e-10, atol=0)
         assert relerr(g["Q_last"], one["Q_last"]) < 1e-8 and relerr(g["Q_best"], one["Q_best"]) < 1e-8
