@@ -56,3 +56,11 @@ python3 profiles/tools/stamp_timeline.py gpurun_out/clock_stamps_60_epochs.npy 2
 unset CB_BANK_UNFUSED
 unset CB_EXTRA_HIPCC_FLAGS
 python3 -c "from cherryml_amd import _build; _build.build()" >> gpurun_out/${TAG}_stamp_build.log 2>&1
+# round 6: SiteRM SQ counters (three passes) and the eigensolver's launch-by-launch timeline without a tracer (diagnostic build)
+cd $R && bash profiles/tools/r6_sq_counters_sp_bank.sh > gpurun_out/${TAG}_r6sq.log 2>&1
+export CB_EXTRA_HIPCC_FLAGS=-DCB_EIGH_STAMPS
+python3 -c "from cherryml_amd import _build; _build.build()" > gpurun_out/${TAG}_eigh_stamp_build.log 2>&1
+CB_DEBUG=1 python3 bench.py --steps 20 --warmup 5 --no-secondary --no-cpu-baseline 2> gpurun_out/${TAG}_eigh_stamps_window.txt > /dev/null < /dev/null
+unset CB_EXTRA_HIPCC_FLAGS
+python3 -c "from cherryml_amd import _build; _build.build()" >> gpurun_out/${TAG}_eigh_stamp_build.log 2>&1
+python3 profiles/tools/r6_phase_event_cost.py > gpurun_out/${TAG}_phase_event_cost.json 2> /dev/null < /dev/null

@@ -25,7 +25,7 @@ def newest(pattern):
 
 
 tag = sys.argv[1] if len(sys.argv) > 1 else "final"
-rnd = sys.argv[2] if len(sys.argv) > 2 else "r05"
+rnd = sys.argv[2] if len(sys.argv) > 2 else "r06"
 here = os.path.dirname(os.path.abspath(__file__))
 root = os.path.dirname(here)
 import datetime
