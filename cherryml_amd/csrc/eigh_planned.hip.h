@@ -6,12 +6,12 @@
 // previous epoch's solve -- in which every kernel reads the control block and does what the state needs:
 //
 //   slot s  (a "rotation sweep"):  lge_gram   Gamma = G^T G straight from the column-major G (both operands k-contiguous, 32-byte
-//                                             loads), X / Xf, the sweep statistics, and -- its last workgroup -- the DECISION:
-//                                             all pairs or far pairs only, polynomial order, scaling, squarings, "this is the
-//                                             final sweep"
+//                                             loads), X / Xf and the sweep statistics; the launch behind it takes the DECISION
+//                                             (lge_decide_here): all pairs or far pairs only, polynomial order, scaling,
+//                                             squarings, "this is the final sweep"
 //                                  lge_gemm   the powers of X, the Paterson-Stockmeyer steps, the squarings and G <- G R, each
 //                                             predicated on the decision (a launch that is not needed returns at once)
-//                                  lge_poly   the polynomial coefficients B0, B1, B2 (elementwise)
+//                                  lge_p34    X^3, X^4 and the polynomial coefficients B0, B1, B2
 //   band pass after slot s:        lgj_round  banded Jacobi rounds (jacobi_block.hip.h), run when the sweep was a masked one
 //   lge_norms / lge_finish:        norms, sorting, U / lambda -- or, when the plan ran out before convergence, the STALL word:
 //                                  the host then repeats this solve with the host-driven loop (the only host intervention, rare)
@@ -70,6 +70,15 @@ __device__ __forceinline__ void lge_stamp(unsigned long long *ctl, int id) {
 #define LGE_STAMP(ctl, id) ((void)0)
 #endif
 #define EC_NONE 0xFFFFFFFFull
+// Control words are read through the CONSTANT address space: all the words a kernel tests come in one batch of scalar loads.
+// As plain loads the compiler follows the short-circuit order of the tests -- one dependent round trip per word, ~0.7 us each
+// behind a kernel boundary (round 6: 28 us per solve).  A kernel that also writes the block does so after its own reads, in one
+// thread; a workgroup that starts late and sees the new words reads the same decision or words it does not use.
+#ifdef CB_PLAIN_WORDS
+typedef const unsigned long long *lge_const_words;
+#else
+typedef const __attribute__((address_space(4))) unsigned long long *lge_const_words;
+#endif
 
 struct GramArgs {
   int LD, band, slot;
@@ -79,9 +88,38 @@ struct GramArgs {
   double *X, *Xf;
   double *Gm, *dg;   // slots with the second-order launch: Gamma itself and its diagonal (as X was built from it)
   int so;            // the slot has the second-order launch (lge_so)
-  double *part;      // [2][LD/16][LD] row-sum partials, then [(LD/16)^2] cosine partials
+  unsigned long long *acc;   // the sweep's statistics: LGE_ACC_WORDS words (see lge_fix)
   unsigned long long *ctl;
   double trigger;
+};
+
+// The statistics a sweep's decision needs -- max_i sum_j |x_ij| over all pairs and over far pairs (|X|_2 <= |X|_inf for an
+// antisymmetric X), the largest squared cosine -- without a launch to reduce them (rounds 4-5: lge_decide, one workgroup
+// reading 400 x 25 partial row sums, 6.2 us per sweep).  Each of lge_gram's workgroups adds the LARGEST row sum of its tile
+// to the word of its block row: B_I = sum_J max_{i in I} sum_{j in J} |x_ij| >= every row sum of block row I, so max_I B_I
+// bounds |X|_inf from above (1.0 - 1.3x on the recorded trajectory) and every rule below holds a fortiori.  (|X|_F was tried:
+// cheaper still -- three words -- but for a dense generator the final-sweep rule c |X|^2 <= 2e-14 needs the row sums, which
+// are up to sqrt(n) |X|_F: tests/test_gpu_long_horizon.py lost a digit at 64 states.)  The sums are in FIXED POINT (units of
+// 2^-52; integer sums commute, so the result does not depend on the order the tiles arrive in and a solve stays reproducible
+// bit for bit), the cosine as the bits of a non-negative double under an integer maximum, spread over four lines.  No arrival
+// counter, no fence: the kernel boundary publishes them, and the FIRST launch behind lge_gram (lge_so, or lge_gemm<EG_P2> in
+// a slot without it) takes the decision itself in every wave -- one 8-byte load per lane next to its control words, five
+// shuffle steps, ~40 vector instructions (a vector instruction executed by all 24 waves of a CU costs a launch 10 ns: the same
+// decision from 400 exact row sums, ~300 instructions and two barriers, cost 3 us per launch -- as much as the launch it
+// replaced); its workgroup 0 also leaves the decision in the control block for the launches that follow.
+#define LGE_ACC_NT 32                                 // block rows a set has room for (LD <= 512)
+#define LGE_ACC_COS 64                                // [0, 32): B_I all pairs, [32, 64): far pairs, [64 + 16 k]: cosine bits, k < 4
+#define LGE_ACC_WORDS 128
+#define LGE_ACC_UNIT 4503599627370496.0               // 2^52: a row sum is below 2^9
+__device__ __forceinline__ unsigned long long lge_fix(double x) {   // x >= 0 (a tile's share: at most 16 x pi / 4)
+  return x > 0.0 ? (unsigned long long)(fmin(x, 16.0) * LGE_ACC_UNIT) + 1ull : 0ull;
+}
+
+struct DecArgs {
+  int on = 0;        // this launch takes the sweep's decision
+  int cap = 0, nsq = 0, so = 0;
+  double trigger = 0.0;
+  const unsigned long long *acc = nullptr;
 };
 
 __device__ __forceinline__ double lge_lim(int order) {
@@ -97,10 +135,14 @@ __global__ __launch_bounds__(512, 6) void lge_gram(GramArgs a) {   // 6 waves pe
   __shared__ double sRed[8][256];
   __shared__ double sDg[2][32][16];
   __shared__ double sD[2][16];
-  __shared__ double sStat[1][8];
+  __shared__ double sStat[3][4];
   const unsigned long long *ctl = a.ctl;
   LGE_STAMP(ctl, 4);
-  if (ctl[EC_STALL] != 0ull || (unsigned long long)a.slot > ctl[EC_FINAL]) return;
+  {
+    lge_const_words cw = (lge_const_words)ctl;
+    const unsigned long long w_stall = cw[EC_STALL], w_final = cw[EC_FINAL];
+    if (w_stall != 0ull || (unsigned long long)a.slot > w_final) return;
+  }
   const int LD = a.LD, nt = LD / 16;
   const int tm = blockIdx.x / nt, tn = blockIdx.x - tm * nt;
   const int m0 = tm * 16, n0 = tn * 16;
@@ -153,7 +195,7 @@ __global__ __launch_bounds__(512, 6) void lge_gram(GramArgs a) {   // 6 waves pe
     sD[w][c] = (s0 + s1) + (s2 + s3);
   }
   __syncthreads();
-  double mc2 = 0.0, rs = 0.0, rsf = 0.0;
+  double mc2 = 0.0;
   if (threadIdx.x < 256) {
     const int t = threadIdx.x, r = t >> 6, l = t & 63;
     const int ri = (l >> 4) + 4 * r, ci = l & 15;
@@ -174,7 +216,6 @@ __global__ __launch_bounds__(512, 6) void lge_gram(GramArgs a) {   // 6 waves pe
       // all-pairs limit and into a masked sweep that has no band pass planned behind it (a stalled solve), and exp(X) rotates
       // it by exactly its Jacobi angle.  (atan and fast_rcp are odd: X stays exactly antisymmetric.)
       x = d != 0.0 ? 0.5 * atan(2.0 * g * fast_rcp(d)) : (g > 0.0 ? 0.78539816339744831 : -0.78539816339744831);
-      rs = fabs(x);
     }
     const int bd = row / JB_W - col / JB_W;
     const bool far = bd > a.band || -bd > a.band;
@@ -184,126 +225,179 @@ __global__ __launch_bounds__(512, 6) void lge_gram(GramArgs a) {   // 6 waves pe
       a.Gm[(size_t)row * LD + col] = g;
       if (row == col) a.dg[row] = gii;
     }
-    rsf = far ? rs : 0.0;
-    // row sums over this tile's 16 columns (lanes with equal l >> 4)
+    double rs = fabs(x), rsf = far ? fabs(x) : 0.0;
+    // row sums over this tile's 16 columns (lanes with equal l >> 4), then the largest over the four rows of the wave
 #pragma unroll
     for (int m = 1; m < 16; m <<= 1) {
       rs += __shfl_xor(rs, m);
       rsf += __shfl_xor(rsf, m);
+      mc2 = fmax(mc2, __shfl_xor(mc2, m));
     }
-    if (ci == 0) {
-      a.part[(size_t)tn * LD + row] = rs;
-      a.part[(size_t)(nt + tn) * LD + row] = rsf;
+#pragma unroll
+    for (int m = 16; m < 64; m <<= 1) {
+      rs = fmax(rs, __shfl_xor(rs, m));
+      rsf = fmax(rsf, __shfl_xor(rsf, m));
+      mc2 = fmax(mc2, __shfl_xor(mc2, m));
     }
-    mc2 = wave_max(mc2);
-    if (l == 0) sStat[0][r] = mc2;
+    if (l == 0) {
+      sStat[0][r] = rs;
+      sStat[1][r] = rsf;
+      sStat[2][r] = mc2;
+    }
   }
   __syncthreads();
-  if (threadIdx.x == 0)
-    a.part[(size_t)2 * nt * LD + blockIdx.x] = fmax(fmax(sStat[0][0], sStat[0][1]), fmax(sStat[0][2], sStat[0][3]));
+  if (threadIdx.x < 3) {   // (one statistic per thread)
+    const int k = threadIdx.x;
+    const double v = fmax(fmax(sStat[k][0], sStat[k][1]), fmax(sStat[k][2], sStat[k][3]));
+    if (k < 2) atomicAdd(a.acc + k * LGE_ACC_NT + tm, lge_fix(v));
+    else atomicMax(a.acc + LGE_ACC_COS + 16 * (blockIdx.x & 3), dbl_bits(v));
+  }
 }
 
-// The statistics of the sweep from lge_gram's partials (fixed order) and the DECISION, one workgroup.  A launch of its own:
-// as the last-arriving workgroup of lge_gram it needed 625 arrivals on one device-scope counter and a release fence in every
-// workgroup -- 34 us for the pair against 10 + 5 for two launches.
-__global__ __launch_bounds__(512) void lge_decide(GramArgs a) {
-  __shared__ double sStat[3][8];
-  unsigned long long *ctl = a.ctl;
-  LGE_STAMP(ctl, 5);
-  if (ctl[EC_STALL] != 0ull || (unsigned long long)a.slot > ctl[EC_FINAL]) return;
-  const int LD = a.LD, nt = LD / 16;
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const double *pp = a.part;
-  double m0s = 0.0, m1s = 0.0, m2s = 0.0;
-  for (int i = threadIdx.x; i < LD; i += 512) {
-    double s1 = 0.0, s2 = 0.0;
-    int t = 0;
-    for (; t + 5 <= nt; t += 5) {
-      double u[5], v[5];
+// The DECISION of a sweep from lge_gram's statistics, taken by every wave of the first launch behind it (no LDS, no barrier:
+// lane I holds B_I, lane 32 + I the far-pair B_I).  Workgroup 0 publishes it -- control words and the solve's record -- for the
+// launches that follow.  The caller requests the statistics (lge_acc_request) together with its control words: one memory round
+// trip for both.
+struct LgeDecision {
+  unsigned long long mode, sq, sc_bits;
+};
+struct LgeAcc {
+  unsigned long long w = 0ull, c2 = 0ull;
+};
+__device__ __forceinline__ LgeAcc lge_acc_request(const DecArgs &d) {
+  LgeAcc q;
+  if (d.on) {
+    q.w = d.acc[threadIdx.x & 63];
+    lge_const_words ar = (lge_const_words)d.acc;
 #pragma unroll
-      for (int q = 0; q < 5; ++q) {
-        u[q] = pp[(size_t)(t + q) * LD + i];
-        v[q] = pp[(size_t)(nt + t + q) * LD + i];
-      }
+    for (int i = 0; i < 4; ++i) {
+      const unsigned long long c = ar[LGE_ACC_COS + 16 * i];
+      q.c2 = c > q.c2 ? c : q.c2;
+    }
+  }
+  return q;
+}
+__device__ __forceinline__ double lge_uniform(double v, int lane) {
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), lane), __builtin_amdgcn_readlane(__double2loint(v), lane));
+}
+__device__ __forceinline__ LgeDecision lge_decide_here(int slot, const DecArgs &d, const LgeAcc &q, unsigned long long *ctl,
+                                                       unsigned long long nsweep) {
+  double v = (double)q.w * (1.0 / LGE_ACC_UNIT);
 #pragma unroll
-      for (int q = 0; q < 5; ++q) {
-        s1 += u[q];
-        s2 += v[q];
-      }
-    }
-    for (; t < nt; ++t) {
-      s1 += pp[(size_t)t * LD + i];
-      s2 += pp[(size_t)(nt + t) * LD + i];
-    }
-    m1s = fmax(m1s, s1);
-    m2s = fmax(m2s, s2);
-    if (!(s1 == s1)) m0s = INFINITY;
-  }
-  for (int i = threadIdx.x; i < nt * nt; i += 512) m0s = fmax(m0s, pp[(size_t)2 * nt * LD + i]);
-  m0s = wave_max(m0s);
-  m1s = wave_max(m1s);
-  m2s = wave_max(m2s);
-  if (lane == 0) {
-    sStat[0][wave] = m0s;
-    sStat[1][wave] = m1s;
-    sStat[2][wave] = m2s;
-  }
-  __syncthreads();
-  if (threadIdx.x != 0) return;
-  double c2 = 0.0, rowsum = 0.0, rowsum_far = 0.0;
-  for (int w = 0; w < 8; ++w) {
-    c2 = fmax(c2, sStat[0][w]);
-    rowsum = fmax(rowsum, sStat[1][w]);
-    rowsum_far = fmax(rowsum_far, sStat[2][w]);
-  }
-  const double cosmax = sqrt(c2);
-  const unsigned long long k = ctl[EC_NSWEEP];
-  ctl[EC_NSWEEP] = k + 1;
-  unsigned long long mode = 0ull, sq = 0ull;
-  double sc = 1.0;
-  if (!(cosmax == cosmax) || !(rowsum == rowsum) || cosmax > 1e300 || rowsum > 1e300) {
-    ctl[EC_ERR] = 2ull;
-    ctl[EC_STALL] = 1ull;
-    ctl[EC_MASKED] = 0ull;
-  } else {
+  for (int m = 1; m < 32; m <<= 1) v = fmax(v, __shfl_xor(v, m));
+  const double rowsum = lge_uniform(v, 0), rowsum_far = lge_uniform(v, 32);
+  double c2;
+  memcpy(&c2, &q.c2, 8);
+  LgeDecision o{0ull, 0ull, 0x3FF0000000000000ull};
+  const bool bad = q.c2 >= 0x7FF0000000000000ull;   // (lge_gram stores +inf for a NaN)
+  bool masked = false, fin = false;
+  if (!bad) {
     // all pairs at once only when the state is close enough for the small-angle limit to hold for the near-degenerate
     // neighbours too (the rule of eigh_large_host.hip.h)
     // (row sums of Jacobi ANGLES: one near-degenerate pair contributes at most pi / 4, so the all-pairs limit is 1 -- a row
     // with two large angles, i.e. a cluster, is still sent to the band passes)
-    const bool masked = cosmax > a.trigger || rowsum > 1.0;
+    masked = c2 > d.trigger * d.trigger || rowsum > 1.0;
     const double rsu = masked ? rowsum_far : rowsum;
     // second-order generator (lge_so): the sweep then converges cubically -- it ends at ~ c |X|^2 instead of ~ c |X| --,
     // so it is the last one already when c |X|^2 <= 2e-14 (what a first-order sweep from 1e-8 leaves at worst)
-    const bool so = a.so != 0 && !masked && cosmax > 1e-8;
-    if (!masked && (cosmax <= 1e-8 || (so && cosmax * rowsum * rowsum <= 2e-14)))
-      ctl[EC_FINAL] = (unsigned long long)a.slot;   // starts below 1e-8: ends at rounding level
+    // (and only below |X| = 0.3: the correction is worth a launch when the sweep is about to converge, and its own size is
+    // O(|X|^2) only there -- the order and the squarings below are chosen from X1's norm)
+    const bool so = d.so != 0 && !masked && c2 > 1e-16 && rowsum <= 0.3;
+    const double r2 = rowsum * rowsum;
+    fin = !masked && (c2 <= 1e-16 || (so && c2 * r2 * r2 <= 4e-28));   // starts below 1e-8: ends at rounding level
     int order = rsu <= lge_lim(2) ? 2 : rsu <= lge_lim(4) ? 4 : rsu <= lge_lim(8) ? 8 : 12;
-    if (order > a.cap) order = a.cap;
+    if (order > d.cap) order = d.cap;
     const double lim = lge_lim(order);
+    double sc = 1.0;
     while (rsu * sc > lim) {
       sc *= 0.5;
-      ++sq;
+      ++o.sq;
     }
     unsigned long long damped = 0ull;
-    if (sq > (unsigned long long)a.nsq) {   // the slot cannot square that often: a partial (still orthogonal) rotation
-      sq = (unsigned long long)a.nsq;
+    if (o.sq > (unsigned long long)d.nsq) {   // the slot cannot square that often: a partial (still orthogonal) rotation
+      o.sq = (unsigned long long)d.nsq;
       sc = lim / rsu;
       damped = 1ull;
     }
-    mode = (unsigned long long)order | (masked ? 256ull : 0ull) | (damped << 9) | (so ? 1024ull : 0ull) | (1ull << 16);
-    ctl[EC_MASKED] = masked ? 1ull : 0ull;
+    o.sc_bits = dbl_bits(sc);
+    o.mode = (unsigned long long)order | (masked ? 256ull : 0ull) | (damped << 9) | (so ? 1024ull : 0ull) | (1ull << 16);
   }
-  ctl[EC_MODE] = mode;
-  ctl[EC_SQ] = sq;
-  ctl[EC_SC] = dbl_bits(sc);
-  if (k < EC_MAXREC) {
-    ctl[EC_TSWEEP + k] = __builtin_amdgcn_s_memrealtime();
-    ctl[EC_REC + 4 * k + 0] = dbl_bits(cosmax);
-    ctl[EC_REC + 4 * k + 1] = dbl_bits(rowsum);
-    ctl[EC_REC + 4 * k + 2] = dbl_bits(rowsum_far);
-    ctl[EC_REC + 4 * k + 3] = mode | (sq << 24) | ((unsigned long long)a.slot << 32);
+  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
+    const unsigned long long k = nsweep;
+    ctl[EC_NSWEEP] = k + 1;
+    if (bad) {
+      ctl[EC_ERR] = 2ull;
+      ctl[EC_STALL] = 1ull;
+    }
+    if (fin) ctl[EC_FINAL] = (unsigned long long)slot;
+    ctl[EC_MASKED] = masked ? 1ull : 0ull;
+    ctl[EC_MODE] = o.mode;
+    ctl[EC_SQ] = o.sq;
+    ctl[EC_SC] = o.sc_bits;
+    if (k < EC_MAXREC) {
+      ctl[EC_TSWEEP + k] = __builtin_amdgcn_s_memrealtime();
+      ctl[EC_REC + 4 * k + 0] = dbl_bits(sqrt(c2));
+      ctl[EC_REC + 4 * k + 1] = dbl_bits(rowsum);
+      ctl[EC_REC + 4 * k + 2] = dbl_bits(rowsum_far);
+      ctl[EC_REC + 4 * k + 3] = o.mode | (o.sq << 24) | ((unsigned long long)slot << 32);
+    }
+  }
+  return o;
+}
+
+#ifdef CB_DECIDE_KERNEL   // (experiment: the decision as a launch of its own again -- one wave, the same function)
+__global__ void lge_decide_k(int slot, DecArgs d, unsigned long long *ctl) {
+  const LgeAcc q = lge_acc_request(d);
+  lge_const_words cw = (lge_const_words)ctl;
+  const unsigned long long w_stall = cw[EC_STALL], w_final = cw[EC_FINAL], w_nsw = cw[EC_NSWEEP];
+  if (w_stall != 0ull || (unsigned long long)slot > w_final) return;
+  (void)lge_decide_here(slot, d, q, ctl, w_nsw);
+}
+#endif
+
+#ifdef CB_NANCHECK
+// (debugging aid: max_k |A u_k - lambda_k u_k|_inf of the decomposition a solve left, as double bits under an integer maximum in word 92)
+__global__ void lge_residual(int LD, const double *A, const double *Ut, const double *lam, unsigned long long *ctl) {
+  const int k = blockIdx.x;
+  double m = 0.0;
+  for (int i = threadIdx.x; i < LD; i += blockDim.x) {
+    double r = -lam[k] * Ut[(size_t)k * LD + i];
+    for (int j = 0; j < LD; ++j) r = fma(A[(size_t)i * LD + j], Ut[(size_t)k * LD + j], r);
+    m = fmax(m, fabs(r));
+    if (!(r == r)) m = INFINITY;
+  }
+  m = wave_max(m);
+  if ((threadIdx.x & 63) == 0) atomicMax(ctl + 92, dbl_bits(m));
+}
+#endif
+#ifdef CB_NANCHECK
+// (debugging aid: |R^T R - I|_max of a sweep's rotation; the largest value of the solve and its slot in words 91 / 90)
+__global__ void lge_orthcheck(int LD, const double *R, unsigned long long slot, unsigned long long *ctl) {
+  lge_const_words cw = (lge_const_words)ctl;
+  if (cw[EC_STALL] != 0ull || slot > cw[EC_FINAL] || !(cw[EC_MODE] >> 16)) return;
+  const int k = blockIdx.x;
+  double m = 0.0;
+  for (int j = threadIdx.x; j < LD; j += blockDim.x) {
+    double d = j == k ? -1.0 : 0.0;
+    for (int i = 0; i < LD; ++i) d = fma(R[(size_t)i * LD + k], R[(size_t)i * LD + j], d);
+    m = fmax(m, fabs(d));
+    if (!(d == d)) m = INFINITY;
+  }
+  m = wave_max(m);
+  if ((threadIdx.x & 63) == 0) {
+    const unsigned long long old = atomicMax(ctl + 91, dbl_bits(m));
+    if (dbl_bits(m) > old) ctl[90] = slot;
   }
 }
+#endif
+#ifdef CB_NANCHECK   // (debugging aid: the first buffer of a solve that holds a non-finite entry, as slot * 100 + tag in word 94)
+__global__ void lge_nancheck(int LD, const double *buf, unsigned long long tag, unsigned long long *ctl) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)LD * LD) return;
+  const double v = buf[i];
+  if (!(v - v == 0.0)) atomicCAS(ctl + 94, 0ull, tag);
+}
+#endif
 
 // what a launch of lge_gemm is (the control block decides whether it runs and on which operands)
 enum { EG_P2 = 0, EG_P34, EG_T1, EG_RP, EG_SQ, EG_GR, EG_R4 };
@@ -323,6 +417,8 @@ struct EgArgs {
   double *Rfin;                      // the rotation of the sweep (whichever launch completes it writes it HERE: EG_GR's operand is static)
   const double *Gin;                 // EG_GR
   double *Gout;
+  DecArgs dec;                       // EG_P2 of a slot without lge_so: the first launch behind lge_gram takes the decision
+  unsigned long long *zacc;          // EG_GR: the statistics lines of this slot, cleared for the slot after next
 };
 
 // The polynomial coefficients of exp(Y), Y = s X, from X, P2 = -X^2, P3 = X^3, P4 = X^4 (elementwise):
@@ -401,9 +497,24 @@ __global__ __launch_bounds__(512) void lge_gemm(EgArgs a) {
   }
   // ---- the decision: five words of one cache line, requested BEHIND the early operand loads (scalar loads return out of order:
   // a wait for the kernel's own arguments would be a wait for every scalar load issued before it)
-  const unsigned long long w_stall = ctl[EC_STALL], w_final = ctl[EC_FINAL], mode = ctl[EC_MODE], w_sq = ctl[EC_SQ], w_sc = ctl[EC_SC];
+  LgeAcc accq;
+  if (KIND == EG_P2) accq = lge_acc_request(a.dec);
+  // (through the constant address space: ONE batch of scalar loads.  The deciding launch also writes the control block -- its
+  // workgroup 0, after this point; a workgroup that starts late and sees the new words reads the same decision or words it
+  // does not use -- and as plain global loads the compiler makes three dependent round trips of the tests below: 1.9 us)
+  lge_const_words cw = (lge_const_words)ctl;
+  const unsigned long long w_stall = cw[EC_STALL], w_final = cw[EC_FINAL], w_nsw = cw[EC_NSWEEP];
+  unsigned long long mode = cw[EC_MODE], w_sq = cw[EC_SQ], w_sc = cw[EC_SC];
   if (w_stall != 0ull || (unsigned long long)a.slot > w_final) return;
+  if (KIND == EG_P2 && a.dec.on) {
+    const LgeDecision dd = lge_decide_here(a.slot, a.dec, accq, const_cast<unsigned long long *>(ctl), w_nsw);
+    mode = dd.mode;
+    w_sq = dd.sq;
+    w_sc = dd.sc_bits;
+  }
   if (!(mode >> 16)) return;
+  if (KIND == EG_GR && a.zacc && blockIdx.x == 0 && threadIdx.x < LGE_ACC_WORDS)   // (every reader of this slot's statistics has finished)
+    a.zacc[threadIdx.x] = 0ull;
   const int order = (int)(mode & 255ull);
   const bool masked = (mode & (256ull | 1024ull)) != 0ull;   // far pairs only, OR the second-order generator: both live in Xf
   const int sq = (int)w_sq;
@@ -507,7 +618,8 @@ __global__ __launch_bounds__(512) void lge_p34(EgArgs a) {
     }
     if (ep) e2 = a.P2[idx];
   }
-  const unsigned long long w_stall = ctl[EC_STALL], w_final = ctl[EC_FINAL], mode = ctl[EC_MODE], w_sc = ctl[EC_SC];
+  lge_const_words cw = (lge_const_words)ctl;
+  const unsigned long long w_stall = cw[EC_STALL], w_final = cw[EC_FINAL], mode = cw[EC_MODE], w_sc = cw[EC_SC];
   if (w_stall != 0ull || (unsigned long long)a.slot > w_final) return;
   if (!(mode >> 16)) return;
   const int order = (int)(mode & 255ull);
@@ -586,6 +698,7 @@ struct SoArgs {
   const double *Gm, *dg, *X;
   double *Xs;   // = Xf
   int early;    // the plan expects the launch to run: its first operands are requested before the control block is looked at
+  DecArgs dec;  // the first launch behind lge_gram: takes the sweep's decision
 };
 
 __global__ __launch_bounds__(512) void lge_so(SoArgs a) {
@@ -614,8 +727,12 @@ __global__ __launch_bounds__(512) void lge_so(SoArgs a) {
   };
   if (a.early) issue(wave);
   // (the control words are requested BEHIND the early loads: see lge_gemm)
-  const unsigned long long w_stall = ctl[EC_STALL], w_final = ctl[EC_FINAL], w_mode = ctl[EC_MODE];
+  const LgeAcc accq = lge_acc_request(a.dec);
+  lge_const_words cw = (lge_const_words)ctl;   // (one batch of scalar loads: see lge_gemm)
+  const unsigned long long w_stall = cw[EC_STALL], w_final = cw[EC_FINAL], w_nsw = cw[EC_NSWEEP];
+  unsigned long long w_mode = cw[EC_MODE];
   if (w_stall != 0ull || (unsigned long long)a.slot > w_final) return;
+  if (a.dec.on) w_mode = lge_decide_here(a.slot, a.dec, accq, const_cast<unsigned long long *>(ctl), w_nsw).mode;
   if (!(w_mode & 1024ull)) return;
   for (int s0 = wave; s0 < nsteps; s0 += 7 * 8) {   // seven k-steps of this wave in flight
     if (!(a.early && s0 == wave)) issue(s0);
@@ -650,14 +767,27 @@ __global__ __launch_bounds__(512) void lge_so(SoArgs a) {
   const double x1v = a.X[idx];
   const double d = a.dg[col] - a.dg[row];
   // (pairs lge_gram left alone -- orthogonal to rounding, or exactly degenerate -- stay as they are)
-  const double x2v = (row != col && x1v != 0.0 && d != 0.0) ? 0.5 * v * fast_rcp(d) : 0.0;
-  a.Xs[idx] = x1v + x2v;
+  // The pair's angle with the second-order coupling in it: x1 = atan(2 g / d) / 2 (lge_gram), so X1 + X2 in the small-angle limit
+  // is (g + v / 2) / d -- taken through the SAME bounded form, atan(2 (g + v / 2) / d) / 2.  The plain sum x1 + v / (2 d) has no
+  // bound: a near-degenerate pair (d -> 0) coupled through third columns got angles of several radians, four times the norm the
+  // sweep's polynomial order was chosen for, and left a rotation 1e-6 from orthogonal (tests/test_gpu_s400_full.py, config 5 in
+  // mixed precision, epoch 92 -- found in round 6; the debug build -DCB_NANCHECK prints |R^T R - I| of every sweep).
+  // (g = Gamma_mn comes from the tile already in registers' reach: E = Gamma off the diagonal; atan and fast_rcp are odd and
+  // v is symmetric: X stays exactly antisymmetric)
+  double xs = x1v;
+  if (row != col && x1v != 0.0 && d != 0.0) xs = 0.5 * atan(2.0 * (a.Gm[idx] + 0.5 * v) * fast_rcp(d));
+  a.Xs[idx] = xs;
 }
 
 // Solve prologue: sigma = max |A_ii| and a clean control block (one launch, first kernel of the solve).
-__global__ void lge_begin(int LD, const double *A, double *sigma, unsigned long long *ctl) {
+__global__ void lge_begin(int LD, const double *A, double *sigma, unsigned long long *ctl, unsigned long long *acc) {
   __shared__ double s[256];
+  if (threadIdx.x < 2 * LGE_ACC_WORDS) acc[threadIdx.x] = 0ull;   // both sets of statistics lines
+#ifdef CB_NANCHECK
+  if (threadIdx.x < EC_WORDS && threadIdx.x != 92)
+#else
   if (threadIdx.x < EC_WORDS)
+#endif
     ctl[threadIdx.x] = threadIdx.x == EC_FINAL ? EC_NONE : threadIdx.x == EC_T0 ? (unsigned long long)__builtin_amdgcn_s_memrealtime() : 0ull;
   double m = 0.0;
   for (int i = threadIdx.x; i < LD; i += 256) m = fmax(m, fabs(A[(size_t)i * LD + i]));
@@ -688,8 +818,9 @@ __global__ void lge_resume(unsigned long long *ctl) {
 __global__ void lge_norms(int LD, const double *G0, const double *G1, double *nrm, unsigned long long *ctl,
                           volatile unsigned long long *pin, unsigned long long seq, const double *sigma, double tb_rho_max) {
   LGE_STAMP(ctl, 20);
-  const unsigned long long fin = ctl[EC_FINAL];
-  const bool stall = ctl[EC_STALL] != 0ull || fin == EC_NONE;
+  lge_const_words cw = (lge_const_words)ctl;
+  const unsigned long long fin = cw[EC_FINAL], w_stall = cw[EC_STALL];
+  const bool stall = w_stall != 0ull || fin == EC_NONE;
   const bool stale = tb_rho_max > 0.0 && !(2.0 * (*sigma) <= tb_rho_max);
   if (blockIdx.x == 0) {   // (blockDim.x == 256)
     if (pin && threadIdx.x < EC_WORDS) {
@@ -697,6 +828,9 @@ __global__ void lge_norms(int LD, const double *G0, const double *G1, double *nr
       pin[i] = i == EC_STALL ? (stall ? 1ull : 0ull) : i == EC_TBSTALE ? (stale ? 1ull : 0ull) : i == EC_SKIP ? ((stall || stale) ? 1ull : 0ull) :
                i == EC_TEND ? (unsigned long long)__builtin_amdgcn_s_memrealtime() : ctl[i];
       __threadfence_system();
+#ifdef CB_NANCHECK
+      if (i == 92) ctl[92] = 0ull;
+#endif
     }
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -747,8 +881,10 @@ __device__ __forceinline__ void tb_table_column(const TbTableArgs &t, int LD, in
 // lgj_finish on the buffer of the final sweep; leaves U / lambda alone after a stall
 __global__ void lge_finish(int LD, const double *G0, const double *G1, const double *nrm, const double *sigma, double *lam,
                            double *U, double *Ut, const unsigned long long *ctl, TbTableArgs tb) {
-  if (ctl[EC_STALL] != 0ull) return;
-  const double *Gc = ((ctl[EC_FINAL] + 1) & 1ull) ? G1 : G0;
+  lge_const_words cw = (lge_const_words)ctl;
+  const unsigned long long w_stall = cw[EC_STALL], w_final = cw[EC_FINAL];
+  if (w_stall != 0ull) return;
+  const double *Gc = ((w_final + 1) & 1ull) ? G1 : G0;
   const int k = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   if (k >= LD) return;

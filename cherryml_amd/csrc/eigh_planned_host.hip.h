@@ -70,7 +70,7 @@ static void eigh_plan_from_record(const EighRecord &r, const EighPlan &prev, Eig
     }
     // a band pass behind the sweep when it is expected to be a masked one (near the rule's thresholds counts)
     q.band_after = (s.masked || s.c > 2e-4 || s.rs > 0.3) ? 1 : 0;
-    q.so = s.masked ? 0 : 1;
+    q.so = (i >= 1 && !s.masked) ? 1 : 0;   // (never in the first sweep: profiles/tools/r6_eigh_proto.py, and the default plan)
     q.expect_run = 1;
     q.expect_order = std::min(s.order, q.cap);
     q.expect_sq = s.sq;
@@ -93,13 +93,14 @@ static bool eigh_planned_setup(cb_bank *h) {
   // a failed attempt is not repeated: what it did allocate stays with the handle (freed with it), and a second attempt
   // would allocate everything again -- the pinned block without anyone left to free the first one
   if (h->planned_unavailable) return false;
+  if (h->LD / 16 > LGE_ACC_NT) return false;   // (the statistics lines have room for 32 block rows: beyond, the host-driven solver)
   h->planned_unavailable = true;   // (cleared at the end)
-  const int LD = h->LD, nt = LD / 16;
+  const int LD = h->LD;
   void *q = nullptr;
   if (hipMalloc(&q, EC_WORDS * sizeof(unsigned long long)) != hipSuccess) return false;
   h->allocs.push_back(q);
   unsigned long long *ctl = static_cast<unsigned long long *>(q);
-  if (hipMalloc(&q, ((size_t)2 * nt * LD + (size_t)nt * nt + 8 + LD) * sizeof(double)) != hipSuccess) return false;
+  if (hipMalloc(&q, ((size_t)2 * LGE_ACC_WORDS + LD) * sizeof(double)) != hipSuccess) return false;   // statistics lines, Gamma's diagonal
   h->allocs.push_back(q);
   h->epart = static_cast<double *>(q);
   if (!h->epin) {
@@ -123,11 +124,17 @@ static bool eigh_planned_setup(cb_bank *h) {
 // Enqueue one warm solve (h->U / h->Vc hold the previous eigenvectors, h->A the new matrix).  `seq` is what lge_norms
 // leaves in the record's sequence word.  first_slot > 0: the CONTINUATION of a stalled solve -- its G buffers hold a valid,
 // partly converged state (every rotation applied so far was orthogonal), so the new slots simply carry on from it.
+#ifdef CB_NANCHECK
+#define NANCHECK(buf, tag) hipLaunchKernelGGL(lge_nancheck, dim3((unsigned)((LL + 255) / 256)), dim3(256), 0, h->stream, LD, buf, (unsigned long long)(tag), ctl)
+#else
+#define NANCHECK(buf, tag) ((void)0)
+#endif
 static int enqueue_planned_solve(cb_bank *h, const EighPlan &p, unsigned long long seq, int first_slot = 0, double tb_rho_max = 0.0,
                                  const TbTableArgs &tbt = TbTableArgs{}) {
   const int LD = h->LD, nt = LD / 16, nb = LD / JB_W;
   const size_t LL = (size_t)LD * LD;
   unsigned long long *ctl = h->ectl;
+  unsigned long long *eacc = reinterpret_cast<unsigned long long *>(h->epart);   // two sets of statistics lines (slot parity)
   double *Gb[2] = {h->Gc, h->Gc2};
   double *X = h->gx, *Xf = h->gx + LL, *P2 = h->gx + 2 * LL, *P3 = h->gx + 3 * LL, *P4 = h->gx + 4 * LL, *B0 = h->gx + 5 * LL,
          *B1 = h->gx + 6 * LL, *B2 = h->gx + 7 * LL, *T = h->gx + 8 * LL, *R0 = h->gx + 9 * LL, *R0t = h->gx + 10 * LL,
@@ -139,7 +146,9 @@ static int enqueue_planned_solve(cb_bank *h, const EighPlan &p, unsigned long lo
   if (first_slot > 0) {
     hipLaunchKernelGGL(lge_resume, dim3(1), dim3(64), 0, h->stream, ctl);
   } else {
-    hipLaunchKernelGGL(lge_begin, dim3(1), dim3(256), 0, h->stream, LD, h->A, h->sigma, ctl);
+    hipLaunchKernelGGL(lge_begin, dim3(1), dim3(256), 0, h->stream, LD, h->A, h->sigma, ctl, eacc);
+    NANCHECK(h->U, 1);
+    NANCHECK(h->A, 2);
     // warm start G = A' U_prev:  Gc[k][r] = sum_j U_prev[j][k] A[j][r] - sigma Ut_prev[k][r]
     K4Args g0{h->S, LD, h->U, h->A, Gb[0], nullptr, h->Vc, h->sigma};
     launch_sg(h, g0, 0);
@@ -164,15 +173,30 @@ static int enqueue_planned_solve(cb_bank *h, const EighPlan &p, unsigned long lo
     const int s = first_slot + i;
     double *Gin = Gb[s & 1], *Gout = Gb[(s + 1) & 1];
     // (Gamma goes to P3's buffer -- dead until the powers are formed --, its diagonal behind the statistics partials)
-    GramArgs ga{LD, kPlannedBand, s, q.cap, q.cap == 12 ? q.nsq : 0, Gin, X, Xf, P3, h->epart + (size_t)2 * nt * LD + (size_t)nt * nt + 8,
-                q.so, h->epart, ctl, 3e-4};
+    unsigned long long *acc = eacc + (size_t)(s & 1) * LGE_ACC_WORDS;
+    GramArgs ga{LD, kPlannedBand, s, q.cap, q.cap == 12 ? q.nsq : 0, Gin, X, Xf, P3, h->epart + (size_t)2 * LGE_ACC_WORDS,
+                q.so, acc, ctl, 3e-4};
+    NANCHECK(Gin, 1000 + s * 100 + 1);
     hipLaunchKernelGGL(lge_gram, tiles, dim3(512), 0, h->stream, ga);
-    hipLaunchKernelGGL(lge_decide, dim3(1), dim3(512), 0, h->stream, ga);
+    NANCHECK(X, 1000 + s * 100 + 2);
+    // the sweep's decision is taken by the first launch behind lge_gram
+    DecArgs dec;
+    dec.on = 1; dec.cap = ga.cap; dec.nsq = ga.nsq; dec.so = q.so; dec.acc = acc; dec.trigger = ga.trigger;
+#ifdef CB_DECIDE_KERNEL
+    hipLaunchKernelGGL(lge_decide_k, dim3(1), dim3(64), 0, h->stream, s, dec, ctl);
+    dec.on = 0;
+#endif
     if (q.so) {
-      SoArgs so{LD, s, ctl, ga.Gm, ga.dg, X, Xf, q.expect_run && i >= 1};
+      SoArgs so{LD, s, ctl, ga.Gm, ga.dg, X, Xf, q.expect_run && i >= 1, dec};
+#ifdef CB_NO_EARLY
+      so.early = 0;
+#endif
       hipLaunchKernelGGL(lge_so, tiles, dim3(512), 0, h->stream, so);
+      NANCHECK(Xf, 1000 + s * 100 + 3);
     }
     EgArgs e{};
+    if (!q.so) e.dec = dec;
+    e.zacc = acc;
     e.LD = LD; e.slot = s; e.cap = q.cap; e.ctl = ctl; e.X = X; e.Xf = Xf; e.P2 = P2; e.P4 = P4; e.B0 = B0; e.B1 = B1; e.B2 = B2; e.T = T;
     e.R[0] = R0; e.R[1] = R1; e.Rt[0] = R0t; e.Rt[1] = R1t; e.Rfin = Rfin; e.Gin = Gin; e.Gout = Gout;
     auto gemm = [&](int kind, int qq = 0) {
@@ -182,6 +206,9 @@ static int enqueue_planned_solve(cb_bank *h, const EighPlan &p, unsigned long lo
       const int xo = q.expect_order;
       c.early = !q.expect_run ? 0 : kind == EG_P34 ? xo >= 4 : kind == EG_T1 ? xo == 12 : kind == EG_RP ? xo >= 8 :
                 kind == EG_SQ ? qq < q.expect_sq : kind == EG_R4 ? xo == 4 : 1;
+#ifdef CB_NO_EARLY
+      c.early = 0;
+#endif
       switch (kind) {
         case EG_P2: hipLaunchKernelGGL(lge_gemm<EG_P2>, tiles, dim3(512), 0, h->stream, c); break;
         case EG_P34: hipLaunchKernelGGL(lge_p34, tiles, dim3(512), 0, h->stream, c); break;
@@ -201,13 +228,21 @@ static int enqueue_planned_solve(cb_bank *h, const EighPlan &p, unsigned long lo
     } else if (q.cap == 4) {
       gemm(EG_R4);   // (second order: EG_P2 has written R already and this launch returns)
     }
+    NANCHECK(Rfin, 1000 + s * 100 + 4);
+#ifdef CB_NANCHECK
+    hipLaunchKernelGGL(lge_orthcheck, dim3((unsigned)LD), dim3(256), 0, h->stream, LD, Rfin, (unsigned long long)s, ctl);
+#endif
     gemm(EG_GR);
+    NANCHECK(Gout, 1000 + s * 100 + 5);
     if (q.band_after) band_pass(Gout, ctl + EC_MASKED);
   }
   volatile unsigned long long *pin = h->epin + (size_t)(seq & 1ull) * (EC_WORDS + 16);
   hipLaunchKernelGGL(lge_norms, dim3((LD + 3) / 4), dim3(256), 0, h->stream, LD, Gb[0], Gb[1], h->X, ctl, pin, seq, h->sigma, tb_rho_max);
   LAUNCH_STOP(stop_event(h, EV_EIGH), lge_finish, dim3((LD + 3) / 4), dim3(256), 0, h->stream, LD, Gb[0], Gb[1], h->X, h->sigma, h->lam, h->U, h->Vc,
                      ctl, tbt);
+#ifdef CB_NANCHECK
+  hipLaunchKernelGGL(lge_residual, dim3((unsigned)LD), dim3(256), 0, h->stream, LD, h->A, h->Vc, h->lam, ctl);
+#endif
   HIP_TRY(hipGetLastError());
   return CB_OK;
 }
@@ -264,13 +299,26 @@ static int eigh_planned_record(cb_bank *h, unsigned long long seq, EighRecord &r
       fprintf(stderr, " %s%d%s/%d c=%.1e |X|<=%.1e(%.1e)", r.sweep[k].masked ? "M" : "L", r.sweep[k].order, r.sweep[k].damped ? "d" : "",
               r.sweep[k].sq, r.sweep[k].c, r.sweep[k].rs, r.sweep[k].rsf);
     // where the solve's time went on the device's own 100 MHz clock: begin -> each decision -> lge_norms, in microseconds
-    fprintf(stderr, "  | us:");
+    fprintf(stderr, " final slot %d (slots", r.final_slot);
+    for (int k = 0; k < r.nsweep; ++k) fprintf(stderr, " %d", r.sweep[k].slot);
+    fprintf(stderr, ")  | us:");
     unsigned long long tp = pin[EC_T0];
     for (int k = 0; k < r.nsweep; ++k) {
       fprintf(stderr, " %.1f", (double)(pin[EC_TSWEEP + k] - tp) * 0.01);
       tp = pin[EC_TSWEEP + k];
     }
     fprintf(stderr, " %.1f = %.1f\n", (double)(pin[EC_TEND] - tp) * 0.01, (double)(pin[EC_TEND] - pin[EC_T0]) * 0.01);
+#ifdef CB_NANCHECK
+    {
+      double rr;
+      const unsigned long long rb = pin[92];
+      memcpy(&rr, &rb, 8);
+      double oo;
+      const unsigned long long ob = pin[91];
+      memcpy(&oo, &ob, 8);
+      fprintf(stderr, "  | nancheck tag %llu, largest residual since the last print %.2e; largest |R^T R - I| of this solve %.2e (slot %llu)\n", pin[94], rr, oo, pin[90]);
+    }
+#endif
 #ifdef CB_EIGH_STAMPS
     {   // launch by launch: kernel id : microseconds since the previous entry
       const unsigned long long ns = pin[EC_NSTAMP];

@@ -68,8 +68,20 @@ __global__ __launch_bounds__(JB_THREADS) void lgj_round(int LD, int round, int i
     if (i < 96ull) c[96 + i] = ((unsigned long long)__builtin_amdgcn_s_memrealtime() << 8) | 3ull;
   }
 #endif
-  if (off_bits[1] != 0ull) return;
-  if ((must_zero && *must_zero != 0ull) || (must_nonzero && *must_nonzero == 0ull)) return;
+  {
+    // the three words that decide whether this launch runs, in ONE batch of scalar loads (constant address space); as plain
+    // loads in the short-circuit order of the tests they were three dependent round trips behind a kernel boundary
+#ifdef CB_PLAIN_WORDS
+    typedef const unsigned long long *const_words;
+#else
+    typedef const __attribute__((address_space(4))) unsigned long long *const_words;
+#endif
+    const_words p0 = (const_words)off_bits, p1 = (const_words)(must_zero ? must_zero : off_bits + 1),
+                p2 = (const_words)(must_nonzero ? must_nonzero : off_bits + 1);
+    const unsigned long long w0 = p0[1], w1 = *p1, w2 = *p2;
+    if (w0 != 0ull) return;
+    if ((must_zero && w1 != 0ull) || (must_nonzero && w2 == 0ull)) return;
+  }
   extern __shared__ double lds[];
   const int RS = jb_rowstride(LD);
   double *sG = lds;                 // [16][RS]

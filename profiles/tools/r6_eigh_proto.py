@@ -8,6 +8,7 @@ import numpy as np
 
 JB = 8
 SKIP = 1e-16
+NORM = "rowsum"
 
 
 def build_A(upper, log_pi, mask):
@@ -41,6 +42,11 @@ def stats_X(Gam, band, angles=True):
     bi = np.arange(n) // JB
     far = np.abs(bi[:, None] - bi[None, :]) > band
     Xf = X * far
+    if NORM == "fro":   # (round 6: would a single global sum do instead of 400 row sums?  |X|_2 <= |X|_F)
+        return X, Xf, far, c, np.sqrt((X * X).sum()), np.sqrt((Xf * Xf).sum())
+    if NORM == "cmp":
+        print(f"      rowsum {np.abs(X).sum(1).max():.2e} fro {np.sqrt((X * X).sum()):.2e} two {np.linalg.norm(X, 2):.2e} | far: rowsum "
+              f"{np.abs(Xf).sum(1).max():.2e} fro {np.sqrt((Xf * Xf).sum()):.2e} two {np.linalg.norm(Xf, 2):.2e}")
     return X, Xf, far, c, np.abs(X).sum(1).max(), np.abs(Xf).sum(1).max()
 
 
@@ -366,6 +372,9 @@ def main():
         "gwf32b1": (solve_gamma_w, {"width": 32, "far_sweeps": 1, "band": 1}),
         "gwf32b3": (solve_gamma_w, {"width": 32, "far_sweeps": 1, "band": 3}),
     }
+    global NORM
+    if sys.argv[1:] and sys.argv[1].startswith("norm="):
+        NORM = sys.argv.pop(1)[5:]
     pick = sys.argv[1:] or list(variants)
     for name in pick:
         fn, v = variants[name]
