@@ -40,7 +40,7 @@ enum {
   EC_MASKED = 7,   // the last sweep rotated far pairs only (the band pass behind it runs)
   EC_SC = 8,       // bits of the scale s: Y = s X
   EC_BANDS = 9,    // band passes run so far
-  EC_SIGMA = 10,   // bits of sigma = max |A_ii| (lge_begin): the host follows 2 sigma >= rho, the range of the bank's time basis
+  EC_SIGMA = 10,   // (in the host's record only: lge_norms) bits of sigma = max |A_ii|: the host follows 2 sigma >= rho, the range of the bank's time basis
   EC_TBSTALE = 11, // lge_norms: 2 sigma left the range the time basis was built for (tbasis.hip.h); the bank returns at once
   EC_SKIP = 12,    // EC_STALL | EC_TBSTALE: the word the kernels of a time-basis bank look at
   EC_REC = 16,     // 4 words per sweep: cosine, row sum (all pairs), row sum (far pairs), EC_MODE | sq << 24
@@ -779,16 +779,16 @@ __global__ __launch_bounds__(512) void lge_so(SoArgs a) {
   a.Xs[idx] = xs;
 }
 
-// Solve prologue: sigma = max |A_ii| and a clean control block (one launch, first kernel of the solve).
+// A clean control block and clean statistics lines (blockDim.x == 256): the planned solve's prologue.  In the trainer it rides on
+// lt_build (train_large.hip.h), which also leaves sigma = max |A_ii|; lge_begin is the launch of its own for every other caller.
+__device__ void lge_reset_words(unsigned long long *ctl, unsigned long long *acc) {
+  if (threadIdx.x < EC_WORDS)
+    ctl[threadIdx.x] = threadIdx.x == EC_FINAL ? EC_NONE : threadIdx.x == EC_T0 ? (unsigned long long)__builtin_amdgcn_s_memrealtime() : 0ull;
+  if (threadIdx.x < 2 * LGE_ACC_WORDS) acc[threadIdx.x] = 0ull;   // both sets of statistics lines
+}
 __global__ void lge_begin(int LD, const double *A, double *sigma, unsigned long long *ctl, unsigned long long *acc) {
   __shared__ double s[256];
-  if (threadIdx.x < 2 * LGE_ACC_WORDS) acc[threadIdx.x] = 0ull;   // both sets of statistics lines
-#ifdef CB_NANCHECK
-  if (threadIdx.x < EC_WORDS && threadIdx.x != 92)
-#else
-  if (threadIdx.x < EC_WORDS)
-#endif
-    ctl[threadIdx.x] = threadIdx.x == EC_FINAL ? EC_NONE : threadIdx.x == EC_T0 ? (unsigned long long)__builtin_amdgcn_s_memrealtime() : 0ull;
+  lge_reset_words(ctl, acc);
   double m = 0.0;
   for (int i = threadIdx.x; i < LD; i += 256) m = fmax(m, fabs(A[(size_t)i * LD + i]));
   s[threadIdx.x] = m;
@@ -797,11 +797,39 @@ __global__ void lge_begin(int LD, const double *A, double *sigma, unsigned long 
     if ((int)threadIdx.x < st) s[threadIdx.x] = fmax(s[threadIdx.x], s[threadIdx.x + st]);
     __syncthreads();
   }
-  if (threadIdx.x == 0) {
-    const double sg = s[0] > 0.0 ? s[0] : 1.0;
-    *sigma = sg;
-    ctl[EC_SIGMA] = dbl_bits(sg);   // (a different word than the ones zeroed above by this thread's neighbours)
+  if (threadIdx.x == 0) *sigma = s[0] > 0.0 ? s[0] : 1.0;
+}
+
+// Warm start G = A' U_prev:  Gc[k][r] = sum_j U_prev[j][k] A[j][r] - sigma Ut_prev[k][r] -- lge_gemm's tile (16 x 16, K over eight
+// waves, all 13 k-steps of a wave in flight) with nothing to wait for but its kernel arguments: no control word decides anything
+// here.  (Rounds 2-5: the generic single-matrix product, two batches of seven k-steps, 8.5 us.)
+__global__ __launch_bounds__(512) void lge_warm(int LD, const double *U, const double *A, const double *Ut, const double *sigma, double *G) {
+  __shared__ double sRed[4][256];
+  const int nt = LD / 16;
+  const int tm = blockIdx.x / nt, tn = blockIdx.x - tm * nt;
+  const int m0 = tm * 16, n0 = tn * 16;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, lo = lane & 15, hi = lane >> 4;
+  const int nsteps = LD / 4;
+  const unsigned loff = (unsigned)(hi * LD + lo) * 8u;
+  const int et = threadIdx.x & 255, er = et >> 6, el = et & 63;
+  const int row = m0 + (el >> 4) + 4 * er, col = n0 + (el & 15);
+  const size_t idx = (size_t)row * LD + col;
+  double av[LGE_UU], bv[LGE_UU];
+  d4 acc = {0.0, 0.0, 0.0, 0.0};
+  for (int s0 = wave; s0 < nsteps; s0 += 8 * LGE_UU) {
+#pragma unroll
+    for (int u = 0; u < LGE_UU; ++u) {
+      const int sk = min(s0 + 8 * u, nsteps - 1);
+      av[u] = lge_ld(U, sk, LD, m0, loff);
+      bv[u] = lge_ld(A, sk, LD, n0, loff);
+    }
+#pragma unroll
+    for (int u = 0; u < LGE_UU; ++u)
+      if (s0 + 8 * u < nsteps) acc = mfma_f64(av[u], bv[u], acc);
   }
+  const double sg = *sigma, e1 = threadIdx.x < 256 ? Ut[idx] : 0.0;
+  const double v = lge_fold8(sRed, acc, wave, lane, et);
+  if (threadIdx.x < 256) G[idx] = fma(-sg, e1, v);
 }
 
 // A stalled solve continues (more slots on the same G): the stall word cleared, everything else kept.
@@ -826,7 +854,7 @@ __global__ void lge_norms(int LD, const double *G0, const double *G1, double *nr
     if (pin && threadIdx.x < EC_WORDS) {
       const int i = threadIdx.x;
       pin[i] = i == EC_STALL ? (stall ? 1ull : 0ull) : i == EC_TBSTALE ? (stale ? 1ull : 0ull) : i == EC_SKIP ? ((stall || stale) ? 1ull : 0ull) :
-               i == EC_TEND ? (unsigned long long)__builtin_amdgcn_s_memrealtime() : ctl[i];
+               i == EC_TEND ? (unsigned long long)__builtin_amdgcn_s_memrealtime() : i == EC_SIGMA ? dbl_bits(*sigma) : ctl[i];
       __threadfence_system();
 #ifdef CB_NANCHECK
       if (i == 92) ctl[92] = 0ull;

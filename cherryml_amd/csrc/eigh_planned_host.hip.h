@@ -146,12 +146,12 @@ static int enqueue_planned_solve(cb_bank *h, const EighPlan &p, unsigned long lo
   if (first_slot > 0) {
     hipLaunchKernelGGL(lge_resume, dim3(1), dim3(64), 0, h->stream, ctl);
   } else {
-    hipLaunchKernelGGL(lge_begin, dim3(1), dim3(256), 0, h->stream, LD, h->A, h->sigma, ctl, eacc);
+    // (the trainer's lt_build has reset the control block and left sigma: h->begin_folded)
+    if (!h->begin_folded) hipLaunchKernelGGL(lge_begin, dim3(1), dim3(256), 0, h->stream, LD, h->A, h->sigma, ctl, eacc);
     NANCHECK(h->U, 1);
     NANCHECK(h->A, 2);
     // warm start G = A' U_prev:  Gc[k][r] = sum_j U_prev[j][k] A[j][r] - sigma Ut_prev[k][r]
-    K4Args g0{h->S, LD, h->U, h->A, Gb[0], nullptr, h->Vc, h->sigma};
-    launch_sg(h, g0, 0);
+    hipLaunchKernelGGL(lge_warm, dim3((unsigned)(nt * nt)), dim3(512), 0, h->stream, LD, h->U, h->A, h->Vc, h->sigma, Gb[0]);
   }
   unsigned long long *jstate = ctl + EC_JSTATE;   // lgj_round's own two words (zeroed by lge_begin)
   int shift = 0;

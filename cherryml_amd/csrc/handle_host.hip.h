@@ -77,6 +77,9 @@ struct cb_bank {
   // planned (device-controlled) warm solves, eigh_planned_host.hip.h: control block, statistics partials, pinned records
   unsigned long long *ectl = nullptr, *epin = nullptr;
   double *epart = nullptr;
+  bool begin_folded = false;          // this epoch's lt_build carried the planned solve's prologue (train_host.hip.h)
+  double *sigma_home = nullptr;       // h->sigma outside the trainer's epochs
+  double *sigma2 = nullptr;           // two words used in turn by the trainer's epochs (lt_build folds max |A_ii| into them)
   unsigned long long eseq = 0;
   bool planned_unavailable = false;   // eigh_planned_setup failed once on this handle: not tried again (host-driven solver)
   int planned_solves = 0, planned_stalls = 0;   // counters (cb_eigh_counters)

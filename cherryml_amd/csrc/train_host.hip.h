@@ -75,7 +75,12 @@ static int run_fused_training_large(cb_bank *h, double *pi_param, double *up_par
   const int e0 = resume ? h->tr_epochs : 0;
   int slot = 0;
   auto alloc = [&](double **p, size_t n) -> bool { return ws_get(h, slot++, n, p); };
-  auto release = [&]() { (void)hipStreamSynchronize(h->stream); };
+  // (every exit: h->sigma back where the other entry points expect it -- the epochs below use two words in turn, see lt_build)
+  auto release = [&]() {
+    (void)hipStreamSynchronize(h->stream);
+    if (h->sigma_home) h->sigma = h->sigma_home;
+    h->begin_folded = false;
+  };
   double *d_pi = nullptr, *d_up = nullptr, *d_mom = nullptr, *d_mask = nullptr, *d_loss = nullptr, *d_Qb = nullptr,
          *d_Ql = nullptr, *d_Qp = nullptr, *d_vec = nullptr, *d_time = nullptr;
   const size_t nmom = 2 * (S + nup);
@@ -131,6 +136,15 @@ static int run_fused_training_large(cb_bank *h, double *pi_param, double *up_par
   if (h->profile) fold_pending(h);
   if (dbg) fprintf(stderr, "[cherrybank] large trainer: parameters uploaded after %.2f ms\n", now() - t_enter);
   double pow_b1 = resume ? h->tr_pow_b1 : 1.0, pow_b2 = resume ? h->tr_pow_b2 : 1.0;
+  // sigma = max |A_ii| is folded into one of two words by lt_build (the other is cleared for the next epoch)
+  if (!h->sigma2) {
+    if (dev_alloc(h, &h->sigma2, 2) != CB_OK) {
+      release();
+      return CB_ENOMEM;
+    }
+  }
+  if (!h->sigma_home) h->sigma_home = h->sigma;
+  TRYH(hipMemsetAsync(h->sigma2, 0, 2 * sizeof(double), h->stream));
   h->last_form = 4000;
   h->tr_epochs = 0;   // (set again when this call succeeds)
   // fault injection for the tests of the collective failure protocol: this rank's evaluation "fails" at that epoch
@@ -170,13 +184,23 @@ static int run_fused_training_large(cb_bank *h, double *pi_param, double *up_par
     }
     if (trace_slow > 0.0) te_fold = now();
     for (bool &b : h->ev_rec) b = false;
+    const bool use_plan = planned && h->have_prev && e0 + e >= 3;
+    {
+      const int par = (e0 + e) & 1;
+      h->sigma = h->sigma2 + par;
+      a.sig_cur = reinterpret_cast<unsigned long long *>(h->sigma2 + par);
+      a.sig_next = reinterpret_cast<unsigned long long *>(h->sigma2 + (par ^ 1));
+      a.ectl = use_plan ? h->ectl : nullptr;                                        // the planned solve's prologue rides on the build
+      a.eacc = use_plan ? reinterpret_cast<unsigned long long *>(h->epart) : nullptr;
+      h->begin_folded = use_plan;
+    }
     LAUNCH_STOP(stop_event(h, EV_START), lt_build, dim3(LD), dim3(256), 0, h->stream, a, e0 + e);
     // Every solve after the first is a PLAN (eigh_planned_host.hip.h): the device takes the sweep decisions, the host enqueues
     // the whole epoch and only then looks at the solve's record -- with K1 .. K4 queued behind it, so the GPU never waits.
     // (the first warm solves of an optimisation start far from converged -- cosines of 1e-2, every sweep damped --: they stay
     // with the host-driven solver, whose tournament sweeps are made for that; plans from the fourth epoch on)
-    const bool use_plan = planned && h->have_prev && e0 + e >= 3;
     rc = large_eval(h, flags & CB_NORMALIZE, h->loss, h->Mt, true, nullptr, false, use_plan ? &plan : nullptr);
+    h->begin_folded = false;   // (a solve enqueued later in this epoch starts with its own prologue)
     if (trace_slow > 0.0) te_enq = now();
     if (rc == CB_OK && use_plan) {
       EighRecord rec;
@@ -270,6 +294,7 @@ static int run_fused_training_large(cb_bank *h, double *pi_param, double *up_par
     hipLaunchKernelGGL(lt_step, dim3(S + 1), dim3(256), 0, h->stream, a, e0 + e, 1.0 - pow_b1, std::sqrt(1.0 - pow_b2));
     if (hipGetLastError() != hipSuccess) rc = fail(CB_EHIP, "fused training launch failed");
   }
+  if (E > 0 && h->sigma_home) TRYH(hipMemcpyAsync(h->sigma_home, h->sigma2 + ((e0 + E - 1) & 1), sizeof(double), hipMemcpyDeviceToDevice, h->stream));
   TRYH(hipStreamSynchronize(h->stream));
   if (h->profile) {  // the older of the two event sets; the newest stays pending (cb_last_timings reads it)
     swap_event_sets(h);

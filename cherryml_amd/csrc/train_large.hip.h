@@ -34,7 +34,15 @@ struct LargeTrain {
   double *loss_curve;                   // [E]
   double *time_curve;                   // [E] or null: the 100 MHz wall clock at the end of each epoch's parameter step
   double *Q_last, *Q_best, *Q_pow2;     // [S][S], [S][S], [n_pow2][S][S]
+  // sigma = max |A_ii| falls out of the build (round 6: the planned eigensolve's prologue, lge_begin, was a launch of its own --
+  // one workgroup reading 400 diagonal entries, 5 us per epoch): every row's workgroup folds |A_ii| into sig_cur with an integer
+  // maximum (non-negative doubles order like their bits), workgroup 0 clears the word of the NEXT epoch (the two are used in
+  // turn) and, when a planned solve follows (ectl != null), resets its control block and statistics lines
+  unsigned long long *sig_cur = nullptr, *sig_next = nullptr;
+  unsigned long long *ectl = nullptr, *eacc = nullptr;
 };
+
+__device__ void lge_reset_words(unsigned long long *ctl, unsigned long long *acc);   // eigh_planned.hip.h
 
 __device__ __forceinline__ double lt_block_sum(double v, double *s) {  // 256 threads, fixed order
   s[threadIdx.x] = v;
@@ -56,6 +64,10 @@ __global__ __launch_bounds__(256) void lt_build(LargeTrain a, int epoch) {
   __shared__ double sd[1024];   // d_j (LD <= 1024)
   const int S = a.S, LD = a.LD, i = blockIdx.x;
   double *Arow = a.A + (size_t)i * LD;
+  if (i == 0) {
+    if (a.sig_next && threadIdx.x == 255) *a.sig_next = 0ull;
+    if (a.ectl) lge_reset_words(a.ectl, a.eacc);
+  }
   if (i >= S) {
     for (int j = threadIdx.x; j < LD; j += 256) Arow[j] = 0.0;
     if (threadIdx.x == 0) {
@@ -115,6 +127,7 @@ __global__ __launch_bounds__(256) void lt_build(LargeTrain a, int epoch) {
     Arow[i] = aii;
     Ql[i] = aii;
     if (Qp) Qp[i] = aii;
+    if (a.sig_cur) atomicMax(a.sig_cur, (unsigned long long)__double_as_longlong(fabs(aii)));
   }
 }
 
