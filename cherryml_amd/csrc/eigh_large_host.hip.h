@@ -16,6 +16,13 @@ static void launch_sg(cb_bank *h, const K4Args &g, int ns, double alpha = 0.0, d
   // chains (launch floor 2.6 us + load -> MFMA -> LDS reduce), not bandwidth: the 16 x 16 shape reads 64 MB from L2 per
   // product against 38 MB for the strips and is still the fastest.  (The other shapes were removed with their switch.)
   const K4Args &g2 = second ? *second : g;
+  // a plain padded product (the two that turn the bank's sum into dL/dA in the trainer; out = Aop^T Bop, optionally - s Sub): the
+  // 13-in-flight tile of the planned eigensolve, its operands requested before the skip word is looked at (eigh_planned.hip.h)
+  if (!second && ny == 1 && ns == 0 && !g.ystride && !g.dsq && !g.outT && !g.diag && !g.sel && h->LD % 16 == 0 && (!g.sub || g.sub_scale)) {
+    LAUNCH_STOP(stop, lge_plain, dim3((unsigned)((h->LD / 16) * (h->LD / 16))), dim3(512), 0, h->stream, h->LD, g.Aop, g.Bop, g.sub, g.sub_scale,
+                g.out, g.skip);
+    return;
+  }
   if (g.ystride) {
     // `ny` products in one launch (the bucket sums' Lt_k = Y_k^T U): enough workgroups for 16 x 80 strips -- 125 per product,
     // 10.5 us for the launch -- where the 16 x 16 shape would queue 4375 workgroups in four rounds (37 us at ny = 7)

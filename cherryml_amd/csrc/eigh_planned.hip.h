@@ -800,10 +800,13 @@ __global__ void lge_begin(int LD, const double *A, double *sigma, unsigned long 
   if (threadIdx.x == 0) *sigma = s[0] > 0.0 ? s[0] : 1.0;
 }
 
-// Warm start G = A' U_prev:  Gc[k][r] = sum_j U_prev[j][k] A[j][r] - sigma Ut_prev[k][r] -- lge_gemm's tile (16 x 16, K over eight
-// waves, all 13 k-steps of a wave in flight) with nothing to wait for but its kernel arguments: no control word decides anything
-// here.  (Rounds 2-5: the generic single-matrix product, two batches of seven k-steps, 8.5 us.)
-__global__ __launch_bounds__(512) void lge_warm(int LD, const double *U, const double *A, const double *Ut, const double *sigma, double *G) {
+// out[m][n] = sum_k Aop[k][m] Bop[k][n] (- (*sigma) Sub[m][n]): lge_gemm's tile (16 x 16, K over eight waves, all 13 k-steps of a wave
+// in flight) for products whose operands are known at launch -- the warm start G = A' U_prev (Gc[k][r] = sum_j U_prev[j][k] A[j][r]
+// - sigma Ut_prev[k][r]) and the two products that turn the bank's sum into dL/dA.  Nothing decides which operands: they are
+// requested at once, and the word that says "the solve in front stalled: return" (skip) is looked at while they are in flight.
+// (Rounds 2-5: the generic single-matrix product sg_gemm, two batches of seven k-steps behind its skip word: 8.5 us; this: 6.5.)
+__global__ __launch_bounds__(512) void lge_plain(int LD, const double *Aop, const double *Bop, const double *Sub, const double *sigma,
+                                                 double *out, const unsigned long long *skip) {
   __shared__ double sRed[4][256];
   const int nt = LD / 16;
   const int tm = blockIdx.x / nt, tn = blockIdx.x - tm * nt;
@@ -815,21 +818,32 @@ __global__ __launch_bounds__(512) void lge_warm(int LD, const double *U, const d
   const int row = m0 + (el >> 4) + 4 * er, col = n0 + (el & 15);
   const size_t idx = (size_t)row * LD + col;
   double av[LGE_UU], bv[LGE_UU];
+#pragma unroll
+  for (int u = 0; u < LGE_UU; ++u) {
+    const int sk = min(wave + 8 * u, nsteps - 1);
+    av[u] = lge_ld(Aop, sk, LD, m0, loff);
+    bv[u] = lge_ld(Bop, sk, LD, n0, loff);
+  }
+  const double e1 = (Sub && threadIdx.x < 256) ? Sub[idx] : 0.0;
+  const double sg = sigma ? *sigma : 0.0;
+  if (skip && *(lge_const_words)skip != 0ull) return;
   d4 acc = {0.0, 0.0, 0.0, 0.0};
-  for (int s0 = wave; s0 < nsteps; s0 += 8 * LGE_UU) {
+#pragma unroll
+  for (int u = 0; u < LGE_UU; ++u)
+    if (wave + 8 * u < nsteps) acc = mfma_f64(av[u], bv[u], acc);
+  for (int s0 = wave + 8 * LGE_UU; s0 < nsteps; s0 += 8 * LGE_UU) {   // (LD > 416)
 #pragma unroll
     for (int u = 0; u < LGE_UU; ++u) {
       const int sk = min(s0 + 8 * u, nsteps - 1);
-      av[u] = lge_ld(U, sk, LD, m0, loff);
-      bv[u] = lge_ld(A, sk, LD, n0, loff);
+      av[u] = lge_ld(Aop, sk, LD, m0, loff);
+      bv[u] = lge_ld(Bop, sk, LD, n0, loff);
     }
 #pragma unroll
     for (int u = 0; u < LGE_UU; ++u)
       if (s0 + 8 * u < nsteps) acc = mfma_f64(av[u], bv[u], acc);
   }
-  const double sg = *sigma, e1 = threadIdx.x < 256 ? Ut[idx] : 0.0;
   const double v = lge_fold8(sRed, acc, wave, lane, et);
-  if (threadIdx.x < 256) G[idx] = fma(-sg, e1, v);
+  if (threadIdx.x < 256) out[idx] = fma(-sg, e1, v);
 }
 
 // A stalled solve continues (more slots on the same G): the stall word cleared, everything else kept.

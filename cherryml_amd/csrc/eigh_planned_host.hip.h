@@ -151,7 +151,7 @@ static int enqueue_planned_solve(cb_bank *h, const EighPlan &p, unsigned long lo
     NANCHECK(h->U, 1);
     NANCHECK(h->A, 2);
     // warm start G = A' U_prev:  Gc[k][r] = sum_j U_prev[j][k] A[j][r] - sigma Ut_prev[k][r]
-    hipLaunchKernelGGL(lge_warm, dim3((unsigned)(nt * nt)), dim3(512), 0, h->stream, LD, h->U, h->A, h->Vc, h->sigma, Gb[0]);
+    hipLaunchKernelGGL(lge_plain, dim3((unsigned)(nt * nt)), dim3(512), 0, h->stream, LD, h->U, h->A, h->Vc, h->sigma, Gb[0], nullptr);
   }
   unsigned long long *jstate = ctl + EC_JSTATE;   // lgj_round's own two words (zeroed by lge_begin)
   int shift = 0;
