@@ -35,7 +35,7 @@ out = {**STAMP, "bytes_per_launch": {}, "detail": {}, "calibration": {},
 NAMES = ["k123_bank", "k1_pt_loss_gt", "k2_t_eq_g_u", "k3_w_phi", "lgj_round", "lg_transpose_pad", "small_train_kernel", "small_bank_kernel",
          "lg_prepare", "lg_bank", "lg_finish", "count_transitions_lds_kernel", "count_reduce_slabs", "k3_reduce", "sp_prepare",
          "sp_bank", "sp_finish", "sp_step", "sg_gemm", "co_bucket_kernel", "co_plan_kernel", "co_expand_kernel", "co_count_lds_kernel", "lgx_build", "ble_branch_lengths_kernel", "ble_site_rates_kernel",
-         "siterm_raw_counts_kernel", "siterm_mix_kernel", "tl_mfma_kernel", "tl_leaf_kernel", "tl_group_kernel", "lg_cast_f32", "lge_gram", "lge_gemm", "lge_so", "lge_decide", "lge_poly",
+         "siterm_raw_counts_kernel", "siterm_mix_kernel", "tl_mfma_kernel", "tl_leaf_kernel", "tl_group_kernel", "lg_cast_f32", "lge_gram", "lge_gemm", "lge_so", "lge_p34", "lge_plain", "tl_leaf_mfma_kernel",
          "jtt_stats_partial", "ky_reduce_loss", "kphi_combine", "k3_reduce_loss", "tb_ew", "tb_tables"]
 WORKLOADS = ["coevo400", "coevo400_perbucket", "coevo400_mixed", "coevo400_f32", "coevo400_demo", "coevo400_shard8", "lg20", "siterm", "counting", "co_counting",
              "ble", "assembly", "likelihood"]
