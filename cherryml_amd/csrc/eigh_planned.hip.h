@@ -931,6 +931,11 @@ __global__ void lge_finish(int LD, const double *G0, const double *G1, const dou
   const int lane = threadIdx.x & 63;
   if (k >= LD) return;
   const double mine = nrm[k];
+  // (the column is requested together with the norms -- where it goes is decided by them, what it holds is not: one round trip
+  // instead of two in a row; columns longer than 512 take the rest afterwards)
+  double gcol[8];
+#pragma unroll
+  for (int u = 0; u < 8; ++u) gcol[u] = lane + 64 * u < LD ? Gc[(size_t)k * LD + lane + 64 * u] : 0.0;
   int before = 0;
   for (int j = lane; j < LD; j += 64) {
     const double o = nrm[j];
@@ -938,7 +943,16 @@ __global__ void lge_finish(int LD, const double *G0, const double *G1, const dou
   }
   const int pos = (int)wave_sum((double)before);
   const double inv = -1.0 / mine;
-  for (int r = lane; r < LD; r += 64) {
+#pragma unroll
+  for (int u = 0; u < 8; ++u) {
+    const int r = lane + 64 * u;
+    if (r < LD) {
+      const double v = gcol[u] * inv;
+      Ut[(size_t)pos * LD + r] = v;
+      U[(size_t)r * LD + pos] = v;
+    }
+  }
+  for (int r = lane + 512; r < LD; r += 64) {
     const double v = Gc[(size_t)k * LD + r] * inv;
     Ut[(size_t)pos * LD + r] = v;
     U[(size_t)r * LD + pos] = v;
