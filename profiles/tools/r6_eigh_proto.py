@@ -116,10 +116,10 @@ def group_rot(G, cols, inner, exact=False):
     G[:, cols] = P @ R
 
 
-def band_pass(G, shift, band, inner, exact=False):
+def band_pass(G, shift, band, inner, exact=False, tilings=2):
     n = G.shape[1]
     nb = n // JB
-    for w in range(2):
+    for w in range(tilings):
         odd = ((shift + w) & 1) and nb > 2
         for g in range(nb // 2):
             b0, b1 = (2 * g + 1, (2 * g + 2) % nb) if odd else (2 * g, 2 * g + 1)
@@ -144,9 +144,9 @@ def solve_current(Ap, U_prev, v):
     hist = []
     shift = 0
     if v.get("lead", True):
-        band_pass(G, shift, band, v.get("lead_inner", 2), v.get("exact", False))
+        band_pass(G, shift, band, v.get("lead_inner", 2), v.get("exact", False), v.get("lead_tilings", 2))
         shift += 1
-        launches += 2 * band
+        launches += v.get("lead_tilings", 2) * band
     for it in range(12):
         Gam = G.T @ G
         X, Xf, far, c, rs, rsf = stats_X(Gam, band)
@@ -167,9 +167,9 @@ def solve_current(Ap, U_prev, v):
         launches += {2: 5, 4: 6, 8: 8, 12: 9}[order] + (1 if it >= 1 else 0)
         if masked:
             if v.get("post", True):
-                band_pass(G, shift, band, v.get("post_inner", 1), v.get("exact", False))
+                band_pass(G, shift, band, v.get("post_inner", 1), v.get("exact", False), v.get("post_tilings", 2))
                 shift += 1
-                launches += 2 * band
+                launches += v.get("post_tilings", 2) * band
         hist.append(("M" if masked else "L", c, rs, rsf, order))
         if final:
             break
@@ -337,6 +337,10 @@ def main():
     variants = {
         "current": (solve_current, {}),
         "cur_b1": (solve_current, {"band": 1}),
+        "b1_lead1": (solve_current, {"band": 1, "lead_tilings": 1}),
+        "b1_post1": (solve_current, {"band": 1, "post_tilings": 1}),
+        "b1_lead1_post1": (solve_current, {"band": 1, "lead_tilings": 1, "post_tilings": 1}),
+        "b1_lead1_li3": (solve_current, {"band": 1, "lead_tilings": 1, "lead_inner": 3}),
         "cur_forceL1": (solve_current, {"force_L_from": 1}),
         "cur_forceL0": (solve_current, {"force_L_from": 0}),
         "cur_nopost_forceL1": (solve_current, {"force_L_from": 1, "post": False}),
