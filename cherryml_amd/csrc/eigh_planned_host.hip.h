@@ -238,8 +238,8 @@ static int enqueue_planned_solve(cb_bank *h, const EighPlan &p, unsigned long lo
   }
   volatile unsigned long long *pin = h->epin + (size_t)(seq & 1ull) * (EC_WORDS + 16);
   hipLaunchKernelGGL(lge_norms, dim3((LD + 3) / 4), dim3(256), 0, h->stream, LD, Gb[0], Gb[1], h->X, ctl, pin, seq, h->sigma, tb_rho_max);
-  LAUNCH_STOP(stop_event(h, EV_EIGH), lge_finish, dim3((LD + 3) / 4), dim3(256), 0, h->stream, LD, Gb[0], Gb[1], h->X, h->sigma, h->lam, h->U, h->Vc,
-                     ctl, tbt);
+  LAUNCH_STOP(stop_event(h, EV_EIGH), lge_finish, dim3((LD + 3) / 4 + 1), dim3(256), 0, h->stream, LD, Gb[0], Gb[1], h->X, h->sigma, h->lam, h->U, h->Vc,
+                     ctl, tbt, pin, seq);
 #ifdef CB_NANCHECK
   hipLaunchKernelGGL(lge_residual, dim3((unsigned)LD), dim3(256), 0, h->stream, LD, h->A, h->Vc, h->lam, ctl);
 #endif
