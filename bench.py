@@ -81,6 +81,8 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8.0 TB/s spec
 F64_PEAK_TFLOPS = 78.6     # 256 CU x 4 SIMD x 32 flop/clk x 2.4 GHz (f64 MFMA = f64 vector rate)
+PHASE_EVENTS_EVERY = 4   # the 400-state trainer's phase events (phase_ms, roofline) are recorded in every 4th timed epoch: six completion
+                         # events cost an epoch 0.015 ms (profiles/r06_phase_event_cost.json); averages are over the recorded epochs
 PREWARM_EPOCHS = 30   # throw-away epochs in front of the W warm-up epochs of the 400-state trainer (see main)
 F32_PEAK_TFLOPS = 157.3    # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 / 32x32x2, 64 flop/clk/SIMD (exact f32)
 LDS_ATOMIC_PEAK_G = 9830.4  # G lane-atomics/s: 16 lanes per clock per CU (LDS table: a 4-byte LDS write / atomic = 4 cycles per
@@ -477,7 +479,7 @@ def main():
                     call(PREWARM_EPOCHS)   # (see the single-GPU branch below: one-time events of a fresh process)
                     prewarm_ms = (time.perf_counter() - tp0) * 1e3
                     call(warmup)
-                bank.profile(True)
+                bank.profile(True, every=PHASE_EVENTS_EVERY)
                 fence()
                 t0 = time.perf_counter()
                 r = call(steps, warmup > 0)
@@ -553,7 +555,7 @@ def main():
                 prewarm_ms = (time.perf_counter() - tp0) * 1e3
             if warmup > 0:
                 call(warmup)
-            bank.profile(True)
+            bank.profile(True, every=PHASE_EVENTS_EVERY if S > 32 else 1)
             fence()
             t0 = time.perf_counter()
             r = call(steps, warmup > 0)
@@ -759,6 +761,7 @@ def main():
             "roofline": roofline,
             "epochs_per_s": steps / dt,   # the epoch's cost does not depend on the pair count
             "phase_ms": {k: round(v, 4) for k, v in tm.items()},
+            **({"phase_events": f"recorded in every {PHASE_EVENTS_EVERY}th epoch of the timed region"} if S > 32 else {}),
             **({"bank_form": bank_form} if bank_form else {}),
             "final_loss": final_loss,
         }

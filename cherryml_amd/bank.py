@@ -149,8 +149,9 @@ class CherryBank:
     # -- profiling ----------------------------------------------------------
     TIMING_NAMES = ("total", "eigh", "k1", "k2", "k3", "k4", "small", "allreduce")
 
-    def profile(self, enable: bool = True):
-        _lib.check(_lib.load().cb_profile(self._h, int(enable)), "cb_profile")
+    def profile(self, enable: bool = True, every: int = 1):
+        """phase events on (every: the C-driven 400-state trainer records them in every `every`-th epoch only) / off"""
+        _lib.check(_lib.load().cb_profile(self._h, int(every) if enable else 0), "cb_profile")
 
     def last_timings(self) -> dict:
         """milliseconds per phase of the last profiled cb_loss_grad (HIP events)."""

@@ -454,7 +454,7 @@ static int large_eval(cb_bank *h, bool normalize, double *lossd, double *out, bo
     const int sym = h->sym_counts ? 1 : 0;
     const int test_no_claim = cb_test_hook("CB_BANK_TEST_NO_CLAIM") ? 1 : 0;   // (tests/test_gpu_s400_full.py: the help path)
     // (the phase marks ride on the launches as stop events: handle_host.hip.h, stop_event())
-    if (h->profile) h->ev_rec[EV_K1] = h->ev_rec[EV_K2] = false;   // CB_T_K1 = the whole launch (+ tables), see read_phase_times
+    if (h->profile && h->profile_now) h->ev_rec[EV_K1] = h->ev_rec[EV_K2] = false;   // CB_T_K1 = the whole launch (+ tables), see read_phase_times
     const hipEvent_t bank_stop = stop_event(h, EV_K3);
     auto launch = [&](auto args) {
       typedef decltype(args) A;
@@ -880,6 +880,8 @@ static void fold_pending(cb_bank *h) {
 extern "C" int cb_profile(cb_handle h, int enable) {
   if (!h) return fail(CB_EINVAL, "cb_profile: NULL handle");
   h->profile = enable != 0;
+  h->profile_every = enable > 1 ? enable : 1;
+  h->profile_now = h->profile;
   for (double &x : h->t_sum) x = 0.0;
   h->t_calls = 0;
   h->t_pending = false;

@@ -136,6 +136,8 @@ struct cb_bank {
   size_t pin_cap = 0, pin_off = 0;
   // profiling
   bool profile = false;
+  int profile_every = 1;       // cb_profile(h, n > 1): the C-driven large trainer records its phase events in every n-th epoch only
+  bool profile_now = false;    // ... and this epoch is one of them (everywhere else: = profile)
   hipEvent_t ev[CB_T_COUNT + 1] = {};
   bool ev_rec[CB_T_COUNT + 1] = {};
   double t_sum[CB_T_COUNT] = {};
@@ -161,7 +163,7 @@ static void fold_pending(cb_bank *h);
 // event i marks the END of phase i-1 .. see mark()
 enum { EV_START = 0, EV_EIGH, EV_K1, EV_K2, EV_K3, EV_K4, EV_SMALL, EV_END, EV_AR };   // (EV_AR = CB_T_COUNT: the last slot)
 static void mark(cb_bank *h, int which) {
-  if (!h->profile) return;
+  if (!h->profile || !h->profile_now) return;
   if (!h->ev[which]) (void)hipEventCreate(&h->ev[which]);
   (void)hipEventRecord(h->ev[which], h->stream);
   h->ev_rec[which] = true;
@@ -172,10 +174,14 @@ static void mark(cb_bank *h, int which) {
 // profiles/tools/ext_event_probe: +0.0 us per launch, a START event costs 5 us).  stop_event() returns the event to pass --
 // null when the call is not profiled, and the launch is then a plain one.
 static hipEvent_t stop_event(cb_bank *h, int which) {
-  if (!h->profile) return nullptr;
+  if (!h->profile || !h->profile_now) return nullptr;
   if (!h->ev[which] && hipEventCreate(&h->ev[which]) != hipSuccess) return nullptr;
   h->ev_rec[which] = true;
   return h->ev[which];
+}
+static void clear_marks(cb_bank *h) {   // (an epoch that records no events must leave the pending set's flags alone)
+  if (h->profile && !h->profile_now) return;
+  for (bool &b : h->ev_rec) b = false;
 }
 #define LAUNCH_STOP(ev, kernel, grid, block, shmem, stream, ...)                                              \
   do {                                                                                                        \

@@ -80,6 +80,7 @@ static int run_fused_training_large(cb_bank *h, double *pi_param, double *up_par
     (void)hipStreamSynchronize(h->stream);
     if (h->sigma_home) h->sigma = h->sigma_home;
     h->begin_folded = false;
+    h->profile_now = h->profile;
   };
   double *d_pi = nullptr, *d_up = nullptr, *d_mom = nullptr, *d_mask = nullptr, *d_loss = nullptr, *d_Qb = nullptr,
          *d_Ql = nullptr, *d_Qp = nullptr, *d_vec = nullptr, *d_time = nullptr;
@@ -178,12 +179,14 @@ static int run_fused_training_large(cb_bank *h, double *pi_param, double *up_par
   for (int e = 0; e < E && rc == CB_OK; ++e) {
     const double te0 = trace_slow > 0.0 ? now() : 0.0;
     double te_fold = 0.0, te_enq = 0.0, te_rec = 0.0;
-    if (h->profile) {  // fold the epoch before the previous one (its events are long complete), then re-record that set
+    // (cb_profile(h, n): the phase events of every n-th epoch -- each completion event costs the epoch ~2.5 us, six of them 2 %)
+    h->profile_now = h->profile && (e0 + e) % h->profile_every == 0;
+    if (h->profile_now) {  // fold the profiled epoch before the previous one (its events are long complete), then re-record that set
       swap_event_sets(h);
       fold_pending(h);
     }
     if (trace_slow > 0.0) te_fold = now();
-    for (bool &b : h->ev_rec) b = false;
+    clear_marks(h);
     const bool use_plan = planned && h->have_prev && e0 + e >= 3;
     {
       const int par = (e0 + e) & 1;
@@ -214,7 +217,7 @@ static int run_fused_training_large(cb_bank *h, double *pi_param, double *up_par
         ++h->planned_stalls;
         EighPlan more;
         eigh_plan_continue(rec, more);
-        for (bool &b : h->ev_rec) b = false;
+        clear_marks(h);
         mark(h, EV_START);
         rc = large_eval(h, flags & CB_NORMALIZE, h->loss, h->Mt, true, nullptr, false, &more, slots_done);
         slots_done += more.nslots;
@@ -228,7 +231,7 @@ static int run_fused_training_large(cb_bank *h, double *pi_param, double *up_par
         if (hipStreamSynchronize(h->stream) != hipSuccess) rc = fail(CB_EHIP, "hipStreamSynchronize failed (host-driven solver fallback)");
         else if (hipMemsetAsync(h->ectl, 0, sizeof(unsigned long long), h->stream) != hipSuccess)
           rc = fail(CB_EHIP, "hipMemsetAsync failed (host-driven solver fallback)");
-        for (bool &b : h->ev_rec) b = false;
+        clear_marks(h);
         mark(h, EV_START);
         if (rc == CB_OK) rc = large_eval(h, flags & CB_NORMALIZE, h->loss, h->Mt, true, nullptr);
       }
@@ -237,7 +240,7 @@ static int run_fused_training_large(cb_bank *h, double *pi_param, double *up_par
         // at once): the evaluation is repeated on the finished decomposition with per-bucket products.  Close to the end of
         // the range, or far below it: a new basis, built by a helper thread beside the epochs (tb_maintain, cherrybank.hip).
         if (rec.tb_stale) {
-          for (bool &b : h->ev_rec) b = false;
+          clear_marks(h);
           mark(h, EV_START);
           h->tb_block = true;
           rc = large_eval(h, flags & CB_NORMALIZE, h->loss, h->Mt, true, nullptr, true, nullptr);
@@ -287,7 +290,7 @@ static int run_fused_training_large(cb_bank *h, double *pi_param, double *up_par
       }
       mark(h, EV_AR);   // CB_T_ALLREDUCE = the span from the end of K4 to here
     }
-    if (h->profile) h->t_pending = true;
+    if (h->profile_now) h->t_pending = true;
     pow_b1 *= a.beta1;
     pow_b2 *= a.beta2;
     hipLaunchKernelGGL(lt_gd, dim3((S + 3) / 4), dim3(256), 0, h->stream, a);
