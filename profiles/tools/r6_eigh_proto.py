@@ -153,7 +153,7 @@ def solve_current(Ap, U_prev, v):
         masked = c > v.get("trigger", 3e-4) or rs > v.get("rs_max", 1.0)
         if it >= v.get("force_L_from", 99):
             masked = False
-        so = (it >= 1) and not masked and c > 1e-8
+        so = (it >= 1) and not masked and c > 1e-8 and rs <= v.get("so_max", 1e9)
         final = (not masked) and (c <= 1e-8 or (so and c * rs * rs <= 2e-14))
         if masked:
             Xu = Xf
@@ -337,6 +337,13 @@ def main():
     variants = {
         "current": (solve_current, {}),
         "cur_b1": (solve_current, {"band": 1}),
+        "b1_so03": (solve_current, {"band": 1, "so_max": 0.3}),
+        "b1_so03_trig1e-3": (solve_current, {"band": 1, "so_max": 0.3, "trigger": 1e-3}),
+        "b1_so05_trig1e-3": (solve_current, {"band": 1, "so_max": 0.5, "trigger": 1e-3}),
+        "b1_so1_trig1e-3": (solve_current, {"band": 1, "so_max": 1.0, "trigger": 1e-3}),
+        "b1_trig6e-4": (solve_current, {"band": 1, "trigger": 6e-4}),
+        "b1_trig1e-3": (solve_current, {"band": 1, "trigger": 1e-3}),
+        "b1_trig1e-3_rs2": (solve_current, {"band": 1, "trigger": 1e-3, "rs_max": 2.0}),
         "b1_lead1": (solve_current, {"band": 1, "lead_tilings": 1}),
         "b1_post1": (solve_current, {"band": 1, "post_tilings": 1}),
         "b1_lead1_post1": (solve_current, {"band": 1, "lead_tilings": 1, "post_tilings": 1}),
