@@ -479,7 +479,7 @@ def main():
                     call(PREWARM_EPOCHS)   # (see the single-GPU branch below: one-time events of a fresh process)
                     prewarm_ms = (time.perf_counter() - tp0) * 1e3
                     call(warmup)
-                bank.profile(True, every=PHASE_EVENTS_EVERY)
+                bank.profile(True, every=PHASE_EVENTS_EVERY if steps >= 2 * PHASE_EVENTS_EVERY else 1)
                 fence()
                 t0 = time.perf_counter()
                 r = call(steps, warmup > 0)
@@ -555,7 +555,7 @@ def main():
                 prewarm_ms = (time.perf_counter() - tp0) * 1e3
             if warmup > 0:
                 call(warmup)
-            bank.profile(True, every=PHASE_EVENTS_EVERY if S > 32 else 1)
+            bank.profile(True, every=PHASE_EVENTS_EVERY if S > 32 and steps >= 2 * PHASE_EVENTS_EVERY else 1)
             fence()
             t0 = time.perf_counter()
             r = call(steps, warmup > 0)
@@ -761,7 +761,8 @@ def main():
             "roofline": roofline,
             "epochs_per_s": steps / dt,   # the epoch's cost does not depend on the pair count
             "phase_ms": {k: round(v, 4) for k, v in tm.items()},
-            **({"phase_events": f"recorded in every {PHASE_EVENTS_EVERY}th epoch of the timed region"} if S > 32 else {}),
+            **({"phase_events": f"recorded in every {PHASE_EVENTS_EVERY}th epoch of the timed region"}
+               if S > 32 and steps >= 2 * PHASE_EVENTS_EVERY else {}),
             **({"bank_form": bank_form} if bank_form else {}),
             "final_loss": final_loss,
         }
